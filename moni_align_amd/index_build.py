@@ -1,0 +1,286 @@
+"""Flat r-index builder (suffix array -> run-length BWT, SA samples, thresholds, LCP samples).
+
+The reference builds these files offline with prefix-free parsing
+(pipeline/moni.in:115-212; thirdparty pfp / pfp-thresholds, both absent), which
+SURVEY.md §2 marks OUT OF SCOPE.  The hot path still needs an index to run on,
+so this module produces the *semantic* content of `<prefix>.thrbv.full.lcp.ms`
+(+ `.plain.slp` text, `.ldx` sequence starts) as plain arrays:
+
+  heads[r], starts[r+1]          run-length BWT            (ms_rle_string.hpp:245-303)
+  ssa[r], esa[r]                 (SA[run start]-1) mod n, (SA[run end]-1) mod n
+                                 = samples_start / samples_last (moni.hpp:148-184)
+  thr[r]                         threshold position per run, 0 for the first run
+                                 of a letter (thresholds_ds.hpp:413-426)
+  slcp[r]                        LCP at each run start      (moni_lcp.hpp:117-145)
+  F[256]                         (moni.hpp:253-282)
+  text[n-1], seq_starts, names   (.plain.slp / .ldx content)
+
+Everything is expressed with torch tensor ops (sort / gather / scatter-reduce)
+so the same code runs on CPU for the small test genomes and on the MI355X for
+the 0.8 G-character benchmark text: prefix doubling with radix sorts, LCP from
+the stored doubling ranks, thresholds by a segmented arg-min.  torch is used as
+a sorting/gather engine here, nothing else.
+"""
+from __future__ import annotations
+
+import dataclasses
+import io
+import struct
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+TERMINATOR = 1           # moni.hpp / r-index: bytes <= 1 in the BWT are stored as 1
+MAGIC = b"MONIFLT2"
+
+
+@dataclasses.dataclass
+class FlatIndex:
+    n: int                       # BWT length = len(text) + 1
+    r: int
+    w: int
+    F: np.ndarray                # uint64[256]
+    heads: np.ndarray            # uint8[r]
+    starts: np.ndarray           # uint64[r+1], starts[r] = n
+    ssa: np.ndarray              # uint64[r]
+    esa: np.ndarray              # uint64[r]
+    thr: np.ndarray              # uint64[r]
+    slcp: np.ndarray             # uint64[r]
+    text: np.ndarray             # uint8[n-1]
+    seq_starts: np.ndarray       # uint64[nseq+1]
+    names: List[str]
+
+    # ---- (de)serialisation: one flat little-endian file ----
+    def save(self, path: str) -> None:
+        names_blob = b"".join(struct.pack("<Q", len(s.encode())) + s.encode() for s in self.names)
+        with open(path, "wb") as f:
+            f.write(MAGIC)
+            f.write(struct.pack("<6Q", self.n, self.r, self.w, len(self.seq_starts) - 1,
+                                len(names_blob), 0))
+            def put(a, dt):
+                b = np.ascontiguousarray(a, dtype=dt).tobytes()
+                f.write(b)
+                f.write(b"\0" * ((-len(b)) % 8))
+            put(self.F, np.uint64)
+            put(self.heads, np.uint8)
+            put(self.starts, np.uint64)
+            put(self.ssa, np.uint64)
+            put(self.esa, np.uint64)
+            put(self.thr, np.uint64)
+            put(self.slcp, np.uint64)
+            put(self.text, np.uint8)
+            put(self.seq_starts, np.uint64)
+            f.write(names_blob)
+            f.write(b"\0" * ((-len(names_blob)) % 8))
+
+    @staticmethod
+    def load(path: str) -> "FlatIndex":
+        with open(path, "rb") as f:
+            buf = f.read()
+        if buf[:8] != MAGIC:
+            raise ValueError("not a MONIFLT2 file: " + path)
+        n, r, w, nseq, nblob, _ = struct.unpack_from("<6Q", buf, 8)
+        off = 8 + 48
+        def get(count, dt):
+            nonlocal off
+            a = np.frombuffer(buf, dtype=dt, count=count, offset=off).copy()
+            nb = count * np.dtype(dt).itemsize
+            off += nb + ((-nb) % 8)
+            return a
+        F = get(256, np.uint64)
+        heads = get(r, np.uint8)
+        starts = get(r + 1, np.uint64)
+        ssa = get(r, np.uint64)
+        esa = get(r, np.uint64)
+        thr = get(r, np.uint64)
+        slcp = get(r, np.uint64)
+        text = get(n - 1, np.uint8)
+        seq_starts = get(nseq + 1, np.uint64)
+        names = []
+        p = off
+        for _ in range(nseq):
+            (ln,) = struct.unpack_from("<Q", buf, p)
+            names.append(buf[p + 8:p + 8 + ln].decode())
+            p += 8 + ln
+        return FlatIndex(n, r, w, F, heads, starts, ssa, esa, thr, slcp, text, seq_starts, names)
+
+
+# --------------------------------------------------------------------------------------
+# suffix array by prefix doubling
+# --------------------------------------------------------------------------------------
+
+def _group_starts(sorted_keys: torch.Tensor):
+    n = sorted_keys.numel()
+    flag = torch.ones(n, dtype=torch.bool, device=sorted_keys.device)
+    flag[1:] = sorted_keys[1:] != sorted_keys[:-1]
+    idx = torch.arange(n, device=sorted_keys.device, dtype=torch.int64)
+    gstart = torch.cummax(torch.where(flag, idx, torch.zeros_like(idx)), 0).values
+    return flag, gstart
+
+
+def suffix_array(codes: torch.Tensor, bits: int, keep_levels: bool = True, log=None):
+    """codes: uint8/int64 [n] with a unique smallest 0 at the end.  Returns (sa, key0, k0, levels)
+    where levels = [(k, rank_k int32)] for every doubling level (rank_k equal <=> first k
+    symbols equal)."""
+    dev = codes.device
+    n = codes.numel()
+    k0 = 60 // bits
+    c64 = torch.cat([codes.to(torch.int64), torch.zeros(k0, dtype=torch.int64, device=dev)])
+    key0 = torch.zeros(n, dtype=torch.int64, device=dev)
+    for d in range(k0):
+        key0 = (key0 << bits) | c64[d:d + n]
+    del c64
+    skey, sa = torch.sort(key0)
+    flag, gstart = _group_starts(skey)
+    del skey
+    rank = torch.empty(n, dtype=torch.int64, device=dev)
+    rank[sa] = gstart
+    levels = [(k0, rank.to(torch.int32))] if keep_levels else []
+    k = k0
+    while not bool(flag.all()):
+        if log:
+            log("  prefix doubling k=%d, groups=%d / %d" % (k, int(flag.sum()), n))
+        r2 = torch.zeros(n, dtype=torch.int64, device=dev)
+        if k < n:
+            r2[: n - k] = rank[k:] + 1
+        key = rank * (n + 1) + r2
+        del r2
+        skey, sa = torch.sort(key)
+        del key
+        flag, gstart = _group_starts(skey)
+        del skey
+        rank = torch.empty(n, dtype=torch.int64, device=dev)
+        rank[sa] = gstart
+        k *= 2
+        if keep_levels:
+            levels.append((k, rank.to(torch.int32)))
+    return sa, key0, k0, levels
+
+
+def lcp_from_levels(sa: torch.Tensor, key0: torch.Tensor, k0: int, bits: int, levels) -> torch.Tensor:
+    """LCP[j] = lcp(suffix sa[j-1], suffix sa[j]), LCP[0] = 0 (int64 [n])."""
+    n = sa.numel()
+    dev = sa.device
+    x = sa[:-1].clone()
+    y = sa[1:].clone()
+    l = torch.zeros(n - 1, dtype=torch.int64, device=dev)
+    for k, R in reversed(levels):
+        ok = (x < n) & (y < n)
+        xe = torch.clamp(x, max=n - 1)
+        ye = torch.clamp(y, max=n - 1)
+        eq = ok & (R[xe] == R[ye])
+        step = eq.to(torch.int64) * k
+        l += step
+        x += step
+        y += step
+    ok = (x < n) & (y < n)
+    xe = torch.clamp(x, max=n - 1)
+    ye = torch.clamp(y, max=n - 1)
+    xr = key0[xe] ^ key0[ye]
+    run = ok.clone()
+    mask = (1 << bits) - 1
+    for d in range(k0):
+        run &= ((xr >> (bits * (k0 - 1 - d))) & mask) == 0
+        l += run.to(torch.int64)
+    out = torch.zeros(n, dtype=torch.int64, device=dev)
+    out[1:] = l
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# the builder
+# --------------------------------------------------------------------------------------
+
+def build_flat_index(text: np.ndarray, seq_starts: np.ndarray, names: List[str], w: int,
+                     device: Optional[str] = None, log=None) -> FlatIndex:
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    dev = torch.device(device)
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    if text.min() < 2:
+        raise ValueError("text bytes 0/1 are reserved for the terminator")
+    n = int(text.shape[0]) + 1
+    present = np.unique(text)
+    sigma = len(present) + 1
+    bits = max(1, int(np.ceil(np.log2(sigma))))
+    b2c = np.zeros(256, dtype=np.uint8)
+    b2c[present] = np.arange(1, sigma, dtype=np.uint8)
+    c2b = np.zeros(sigma, dtype=np.uint8)
+    c2b[0] = TERMINATOR
+    c2b[1:] = present
+    codes = torch.from_numpy(np.concatenate([b2c[text], np.zeros(1, np.uint8)])).to(dev)
+    if log:
+        log("suffix array: n=%d sigma=%d bits=%d on %s" % (n, sigma, bits, dev))
+    sa, key0, k0, levels = suffix_array(codes, bits, keep_levels=True, log=log)
+    if log:
+        log("lcp from %d levels" % len(levels))
+    lcp = lcp_from_levels(sa, key0, k0, bits, levels)
+    del levels, key0
+    # BWT (codes), runs
+    prev = sa - 1
+    prev[prev < 0] = n - 1
+    bwt = codes[prev].to(torch.int64)
+    del prev
+    rs = torch.ones(n, dtype=torch.bool, device=dev)
+    rs[1:] = bwt[1:] != bwt[:-1]
+    starts = torch.nonzero(rs).flatten()
+    r = int(starts.numel())
+    ends = torch.cat([starts[1:] - 1, torch.tensor([n - 1], device=dev)])
+    heads_c = bwt[starts]
+    ssa = (sa[starts] - 1) % n
+    esa = (sa[ends] - 1) % n
+    slcp = lcp[starts]
+    if log:
+        log("r=%d n/r=%.2f; thresholds" % (r, n / r))
+    # thresholds: per letter, arg-min of LCP over (end of previous c-run, start of this c-run]
+    thr = torch.zeros(r, dtype=torch.int64, device=dev)
+    idx = torch.arange(n, dtype=torch.int64, device=dev)
+    BIG = torch.iinfo(torch.int64).max
+    for c in range(sigma):
+        runs_c = torch.nonzero(heads_c == c).flatten()
+        rc = int(runs_c.numel())
+        if rc <= 1:
+            continue
+        is_c = bwt == c
+        nxt = torch.zeros(n, dtype=torch.bool, device=dev)
+        nxt[:-1] = is_c[1:]
+        run_end = is_c & ~nxt
+        seg = torch.cumsum(run_end.to(torch.int64), 0) - run_end.to(torch.int64)
+        del nxt, run_end
+        prv = torch.zeros(n, dtype=torch.bool, device=dev)
+        prv[1:] = is_c[:-1]
+        interior = is_c & prv
+        del prv, is_c
+        key = torch.where(interior, torch.full_like(idx, BIG), lcp * n + idx)
+        del interior
+        out = torch.full((rc + 1,), BIG, dtype=torch.int64, device=dev)
+        out.scatter_reduce_(0, seg, key, "amin", include_self=True)
+        del key, seg
+        t = out[:rc] % n
+        t[0] = 0
+        thr[runs_c] = t
+    # F
+    counts = torch.bincount(bwt, minlength=sigma).cpu().numpy()
+    cnt_b = np.zeros(256, dtype=np.uint64)
+    for c in range(sigma):
+        cnt_b[c2b[c]] += np.uint64(counts[c])
+    F = np.zeros(256, dtype=np.uint64)
+    F[1:] = np.cumsum(cnt_b)[:-1]
+    starts_np = np.concatenate([starts.cpu().numpy().astype(np.uint64), np.array([n], dtype=np.uint64)])
+    return FlatIndex(
+        n=n, r=r, w=int(w), F=F,
+        heads=c2b[heads_c.cpu().numpy()],
+        starts=starts_np,
+        ssa=ssa.cpu().numpy().astype(np.uint64),
+        esa=esa.cpu().numpy().astype(np.uint64),
+        thr=thr.cpu().numpy().astype(np.uint64),
+        slcp=slcp.cpu().numpy().astype(np.uint64),
+        text=text,
+        seq_starts=np.asarray(seq_starts, dtype=np.uint64),
+        names=list(names),
+    )
+
+
+def build_from_pangenome(pg, device: Optional[str] = None, log=None) -> FlatIndex:
+    return build_flat_index(pg.text, pg.seq_starts, pg.names, pg.w, device=device, log=log)

@@ -1,0 +1,170 @@
+"""Synthetic pangenome + read generator.
+
+The mouse chr19 FASTA is absent from the reference checkout and nothing but
+/root/repo travels to the GPU box, so every input is generated from a seed:
+
+  * base genome G0: i.i.d. ACGT of the requested length,
+  * haplotypes: G0 + shared variant sites (85 % SNP / 15 % indel, geometric
+    indel length mean 3, cap 50), each site carried by a haplotype with the
+    site's allele frequency (Beta(0.5, 0.5)),
+  * text: every sequence followed by `w` separator bytes (<= 5), the last one
+    by w + (w-1), the layout test/src/ldx_slp_test.cpp:101-137 checks,
+  * reads: uniform haplotype / position, fair strand, substitution and indel
+    errors, no N.
+
+This is test/bench infrastructure, not the product path.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import List
+
+import numpy as np
+
+SEP_SEQ = 5      # separator byte after every sequence (<= 5, never in a read)
+SEP_END = 4      # the extra w-1 bytes after the last sequence
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+_COMP[:] = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGT", b"TGCA"):
+    _COMP[_a] = _b
+
+
+@dataclasses.dataclass
+class Pangenome:
+    seqs: List[np.ndarray]          # uint8 ASCII, one per sequence
+    names: List[str]
+    w: int
+
+    @property
+    def text(self) -> np.ndarray:
+        parts = []
+        for s in self.seqs:
+            parts.append(s)
+            parts.append(np.full(self.w, SEP_SEQ, dtype=np.uint8))
+        parts.append(np.full(self.w - 1, SEP_END, dtype=np.uint8))
+        return np.concatenate(parts)
+
+    @property
+    def seq_starts(self) -> np.ndarray:
+        """onsets in text coordinates: 0, len0+w, ... , sum(len_i+w)  (k+1 values)."""
+        on = [0]
+        for s in self.seqs:
+            on.append(on[-1] + len(s) + self.w)
+        return np.asarray(on, dtype=np.uint64)
+
+
+def make_pangenome(base_len: int, n_haps: int, seed: int = 19, var_seed: int = 12,
+                   site_spacing: int = 1800, w: int = 10,
+                   contig: str = "chr19") -> Pangenome:
+    rng = np.random.Generator(np.random.MT19937(seed))
+    g0 = _ACGT[rng.integers(0, 4, size=base_len, dtype=np.uint8)]
+    seqs = [g0]
+    names = [contig]
+    vr = np.random.Generator(np.random.MT19937(var_seed))
+    n_sites = max(1, base_len // site_spacing) if n_haps > 0 else 0
+    # sites: sorted, at least 64 apart so that a deletion (<= 50) never reaches the next one
+    pos = np.sort(vr.choice(max(1, (base_len - 128) // 64), size=min(n_sites, max(1, (base_len - 128) // 64)),
+                            replace=False)) * 64 + 32
+    n_sites = len(pos)
+    kind = vr.random(n_sites)           # <0.85 SNP, <0.925 ins, else del
+    ilen = np.minimum(vr.geometric(1.0 / 3.0, size=n_sites), 50)
+    af = vr.beta(0.5, 0.5, size=n_sites)
+    snp_shift = vr.integers(1, 4, size=n_sites)
+    ins_bases = _ACGT[vr.integers(0, 4, size=(n_sites, 50), dtype=np.uint8)]
+    code = np.full(256, 255, dtype=np.uint8)
+    code[_ACGT] = np.arange(4, dtype=np.uint8)
+    for h in range(n_haps):
+        carry = vr.random(n_sites) < af
+        pieces = []
+        prev = 0
+        for s in np.nonzero(carry)[0]:
+            p = int(pos[s])
+            if kind[s] < 0.85:
+                pieces.append(g0[prev:p])
+                pieces.append(_ACGT[[(int(code[g0[p]]) + int(snp_shift[s])) & 3]])
+                prev = p + 1
+            elif kind[s] < 0.925:
+                pieces.append(g0[prev:p])
+                pieces.append(ins_bases[s, : int(ilen[s])])
+                prev = p
+            else:
+                pieces.append(g0[prev:p])
+                prev = p + int(ilen[s])
+        pieces.append(g0[prev:])
+        seqs.append(np.concatenate(pieces))
+        names.append("S%d_H%d_%s" % (h // 2 + 1, h % 2 + 1, contig))
+    return Pangenome(seqs=seqs, names=names, w=w)
+
+
+def revcomp(reads: np.ndarray) -> np.ndarray:
+    """Reverse-complement of a [N, L] uint8 matrix (ACGT only complemented)."""
+    return _COMP[reads[:, ::-1]]
+
+
+def make_reads(pg: Pangenome, n_reads: int, read_len: int = 150, seed: int = 150,
+               sub_rate: float = 0.01, indel_rate: float = 0.0005,
+               n_rate: float = 0.0) -> np.ndarray:
+    """[n_reads, read_len] uint8 ASCII reads (fixed length)."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    hap = rng.integers(0, len(pg.seqs), size=n_reads)
+    out = np.empty((n_reads, read_len), dtype=np.uint8)
+    pad = 4
+    col = np.arange(read_len + pad)
+    for h, s in enumerate(pg.seqs):
+        sel = np.nonzero(hap == h)[0]
+        if len(sel) == 0:
+            continue
+        if len(s) < read_len + pad:
+            raise ValueError("sequence shorter than a read")
+        start = rng.integers(0, len(s) - read_len - pad + 1, size=len(sel))
+        win = s[start[:, None] + col[None, :]]          # [k, L+pad]
+        # at most one indel per read (rate is per base)
+        has = rng.random(len(sel)) < indel_rate * read_len
+        ipos = rng.integers(1, read_len - 1, size=len(sel))
+        is_ins = rng.random(len(sel)) < 0.5
+        base_idx = np.arange(read_len)[None, :].repeat(len(sel), 0)
+        # deletion: skip one reference base at ipos
+        del_rows = has & ~is_ins
+        base_idx[del_rows] += (base_idx[del_rows] >= ipos[del_rows, None])
+        # insertion: positions > ipos read one base earlier, ipos gets a random base
+        ins_rows = has & is_ins
+        base_idx[ins_rows] -= (base_idx[ins_rows] > ipos[ins_rows, None])
+        r = np.take_along_axis(win, base_idx, axis=1)
+        rnd = _ACGT[rng.integers(0, 4, size=len(sel), dtype=np.uint8)]
+        rows = np.nonzero(ins_rows)[0]
+        r[rows, ipos[rows]] = rnd[rows]
+        out[sel] = r
+    # substitutions
+    code = np.full(256, 0, dtype=np.uint8)
+    code[_ACGT] = np.arange(4, dtype=np.uint8)
+    sub = rng.random(out.shape) < sub_rate
+    shift = rng.integers(1, 4, size=out.shape, dtype=np.uint8)
+    out = np.where(sub, _ACGT[(code[out] + shift) & 3], out)
+    if n_rate > 0:
+        out = np.where(rng.random(out.shape) < n_rate, np.uint8(ord("N")), out)
+    # strand
+    rc = rng.random(n_reads) < 0.5
+    out[rc] = revcomp(out[rc])
+    return np.ascontiguousarray(out)
+
+
+def write_fastq(path: str, reads: np.ndarray, prefix: str = "simulated") -> None:
+    with open(path, "wb") as f:
+        q = b"I" * reads.shape[1]
+        for i in range(reads.shape[0]):
+            f.write(b"@%s.%d\n" % (prefix.encode(), i))
+            f.write(reads[i].tobytes())
+            f.write(b"\n+\n")
+            f.write(q)
+            f.write(b"\n")
+
+
+def write_fasta(path: str, pg: Pangenome, width: int = 60) -> None:
+    with open(path, "wb") as f:
+        for name, s in zip(pg.names, pg.seqs):
+            f.write(b">" + name.encode() + b"\n")
+            b = s.tobytes()
+            for i in range(0, len(b), width):
+                f.write(b[i:i + width])
+                f.write(b"\n")

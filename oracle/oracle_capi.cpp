@@ -1,0 +1,142 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see flat_index.hpp header).  PARITY UNPINNED.
+// C entry points so that tests/ and bench.py's cpu_baseline leg can drive the restatement
+// through ctypes.  Not linked into, loaded by, or called from the product library.
+#include "flat_index.hpp"
+#include "seed.hpp"
+#include "ksw2.hpp"
+
+#include <atomic>
+#include <chrono>
+#include <thread>
+
+using namespace oracle;
+
+namespace {
+
+// kpbseq.h:120-137
+static unsigned char seq_compl_table[256];
+struct InitTables {
+    InitTables() {
+        for (int i = 0; i < 256; ++i) seq_compl_table[i] = (unsigned char)i;
+        seq_compl_table['A'] = 'T'; seq_compl_table['C'] = 'G'; seq_compl_table['G'] = 'C'; seq_compl_table['T'] = 'A';
+        seq_compl_table['a'] = 'T'; seq_compl_table['c'] = 'G'; seq_compl_table['g'] = 'C'; seq_compl_table['t'] = 'A';
+    }
+} init_tables;
+
+struct SeedResult {
+    // one row per MEM, in the order of the reference's per-read `mems` vector
+    std::vector<uint64_t> mem_read, mem_pos, mem_len, mem_idx, mem_mate, mem_rpos, mem_total_occ, mem_num_filtered,
+        mem_occ_off, mem_occ_cnt;
+    std::vector<uint64_t> occs;
+    std::vector<uint64_t> read_mem_off;   // n_reads + 1
+    ms_counters cnt;
+};
+
+static void seed_one(const FlatIndex& ix, seed_finder& sf, const char* s, size_t l, std::vector<mem_t>& mems) {
+    // aligner_ksw2.hpp:169-176 (rc copy), 333-337
+    std::string rc(l, 0);
+    for (size_t i = 0; i < l; ++i) rc[i] = (char)seq_compl_table[(unsigned char)s[l - i - 1]];
+    sf.find_mems(s, l, mems, 0, MATE_1 | MATE_F);
+    sf.find_mems(rc.data(), l, mems, 0, MATE_1 | MATE_RC);
+    sf.populate_seeds(mems);
+}
+
+}  // namespace
+
+extern "C" {
+
+void* orc_index_load(const char* path) {
+    FlatIndex* ix = new FlatIndex();
+    if (!ix->load(path)) { delete ix; return nullptr; }
+    return ix;
+}
+void orc_index_free(void* h) { delete (FlatIndex*)h; }
+uint64_t orc_index_n(void* h) { return ((FlatIndex*)h)->n; }
+uint64_t orc_index_r(void* h) { return ((FlatIndex*)h)->r; }
+
+void orc_ms_query(void* h, const char* p, uint64_t m, uint64_t* out) {
+    auto v = ms_query(*(FlatIndex*)h, p, m);
+    for (uint64_t i = 0; i < m; ++i) out[i] = v[i];
+}
+
+void orc_phi_lcp(void* h, uint64_t i, int inverse, uint64_t* out2) {
+    auto pr = inverse ? ((FlatIndex*)h)->Phi_inv_lcp(i) : ((FlatIndex*)h)->Phi_lcp(i);
+    out2[0] = pr.first; out2[1] = pr.second;
+}
+
+// seeds (MEMs + occurrences) for a ragged batch of reads, T threads over contiguous read ranges
+void* orc_seed_batch(void* h, const uint8_t* seqs, const uint64_t* offsets, uint64_t n_reads,
+                     uint64_t min_len, int filter_seeds, uint64_t n_seeds_thr, int threads) {
+    const FlatIndex& ix = *(FlatIndex*)h;
+    if (threads < 1) threads = 1;
+    std::vector<SeedResult> part(threads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) {
+        th.emplace_back([&, t]() {
+            uint64_t lo = n_reads * t / threads, hi = n_reads * (t + 1) / threads;
+            seed_finder sf(ix, min_len, filter_seeds != 0, n_seeds_thr);
+            SeedResult& R = part[t];
+            for (uint64_t rd = lo; rd < hi; ++rd) {
+                std::vector<mem_t> mems;
+                seed_one(ix, sf, (const char*)seqs + offsets[rd], offsets[rd + 1] - offsets[rd], mems);
+                R.read_mem_off.push_back(R.mem_pos.size());
+                for (auto& m : mems) {
+                    R.mem_read.push_back(rd); R.mem_pos.push_back(m.pos); R.mem_len.push_back(m.len);
+                    R.mem_idx.push_back(m.idx); R.mem_mate.push_back(m.mate); R.mem_rpos.push_back(m.rpos);
+                    R.mem_total_occ.push_back(m.total_occ); R.mem_num_filtered.push_back(m.num_filtered);
+                    R.mem_occ_off.push_back(R.occs.size()); R.mem_occ_cnt.push_back(m.occs.size());
+                    for (auto o : m.occs) R.occs.push_back(o);
+                }
+            }
+            R.cnt = sf.cnt;
+        });
+    }
+    for (auto& x : th) x.join();
+    SeedResult* out = new SeedResult();
+    for (int t = 0; t < threads; ++t) {
+        SeedResult& R = part[t];
+        uint64_t mbase = out->mem_pos.size(), obase = out->occs.size();
+        for (auto v : R.read_mem_off) out->read_mem_off.push_back(v + mbase);
+        for (auto v : R.mem_occ_off) out->mem_occ_off.push_back(v + obase);
+#define APP(f) out->f.insert(out->f.end(), R.f.begin(), R.f.end())
+        APP(mem_read); APP(mem_pos); APP(mem_len); APP(mem_idx); APP(mem_mate); APP(mem_rpos);
+        APP(mem_total_occ); APP(mem_num_filtered); APP(mem_occ_cnt); APP(occs);
+#undef APP
+        out->cnt.lf_steps += R.cnt.lf_steps; out->cnt.jumps += R.cnt.jumps;
+        out->cnt.phi_steps += R.cnt.phi_steps; out->cnt.text_cmp += R.cnt.text_cmp;
+    }
+    out->read_mem_off.push_back(out->mem_pos.size());
+    return out;
+}
+uint64_t orc_seed_n_mems(void* r) { return ((SeedResult*)r)->mem_pos.size(); }
+uint64_t orc_seed_n_occs(void* r) { return ((SeedResult*)r)->occs.size(); }
+// fields: 0 read,1 pos,2 len,3 idx,4 mate,5 rpos,6 total_occ,7 num_filtered,8 occ_off,9 occ_cnt,10 occs,11 read_mem_off,12 counters
+void orc_seed_get(void* r, int field, uint64_t* out) {
+    SeedResult* R = (SeedResult*)r;
+    const std::vector<uint64_t>* v = nullptr;
+    switch (field) {
+        case 0: v = &R->mem_read; break; case 1: v = &R->mem_pos; break; case 2: v = &R->mem_len; break;
+        case 3: v = &R->mem_idx; break; case 4: v = &R->mem_mate; break; case 5: v = &R->mem_rpos; break;
+        case 6: v = &R->mem_total_occ; break; case 7: v = &R->mem_num_filtered; break;
+        case 8: v = &R->mem_occ_off; break; case 9: v = &R->mem_occ_cnt; break; case 10: v = &R->occs; break;
+        case 11: v = &R->read_mem_off; break;
+        case 12: out[0] = R->cnt.lf_steps; out[1] = R->cnt.jumps; out[2] = R->cnt.phi_steps; out[3] = R->cnt.text_cmp; return;
+    }
+    if (v && !v->empty()) memcpy(out, v->data(), v->size() * 8);
+}
+void orc_seed_free(void* r) { delete (SeedResult*)r; }
+
+// ksw2 restatement: one problem. out[11] = max,max_q,max_t,mqe,mqe_t,mte,mte_q,score,reach_end,n_cigar,zdropped
+void orc_extz(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int8_t m, const int8_t* mat,
+              int8_t q, int8_t e, int w, int zdrop, int end_bonus, int flag, int32_t* out, uint32_t* cigar, int cigar_cap) {
+    ksw_extz_t ez;
+    memset(&ez, 0, sizeof(ez));
+    ksw_extz2_restated(qlen, query, tlen, target, m, mat, q, e, w, zdrop, end_bonus, flag, &ez);
+    out[0] = (int32_t)ez.max; out[1] = ez.max_q; out[2] = ez.max_t; out[3] = ez.mqe; out[4] = ez.mqe_t;
+    out[5] = ez.mte; out[6] = ez.mte_q; out[7] = ez.score; out[8] = ez.reach_end; out[9] = ez.n_cigar;
+    out[10] = ez.zdropped;
+    for (int i = 0; i < ez.n_cigar && i < cigar_cap; ++i) cigar[i] = ez.cigar[i];
+    free(ez.cigar);
+}
+
+}  // extern "C"

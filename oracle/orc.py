@@ -1,0 +1,130 @@
+"""ctypes driver for the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Dict
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FLAG_SCORE_ONLY = 0x01
+FLAG_RIGHT = 0x02
+FLAG_EXTZ_ONLY = 0x40
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".hpp"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        L.orc_index_load.restype = ctypes.c_void_p
+        L.orc_index_load.argtypes = [ctypes.c_char_p]
+        L.orc_index_free.argtypes = [ctypes.c_void_p]
+        L.orc_index_n.restype = ctypes.c_uint64
+        L.orc_index_n.argtypes = [ctypes.c_void_p]
+        L.orc_index_r.restype = ctypes.c_uint64
+        L.orc_index_r.argtypes = [ctypes.c_void_p]
+        L.orc_ms_query.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p]
+        L.orc_phi_lcp.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
+        L.orc_seed_batch.restype = ctypes.c_void_p
+        L.orc_seed_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                     ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int]
+        L.orc_seed_n_mems.restype = ctypes.c_uint64
+        L.orc_seed_n_mems.argtypes = [ctypes.c_void_p]
+        L.orc_seed_n_occs.restype = ctypes.c_uint64
+        L.orc_seed_n_occs.argtypes = [ctypes.c_void_p]
+        L.orc_seed_get.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.orc_seed_free.argtypes = [ctypes.c_void_p]
+        L.orc_extz.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int8,
+                               ctypes.c_void_p, ctypes.c_int8, ctypes.c_int8, ctypes.c_int, ctypes.c_int,
+                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        _LIB = L
+    return _LIB
+
+
+class OracleIndex:
+    def __init__(self, path: str):
+        self._L = lib()
+        self._h = self._L.orc_index_load(path.encode())
+        if not self._h:
+            raise IOError("oracle: cannot load " + path)
+        self.n = self._L.orc_index_n(self._h)
+        self.r = self._L.orc_index_r(self._h)
+
+    def close(self):
+        if self._h:
+            self._L.orc_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def ms_query(self, pattern: bytes) -> np.ndarray:
+        out = np.empty(len(pattern), dtype=np.uint64)
+        self._L.orc_ms_query(self._h, pattern, len(pattern), out.ctypes.data)
+        return out
+
+    def phi_lcp(self, i: int, inverse: bool = False):
+        out = np.empty(2, dtype=np.uint64)
+        self._L.orc_phi_lcp(self._h, i, int(inverse), out.ctypes.data)
+        return int(out[0]), int(out[1])
+
+    def seed_batch(self, seqs: np.ndarray, offsets: np.ndarray, min_len: int = 25, filter_seeds: bool = True,
+                   n_seeds_thr: int = 1000, threads: int = 1) -> Dict[str, np.ndarray]:
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n_reads = len(offsets) - 1
+        r = self._L.orc_seed_batch(self._h, seqs.ctypes.data, offsets.ctypes.data, n_reads, min_len,
+                                   int(filter_seeds), n_seeds_thr, threads)
+        try:
+            nm = self._L.orc_seed_n_mems(r)
+            no = self._L.orc_seed_n_occs(r)
+            names = ["read", "pos", "len", "idx", "mate", "rpos", "total_occ", "num_filtered", "occ_off", "occ_cnt"]
+            out = {}
+            for f, nme in enumerate(names):
+                a = np.empty(nm, dtype=np.uint64)
+                self._L.orc_seed_get(r, f, a.ctypes.data)
+                out[nme] = a
+            a = np.empty(no, dtype=np.uint64)
+            self._L.orc_seed_get(r, 10, a.ctypes.data)
+            out["occs"] = a
+            a = np.empty(n_reads + 1, dtype=np.uint64)
+            self._L.orc_seed_get(r, 11, a.ctypes.data)
+            out["read_mem_off"] = a
+            a = np.empty(4, dtype=np.uint64)
+            self._L.orc_seed_get(r, 12, a.ctypes.data)
+            out["counters"] = a      # lf_steps, jumps, phi_steps, text_cmp
+            return out
+        finally:
+            self._L.orc_seed_free(r)
+
+
+DEFAULT_MAT = np.array([2, -4, -4, -4, 0, -4, 2, -4, -4, 0, -4, -4, 2, -4, 0, -4, -4, -4, 2, 0, 0, 0, 0, 0, 0],
+                       dtype=np.int8)   # ksw_gen_simple_mat(5, mat, 2, -4), aligner_ksw2.hpp:3199-3211
+
+
+def extz(query: np.ndarray, target: np.ndarray, flag: int, m: int = 5, mat: np.ndarray = DEFAULT_MAT, q: int = 4,
+         e: int = 2, w: int = -1, zdrop: int = -1, end_bonus: int = 400):
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    target = np.ascontiguousarray(target, dtype=np.uint8)
+    out = np.zeros(11, dtype=np.int32)
+    cap = len(query) + len(target) + 2
+    cig = np.zeros(cap, dtype=np.uint32)
+    lib().orc_extz(len(query), query.ctypes.data, len(target), target.ctypes.data, m, mat.ctypes.data, q, e, w, zdrop,
+                   end_bonus, flag, out.ctypes.data, cig.ctypes.data, cap)
+    keys = ["max", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score", "reach_end", "n_cigar", "zdropped"]
+    res = {k: int(v) for k, v in zip(keys, out)}
+    res["cigar"] = cig[: res["n_cigar"]].copy()
+    return res

@@ -1,0 +1,71 @@
+"""index_build (torch prefix doubling) against a naive suffix sort on a small text."""
+import collections
+
+import numpy as np
+
+
+def test_flat_index_matches_naive(small_case):
+    fi = small_case.fi
+    tb = small_case.text + b"\x00"
+    n = len(tb)
+    sa = sorted(range(n), key=lambda i: tb[i:])
+    bwt = [tb[(i - 1) % n] for i in sa]
+    bwt = [1 if b <= 1 else b for b in bwt]
+    lcp = [0] * n
+    for j in range(1, n):
+        a, b = sa[j - 1], sa[j]
+        l = 0
+        while a + l < n and b + l < n and tb[a + l] == tb[b + l]:
+            l += 1
+        lcp[j] = l
+    starts = [j for j in range(n) if j == 0 or bwt[j] != bwt[j - 1]]
+    ends = starts[1:] + [n]
+    assert fi.n == n and fi.r == len(starts)
+    assert starts == list(fi.starts[:-1]) and int(fi.starts[-1]) == n
+    assert [bwt[s] for s in starts] == list(fi.heads)
+    assert [(sa[s] - 1) % n for s in starts] == list(fi.ssa)
+    assert [(sa[e - 1] - 1) % n for e in ends] == list(fi.esa)
+    assert [lcp[s] for s in starts] == list(fi.slcp)
+    last_end = {}
+    thr = []
+    for k, s in enumerate(starts):
+        c = bwt[s]
+        if c not in last_end:
+            thr.append(0)
+        else:
+            best = None
+            for p in range(last_end[c] + 1, s + 1):
+                if best is None or lcp[p] < lcp[best]:
+                    best = p
+            thr.append(best)
+        last_end[c] = ends[k] - 1
+    assert thr == list(fi.thr)
+    cnt = collections.Counter(bwt)
+    F = [0] * 256
+    for c in range(1, 256):
+        F[c] = F[c - 1] + cnt.get(c - 1, 0)
+    assert F == list(fi.F)
+
+
+def test_save_load_roundtrip(small_case, tmp_path):
+    from moni_align_amd.index_build import FlatIndex
+    g = FlatIndex.load(small_case.path)
+    fi = small_case.fi
+    for k in ("F", "heads", "starts", "ssa", "esa", "thr", "slcp", "text", "seq_starts"):
+        assert np.array_equal(getattr(g, k), getattr(fi, k)), k
+    assert g.names == fi.names and g.n == fi.n and g.r == fi.r and g.w == fi.w
+
+
+def test_text_layout(small_case):
+    # every sequence is followed by w bytes <= 5, the last by w + (w-1)  (test/src/ldx_slp_test.cpp:101-137)
+    pg, fi = small_case.pg, small_case.fi
+    t = fi.text
+    acc = 0
+    for i, s in enumerate(pg.seqs):
+        assert (t[acc:acc + len(s)] > 5).all()
+        acc += len(s)
+        last = pg.w + (pg.w - 1 if i == len(pg.seqs) - 1 else 0)
+        assert (t[acc:acc + last] <= 5).all()
+        assert int(fi.seq_starts[i + 1]) == acc + pg.w
+        acc += last
+    assert acc == len(t)

@@ -1,0 +1,165 @@
+/*
+ * moni_hip.h — C ABI of libmoni_hip.so, the MI355X (gfx950) implementation of the moni-align
+ * per-read hot path.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * The reference has no FFI layer of its own: its seams are C++ template
+ * concepts and one C function from ksw2.  Each entry point below names the reference interface
+ * it stands in for (paths relative to the reference checkout).
+ *
+ * Conventions: opaque handles; every function returns 0 on success and a negative MONI_E* code
+ * on failure and never calls exit(); the caller owns every input buffer; the library owns all
+ * device memory; one moni_ctx_t per host thread / HIP stream (not thread-safe per ctx, thread-safe
+ * across ctxs — mirrors include/aligner/align_reads_dispatcher.hpp:226-235: shared const index,
+ * per-thread everything else).  There is no CPU fallback anywhere behind this ABI.
+ */
+#ifndef MONI_HIP_H
+#define MONI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MONI_OK 0
+#define MONI_EINVAL (-22)
+#define MONI_ENOMEM (-12)
+#define MONI_EIO (-5)
+#define MONI_ENODEV (-19)   /* no HIP device / kernel launch failed */
+#define MONI_ERANGE (-34)   /* index violates an invariant the device layout relies on */
+
+typedef struct moni_index moni_index_t;   /* device-resident index image (one per GPU) */
+typedef struct moni_ctx moni_ctx_t;       /* stream + workspaces + resident read batch */
+
+/* Semantic content of <prefix>.thrbv.full.lcp.ms + .plain.slp + .ldx as flat host arrays
+ * (field order of include/aligner/moni_lcp.hpp:208-225; values as built by
+ * include/ms/moni.hpp:148-251, include/ms/ms_rle_string.hpp:245-303,
+ * include/ms/thresholds_ds.hpp:393-430, include/common/seqidx.hpp:215-238). */
+typedef struct {
+    uint64_t n;              /* bwt.size() = text length + 1 */
+    uint64_t r;              /* number of BWT runs */
+    uint64_t w;              /* separator width */
+    uint64_t n_seq;          /* number of sequences */
+    const uint64_t *F;       /* [256] */
+    const uint8_t *heads;    /* [r]   run heads (bytes <= 1 stored as 1) */
+    const uint64_t *starts;  /* [r+1] run start positions, starts[r] = n */
+    const uint64_t *ssa;     /* [r]   samples_start */
+    const uint64_t *esa;     /* [r]   samples_last */
+    const uint64_t *thr;     /* [r]   threshold position of each run, 0 = first run of its letter */
+    const uint64_t *slcp;    /* [r]   LCP at each run start */
+    const uint8_t *text;     /* [n-1] */
+    const uint64_t *seq_starts; /* [n_seq+1] onsets in text coordinates */
+} moni_flat_index_t;
+
+/* Ragged batch of reads: read i is seq[offsets[i] .. offsets[i+1]).  Replaces the kseq_t batches of
+ * include/common/kpbseq.h:315-326 (kbseq_read). */
+typedef struct {
+    const uint8_t *seq;
+    const uint64_t *offsets; /* [n_reads+1] */
+    uint64_t n_reads;
+} moni_read_batch_t;
+
+/* One MEM / seed, fields of include/aligner/mems.hpp:31-60 (count_dict is internal). */
+typedef struct {
+    uint64_t pos;          /* position in the text */
+    uint32_t len;
+    uint32_t idx;          /* position in the read */
+    uint32_t rpos;
+    uint32_t mate;         /* MATE_1|MATE_F = 0, MATE_1|MATE_RC = 2 */
+    uint32_t total_occ;
+    uint32_t num_filtered;
+    uint64_t occ_off;      /* into the occs array */
+    uint32_t occ_cnt;
+    uint32_t read;         /* read index in the batch */
+} moni_mem_t;
+
+/* Seeding parameters: seed_finder ctor (include/aligner/seed_finder.hpp:64-68). */
+typedef struct {
+    uint32_t min_len;      /* -l, default 25 */
+    uint32_t filter_seeds; /* -f off, default on */
+    uint32_t n_seeds_thr;  /* -S, wrapper default 1000 */
+    uint32_t report_mems;  /* populate_seeds(mems, report_mems) */
+} moni_seed_params_t;
+
+/* ksw_extz_t result fields (lh3/ksw2 ksw2.h) of one DP problem. */
+typedef struct {
+    int32_t max, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end, zdropped;
+    uint32_t n_cigar;
+    uint32_t cigar_off;    /* into the cigar pool */
+} moni_dp_result_t;
+
+/* One ksw_extz2_sse call: query = qseq[q_off .. q_off+qlen), target = tseq[t_off .. t_off+tlen), nt4 codes. */
+typedef struct {
+    uint64_t q_off, t_off;
+    int32_t qlen, tlen;
+    int32_t flag;          /* KSW_EZ_* */
+    int32_t reserved;
+} moni_dp_task_t;
+
+typedef struct {
+    int8_t m;              /* 5 */
+    int8_t mat[25];        /* ksw_gen_simple_mat, include/aligner/aligner_ksw2.hpp:3199-3211 */
+    int8_t q, e;           /* gapo 4, gape 2 */
+    int32_t w, zdrop, end_bonus; /* -1, -1, 400 (aligner_ksw2.hpp:110-113) */
+} moni_dp_params_t;
+
+/* ---- index ------------------------------------------------------------------------------- */
+/* Replaces seed_finder's loading of .thrbv.full.lcp.ms/.plain.slp/.ldx (seed_finder.hpp:64-124):
+ * converts the semantic arrays to the device layout and uploads it to `device`. */
+int moni_index_create(const moni_flat_index_t *flat, int device, moni_index_t **out);
+/* Same, from a MONIFLT2 file written by moni_align_amd/index_build.py. */
+int moni_index_load(const char *path, int device, moni_index_t **out);
+void moni_index_destroy(moni_index_t *idx);
+uint64_t moni_index_n(const moni_index_t *idx);
+uint64_t moni_index_r(const moni_index_t *idx);
+uint64_t moni_index_device_bytes(const moni_index_t *idx);
+
+/* ---- context / resident batch ------------------------------------------------------------ */
+int moni_ctx_create(moni_index_t *idx, moni_ctx_t **out);
+void moni_ctx_destroy(moni_ctx_t *ctx);
+/* Copy a read batch to HBM (replaces rc_copy_kseq_t + kseq storage; the reverse-complement strand is
+ * derived on the device with the table of include/common/kpbseq.h:120-137). */
+int moni_reads_upload(moni_ctx_t *ctx, const moni_read_batch_t *batch);
+
+/* ---- matching statistics: ms_t::query (include/ms/moni.hpp:292-295, 568-624) -------------- */
+/* Device-only run over the resident batch, both strands (aligner_ksw2.hpp:333-334). */
+int moni_ms_run(moni_ctx_t *ctx);
+/* Host-buffer form: pointers[2*offsets[i] + s*len_i + k] = pointer k of strand s (0 fwd, 1 rc) of read i. */
+int moni_ms_query_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, uint64_t *pointers);
+
+/* ---- seeds: seed_finder::find_mems + populate_seeds (seed_finder.hpp:126-166, 258-318) ----- */
+/* Device-only run (ms + mems + occurrences) over the resident batch. */
+int moni_seed_run(moni_ctx_t *ctx, const moni_seed_params_t *prm);
+/* Sizes of the last moni_seed_run. */
+int moni_seed_counts(moni_ctx_t *ctx, uint64_t *n_mems, uint64_t *n_occs);
+/* Copy the last result to host: mems in the order of the reference's per-read `mems` vector
+ * (forward MEMs, reverse-complement MEMs, then for every MEM in that order its two halves),
+ * read_mem_off[n_reads+1] delimits reads. */
+int moni_seed_fetch(moni_ctx_t *ctx, moni_mem_t *mems, uint64_t *occs, uint64_t *read_mem_off);
+/* Host-buffer form of the three calls above; *mems / *occs / *read_mem_off are malloc'ed, free with moni_free. */
+int moni_seed_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const moni_seed_params_t *prm,
+                    moni_mem_t **mems, uint64_t *n_mems, uint64_t **occs, uint64_t *n_occs, uint64_t **read_mem_off);
+void moni_free(void *p);
+
+/* ---- phi: moni_lcp::Phi_lcp / Phi_inv_lcp (include/aligner/moni_lcp.hpp:230-272) ---------- */
+int moni_phi_lcp_batch(moni_ctx_t *ctx, const uint64_t *pos, uint64_t n, int inverse, uint64_t *out_pos, uint64_t *out_lcp);
+
+/* ---- seed extension: ksw_extz2_sse (thirdparty/ksw2; call sites aligner_ksw2.hpp:2812-3015) */
+int moni_extz_batch(moni_ctx_t *ctx, const moni_dp_params_t *prm, const uint8_t *qseq, uint64_t qseq_len,
+                    const uint8_t *tseq, uint64_t tseq_len, const moni_dp_task_t *tasks, uint64_t n_tasks,
+                    moni_dp_result_t *results, uint32_t *cigar_pool, uint64_t cigar_pool_cap, uint64_t *cigar_pool_used);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* HIP-event time (ms) of the kernels of the last *_run on this ctx's stream.
+ * which: 0 ms_lf, 1 mem_count, 2 mem_emit, 3 phi_count, 4 phi_emit, 5 extz, 6 whole run. */
+int moni_last_kernel_ms(moni_ctx_t *ctx, int which, float *ms);
+/* Work counters of the last moni_seed_run: out[0] LF steps, [1] threshold jumps, [2] phi steps,
+ * [3] text bytes compared (the S, J, P, C of SURVEY.md §8(d)). */
+int moni_last_counters(moni_ctx_t *ctx, uint64_t out[4]);
+const char *moni_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONI_HIP_H */

@@ -1,0 +1,225 @@
+"""ctypes binding of libmoni_hip.so (include/moni_hip.h).
+
+Python is only the test/bench driver here; the product is the shared library.  There is no
+Python or CPU implementation behind these calls: if the library is missing or no HIP device is
+present the calls raise."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libmoni_hip.so")
+
+EXPORTS = [
+    "moni_version", "moni_index_create", "moni_index_load", "moni_index_destroy", "moni_index_n", "moni_index_r",
+    "moni_index_device_bytes", "moni_ctx_create", "moni_ctx_destroy", "moni_reads_upload", "moni_ms_run",
+    "moni_ms_query_batch", "moni_seed_run", "moni_seed_counts", "moni_seed_fetch", "moni_seed_batch", "moni_free",
+    "moni_phi_lcp_batch", "moni_extz_batch", "moni_last_kernel_ms", "moni_last_counters",
+]
+
+
+class FlatIndexC(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("r", C.c_uint64), ("w", C.c_uint64), ("n_seq", C.c_uint64),
+                ("F", C.c_void_p), ("heads", C.c_void_p), ("starts", C.c_void_p), ("ssa", C.c_void_p),
+                ("esa", C.c_void_p), ("thr", C.c_void_p), ("slcp", C.c_void_p), ("text", C.c_void_p),
+                ("seq_starts", C.c_void_p)]
+
+
+class ReadBatchC(C.Structure):
+    _fields_ = [("seq", C.c_void_p), ("offsets", C.c_void_p), ("n_reads", C.c_uint64)]
+
+
+class SeedParamsC(C.Structure):
+    _fields_ = [("min_len", C.c_uint32), ("filter_seeds", C.c_uint32), ("n_seeds_thr", C.c_uint32),
+                ("report_mems", C.c_uint32)]
+
+
+class DpParamsC(C.Structure):
+    _fields_ = [("m", C.c_int8), ("mat", C.c_int8 * 25), ("q", C.c_int8), ("e", C.c_int8),
+                ("w", C.c_int32), ("zdrop", C.c_int32), ("end_bonus", C.c_int32)]
+
+
+MEM_DTYPE = np.dtype([("pos", "<u8"), ("len", "<u4"), ("idx", "<u4"), ("rpos", "<u4"), ("mate", "<u4"),
+                      ("total_occ", "<u4"), ("num_filtered", "<u4"), ("occ_off", "<u8"), ("occ_cnt", "<u4"),
+                      ("read", "<u4")])
+DP_TASK_DTYPE = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("qlen", "<i4"), ("tlen", "<i4"), ("flag", "<i4"),
+                          ("reserved", "<i4")])
+DP_RESULT_DTYPE = np.dtype([("max", "<i4"), ("max_q", "<i4"), ("max_t", "<i4"), ("mqe", "<i4"), ("mqe_t", "<i4"),
+                            ("mte", "<i4"), ("mte_q", "<i4"), ("score", "<i4"), ("reach_end", "<i4"),
+                            ("zdropped", "<i4"), ("n_cigar", "<u4"), ("cigar_off", "<u4")])
+assert MEM_DTYPE.itemsize == 48 and DP_TASK_DTYPE.itemsize == 32 and DP_RESULT_DTYPE.itemsize == 48
+
+DEFAULT_MAT = [2, -4, -4, -4, 0, -4, 2, -4, -4, 0, -4, -4, 2, -4, 0, -4, -4, -4, 2, 0, 0, 0, 0, 0, 0]
+
+_lib = None
+
+
+def build_lib(force: bool = False) -> str:
+    """hipcc cross-compiles for gfx950 without a GPU."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".hpp", ".inc"))]
+    srcs.append(os.path.join(os.path.dirname(HERE), "include", "moni_hip.h"))
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                               "-o", LIB_PATH, os.path.join(CSRC, "moni_hip.hip")])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libmoni_hip.so is not built (run __graft_entry__.build()); there is no fallback path")
+        L = C.CDLL(LIB_PATH)
+        L.moni_version.restype = C.c_char_p
+        L.moni_index_n.restype = C.c_uint64
+        L.moni_index_r.restype = C.c_uint64
+        L.moni_index_device_bytes.restype = C.c_uint64
+        for name in ("moni_index_n", "moni_index_r", "moni_index_device_bytes", "moni_index_destroy",
+                     "moni_ctx_destroy", "moni_free"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.moni_index_create.argtypes = [C.POINTER(FlatIndexC), C.c_int, C.POINTER(C.c_void_p)]
+        L.moni_index_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.moni_ctx_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.moni_reads_upload.argtypes = [C.c_void_p, C.POINTER(ReadBatchC)]
+        L.moni_ms_run.argtypes = [C.c_void_p]
+        L.moni_ms_query_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p]
+        L.moni_seed_run.argtypes = [C.c_void_p, C.POINTER(SeedParamsC)]
+        L.moni_seed_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.moni_seed_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.moni_phi_lcp_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+        L.moni_extz_batch.argtypes = [C.c_void_p, C.POINTER(DpParamsC), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                      C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.moni_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        L.moni_last_counters.argtypes = [C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (what, rc))
+
+
+def flat_struct(fi) -> FlatIndexC:
+    """fi: moni_align_amd.index_build.FlatIndex (arrays are kept alive by the caller)."""
+    s = FlatIndexC()
+    s.n, s.r, s.w, s.n_seq = fi.n, fi.r, fi.w, len(fi.seq_starts) - 1
+    for k in ("F", "heads", "starts", "ssa", "esa", "thr", "slcp", "text", "seq_starts"):
+        a = getattr(fi, k)
+        assert a.flags["C_CONTIGUOUS"]
+        setattr(s, k, a.ctypes.data)
+    return s
+
+
+class Index:
+    def __init__(self, fi=None, path: Optional[str] = None, device: int = 0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        self._keep = fi
+        if fi is not None:
+            st = flat_struct(fi)
+            _chk(self._L.moni_index_create(C.byref(st), device, C.byref(self._h)), "moni_index_create")
+        else:
+            _chk(self._L.moni_index_load(path.encode(), device, C.byref(self._h)), "moni_index_load")
+        self.n = self._L.moni_index_n(self._h)
+        self.r = self._L.moni_index_r(self._h)
+        self.device_bytes = self._L.moni_index_device_bytes(self._h)
+
+    def close(self):
+        if self._h:
+            self._L.moni_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class Ctx:
+    def __init__(self, index: Index):
+        self._L = lib()
+        self.index = index
+        self._h = C.c_void_p()
+        _chk(self._L.moni_ctx_create(index._h, C.byref(self._h)), "moni_ctx_create")
+        self.n_reads = 0
+
+    def close(self):
+        if self._h:
+            self._L.moni_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    @staticmethod
+    def _batch(seq: np.ndarray, offsets: np.ndarray):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        b = ReadBatchC(seq.ctypes.data, offsets.ctypes.data, len(offsets) - 1)
+        return b, (seq, offsets)
+
+    def upload(self, seq: np.ndarray, offsets: np.ndarray):
+        b, keep = self._batch(seq, offsets)
+        _chk(self._L.moni_reads_upload(self._h, C.byref(b)), "moni_reads_upload")
+        self.n_reads = len(offsets) - 1
+
+    def ms_run(self):
+        _chk(self._L.moni_ms_run(self._h), "moni_ms_run")
+
+    def ms_query_batch(self, seq: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+        b, keep = self._batch(seq, offsets)
+        total = int(keep[1][-1] - keep[1][0])
+        out = np.empty(2 * total, dtype=np.uint64)
+        _chk(self._L.moni_ms_query_batch(self._h, C.byref(b), out.ctypes.data), "moni_ms_query_batch")
+        self.n_reads = len(offsets) - 1
+        return out
+
+    def seed_run(self, min_len: int = 25, filter_seeds: bool = True, n_seeds_thr: int = 1000, report_mems: bool = False):
+        p = SeedParamsC(min_len, int(filter_seeds), n_seeds_thr, int(report_mems))
+        _chk(self._L.moni_seed_run(self._h, C.byref(p)), "moni_seed_run")
+
+    def seed_fetch(self) -> Dict[str, np.ndarray]:
+        nm, no = C.c_uint64(), C.c_uint64()
+        _chk(self._L.moni_seed_counts(self._h, C.byref(nm), C.byref(no)), "moni_seed_counts")
+        mems = np.empty(nm.value, dtype=MEM_DTYPE)
+        occs = np.empty(no.value, dtype=np.uint64)
+        rmo = np.empty(self.n_reads + 1, dtype=np.uint64)
+        _chk(self._L.moni_seed_fetch(self._h, mems.ctypes.data, occs.ctypes.data, rmo.ctypes.data), "moni_seed_fetch")
+        return {"mems": mems, "occs": occs, "read_mem_off": rmo}
+
+    def phi_lcp_batch(self, pos: np.ndarray, inverse: bool = False):
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        a = np.empty(len(pos), dtype=np.uint64)
+        b = np.empty(len(pos), dtype=np.uint64)
+        _chk(self._L.moni_phi_lcp_batch(self._h, pos.ctypes.data, len(pos), int(inverse), a.ctypes.data, b.ctypes.data),
+             "moni_phi_lcp_batch")
+        return a, b
+
+    def extz_batch(self, qseq: np.ndarray, tseq: np.ndarray, tasks: np.ndarray, cigar_cap: Optional[int] = None,
+                   mat=DEFAULT_MAT, q: int = 4, e: int = 2, w: int = -1, zdrop: int = -1, end_bonus: int = 400):
+        qseq = np.ascontiguousarray(qseq, dtype=np.uint8)
+        tseq = np.ascontiguousarray(tseq, dtype=np.uint8)
+        tasks = np.ascontiguousarray(tasks, dtype=DP_TASK_DTYPE)
+        prm = DpParamsC()
+        prm.m = 5
+        for i, v in enumerate(mat):
+            prm.mat[i] = v
+        prm.q, prm.e, prm.w, prm.zdrop, prm.end_bonus = q, e, w, zdrop, end_bonus
+        res = np.zeros(len(tasks), dtype=DP_RESULT_DTYPE)
+        if cigar_cap is None:
+            cigar_cap = int((tasks["qlen"].astype(np.int64) + tasks["tlen"].astype(np.int64)).sum()) + 16
+        pool = np.zeros(cigar_cap, dtype=np.uint32)
+        used = C.c_uint64()
+        _chk(self._L.moni_extz_batch(self._h, C.byref(prm), qseq.ctypes.data, len(qseq), tseq.ctypes.data, len(tseq),
+                                     tasks.ctypes.data, len(tasks), res.ctypes.data, pool.ctypes.data, cigar_cap,
+                                     C.byref(used)), "moni_extz_batch")
+        return res, pool[: used.value]
+
+    def kernel_ms(self, which: int) -> float:
+        v = C.c_float()
+        _chk(self._L.moni_last_kernel_ms(self._h, which, C.byref(v)), "moni_last_kernel_ms")
+        return float(v.value)
+
+    def counters(self) -> np.ndarray:
+        out = np.zeros(4, dtype=np.uint64)
+        _chk(self._L.moni_last_counters(self._h, out.ctypes.data), "moni_last_counters")
+        return out

@@ -1,0 +1,216 @@
+// extz_kernel: ksw_extz2_sse (lh3/ksw2, absent submodule; semantics per SURVEY.md App. A and the call sites
+// include/aligner/aligner_ksw2.hpp:2812,2844,2965,2988,3015) as a hand-written anti-diagonal DP for gfx950.
+//
+// One 64-lane wavefront (= one workgroup) per DP problem.  Target rows live on lanes: lane l owns rows
+// l, l+64, ... (NCH chunks), so H(i,j-1) and F(i,j-1) are the lane's own registers from the previous
+// anti-diagonal and H(i-1,j), H(i-1,j-1), E(i-1,j) come from lane l-1 by a one-lane shuffle (DPP), with a
+// readlane from lane 63 of the previous chunk at chunk seams.  No LDS traffic in the recurrence except the
+// query byte; exact int32 arithmetic (the SSE code's 8-bit difference form is the same recurrence).
+// Direction bytes (ksw2 encoding: bits 0-2 source, 0x08 E continues, 0x10 F continues) go to a per-task
+// global scratch row-major by anti-diagonal, and lane 0 backtracks them exactly like ksw_backtrack.
+// Integer DP: VALU-bound, reported in GCUPS; no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/moni_hip.h"
+
+#define DP_NEG_INF (-0x40000000)
+#define DP_EZ_SCORE_ONLY 0x01
+#define DP_EZ_RIGHT 0x02
+#define DP_EZ_EXTZ_ONLY 0x40
+#define DP_MAX_QLEN 2048
+
+struct dp_launch_t {
+    const uint8_t* qseq;
+    const uint8_t* tseq;
+    const moni_dp_task_t* tasks;
+    const uint32_t* order;        // task indices of this launch
+    const uint64_t* dir_off;      // per task: offset of its direction bytes (CIGAR tasks)
+    const uint64_t* cig_off;      // per task: offset of its temporary CIGAR slots
+    uint8_t* dirs;
+    uint32_t* cig_tmp;
+    moni_dp_result_t* results;
+    int32_t sc_mch, sc_mis, sc_N, wild;
+    int32_t qo, e, end_bonus;
+};
+
+__device__ __forceinline__ int32_t dp_bound(int32_t k, int32_t qo, int32_t e) {   // H(k,-1) = H(-1,k), k >= -1
+    return k < 0 ? 0 : -(qo + (k + 1) * e);
+}
+
+__device__ __forceinline__ long long wave_max_i64(long long v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long w = __shfl_xor(v, o);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(64)
+extz_kernel(const dp_launch_t P) {
+    __shared__ uint8_t qs[DP_MAX_QLEN];
+    const int lane = threadIdx.x;
+    const uint32_t tix = P.order[blockIdx.x];
+    const moni_dp_task_t task = P.tasks[tix];
+    const int qlen = task.qlen, tlen = task.tlen, flag = task.flag;
+    moni_dp_result_t R;
+    R.max = 0; R.max_q = R.max_t = R.mqe_t = R.mte_q = -1; R.mqe = R.mte = R.score = DP_NEG_INF;
+    R.reach_end = 0; R.zdropped = 0; R.n_cigar = 0; R.cigar_off = 0;
+    if (qlen <= 0 || tlen <= 0) {                       // ksw_extz2_sse returns right after ksw_reset_extz
+        if (lane == 0) P.results[tix] = R;
+        return;
+    }
+    const bool with_cigar = !(flag & DP_EZ_SCORE_ONLY);
+    const bool right = (flag & DP_EZ_RIGHT) != 0;
+    const uint8_t* __restrict__ q = P.qseq + task.q_off;
+    const uint8_t* __restrict__ tg = P.tseq + task.t_off;
+    for (int k = lane; k < qlen; k += 64) qs[k] = q[k];
+    __syncthreads();
+    const int32_t qo = P.qo, e = P.e;
+    uint8_t* __restrict__ dir = with_cigar ? P.dirs + P.dir_off[tix] : nullptr;
+
+    int32_t H1[NCH], H2[NCH], E1[NCH], F1[NCH];
+    int32_t tcode[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int i = lane + 64 * k;
+        H1[k] = dp_bound(i, qo, e);                     // H(i,-1)
+        H2[k] = 0;
+        E1[k] = DP_NEG_INF;
+        F1[k] = DP_NEG_INF;
+        tcode[k] = i < tlen ? (int32_t)tg[i] : 255;
+    }
+    // per-lane running results
+    int32_t mqe_h = DP_NEG_INF, mqe_i = -1;            // best H(i, qlen-1) over own rows (rows ascend with the chunk index)
+    long long max_key = -1;                             // (H, earliest diagonal, ksw2 lane order) of the best H > 0
+    int32_t mte_h = DP_NEG_INF, mte_q = -1;
+    const int en_r = (tlen - 1 + 16) / 16 * 16 - 1;     // ksw2 reports mte_q relative to the 16-padded band end
+
+    const int n_diag = qlen + tlen - 1;
+    for (int r = 0; r < n_diag; ++r) {
+        const int st0 = r - qlen + 1 > 0 ? r - qlen + 1 : 0;
+        const int en0 = r < tlen - 1 ? r : tlen - 1;
+        const int en1 = st0 + (en0 - st0) / 4 * 4;
+        // neighbour values from the previous anti-diagonal, for every chunk, before anything is updated
+        int32_t uH1[NCH], uH2[NCH], uE[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            uH1[k] = __shfl_up(H1[k], 1);
+            uH2[k] = __shfl_up(H2[k], 1);
+            uE[k] = __shfl_up(E1[k], 1);
+        }
+#pragma unroll
+        for (int k = NCH - 1; k >= 0; --k) {
+            int32_t bH1, bH2, bE;
+            if (k == 0) { bH1 = dp_bound(r, qo, e); bH2 = dp_bound(r - 1, qo, e); bE = DP_NEG_INF; }   // row -1: H(-1,j), H(-1,j-1)
+            else { bH1 = __shfl(H1[k - 1], 63); bH2 = __shfl(H2[k - 1], 63); bE = __shfl(E1[k - 1], 63); }
+            if (lane == 0) { uH1[k] = bH1; uH2[k] = bH2; uE[k] = bE; }
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (64 * k > en0 || 64 * k + 63 < st0) continue;          // wave-uniform: chunk outside this diagonal
+            const int i = lane + 64 * k;
+            const int j = r - i;
+            if (i >= st0 && i <= en0) {
+                const int32_t h_left = H1[k];
+                const int32_t Eo = uH1[k] - qo;
+                const int32_t E = (Eo > uE[k] ? Eo : uE[k]) - e;
+                const int32_t Fo = h_left - qo;
+                const int32_t F = (Fo > F1[k] ? Fo : F1[k]) - e;
+                const int32_t qc = qs[j];
+                const int32_t tc = tcode[k];
+                const int32_t s = (tc == P.wild || qc == P.wild) ? P.sc_N : (tc == qc ? P.sc_mch : P.sc_mis);
+                int32_t z = uH2[k] + s;
+                uint32_t d;
+                if (!right) {
+                    d = E > z ? 1u : 0u;
+                    z = z > E ? z : E;
+                    d = F > z ? 2u : d;
+                    z = z > F ? z : F;
+                    if (E > z - qo) d |= 0x08u;
+                    if (F > z - qo) d |= 0x10u;
+                } else {
+                    d = z > E ? 0u : 1u;
+                    z = z > E ? z : E;
+                    d = z > F ? d : 2u;
+                    z = z > F ? z : F;
+                    if (E >= z - qo) d |= 0x08u;
+                    if (F >= z - qo) d |= 0x10u;
+                }
+                H2[k] = h_left; H1[k] = z; E1[k] = E; F1[k] = F;
+                if (with_cigar) dir[(size_t)r * tlen + i] = (uint8_t)d;
+                if (j == qlen - 1 && z > mqe_h) { mqe_h = z; mqe_i = i; }
+                if (i == tlen - 1 && z > mte_h) { mte_h = z; mte_q = r - en_r; }
+                if (z > 0) {
+                    int rank;
+                    if (i == en0) rank = 0;
+                    else if (i < en1) rank = 1 + ((i - st0) & 3) * 4096 + ((i - st0) >> 2);
+                    else rank = 1 + 4 * 4096 + (i - en1);
+                    if (r == 0) rank = 0;
+                    const long long key = (long long)(((unsigned long long)(uint32_t)z << 32) | ((unsigned long long)(0xFFFF - r) << 16) |
+                                                      (unsigned long long)(0xFFFF - rank));
+                    if (key > max_key) max_key = key;
+                }
+            }
+        }
+    }
+    // ---- wave reductions ----
+    const long long mqe_key = wave_max_i64((long long)(((unsigned long long)(long long)mqe_h << 32) |
+                                                       (unsigned long long)(uint32_t)(0x7FFFFFFF - (mqe_i < 0 ? 0x7FFFFFFF : mqe_i))));
+    R.mqe = (int32_t)(mqe_key >> 32);
+    R.mqe_t = 0x7FFFFFFF - (int32_t)(mqe_key & 0xFFFFFFFFll);
+    max_key = wave_max_i64(max_key);
+    if (max_key >= 0) {
+        R.max = (int32_t)(max_key >> 32);
+        const int rr = 0xFFFF - (int)((max_key >> 16) & 0xFFFF);
+        const int rank = 0xFFFF - (int)(max_key & 0xFFFF);
+        const int st0 = rr - qlen + 1 > 0 ? rr - qlen + 1 : 0;
+        const int en0 = rr < tlen - 1 ? rr : tlen - 1;
+        const int en1 = st0 + (en0 - st0) / 4 * 4;
+        int t;
+        if (rank == 0) t = rr == 0 ? 0 : en0;
+        else if (rank < 1 + 4 * 4096) t = st0 + ((rank - 1) / 4096) + 4 * ((rank - 1) % 4096);
+        else t = en1 + (rank - 1 - 4 * 4096);
+        R.max_t = t; R.max_q = rr - t;
+    }
+    {   // the lane that owns row tlen-1 holds mte and the global score
+        const int owner = (tlen - 1) & 63;
+        int32_t sc = DP_NEG_INF;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) if ((tlen - 1) >> 6 == k) sc = H1[k];
+        R.mte = __shfl(mte_h, owner);
+        R.mte_q = __shfl(mte_q, owner);
+        R.score = __shfl(sc, owner);
+    }
+    // ---- backtrack (ksw_backtrack, is_rot = 1) by lane 0 ----
+    if (with_cigar) {
+        __syncthreads();                                // direction bytes written by all lanes -> visible to lane 0
+        int i0 = -1, j0 = -1;
+        if (!(flag & DP_EZ_EXTZ_ONLY)) { i0 = tlen - 1; j0 = qlen - 1; }
+        else if (R.mqe + P.end_bonus > R.max) { R.reach_end = 1; i0 = R.mqe_t; j0 = qlen - 1; }
+        else if (R.max_t >= 0 && R.max_q >= 0) { i0 = R.max_t; j0 = R.max_q; }
+        if (lane == 0 && i0 >= 0 && j0 >= 0) {
+            uint32_t* __restrict__ cg = P.cig_tmp + P.cig_off[tix];
+            int n = 0, i = i0, j = j0, state = 0;
+            auto push = [&](uint32_t op, int len) {
+                if (n == 0 || op != (cg[n - 1] & 0xf)) cg[n++] = (uint32_t)len << 4 | op;
+                else cg[n - 1] += (uint32_t)len << 4;
+            };
+            while (i >= 0 && j >= 0) {
+                const uint32_t tmp = dir[(size_t)(i + j) * tlen + i];
+                if (state == 0) state = tmp & 7;
+                else if (!(tmp >> (state + 2) & 1)) state = 0;
+                if (state == 0) state = tmp & 7;
+                if (state == 0) { push(0, 1); --i; --j; }
+                else if (state == 1 || state == 3) { push(2, 1); --i; }
+                else { push(1, 1); --j; }
+            }
+            if (i >= 0) push(2, i + 1);
+            if (j >= 0) push(1, j + 1);
+            for (int a = 0; a < n >> 1; ++a) { const uint32_t t2 = cg[a]; cg[a] = cg[n - 1 - a]; cg[n - 1 - a] = t2; }
+            R.n_cigar = (uint32_t)n;
+        }
+    }
+    if (lane == 0) P.results[tix] = R;
+}

@@ -1,0 +1,178 @@
+// Host-side conversion: semantic index arrays (moni_flat_index_t) -> device layout (layout.h).
+// O(r) single pass per structure; runs once at load time, like seed_finder's constructor
+// (include/aligner/seed_finder.hpp:64-124).
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/moni_hip.h"
+#include "layout.h"
+
+struct HostImage {
+    moni_consts_t K;
+    moni_tables_t T;
+    std::vector<moni_row_t> rows;      // r + 2
+    std::vector<uint32_t> cr;          // (r + 1) * sigma
+    std::vector<moni_rec_t> recs;
+    std::vector<moni_phi_t> phi, phi_inv;   // r each
+    std::vector<uint32_t> phi_dir, phi_inv_dir;
+    std::vector<uint64_t> seq_starts;
+    std::string err;
+
+    static inline moni_row_t pack_row(uint64_t start, uint32_t head, uint64_t lfbase, uint64_t dest) {
+        moni_row_t x;
+        x.w0 = start | ((uint64_t)head << 40) | ((dest >> 24) << 44);
+        x.w1 = lfbase | ((dest & 0xFFFFFFull) << 40);
+        return x;
+    }
+
+    int build(const moni_flat_index_t& f) {
+        const uint64_t n = f.n, r = f.r;
+        if (n >= (1ull << 40) || r >= (1ull << 32) - 2 || r == 0) { err = "index too large for the 40/32-bit layout"; return MONI_ERANGE; }
+        memset(&K, 0, sizeof(K));
+        memset(&T, 0, sizeof(T));
+        K.n = n; K.r = r; K.n_text = n - 1; K.n_seq = (uint32_t)f.n_seq;
+        K.last_run_sample = (f.esa[r - 1] + 1) % n;
+        K.first_run_sample = (f.ssa[0] + 1) % n;
+        // alphabet
+        uint64_t n_letter[256] = {0};
+        uint64_t runs_letter[256] = {0};
+        for (uint64_t k = 0; k < r; ++k) {
+            if (f.starts[k + 1] <= f.starts[k]) { err = "run starts not increasing"; return MONI_ERANGE; }
+            n_letter[f.heads[k]] += f.starts[k + 1] - f.starts[k];
+            runs_letter[f.heads[k]]++;
+        }
+        if (f.starts[0] != 0 || f.starts[r] != n) { err = "run starts do not cover [0,n)"; return MONI_ERANGE; }
+        uint32_t sigma = 0;
+        int code_of[256];
+        int byte_of[MONI_MAX_SIGMA];
+        for (int b = 0; b < 256; ++b) {
+            code_of[b] = -1;
+            T.code[b] = MONI_CODE_ABSENT;
+            if (n_letter[b]) {
+                if (sigma >= MONI_MAX_SIGMA - 1) { err = "more than 15 distinct BWT symbols"; return MONI_ERANGE; }
+                code_of[b] = (int)sigma; byte_of[sigma] = b; T.code[b] = (uint8_t)sigma; ++sigma;
+            }
+            T.compl_tab[b] = (uint8_t)b;
+        }
+        T.compl_tab['A'] = 'T'; T.compl_tab['C'] = 'G'; T.compl_tab['G'] = 'C'; T.compl_tab['T'] = 'A';
+        T.compl_tab['a'] = 'T'; T.compl_tab['c'] = 'G'; T.compl_tab['g'] = 'C'; T.compl_tab['t'] = 'A';
+        K.sigma = sigma;
+        // F must be the cumulative letter counts (moni.hpp:253-282)
+        {
+            uint64_t acc = 0;
+            for (int b = 0; b < 256; ++b) {
+                if (f.F[b] != acc) { err = "F is not the cumulative symbol count"; return MONI_ERANGE; }
+                acc += n_letter[b];
+            }
+        }
+        // rows: start/head, then lfbase/dest in F order (one monotone pointer over the run starts)
+        rows.assign(r + 2, pack_row(0, 0, 0, 0));
+        std::vector<uint64_t> lfbase(r), dest(r);
+        {
+            std::vector<std::vector<uint32_t>> cruns(sigma);
+            for (uint32_t c = 0; c < sigma; ++c) cruns[c].reserve(runs_letter[byte_of[c]]);
+            for (uint64_t k = 0; k < r; ++k) cruns[code_of[f.heads[k]]].push_back((uint32_t)k);
+            // recs
+            uint32_t base = 0;
+            for (uint32_t c = 0; c < sigma; ++c) { K.rec_base[c] = base; K.rec_cnt[c] = (uint32_t)cruns[c].size(); base += (uint32_t)cruns[c].size() + 1; }
+            K.rec_base[sigma] = base;
+            recs.assign(base, moni_rec_t{0, 0, 0, 0});
+            uint64_t d = 0;   // run containing the current lf position
+            for (uint32_t c = 0; c < sigma; ++c) {
+                const int b = byte_of[c];
+                uint64_t cum = 0;
+                const size_t Rc = cruns[c].size();
+                for (size_t j = 0; j <= Rc; ++j) {
+                    const uint64_t lfpos = f.F[b] + cum;
+                    while (d < r && f.starts[d + 1] <= lfpos) ++d;     // d == r  <=>  lfpos == n
+                    moni_rec_t& R = recs[K.rec_base[c] + j];
+                    uint64_t thr = 0, ssa = 0, esa_prev = 0;
+                    if (j < Rc) {
+                        const uint64_t k = cruns[c][j];
+                        thr = f.thr[k]; ssa = f.ssa[k];
+                        if ((j == 0) != (thr == 0)) { err = "threshold 0 must mark exactly the first run of a letter"; return MONI_ERANGE; }
+                        if (j > 0) {
+                            const uint64_t kp = cruns[c][j - 1];
+                            // the device compares pos with thr_j only; that equals thr_bv::rank (thresholds_ds.hpp:494)
+                            // iff every threshold lies in (end of previous c-run, start of this c-run]
+                            if (!(thr > f.starts[kp + 1] - 1 && thr <= f.starts[k])) { err = "threshold outside its inter-run interval"; return MONI_ERANGE; }
+                        }
+                        lfbase[k] = lfpos; dest[k] = d;
+                        cum += f.starts[k + 1] - f.starts[k];
+                    }
+                    if (j > 0) esa_prev = f.esa[cruns[c][j - 1]];
+                    if ((thr | ssa | esa_prev | lfpos) >> 40) { err = "value exceeds 40 bits"; return MONI_ERANGE; }
+                    R.w0 = thr | ((d >> 24) << 40);
+                    R.w1 = ssa | ((d & 0xFFFFFFull) << 40);
+                    R.w2 = esa_prev;
+                    R.w3 = lfpos;
+                }
+            }
+            // cr
+            cr.assign((r + 1) * (uint64_t)sigma, 0);
+            std::vector<uint32_t> seen(sigma, 0);
+            for (uint64_t k = 0; k <= r; ++k) {
+                for (uint32_t c = 0; c < sigma; ++c) cr[k * sigma + c] = seen[c];
+                if (k < r) seen[code_of[f.heads[k]]]++;
+            }
+        }
+        for (uint64_t k = 0; k < r; ++k) rows[k] = pack_row(f.starts[k], (uint32_t)code_of[f.heads[k]], lfbase[k], dest[k]);
+        rows[r] = pack_row(n, MONI_HEAD_NONE, 0, r);
+        rows[r + 1] = pack_row(MONI_POS_MASK, MONI_HEAD_NONE, 0, r);
+        // absent bytes: LF(pos, b) = F[b]   (moni.hpp:583-588)
+        for (int b = 0; b < 256; ++b) {
+            T.abs_pos[b] = f.F[b];
+            uint64_t k = (uint64_t)(std::upper_bound(f.starts, f.starts + r, f.F[b]) - f.starts) - 1;
+            if (f.F[b] >= n) k = r;
+            T.abs_run[b] = (uint32_t)k;
+        }
+        // phi
+        uint32_t sh = 0;
+        while ((n >> sh) > 2 * r + 1024 && sh < 30) ++sh;   // about <= 2 keys per directory slot on average
+        K.phi_shift = sh;
+        int rc;
+        if ((rc = build_phi(f, f.ssa, false, phi, phi_dir))) return rc;
+        if ((rc = build_phi(f, f.esa, true, phi_inv, phi_inv_dir))) return rc;
+        seq_starts.assign(f.seq_starts, f.seq_starts + f.n_seq + 1);
+        return MONI_OK;
+    }
+
+    // moni.hpp:186-251 (build_phi) + the lookups of moni_lcp.hpp:230-272 folded into one record per key
+    int build_phi(const moni_flat_index_t& f, const uint64_t* smp, bool inverse, std::vector<moni_phi_t>& out,
+                  std::vector<uint32_t>& dir) {
+        const uint64_t n = f.n, r = f.r;
+        std::vector<std::pair<uint64_t, uint64_t>> s(r);
+        for (uint64_t i = 0; i < r; ++i) s[i] = std::make_pair(smp[i], i);
+        std::sort(s.begin(), s.end());
+        out.resize(r);
+        for (uint64_t i = 0; i < r; ++i) {
+            const uint64_t run = s[i].second;
+            uint64_t prev = MONI_POS_MASK, lcp = 0;   // undefined entries (Phi of SA[0] / Phi_inv of SA[n-1]) are guarded by the caller
+            if (!inverse) { if (run > 0) { prev = f.esa[run - 1]; lcp = f.slcp[run]; } }
+            else { if (run + 1 < r) { prev = f.ssa[run + 1]; lcp = f.slcp[run + 1]; } }
+            if ((lcp >> 40) || (s[i].first >> 40)) { err = "phi value exceeds 40 bits"; return MONI_ERANGE; }
+            out[i].w0 = s[i].first | ((lcp & 0xFFFFFFull) << 40);
+            out[i].w1 = prev | ((lcp >> 24) << 40);
+            if (i > 0 && s[i].first == s[i - 1].first) { err = "duplicate SA sample"; return MONI_ERANGE; }
+        }
+        const uint32_t sh = K.phi_shift;
+        const uint64_t slots = (n >> sh) + 2;
+        dir.resize(slots + 1);
+        uint64_t p = 0;
+        for (uint64_t sl = 0; sl <= slots; ++sl) {
+            const uint64_t lo = sl << sh;
+            while (p < r && s[p].first < lo) ++p;
+            dir[sl] = (uint32_t)p;
+        }
+        return MONI_OK;
+    }
+
+    uint64_t bytes() const {
+        return rows.size() * sizeof(moni_row_t) + cr.size() * 4 + recs.size() * sizeof(moni_rec_t) +
+               (phi.size() + phi_inv.size()) * sizeof(moni_phi_t) + (phi_dir.size() + phi_inv_dir.size()) * 4;
+    }
+};

@@ -1,0 +1,431 @@
+// libmoni_hip.so: C ABI (include/moni_hip.h) over the HIP kernels.  Host side only orchestrates:
+// device buffers, launches on the context's stream, exclusive scans (rocPRIM), HIP-event timing.
+// There is no CPU implementation of any kernel in this library: without a HIP device every entry
+// point fails with MONI_ENODEV.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/moni_hip.h"
+#include "image.hpp"
+#include "layout.h"
+#include "seed_kernels.hip"
+#include "extz_kernels.hip"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "moni_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return MONI_ENODEV; } } while (0)
+
+enum { EV_MS0 = 0, EV_MS1, EV_MC0, EV_MC1, EV_ME0, EV_ME1, EV_PC0, EV_PC1, EV_PE0, EV_PE1, EV_DP0, EV_DP1, EV_ALL0, EV_ALL1, EV_N };
+
+struct moni_index {
+    int device = 0;
+    moni_consts_t K;
+    moni_tables_t* d_tables = nullptr;
+    moni_row_t* d_rows = nullptr;
+    uint32_t* d_cr = nullptr;
+    moni_rec_t* d_recs = nullptr;
+    moni_phi_t *d_phi = nullptr, *d_phi_inv = nullptr;
+    uint32_t *d_phi_dir = nullptr, *d_phi_inv_dir = nullptr;
+    uint8_t* d_text = nullptr;
+    uint64_t* d_seq_starts = nullptr;
+    uint32_t* d_name_id = nullptr;
+    uint64_t bytes = 0;
+};
+
+template <class Tp>
+struct DBuf {
+    Tp* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t need) {
+        if (need <= cap) return MONI_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = need + need / 8 + 64;
+        if (hipMalloc((void**)&p, want * sizeof(Tp)) != hipSuccess) { p = nullptr; return MONI_ENOMEM; }
+        cap = want;
+        return MONI_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct moni_ctx {
+    moni_index* idx = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[EV_N];
+    bool ev_valid[EV_N];
+    // resident batch
+    DBuf<uint8_t> seq;
+    DBuf<uint64_t> offs;
+    uint64_t n_reads = 0, total_len = 0, max_len = 0;
+    // workspaces
+    DBuf<uint64_t> ptr;
+    DBuf<uint32_t> cnt_m, cnt_s;
+    DBuf<uint64_t> tot, read_mem_off;
+    DBuf<moni_mem_t> mems;
+    DBuf<uint32_t> aux;
+    DBuf<uint64_t> lowers, tmp, occ_cnt, occ_off, occs;
+    DBuf<uint32_t> pool;
+    DBuf<uint8_t> scan_tmp;
+    uint32_t* d_small = nullptr;            // [0] pool_next, [1] error_flag
+    unsigned long long* d_counters = nullptr;   // 4
+    uint64_t n_mems = 0, n_occs = 0;
+    uint32_t tmp_cap = 16;
+    uint32_t pool_rows = 4096;
+    // dp
+    DBuf<uint8_t> dp_q, dp_t, dp_dir;
+    DBuf<moni_dp_task_t> dp_tasks;
+    DBuf<moni_dp_result_t> dp_res;
+    DBuf<uint32_t> dp_cig;
+    DBuf<uint64_t> dp_off;
+    DBuf<uint32_t> dp_ws;
+};
+
+namespace {
+
+template <class Tp>
+int upload(Tp** d, const std::vector<Tp>& h, uint64_t& bytes) {
+    size_t nb = h.size() * sizeof(Tp);
+    if (hipMalloc((void**)d, nb ? nb : 8) != hipSuccess) return MONI_ENOMEM;
+    if (nb && hipMemcpy(*d, h.data(), nb, hipMemcpyHostToDevice) != hipSuccess) return MONI_ENODEV;
+    bytes += nb;
+    return MONI_OK;
+}
+
+int exclusive_scan_u64(moni_ctx* c, uint64_t* in, uint64_t* out, size_t n) {
+    size_t tmp_bytes = 0;
+    if (rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c->stream) != hipSuccess) return MONI_ENODEV;
+    int rc = c->scan_tmp.ensure(tmp_bytes + 16);
+    if (rc) return rc;
+    if (rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c->stream) != hipSuccess) return MONI_ENODEV;
+    return MONI_OK;
+}
+
+inline void rec(moni_ctx* c, int e) { (void)hipEventRecord(c->ev[e], c->stream); c->ev_valid[e] = true; }
+
+}  // namespace
+
+extern "C" {
+
+const char* moni_version(void) { return "moni_hip 0.1 (gfx950)"; }
+
+int moni_index_create(const moni_flat_index_t* f, int device, moni_index_t** out) {
+    if (!f || !out || !f->F || !f->heads || !f->starts || !f->ssa || !f->esa || !f->thr || !f->slcp || !f->text || !f->seq_starts)
+        return MONI_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) {
+        fprintf(stderr, "moni_hip: no HIP device %d (found %d); this library has no CPU path\n", device, ndev);
+        return MONI_ENODEV;
+    }
+    HIPCHK(hipSetDevice(device));
+    HostImage img;
+    int rc = img.build(*f);
+    if (rc) { fprintf(stderr, "moni_hip: index rejected: %s\n", img.err.c_str()); return rc; }
+    moni_index* I = new moni_index();
+    I->device = device;
+    I->K = img.K;
+    std::vector<moni_tables_t> tv(1, img.T);
+    std::vector<uint8_t> text(f->text, f->text + (f->n - 1));
+    std::vector<uint32_t> name_id(f->n_seq);
+    for (uint64_t i = 0; i < f->n_seq; ++i) name_id[i] = (uint32_t)i;
+    if ((rc = upload(&I->d_tables, tv, I->bytes)) || (rc = upload(&I->d_rows, img.rows, I->bytes)) ||
+        (rc = upload(&I->d_cr, img.cr, I->bytes)) || (rc = upload(&I->d_recs, img.recs, I->bytes)) ||
+        (rc = upload(&I->d_phi, img.phi, I->bytes)) || (rc = upload(&I->d_phi_inv, img.phi_inv, I->bytes)) ||
+        (rc = upload(&I->d_phi_dir, img.phi_dir, I->bytes)) || (rc = upload(&I->d_phi_inv_dir, img.phi_inv_dir, I->bytes)) ||
+        (rc = upload(&I->d_text, text, I->bytes)) || (rc = upload(&I->d_seq_starts, img.seq_starts, I->bytes)) ||
+        (rc = upload(&I->d_name_id, name_id, I->bytes))) {
+        moni_index_destroy(I);
+        return rc;
+    }
+    *out = I;
+    return MONI_OK;
+}
+
+int moni_index_load(const char* path, int device, moni_index_t** out) {
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return MONI_EIO;
+    char magic[8];
+    uint64_t hdr[6];
+    if (fread(magic, 1, 8, fp) != 8 || memcmp(magic, "MONIFLT2", 8) != 0 || fread(hdr, 8, 6, fp) != 6) { fclose(fp); return MONI_EIO; }
+    const uint64_t n = hdr[0], r = hdr[1], w = hdr[2], nseq = hdr[3];
+    std::vector<uint64_t> F(256), starts(r + 1), ssa(r), esa(r), thr(r), slcp(r), seq_starts(nseq + 1);
+    std::vector<uint8_t> heads(r), text(n - 1);
+    auto get = [&](void* dst, size_t bytes) {
+        if (bytes && fread(dst, 1, bytes, fp) != bytes) return false;
+        size_t pad = (8 - bytes % 8) % 8;
+        char t8[8];
+        if (pad && fread(t8, 1, pad, fp) != pad) return false;
+        return true;
+    };
+    bool ok = get(F.data(), 256 * 8) && get(heads.data(), r) && get(starts.data(), (r + 1) * 8) && get(ssa.data(), r * 8) &&
+              get(esa.data(), r * 8) && get(thr.data(), r * 8) && get(slcp.data(), r * 8) && get(text.data(), n - 1) &&
+              get(seq_starts.data(), (nseq + 1) * 8);
+    fclose(fp);
+    if (!ok) return MONI_EIO;
+    moni_flat_index_t f;
+    f.n = n; f.r = r; f.w = w; f.n_seq = nseq;
+    f.F = F.data(); f.heads = heads.data(); f.starts = starts.data(); f.ssa = ssa.data(); f.esa = esa.data();
+    f.thr = thr.data(); f.slcp = slcp.data(); f.text = text.data(); f.seq_starts = seq_starts.data();
+    return moni_index_create(&f, device, out);
+}
+
+void moni_index_destroy(moni_index_t* I) {
+    if (!I) return;
+    (void)hipSetDevice(I->device);
+    void* ps[] = {I->d_tables, I->d_rows, I->d_cr, I->d_recs, I->d_phi, I->d_phi_inv, I->d_phi_dir, I->d_phi_inv_dir, I->d_text, I->d_seq_starts, I->d_name_id};
+    for (void* p : ps) if (p) (void)hipFree(p);
+    delete I;
+}
+uint64_t moni_index_n(const moni_index_t* I) { return I ? I->K.n : 0; }
+uint64_t moni_index_r(const moni_index_t* I) { return I ? I->K.r : 0; }
+uint64_t moni_index_device_bytes(const moni_index_t* I) { return I ? I->bytes : 0; }
+
+int moni_ctx_create(moni_index_t* I, moni_ctx_t** out) {
+    if (!I || !out) return MONI_EINVAL;
+    HIPCHK(hipSetDevice(I->device));
+    moni_ctx* c = new moni_ctx();
+    c->idx = I;
+    HIPCHK(hipStreamCreate(&c->stream));
+    for (int i = 0; i < EV_N; ++i) { HIPCHK(hipEventCreate(&c->ev[i])); c->ev_valid[i] = false; }
+    HIPCHK(hipMalloc((void**)&c->d_small, 16));
+    HIPCHK(hipMalloc((void**)&c->d_counters, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->d_small, 0, 16));
+    HIPCHK(hipMemset(c->d_counters, 0, 4 * sizeof(unsigned long long)));
+    *out = c;
+    return MONI_OK;
+}
+
+void moni_ctx_destroy(moni_ctx_t* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->idx->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->seq.release(); c->offs.release(); c->ptr.release(); c->cnt_m.release(); c->cnt_s.release(); c->tot.release();
+    c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
+    c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
+    c->dp_q.release(); c->dp_t.release(); c->dp_dir.release(); c->dp_tasks.release(); c->dp_res.release(); c->dp_cig.release();
+    c->dp_off.release(); c->dp_ws.release();
+    if (c->d_small) (void)hipFree(c->d_small);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(c->ev[i]);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int moni_reads_upload(moni_ctx_t* c, const moni_read_batch_t* b) {
+    if (!c || !b || !b->offsets || (b->n_reads && !b->seq)) return MONI_EINVAL;
+    HIPCHK(hipSetDevice(c->idx->device));
+    const uint64_t nr = b->n_reads;
+    uint64_t mx = 0;
+    for (uint64_t i = 0; i < nr; ++i) {
+        if (b->offsets[i + 1] < b->offsets[i]) return MONI_EINVAL;
+        uint64_t l = b->offsets[i + 1] - b->offsets[i];
+        if (l > mx) mx = l;
+    }
+    if (mx >= (1ull << 31)) return MONI_EINVAL;
+    const uint64_t total = nr ? b->offsets[nr] - b->offsets[0] : 0;
+    int rc;
+    if ((rc = c->seq.ensure(total + 16)) || (rc = c->offs.ensure(nr + 1))) return rc;
+    std::vector<uint64_t> rel(nr + 1);
+    for (uint64_t i = 0; i <= nr; ++i) rel[i] = b->offsets[i] - b->offsets[0];
+    if (total) HIPCHK(hipMemcpyAsync(c->seq.p, b->seq + b->offsets[0], total, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->offs.p, rel.data(), (nr + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->n_reads = nr; c->total_len = total; c->max_len = mx;
+    c->n_mems = c->n_occs = 0;
+    return MONI_OK;
+}
+
+static int ms_launch(moni_ctx* c) {
+    moni_index* I = c->idx;
+    const uint64_t n_tasks = 2 * c->n_reads;
+    int rc = c->ptr.ensure(n_tasks * c->max_len + 1);
+    if (rc) return rc;
+    rec(c, EV_MS0);
+    if (n_tasks) {
+        const unsigned grid = (unsigned)((n_tasks + MS_BLOCK - 1) / MS_BLOCK);
+        hipLaunchKernelGGL(ms_lf_kernel, dim3(grid), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_rows, I->d_cr, I->d_recs,
+                           c->seq.p, c->offs.p, n_tasks, c->ptr.p, c->d_counters);
+    }
+    rec(c, EV_MS1);
+    HIPCHK(hipGetLastError());
+    return MONI_OK;
+}
+
+int moni_ms_run(moni_ctx_t* c) {
+    if (!c) return MONI_EINVAL;
+    HIPCHK(hipSetDevice(c->idx->device));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), c->stream));
+    rec(c, EV_ALL0);
+    int rc = ms_launch(c);
+    rec(c, EV_ALL1);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MONI_OK;
+}
+
+int moni_ms_query_batch(moni_ctx_t* c, const moni_read_batch_t* b, uint64_t* pointers) {
+    if (!pointers) return MONI_EINVAL;
+    int rc = moni_reads_upload(c, b);
+    if (rc) return rc;
+    if ((rc = moni_ms_run(c))) return rc;
+    const uint64_t n_tasks = 2 * c->n_reads;
+    std::vector<uint64_t> h(n_tasks * c->max_len);
+    if (!h.empty()) HIPCHK(hipMemcpy(h.data(), c->ptr.p, h.size() * 8, hipMemcpyDeviceToHost));
+    const uint64_t base = b->offsets[0];
+    for (uint64_t rd = 0; rd < c->n_reads; ++rd) {
+        const uint64_t off = b->offsets[rd] - base, m = b->offsets[rd + 1] - b->offsets[rd];
+        for (uint64_t s = 0; s < 2; ++s)
+            for (uint64_t k = 0; k < m; ++k)
+                pointers[2 * off + s * m + k] = h[(m - 1 - k) * n_tasks + (2 * rd + s)];
+    }
+    return MONI_OK;
+}
+
+int moni_seed_run(moni_ctx_t* c, const moni_seed_params_t* prm) {
+    if (!c || !prm) return MONI_EINVAL;
+    moni_index* I = c->idx;
+    HIPCHK(hipSetDevice(I->device));
+    const uint64_t nr = c->n_reads, n_tasks = 2 * nr;
+    int rc;
+    if ((rc = c->cnt_m.ensure(n_tasks + 2)) || (rc = c->cnt_s.ensure(n_tasks + 2)) || (rc = c->tot.ensure(nr + 2)) ||
+        (rc = c->read_mem_off.ensure(nr + 2)))
+        return rc;
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_small, 0, 16, c->stream));
+    rec(c, EV_ALL0);
+    if ((rc = ms_launch(c))) return rc;
+    const unsigned grid_t = (unsigned)((n_tasks + MS_BLOCK - 1) / MS_BLOCK);
+    const uint32_t split_on = prm->report_mems ? 0u : 1u;
+    rec(c, EV_MC0);
+    if (n_tasks)
+        hipLaunchKernelGGL(mem_kernel<false>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, c->seq.p, c->offs.p,
+                           n_tasks, c->ptr.p, prm->min_len, split_on, c->cnt_m.p, c->cnt_s.p, (const uint64_t*)nullptr,
+                           (moni_mem_t*)nullptr, (uint32_t*)nullptr, c->d_counters);
+    rec(c, EV_MC1);
+    hipLaunchKernelGGL(read_totals_kernel, dim3((unsigned)((nr + 1 + 255) / 256)), dim3(256), 0, c->stream, c->cnt_m.p, c->cnt_s.p, nr, c->tot.p);
+    if ((rc = exclusive_scan_u64(c, c->tot.p, c->read_mem_off.p, nr + 1))) return rc;
+    uint64_t n_mems = 0;
+    HIPCHK(hipMemcpyAsync(&n_mems, c->read_mem_off.p + nr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->n_mems = n_mems;
+    c->tmp_cap = 16;
+    if ((rc = c->mems.ensure(n_mems + 1)) || (rc = c->aux.ensure(n_mems + 1)) || (rc = c->lowers.ensure(n_mems + 1)) ||
+        (rc = c->tmp.ensure(n_mems * c->tmp_cap + 1)) || (rc = c->occ_cnt.ensure(n_mems + 2)) || (rc = c->occ_off.ensure(n_mems + 2)) ||
+        (rc = c->pool.ensure((size_t)c->pool_rows * I->K.n_seq + 1)))
+        return rc;
+    rec(c, EV_ME0);
+    if (n_tasks)
+        hipLaunchKernelGGL(mem_kernel<true>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, c->seq.p, c->offs.p,
+                           n_tasks, c->ptr.p, prm->min_len, split_on, c->cnt_m.p, c->cnt_s.p, c->read_mem_off.p, c->mems.p, c->aux.p,
+                           c->d_counters);
+    rec(c, EV_ME1);
+    occ_args_t A;
+    A.phi.recs = I->d_phi; A.phi.dir = I->d_phi_dir; A.phi_inv.recs = I->d_phi_inv; A.phi_inv.dir = I->d_phi_inv_dir;
+    A.seq_starts = I->d_seq_starts; A.name_id = I->d_name_id; A.mems = c->mems.p; A.aux = c->aux.p; A.read_mem_off = c->read_mem_off.p;
+    A.n_mems = n_mems; A.occs = nullptr; A.tmp = c->tmp.p; A.lowers = c->lowers.p; A.tmp_cap = c->tmp_cap;
+    A.filter_seeds = prm->filter_seeds; A.n_seeds_thr = prm->n_seeds_thr; A.pool_rows = c->pool_rows; A.pool = c->pool.p;
+    A.pool_next = c->d_small; A.error_flag = c->d_small + 1; A.counters = c->d_counters;
+    const unsigned grid_m = (unsigned)((n_mems + MS_BLOCK - 1) / MS_BLOCK);
+    rec(c, EV_PC0);
+    if (n_mems) hipLaunchKernelGGL(occ_kernel<false>, dim3(grid_m), dim3(MS_BLOCK), 0, c->stream, I->K, A);
+    rec(c, EV_PC1);
+    hipLaunchKernelGGL(occ_cnt_gather_kernel, dim3((unsigned)((n_mems + 1 + 255) / 256)), dim3(256), 0, c->stream, c->mems.p, n_mems, c->occ_cnt.p);
+    if ((rc = exclusive_scan_u64(c, c->occ_cnt.p, c->occ_off.p, n_mems + 1))) return rc;
+    if (n_mems) hipLaunchKernelGGL(occ_off_scatter_kernel, dim3(grid_m), dim3(256), 0, c->stream, c->mems.p, n_mems, c->occ_off.p);
+    uint64_t n_occs = 0;
+    uint32_t small[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&n_occs, c->occ_off.p + n_mems, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(small, c->d_small, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (small[1]) { fprintf(stderr, "moni_hip: per-genome counter pool exhausted (%u rows)\n", c->pool_rows); return MONI_ENOMEM; }
+    c->n_occs = n_occs;
+    if ((rc = c->occs.ensure(n_occs + 1))) return rc;
+    A.occs = c->occs.p;
+    HIPCHK(hipMemsetAsync(c->d_small, 0, 16, c->stream));
+    rec(c, EV_PE0);
+    if (n_mems) hipLaunchKernelGGL(occ_kernel<true>, dim3(grid_m), dim3(MS_BLOCK), 0, c->stream, I->K, A);
+    rec(c, EV_PE1);
+    rec(c, EV_ALL1);
+    HIPCHK(hipMemcpyAsync(small, c->d_small, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    if (small[1]) { fprintf(stderr, "moni_hip: per-genome counter pool exhausted (%u rows)\n", c->pool_rows); return MONI_ENOMEM; }
+    return MONI_OK;
+}
+
+int moni_seed_counts(moni_ctx_t* c, uint64_t* n_mems, uint64_t* n_occs) {
+    if (!c) return MONI_EINVAL;
+    if (n_mems) *n_mems = c->n_mems;
+    if (n_occs) *n_occs = c->n_occs;
+    return MONI_OK;
+}
+
+int moni_seed_fetch(moni_ctx_t* c, moni_mem_t* mems, uint64_t* occs, uint64_t* read_mem_off) {
+    if (!c) return MONI_EINVAL;
+    HIPCHK(hipSetDevice(c->idx->device));
+    if (mems && c->n_mems) HIPCHK(hipMemcpy(mems, c->mems.p, c->n_mems * sizeof(moni_mem_t), hipMemcpyDeviceToHost));
+    if (occs && c->n_occs) HIPCHK(hipMemcpy(occs, c->occs.p, c->n_occs * 8, hipMemcpyDeviceToHost));
+    if (read_mem_off) HIPCHK(hipMemcpy(read_mem_off, c->read_mem_off.p, (c->n_reads + 1) * 8, hipMemcpyDeviceToHost));
+    return MONI_OK;
+}
+
+int moni_seed_batch(moni_ctx_t* c, const moni_read_batch_t* b, const moni_seed_params_t* prm, moni_mem_t** mems, uint64_t* n_mems,
+                    uint64_t** occs, uint64_t* n_occs, uint64_t** read_mem_off) {
+    if (!mems || !n_mems || !occs || !n_occs || !read_mem_off) return MONI_EINVAL;
+    int rc = moni_reads_upload(c, b);
+    if (rc) return rc;
+    if ((rc = moni_seed_run(c, prm))) return rc;
+    *n_mems = c->n_mems; *n_occs = c->n_occs;
+    *mems = (moni_mem_t*)malloc((c->n_mems + 1) * sizeof(moni_mem_t));
+    *occs = (uint64_t*)malloc((c->n_occs + 1) * 8);
+    *read_mem_off = (uint64_t*)malloc((c->n_reads + 1) * 8);
+    if (!*mems || !*occs || !*read_mem_off) return MONI_ENOMEM;
+    return moni_seed_fetch(c, *mems, *occs, *read_mem_off);
+}
+
+void moni_free(void* p) { free(p); }
+
+int moni_phi_lcp_batch(moni_ctx_t* c, const uint64_t* pos, uint64_t n, int inverse, uint64_t* out_pos, uint64_t* out_lcp) {
+    if (!c || (n && (!pos || !out_pos || !out_lcp))) return MONI_EINVAL;
+    moni_index* I = c->idx;
+    HIPCHK(hipSetDevice(I->device));
+    if (!n) return MONI_OK;
+    uint64_t* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, 3 * n * 8));
+    HIPCHK(hipMemcpy(d, pos, n * 8, hipMemcpyHostToDevice));
+    phi_tab_t P;
+    P.recs = inverse ? I->d_phi_inv : I->d_phi;
+    P.dir = inverse ? I->d_phi_inv_dir : I->d_phi_dir;
+    hipLaunchKernelGGL(phi_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, I->K, P, d, n, d + n, d + 2 * n);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out_pos, d + n, n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_lcp, d + 2 * n, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return MONI_OK;
+}
+
+int moni_last_kernel_ms(moni_ctx_t* c, int which, float* ms) {
+    if (!c || !ms || which < 0 || which > 6) return MONI_EINVAL;
+    const int a = which == 6 ? EV_ALL0 : 2 * which, b = a + 1;
+    if (!c->ev_valid[a] || !c->ev_valid[b]) return MONI_EINVAL;
+    HIPCHK(hipEventSynchronize(c->ev[b]));
+    HIPCHK(hipEventElapsedTime(ms, c->ev[a], c->ev[b]));
+    return MONI_OK;
+}
+
+int moni_last_counters(moni_ctx_t* c, uint64_t out[4]) {
+    if (!c || !out) return MONI_EINVAL;
+    HIPCHK(hipSetDevice(c->idx->device));
+    unsigned long long h[4];
+    HIPCHK(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out[i] = h[i];
+    return MONI_OK;
+}
+
+#include "extz_host.inc"
+
+}  // extern "C"

@@ -1,0 +1,370 @@
+// Per-lane logic of the seeding kernels, written once and compiled twice: as __device__ code inside
+// seed_kernels.hip (the product), and as plain host C++ by tests/host_sim.cpp, which replays the
+// same functions lane by lane over the host copy of the index image so that the layout and the step
+// logic can be checked against the oracle without a GPU.  The host build exists only under tests/.
+//
+//   ms_task    ms_pointers::_query            include/ms/moni.hpp:568-624
+//   mem_task   seed_finder::find_mems         include/aligner/seed_finder.hpp:126-166
+//   occ_task   seed_finder::populate_seed(s)  include/aligner/seed_finder.hpp:169-343, 377-393
+//              + moni_lcp::Phi_lcp/Phi_inv_lcp include/aligner/moni_lcp.hpp:230-272
+#pragma once
+#include <stdint.h>
+
+#include "../../include/moni_hip.h"
+#include "layout.h"
+
+#if defined(__HIPCC__)
+#define MONI_HD __host__ __device__ __forceinline__
+#else
+#define MONI_HD inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MONI_ATOMIC_INC_U32(p) atomicAdd((p), 1u)
+#define MONI_FLAG_SET(p) atomicExch((p), 1u)
+#else
+#define MONI_ATOMIC_INC_U32(p) ((*(p))++)
+#define MONI_FLAG_SET(p) (*(p) = 1u)
+#endif
+
+struct alignas(16) moni_u64x2 { uint64_t x, y; };
+struct alignas(32) moni_u64x4 { uint64_t x, y, z, w; };
+
+struct lds_tables_t {
+    uint8_t code[256];
+    uint8_t compl_tab[256];
+    uint32_t abs_run[256];
+    uint64_t abs_pos[256];
+};
+
+MONI_HD uint64_t row_start(const moni_row_t& x) { return x.w0 & MONI_POS_MASK; }
+MONI_HD uint32_t row_head(const moni_row_t& x) { return (uint32_t)(x.w0 >> 40) & 15u; }
+MONI_HD uint64_t row_lfbase(const moni_row_t& x) { return x.w1 & MONI_POS_MASK; }
+MONI_HD uint32_t row_dest(const moni_row_t& x) { return (uint32_t)((x.w0 >> 44) << 24) | (uint32_t)(x.w1 >> 40); }
+
+MONI_HD moni_row_t ld_row(const moni_row_t* __restrict__ rows, uint32_t k) {
+    const moni_u64x2 v = *reinterpret_cast<const moni_u64x2*>(rows + k);
+    moni_row_t x; x.w0 = v.x; x.w1 = v.y; return x;
+}
+
+// Find the run with start[run] <= pos < start[run+1], starting from a guess.  The guess is the
+// destination run of the LF mapping, so the answer is normally the guess or its neighbour; a
+// galloping search bounds the cost when a long run maps onto many short ones.
+MONI_HD void settle_run(const moni_row_t* __restrict__ rows, uint64_t r, uint64_t pos, uint32_t& run, moni_row_t& A) {
+    A = ld_row(rows, run);
+    if (pos < row_start(A)) {          // a jump up lands on lfpos-1, possibly the run before the stored one
+        uint32_t step = 1;
+        uint32_t hi = run;             // start[hi] > pos
+        uint32_t lo = run >= step ? run - step : 0;
+        while (lo > 0 && (rows[lo].w0 & MONI_POS_MASK) > pos) { hi = lo; step <<= 1; lo = lo >= step ? lo - step : 0; }
+        while (hi - lo > 1) { uint32_t mid = lo + ((hi - lo) >> 1); if ((rows[mid].w0 & MONI_POS_MASK) <= pos) lo = mid; else hi = mid; }
+        run = lo; A = ld_row(rows, run);
+        return;
+    }
+    moni_row_t B = ld_row(rows, run + 1);
+    int lin = 0;
+    while (pos >= row_start(B)) {
+        if (++lin > 3) {
+            uint32_t lo = run + 1;     // start[lo] <= pos
+            uint32_t step = 4;
+            uint32_t hi = lo + step;
+            const uint32_t top = (uint32_t)r + 1;   // start[r+1] = 2^40-1 > any pos
+            while (true) { if (hi > top) hi = top; if ((rows[hi].w0 & MONI_POS_MASK) > pos) break; lo = hi; step <<= 1; hi = lo + step; }
+            while (hi - lo > 1) { uint32_t mid = lo + ((hi - lo) >> 1); if ((rows[mid].w0 & MONI_POS_MASK) <= pos) lo = mid; else hi = mid; }
+            run = lo; A = ld_row(rows, run);
+            return;
+        }
+        ++run; A = B; B = ld_row(rows, run + 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ms_task: pointers[s * n_tasks + task] = sample after step s, i.e. ms_pointers[m-1-s];  task = 2*read + strand
+// ------------------------------------------------------------------------------------------------
+MONI_HD void ms_task(const moni_consts_t& K, const lds_tables_t& L, const moni_row_t* __restrict__ rows,
+                     const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs, const uint8_t* __restrict__ seq,
+                     const uint64_t* __restrict__ offs, uint64_t n_tasks, uint64_t task, uint64_t* __restrict__ ptr_out,
+                     unsigned long long& n_steps, unsigned long long& n_jumps) {
+    const uint64_t read = task >> 1;
+    const uint32_t strand = (uint32_t)task & 1u;
+    const uint64_t off = offs[read];
+    const uint32_t m = (uint32_t)(offs[read + 1] - off);
+    uint32_t run = (uint32_t)K.r - 1;
+    uint64_t pos = K.n - 1;
+    uint64_t sample = K.last_run_sample;
+    const uint32_t sigma = K.sigma;
+    for (uint32_t s = 0; s < m; ++s) {
+        // pattern[m-1-s]: the forward strand reads seq backwards, the reverse complement reads it forwards
+        const uint8_t raw = strand ? L.compl_tab[seq[off + s]] : seq[off + (m - 1 - s)];
+        const uint32_t c = L.code[raw];
+        if (c == MONI_CODE_ABSENT) {                     // n_c == 0   (moni.hpp:583-588)
+            sample = 0;
+            pos = L.abs_pos[raw];
+            run = L.abs_run[raw];
+        } else {
+            moni_row_t A;
+            settle_run(rows, K.r, pos, run, A);
+            if (row_head(A) == c) {                      // bwt[pos] == c  (moni.hpp:589-594); the sentinel head never matches
+                sample--;
+                pos = row_lfbase(A) + (pos - row_start(A));
+                run = row_dest(A);
+            } else {                                     // threshold jump (moni.hpp:595-618)
+                ++n_jumps;
+                const uint32_t j = cr[(uint64_t)run * sigma + c];
+                const moni_u64x4 rv = *reinterpret_cast<const moni_u64x4*>(recs + K.rec_base[c] + j);
+                const uint64_t thr = rv.x & MONI_POS_MASK;
+                const uint32_t d = (uint32_t)((rv.x >> 40) << 24) | (uint32_t)(rv.y >> 40);
+                // rnk_c.first > thresholds.rank(pos+1, c)  <=>  j >= 1 and (no c-run below, or pos < thr_j)
+                const bool up = j > 0 && (j == K.rec_cnt[c] || pos < thr);
+                if (up) { sample = rv.z; pos = rv.w - 1; }
+                else { sample = rv.y & MONI_POS_MASK; pos = rv.w; }
+                run = d;
+            }
+        }
+        ptr_out[(uint64_t)s * n_tasks + task] = sample;
+    }
+    n_steps += m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mem_task<EMIT>: the forward text-comparison loop of find_mems.
+//   EMIT = false: cnt_m[task] = number of MEMs, cnt_s[task] = number of MEMs that will be split in halves
+//   EMIT = true : writes the MEM (and the fixed fields of its two halves) to its final slot.
+// Final order per read (seed_finder.hpp:311-318 with aligner_ksw2.hpp:333-337): forward MEMs, reverse-
+// complement MEMs, then for every MEM in that order [left half, right half] if len >= 2*min_len.
+// aux[g]: 0xFFFFFFFF plain MEM, 0xFFFFFFFE left half, 0xFFFFFFFD right half, else offset of the MEM's halves
+// from the read's first slot.
+// ------------------------------------------------------------------------------------------------
+template <bool EMIT>
+MONI_HD void mem_task(const moni_consts_t& K, const lds_tables_t& L, const uint8_t* __restrict__ text,
+                      const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t n_tasks, uint64_t task,
+                      const uint64_t* __restrict__ ptr, uint32_t min_len, uint32_t split_on, uint32_t* __restrict__ cnt_m,
+                      uint32_t* __restrict__ cnt_s, const uint64_t* __restrict__ read_mem_off, moni_mem_t* __restrict__ mems,
+                      uint32_t* __restrict__ aux, unsigned long long& n_cmp) {
+    const uint64_t read = task >> 1;
+    const uint32_t strand = (uint32_t)task & 1u;
+    const uint64_t off = offs[read];
+    const uint32_t m = (uint32_t)(offs[read + 1] - off);
+    const uint64_t n = K.n_text;                       // seed_finder::n = ra.getLen()
+    uint64_t l = 0, pl = 0, n_Ns = 0;
+    uint64_t prev_pos_plus_one = n + 1;
+    uint32_t km = 0, ks = 0;
+    uint64_t base = 0, k_read = 0, j0 = 0, s0 = 0;
+    if (EMIT) {
+        base = read_mem_off[read];
+        k_read = (uint64_t)cnt_m[2 * read] + cnt_m[2 * read + 1];
+        if (strand) { j0 = cnt_m[2 * read]; s0 = cnt_s[2 * read]; }
+    }
+    for (uint32_t i = 0; i < m; ++i) {
+        const uint64_t pos = ptr[(uint64_t)(m - 1 - i) * n_tasks + task];
+        while (pos != prev_pos_plus_one && (i + l) < m && (pos + l) < n) {
+            const uint32_t qi = (uint32_t)(i + l);
+            const uint8_t qc = strand ? L.compl_tab[seq[off + (m - 1 - qi)]] : seq[off + qi];
+            ++n_cmp;
+            if (qc != text[pos + l]) break;
+            if (qc == 'N') n_Ns++; else n_Ns = 0;
+            ++l;
+        }
+        if (l >= pl && n_Ns < l && l >= min_len) {
+            const bool split = split_on && l >= ((uint64_t)min_len << 1);
+            if (EMIT) {
+                const uint64_t g = base + j0 + km;
+                moni_mem_t M;
+                M.pos = pos; M.len = (uint32_t)l; M.idx = i; M.rpos = (uint32_t)(i + l - 1); M.mate = strand ? 2u : 0u;
+                M.total_occ = 0; M.num_filtered = 0; M.occ_off = 0; M.occ_cnt = 0; M.read = (uint32_t)read;
+                mems[g] = M;
+                if (split) {
+                    const uint64_t hb = base + k_read + 2 * (s0 + ks);
+                    const uint32_t ll = (uint32_t)(l >> 1);
+                    moni_mem_t B = M;                    // left half: pos is the parent's upper suffix (occ_task)
+                    B.pos = 0; B.len = ll; B.rpos = (uint32_t)((i + l - 1) - l + ll);
+                    mems[hb] = B;
+                    moni_mem_t C = M;                    // right half (seed_finder.hpp:296-298)
+                    C.pos = pos + ll; C.len = (uint32_t)(l - ll); C.idx = i + ll;
+                    mems[hb + 1] = C;
+                    aux[g] = (uint32_t)(hb - base);
+                    aux[hb] = 0xFFFFFFFEu;
+                    aux[hb + 1] = 0xFFFFFFFDu;
+                } else {
+                    aux[g] = 0xFFFFFFFFu;
+                }
+            }
+            ++km;
+            if (split) ++ks;
+        }
+        pl = l;
+        l = (l == 0 ? 0 : (l - 1));
+        prev_pos_plus_one = pos + 1;
+    }
+    if (!EMIT) { cnt_m[task] = km; cnt_s[task] = ks; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// phi
+// ------------------------------------------------------------------------------------------------
+struct phi_tab_t {
+    const moni_phi_t* recs;
+    const uint32_t* dir;
+};
+
+MONI_HD void phi_step(const phi_tab_t P, const moni_consts_t& K, uint64_t i, uint64_t& out_pos, uint64_t& out_lcp) {
+    const uint64_t slot = i >> K.phi_shift;
+    uint32_t lo = P.dir[slot], hi = P.dir[slot + 1];
+    while (lo < hi) {                                   // rank(i) = number of keys < i
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((P.recs[mid].w0 & MONI_POS_MASK) < i) lo = mid + 1; else hi = mid;
+    }
+    const uint32_t jr = lo ? lo - 1 : (uint32_t)K.r - 1;   // predecessor_rank_circular
+    const moni_u64x2 v = *reinterpret_cast<const moni_u64x2*>(P.recs + jr);
+    const uint64_t j = v.x & MONI_POS_MASK;
+    const uint64_t delta = j < i ? i - j : i + 1;
+    const uint64_t prev = v.y & MONI_POS_MASK;
+    const uint64_t lcp = (v.x >> 40) | ((v.y >> 40) << 24);
+    uint64_t p = prev + delta;
+    if (p >= K.n) p -= K.n;                             // (prev_sample + delta) % n
+    if (p >= K.n) p %= K.n;
+    out_pos = p;
+    out_lcp = lcp - delta + 1;                          // unsigned, as in the reference
+}
+
+struct occ_args_t {
+    phi_tab_t phi, phi_inv;
+    const uint64_t* seq_starts;     // n_seq + 1
+    const uint32_t* name_id;        // n_seq
+    moni_mem_t* mems;
+    const uint32_t* aux;
+    const uint64_t* read_mem_off;
+    uint64_t n_mems;
+    uint64_t* occs;                 // FILL: final occurrence array
+    uint64_t* tmp;                  // COUNT: first tmp_cap occurrences per seed; FILL: source for short lists
+    uint64_t* lowers;               // lower suffix of every left half's parent (seed_finder.hpp:276)
+    uint32_t tmp_cap;
+    uint32_t filter_seeds;
+    uint32_t n_seeds_thr;
+    uint32_t pool_rows;             // per-name counter rows available
+    uint32_t* pool;                 // pool_rows * n_seq counters
+    uint32_t* pool_next;            // bump allocator
+    uint32_t* error_flag;
+    unsigned long long* counters;
+};
+
+struct walk_t {
+    uint64_t total, filtered, kept;
+    uint64_t last_kept;             // occs.back()
+    uint32_t* names;                // per-name counters or nullptr
+    uint64_t* out;                  // destination for kept occurrences or nullptr
+    uint64_t out_cap;
+    unsigned long long phi_steps;
+};
+
+MONI_HD uint32_t seq_of(const uint64_t* __restrict__ seq_starts, uint32_t n_seq, uint64_t pos) {
+    // rank1(pos + 1) - 1  (seqidx.hpp:136-139): number of onsets <= pos, minus one
+    uint32_t lo = 0, hi = n_seq + 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (seq_starts[mid] <= pos) lo = mid + 1; else hi = mid; }
+    uint32_t k = lo ? lo - 1 : 0;
+    return k < n_seq ? k : n_seq - 1;
+}
+
+// one occurrence (seed_finder.hpp:182-193 / 246-248): count it, apply the per-genome filter, keep or drop
+MONI_HD void walk_push(walk_t& W, const occ_args_t& A, const moni_consts_t& K, uint64_t pos, bool first) {
+    bool keep = true;
+    if (W.names) {
+        const uint32_t id = A.name_id[seq_of(A.seq_starts, K.n_seq, pos)];
+        const uint32_t c = ++W.names[id];
+        if (!first && A.filter_seeds && c > A.n_seeds_thr) keep = false;
+    }
+    W.total++;
+    if (keep) {
+        if (W.out && W.kept < W.out_cap) W.out[W.kept] = pos;
+        W.kept++;
+        W.last_kept = pos;
+    } else W.filtered++;
+}
+
+// find_MEM_above / find_MEM_below (seed_finder.hpp:169-239 with the guards of 377-393)
+template <bool ABOVE>
+MONI_HD void walk_dir(walk_t& W, const occ_args_t& A, const moni_consts_t& K, uint64_t curr, uint64_t len) {
+    while (true) {
+        uint64_t nxt, lcp;
+        if (ABOVE) {
+            if (curr == K.first_run_sample) break;              // returns {last_run_sample, 0}: 0 >= len is false
+            phi_step(A.phi, K, curr, nxt, lcp);
+        } else {
+            if (curr == K.last_run_sample) break;
+            phi_step(A.phi_inv, K, curr, nxt, lcp);
+        }
+        W.phi_steps++;
+        if (!(lcp >= len)) break;
+        walk_push(W, A, K, nxt, false);
+        curr = nxt;
+    }
+}
+
+// [first_pos] + above(above_from) + below(below_from); full MEMs and right halves pass the same position three
+// times (find_MEM_occs), left halves pass (upper, upper, lower) (seed_finder.hpp:283-290).
+MONI_HD void walk_seed(walk_t& W, const occ_args_t& A, const moni_consts_t& K, uint64_t first_pos, uint64_t above_from,
+                       uint64_t below_from, uint64_t len, uint64_t& upper, uint64_t& lower) {
+    walk_push(W, A, K, first_pos, true);
+    walk_dir<true>(W, A, K, above_from, len);
+    upper = W.last_kept;
+    walk_dir<false>(W, A, K, below_from, len);
+    lower = W.last_kept;
+}
+
+// A walk can only lose occurrences to the per-genome filter when it sees more than n_seeds_thr of them in
+// total; only then is it redone with per-name counters taken from the pool.
+MONI_HD void run_seed(const occ_args_t& A, const moni_consts_t& K, uint64_t first_pos, uint64_t above_from, uint64_t below_from,
+                      uint64_t len, uint64_t* out, uint64_t out_cap, walk_t& W, uint64_t& upper, uint64_t& lower) {
+    W.total = W.filtered = W.kept = 0; W.last_kept = first_pos; W.names = nullptr; W.out = out; W.out_cap = out_cap;
+    walk_seed(W, A, K, first_pos, above_from, below_from, len, upper, lower);
+    if (A.filter_seeds && W.total > A.n_seeds_thr) {
+        const uint32_t row = MONI_ATOMIC_INC_U32(A.pool_next);
+        if (row >= A.pool_rows) { MONI_FLAG_SET(A.error_flag); return; }
+        uint32_t* names = A.pool + (uint64_t)row * K.n_seq;
+        for (uint32_t i = 0; i < K.n_seq; ++i) names[i] = 0;
+        const unsigned long long ps = W.phi_steps;
+        W.total = W.filtered = W.kept = 0; W.last_kept = first_pos; W.names = names;
+        walk_seed(W, A, K, first_pos, above_from, below_from, len, upper, lower);
+        W.phi_steps = ps;                                  // count the reference's walk once
+    }
+}
+
+// occ_task<FILL>: one lane per final MEM slot.  A full MEM's lane also walks its left half (which starts
+// from the MEM's upper/lower suffix); right halves have their own lane.
+//   FILL = false: fills total_occ / num_filtered / occ_cnt (+ left-half pos, lower suffix) and keeps the
+//                 first tmp_cap occurrences of every seed in tmp.
+//   FILL = true : writes occurrences at occ_off (from tmp when the list fits, otherwise by walking again).
+template <bool FILL>
+MONI_HD void occ_task(const moni_consts_t& K, const occ_args_t& A, uint64_t g, unsigned long long& phi_steps) {
+    const uint32_t ax = A.aux[g];
+    if (ax == 0xFFFFFFFEu) return;                         // left halves ride with their parent
+    const moni_mem_t M = A.mems[g];
+    walk_t W; W.phi_steps = 0;
+    uint64_t upper = 0, lower = 0;
+    if (!FILL) {
+        run_seed(A, K, M.pos, M.pos, M.pos, M.len, A.tmp + g * A.tmp_cap, A.tmp_cap, W, upper, lower);
+        A.mems[g].total_occ = (uint32_t)W.total; A.mems[g].num_filtered = (uint32_t)W.filtered; A.mems[g].occ_cnt = (uint32_t)W.kept;
+    } else if (M.occ_cnt <= A.tmp_cap) {
+        for (uint32_t i = 0; i < M.occ_cnt; ++i) A.occs[M.occ_off + i] = A.tmp[g * A.tmp_cap + i];
+    } else {
+        run_seed(A, K, M.pos, M.pos, M.pos, M.len, A.occs + M.occ_off, M.occ_cnt, W, upper, lower);
+    }
+    if (ax < 0xFFFFFFFDu) {                                // this MEM has halves: its left half is walked here
+        const uint64_t hb = A.read_mem_off[M.read] + ax;
+        const moni_mem_t Bm = A.mems[hb];
+        walk_t WB; WB.phi_steps = 0;
+        uint64_t u2, l2;
+        if (!FILL) {
+            run_seed(A, K, upper, upper, lower, Bm.len, A.tmp + hb * A.tmp_cap, A.tmp_cap, WB, u2, l2);
+            A.mems[hb].pos = upper;
+            A.mems[hb].total_occ = (uint32_t)WB.total; A.mems[hb].num_filtered = (uint32_t)WB.filtered; A.mems[hb].occ_cnt = (uint32_t)WB.kept;
+            A.lowers[hb] = lower;
+            W.phi_steps += WB.phi_steps;
+        } else if (Bm.occ_cnt <= A.tmp_cap) {
+            for (uint32_t i = 0; i < Bm.occ_cnt; ++i) A.occs[Bm.occ_off + i] = A.tmp[hb * A.tmp_cap + i];
+        } else {
+            run_seed(A, K, Bm.pos, Bm.pos, A.lowers[hb], Bm.len, A.occs + Bm.occ_off, Bm.occ_cnt, WB, u2, l2);
+        }
+    }
+    phi_steps += W.phi_steps;
+}

@@ -1,0 +1,94 @@
+// HIP kernels (gfx950) for the seeding half of the hot path; the per-lane logic is in seed_core.h.
+//
+// Mapping: one LANE per (read, strand) for the LF / MEM loops and one lane per MEM for the phi walks.
+// Every step is a dependent random access into a multi-GB table, so the only parallelism is across
+// reads; 64 independent reads per wavefront keep 64 row fetches in flight per wave instruction
+// (a wave-per-read mapping keeps one), and the per-step state is a handful of registers so every
+// SIMD runs 8 waves.  Tables are laid out so that a step reads one or two adjacent 16-byte rows
+// (layout.h).  Byte tables live in LDS.  Integer/indexing work only: no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "seed_core.h"
+
+#define MS_BLOCK 256
+
+__device__ __forceinline__ void load_tables(lds_tables_t& L, const moni_tables_t* __restrict__ T) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        L.code[i] = T->code[i];
+        L.compl_tab[i] = T->compl_tab[i];
+        L.abs_run[i] = T->abs_run[i];
+        L.abs_pos[i] = T->abs_pos[i];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void wave_add(unsigned long long v, unsigned long long* dst) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+}
+
+extern "C" __global__ void __launch_bounds__(MS_BLOCK)
+ms_lf_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const moni_row_t* __restrict__ rows,
+             const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs,
+             const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t n_tasks,
+             uint64_t* __restrict__ ptr_out, unsigned long long* __restrict__ counters) {
+    __shared__ lds_tables_t L;
+    load_tables(L, T);
+    const uint64_t task = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
+    unsigned long long n_steps = 0, n_jumps = 0;
+    if (task < n_tasks) ms_task(K, L, rows, cr, recs, seq, offs, n_tasks, task, ptr_out, n_steps, n_jumps);
+    wave_add(n_steps, &counters[0]);
+    wave_add(n_jumps, &counters[1]);
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(MS_BLOCK)
+mem_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const uint8_t* __restrict__ text,
+           const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t n_tasks,
+           const uint64_t* __restrict__ ptr, uint32_t min_len, uint32_t split_on,
+           uint32_t* __restrict__ cnt_m, uint32_t* __restrict__ cnt_s,
+           const uint64_t* __restrict__ read_mem_off, moni_mem_t* __restrict__ mems, uint32_t* __restrict__ aux,
+           unsigned long long* __restrict__ counters) {
+    __shared__ lds_tables_t L;
+    load_tables(L, T);
+    const uint64_t task = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
+    unsigned long long n_cmp = 0;
+    if (task < n_tasks)
+        mem_task<EMIT>(K, L, text, seq, offs, n_tasks, task, ptr, min_len, split_on, cnt_m, cnt_s, read_mem_off, mems, aux, n_cmp);
+    if (!EMIT) wave_add(n_cmp, &counters[3]);
+}
+
+// per-read final MEM count (orig + 2 * split)
+extern "C" __global__ void read_totals_kernel(const uint32_t* __restrict__ cnt_m, const uint32_t* __restrict__ cnt_s,
+                                              uint64_t n_reads, uint64_t* __restrict__ tot) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_reads) tot[r] = (uint64_t)cnt_m[2 * r] + cnt_m[2 * r + 1] + 2ull * ((uint64_t)cnt_s[2 * r] + cnt_s[2 * r + 1]);
+    if (r == n_reads) tot[r] = 0;
+}
+
+extern "C" __global__ void phi_batch_kernel(const moni_consts_t K, phi_tab_t P, const uint64_t* __restrict__ pos, uint64_t n,
+                                            uint64_t* __restrict__ out_pos, uint64_t* __restrict__ out_lcp) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) { uint64_t a, b; phi_step(P, K, pos[t], a, b); out_pos[t] = a; out_lcp[t] = b; }
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(MS_BLOCK)
+occ_kernel(const moni_consts_t K, occ_args_t A) {
+    const uint64_t g = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
+    unsigned long long phi_steps = 0;
+    if (g < A.n_mems) occ_task<FILL>(K, A, g, phi_steps);
+    if (!FILL) wave_add(phi_steps, &A.counters[2]);
+}
+
+// gather occ_cnt into a u64 array for the scan, and scatter the scanned offsets back
+extern "C" __global__ void occ_cnt_gather_kernel(const moni_mem_t* __restrict__ mems, uint64_t n, uint64_t* __restrict__ cnt) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) cnt[g] = mems[g].occ_cnt;
+    if (g == n) cnt[g] = 0;
+}
+extern "C" __global__ void occ_off_scatter_kernel(moni_mem_t* __restrict__ mems, uint64_t n, const uint64_t* __restrict__ off) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) mems[g].occ_off = off[g];
+}

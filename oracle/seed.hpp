@@ -80,10 +80,10 @@ struct seed_finder {
         size_t prev_pos_plus_one = n + 1;
         for (size_t i = 0; i < pointers.size(); ++i) {
             size_t pos = pointers[i];
-            while (pos != prev_pos_plus_one && (i + l) < seq_l && (pos + l) < n && (uint8_t)seq[i + l] == ix.text[pos + l]) {
+            // cnt.text_cmp counts every ra.charAt() the reference's loop condition evaluates (matches and the final mismatch)
+            while (pos != prev_pos_plus_one && (i + l) < seq_l && (pos + l) < n && (++cnt.text_cmp, (uint8_t)seq[i + l] == ix.text[pos + l])) {
                 if (seq[i + l] == 'N') n_Ns++; else n_Ns = 0;
                 ++l;
-                cnt.text_cmp++;
             }
             if (l >= pl and n_Ns < l and l >= min_len) {
                 size_t r = r_offset + (i + l - 1);

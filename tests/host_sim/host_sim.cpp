@@ -1,0 +1,122 @@
+// TEST HARNESS ONLY — not part of the product, never linked into libmoni_hip.so.
+// Replays the per-lane functions of moni_align_amd/csrc/seed_core.h (the code the HIP kernels run)
+// sequentially on the host over the host copy of the index image, with the same orchestration as
+// moni_seed_run, so that the device layout and step logic can be checked against the oracle on a
+// machine without a GPU.  The GPU tests (-m gpu) check the real kernels through the C ABI.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../moni_align_amd/csrc/image.hpp"
+#include "../../moni_align_amd/csrc/seed_core.h"
+
+struct Sim {
+    HostImage img;
+    std::vector<uint8_t> text;
+    std::vector<uint32_t> name_id;
+    lds_tables_t L;
+    // last result
+    std::vector<uint64_t> ptr;
+    std::vector<moni_mem_t> mems;
+    std::vector<uint64_t> occs, read_mem_off;
+    uint64_t counters[4];
+    uint64_t max_len = 0, n_reads = 0;
+};
+
+extern "C" {
+
+void* sim_create(const moni_flat_index_t* f) {
+    Sim* S = new Sim();
+    if (S->img.build(*f)) { fprintf(stderr, "host_sim: %s\n", S->img.err.c_str()); delete S; return nullptr; }
+    S->text.assign(f->text, f->text + f->n - 1);
+    S->name_id.resize(f->n_seq);
+    for (uint64_t i = 0; i < f->n_seq; ++i) S->name_id[i] = (uint32_t)i;
+    memcpy(S->L.code, S->img.T.code, 256);
+    memcpy(S->L.compl_tab, S->img.T.compl_tab, 256);
+    memcpy(S->L.abs_run, S->img.T.abs_run, sizeof(S->L.abs_run));
+    memcpy(S->L.abs_pos, S->img.T.abs_pos, sizeof(S->L.abs_pos));
+    return S;
+}
+void sim_destroy(void* s) { delete (Sim*)s; }
+
+int sim_seed_run(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_reads, const moni_seed_params_t* prm,
+                 uint32_t tmp_cap, uint32_t pool_rows) {
+    Sim* S = (Sim*)s;
+    const moni_consts_t& K = S->img.K;
+    const uint64_t n_tasks = 2 * n_reads;
+    uint64_t mx = 0;
+    for (uint64_t i = 0; i < n_reads; ++i) mx = std::max<uint64_t>(mx, offs[i + 1] - offs[i]);
+    S->max_len = mx; S->n_reads = n_reads;
+    S->ptr.assign(n_tasks * mx + 1, 0);
+    unsigned long long cnt[4] = {0, 0, 0, 0};
+    for (uint64_t t = 0; t < n_tasks; ++t)
+        ms_task(K, S->L, S->img.rows.data(), S->img.cr.data(), S->img.recs.data(), seq, offs, n_tasks, t, S->ptr.data(), cnt[0], cnt[1]);
+    std::vector<uint32_t> cnt_m(n_tasks + 1), cnt_s(n_tasks + 1);
+    const uint32_t split_on = prm->report_mems ? 0 : 1;
+    for (uint64_t t = 0; t < n_tasks; ++t)
+        mem_task<false>(K, S->L, S->text.data(), seq, offs, n_tasks, t, S->ptr.data(), prm->min_len, split_on, cnt_m.data(), cnt_s.data(),
+                        nullptr, nullptr, nullptr, cnt[3]);
+    S->read_mem_off.assign(n_reads + 1, 0);
+    for (uint64_t r = 0; r < n_reads; ++r)
+        S->read_mem_off[r + 1] = S->read_mem_off[r] + cnt_m[2 * r] + cnt_m[2 * r + 1] + 2ull * (cnt_s[2 * r] + cnt_s[2 * r + 1]);
+    const uint64_t n_mems = S->read_mem_off[n_reads];
+    S->mems.assign(n_mems + 1, moni_mem_t());
+    std::vector<uint32_t> aux(n_mems + 1);
+    unsigned long long dummy = 0;
+    for (uint64_t t = 0; t < n_tasks; ++t)
+        mem_task<true>(K, S->L, S->text.data(), seq, offs, n_tasks, t, S->ptr.data(), prm->min_len, split_on, cnt_m.data(), cnt_s.data(),
+                       S->read_mem_off.data(), S->mems.data(), aux.data(), dummy);
+    std::vector<uint64_t> tmp(n_mems * tmp_cap + 1), lowers(n_mems + 1);
+    std::vector<uint32_t> pool((size_t)pool_rows * K.n_seq + 1);
+    uint32_t small[2] = {0, 0};
+    occ_args_t A;
+    A.phi.recs = S->img.phi.data(); A.phi.dir = S->img.phi_dir.data();
+    A.phi_inv.recs = S->img.phi_inv.data(); A.phi_inv.dir = S->img.phi_inv_dir.data();
+    A.seq_starts = S->img.seq_starts.data(); A.name_id = S->name_id.data(); A.mems = S->mems.data(); A.aux = aux.data();
+    A.read_mem_off = S->read_mem_off.data(); A.n_mems = n_mems; A.occs = nullptr; A.tmp = tmp.data(); A.lowers = lowers.data();
+    A.tmp_cap = tmp_cap; A.filter_seeds = prm->filter_seeds; A.n_seeds_thr = prm->n_seeds_thr; A.pool_rows = pool_rows;
+    A.pool = pool.data(); A.pool_next = &small[0]; A.error_flag = &small[1]; A.counters = nullptr;
+    for (uint64_t g = 0; g < n_mems; ++g) occ_task<false>(K, A, g, cnt[2]);
+    if (small[1]) return MONI_ENOMEM;
+    uint64_t acc = 0;
+    for (uint64_t g = 0; g < n_mems; ++g) { S->mems[g].occ_off = acc; acc += S->mems[g].occ_cnt; }
+    S->occs.assign(acc + 1, 0);
+    A.occs = S->occs.data();
+    small[0] = small[1] = 0;
+    for (uint64_t g = 0; g < n_mems; ++g) occ_task<true>(K, A, g, dummy);
+    if (small[1]) return MONI_ENOMEM;
+    S->occs.resize(acc);
+    S->mems.resize(n_mems);
+    for (int i = 0; i < 4; ++i) S->counters[i] = cnt[i];
+    return MONI_OK;
+}
+
+uint64_t sim_n_mems(void* s) { return ((Sim*)s)->mems.size(); }
+uint64_t sim_n_occs(void* s) { return ((Sim*)s)->occs.size(); }
+void sim_fetch(void* s, moni_mem_t* mems, uint64_t* occs, uint64_t* read_mem_off, uint64_t* counters) {
+    Sim* S = (Sim*)s;
+    if (!S->mems.empty()) memcpy(mems, S->mems.data(), S->mems.size() * sizeof(moni_mem_t));
+    if (!S->occs.empty()) memcpy(occs, S->occs.data(), S->occs.size() * 8);
+    memcpy(read_mem_off, S->read_mem_off.data(), S->read_mem_off.size() * 8);
+    memcpy(counters, S->counters, 32);
+}
+// pointers in the layout of moni_ms_query_batch
+void sim_fetch_pointers(void* s, const uint64_t* offs, uint64_t* pointers) {
+    Sim* S = (Sim*)s;
+    const uint64_t n_tasks = 2 * S->n_reads;
+    for (uint64_t rd = 0; rd < S->n_reads; ++rd) {
+        const uint64_t off = offs[rd] - offs[0], m = offs[rd + 1] - offs[rd];
+        for (uint64_t st = 0; st < 2; ++st)
+            for (uint64_t k = 0; k < m; ++k) pointers[2 * off + st * m + k] = S->ptr[(m - 1 - k) * n_tasks + (2 * rd + st)];
+    }
+}
+void sim_phi(void* s, uint64_t i, int inverse, uint64_t* out2) {
+    Sim* S = (Sim*)s;
+    phi_tab_t P;
+    P.recs = inverse ? S->img.phi_inv.data() : S->img.phi.data();
+    P.dir = inverse ? S->img.phi_inv_dir.data() : S->img.phi_dir.data();
+    phi_step(P, S->img.K, i, out2[0], out2[1]);
+}
+
+}  // extern "C"

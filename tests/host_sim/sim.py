@@ -1,0 +1,66 @@
+"""ctypes driver for tests/host_sim/libhost_sim.so (TEST HARNESS: the kernels' per-lane code compiled for the host)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from moni_align_amd import capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(HERE, "libhost_sim.so")
+        srcs = [os.path.join(HERE, "host_sim.cpp")] + [os.path.join(capi.CSRC, f) for f in ("seed_core.h", "image.hpp", "layout.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(HERE, "host_sim.cpp")])
+        L = C.CDLL(so)
+        L.sim_create.restype = C.c_void_p
+        L.sim_create.argtypes = [C.POINTER(capi.FlatIndexC)]
+        L.sim_destroy.argtypes = [C.c_void_p]
+        L.sim_seed_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(capi.SeedParamsC), C.c_uint32, C.c_uint32]
+        L.sim_n_mems.restype = C.c_uint64
+        L.sim_n_mems.argtypes = [C.c_void_p]
+        L.sim_n_occs.restype = C.c_uint64
+        L.sim_n_occs.argtypes = [C.c_void_p]
+        L.sim_fetch.argtypes = [C.c_void_p] * 5
+        L.sim_fetch_pointers.argtypes = [C.c_void_p] * 3
+        L.sim_phi.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class Sim:
+    def __init__(self, fi):
+        self.fi = fi
+        st = capi.flat_struct(fi)
+        self.h = lib().sim_create(C.byref(st))
+        if not self.h:
+            raise RuntimeError("host_sim: index rejected")
+
+    def seed_run(self, seq, offsets, min_len=25, filter_seeds=True, n_seeds_thr=1000, report_mems=False, tmp_cap=16,
+                 pool_rows=64):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        p = capi.SeedParamsC(min_len, int(filter_seeds), n_seeds_thr, int(report_mems))
+        rc = lib().sim_seed_run(self.h, seq.ctypes.data, offsets.ctypes.data, len(offsets) - 1, C.byref(p), tmp_cap, pool_rows)
+        if rc:
+            raise RuntimeError("sim_seed_run rc=%d" % rc)
+        mems = np.empty(lib().sim_n_mems(self.h), dtype=capi.MEM_DTYPE)
+        occs = np.empty(lib().sim_n_occs(self.h), dtype=np.uint64)
+        rmo = np.empty(len(offsets), dtype=np.uint64)
+        cnt = np.empty(4, dtype=np.uint64)
+        lib().sim_fetch(self.h, mems.ctypes.data, occs.ctypes.data, rmo.ctypes.data, cnt.ctypes.data)
+        ptr = np.empty(2 * int(offsets[-1] - offsets[0]), dtype=np.uint64)
+        lib().sim_fetch_pointers(self.h, offsets.ctypes.data, ptr.ctypes.data)
+        return {"mems": mems, "occs": occs, "read_mem_off": rmo, "counters": cnt, "pointers": ptr}
+
+    def phi(self, i, inverse=False):
+        out = np.empty(2, dtype=np.uint64)
+        lib().sim_phi(self.h, i, int(inverse), out.ctypes.data)
+        return int(out[0]), int(out[1])

@@ -1,0 +1,85 @@
+"""The kernels' per-lane code (seed_core.h) replayed on the host over the device index image, against
+the oracle: bit-exact pointers, MEMs, halves, occurrence lists and filter counts.  Catches layout and
+logic errors without a GPU; the same comparisons run on the real kernels under -m gpu."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests.host_sim import sim as hs
+from tests.parity import assert_seeds_equal
+
+
+def ragged(reads_list):
+    offs = np.zeros(len(reads_list) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads_list])
+    seq = np.concatenate(reads_list) if reads_list else np.zeros(0, np.uint8)
+    return seq, offs
+
+
+@pytest.fixture(scope="module")
+def pair(medium_case):
+    return orc.OracleIndex(medium_case.path), hs.Sim(medium_case.fi)
+
+
+def run_both(pair, seq, offs, **kw):
+    o, s = pair
+    want = o.seed_batch(seq, offs, kw.get("min_len", 25), kw.get("filter_seeds", True), kw.get("n_seeds_thr", 1000))
+    got = s.seed_run(seq, offs, **kw)
+    return got, want
+
+
+def test_pointers_and_seeds_150bp(medium_case, pair):
+    reads = medium_case.synth.make_reads(medium_case.pg, 300, 150, seed=150)
+    seq, offs = ragged(list(reads))
+    got, want = run_both(pair, seq, offs)
+    o = pair[0]
+    rc = medium_case.synth.revcomp(reads)
+    for i in range(0, 300, 17):
+        assert np.array_equal(got["pointers"][2 * 150 * i:2 * 150 * i + 150], o.ms_query(reads[i].tobytes()))
+        assert np.array_equal(got["pointers"][2 * 150 * i + 150:2 * 150 * (i + 1)], o.ms_query(rc[i].tobytes()))
+    assert_seeds_equal(got, want)
+    assert np.array_equal(got["counters"], want["counters"])
+    assert int(got["counters"][0]) == 2 * 150 * 300
+
+
+def test_ragged_edge_cases(medium_case, pair):
+    rng = np.random.default_rng(5)
+    base = medium_case.synth.make_reads(medium_case.pg, 40, 250, seed=9, sub_rate=0.03, indel_rate=0.003)
+    reads = []
+    for i, r in enumerate(base):
+        reads.append(r[: int(rng.integers(1, 251))].copy())
+    reads.append(np.zeros(0, np.uint8))                       # empty read
+    reads.append(np.frombuffer(b"N" * 60, dtype=np.uint8))    # all N (absent from the text)
+    reads.append(np.frombuffer(b"acgtacgtacgtacgtacgtacgtacgtacgtacgt", dtype=np.uint8))   # lower case
+    x = base[0].copy(); x[40:45] = ord("N"); reads.append(x)
+    reads.append(np.frombuffer(bytes(medium_case.fi.text[100:400]), dtype=np.uint8))        # exact 300-mer
+    seq, offs = ragged(reads)
+    got, want = run_both(pair, seq, offs)
+    assert_seeds_equal(got, want)
+    assert np.array_equal(got["counters"], want["counters"])
+
+
+def test_filter_and_small_tmp(medium_case, pair):
+    reads = medium_case.synth.make_reads(medium_case.pg, 120, 150, seed=21, sub_rate=0.005)
+    seq, offs = ragged(list(reads))
+    for thr in (0, 1, 3, 1000):
+        got, want = run_both(pair, seq, offs, filter_seeds=True, n_seeds_thr=thr, tmp_cap=2, pool_rows=100000)
+        assert_seeds_equal(got, want)
+    got, want = run_both(pair, seq, offs, filter_seeds=False, n_seeds_thr=0, tmp_cap=1)
+    assert_seeds_equal(got, want)
+    got, want = run_both(pair, seq, offs, min_len=12)
+    assert_seeds_equal(got, want)
+
+
+def test_phi_records(medium_case, pair):
+    o, s = pair
+    rng = np.random.default_rng(1)
+    n = medium_case.fi.n
+    first = (int(medium_case.fi.ssa[0]) + 1) % n
+    last = (int(medium_case.fi.esa[-1]) + 1) % n
+    for i in rng.integers(0, n, size=2000):
+        i = int(i)
+        if i != first:
+            assert s.phi(i) == o.phi_lcp(i)
+        if i != last:
+            assert s.phi(i, True) == o.phi_lcp(i, True)

@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the HIP hot path on the BASELINE.json workload.
+
+One "step" = one pass of the seeding hot path (MS pointers by LF/threshold jumps -> MEMs -> phi/phi^-1
+occurrence enumeration, both strands) over one resident batch of synthetic 150 bp reads on the
+mouse-chr19-scale x12-haplotype index (BASELINE.json configs[1]).  Inputs are already in HBM when the
+timed region starts.  N > 1: one process per GPU (torch.distributed / RCCL), reads sharded, index
+replicated, no data-path collective ("weak" scaling: per-GPU batch fixed).
+
+Prints ONE JSON line (rank 0) with `roofline` (ms_lf_kernel, HIP-event timed inside the library on its
+own stream) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def log(*a):
+    print("[bench %s]" % time.strftime("%H:%M:%S"), *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--base-len", type=int, default=61420004)   # GRCm39 chr19
+    ap.add_argument("--haps", type=int, default=12)
+    ap.add_argument("--reads", type=int, default=1000000)       # per GPU
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cache", default="/tmp/moni_bench_cache")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from moni_align_amd import capi, index_build, synth
+
+    # ---- inputs (seeded, synthetic: SURVEY.md §8(d)) -------------------------------------------------
+    t0 = time.time()
+    pg = synth.make_pangenome(args.base_len, args.haps, seed=19, var_seed=12)
+    log("rank %d: pangenome %d sequences, %.1f Mchar in %.1fs" % (rank, len(pg.seqs), sum(len(s) for s in pg.seqs) / 1e6, time.time() - t0))
+    os.makedirs(args.cache, exist_ok=True)
+    key = "idx_%d_%d.mfi" % (args.base_len, args.haps)
+    path = os.path.join(args.cache, key)
+    fi = None
+    if rank == 0:
+        if os.path.exists(path):
+            log("loading cached flat index", path)
+            fi = index_build.FlatIndex.load(path)
+        else:
+            t0 = time.time()
+            fi = index_build.build_from_pangenome(pg, device="cuda:%d" % local_rank, log=log)
+            torch.cuda.empty_cache()
+            log("flat index built on GPU in %.1fs: n=%d r=%d n/r=%.2f" % (time.time() - t0, fi.n, fi.r, fi.n / fi.r))
+            if world > 1 or os.environ.get("MONI_BENCH_SAVE_INDEX"):
+                fi.save(path + ".tmp")
+                os.replace(path + ".tmp", path)
+    if world > 1:
+        dist.barrier()
+        if rank != 0:
+            fi = index_build.FlatIndex.load(path)
+    t0 = time.time()
+    idx = capi.Index(fi=fi, device=local_rank)
+    log("rank %d: device image %.2f GB in %.1fs" % (rank, idx.device_bytes / 1e9, time.time() - t0))
+    ctx = capi.Ctx(idx)
+    L = args.read_len
+    reads = synth.make_reads(pg, args.reads, L, seed=150 + rank)
+    offs = np.arange(0, (args.reads + 1) * L, L, dtype=np.uint64)
+    ctx.upload(reads.reshape(-1), offs)
+    del pg
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup + timed steps ---------------------------------------------------------------------------
+    for _ in range(args.warmup):
+        ctx.seed_run(25, True, 1000)
+    sync_all()
+    kern = np.zeros(7)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.seed_run(25, True, 1000)
+        kern += [ctx.kernel_ms(w) if w != 5 else 0.0 for w in range(7)]
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern /= max(1, args.steps)
+    cnt = ctx.counters()
+    res = ctx.seed_fetch()
+    n_mems, n_occs = len(res["mems"]), len(res["occs"])
+
+    out = None
+    if rank == 0:
+        S, J, P, C = (int(x) for x in cnt)
+        ms_bytes = 128 * S + 64 * J                 # algorithmic bytes of the LF stage
+        ms_s = kern[0] / 1e3
+        achieved = ms_bytes / ms_s / 1e9 if ms_s > 0 else 0.0
+        value = world * args.reads * args.steps / elapsed
+        out = {
+            "metric": "reads/s (whole node), 150 bp SE, seeding hot path (MS/LF + MEM + phi occurrences)",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: mouse-chr19-scale index (%d bp base + %d haplotypes, n=%d, r=%d), "
+                                   "%d x %d bp reads per GPU, MEM seeding stage on GPU (ksw2 extension not in this step)"
+                                   % (args.base_len, args.haps, fi.n, fi.r, args.reads, L),
+                       "reads_per_gpu": args.reads, "read_len": L, "parallelism": "reads sharded x%d, index replicated" % world},
+            "roofline": {"bound": "hbm", "kernel": "ms_lf_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": ms_bytes, "avg_launch_ms": kern[0],
+                         "per_read_bytes": ms_bytes / args.reads},
+            "kernels_ms": {"ms_lf": kern[0], "mem_count": kern[1], "mem_emit": kern[2], "occ_count": kern[3], "occ_fill": kern[4],
+                           "whole_run": kern[6]},
+            "work_per_step": {"lf_steps": S, "threshold_jumps": J, "phi_steps": P, "text_bytes": C, "mems": n_mems, "occs": n_occs},
+        }
+        if world == 1 and not args.no_cpu:
+            from oracle import orc
+            oidx = orc.OracleIndex(fi=fi)
+            threads = min(os.cpu_count() or 1, 64)
+            probe = 2000
+            t1 = time.perf_counter()
+            oidx.seed_batch(reads[:probe].reshape(-1), offs[:probe + 1], 25, True, 1000, threads=threads)
+            rate = probe / (time.perf_counter() - t1)
+            n_cpu = int(max(probe, min(args.reads, rate * args.cpu_seconds)))
+            t1 = time.perf_counter()
+            want = oidx.seed_batch(reads[:n_cpu].reshape(-1), offs[:n_cpu + 1], 25, True, 1000, threads=threads)
+            dt = time.perf_counter() - t1
+            # the same sample doubles as an at-scale parity check of the GPU result
+            k = int(want["read_mem_off"][-1])
+            same = (np.array_equal(res["read_mem_off"][:n_cpu + 1], want["read_mem_off"]) and
+                    np.array_equal(res["mems"]["pos"][:k], want["pos"]) and np.array_equal(res["mems"]["len"][:k].astype(np.uint64), want["len"]) and
+                    np.array_equal(res["mems"]["occ_cnt"][:k].astype(np.uint64), want["occ_cnt"]) and
+                    np.array_equal(res["occs"][:len(want["occs"])], want["occs"]))
+            out["cpu_baseline"] = {"value": n_cpu / dt, "unit": "reads/s", "cores": threads, "kind": "port",
+                                   "sample": "first %d reads of the same batch, same stage, oracle/seed.hpp with %d threads" % (n_cpu, threads),
+                                   "gpu_matches_cpu_on_sample": bool(same)}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    idx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

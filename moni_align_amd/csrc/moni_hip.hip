@@ -330,30 +330,48 @@ int moni_seed_run(moni_ctx_t* c, const moni_seed_params_t* prm) {
     A.filter_seeds = prm->filter_seeds; A.n_seeds_thr = prm->n_seeds_thr; A.pool_rows = c->pool_rows; A.pool = c->pool.p;
     A.pool_next = c->d_small; A.error_flag = c->d_small + 1; A.counters = c->d_counters;
     const unsigned grid_m = (unsigned)((n_mems + MS_BLOCK - 1) / MS_BLOCK);
-    rec(c, EV_PC0);
-    if (n_mems) hipLaunchKernelGGL(occ_kernel<false>, dim3(grid_m), dim3(MS_BLOCK), 0, c->stream, I->K, A);
-    rec(c, EV_PC1);
+    // The per-genome filter needs a row of per-name counters only for seeds with more than n_seeds_thr occurrences;
+    // rows come from a bump-allocated pool.  If a pass asks for more rows than the pool holds, the pool is grown to the
+    // demand the pass reported and the pass is repeated (results of an exhausted pass are discarded).
+    uint64_t n_occs = 0;
+    uint32_t small[2] = {0, 0};
+    for (int attempt = 0;; ++attempt) {
+        A.pool = c->pool.p; A.pool_rows = c->pool_rows;
+        HIPCHK(hipMemsetAsync(c->d_small, 0, 16, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_counters + 2, 0, sizeof(unsigned long long), c->stream));
+        rec(c, EV_PC0);
+        if (n_mems) hipLaunchKernelGGL(occ_kernel<false>, dim3(grid_m), dim3(MS_BLOCK), 0, c->stream, I->K, A);
+        rec(c, EV_PC1);
+        HIPCHK(hipMemcpyAsync(small, c->d_small, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!small[1]) break;
+        if (attempt >= 2) { fprintf(stderr, "moni_hip: per-genome counter pool exhausted (%u rows)\n", c->pool_rows); return MONI_ENOMEM; }
+        c->pool_rows = small[0] + small[0] / 4 + 64;
+        if ((rc = c->pool.ensure((size_t)c->pool_rows * I->K.n_seq + 1))) return rc;
+    }
     hipLaunchKernelGGL(occ_cnt_gather_kernel, dim3((unsigned)((n_mems + 1 + 255) / 256)), dim3(256), 0, c->stream, c->mems.p, n_mems, c->occ_cnt.p);
     if ((rc = exclusive_scan_u64(c, c->occ_cnt.p, c->occ_off.p, n_mems + 1))) return rc;
     if (n_mems) hipLaunchKernelGGL(occ_off_scatter_kernel, dim3(grid_m), dim3(256), 0, c->stream, c->mems.p, n_mems, c->occ_off.p);
-    uint64_t n_occs = 0;
-    uint32_t small[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(&n_occs, c->occ_off.p + n_mems, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(small, c->d_small, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (small[1]) { fprintf(stderr, "moni_hip: per-genome counter pool exhausted (%u rows)\n", c->pool_rows); return MONI_ENOMEM; }
     c->n_occs = n_occs;
     if ((rc = c->occs.ensure(n_occs + 1))) return rc;
     A.occs = c->occs.p;
-    HIPCHK(hipMemsetAsync(c->d_small, 0, 16, c->stream));
-    rec(c, EV_PE0);
-    if (n_mems) hipLaunchKernelGGL(occ_kernel<true>, dim3(grid_m), dim3(MS_BLOCK), 0, c->stream, I->K, A);
-    rec(c, EV_PE1);
-    rec(c, EV_ALL1);
-    HIPCHK(hipMemcpyAsync(small, c->d_small, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int attempt = 0;; ++attempt) {
+        A.pool = c->pool.p; A.pool_rows = c->pool_rows;
+        HIPCHK(hipMemsetAsync(c->d_small, 0, 16, c->stream));
+        rec(c, EV_PE0);
+        if (n_mems) hipLaunchKernelGGL(occ_kernel<true>, dim3(grid_m), dim3(MS_BLOCK), 0, c->stream, I->K, A);
+        rec(c, EV_PE1);
+        rec(c, EV_ALL1);
+        HIPCHK(hipMemcpyAsync(small, c->d_small, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!small[1]) break;
+        if (attempt >= 2) { fprintf(stderr, "moni_hip: per-genome counter pool exhausted (%u rows)\n", c->pool_rows); return MONI_ENOMEM; }
+        c->pool_rows = small[0] + small[0] / 4 + 64;
+        if ((rc = c->pool.ensure((size_t)c->pool_rows * I->K.n_seq + 1))) return rc;
+    }
     HIPCHK(hipGetLastError());
-    if (small[1]) { fprintf(stderr, "moni_hip: per-genome counter pool exhausted (%u rows)\n", c->pool_rows); return MONI_ENOMEM; }
     return MONI_OK;
 }
 

@@ -50,6 +50,21 @@ void* orc_index_load(const char* path) {
     if (!ix->load(path)) { delete ix; return nullptr; }
     return ix;
 }
+
+// build from host arrays (same content as the MONIFLT2 file); names: n_seq NUL-terminated strings back to back
+void* orc_index_create(uint64_t n, uint64_t r, uint64_t w, uint64_t n_seq, const uint64_t* F, const uint8_t* heads,
+                       const uint64_t* starts, const uint64_t* ssa, const uint64_t* esa, const uint64_t* thr,
+                       const uint64_t* slcp, const uint8_t* text, const uint64_t* seq_starts, const char* names) {
+    FlatIndex* ix = new FlatIndex();
+    ix->n = n; ix->r = r; ix->w = w;
+    ix->F.assign(F, F + 256); ix->heads.assign(heads, heads + r); ix->starts.assign(starts, starts + r + 1);
+    ix->samples_start.assign(ssa, ssa + r); ix->samples_last.assign(esa, esa + r); ix->thr.assign(thr, thr + r);
+    ix->slcp.assign(slcp, slcp + r); ix->text.assign(text, text + n - 1); ix->seq_starts.assign(seq_starts, seq_starts + n_seq + 1);
+    const char* p = names;
+    for (uint64_t i = 0; i < n_seq; ++i) { ix->names.emplace_back(p); p += ix->names.back().size() + 1; }
+    ix->finalize();
+    return ix;
+}
 void orc_index_free(void* h) { delete (FlatIndex*)h; }
 uint64_t orc_index_n(void* h) { return ((FlatIndex*)h)->n; }
 uint64_t orc_index_r(void* h) { return ((FlatIndex*)h)->r; }

@@ -31,6 +31,8 @@ def lib():
         L = ctypes.CDLL(build())
         L.orc_index_load.restype = ctypes.c_void_p
         L.orc_index_load.argtypes = [ctypes.c_char_p]
+        L.orc_index_create.restype = ctypes.c_void_p
+        L.orc_index_create.argtypes = [ctypes.c_uint64] * 4 + [ctypes.c_void_p] * 9 + [ctypes.c_char_p]
         L.orc_index_free.argtypes = [ctypes.c_void_p]
         L.orc_index_n.restype = ctypes.c_uint64
         L.orc_index_n.argtypes = [ctypes.c_void_p]
@@ -55,11 +57,17 @@ def lib():
 
 
 class OracleIndex:
-    def __init__(self, path: str):
+    def __init__(self, path: str = None, fi=None):
         self._L = lib()
-        self._h = self._L.orc_index_load(path.encode())
+        if fi is not None:
+            names = b"".join(s.encode() + b"\0" for s in fi.names)
+            self._h = self._L.orc_index_create(fi.n, fi.r, fi.w, len(fi.seq_starts) - 1, fi.F.ctypes.data, fi.heads.ctypes.data,
+                                               fi.starts.ctypes.data, fi.ssa.ctypes.data, fi.esa.ctypes.data, fi.thr.ctypes.data,
+                                               fi.slcp.ctypes.data, fi.text.ctypes.data, fi.seq_starts.ctypes.data, names)
+        else:
+            self._h = self._L.orc_index_load(path.encode())
         if not self._h:
-            raise IOError("oracle: cannot load " + path)
+            raise IOError("oracle: cannot load " + str(path))
         self.n = self._L.orc_index_n(self._h)
         self.r = self._L.orc_index_r(self._h)
 

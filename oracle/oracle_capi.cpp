@@ -4,6 +4,7 @@
 #include "flat_index.hpp"
 #include "seed.hpp"
 #include "ksw2.hpp"
+#include "align.hpp"
 
 #include <atomic>
 #include <chrono>
@@ -140,6 +141,48 @@ void orc_seed_get(void* r, int field, uint64_t* out) {
     if (v && !v->empty()) memcpy(out, v->data(), v->size() * 8);
 }
 void orc_seed_free(void* r) { delete (SeedResult*)r; }
+
+
+// Full single-end `moni align` path for a ragged batch of reads -> SAM text (no header unless asked).
+// names: ragged bytes with name_off[n_reads+1]; quals: same offsets as seqs or NULL (FASTA reads print '*').
+// counters[8]: lf_steps, jumps, phi_steps, text_cmp, dp_cells, dp_calls, ref_bytes, aligned_reads
+char* orc_align_batch(void* h, const uint8_t* seqs, const uint64_t* offsets, uint64_t n_reads, const uint8_t* names,
+                      const uint64_t* name_off, const uint8_t* quals, int with_header, int threads, uint64_t* out_len,
+                      uint64_t* counters) {
+    const FlatIndex& ix = *(FlatIndex*)h;
+    if (threads < 1) threads = 1;
+    std::vector<std::string> parts(threads);
+    std::vector<std::vector<uint64_t>> cnt(threads, std::vector<uint64_t>(8, 0));
+    std::vector<std::thread> th;
+    align_config_t cfg;
+    for (int t = 0; t < threads; ++t) {
+        th.emplace_back([&, t]() {
+            uint64_t lo = n_reads * t / threads, hi = n_reads * (t + 1) / threads;
+            aligner A(ix, cfg);
+            std::string& out = parts[t];
+            for (uint64_t rd = lo; rd < hi; ++rd) {
+                read_t r;
+                r.name.assign((const char*)names + name_off[rd], (const char*)names + name_off[rd + 1]);
+                r.seq.assign((const char*)seqs + offsets[rd], (const char*)seqs + offsets[rd + 1]);
+                if (quals) { r.qual.assign((const char*)quals + offsets[rd], (const char*)quals + offsets[rd + 1]); r.has_qual = true; }
+                if (A.align_read(r, out)) cnt[t][7]++;
+            }
+            cnt[t][0] = A.mem_finder.cnt.lf_steps; cnt[t][1] = A.mem_finder.cnt.jumps; cnt[t][2] = A.mem_finder.cnt.phi_steps;
+            cnt[t][3] = A.mem_finder.cnt.text_cmp; cnt[t][4] = A.kc.cells; cnt[t][5] = A.kc.calls; cnt[t][6] = A.dpc.ref_bytes;
+        });
+    }
+    for (auto& x : th) x.join();
+    std::string all;
+    if (with_header) { aligner A(ix, cfg); all = A.sam_header(); }
+    for (auto& p : parts) all += p;
+    if (counters) for (int i = 0; i < 8; ++i) { counters[i] = 0; for (int t = 0; t < threads; ++t) counters[i] += cnt[t][i]; }
+    char* buf = (char*)malloc(all.size() + 1);
+    memcpy(buf, all.data(), all.size());
+    buf[all.size()] = 0;
+    *out_len = all.size();
+    return buf;
+}
+void orc_free(void* p) { free(p); }
 
 // ksw2 restatement: one problem. out[11] = max,max_q,max_t,mqe,mqe_t,mte,mte_q,score,reach_end,n_cigar,zdropped
 void orc_extz(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int8_t m, const int8_t* mat,

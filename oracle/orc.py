@@ -49,6 +49,10 @@ def lib():
         L.orc_seed_n_occs.argtypes = [ctypes.c_void_p]
         L.orc_seed_get.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.orc_seed_free.argtypes = [ctypes.c_void_p]
+        L.orc_align_batch.restype = ctypes.c_void_p
+        L.orc_align_batch.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint64] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int,
+                                                                                                     ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_free.argtypes = [ctypes.c_void_p]
         L.orc_extz.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int8,
                                ctypes.c_void_p, ctypes.c_int8, ctypes.c_int8, ctypes.c_int, ctypes.c_int,
                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -117,6 +121,38 @@ class OracleIndex:
             return out
         finally:
             self._L.orc_seed_free(r)
+
+
+def make_names(n: int, prefix: str = "simulated"):
+    names = [("%s.%d" % (prefix, i)).encode() for i in range(n)]
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in names])
+    return np.frombuffer(b"".join(names), dtype=np.uint8).copy(), off
+
+
+def align_batch(oidx: "OracleIndex", seqs: np.ndarray, offsets: np.ndarray, names=None, name_off=None, quals=None,
+                with_header: bool = False, threads: int = 1):
+    """SAM text (bytes) of the reference's single-end path, plus work counters."""
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    if names is None:
+        names, name_off = make_names(n)
+    names = np.ascontiguousarray(names, dtype=np.uint8)
+    name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
+    if quals is not None:
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+    out_len = ctypes.c_uint64()
+    cnt = np.zeros(8, dtype=np.uint64)
+    p = lib().orc_align_batch(oidx._h, seqs.ctypes.data, offsets.ctypes.data, n, names.ctypes.data, name_off.ctypes.data,
+                              quals.ctypes.data if quals is not None else None, int(with_header), threads,
+                              ctypes.byref(out_len), cnt.ctypes.data)
+    try:
+        sam = ctypes.string_at(p, out_len.value)
+    finally:
+        lib().orc_free(p)
+    keys = ["lf_steps", "jumps", "phi_steps", "text_cmp", "dp_cells", "dp_calls", "ref_bytes", "aligned"]
+    return sam, {k: int(v) for k, v in zip(keys, cnt)}
 
 
 DEFAULT_MAT = np.array([2, -4, -4, -4, 0, -4, 2, -4, -4, 0, -4, -4, 2, -4, 0, -4, -4, -4, 2, 0, 0, 0, 0, 0, 0],

@@ -43,9 +43,8 @@ def main():
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from moni_align_amd import dist as mdist
+    rank, local_rank, world = mdist.env_world()
     if world != args.gpus:
         log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     if not torch.cuda.is_available():
@@ -53,9 +52,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist = mdist.init("nccl", rank, world, local_rank)
 
     from moni_align_amd import capi, index_build, synth
 
@@ -109,14 +106,12 @@ def main():
         kern += [ctx.kernel_ms(w) if w != 5 else 0.0 for w in range(7)]
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = mdist.max_over_ranks(elapsed, dist, "cuda")
     kern /= max(1, args.steps)
     cnt = ctx.counters()
     res = ctx.seed_fetch()
     n_mems, n_occs = len(res["mems"]), len(res["occs"])
+    sizes = mdist.gather_counts([n_mems, n_occs], dist, "cuda")     # the only result exchange: per-rank record counts
 
     out = None
     if rank == 0:
@@ -140,7 +135,8 @@ def main():
                          "per_read_bytes": ms_bytes / args.reads},
             "kernels_ms": {"ms_lf": kern[0], "mem_count": kern[1], "mem_emit": kern[2], "occ_count": kern[3], "occ_fill": kern[4],
                            "whole_run": kern[6]},
-            "work_per_step": {"lf_steps": S, "threshold_jumps": J, "phi_steps": P, "text_bytes": C, "mems": n_mems, "occs": n_occs},
+            "work_per_step": {"lf_steps": S, "threshold_jumps": J, "phi_steps": P, "text_bytes": C, "mems": n_mems, "occs": n_occs,
+                              "mems_all_ranks": sum(x[0] for x in sizes), "occs_all_ranks": sum(x[1] for x in sizes)},
         }
         if world == 1 and not args.no_cpu:
             from oracle import orc

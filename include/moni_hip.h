@@ -50,6 +50,7 @@ typedef struct {
     const uint64_t *slcp;    /* [r]   LCP at each run start */
     const uint8_t *text;     /* [n-1] */
     const uint64_t *seq_starts; /* [n_seq+1] onsets in text coordinates */
+    const char *seq_names;   /* n_seq NUL-terminated names back to back (seqidx names), or NULL */
 } moni_flat_index_t;
 
 /* Ragged batch of reads: read i is seq[offsets[i] .. offsets[i+1]).  Replaces the kseq_t batches of
@@ -149,6 +150,34 @@ int moni_phi_lcp_batch(moni_ctx_t *ctx, const uint64_t *pos, uint64_t n, int inv
 int moni_extz_batch(moni_ctx_t *ctx, const moni_dp_params_t *prm, const uint8_t *qseq, uint64_t qseq_len,
                     const uint8_t *tseq, uint64_t tseq_len, const moni_dp_task_t *tasks, uint64_t n_tasks,
                     moni_dp_result_t *results, uint32_t *cigar_pool, uint64_t cigar_pool_cap, uint64_t *cigar_pool_used);
+
+/* ---- the whole single-end path: aligner::align (include/aligner/aligner_ksw2.hpp:314-521) over a batch --- */
+/* aligner::config_t (aligner_ksw2.hpp:84-130) with the `moni align` wrapper defaults (pipeline/moni.in:748-768). */
+typedef struct {
+    uint32_t min_len, ext_len, check_k, region_dist;      /* 25, 100, 5, 10 */
+    uint32_t filter_seeds, n_seeds_thr, filter_freq, left_mem_check; /* 1, 1000, 1, 1 */
+    double freq_thr;                                      /* 0.5 */
+    int8_t smatch, smismatch, gapo, gapo2, gape, gape2;   /* 2, 4, 4, 13, 2, 1 */
+    int32_t end_bonus, w, zdrop;                          /* 400, -1, -1 */
+    int64_t max_dist_x, max_dist_y, max_iter, max_pred, min_chain_score, min_chain_length; /* 500,100,10,5,40,1 */
+    uint32_t host_threads;                                /* threads for the host stages (chaining, stitching, SAM) */
+    uint32_t reserved;
+} moni_align_params_t;
+
+typedef struct {
+    uint64_t reads, aligned, dp_tasks, dp_cells, dp_rounds;
+    double t_seed, t_chain, t_dp, t_host;                 /* seconds */
+} moni_align_stats_t;
+
+void moni_align_params_default(moni_align_params_t *p);
+/* Replaces the per-read loop of st_align/mt_align (include/aligner/align_reads_dispatcher.hpp:346-357): SAM records of
+ * the batch in input order, no header.  names: ragged bytes with name_off[n_reads+1]; quals: same offsets as the reads
+ * or NULL.  *sam is malloc'ed (moni_free). */
+int moni_align_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
+                     const uint8_t *quals, const moni_align_params_t *prm, char **sam, uint64_t *sam_len,
+                     moni_align_stats_t *stats);
+/* aligner::to_sam (aligner_ksw2.hpp:3213-3219): "@HD", one "@SQ" per sequence, "@PG". */
+int moni_sam_header(const moni_index_t *idx, char **sam, uint64_t *sam_len);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 /* HIP-event time (ms) of the kernels of the last *_run on this ctx's stream.

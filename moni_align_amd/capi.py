@@ -21,6 +21,7 @@ EXPORTS = [
     "moni_index_device_bytes", "moni_ctx_create", "moni_ctx_destroy", "moni_reads_upload", "moni_ms_run",
     "moni_ms_query_batch", "moni_seed_run", "moni_seed_counts", "moni_seed_fetch", "moni_seed_batch", "moni_free",
     "moni_phi_lcp_batch", "moni_extz_batch", "moni_last_kernel_ms", "moni_last_counters",
+    "moni_align_params_default", "moni_align_batch", "moni_sam_header",
 ]
 
 
@@ -28,7 +29,7 @@ class FlatIndexC(C.Structure):
     _fields_ = [("n", C.c_uint64), ("r", C.c_uint64), ("w", C.c_uint64), ("n_seq", C.c_uint64),
                 ("F", C.c_void_p), ("heads", C.c_void_p), ("starts", C.c_void_p), ("ssa", C.c_void_p),
                 ("esa", C.c_void_p), ("thr", C.c_void_p), ("slcp", C.c_void_p), ("text", C.c_void_p),
-                ("seq_starts", C.c_void_p)]
+                ("seq_starts", C.c_void_p), ("seq_names", C.c_char_p)]
 
 
 class ReadBatchC(C.Structure):
@@ -38,6 +39,22 @@ class ReadBatchC(C.Structure):
 class SeedParamsC(C.Structure):
     _fields_ = [("min_len", C.c_uint32), ("filter_seeds", C.c_uint32), ("n_seeds_thr", C.c_uint32),
                 ("report_mems", C.c_uint32)]
+
+
+class AlignParamsC(C.Structure):
+    _fields_ = [("min_len", C.c_uint32), ("ext_len", C.c_uint32), ("check_k", C.c_uint32), ("region_dist", C.c_uint32),
+                ("filter_seeds", C.c_uint32), ("n_seeds_thr", C.c_uint32), ("filter_freq", C.c_uint32), ("left_mem_check", C.c_uint32),
+                ("freq_thr", C.c_double),
+                ("smatch", C.c_int8), ("smismatch", C.c_int8), ("gapo", C.c_int8), ("gapo2", C.c_int8), ("gape", C.c_int8), ("gape2", C.c_int8),
+                ("end_bonus", C.c_int32), ("w", C.c_int32), ("zdrop", C.c_int32),
+                ("max_dist_x", C.c_int64), ("max_dist_y", C.c_int64), ("max_iter", C.c_int64), ("max_pred", C.c_int64),
+                ("min_chain_score", C.c_int64), ("min_chain_length", C.c_int64),
+                ("host_threads", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class AlignStatsC(C.Structure):
+    _fields_ = [("reads", C.c_uint64), ("aligned", C.c_uint64), ("dp_tasks", C.c_uint64), ("dp_cells", C.c_uint64), ("dp_rounds", C.c_uint64),
+                ("t_seed", C.c_double), ("t_chain", C.c_double), ("t_dp", C.c_double), ("t_host", C.c_double)]
 
 
 class DpParamsC(C.Structure):
@@ -95,6 +112,11 @@ def lib():
         L.moni_phi_lcp_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
         L.moni_extz_batch.argtypes = [C.c_void_p, C.POINTER(DpParamsC), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                       C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.moni_align_params_default.argtypes = [C.POINTER(AlignParamsC)]
+        L.moni_align_params_default.restype = None
+        L.moni_align_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
+        L.moni_sam_header.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.moni_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.moni_last_counters.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
@@ -114,6 +136,8 @@ def flat_struct(fi) -> FlatIndexC:
         a = getattr(fi, k)
         assert a.flags["C_CONTIGUOUS"]
         setattr(s, k, a.ctypes.data)
+    s._names_keep = b"".join(x.encode() + b"\0" for x in fi.names)
+    s.seq_names = s._names_keep
     return s
 
 
@@ -213,6 +237,42 @@ class Ctx:
                                      tasks.ctypes.data, len(tasks), res.ctypes.data, pool.ctypes.data, cigar_cap,
                                      C.byref(used)), "moni_extz_batch")
         return res, pool[: used.value]
+
+    def align_batch(self, seq: np.ndarray, offsets: np.ndarray, names: np.ndarray, name_off: np.ndarray, quals=None,
+                    host_threads: Optional[int] = None, **overrides):
+        """SAM text (bytes) of the batch + stats dict; the whole single-end path on the GPU + host stages."""
+        b, keep = self._batch(seq, offsets)
+        names = np.ascontiguousarray(names, dtype=np.uint8)
+        name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
+        if quals is not None:
+            quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        prm = AlignParamsC()
+        self._L.moni_align_params_default(C.byref(prm))
+        if host_threads is not None:
+            prm.host_threads = host_threads
+        for k, v in overrides.items():
+            setattr(prm, k, v)
+        out = C.c_void_p()
+        ln = C.c_uint64()
+        st = AlignStatsC()
+        _chk(self._L.moni_align_batch(self._h, C.byref(b), names.ctypes.data, name_off.ctypes.data,
+                                      quals.ctypes.data if quals is not None else None, C.byref(prm), C.byref(out), C.byref(ln),
+                                      C.byref(st)), "moni_align_batch")
+        self.n_reads = len(offsets) - 1
+        try:
+            sam = C.string_at(out, ln.value)
+        finally:
+            self._L.moni_free(out)
+        return sam, {k: getattr(st, k) for k, _ in AlignStatsC._fields_}
+
+    def sam_header(self) -> bytes:
+        out = C.c_void_p()
+        ln = C.c_uint64()
+        _chk(self._L.moni_sam_header(self.index._h, C.byref(out), C.byref(ln)), "moni_sam_header")
+        try:
+            return C.string_at(out, ln.value)
+        finally:
+            self._L.moni_free(out)
 
     def kernel_ms(self, which: int) -> float:
         v = C.c_float()

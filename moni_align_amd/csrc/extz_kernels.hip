@@ -19,6 +19,12 @@
 #define DP_EZ_RIGHT 0x02
 #define DP_EZ_EXTZ_ONLY 0x40
 #define DP_MAX_QLEN 2048
+// moni_dp_task_t::reserved carries the operand mode (0 = nt4 codes in qseq/tseq, ascending: the plain ksw2 call)
+#define DP_Q_READS 0x01   // query bytes come from the resident read batch (ASCII -> nt4, aligner_ksw2.hpp:3273 table)
+#define DP_Q_REV   0x02   // query[k] = src[q_off - k]
+#define DP_Q_COMP  0x04   // complement (the reverse-complement strand: kpbseq.h:120-137 then nt4)
+#define DP_T_TEXT  0x08   // target bytes come from the index text (ASCII -> nt4)
+#define DP_T_REV   0x10   // target[k] = src[t_off - k]   (left context, aligner_ksw2.hpp:2803-2805)
 
 struct dp_launch_t {
     const uint8_t* qseq;
@@ -32,7 +38,16 @@ struct dp_launch_t {
     moni_dp_result_t* results;
     int32_t sc_mch, sc_mis, sc_N, wild;
     int32_t qo, e, end_bonus;
+    const uint8_t* reads;         // resident read batch (DP_Q_READS)
+    const uint8_t* text;          // index text (DP_T_TEXT)
+    uint64_t n_text;
 };
+
+__device__ __forceinline__ uint32_t dp_nt4(uint32_t b) {      // seq_nt4_table, aligner_ksw2.hpp:3272-3288
+    if (b < 4) return b;
+    const uint32_t u = b & 0xDFu;                              // fold case
+    return u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : 4u;
+}
 
 __device__ __forceinline__ int32_t dp_bound(int32_t k, int32_t qo, int32_t e) {   // H(k,-1) = H(-1,k), k >= -1
     return k < 0 ? 0 : -(qo + (k + 1) * e);
@@ -63,9 +78,18 @@ extz_kernel(const dp_launch_t P) {
     }
     const bool with_cigar = !(flag & DP_EZ_SCORE_ONLY);
     const bool right = (flag & DP_EZ_RIGHT) != 0;
-    const uint8_t* __restrict__ q = P.qseq + task.q_off;
-    const uint8_t* __restrict__ tg = P.tseq + task.t_off;
-    for (int k = lane; k < qlen; k += 64) qs[k] = q[k];
+    const int mode = task.reserved;
+    if (mode & DP_Q_READS) {
+        const uint8_t* __restrict__ q = P.reads + task.q_off;
+        for (int k = lane; k < qlen; k += 64) {
+            uint32_t c = dp_nt4((mode & DP_Q_REV) ? q[-(long)k] : q[k]);
+            if ((mode & DP_Q_COMP) && c < 4) c = 3 - c;
+            qs[k] = (uint8_t)c;
+        }
+    } else {
+        const uint8_t* __restrict__ q = P.qseq + task.q_off;
+        for (int k = lane; k < qlen; k += 64) qs[k] = (mode & DP_Q_REV) ? q[-(long)k] : q[k];
+    }
     __syncthreads();
     const int32_t qo = P.qo, e = P.e;
     uint8_t* __restrict__ dir = with_cigar ? P.dirs + P.dir_off[tix] : nullptr;
@@ -79,7 +103,16 @@ extz_kernel(const dp_launch_t P) {
         H2[k] = 0;
         E1[k] = DP_NEG_INF;
         F1[k] = DP_NEG_INF;
-        tcode[k] = i < tlen ? (int32_t)tg[i] : 255;
+        int32_t tc = 255;
+        if (i < tlen) {
+            if (mode & DP_T_TEXT) {
+                const uint64_t a = (mode & DP_T_REV) ? task.t_off - (uint64_t)i : task.t_off + (uint64_t)i;
+                tc = (int32_t)dp_nt4(a < P.n_text ? P.text[a] : 0u);
+            } else {
+                tc = (int32_t)P.tseq[(mode & DP_T_REV) ? task.t_off - (uint64_t)i : task.t_off + (uint64_t)i];
+            }
+        }
+        tcode[k] = tc;
     }
     // per-lane running results
     int32_t mqe_h = DP_NEG_INF, mqe_i = -1;            // best H(i, qlen-1) over own rows (rows ascend with the chunk index)

@@ -22,10 +22,12 @@ struct HostImage {
     std::vector<uint64_t> seq_starts;
     std::string err;
 
-    static inline moni_row_t pack_row(uint64_t start, uint32_t head, uint64_t lfbase, uint64_t dest) {
+    static inline moni_row_t pack_row(uint64_t start, uint32_t head, uint64_t lfbase, uint64_t dest, uint64_t len = 0) {
         moni_row_t x;
-        x.w0 = start | ((uint64_t)head << 40) | ((dest >> 24) << 44);
+        const uint64_t l = len > MONI_ROW_LEN_SAT ? MONI_ROW_LEN_SAT : len;
+        x.w0 = start | ((uint64_t)head << 40) | ((dest >> 24) << 44) | (l << 52);
         x.w1 = lfbase | ((dest & 0xFFFFFFull) << 40);
+        x.hot_cr[0] = x.hot_cr[1] = x.hot_cr[2] = x.hot_cr[3] = 0;
         return x;
     }
 
@@ -120,9 +122,20 @@ struct HostImage {
                 if (k < r) seen[code_of[f.heads[k]]]++;
             }
         }
-        for (uint64_t k = 0; k < r; ++k) rows[k] = pack_row(f.starts[k], (uint32_t)code_of[f.heads[k]], lfbase[k], dest[k]);
-        rows[r] = pack_row(n, MONI_HEAD_NONE, 0, r);
-        rows[r + 1] = pack_row(MONI_POS_MASK, MONI_HEAD_NONE, 0, r);
+        // hot symbols: the (up to) four codes with the most runs get their c-run count inside the row
+        {
+            for (uint32_t c = 0; c < MONI_MAX_SIGMA; ++c) K.hot_slot[c] = 0xFF;
+            std::vector<std::pair<uint64_t, uint32_t>> by_runs;
+            for (uint32_t c = 0; c < sigma; ++c) by_runs.push_back(std::make_pair(runs_letter[byte_of[c]], c));
+            std::sort(by_runs.begin(), by_runs.end(), std::greater<std::pair<uint64_t, uint32_t>>());
+            for (uint32_t s = 0; s < 4 && s < by_runs.size(); ++s) K.hot_slot[by_runs[s].second] = (uint8_t)s;
+        }
+        for (uint64_t k = 0; k <= r; ++k) {
+            rows[k] = k < r ? pack_row(f.starts[k], (uint32_t)code_of[f.heads[k]], lfbase[k], dest[k], f.starts[k + 1] - f.starts[k])
+                            : pack_row(n, MONI_HEAD_NONE, 0, r, MONI_ROW_LEN_SAT);
+            for (uint32_t c = 0; c < sigma; ++c) if (K.hot_slot[c] != 0xFF) rows[k].hot_cr[K.hot_slot[c]] = cr[k * sigma + c];
+        }
+        rows[r + 1] = pack_row(MONI_POS_MASK, MONI_HEAD_NONE, 0, r, MONI_ROW_LEN_SAT);
         // absent bytes: LF(pos, b) = F[b]   (moni.hpp:583-588)
         for (int b = 0; b < 256; ++b) {
             T.abs_pos[b] = f.F[b];

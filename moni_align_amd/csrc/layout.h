@@ -7,10 +7,14 @@
 // hot loop makes is precomputed per run, so one step costs one 32-byte row read, plus one 4-byte
 // and one 32-byte read on a threshold jump:
 //
-//   rows[k]   (k = 0..r+1)   start(40) head(4) dest(32) lfbase(40)              16 B / run
-//       LF(start of run k) = lfbase, dest = run containing it; rows[r] is the sentinel run
-//       [n, 2^40) that stands for rle_string::run_of_position(n) == R.
-//   cr[k*sigma + c]          number of c-runs before run k   (ms_rle_string::run_and_head_rank .first)
+//   rows[k]   (k = 0..r+1)   start(40) head(4) dest(32) lfbase(40) len(12) hot_cr[4]   32 B / run
+//       LF(start of run k) = lfbase, dest = run containing it; len = min(run length, 4095) so that
+//       "is pos still inside this run" needs no second row; hot_cr[s] = number of c-runs before run k
+//       for the four symbols with the most runs (A, C, G, T on DNA), the only ones a read can ask a
+//       threshold jump for; rows[r] is the sentinel run [n, 2^40) that stands for
+//       rle_string::run_of_position(n) == R.  One 32-byte aligned row = one 64-byte HBM request.
+//   cr[k*sigma + c]          the same count for every symbol (used only for symbols without a hot slot)
+//                            (ms_rle_string::run_and_head_rank .first)
 //   recs[base[c] + j]        for the j-th c-run (j = 0..Rc):                     32 B / run
 //       thr(40)   threshold of c-run j                      (thr_bv, thresholds_ds.hpp:478-497)
 //       ssa(40)   samples_start of c-run j                  (moni.hpp:614)
@@ -28,9 +32,11 @@
 #define MONI_HEAD_NONE 15
 #define MONI_POS_MASK ((1ull << 40) - 1)
 
-struct moni_row_t {   // 16 bytes
-    uint64_t w0;      // start | head << 40 | (dest >> 24) << 44
+#define MONI_ROW_LEN_SAT 4095u
+struct alignas(32) moni_row_t {   // 32 bytes
+    uint64_t w0;      // start | head << 40 | (dest >> 24) << 44 | min(len, 4095) << 52
     uint64_t w1;      // lfbase | (dest & 0xFFFFFF) << 40
+    uint32_t hot_cr[4];
 };
 
 struct moni_rec_t {   // 32 bytes
@@ -55,6 +61,7 @@ struct moni_consts_t {
     uint32_t pad;
     uint32_t rec_base[MONI_MAX_SIGMA + 1];
     uint32_t rec_cnt[MONI_MAX_SIGMA];             // Rc per code
+    uint8_t hot_slot[MONI_MAX_SIGMA];             // code -> slot in moni_row_t::hot_cr, 0xFF if none
 };
 
 // 256-entry byte tables (kept in one device buffer, staged to LDS by the kernels)

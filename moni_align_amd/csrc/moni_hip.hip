@@ -14,6 +14,7 @@
 
 #include "../../include/moni_hip.h"
 #include "image.hpp"
+#include "align_host.hpp"
 #include "layout.h"
 #include "seed_kernels.hip"
 #include "extz_kernels.hip"
@@ -35,6 +36,9 @@ struct moni_index {
     uint64_t* d_seq_starts = nullptr;
     uint32_t* d_name_id = nullptr;
     uint64_t bytes = 0;
+    // host copies for the host stages of the full path (chaining, MD/NM, SAM)
+    std::vector<uint8_t> h_text;
+    mh::HostIndex hix;
 };
 
 template <class Tp>
@@ -62,9 +66,12 @@ struct moni_ctx {
     DBuf<uint8_t> seq;
     DBuf<uint64_t> offs;
     uint64_t n_reads = 0, total_len = 0, max_len = 0;
+    std::vector<uint8_t> h_seq;              // host copy of the resident batch (SAM SEQ, MD/NM)
+    std::vector<uint64_t> h_offs;
     // workspaces
-    DBuf<uint64_t> ptr;
+    DBuf<uint64_t> ptr, pat;
     DBuf<uint32_t> cnt_m, cnt_s;
+    DBuf<moni_u64x2> mem_slots;
     DBuf<uint64_t> tot, read_mem_off;
     DBuf<moni_mem_t> mems;
     DBuf<uint32_t> aux;
@@ -130,8 +137,21 @@ int moni_index_create(const moni_flat_index_t* f, int device, moni_index_t** out
     I->K = img.K;
     std::vector<moni_tables_t> tv(1, img.T);
     std::vector<uint8_t> text(f->text, f->text + (f->n - 1));
+    text.resize(text.size() + 16, 0);            // text_byte() reads aligned 8-byte words
     std::vector<uint32_t> name_id(f->n_seq);
-    for (uint64_t i = 0; i < f->n_seq; ++i) name_id[i] = (uint32_t)i;
+    {   // names; sequences that share a name share a counter in the per-genome filter (std::map<std::string,...>, seed_finder.hpp:331-343)
+        const char* p = f->seq_names;
+        for (uint64_t i = 0; i < f->n_seq; ++i) {
+            std::string nm = p ? std::string(p) : ("seq" + std::to_string(i));
+            if (p) p += nm.size() + 1;
+            name_id[i] = (uint32_t)i;
+            for (uint64_t j = 0; j < i; ++j) if (I->hix.names[j] == nm) { name_id[i] = name_id[j]; break; }
+            I->hix.names.push_back(nm);
+        }
+    }
+    I->h_text.assign(f->text, f->text + (f->n - 1));
+    I->hix.n_text = f->n - 1; I->hix.w = f->w; I->hix.text = I->h_text.data();
+    I->hix.seq_starts.assign(f->seq_starts, f->seq_starts + f->n_seq + 1);
     if ((rc = upload(&I->d_tables, tv, I->bytes)) || (rc = upload(&I->d_rows, img.rows, I->bytes)) ||
         (rc = upload(&I->d_cr, img.cr, I->bytes)) || (rc = upload(&I->d_recs, img.recs, I->bytes)) ||
         (rc = upload(&I->d_phi, img.phi, I->bytes)) || (rc = upload(&I->d_phi_inv, img.phi_inv, I->bytes)) ||
@@ -151,7 +171,7 @@ int moni_index_load(const char* path, int device, moni_index_t** out) {
     char magic[8];
     uint64_t hdr[6];
     if (fread(magic, 1, 8, fp) != 8 || memcmp(magic, "MONIFLT2", 8) != 0 || fread(hdr, 8, 6, fp) != 6) { fclose(fp); return MONI_EIO; }
-    const uint64_t n = hdr[0], r = hdr[1], w = hdr[2], nseq = hdr[3];
+    const uint64_t n = hdr[0], r = hdr[1], w = hdr[2], nseq = hdr[3], nblob = hdr[4];
     std::vector<uint64_t> F(256), starts(r + 1), ssa(r), esa(r), thr(r), slcp(r), seq_starts(nseq + 1);
     std::vector<uint8_t> heads(r), text(n - 1);
     auto get = [&](void* dst, size_t bytes) {
@@ -164,12 +184,21 @@ int moni_index_load(const char* path, int device, moni_index_t** out) {
     bool ok = get(F.data(), 256 * 8) && get(heads.data(), r) && get(starts.data(), (r + 1) * 8) && get(ssa.data(), r * 8) &&
               get(esa.data(), r * 8) && get(thr.data(), r * 8) && get(slcp.data(), r * 8) && get(text.data(), n - 1) &&
               get(seq_starts.data(), (nseq + 1) * 8);
+    std::vector<char> blob(nblob + 8), names_flat;
+    ok = ok && get(blob.data(), nblob);
     fclose(fp);
     if (!ok) return MONI_EIO;
+    for (uint64_t i = 0, p = 0; i < nseq; ++i) {
+        uint64_t ln;
+        memcpy(&ln, blob.data() + p, 8);
+        names_flat.insert(names_flat.end(), blob.data() + p + 8, blob.data() + p + 8 + ln);
+        names_flat.push_back(0);
+        p += 8 + ln;
+    }
     moni_flat_index_t f;
     f.n = n; f.r = r; f.w = w; f.n_seq = nseq;
     f.F = F.data(); f.heads = heads.data(); f.starts = starts.data(); f.ssa = ssa.data(); f.esa = esa.data();
-    f.thr = thr.data(); f.slcp = slcp.data(); f.text = text.data(); f.seq_starts = seq_starts.data();
+    f.thr = thr.data(); f.slcp = slcp.data(); f.text = text.data(); f.seq_starts = seq_starts.data(); f.seq_names = names_flat.data();
     return moni_index_create(&f, device, out);
 }
 
@@ -203,7 +232,7 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->idx->device);
     (void)hipStreamSynchronize(c->stream);
-    c->seq.release(); c->offs.release(); c->ptr.release(); c->cnt_m.release(); c->cnt_s.release(); c->tot.release();
+    c->seq.release(); c->offs.release(); c->ptr.release(); c->pat.release(); c->cnt_m.release(); c->cnt_s.release(); c->mem_slots.release(); c->tot.release();
     c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
     c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
     c->dp_q.release(); c->dp_t.release(); c->dp_dir.release(); c->dp_tasks.release(); c->dp_res.release(); c->dp_cig.release();
@@ -235,6 +264,8 @@ int moni_reads_upload(moni_ctx_t* c, const moni_read_batch_t* b) {
     HIPCHK(hipMemcpyAsync(c->offs.p, rel.data(), (nr + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->n_reads = nr; c->total_len = total; c->max_len = mx;
+    c->h_seq.assign(b->seq + b->offsets[0], b->seq + b->offsets[0] + total);
+    c->h_offs = rel;
     c->n_mems = c->n_occs = 0;
     return MONI_OK;
 }
@@ -242,14 +273,17 @@ int moni_reads_upload(moni_ctx_t* c, const moni_read_batch_t* b) {
 static int ms_launch(moni_ctx* c) {
     moni_index* I = c->idx;
     const uint64_t n_tasks = 2 * c->n_reads;
+    const uint32_t n_words = (uint32_t)((c->max_len + 7) / 8);
     int rc = c->ptr.ensure(n_tasks * c->max_len + 1);
     if (rc) return rc;
+    if ((rc = c->pat.ensure(n_tasks * n_words + 1))) return rc;
+    const unsigned grid = (unsigned)((n_tasks + MS_BLOCK - 1) / MS_BLOCK);
+    if (n_tasks)
+        hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(MS_BLOCK), 0, c->stream, I->d_tables, c->seq.p, c->offs.p, n_tasks, n_words, c->pat.p);
     rec(c, EV_MS0);
-    if (n_tasks) {
-        const unsigned grid = (unsigned)((n_tasks + MS_BLOCK - 1) / MS_BLOCK);
+    if (n_tasks)
         hipLaunchKernelGGL(ms_lf_kernel, dim3(grid), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_rows, I->d_cr, I->d_recs,
-                           c->seq.p, c->offs.p, n_tasks, c->ptr.p, c->d_counters);
-    }
+                           c->pat.p, c->offs.p, n_tasks, c->ptr.p, c->d_counters);
     rec(c, EV_MS1);
     HIPCHK(hipGetLastError());
     return MONI_OK;
@@ -292,7 +326,7 @@ int moni_seed_run(moni_ctx_t* c, const moni_seed_params_t* prm) {
     const uint64_t nr = c->n_reads, n_tasks = 2 * nr;
     int rc;
     if ((rc = c->cnt_m.ensure(n_tasks + 2)) || (rc = c->cnt_s.ensure(n_tasks + 2)) || (rc = c->tot.ensure(nr + 2)) ||
-        (rc = c->read_mem_off.ensure(nr + 2)))
+        (rc = c->read_mem_off.ensure(nr + 2)) || (rc = c->mem_slots.ensure(n_tasks * MONI_MEM_SLOTS + 1)))
         return rc;
     HIPCHK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->d_small, 0, 16, c->stream));
@@ -302,9 +336,9 @@ int moni_seed_run(moni_ctx_t* c, const moni_seed_params_t* prm) {
     const uint32_t split_on = prm->report_mems ? 0u : 1u;
     rec(c, EV_MC0);
     if (n_tasks)
-        hipLaunchKernelGGL(mem_kernel<false>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, c->seq.p, c->offs.p,
+        hipLaunchKernelGGL(mem_kernel<false>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, c->pat.p, c->offs.p,
                            n_tasks, c->ptr.p, prm->min_len, split_on, c->cnt_m.p, c->cnt_s.p, (const uint64_t*)nullptr,
-                           (moni_mem_t*)nullptr, (uint32_t*)nullptr, c->d_counters);
+                           (moni_mem_t*)nullptr, (uint32_t*)nullptr, c->mem_slots.p, c->d_counters);
     rec(c, EV_MC1);
     hipLaunchKernelGGL(read_totals_kernel, dim3((unsigned)((nr + 1 + 255) / 256)), dim3(256), 0, c->stream, c->cnt_m.p, c->cnt_s.p, nr, c->tot.p);
     if ((rc = exclusive_scan_u64(c, c->tot.p, c->read_mem_off.p, nr + 1))) return rc;
@@ -319,9 +353,9 @@ int moni_seed_run(moni_ctx_t* c, const moni_seed_params_t* prm) {
         return rc;
     rec(c, EV_ME0);
     if (n_tasks)
-        hipLaunchKernelGGL(mem_kernel<true>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, c->seq.p, c->offs.p,
+        hipLaunchKernelGGL(mem_kernel<true>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, c->pat.p, c->offs.p,
                            n_tasks, c->ptr.p, prm->min_len, split_on, c->cnt_m.p, c->cnt_s.p, c->read_mem_off.p, c->mems.p, c->aux.p,
-                           c->d_counters);
+                           c->mem_slots.p, c->d_counters);
     rec(c, EV_ME1);
     occ_args_t A;
     A.phi.recs = I->d_phi; A.phi.dir = I->d_phi_dir; A.phi_inv.recs = I->d_phi_inv; A.phi_inv.dir = I->d_phi_inv_dir;
@@ -445,5 +479,72 @@ int moni_last_counters(moni_ctx_t* c, uint64_t out[4]) {
 }
 
 #include "extz_host.inc"
+
+}  // extern "C"
+
+namespace {
+// The product backend of the host pipeline: HIP kernels only.
+struct GpuBackend : mh::Backend {
+    moni_ctx* c;
+    explicit GpuBackend(moni_ctx* c_) : c(c_) {}
+    int seed(const moni_seed_params_t& p, std::vector<moni_mem_t>& mems, std::vector<uint64_t>& occs, std::vector<uint64_t>& rmo) override {
+        int rc = moni_seed_run(c, &p);
+        if (rc) return rc;
+        mems.resize(c->n_mems); occs.resize(c->n_occs); rmo.resize(c->n_reads + 1);
+        return moni_seed_fetch(c, mems.data(), occs.data(), rmo.data());
+    }
+    int dp(const moni_dp_params_t& p, const std::vector<moni_dp_task_t>& tasks, std::vector<moni_dp_result_t>& res, std::vector<uint32_t>& cig) override {
+        res.resize(tasks.size());
+        return dp_run(c, &p, nullptr, 0, nullptr, 0, tasks.data(), tasks.size(), res.data(), cig, true);
+    }
+};
+}  // namespace
+
+extern "C" {
+
+void moni_align_params_default(moni_align_params_t* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->min_len = 25; p->ext_len = 100; p->check_k = 5; p->region_dist = 10;
+    p->filter_seeds = 1; p->n_seeds_thr = 1000; p->filter_freq = 1; p->left_mem_check = 1; p->freq_thr = 0.5;
+    p->smatch = 2; p->smismatch = 4; p->gapo = 4; p->gapo2 = 13; p->gape = 2; p->gape2 = 1;
+    p->end_bonus = 400; p->w = -1; p->zdrop = -1;
+    p->max_dist_x = 500; p->max_dist_y = 100; p->max_iter = 10; p->max_pred = 5; p->min_chain_score = 40; p->min_chain_length = 1;
+    unsigned hc = std::thread::hardware_concurrency();
+    p->host_threads = hc ? (hc > 64 ? 64 : hc) : 1;
+}
+
+int moni_align_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
+                     const moni_align_params_t* prm, char** sam, uint64_t* sam_len, moni_align_stats_t* stats) {
+    if (!c || !b || !prm || !sam || !sam_len || (b->n_reads && (!names || !name_off))) return MONI_EINVAL;
+    int rc = moni_reads_upload(c, b);
+    if (rc) return rc;
+    GpuBackend be(c);
+    std::string out;
+    mh::AlignStats st;
+    const uint8_t* q = quals ? quals + b->offsets[0] : nullptr;
+    rc = mh::align_batch(be, c->idx->hix, *prm, c->h_seq.data(), c->h_offs.data(), c->n_reads, names, name_off, q, out, st);
+    if (rc) return rc;
+    *sam = (char*)malloc(out.size() + 1);
+    if (!*sam) return MONI_ENOMEM;
+    memcpy(*sam, out.data(), out.size());
+    (*sam)[out.size()] = 0;
+    *sam_len = out.size();
+    if (stats) {
+        stats->reads = st.reads; stats->aligned = st.aligned; stats->dp_tasks = st.dp_tasks; stats->dp_cells = st.dp_cells; stats->dp_rounds = st.dp_rounds;
+        stats->t_seed = st.t_seed; stats->t_chain = st.t_chain; stats->t_dp = st.t_dp; stats->t_host = st.t_host;
+    }
+    return MONI_OK;
+}
+
+int moni_sam_header(const moni_index_t* I, char** sam, uint64_t* sam_len) {
+    if (!I || !sam || !sam_len) return MONI_EINVAL;
+    const std::string h = I->hix.sam_header();
+    *sam = (char*)malloc(h.size() + 1);
+    if (!*sam) return MONI_ENOMEM;
+    memcpy(*sam, h.data(), h.size() + 1);
+    *sam_len = h.size();
+    return MONI_OK;
+}
 
 }  // extern "C"

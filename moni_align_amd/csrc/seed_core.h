@@ -27,6 +27,7 @@
 #define MONI_FLAG_SET(p) (*(p) = 1u)
 #endif
 
+#define MONI_MEM_SLOTS 4u
 struct alignas(16) moni_u64x2 { uint64_t x, y; };
 struct alignas(32) moni_u64x4 { uint64_t x, y, z, w; };
 
@@ -39,16 +40,34 @@ struct lds_tables_t {
 
 MONI_HD uint64_t row_start(const moni_row_t& x) { return x.w0 & MONI_POS_MASK; }
 MONI_HD uint32_t row_head(const moni_row_t& x) { return (uint32_t)(x.w0 >> 40) & 15u; }
+MONI_HD uint32_t row_len(const moni_row_t& x) { return (uint32_t)(x.w0 >> 52); }           // saturates at 4095
 MONI_HD uint64_t row_lfbase(const moni_row_t& x) { return x.w1 & MONI_POS_MASK; }
-MONI_HD uint32_t row_dest(const moni_row_t& x) { return (uint32_t)((x.w0 >> 44) << 24) | (uint32_t)(x.w1 >> 40); }
+MONI_HD uint32_t row_dest(const moni_row_t& x) { return (uint32_t)(((x.w0 >> 44) & 0xFFu) << 24) | (uint32_t)(x.w1 >> 40); }
 
 MONI_HD moni_row_t ld_row(const moni_row_t* __restrict__ rows, uint32_t k) {
-    const moni_u64x2 v = *reinterpret_cast<const moni_u64x2*>(rows + k);
-    moni_row_t x; x.w0 = v.x; x.w1 = v.y; return x;
+    const moni_u64x4 v = *reinterpret_cast<const moni_u64x4*>(rows + k);           // one 32-byte aligned load
+    moni_row_t x; x.w0 = v.x; x.w1 = v.y;
+    x.hot_cr[0] = (uint32_t)v.z; x.hot_cr[1] = (uint32_t)(v.z >> 32); x.hot_cr[2] = (uint32_t)v.w; x.hot_cr[3] = (uint32_t)(v.w >> 32);
+    return x;
+}
+// hot_cr[slot] without a runtime-indexed register array (which would live in scratch)
+MONI_HD uint32_t row_hot(const moni_row_t& x, uint32_t slot) {
+    return slot == 0 ? x.hot_cr[0] : slot == 1 ? x.hot_cr[1] : slot == 2 ? x.hot_cr[2] : x.hot_cr[3];
+}
+MONI_HD uint64_t ld_start(const moni_row_t* __restrict__ rows, uint32_t k) { return rows[k].w0 & MONI_POS_MASK; }
+
+// Is pos inside run A (which starts at or before pos)?  The row carries min(len, 4095); only runs at
+// least that long need the next row's start.
+MONI_HD bool in_run(const moni_row_t* __restrict__ rows, uint32_t run, const moni_row_t& A, uint64_t pos) {
+    const uint64_t off = pos - row_start(A);
+    const uint32_t len = row_len(A);
+    if (off < len) return true;
+    if (len < MONI_ROW_LEN_SAT) return false;
+    return pos < ld_start(rows, run + 1);
 }
 
 // Find the run with start[run] <= pos < start[run+1], starting from a guess.  The guess is the
-// destination run of the LF mapping, so the answer is normally the guess or its neighbour; a
+// destination run of the LF mapping, so the answer is normally the guess or a close successor; a
 // galloping search bounds the cost when a long run maps onto many short ones.
 MONI_HD void settle_run(const moni_row_t* __restrict__ rows, uint64_t r, uint64_t pos, uint32_t& run, moni_row_t& A) {
     A = ld_row(rows, run);
@@ -56,46 +75,87 @@ MONI_HD void settle_run(const moni_row_t* __restrict__ rows, uint64_t r, uint64_
         uint32_t step = 1;
         uint32_t hi = run;             // start[hi] > pos
         uint32_t lo = run >= step ? run - step : 0;
-        while (lo > 0 && (rows[lo].w0 & MONI_POS_MASK) > pos) { hi = lo; step <<= 1; lo = lo >= step ? lo - step : 0; }
-        while (hi - lo > 1) { uint32_t mid = lo + ((hi - lo) >> 1); if ((rows[mid].w0 & MONI_POS_MASK) <= pos) lo = mid; else hi = mid; }
+        while (lo > 0 && ld_start(rows, lo) > pos) { hi = lo; step <<= 1; lo = lo >= step ? lo - step : 0; }
+        while (hi - lo > 1) { uint32_t mid = lo + ((hi - lo) >> 1); if (ld_start(rows, mid) <= pos) lo = mid; else hi = mid; }
         run = lo; A = ld_row(rows, run);
         return;
     }
-    moni_row_t B = ld_row(rows, run + 1);
     int lin = 0;
-    while (pos >= row_start(B)) {
+    while (!in_run(rows, run, A, pos)) {
         if (++lin > 3) {
-            uint32_t lo = run + 1;     // start[lo] <= pos
+            uint32_t lo = run;         // start[lo] <= pos
             uint32_t step = 4;
             uint32_t hi = lo + step;
             const uint32_t top = (uint32_t)r + 1;   // start[r+1] = 2^40-1 > any pos
-            while (true) { if (hi > top) hi = top; if ((rows[hi].w0 & MONI_POS_MASK) > pos) break; lo = hi; step <<= 1; hi = lo + step; }
-            while (hi - lo > 1) { uint32_t mid = lo + ((hi - lo) >> 1); if ((rows[mid].w0 & MONI_POS_MASK) <= pos) lo = mid; else hi = mid; }
+            while (true) { if (hi > top) hi = top; if (ld_start(rows, hi) > pos) break; lo = hi; step <<= 1; hi = lo + step; }
+            while (hi - lo > 1) { uint32_t mid = lo + ((hi - lo) >> 1); if (ld_start(rows, mid) <= pos) lo = mid; else hi = mid; }
             run = lo; A = ld_row(rows, run);
             return;
         }
-        ++run; A = B; B = ld_row(rows, run + 1);
+        ++run; A = ld_row(rows, run);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packed patterns: pat[w * n_tasks + task] holds the bytes the LF loop consumes in steps 8w .. 8w+7 of a task
+// (step s reads pattern[m-1-s]; the reverse-complement strand is complemented here: aligner_ksw2.hpp:169-176,
+// kpbseq.h:150-168).  One coalesced 8-byte load per lane every 8 steps replaces a byte load per step.
+// ------------------------------------------------------------------------------------------------
+MONI_HD void pack_task(const lds_tables_t& L, const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t n_tasks,
+                       uint64_t task, uint32_t n_words, uint64_t* __restrict__ pat) {
+    const uint64_t read = task >> 1;
+    const uint32_t strand = (uint32_t)task & 1u;
+    const uint64_t off = offs[read];
+    const uint32_t m = (uint32_t)(offs[read + 1] - off);
+    for (uint32_t w = 0; w < n_words; ++w) {
+        uint64_t word = 0;
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t s = 8 * w + j;
+            if (s < m) {
+                const uint8_t raw = strand ? L.compl_tab[seq[off + s]] : seq[off + (m - 1 - s)];
+                word |= (uint64_t)raw << (8 * j);
+            }
+        }
+        pat[(uint64_t)w * n_tasks + task] = word;
+    }
+}
+
+// byte qi of the strand-oriented pattern (= the byte consumed at step m-1-qi), through a one-word register cache
+struct pat_cache_t { uint64_t word; uint32_t w; };
+MONI_HD uint8_t pat_byte(const uint64_t* __restrict__ pat, uint64_t n_tasks, uint64_t task, uint32_t m, uint32_t qi, pat_cache_t& c) {
+    const uint32_t s = m - 1 - qi;
+    const uint32_t w = s >> 3;
+    if (w != c.w) { c.word = pat[(uint64_t)w * n_tasks + task]; c.w = w; }
+    return (uint8_t)(c.word >> (8 * (s & 7)));
+}
+// byte a of the text through a one-word register cache (text is allocated 8-byte aligned and padded)
+struct text_cache_t { uint64_t word; uint64_t w; };
+MONI_HD uint8_t text_byte(const uint8_t* __restrict__ text, uint64_t a, text_cache_t& c) {
+    const uint64_t w = a >> 3;
+    if (w != c.w) { c.word = *reinterpret_cast<const uint64_t*>(text + (w << 3)); c.w = w; }
+    return (uint8_t)(c.word >> (8 * (a & 7)));
 }
 
 // ------------------------------------------------------------------------------------------------
 // ms_task: pointers[s * n_tasks + task] = sample after step s, i.e. ms_pointers[m-1-s];  task = 2*read + strand
 // ------------------------------------------------------------------------------------------------
 MONI_HD void ms_task(const moni_consts_t& K, const lds_tables_t& L, const moni_row_t* __restrict__ rows,
-                     const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs, const uint8_t* __restrict__ seq,
+                     const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs, const uint64_t* __restrict__ pat,
                      const uint64_t* __restrict__ offs, uint64_t n_tasks, uint64_t task, uint64_t* __restrict__ ptr_out,
                      unsigned long long& n_steps, unsigned long long& n_jumps) {
     const uint64_t read = task >> 1;
-    const uint32_t strand = (uint32_t)task & 1u;
     const uint64_t off = offs[read];
     const uint32_t m = (uint32_t)(offs[read + 1] - off);
+    uint64_t word = 0;
     uint32_t run = (uint32_t)K.r - 1;
     uint64_t pos = K.n - 1;
     uint64_t sample = K.last_run_sample;
     const uint32_t sigma = K.sigma;
     for (uint32_t s = 0; s < m; ++s) {
-        // pattern[m-1-s]: the forward strand reads seq backwards, the reverse complement reads it forwards
-        const uint8_t raw = strand ? L.compl_tab[seq[off + s]] : seq[off + (m - 1 - s)];
+        // pattern[m-1-s], already strand-resolved by pack_task
+        if ((s & 7u) == 0) word = pat[(uint64_t)(s >> 3) * n_tasks + task];
+        const uint8_t raw = (uint8_t)word;
+        word >>= 8;
         const uint32_t c = L.code[raw];
         if (c == MONI_CODE_ABSENT) {                     // n_c == 0   (moni.hpp:583-588)
             sample = 0;
@@ -110,7 +170,8 @@ MONI_HD void ms_task(const moni_consts_t& K, const lds_tables_t& L, const moni_r
                 run = row_dest(A);
             } else {                                     // threshold jump (moni.hpp:595-618)
                 ++n_jumps;
-                const uint32_t j = cr[(uint64_t)run * sigma + c];
+                const uint32_t hs = K.hot_slot[c];
+                const uint32_t j = hs != 0xFF ? row_hot(A, hs) : cr[(uint64_t)run * sigma + c];
                 const moni_u64x4 rv = *reinterpret_cast<const moni_u64x4*>(recs + K.rec_base[c] + j);
                 const uint64_t thr = rv.x & MONI_POS_MASK;
                 const uint32_t d = (uint32_t)((rv.x >> 40) << 24) | (uint32_t)(rv.y >> 40);
@@ -137,10 +198,10 @@ MONI_HD void ms_task(const moni_consts_t& K, const lds_tables_t& L, const moni_r
 // ------------------------------------------------------------------------------------------------
 template <bool EMIT>
 MONI_HD void mem_task(const moni_consts_t& K, const lds_tables_t& L, const uint8_t* __restrict__ text,
-                      const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t n_tasks, uint64_t task,
+                      const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, uint64_t n_tasks, uint64_t task,
                       const uint64_t* __restrict__ ptr, uint32_t min_len, uint32_t split_on, uint32_t* __restrict__ cnt_m,
                       uint32_t* __restrict__ cnt_s, const uint64_t* __restrict__ read_mem_off, moni_mem_t* __restrict__ mems,
-                      uint32_t* __restrict__ aux, unsigned long long& n_cmp) {
+                      uint32_t* __restrict__ aux, moni_u64x2* __restrict__ slots, unsigned long long& n_cmp) {
     const uint64_t read = task >> 1;
     const uint32_t strand = (uint32_t)task & 1u;
     const uint64_t off = offs[read];
@@ -155,43 +216,58 @@ MONI_HD void mem_task(const moni_consts_t& K, const lds_tables_t& L, const uint8
         k_read = (uint64_t)cnt_m[2 * read] + cnt_m[2 * read + 1];
         if (strand) { j0 = cnt_m[2 * read]; s0 = cnt_s[2 * read]; }
     }
+    // one MEM found at read offset i with pointer pos and length l
+    auto found = [&](uint64_t pos, uint64_t l, uint32_t i) {
+        const bool split = split_on && l >= ((uint64_t)min_len << 1);
+        if (EMIT) {
+            const uint64_t g = base + j0 + km;
+            moni_mem_t M;
+            M.pos = pos; M.len = (uint32_t)l; M.idx = i; M.rpos = (uint32_t)(i + l - 1); M.mate = strand ? 2u : 0u;
+            M.total_occ = 0; M.num_filtered = 0; M.occ_off = 0; M.occ_cnt = 0; M.read = (uint32_t)read;
+            mems[g] = M;
+            if (split) {
+                const uint64_t hb = base + k_read + 2 * (s0 + ks);
+                const uint32_t ll = (uint32_t)(l >> 1);
+                moni_mem_t B = M;                    // left half: pos is the parent's upper suffix (occ_task)
+                B.pos = 0; B.len = ll; B.rpos = (uint32_t)((i + l - 1) - l + ll);
+                mems[hb] = B;
+                moni_mem_t C = M;                    // right half (seed_finder.hpp:296-298)
+                C.pos = pos + ll; C.len = (uint32_t)(l - ll); C.idx = i + ll;
+                mems[hb + 1] = C;
+                aux[g] = (uint32_t)(hb - base);
+                aux[hb] = 0xFFFFFFFEu;
+                aux[hb + 1] = 0xFFFFFFFDu;
+            } else {
+                aux[g] = 0xFFFFFFFFu;
+            }
+        } else if (km < MONI_MEM_SLOTS) {            // remember the first few MEMs so the emit pass need not redo the text walk
+            moni_u64x2 sl; sl.x = pos; sl.y = (l << 32) | i;
+            slots[task * MONI_MEM_SLOTS + km] = sl;
+        }
+        ++km;
+        if (split) ++ks;
+    };
+    if (EMIT && cnt_m[task] <= MONI_MEM_SLOTS) {
+        const uint32_t cnt = cnt_m[task];
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const moni_u64x2 sl = slots[task * MONI_MEM_SLOTS + k];
+            found(sl.x, sl.y >> 32, (uint32_t)sl.y);
+        }
+        return;
+    }
+    pat_cache_t pc; pc.w = 0xFFFFFFFFu; pc.word = 0;
+    text_cache_t tc; tc.w = ~0ull; tc.word = 0;
     for (uint32_t i = 0; i < m; ++i) {
         const uint64_t pos = ptr[(uint64_t)(m - 1 - i) * n_tasks + task];
         while (pos != prev_pos_plus_one && (i + l) < m && (pos + l) < n) {
             const uint32_t qi = (uint32_t)(i + l);
-            const uint8_t qc = strand ? L.compl_tab[seq[off + (m - 1 - qi)]] : seq[off + qi];
+            const uint8_t qc = pat_byte(pat, n_tasks, task, m, qi, pc);
             ++n_cmp;
-            if (qc != text[pos + l]) break;
+            if (qc != text_byte(text, pos + l, tc)) break;
             if (qc == 'N') n_Ns++; else n_Ns = 0;
             ++l;
         }
-        if (l >= pl && n_Ns < l && l >= min_len) {
-            const bool split = split_on && l >= ((uint64_t)min_len << 1);
-            if (EMIT) {
-                const uint64_t g = base + j0 + km;
-                moni_mem_t M;
-                M.pos = pos; M.len = (uint32_t)l; M.idx = i; M.rpos = (uint32_t)(i + l - 1); M.mate = strand ? 2u : 0u;
-                M.total_occ = 0; M.num_filtered = 0; M.occ_off = 0; M.occ_cnt = 0; M.read = (uint32_t)read;
-                mems[g] = M;
-                if (split) {
-                    const uint64_t hb = base + k_read + 2 * (s0 + ks);
-                    const uint32_t ll = (uint32_t)(l >> 1);
-                    moni_mem_t B = M;                    // left half: pos is the parent's upper suffix (occ_task)
-                    B.pos = 0; B.len = ll; B.rpos = (uint32_t)((i + l - 1) - l + ll);
-                    mems[hb] = B;
-                    moni_mem_t C = M;                    // right half (seed_finder.hpp:296-298)
-                    C.pos = pos + ll; C.len = (uint32_t)(l - ll); C.idx = i + ll;
-                    mems[hb + 1] = C;
-                    aux[g] = (uint32_t)(hb - base);
-                    aux[hb] = 0xFFFFFFFEu;
-                    aux[hb + 1] = 0xFFFFFFFDu;
-                } else {
-                    aux[g] = 0xFFFFFFFFu;
-                }
-            }
-            ++km;
-            if (split) ++ks;
-        }
+        if (l >= pl && n_Ns < l && l >= min_len) found(pos, l, i);
         pl = l;
         l = (l == 0 ? 0 : (l - 1));
         prev_pos_plus_one = pos + 1;

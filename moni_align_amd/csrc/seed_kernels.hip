@@ -29,15 +29,24 @@ __device__ __forceinline__ void wave_add(unsigned long long v, unsigned long lon
 }
 
 extern "C" __global__ void __launch_bounds__(MS_BLOCK)
+pack_kernel(const moni_tables_t* __restrict__ T, const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t n_tasks,
+            uint32_t n_words, uint64_t* __restrict__ pat) {
+    __shared__ lds_tables_t L;
+    load_tables(L, T);
+    const uint64_t task = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
+    if (task < n_tasks) pack_task(L, seq, offs, n_tasks, task, n_words, pat);
+}
+
+extern "C" __global__ void __launch_bounds__(MS_BLOCK)
 ms_lf_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const moni_row_t* __restrict__ rows,
              const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs,
-             const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t n_tasks,
+             const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, uint64_t n_tasks,
              uint64_t* __restrict__ ptr_out, unsigned long long* __restrict__ counters) {
     __shared__ lds_tables_t L;
     load_tables(L, T);
     const uint64_t task = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
     unsigned long long n_steps = 0, n_jumps = 0;
-    if (task < n_tasks) ms_task(K, L, rows, cr, recs, seq, offs, n_tasks, task, ptr_out, n_steps, n_jumps);
+    if (task < n_tasks) ms_task(K, L, rows, cr, recs, pat, offs, n_tasks, task, ptr_out, n_steps, n_jumps);
     wave_add(n_steps, &counters[0]);
     wave_add(n_jumps, &counters[1]);
 }
@@ -45,17 +54,17 @@ ms_lf_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const m
 template <bool EMIT>
 __global__ void __launch_bounds__(MS_BLOCK)
 mem_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const uint8_t* __restrict__ text,
-           const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t n_tasks,
+           const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, uint64_t n_tasks,
            const uint64_t* __restrict__ ptr, uint32_t min_len, uint32_t split_on,
            uint32_t* __restrict__ cnt_m, uint32_t* __restrict__ cnt_s,
            const uint64_t* __restrict__ read_mem_off, moni_mem_t* __restrict__ mems, uint32_t* __restrict__ aux,
-           unsigned long long* __restrict__ counters) {
+           moni_u64x2* __restrict__ slots, unsigned long long* __restrict__ counters) {
     __shared__ lds_tables_t L;
     load_tables(L, T);
     const uint64_t task = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
     unsigned long long n_cmp = 0;
     if (task < n_tasks)
-        mem_task<EMIT>(K, L, text, seq, offs, n_tasks, task, ptr, min_len, split_on, cnt_m, cnt_s, read_mem_off, mems, aux, n_cmp);
+        mem_task<EMIT>(K, L, text, pat, offs, n_tasks, task, ptr, min_len, split_on, cnt_m, cnt_s, read_mem_off, mems, aux, slots, n_cmp);
     if (!EMIT) wave_add(n_cmp, &counters[3]);
 }
 

@@ -10,6 +10,8 @@
 
 #include "../../moni_align_amd/csrc/image.hpp"
 #include "../../moni_align_amd/csrc/seed_core.h"
+#include "../../moni_align_amd/csrc/align_host.hpp"
+#include "../../oracle/ksw2.hpp"      // CPU stand-in for extz_kernel in this harness (tests may use the oracle)
 
 struct Sim {
     HostImage img;
@@ -22,6 +24,7 @@ struct Sim {
     std::vector<uint64_t> occs, read_mem_off;
     uint64_t counters[4];
     uint64_t max_len = 0, n_reads = 0;
+    mh::HostIndex hix;
 };
 
 extern "C" {
@@ -30,12 +33,17 @@ void* sim_create(const moni_flat_index_t* f) {
     Sim* S = new Sim();
     if (S->img.build(*f)) { fprintf(stderr, "host_sim: %s\n", S->img.err.c_str()); delete S; return nullptr; }
     S->text.assign(f->text, f->text + f->n - 1);
+    S->text.resize(S->text.size() + 16, 0);
     S->name_id.resize(f->n_seq);
     for (uint64_t i = 0; i < f->n_seq; ++i) S->name_id[i] = (uint32_t)i;
     memcpy(S->L.code, S->img.T.code, 256);
     memcpy(S->L.compl_tab, S->img.T.compl_tab, 256);
     memcpy(S->L.abs_run, S->img.T.abs_run, sizeof(S->L.abs_run));
     memcpy(S->L.abs_pos, S->img.T.abs_pos, sizeof(S->L.abs_pos));
+    S->hix.n_text = f->n - 1; S->hix.w = f->w; S->hix.text = S->text.data();
+    S->hix.seq_starts.assign(f->seq_starts, f->seq_starts + f->n_seq + 1);
+    const char* p = f->seq_names;
+    for (uint64_t i = 0; i < f->n_seq; ++i) { std::string nm = p ? std::string(p) : ("seq" + std::to_string(i)); if (p) p += nm.size() + 1; S->hix.names.push_back(nm); }
     return S;
 }
 void sim_destroy(void* s) { delete (Sim*)s; }
@@ -50,13 +58,17 @@ int sim_seed_run(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_r
     S->max_len = mx; S->n_reads = n_reads;
     S->ptr.assign(n_tasks * mx + 1, 0);
     unsigned long long cnt[4] = {0, 0, 0, 0};
+    const uint32_t n_words = (uint32_t)((mx + 7) / 8);
+    std::vector<uint64_t> pat(n_tasks * n_words + 1);
+    for (uint64_t t = 0; t < n_tasks; ++t) pack_task(S->L, seq, offs, n_tasks, t, n_words, pat.data());
     for (uint64_t t = 0; t < n_tasks; ++t)
-        ms_task(K, S->L, S->img.rows.data(), S->img.cr.data(), S->img.recs.data(), seq, offs, n_tasks, t, S->ptr.data(), cnt[0], cnt[1]);
+        ms_task(K, S->L, S->img.rows.data(), S->img.cr.data(), S->img.recs.data(), pat.data(), offs, n_tasks, t, S->ptr.data(), cnt[0], cnt[1]);
     std::vector<uint32_t> cnt_m(n_tasks + 1), cnt_s(n_tasks + 1);
+    std::vector<moni_u64x2> slots(n_tasks * MONI_MEM_SLOTS + 1);
     const uint32_t split_on = prm->report_mems ? 0 : 1;
     for (uint64_t t = 0; t < n_tasks; ++t)
-        mem_task<false>(K, S->L, S->text.data(), seq, offs, n_tasks, t, S->ptr.data(), prm->min_len, split_on, cnt_m.data(), cnt_s.data(),
-                        nullptr, nullptr, nullptr, cnt[3]);
+        mem_task<false>(K, S->L, S->text.data(), pat.data(), offs, n_tasks, t, S->ptr.data(), prm->min_len, split_on, cnt_m.data(), cnt_s.data(),
+                        nullptr, nullptr, nullptr, slots.data(), cnt[3]);
     S->read_mem_off.assign(n_reads + 1, 0);
     for (uint64_t r = 0; r < n_reads; ++r)
         S->read_mem_off[r + 1] = S->read_mem_off[r] + cnt_m[2 * r] + cnt_m[2 * r + 1] + 2ull * (cnt_s[2 * r] + cnt_s[2 * r + 1]);
@@ -65,8 +77,8 @@ int sim_seed_run(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_r
     std::vector<uint32_t> aux(n_mems + 1);
     unsigned long long dummy = 0;
     for (uint64_t t = 0; t < n_tasks; ++t)
-        mem_task<true>(K, S->L, S->text.data(), seq, offs, n_tasks, t, S->ptr.data(), prm->min_len, split_on, cnt_m.data(), cnt_s.data(),
-                       S->read_mem_off.data(), S->mems.data(), aux.data(), dummy);
+        mem_task<true>(K, S->L, S->text.data(), pat.data(), offs, n_tasks, t, S->ptr.data(), prm->min_len, split_on, cnt_m.data(), cnt_s.data(),
+                       S->read_mem_off.data(), S->mems.data(), aux.data(), slots.data(), dummy);
     std::vector<uint64_t> tmp(n_mems * tmp_cap + 1), lowers(n_mems + 1);
     std::vector<uint32_t> pool((size_t)pool_rows * K.n_seq + 1);
     uint32_t small[2] = {0, 0};
@@ -118,5 +130,65 @@ void sim_phi(void* s, uint64_t i, int inverse, uint64_t* out2) {
     P.dir = inverse ? S->img.phi_inv_dir.data() : S->img.phi_dir.data();
     phi_step(P, S->img.K, i, out2[0], out2[1]);
 }
+
+// ---- the host pipeline (align_host.hpp) driven by CPU stand-ins: replayed seed kernels + the oracle's ksw2 ----
+struct SimBackend : mh::Backend {
+    Sim* S; const uint8_t* seq; const uint64_t* offs; uint64_t n_reads;
+    int seed(const moni_seed_params_t& p, std::vector<moni_mem_t>& mems, std::vector<uint64_t>& occs, std::vector<uint64_t>& rmo) override {
+        int rc = sim_seed_run(S, seq, offs, n_reads, &p, 16, 4096);
+        if (rc) return rc;
+        mems = S->mems; occs = S->occs; rmo = S->read_mem_off;
+        return 0;
+    }
+    int dp(const moni_dp_params_t& p, const std::vector<moni_dp_task_t>& tasks, std::vector<moni_dp_result_t>& res, std::vector<uint32_t>& cig) override {
+        res.resize(tasks.size());
+        cig.clear();
+        for (size_t i = 0; i < tasks.size(); ++i) {
+            const moni_dp_task_t& t = tasks[i];
+            std::vector<uint8_t> q(t.qlen > 0 ? t.qlen : 0), tg(t.tlen > 0 ? t.tlen : 0);
+            for (int k = 0; k < t.qlen; ++k) {
+                uint8_t c = mh::nt4_of(seq[(t.reserved & DP_Q_REV) ? t.q_off - k : t.q_off + k]);
+                if ((t.reserved & DP_Q_COMP) && c < 4) c = 3 - c;
+                q[k] = c;
+            }
+            for (int k = 0; k < t.tlen; ++k) {
+                const uint64_t a = (t.reserved & DP_T_REV) ? t.t_off - k : t.t_off + k;
+                tg[k] = mh::nt4_of(a < S->hix.n_text ? S->text[a] : 0);
+            }
+            oracle::ksw_extz_t ez;
+            memset(&ez, 0, sizeof ez);
+            oracle::ksw_extz2_restated(t.qlen, q.data(), t.tlen, tg.data(), p.m, p.mat, p.q, p.e, p.w, p.zdrop, p.end_bonus, t.flag, &ez);
+            moni_dp_result_t& r = res[i];
+            r.max = (int32_t)ez.max; r.max_q = ez.max_q; r.max_t = ez.max_t; r.mqe = ez.mqe; r.mqe_t = ez.mqe_t; r.mte = ez.mte; r.mte_q = ez.mte_q;
+            r.score = ez.score; r.reach_end = ez.reach_end; r.zdropped = ez.zdropped; r.n_cigar = ez.n_cigar; r.cigar_off = (uint32_t)cig.size();
+            for (int k = 0; k < ez.n_cigar; ++k) cig.push_back(ez.cigar[k]);
+            free(ez.cigar);
+        }
+        return 0;
+    }
+};
+
+char* sim_align_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_reads, const uint8_t* names, const uint64_t* name_off,
+                      const uint8_t* quals, int threads, uint64_t* out_len, uint64_t* stats5) {
+    Sim* S = (Sim*)s;
+    SimBackend be;
+    be.S = S; be.seq = seq; be.offs = offs; be.n_reads = n_reads;
+    moni_align_params_t P;
+    memset(&P, 0, sizeof P);
+    P.min_len = 25; P.ext_len = 100; P.check_k = 5; P.region_dist = 10; P.filter_seeds = 1; P.n_seeds_thr = 1000; P.filter_freq = 1;
+    P.left_mem_check = 1; P.freq_thr = 0.5; P.smatch = 2; P.smismatch = 4; P.gapo = 4; P.gapo2 = 13; P.gape = 2; P.gape2 = 1;
+    P.end_bonus = 400; P.w = -1; P.zdrop = -1; P.max_dist_x = 500; P.max_dist_y = 100; P.max_iter = 10; P.max_pred = 5;
+    P.min_chain_score = 40; P.min_chain_length = 1; P.host_threads = threads;
+    std::string out;
+    mh::AlignStats st;
+    int rc = mh::align_batch(be, S->hix, P, seq, offs, n_reads, names, name_off, quals, out, st);
+    if (rc) return nullptr;
+    char* buf = (char*)malloc(out.size() + 1);
+    memcpy(buf, out.data(), out.size() + 1);
+    *out_len = out.size();
+    if (stats5) { stats5[0] = st.reads; stats5[1] = st.aligned; stats5[2] = st.dp_tasks; stats5[3] = st.dp_cells; stats5[4] = st.dp_rounds; }
+    return buf;
+}
+void sim_free(void* p) { free(p); }
 
 }  // extern "C"

@@ -16,9 +16,10 @@ def lib():
     global _lib
     if _lib is None:
         so = os.path.join(HERE, "libhost_sim.so")
-        srcs = [os.path.join(HERE, "host_sim.cpp")] + [os.path.join(capi.CSRC, f) for f in ("seed_core.h", "image.hpp", "layout.h")]
+        srcs = [os.path.join(HERE, "host_sim.cpp"), os.path.join(ROOT, "oracle", "ksw2.hpp")] + \
+               [os.path.join(capi.CSRC, f) for f in ("seed_core.h", "image.hpp", "layout.h", "align_host.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(HERE, "host_sim.cpp")])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(HERE, "host_sim.cpp")])
         L = C.CDLL(so)
         L.sim_create.restype = C.c_void_p
         L.sim_create.argtypes = [C.POINTER(capi.FlatIndexC)]
@@ -31,6 +32,10 @@ def lib():
         L.sim_fetch.argtypes = [C.c_void_p] * 5
         L.sim_fetch_pointers.argtypes = [C.c_void_p] * 3
         L.sim_phi.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+        L.sim_align_batch.restype = C.c_void_p
+        L.sim_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.POINTER(C.c_uint64), C.c_void_p]
+        L.sim_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -64,3 +69,22 @@ class Sim:
         out = np.empty(2, dtype=np.uint64)
         lib().sim_phi(self.h, i, int(inverse), out.ctypes.data)
         return int(out[0]), int(out[1])
+
+
+    def align_batch(self, seq, offsets, names, name_off, quals=None, threads=1):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        names = np.ascontiguousarray(names, dtype=np.uint8)
+        name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
+        if quals is not None:
+            quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        ln = C.c_uint64()
+        st = np.zeros(5, dtype=np.uint64)
+        p = lib().sim_align_batch(self.h, seq.ctypes.data, offsets.ctypes.data, len(offsets) - 1, names.ctypes.data, name_off.ctypes.data,
+                                  quals.ctypes.data if quals is not None else None, threads, C.byref(ln), st.ctypes.data)
+        if not p:
+            raise RuntimeError("sim_align_batch failed")
+        try:
+            return C.string_at(p, ln.value), st
+        finally:
+            lib().sim_free(p)

@@ -28,6 +28,18 @@ def log(*a):
     print("[bench %s]" % time.strftime("%H:%M:%S"), *a, file=sys.stderr, flush=True)
 
 
+def host_cpus() -> int:
+    """CPUs this job may use: affinity and cgroup quota (the GPU box gives each job a CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 128))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,6 +52,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cache", default="/tmp/moni_bench_cache")
+    ap.add_argument("--full-path-reads", type=int, default=200000,
+                    help="also time moni_align_batch (seeding + HIP ksw2 extension + host stages + SAM) on this many reads; 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -141,7 +155,7 @@ def main():
         if world == 1 and not args.no_cpu:
             from oracle import orc
             oidx = orc.OracleIndex(fi=fi)
-            threads = min(os.cpu_count() or 1, 64)
+            threads = host_cpus()
             probe = 2000
             t1 = time.perf_counter()
             oidx.seed_batch(reads[:probe].reshape(-1), offs[:probe + 1], 25, True, 1000, threads=threads)
@@ -159,6 +173,33 @@ def main():
             out["cpu_baseline"] = {"value": n_cpu / dt, "unit": "reads/s", "cores": threads, "kind": "port",
                                    "sample": "first %d reads of the same batch, same stage, oracle/seed.hpp with %d threads" % (n_cpu, threads),
                                    "gpu_matches_cpu_on_sample": bool(same)}
+        out["host"] = {"cpus_usable": host_cpus(), "cpu_count": os.cpu_count()}
+        if world == 1 and args.full_path_reads > 0:
+            # BASELINE.json configs[2]: the whole SE path (host buffers in, SAM text out: PCIe and host stages included)
+            from oracle import orc as _orc
+            nfp = min(args.full_path_reads, args.reads)
+            names, noff = _orc.make_names(nfp)
+            quals = np.full(nfp * L, ord("I"), dtype=np.uint8)
+            ctx.align_batch(reads[:2000].reshape(-1), offs[:2001], names[:int(noff[2000])], noff[:2001], quals[:2000 * L])   # warm-up
+            t1 = time.perf_counter()
+            sam, stf = ctx.align_batch(reads[:nfp].reshape(-1), offs[:nfp + 1], names, noff, quals)
+            dtf = time.perf_counter() - t1
+            out["full_path"] = {"workload": "BASELINE.json configs[2]: seeding + HIP ksw2 extension + chaining/MAPQ/SAM on host, %d reads, "
+                                            "host buffers in / SAM text out" % nfp,
+                                "value": nfp / dtf, "unit": "reads/s", "aligned": stf["aligned"], "dp_tasks": stf["dp_tasks"],
+                                "dp_cells": stf["dp_cells"], "dp_rounds": stf["dp_rounds"], "host_threads": host_cpus(),
+                                "seconds": {"seed": stf["t_seed"], "chain": stf["t_chain"], "dp": stf["t_dp"], "host_other": stf["t_host"]},
+                                "gcups_dp_stage": stf["dp_cells"] / stf["t_dp"] / 1e9 if stf["t_dp"] > 0 else None}
+            if not args.no_cpu:
+                ncpu = min(nfp, 20000)
+                t1 = time.perf_counter()
+                wsam, wc = _orc.align_batch(oidx, reads[:ncpu].reshape(-1), offs[:ncpu + 1], names[:int(noff[ncpu])], noff[:ncpu + 1],
+                                            quals[:ncpu * L], threads=threads)
+                dtc = time.perf_counter() - t1
+                head = b"\n".join(sam.split(b"\n")[:ncpu]) + b"\n"
+                out["full_path"]["cpu_baseline"] = {"value": ncpu / dtc, "unit": "reads/s", "cores": threads, "kind": "port",
+                                                    "sample": "first %d reads, oracle/align.hpp" % ncpu,
+                                                    "sam_identical_on_sample": bool(head == wsam)}
         print(json.dumps(out), flush=True)
     ctx.close()
     idx.close()

@@ -24,7 +24,9 @@
 #include <cstdio>
 #include <chrono>
 #include <cstring>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <set>
 #include <string>
 #include <thread>
@@ -574,12 +576,45 @@ struct Aligner {
     }
 };
 
-template <class Fn>
-static void parallel_for(size_t n, int threads, Fn fn) {
-    if (threads <= 1 || n < 2) { fn(0, (size_t)0, n); return; }
+// Persistent worker pool for the host stages: a batch goes through ~100 short parallel phases, far too many to pay a
+// thread spawn each time.
+class Pool {
     std::vector<std::thread> th;
-    for (int t = 0; t < threads; ++t) th.emplace_back([&, t]() { fn(t, n * t / threads, n * (t + 1) / threads); });
-    for (auto& x : th) x.join();
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::function<void(int)> job;
+    uint64_t gen = 0;
+    int pending = 0;
+    bool quit = false;
+public:
+    const int n;
+    explicit Pool(int n_) : n(n_ < 1 ? 1 : n_) {
+        for (int t = 1; t < n; ++t) th.emplace_back([this, t]() {
+            uint64_t seen = 0;
+            while (true) {
+                std::function<void(int)> j;
+                { std::unique_lock<std::mutex> lk(mu); cv_go.wait(lk, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; j = job; }
+                j(t);
+                { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv_done.notify_one(); }
+            }
+        });
+    }
+    ~Pool() { { std::lock_guard<std::mutex> lk(mu); quit = true; } cv_go.notify_all(); for (auto& x : th) x.join(); }
+    void run(const std::function<void(int)>& fn) {
+        if (n == 1) { fn(0); return; }
+        { std::lock_guard<std::mutex> lk(mu); job = fn; pending = n - 1; ++gen; }
+        cv_go.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+
+template <class Fn>
+static void parallel_for(Pool& pool, size_t n, Fn fn) {
+    if (pool.n <= 1 || n < 2) { fn(0, (size_t)0, n); return; }
+    const int T = pool.n;
+    pool.run([&](int t) { const size_t lo = n * t / T, hi = n * (t + 1) / T; if (lo < hi) fn(t, lo, hi); });
 }
 
 struct AlignStats { uint64_t reads = 0, aligned = 0, dp_tasks = 0, dp_cells = 0, dp_rounds = 0; double t_seed = 0, t_chain = 0, t_dp = 0, t_host = 0; };
@@ -594,6 +629,7 @@ static int align_batch(Backend& be, const HostIndex& ix, const moni_align_params
                        uint64_t n_reads, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals, std::string& sam_out,
                        AlignStats& st) {
     const int T = P.host_threads > 0 ? (int)P.host_threads : 1;
+    Pool pool(T);
     std::vector<moni_mem_t> gm;
     std::vector<uint64_t> go, rmo;
     moni_seed_params_t sp;
@@ -606,7 +642,7 @@ static int align_batch(Backend& be, const HostIndex& ix, const moni_align_params
     Aligner A(ix, P, reads, offs);
     std::vector<ReadState> RS(n_reads);
     // frequency filter + chaining (aligner_ksw2.hpp:342, 382, 394)
-    parallel_for(n_reads, T, [&](int, size_t lo, size_t hi) {
+    parallel_for(pool, n_reads, [&](int, size_t lo, size_t hi) {
         for (size_t r = lo; r < hi; ++r) {
             ReadState& R = RS[r];
             R.off = offs[r] - offs[0]; R.m = (uint32_t)(offs[r + 1] - offs[r]);
@@ -700,7 +736,7 @@ static int align_batch(Backend& be, const HostIndex& ix, const moni_align_params
     {
         std::vector<uint32_t> act;
         for (size_t r = 0; r < n_reads; ++r) if (RS[r].stage != ReadState::DONE) act.push_back((uint32_t)r);
-        parallel_for(act.size(), T, [&](int t, size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) with_queue(t, act[k]); });
+        parallel_for(pool, act.size(), [&](int t, size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) with_queue(t, act[k]); });
     }
     while (true) {
         // merge the per-thread queues into one batch
@@ -723,11 +759,11 @@ static int align_batch(Backend& be, const HostIndex& ix, const moni_align_params
         st.t_dp += now_s() - t0;
         t0 = now_s();
         // consume results; reads that continue queue their next problems for the next batch
-        parallel_for(waiting.size(), T, [&](int t, size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) with_queue(t, waiting[k]); });
+        parallel_for(pool, waiting.size(), [&](int t, size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) with_queue(t, waiting[k]); });
     }
     // SAM text in read order (align_reads_dispatcher.hpp:346-357, sam.hpp:144-188)
     std::vector<std::string> parts(T);
-    parallel_for(n_reads, T, [&](int t, size_t lo, size_t hi) {
+    parallel_for(pool, n_reads, [&](int t, size_t lo, size_t hi) {
         std::string& out = parts[t];
         std::string seq, qual, name;
         for (size_t r = lo; r < hi; ++r) {

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
 
+#include <sched.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -83,6 +84,7 @@ struct moni_ctx {
     uint64_t n_mems = 0, n_occs = 0;
     uint32_t tmp_cap = 16;
     uint32_t pool_rows = 4096;
+    int ms_variant = 0;                        // 0 = default; MONI_MS_VARIANT selects an (interleave, occupancy) variant for tuning
     // dp
     DBuf<uint8_t> dp_q, dp_t, dp_dir;
     DBuf<moni_dp_task_t> dp_tasks;
@@ -218,6 +220,7 @@ int moni_ctx_create(moni_index_t* I, moni_ctx_t** out) {
     HIPCHK(hipSetDevice(I->device));
     moni_ctx* c = new moni_ctx();
     c->idx = I;
+    if (const char* v = getenv("MONI_MS_VARIANT")) c->ms_variant = atoi(v);
     HIPCHK(hipStreamCreate(&c->stream));
     for (int i = 0; i < EV_N; ++i) { HIPCHK(hipEventCreate(&c->ev[i])); c->ev_valid[i] = false; }
     HIPCHK(hipMalloc((void**)&c->d_small, 16));
@@ -279,11 +282,22 @@ static int ms_launch(moni_ctx* c) {
     if ((rc = c->pat.ensure(n_tasks * n_words + 1))) return rc;
     const unsigned grid = (unsigned)((n_tasks + MS_BLOCK - 1) / MS_BLOCK);
     if (n_tasks)
-        hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(MS_BLOCK), 0, c->stream, I->d_tables, c->seq.p, c->offs.p, n_tasks, n_words, c->pat.p);
+        hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, c->seq.p, c->offs.p, n_tasks, n_words, c->pat.p);
     rec(c, EV_MS0);
-    if (n_tasks)
-        hipLaunchKernelGGL(ms_lf_kernel, dim3(grid), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_rows, I->d_cr, I->d_recs,
-                           c->pat.p, c->offs.p, n_tasks, c->ptr.p, c->d_counters);
+    if (n_tasks) {
+#define MS_LAUNCH(NCH, MINW) do { const uint64_t nl = (n_tasks + (NCH) - 1) / (NCH); \
+        hipLaunchKernelGGL((ms_lf_kernel<NCH, MINW>), dim3((unsigned)((nl + MS_BLOCK - 1) / MS_BLOCK)), dim3(MS_BLOCK), 0, c->stream, \
+                           I->K, I->d_tables, I->d_rows, I->d_cr, I->d_recs, c->pat.p, c->offs.p, n_tasks, c->ptr.p, c->d_counters); } while (0)
+        switch (c->ms_variant) {
+            case 1: MS_LAUNCH(1, 8); break;
+            case 2: MS_LAUNCH(2, 5); break;
+            case 3: MS_LAUNCH(2, 6); break;
+            case 4: MS_LAUNCH(2, 8); break;
+            case 5: MS_LAUNCH(4, 4); break;
+            default: MS_LAUNCH(2, 5); break;
+        }
+#undef MS_LAUNCH
+    }
     rec(c, EV_MS1);
     HIPCHK(hipGetLastError());
     return MONI_OK;
@@ -502,6 +516,24 @@ struct GpuBackend : mh::Backend {
 
 extern "C" {
 
+// CPUs this process may actually use: affinity mask and cgroup v2 quota (a GPU box hands each job a CPU share)
+static unsigned moni_host_cpus() {
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { unsigned a = (unsigned)CPU_COUNT(&set); if (a && a < n) n = a; }
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; unsigned long long period = 0;
+        if (fscanf(f, "%63s %llu", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            unsigned c = (unsigned)((strtoull(q, nullptr, 10) + period - 1) / period);
+            if (c && c < n) n = c;
+        }
+        fclose(f);
+    }
+    if (n < 1) n = 1;
+    if (n > 128) n = 128;
+    return n;
+}
+
 void moni_align_params_default(moni_align_params_t* p) {
     if (!p) return;
     memset(p, 0, sizeof(*p));
@@ -510,8 +542,7 @@ void moni_align_params_default(moni_align_params_t* p) {
     p->smatch = 2; p->smismatch = 4; p->gapo = 4; p->gapo2 = 13; p->gape = 2; p->gape2 = 1;
     p->end_bonus = 400; p->w = -1; p->zdrop = -1;
     p->max_dist_x = 500; p->max_dist_y = 100; p->max_iter = 10; p->max_pred = 5; p->min_chain_score = 40; p->min_chain_length = 1;
-    unsigned hc = std::thread::hardware_concurrency();
-    p->host_threads = hc ? (hc > 64 ? 64 : hc) : 1;
+    p->host_threads = moni_host_cpus();
 }
 
 int moni_align_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,

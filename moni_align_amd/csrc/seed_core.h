@@ -36,6 +36,9 @@ struct lds_tables_t {
     uint8_t compl_tab[256];
     uint32_t abs_run[256];
     uint64_t abs_pos[256];
+    uint32_t rec_base[MONI_MAX_SIGMA];     // copies of the per-code constants, so that a divergent code index is an LDS read
+    uint32_t rec_cnt[MONI_MAX_SIGMA];
+    uint32_t hot_slot[MONI_MAX_SIGMA];
 };
 
 MONI_HD uint64_t row_start(const moni_row_t& x) { return x.w0 & MONI_POS_MASK; }
@@ -139,52 +142,88 @@ MONI_HD uint8_t text_byte(const uint8_t* __restrict__ text, uint64_t a, text_cac
 // ------------------------------------------------------------------------------------------------
 // ms_task: pointers[s * n_tasks + task] = sample after step s, i.e. ms_pointers[m-1-s];  task = 2*read + strand
 // ------------------------------------------------------------------------------------------------
+// One lane runs NCH independent tasks in lockstep (task0 .. task0+NCH-1; with NCH = 2 the two strands of one read):
+// every step is a chain of dependent random reads (row, then the jump record), so the only way to have more requests in
+// flight per lane is to interleave independent chains.  All row reads of a step are issued before any is consumed, then
+// all jump-record reads.
+template <int NCH>
 MONI_HD void ms_task(const moni_consts_t& K, const lds_tables_t& L, const moni_row_t* __restrict__ rows,
                      const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs, const uint64_t* __restrict__ pat,
-                     const uint64_t* __restrict__ offs, uint64_t n_tasks, uint64_t task, uint64_t* __restrict__ ptr_out,
+                     const uint64_t* __restrict__ offs, uint64_t n_tasks, uint64_t task0, uint64_t* __restrict__ ptr_out,
                      unsigned long long& n_steps, unsigned long long& n_jumps) {
-    const uint64_t read = task >> 1;
-    const uint64_t off = offs[read];
-    const uint32_t m = (uint32_t)(offs[read + 1] - off);
-    uint64_t word = 0;
-    uint32_t run = (uint32_t)K.r - 1;
-    uint64_t pos = K.n - 1;
-    uint64_t sample = K.last_run_sample;
+    uint32_t m[NCH], run[NCH];
+    uint64_t word[NCH], pos[NCH], sample[NCH];
+    uint32_t m_max = 0;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const uint64_t task = task0 + k;
+        m[k] = 0;
+        if (task < n_tasks) { const uint64_t read = task >> 1; m[k] = (uint32_t)(offs[read + 1] - offs[read]); }
+        m_max = m[k] > m_max ? m[k] : m_max;
+        run[k] = (uint32_t)K.r - 1; pos[k] = K.n - 1; sample[k] = K.last_run_sample; word[k] = 0;
+        n_steps += m[k];
+    }
     const uint32_t sigma = K.sigma;
-    for (uint32_t s = 0; s < m; ++s) {
-        // pattern[m-1-s], already strand-resolved by pack_task
-        if ((s & 7u) == 0) word = pat[(uint64_t)(s >> 3) * n_tasks + task];
-        const uint8_t raw = (uint8_t)word;
-        word >>= 8;
-        const uint32_t c = L.code[raw];
-        if (c == MONI_CODE_ABSENT) {                     // n_c == 0   (moni.hpp:583-588)
-            sample = 0;
-            pos = L.abs_pos[raw];
-            run = L.abs_run[raw];
-        } else {
-            moni_row_t A;
-            settle_run(rows, K.r, pos, run, A);
-            if (row_head(A) == c) {                      // bwt[pos] == c  (moni.hpp:589-594); the sentinel head never matches
-                sample--;
-                pos = row_lfbase(A) + (pos - row_start(A));
-                run = row_dest(A);
-            } else {                                     // threshold jump (moni.hpp:595-618)
-                ++n_jumps;
-                const uint32_t hs = K.hot_slot[c];
-                const uint32_t j = hs != 0xFF ? row_hot(A, hs) : cr[(uint64_t)run * sigma + c];
-                const moni_u64x4 rv = *reinterpret_cast<const moni_u64x4*>(recs + K.rec_base[c] + j);
-                const uint64_t thr = rv.x & MONI_POS_MASK;
-                const uint32_t d = (uint32_t)((rv.x >> 40) << 24) | (uint32_t)(rv.y >> 40);
-                // rnk_c.first > thresholds.rank(pos+1, c)  <=>  j >= 1 and (no c-run below, or pos < thr_j)
-                const bool up = j > 0 && (j == K.rec_cnt[c] || pos < thr);
-                if (up) { sample = rv.z; pos = rv.w - 1; }
-                else { sample = rv.y & MONI_POS_MASK; pos = rv.w; }
-                run = d;
+    for (uint32_t s = 0; s < m_max; ++s) {
+        uint32_t c[NCH], jh[NCH];
+        uint64_t a0[NCH], a1[NCH];                       // row words: start|head|dest_hi|len, lfbase|dest_lo
+        // pattern[m-1-s], already strand-resolved by pack_task; then the row of the current run guess.  All NCH row reads
+        // are issued before any is used.
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (s < m[k] && (s & 7u) == 0) word[k] = pat[(uint64_t)(s >> 3) * n_tasks + (task0 + k)];
+            const uint32_t raw = (uint32_t)word[k] & 0xFFu;
+            c[k] = L.code[raw];
+            const moni_u64x4 v = *reinterpret_cast<const moni_u64x4*>(rows + run[k]);
+            a0[k] = v.x; a1[k] = v.y;
+            const uint32_t hs = c[k] != MONI_CODE_ABSENT ? L.hot_slot[c[k]] : 0u;
+            jh[k] = hs == 0 ? (uint32_t)v.z : hs == 1 ? (uint32_t)(v.z >> 32) : hs == 2 ? (uint32_t)v.w : hs == 3 ? (uint32_t)(v.w >> 32) : 0xFFFFFFFFu;
+        }
+        moni_u64x4 rv[NCH];
+        uint32_t jmp = 0;                                 // bit k: chain k takes a threshold jump this step
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (s < m[k] && c[k] != MONI_CODE_ABSENT) {
+                moni_row_t A; A.w0 = a0[k]; A.w1 = a1[k];
+                if (pos[k] < row_start(A) || !in_run(rows, run[k], A, pos[k])) {
+                    settle_run(rows, K.r, pos[k], run[k], A);
+                    a0[k] = A.w0; a1[k] = A.w1;
+                    const uint32_t hs = L.hot_slot[c[k]];
+                    jh[k] = hs < 4 ? row_hot(A, hs) : 0xFFFFFFFFu;
+                }
+                if (row_head(A) != c[k]) {                    // bwt[pos] != c: threshold jump (moni.hpp:595-618); the sentinel head never matches
+                    jmp |= 1u << k;
+                    if (jh[k] == 0xFFFFFFFFu) jh[k] = cr[(uint64_t)run[k] * sigma + c[k]];     // symbol without a hot slot
+                    rv[k] = *reinterpret_cast<const moni_u64x4*>(recs + L.rec_base[c[k]] + jh[k]);
+                }
             }
         }
-        ptr_out[(uint64_t)s * n_tasks + task] = sample;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (s >= m[k]) continue;
+            if (c[k] == MONI_CODE_ABSENT) {                   // n_c == 0   (moni.hpp:583-588)
+                const uint32_t raw = (uint32_t)word[k] & 0xFFu;
+                sample[k] = 0;
+                pos[k] = L.abs_pos[raw];
+                run[k] = L.abs_run[raw];
+            } else if (!(jmp >> k & 1u)) {                    // bwt[pos] == c  (moni.hpp:589-594)
+                sample[k]--;
+                pos[k] = (a1[k] & MONI_POS_MASK) + (pos[k] - (a0[k] & MONI_POS_MASK));
+                run[k] = (uint32_t)(((a0[k] >> 44) & 0xFFu) << 24) | (uint32_t)(a1[k] >> 40);
+            } else {
+                ++n_jumps;
+                const uint64_t thr = rv[k].x & MONI_POS_MASK;
+                const uint32_t d = (uint32_t)((rv[k].x >> 40) << 24) | (uint32_t)(rv[k].y >> 40);
+                // rnk_c.first > thresholds.rank(pos+1, c)  <=>  j >= 1 and (no c-run below, or pos < thr_j)
+                const bool up = jh[k] > 0 && (jh[k] == L.rec_cnt[c[k]] || pos[k] < thr);
+                if (up) { sample[k] = rv[k].z; pos[k] = rv[k].w - 1; }
+                else { sample[k] = rv[k].y & MONI_POS_MASK; pos[k] = rv[k].w; }
+                run[k] = d;
+            }
+            word[k] >>= 8;
+            ptr_out[(uint64_t)s * n_tasks + (task0 + k)] = sample[k];
+        }
     }
-    n_steps += m;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -12,8 +12,16 @@
 #include "seed_core.h"
 
 #define MS_BLOCK 256
+#ifndef MS_CHAINS
+#define MS_CHAINS 2          // independent tasks interleaved per lane in ms_lf_kernel (both strands of one read)
+#endif
 
-__device__ __forceinline__ void load_tables(lds_tables_t& L, const moni_tables_t* __restrict__ T) {
+__device__ __forceinline__ void load_tables(lds_tables_t& L, const moni_tables_t* __restrict__ T, const moni_consts_t& K) {
+    if (threadIdx.x < MONI_MAX_SIGMA) {
+        L.rec_base[threadIdx.x] = K.rec_base[threadIdx.x];
+        L.rec_cnt[threadIdx.x] = K.rec_cnt[threadIdx.x];
+        L.hot_slot[threadIdx.x] = K.hot_slot[threadIdx.x];
+    }
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
         L.code[i] = T->code[i];
         L.compl_tab[i] = T->compl_tab[i];
@@ -29,24 +37,26 @@ __device__ __forceinline__ void wave_add(unsigned long long v, unsigned long lon
 }
 
 extern "C" __global__ void __launch_bounds__(MS_BLOCK)
-pack_kernel(const moni_tables_t* __restrict__ T, const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t n_tasks,
+pack_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t n_tasks,
             uint32_t n_words, uint64_t* __restrict__ pat) {
     __shared__ lds_tables_t L;
-    load_tables(L, T);
+    load_tables(L, T, K);
     const uint64_t task = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
     if (task < n_tasks) pack_task(L, seq, offs, n_tasks, task, n_words, pat);
 }
 
-extern "C" __global__ void __launch_bounds__(MS_BLOCK)
+// NCH independent tasks per lane (see ms_task); MINW = minimum waves per SIMD the register allocator must leave room for.
+template <int NCH, int MINW>
+__global__ void __launch_bounds__(MS_BLOCK, MINW)
 ms_lf_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const moni_row_t* __restrict__ rows,
              const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs,
              const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, uint64_t n_tasks,
              uint64_t* __restrict__ ptr_out, unsigned long long* __restrict__ counters) {
     __shared__ lds_tables_t L;
-    load_tables(L, T);
-    const uint64_t task = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
+    load_tables(L, T, K);
+    const uint64_t task0 = ((uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x) * NCH;
     unsigned long long n_steps = 0, n_jumps = 0;
-    if (task < n_tasks) ms_task(K, L, rows, cr, recs, pat, offs, n_tasks, task, ptr_out, n_steps, n_jumps);
+    if (task0 < n_tasks) ms_task<NCH>(K, L, rows, cr, recs, pat, offs, n_tasks, task0, ptr_out, n_steps, n_jumps);
     wave_add(n_steps, &counters[0]);
     wave_add(n_jumps, &counters[1]);
 }
@@ -60,7 +70,7 @@ mem_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const uin
            const uint64_t* __restrict__ read_mem_off, moni_mem_t* __restrict__ mems, uint32_t* __restrict__ aux,
            moni_u64x2* __restrict__ slots, unsigned long long* __restrict__ counters) {
     __shared__ lds_tables_t L;
-    load_tables(L, T);
+    load_tables(L, T, K);
     const uint64_t task = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
     unsigned long long n_cmp = 0;
     if (task < n_tasks)

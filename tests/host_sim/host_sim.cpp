@@ -40,6 +40,7 @@ void* sim_create(const moni_flat_index_t* f) {
     memcpy(S->L.compl_tab, S->img.T.compl_tab, 256);
     memcpy(S->L.abs_run, S->img.T.abs_run, sizeof(S->L.abs_run));
     memcpy(S->L.abs_pos, S->img.T.abs_pos, sizeof(S->L.abs_pos));
+    for (int i = 0; i < MONI_MAX_SIGMA; ++i) { S->L.rec_base[i] = S->img.K.rec_base[i]; S->L.rec_cnt[i] = S->img.K.rec_cnt[i]; S->L.hot_slot[i] = S->img.K.hot_slot[i]; }
     S->hix.n_text = f->n - 1; S->hix.w = f->w; S->hix.text = S->text.data();
     S->hix.seq_starts.assign(f->seq_starts, f->seq_starts + f->n_seq + 1);
     const char* p = f->seq_names;
@@ -61,8 +62,8 @@ int sim_seed_run(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_r
     const uint32_t n_words = (uint32_t)((mx + 7) / 8);
     std::vector<uint64_t> pat(n_tasks * n_words + 1);
     for (uint64_t t = 0; t < n_tasks; ++t) pack_task(S->L, seq, offs, n_tasks, t, n_words, pat.data());
-    for (uint64_t t = 0; t < n_tasks; ++t)
-        ms_task(K, S->L, S->img.rows.data(), S->img.cr.data(), S->img.recs.data(), pat.data(), offs, n_tasks, t, S->ptr.data(), cnt[0], cnt[1]);
+    for (uint64_t t = 0; t < n_tasks; t += 2)
+        ms_task<2>(K, S->L, S->img.rows.data(), S->img.cr.data(), S->img.recs.data(), pat.data(), offs, n_tasks, t, S->ptr.data(), cnt[0], cnt[1]);
     std::vector<uint32_t> cnt_m(n_tasks + 1), cnt_s(n_tasks + 1);
     std::vector<moni_u64x2> slots(n_tasks * MONI_MEM_SLOTS + 1);
     const uint32_t split_on = prm->report_mems ? 0 : 1;
@@ -187,6 +188,7 @@ char* sim_align_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint64_
     memcpy(buf, out.data(), out.size() + 1);
     *out_len = out.size();
     if (stats5) { stats5[0] = st.reads; stats5[1] = st.aligned; stats5[2] = st.dp_tasks; stats5[3] = st.dp_cells; stats5[4] = st.dp_rounds; }
+    if (getenv("MH_TIMES")) fprintf(stderr, "host_sim times: seed %.3f chain %.3f dp %.3f host %.3f s\n", st.t_seed, st.t_chain, st.t_dp, st.t_host);
     return buf;
 }
 void sim_free(void* p) { free(p); }

@@ -1,0 +1,70 @@
+"""Full single-end path on the GPU (moni_align_batch: HIP seeding + HIP ksw2 extension + host stages) against the
+oracle's restatement of aligner::align: SAM text byte-identical (CIGAR, POS, MAPQ, AS, NM, MD, ZS, OA, AA, flags)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def first_diff(a: bytes, b: bytes):
+    la, lb = a.split(b"\n"), b.split(b"\n")
+    for k, (x, y) in enumerate(zip(la, lb)):
+        if x != y:
+            return k, x.decode()[:300], y.decode()[:300]
+    return min(len(la), len(lb)), "<%d records>" % len(la), "<%d records>" % len(lb)
+
+
+@pytest.fixture(scope="module")
+def env(medium_case):
+    from moni_align_amd import capi
+    from oracle import orc
+    idx = capi.Index(fi=medium_case.fi)
+    ctx = capi.Ctx(idx)
+    yield orc.OracleIndex(medium_case.path), ctx
+    ctx.close()
+    idx.close()
+
+
+def both(env, reads_list, quals=True):
+    from oracle import orc
+    o, ctx = env
+    offs = np.zeros(len(reads_list) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads_list])
+    seq = np.concatenate(reads_list)
+    names, noff = orc.make_names(len(reads_list))
+    q = np.full(len(seq), ord("I"), dtype=np.uint8) if quals else None
+    want, wcnt = orc.align_batch(o, seq, offs, names, noff, q, threads=8)
+    got, st = ctx.align_batch(seq, offs, names, noff, q, host_threads=8)
+    if got != want:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
+    return wcnt, st
+
+
+def test_sam_identical_150bp(medium_case, env):
+    reads = medium_case.synth.make_reads(medium_case.pg, 20000, 150, seed=150)
+    wcnt, st = both(env, list(reads))
+    assert st["aligned"] == wcnt["aligned"] > 19000
+
+
+def test_sam_identical_250bp_noisy_ragged(medium_case, env):
+    rng = np.random.default_rng(17)
+    base = medium_case.synth.make_reads(medium_case.pg, 4000, 250, seed=9, sub_rate=0.04, indel_rate=0.006)
+    reads = [r[: int(rng.integers(30, 251))].copy() for r in base]
+    reads.append(np.frombuffer(b"N" * 60, dtype=np.uint8))
+    reads.append(np.frombuffer(b"ACGT" * 10, dtype=np.uint8))
+    x = base[0].copy(); x[40:45] = ord("N"); reads.append(x)
+    reads.append(np.frombuffer(bytes(medium_case.fi.text[100:400]), dtype=np.uint8))
+    y = base[1].copy(); y[:] = np.frombuffer(bytes(y).lower(), dtype=np.uint8); reads.append(y)
+    both(env, reads)
+
+
+def test_sam_identical_fasta_reads(medium_case, env):
+    reads = medium_case.synth.make_reads(medium_case.pg, 500, 100, seed=3)
+    both(env, list(reads), quals=False)
+
+
+def test_header(medium_case, env):
+    o, ctx = env
+    h = ctx.sam_header().decode().split("\n")
+    assert h[0] == "@HD\tVN:1.6\tSO:unknown" and h[-2] == "@PG\tID:moni\tPN:moni\tVN:0.1.0"
+    assert h[1] == "@SQ\tSN:chr19\tLN:%d" % len(medium_case.pg.seqs[0])

@@ -188,8 +188,10 @@ def main():
                                             "host buffers in / SAM text out" % nfp,
                                 "value": nfp / dtf, "unit": "reads/s", "aligned": stf["aligned"], "dp_tasks": stf["dp_tasks"],
                                 "dp_cells": stf["dp_cells"], "dp_rounds": stf["dp_rounds"], "host_threads": host_cpus(),
-                                "seconds": {"seed": stf["t_seed"], "chain": stf["t_chain"], "dp": stf["t_dp"], "host_other": stf["t_host"]},
-                                "gcups_dp_stage": stf["dp_cells"] / stf["t_dp"] / 1e9 if stf["t_dp"] > 0 else None}
+                                "seconds": {"seed": stf["t_seed"], "chain": stf["t_chain"], "dp": stf["t_dp"], "host_other": stf["t_host"],
+                                            "dp_kernels": stf["t_dp_kernel"]},
+                                "gcups_dp_stage": stf["dp_cells"] / stf["t_dp"] / 1e9 if stf["t_dp"] > 0 else None,
+                                "gcups_extz_kernel": stf["dp_cells"] / stf["t_dp_kernel"] / 1e9 if stf["t_dp_kernel"] > 0 else None}
             if not args.no_cpu:
                 ncpu = min(nfp, 20000)
                 t1 = time.perf_counter()

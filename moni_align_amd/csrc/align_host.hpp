@@ -120,7 +120,8 @@ static bool chain_mems(const std::vector<Mem>& mems, std::vector<std::pair<uint3
     auto xend = [&](const std::pair<uint32_t, uint32_t>& a) -> uint64_t { return mems[a.first].occs[a.second] + mems[a.first].len - 1; };
     std::sort(anchors.begin(), anchors.end(), [&](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return xend(a) < xend(b); });
     const size_t na = anchors.size();
-    std::vector<ll> f(na, 0), p(na, 0), msc(na, 0), t(na, 0);
+    static thread_local std::vector<ll> f, p, msc, t;        // per-thread scratch, reused across reads
+    f.assign(na, 0); p.assign(na, 0); msc.assign(na, 0); t.assign(na, 0);
     ll lb = 0;
     for (size_t i = 0; i < na; ++i) {
         const Mem& mi = mems[anchors[i].first];
@@ -157,7 +158,8 @@ static bool chain_mems(const std::vector<Mem>& mems, std::vector<std::pair<uint3
     }
     std::fill(t.begin(), t.end(), 0);
     for (size_t i = 0; i < na; ++i) if (p[i] >= 0) t[p[i]] = 1;
-    std::vector<std::pair<ll, size_t>> starts;
+    static thread_local std::vector<std::pair<ll, size_t>> starts;
+    starts.clear();
     for (size_t i = 0; i < na; ++i) {
         if (t[i] == 0 && msc[i] > P.min_chain_score) {
             size_t j = i;
@@ -223,6 +225,22 @@ static size_t md_core(const uint8_t* tseq, const uint8_t* qseq, const std::vecto
     return (size_t)NM;
 }
 
+// Small vector with inline storage: chains rarely have more than a few anchors, and a heap allocation per fill_chain
+// member per read per round is what the host stages would otherwise spend their time on.
+template <class Tp, int N>
+struct SmallVec {
+    Tp inl[N];
+    std::vector<Tp> big;
+    uint32_t n = 0;
+    void assign(size_t k, const Tp& v) { n = (uint32_t)k; if (k > (size_t)N) big.assign(k, v); else for (size_t i = 0; i < k; ++i) inl[i] = v; }
+    void resize(size_t k) { n = (uint32_t)k; if (k > (size_t)N) big.resize(k); }
+    size_t size() const { return n; }
+    Tp& operator[](size_t i) { return n > (uint32_t)N ? big[i] : inl[i]; }
+    const Tp& operator[](size_t i) const { return n > (uint32_t)N ? big[i] : inl[i]; }
+    Tp& back() { return (*this)[n - 1]; }
+    const Tp& back() const { return (*this)[n - 1]; }
+};
+
 struct Sam {                       // sam_t (sam.hpp:47-112), the fields the SE path sets
     bool rev_read = false;         // sam.read = &read_rev
     size_t flag = 4, pos = 0, mapq = 255;
@@ -243,14 +261,14 @@ struct Score { int32_t score = 0; uint64_t pos = 0, lft = 0; bool unmapped_lft =
 // One fill_chain in flight (aligner_ksw2.hpp:2752-3196), split where it needs DP results.
 struct Fill {
     bool score_only = true;
-    std::vector<std::pair<uint32_t, uint32_t>> an;   // chain anchors, left to right
+    SmallVec<std::pair<uint32_t, uint32_t>, 8> an;   // chain anchors, left to right
     uint32_t strand = 0;
     uint64_t lcs_len = 0, rcs_len = 0, rcs_occ = 0;
     bool overlap = false;
     int t_lc = -1, t_rc = -1, t_glob = -1;
-    std::vector<int> t_gap;                          // DP task per gap, -1 for the closed-form shortcuts
-    std::vector<int32_t> gap_score;                  // shortcut scores
-    std::vector<uint32_t> gap_cig;                   // shortcut CIGAR op (0 = none)
+    SmallVec<int, 8> t_gap;                          // DP task per gap, -1 for the closed-form shortcuts
+    SmallVec<int32_t, 8> gap_score;                  // shortcut scores
+    SmallVec<uint32_t, 8> gap_cig;                   // shortcut CIGAR op (0 = none)
     uint64_t ref_pos = 0, ref_len = 0;
     int32_t lc_mqe_t = -1, rc_mqe_t = -1;
     Score score;
@@ -264,7 +282,7 @@ struct ReadState {
     int32_t min_score = 0;
     // selection loop (aligner_ksw2.hpp:394-474)
     size_t i = 0;
-    std::set<size_t> different_scores;
+    SmallVec<size_t, 8> different_scores;           // std::set<size_t> of at most check_k chain scores
     std::vector<std::tuple<int32_t, size_t, size_t>> best_scores;
     std::vector<std::pair<size_t, size_t>> left_mem_vec;
     int32_t max_score = 0;
@@ -295,13 +313,14 @@ struct Aligner {
     uint64_t occ_of(const ReadState& R, const std::pair<uint32_t, uint32_t>& a) const { return R.mems[a.first].occs[a.second]; }
 
     // ---- fill_chain, part 1: define the DP problems (aligner_ksw2.hpp:2782-2979) ----
-    void fill_begin(ReadState& R, const std::vector<uint32_t>& chain_lr, bool score_only, std::vector<moni_dp_task_t>& tasks) {
+    void fill_begin(ReadState& R, const Chain& chain, bool score_only, std::vector<moni_dp_task_t>& tasks) {
         Fill& F = R.fill;
         F = Fill();
         const size_t q0 = tasks.size();                  // task ids are relative to the read's first task of this round
         F.score_only = score_only;
-        F.an.resize(chain_lr.size());
-        for (size_t k = 0; k < chain_lr.size(); ++k) F.an[k] = R.anchors[chain_lr[k]];
+        const size_t cn = chain.anchors.size();              // stored right to left (chain.hpp:166-200); fill_chain wants left to right
+        F.an.resize(cn);
+        for (size_t k = 0; k < cn; ++k) F.an[k] = R.anchors[chain.anchors[cn - 1 - k]];
         const Mem& first = R.mems[F.an[0].first];
         const Mem& last = R.mems[F.an.back().first];
         F.strand = (first.mate & 2) ? 1 : 0;
@@ -528,16 +547,16 @@ struct Aligner {
         if (!replaced) { R.best_scores.push_back(std::make_tuple(score.score, (size_t)score.lft, i)); i++; }
     }
 
-    std::vector<uint32_t> left_to_right(const Chain& c) const { return std::vector<uint32_t>(c.anchors.rbegin(), c.anchors.rend()); }
 
     // Runs the read until it needs DP results (tasks appended) or is done.
     void advance(ReadState& R, std::vector<moni_dp_task_t>& tasks) {
         while (R.stage == ReadState::LOOP) {
             if (R.i < R.chains.size() && R.different_scores.size() < P.check_k) {
-                R.different_scores.insert((size_t)R.chains[R.i].score);
+                { const size_t v = (size_t)R.chains[R.i].score; bool f = false; for (size_t q = 0; q < R.different_scores.size(); ++q) f = f || R.different_scores[q] == v;
+                  if (!f) { const size_t q = R.different_scores.size(); R.different_scores.resize(q + 1); R.different_scores[q] = v; } }
                 if (P.left_mem_check && check_left_mem(R, R.i)) { ++R.i; continue; }
                 if (R.different_scores.size() < P.check_k) {
-                    fill_begin(R, left_to_right(R.chains[R.i]), true, tasks);
+                    fill_begin(R, R.chains[R.i], true, tasks);
                     R.stage = ReadState::WAIT_A;
                     return;
                 }
@@ -552,7 +571,7 @@ struct Aligner {
             if (R.final_chain >= R.chains.size() || R.chain_score_cache[R.final_chain] < R.min_score) { R.stage = ReadState::DONE; return; }
             // chain_score(..., score_only = false): the score-only pass was already done for this chain in the loop;
             // its (cached) score is >= min_score here, so the final pass always runs (aligner_ksw2.hpp:2062-2065)
-            fill_begin(R, left_to_right(R.chains[R.final_chain]), false, tasks);
+            fill_begin(R, R.chains[R.final_chain], false, tasks);
             R.stage = ReadState::FINAL_WAIT_A;
             return;
         }
@@ -732,14 +751,17 @@ static int align_batch(Backend& be, const HostIndex& ix, const moni_align_params
         drive(R, ttasks[t]);
         if (ttasks[t].size() != before) { R.task_base = (uint32_t)before; R.owner_thread = t; temit[t].push_back(r); }
     };
+    double tt_drive = 0, tt_merge = 0, tt_sam = 0; double tq = now_s();
     // round 0: every chained read runs until its first DP request
     {
         std::vector<uint32_t> act;
         for (size_t r = 0; r < n_reads; ++r) if (RS[r].stage != ReadState::DONE) act.push_back((uint32_t)r);
         parallel_for(pool, act.size(), [&](int t, size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) with_queue(t, act[k]); });
     }
+    tt_drive += now_s() - tq;
     while (true) {
         // merge the per-thread queues into one batch
+        tq = now_s();
         tasks.clear(); waiting.clear();
         std::vector<uint32_t> tb(T + 1, 0);
         for (int t = 0; t < T; ++t) {
@@ -750,6 +772,7 @@ static int align_batch(Backend& be, const HostIndex& ix, const moni_align_params
         }
         if (tasks.empty()) break;
         st.dp_tasks += tasks.size(); st.dp_rounds++;
+        tt_merge += now_s() - tq;
         for (auto& t : tasks) st.dp_cells += (uint64_t)(t.qlen > 0 ? t.qlen : 0) * (uint64_t)(t.tlen > 0 ? t.tlen : 0);
         st.t_host += now_s() - t0;
         t0 = now_s();
@@ -759,8 +782,11 @@ static int align_batch(Backend& be, const HostIndex& ix, const moni_align_params
         st.t_dp += now_s() - t0;
         t0 = now_s();
         // consume results; reads that continue queue their next problems for the next batch
+        tq = now_s();
         parallel_for(pool, waiting.size(), [&](int t, size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) with_queue(t, waiting[k]); });
+        tt_drive += now_s() - tq;
     }
+    tq = now_s();
     // SAM text in read order (align_reads_dispatcher.hpp:346-357, sam.hpp:144-188)
     std::vector<std::string> parts(T);
     parallel_for(pool, n_reads, [&](int t, size_t lo, size_t hi) {
@@ -786,6 +812,8 @@ static int align_batch(Backend& be, const HostIndex& ix, const moni_align_params
     });
     sam_out.clear();
     for (auto& p : parts) sam_out += p;
+    tt_sam += now_s() - tq;
+    if (getenv("MH_TIMES")) fprintf(stderr, "align_host: drive %.3f merge %.3f sam %.3f s\n", tt_drive, tt_merge, tt_sam);
     st.reads += n_reads;
     for (auto& R : RS) if (R.aligned) st.aligned++;
     st.t_host += now_s() - t0;

@@ -84,6 +84,7 @@ struct moni_ctx {
     uint64_t n_mems = 0, n_occs = 0;
     uint32_t tmp_cap = 16;
     uint32_t pool_rows = 4096;
+    double dp_kernel_ms_accum = 0;
     int ms_variant = 0;                        // 0 = default; MONI_MS_VARIANT selects an (interleave, occupancy) variant for tuning
     // dp
     DBuf<uint8_t> dp_q, dp_t, dp_dir;
@@ -551,6 +552,7 @@ int moni_align_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* n
     int rc = moni_reads_upload(c, b);
     if (rc) return rc;
     GpuBackend be(c);
+    c->dp_kernel_ms_accum = 0;
     std::string out;
     mh::AlignStats st;
     const uint8_t* q = quals ? quals + b->offsets[0] : nullptr;
@@ -564,6 +566,7 @@ int moni_align_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* n
     if (stats) {
         stats->reads = st.reads; stats->aligned = st.aligned; stats->dp_tasks = st.dp_tasks; stats->dp_cells = st.dp_cells; stats->dp_rounds = st.dp_rounds;
         stats->t_seed = st.t_seed; stats->t_chain = st.t_chain; stats->t_dp = st.t_dp; stats->t_host = st.t_host;
+        stats->t_dp_kernel = c->dp_kernel_ms_accum / 1e3;
     }
     return MONI_OK;
 }

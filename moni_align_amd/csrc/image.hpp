@@ -15,6 +15,7 @@ struct HostImage {
     moni_consts_t K;
     moni_tables_t T;
     std::vector<moni_row_t> rows;      // r + 2
+    std::vector<moni_frow_t> frows;    // r + 2
     std::vector<uint32_t> cr;          // (r + 1) * sigma
     std::vector<moni_rec_t> recs;
     std::vector<moni_phi_t> phi, phi_inv;   // r each
@@ -136,6 +137,47 @@ struct HostImage {
             for (uint32_t c = 0; c < sigma; ++c) if (K.hot_slot[c] != 0xFF) rows[k].hot_cr[K.hot_slot[c]] = cr[k * sigma + c];
         }
         rows[r + 1] = pack_row(MONI_POS_MASK, MONI_HEAD_NONE, 0, r, MONI_ROW_LEN_SAT);
+        // fast rows
+        {
+            moni_frow_t z; memset(&z, 0, sizeof z);
+            frows.assign(r + 2, z);
+            int hot_code[4] = {-1, -1, -1, -1};
+            for (uint32_t c = 0; c < sigma; ++c) if (K.hot_slot[c] != 0xFF) hot_code[K.hot_slot[c]] = (int)c;
+            const bool four = hot_code[0] >= 0 && hot_code[1] >= 0 && hot_code[2] >= 0 && hot_code[3] >= 0;
+            for (uint64_t k = 0; four && k < r; ++k) {
+                const uint32_t h = (uint32_t)code_of[f.heads[k]];
+                const uint64_t len = f.starts[k + 1] - f.starts[k];
+                const uint64_t doff = lfbase[k] - f.starts[dest[k]];
+                bool ok = K.hot_slot[h] != 0xFF && len < MONI_ROW_LEN_SAT && doff < MONI_ROW_LEN_SAT;
+                if (!ok) continue;
+                const uint32_t hs = K.hot_slot[h];
+                uint64_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                uint64_t ssa[3], esa[3];
+                for (uint32_t sl = 0; sl < 3 && ok; ++sl) {
+                    const uint32_t c = (uint32_t)hot_code[(hs + 1 + sl) & 3];
+                    const uint32_t j = cr[k * sigma + c];
+                    const moni_rec_t& R = recs[K.rec_base[c] + j];
+                    const uint64_t thr = R.w0 & MONI_POS_MASK;
+                    const uint64_t sd = ((R.w0 >> 40) << 24) | (R.w1 >> 40);
+                    const uint64_t lfpos = R.w3;
+                    const uint64_t sdoff = lfpos - f.starts[sd];
+                    if (sdoff >= MONI_ROW_LEN_SAT) { ok = false; break; }
+                    uint64_t thr_off;
+                    if (j == 0) thr_off = 0;
+                    else if (j == K.rec_cnt[c]) thr_off = len;
+                    else thr_off = thr <= f.starts[k] ? 0 : (thr >= f.starts[k] + len ? len : thr - f.starts[k]);
+                    ssa[sl] = R.w1 & MONI_POS_MASK; esa[sl] = R.w2;
+                    w[1 + sl] = thr_off | (sdoff << 12) | (sd << 24) | ((ssa[sl] >> 32) << 56);
+                }
+                if (!ok) continue;
+                w[0] = len | (doff << 12) | ((uint64_t)dest[k] << 24) | ((uint64_t)hs << 56) | (1ull << 58);
+                w[4] = (ssa[0] & 0xFFFFFFFFull) | ((ssa[1] & 0xFFFFFFFFull) << 32);
+                w[5] = (ssa[2] & 0xFFFFFFFFull) | ((esa[0] & 0xFFFFFFFFull) << 32);
+                w[6] = (esa[1] & 0xFFFFFFFFull) | ((esa[2] & 0xFFFFFFFFull) << 32);
+                w[7] = (esa[0] >> 32) | ((esa[1] >> 32) << 8) | ((esa[2] >> 32) << 16);
+                memcpy(frows[k].w, w, sizeof w);
+            }
+        }
         // absent bytes: LF(pos, b) = F[b]   (moni.hpp:583-588)
         for (int b = 0; b < 256; ++b) {
             T.abs_pos[b] = f.F[b];
@@ -185,7 +227,7 @@ struct HostImage {
     }
 
     uint64_t bytes() const {
-        return rows.size() * sizeof(moni_row_t) + cr.size() * 4 + recs.size() * sizeof(moni_rec_t) +
+        return rows.size() * sizeof(moni_row_t) + frows.size() * sizeof(moni_frow_t) + cr.size() * 4 + recs.size() * sizeof(moni_rec_t) +
                (phi.size() + phi_inv.size()) * sizeof(moni_phi_t) + (phi_dir.size() + phi_inv_dir.size()) * 4;
     }
 };

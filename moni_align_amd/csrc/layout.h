@@ -39,6 +39,19 @@ struct alignas(32) moni_row_t {   // 32 bytes
     uint32_t hot_cr[4];
 };
 
+// Fast row (one 64-byte aligned record per run = ONE HBM request per LF step, threshold jumps included).  Everything is
+// relative to run starts, so the LF loop carries (run, offset) and never needs an absolute BWT position:
+//   w0      len(12) | doff(12) << 12 | dest(32) << 24 | head_slot(2) << 56 | ok(1) << 58
+//           LF(run start) = offset doff inside run dest
+//   w1..w3  slot s (the hot symbol (head_slot + 1 + s) & 3):  thr_off(12) | sdoff(12) << 12 | sdest(32) << 24 | ssa_hi(8) << 56
+//           jump up  iff offset < thr_off   (thr_off folds "no c-run above/below" and the threshold position, clamped to the run)
+//           down: sample = ssa, go to (sdest, sdoff);  up: sample = esa, go to one position before (sdest, sdoff)
+//   w4..w7  the six 40-bit samples: ssa0|ssa1, ssa2|esa0, esa1|esa2 (low 32 bits), then the three esa high bytes
+// ok = 0 (long runs >= 4095, offsets that do not fit 12 bits, heads or symbols outside the four hot ones, sentinels)
+// sends the step down the general path over rows / cr / recs with absolute positions.
+struct alignas(64) moni_frow_t { uint64_t w[8]; };
+#define MONI_OFF_END 0xFFFFFFFFu
+
 struct moni_rec_t {   // 32 bytes
     uint64_t w0;      // thr | (dest >> 24) << 40
     uint64_t w1;      // ssa | (dest & 0xFFFFFF) << 40

@@ -29,6 +29,7 @@ struct moni_index {
     moni_consts_t K;
     moni_tables_t* d_tables = nullptr;
     moni_row_t* d_rows = nullptr;
+    moni_frow_t* d_frows = nullptr;
     uint32_t* d_cr = nullptr;
     moni_rec_t* d_recs = nullptr;
     moni_phi_t *d_phi = nullptr, *d_phi_inv = nullptr;
@@ -155,7 +156,7 @@ int moni_index_create(const moni_flat_index_t* f, int device, moni_index_t** out
     I->h_text.assign(f->text, f->text + (f->n - 1));
     I->hix.n_text = f->n - 1; I->hix.w = f->w; I->hix.text = I->h_text.data();
     I->hix.seq_starts.assign(f->seq_starts, f->seq_starts + f->n_seq + 1);
-    if ((rc = upload(&I->d_tables, tv, I->bytes)) || (rc = upload(&I->d_rows, img.rows, I->bytes)) ||
+    if ((rc = upload(&I->d_tables, tv, I->bytes)) || (rc = upload(&I->d_rows, img.rows, I->bytes)) || (rc = upload(&I->d_frows, img.frows, I->bytes)) ||
         (rc = upload(&I->d_cr, img.cr, I->bytes)) || (rc = upload(&I->d_recs, img.recs, I->bytes)) ||
         (rc = upload(&I->d_phi, img.phi, I->bytes)) || (rc = upload(&I->d_phi_inv, img.phi_inv, I->bytes)) ||
         (rc = upload(&I->d_phi_dir, img.phi_dir, I->bytes)) || (rc = upload(&I->d_phi_inv_dir, img.phi_inv_dir, I->bytes)) ||
@@ -208,7 +209,7 @@ int moni_index_load(const char* path, int device, moni_index_t** out) {
 void moni_index_destroy(moni_index_t* I) {
     if (!I) return;
     (void)hipSetDevice(I->device);
-    void* ps[] = {I->d_tables, I->d_rows, I->d_cr, I->d_recs, I->d_phi, I->d_phi_inv, I->d_phi_dir, I->d_phi_inv_dir, I->d_text, I->d_seq_starts, I->d_name_id};
+    void* ps[] = {I->d_tables, I->d_rows, I->d_frows, I->d_cr, I->d_recs, I->d_phi, I->d_phi_inv, I->d_phi_dir, I->d_phi_inv_dir, I->d_text, I->d_seq_starts, I->d_name_id};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete I;
 }
@@ -288,14 +289,14 @@ static int ms_launch(moni_ctx* c) {
     if (n_tasks) {
 #define MS_LAUNCH(NCH, MINW) do { const uint64_t nl = (n_tasks + (NCH) - 1) / (NCH); \
         hipLaunchKernelGGL((ms_lf_kernel<NCH, MINW>), dim3((unsigned)((nl + MS_BLOCK - 1) / MS_BLOCK)), dim3(MS_BLOCK), 0, c->stream, \
-                           I->K, I->d_tables, I->d_rows, I->d_cr, I->d_recs, c->pat.p, c->offs.p, n_tasks, c->ptr.p, c->d_counters); } while (0)
+                           I->K, I->d_tables, I->d_rows, I->d_frows, I->d_cr, I->d_recs, c->pat.p, c->offs.p, n_tasks, c->ptr.p, c->d_counters); } while (0)
         switch (c->ms_variant) {
             case 1: MS_LAUNCH(1, 8); break;
-            case 2: MS_LAUNCH(2, 5); break;
+            case 2: MS_LAUNCH(2, 8); break;
             case 3: MS_LAUNCH(2, 6); break;
-            case 4: MS_LAUNCH(2, 8); break;
+            case 4: MS_LAUNCH(1, 6); break;
             case 5: MS_LAUNCH(4, 4); break;
-            default: MS_LAUNCH(2, 5); break;
+            default: MS_LAUNCH(1, 8); break;
         }
 #undef MS_LAUNCH
     }

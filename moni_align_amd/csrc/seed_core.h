@@ -142,86 +142,134 @@ MONI_HD uint8_t text_byte(const uint8_t* __restrict__ text, uint64_t a, text_cac
 // ------------------------------------------------------------------------------------------------
 // ms_task: pointers[s * n_tasks + task] = sample after step s, i.e. ms_pointers[m-1-s];  task = 2*read + strand
 // ------------------------------------------------------------------------------------------------
-// One lane runs NCH independent tasks in lockstep (task0 .. task0+NCH-1; with NCH = 2 the two strands of one read):
-// every step is a chain of dependent random reads (row, then the jump record), so the only way to have more requests in
-// flight per lane is to interleave independent chains.  All row reads of a step are issued before any is consumed, then
-// all jump-record reads.
+// State of one task's LF loop.  In the common case it is (run, off): the position is offset `off` inside run `run`
+// (MONI_OFF_END = last position of the run), and a step reads exactly one 64-byte fast row.  After a step that went
+// through the general path the state is an absolute BWT position (abs = true) and is re-anchored at the next step.
+struct ms_state_t {
+    uint64_t pos, sample, word;
+    uint32_t run, off, m;
+    bool abs;
+};
+
+// The general path of one step: absolute position, rows / cr / recs (moni.hpp:589-618).  c is a symbol of the BWT.
+MONI_HD void ms_step_general(const moni_consts_t& K, const lds_tables_t& L, const moni_row_t* __restrict__ rows,
+                             const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs, uint32_t c, ms_state_t& S,
+                             unsigned long long& n_jumps) {
+    moni_row_t A;
+    settle_run(rows, K.r, S.pos, S.run, A);
+    if (row_head(A) == c) {                                  // bwt[pos] == c  (moni.hpp:589-594); the sentinel head never matches
+        S.sample--;
+        S.pos = row_lfbase(A) + (S.pos - row_start(A));
+        S.run = row_dest(A);
+    } else {                                                 // threshold jump (moni.hpp:595-618)
+        ++n_jumps;
+        const uint32_t hs = L.hot_slot[c];
+        const uint32_t j = hs < 4 ? row_hot(A, hs) : cr[(uint64_t)S.run * K.sigma + c];
+        const moni_u64x4 rv = *reinterpret_cast<const moni_u64x4*>(recs + L.rec_base[c] + j);
+        const uint64_t thr = rv.x & MONI_POS_MASK;
+        const uint32_t d = (uint32_t)((rv.x >> 40) << 24) | (uint32_t)(rv.y >> 40);
+        // rnk_c.first > thresholds.rank(pos+1, c)  <=>  j >= 1 and (no c-run below, or pos < thr_j)
+        const bool up = j > 0 && (j == L.rec_cnt[c] || S.pos < thr);
+        if (up) { S.sample = rv.z; S.pos = rv.w - 1; }
+        else { S.sample = rv.y & MONI_POS_MASK; S.pos = rv.w; }
+        S.run = d;
+    }
+    S.abs = true;
+}
+
+// One LF step of one task for symbol code c (moni.hpp:579-621).
+MONI_HD void ms_step(const moni_consts_t& K, const lds_tables_t& L, const moni_row_t* __restrict__ rows,
+                     const moni_frow_t* __restrict__ frows, const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs,
+                     uint32_t c, ms_state_t& S, unsigned long long& n_jumps) {
+    if (S.abs) {                                             // re-anchor an absolute position: (run, off)
+        moni_row_t A;
+        settle_run(rows, K.r, S.pos, S.run, A);
+        S.off = (uint32_t)(S.pos - row_start(A));            // < 2^32 unless the run is longer, in which case the row is not "ok" anyway
+        if (S.pos - row_start(A) >= MONI_ROW_LEN_SAT) { ms_step_general(K, L, rows, cr, recs, c, S, n_jumps); return; }
+        S.abs = false;
+    }
+    const uint32_t hc = L.hot_slot[c];
+    while (true) {
+        const moni_frow_t* __restrict__ fr = frows + S.run;
+        const moni_u64x2 q0 = *reinterpret_cast<const moni_u64x2*>(&fr->w[0]);   // w0, w1
+        const uint64_t w0 = q0.x;
+        const uint32_t len = (uint32_t)w0 & 0xFFFu;
+        if (!((w0 >> 58) & 1u) || hc >= 4) {                 // general path: absolute position from the 32-byte row
+            const moni_row_t A = ld_row(rows, S.run);
+            if (S.off == MONI_OFF_END) S.pos = ld_start(rows, S.run + 1) - 1;
+            else S.pos = row_start(A) + S.off;
+            ms_step_general(K, L, rows, cr, recs, c, S, n_jumps);
+            return;
+        }
+        if (S.off == MONI_OFF_END) S.off = len - 1;
+        if (S.off >= len) { S.off -= len; ++S.run; continue; }          // the LF image ran past the destination run: next run
+        const uint32_t hh = (uint32_t)(w0 >> 56) & 3u;
+        if (hc == hh) {                                      // bwt[pos] == c
+            S.sample--;
+            S.off += (uint32_t)(w0 >> 12) & 0xFFFu;
+            S.run = (uint32_t)(w0 >> 24);
+            return;
+        }
+        ++n_jumps;
+        const uint32_t sl = (hc - hh - 1u) & 3u;             // 0..2
+        const moni_u64x2 q1 = *reinterpret_cast<const moni_u64x2*>(&fr->w[2]);   // w2, w3
+        const moni_u64x2 q2 = *reinterpret_cast<const moni_u64x2*>(&fr->w[4]);   // w4, w5
+        const moni_u64x2 q3 = *reinterpret_cast<const moni_u64x2*>(&fr->w[6]);   // w6, w7
+        const uint64_t ws = sl == 0 ? q0.y : sl == 1 ? q1.x : q1.y;
+        const uint32_t thr_off = (uint32_t)ws & 0xFFFu;
+        const uint32_t sdoff = (uint32_t)(ws >> 12) & 0xFFFu;
+        const uint32_t sdest = (uint32_t)(ws >> 24);
+        if (S.off < thr_off) {                               // jump up: last position of the previous c-run
+            const uint64_t lo = sl == 0 ? (q2.y >> 32) : sl == 1 ? (q3.x & 0xFFFFFFFFull) : (q3.x >> 32);
+            const uint64_t hi = (q3.y >> (8 * sl)) & 0xFFull;
+            S.sample = lo | (hi << 32);
+            if (sdoff == 0) { S.run = sdest - 1; S.off = MONI_OFF_END; }
+            else { S.run = sdest; S.off = sdoff - 1; }
+        } else {                                             // jump down: first position of the next c-run
+            const uint64_t lo = sl == 0 ? (q2.x & 0xFFFFFFFFull) : sl == 1 ? (q2.x >> 32) : (q2.y & 0xFFFFFFFFull);
+            S.sample = lo | ((ws >> 56) << 32);
+            S.run = sdest; S.off = sdoff;
+        }
+        return;
+    }
+}
+
+// One lane runs NCH tasks (task0 .. task0+NCH-1; with NCH = 2 the two strands of one read).
 template <int NCH>
 MONI_HD void ms_task(const moni_consts_t& K, const lds_tables_t& L, const moni_row_t* __restrict__ rows,
-                     const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs, const uint64_t* __restrict__ pat,
-                     const uint64_t* __restrict__ offs, uint64_t n_tasks, uint64_t task0, uint64_t* __restrict__ ptr_out,
-                     unsigned long long& n_steps, unsigned long long& n_jumps) {
-    uint32_t m[NCH], run[NCH];
-    uint64_t word[NCH], pos[NCH], sample[NCH];
+                     const moni_frow_t* __restrict__ frows, const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs,
+                     const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, uint64_t n_tasks, uint64_t task0,
+                     uint64_t* __restrict__ ptr_out, unsigned long long& n_steps, unsigned long long& n_jumps) {
+    ms_state_t S[NCH];
     uint32_t m_max = 0;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const uint64_t task = task0 + k;
-        m[k] = 0;
-        if (task < n_tasks) { const uint64_t read = task >> 1; m[k] = (uint32_t)(offs[read + 1] - offs[read]); }
-        m_max = m[k] > m_max ? m[k] : m_max;
-        run[k] = (uint32_t)K.r - 1; pos[k] = K.n - 1; sample[k] = K.last_run_sample; word[k] = 0;
-        n_steps += m[k];
+        S[k].m = 0;
+        if (task < n_tasks) { const uint64_t read = task >> 1; S[k].m = (uint32_t)(offs[read + 1] - offs[read]); }
+        m_max = S[k].m > m_max ? S[k].m : m_max;
+        S[k].run = (uint32_t)K.r - 1; S[k].pos = K.n - 1; S[k].abs = true; S[k].off = 0;     // start with the empty string
+        S[k].sample = K.last_run_sample; S[k].word = 0;
+        n_steps += S[k].m;
     }
-    const uint32_t sigma = K.sigma;
     for (uint32_t s = 0; s < m_max; ++s) {
-        uint32_t c[NCH], jh[NCH];
-        uint64_t a0[NCH], a1[NCH];                       // row words: start|head|dest_hi|len, lfbase|dest_lo
-        // pattern[m-1-s], already strand-resolved by pack_task; then the row of the current run guess.  All NCH row reads
-        // are issued before any is used.
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            if (s < m[k] && (s & 7u) == 0) word[k] = pat[(uint64_t)(s >> 3) * n_tasks + (task0 + k)];
-            const uint32_t raw = (uint32_t)word[k] & 0xFFu;
-            c[k] = L.code[raw];
-            const moni_u64x4 v = *reinterpret_cast<const moni_u64x4*>(rows + run[k]);
-            a0[k] = v.x; a1[k] = v.y;
-            const uint32_t hs = c[k] != MONI_CODE_ABSENT ? L.hot_slot[c[k]] : 0u;
-            jh[k] = hs == 0 ? (uint32_t)v.z : hs == 1 ? (uint32_t)(v.z >> 32) : hs == 2 ? (uint32_t)v.w : hs == 3 ? (uint32_t)(v.w >> 32) : 0xFFFFFFFFu;
-        }
-        moni_u64x4 rv[NCH];
-        uint32_t jmp = 0;                                 // bit k: chain k takes a threshold jump this step
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            if (s < m[k] && c[k] != MONI_CODE_ABSENT) {
-                moni_row_t A; A.w0 = a0[k]; A.w1 = a1[k];
-                if (pos[k] < row_start(A) || !in_run(rows, run[k], A, pos[k])) {
-                    settle_run(rows, K.r, pos[k], run[k], A);
-                    a0[k] = A.w0; a1[k] = A.w1;
-                    const uint32_t hs = L.hot_slot[c[k]];
-                    jh[k] = hs < 4 ? row_hot(A, hs) : 0xFFFFFFFFu;
-                }
-                if (row_head(A) != c[k]) {                    // bwt[pos] != c: threshold jump (moni.hpp:595-618); the sentinel head never matches
-                    jmp |= 1u << k;
-                    if (jh[k] == 0xFFFFFFFFu) jh[k] = cr[(uint64_t)run[k] * sigma + c[k]];     // symbol without a hot slot
-                    rv[k] = *reinterpret_cast<const moni_u64x4*>(recs + L.rec_base[c[k]] + jh[k]);
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            if (s >= m[k]) continue;
-            if (c[k] == MONI_CODE_ABSENT) {                   // n_c == 0   (moni.hpp:583-588)
-                const uint32_t raw = (uint32_t)word[k] & 0xFFu;
-                sample[k] = 0;
-                pos[k] = L.abs_pos[raw];
-                run[k] = L.abs_run[raw];
-            } else if (!(jmp >> k & 1u)) {                    // bwt[pos] == c  (moni.hpp:589-594)
-                sample[k]--;
-                pos[k] = (a1[k] & MONI_POS_MASK) + (pos[k] - (a0[k] & MONI_POS_MASK));
-                run[k] = (uint32_t)(((a0[k] >> 44) & 0xFFu) << 24) | (uint32_t)(a1[k] >> 40);
+            if (s >= S[k].m) continue;
+            // pattern[m-1-s], already strand-resolved by pack_task
+            if ((s & 7u) == 0) S[k].word = pat[(uint64_t)(s >> 3) * n_tasks + (task0 + k)];
+            const uint32_t raw = (uint32_t)S[k].word & 0xFFu;
+            S[k].word >>= 8;
+            const uint32_t c = L.code[raw];
+            if (c == MONI_CODE_ABSENT) {                      // n_c == 0   (moni.hpp:583-588)
+                S[k].sample = 0;
+                S[k].pos = L.abs_pos[raw];
+                S[k].run = L.abs_run[raw];
+                S[k].abs = true;
             } else {
-                ++n_jumps;
-                const uint64_t thr = rv[k].x & MONI_POS_MASK;
-                const uint32_t d = (uint32_t)((rv[k].x >> 40) << 24) | (uint32_t)(rv[k].y >> 40);
-                // rnk_c.first > thresholds.rank(pos+1, c)  <=>  j >= 1 and (no c-run below, or pos < thr_j)
-                const bool up = jh[k] > 0 && (jh[k] == L.rec_cnt[c[k]] || pos[k] < thr);
-                if (up) { sample[k] = rv[k].z; pos[k] = rv[k].w - 1; }
-                else { sample[k] = rv[k].y & MONI_POS_MASK; pos[k] = rv[k].w; }
-                run[k] = d;
+                ms_step(K, L, rows, frows, cr, recs, c, S[k], n_jumps);
             }
-            word[k] >>= 8;
-            ptr_out[(uint64_t)s * n_tasks + (task0 + k)] = sample[k];
+            ptr_out[(uint64_t)s * n_tasks + (task0 + k)] = S[k].sample;
         }
     }
 }

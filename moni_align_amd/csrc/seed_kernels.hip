@@ -49,14 +49,14 @@ pack_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const ui
 template <int NCH, int MINW>
 __global__ void __launch_bounds__(MS_BLOCK, MINW)
 ms_lf_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const moni_row_t* __restrict__ rows,
-             const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs,
+             const moni_frow_t* __restrict__ frows, const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs,
              const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, uint64_t n_tasks,
              uint64_t* __restrict__ ptr_out, unsigned long long* __restrict__ counters) {
     __shared__ lds_tables_t L;
     load_tables(L, T, K);
     const uint64_t task0 = ((uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x) * NCH;
     unsigned long long n_steps = 0, n_jumps = 0;
-    if (task0 < n_tasks) ms_task<NCH>(K, L, rows, cr, recs, pat, offs, n_tasks, task0, ptr_out, n_steps, n_jumps);
+    if (task0 < n_tasks) ms_task<NCH>(K, L, rows, frows, cr, recs, pat, offs, n_tasks, task0, ptr_out, n_steps, n_jumps);
     wave_add(n_steps, &counters[0]);
     wave_add(n_jumps, &counters[1]);
 }

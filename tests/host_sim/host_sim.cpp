@@ -32,6 +32,8 @@ extern "C" {
 void* sim_create(const moni_flat_index_t* f) {
     Sim* S = new Sim();
     if (S->img.build(*f)) { fprintf(stderr, "host_sim: %s\n", S->img.err.c_str()); delete S; return nullptr; }
+    if (getenv("MH_TIMES")) { uint64_t ok = 0, cov = 0; for (uint64_t k = 0; k < f->r; ++k) if ((S->img.frows[k].w[0] >> 58) & 1) { ++ok; cov += f->starts[k + 1] - f->starts[k]; }
+        fprintf(stderr, "fast rows: %.4f of runs, %.4f of BWT positions\n", (double)ok / f->r, (double)cov / f->n); }
     S->text.assign(f->text, f->text + f->n - 1);
     S->text.resize(S->text.size() + 16, 0);
     S->name_id.resize(f->n_seq);
@@ -63,7 +65,7 @@ int sim_seed_run(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_r
     std::vector<uint64_t> pat(n_tasks * n_words + 1);
     for (uint64_t t = 0; t < n_tasks; ++t) pack_task(S->L, seq, offs, n_tasks, t, n_words, pat.data());
     for (uint64_t t = 0; t < n_tasks; t += 2)
-        ms_task<2>(K, S->L, S->img.rows.data(), S->img.cr.data(), S->img.recs.data(), pat.data(), offs, n_tasks, t, S->ptr.data(), cnt[0], cnt[1]);
+        ms_task<2>(K, S->L, S->img.rows.data(), S->img.frows.data(), S->img.cr.data(), S->img.recs.data(), pat.data(), offs, n_tasks, t, S->ptr.data(), cnt[0], cnt[1]);
     std::vector<uint32_t> cnt_m(n_tasks + 1), cnt_s(n_tasks + 1);
     std::vector<moni_u64x2> slots(n_tasks * MONI_MEM_SLOTS + 1);
     const uint32_t split_on = prm->report_mems ? 0 : 1;

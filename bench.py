@@ -63,10 +63,15 @@ def main():
         log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # rehearsal overrides (several ranks on one GPU with gloo); the driver's multi-GPU run uses the defaults: RCCL, one GPU per rank
+    backend = os.environ.get("MONI_BENCH_BACKEND", "nccl")
+    if "MONI_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["MONI_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if world > 1:
-        dist = mdist.init("nccl", rank, world, local_rank)
+        dist = mdist.init(backend, rank, world, local_rank)
 
     from moni_align_amd import capi, index_build, synth
 
@@ -120,16 +125,23 @@ def main():
         kern += [ctx.kernel_ms(w) if w != 5 else 0.0 for w in range(7)]
     sync_all()
     elapsed = time.perf_counter() - t0
-    elapsed = mdist.max_over_ranks(elapsed, dist, "cuda")
+    elapsed = mdist.max_over_ranks(elapsed, dist, coll_dev)
     kern /= max(1, args.steps)
     cnt = ctx.counters()
     res = ctx.seed_fetch()
     n_mems, n_occs = len(res["mems"]), len(res["occs"])
-    sizes = mdist.gather_counts([n_mems, n_occs], dist, "cuda")     # the only result exchange: per-rank record counts
+    sizes = mdist.gather_counts([n_mems, n_occs], dist, coll_dev)     # the only result exchange: per-rank record counts
 
     out = None
     if rank == 0:
         S, J, P, C = (int(x) for x in cnt)
+        traffic, traffic_src = None, None
+        try:        # HBM bytes per launch from the separate rocprofv3 --pmc passes of this same command (profiles/run_profile.sh)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_ms_lf.json")))
+            if tj.get("n") == fi.n and tj.get("reads") == args.reads and tj.get("read_len") == L:
+                traffic, traffic_src = tj["fetch_bytes"] + tj["write_bytes"], tj["source"]
+        except Exception:
+            pass
         ms_bytes = 128 * S + 64 * J                 # algorithmic bytes of the LF stage
         ms_s = kern[0] / 1e3
         achieved = ms_bytes / ms_s / 1e9 if ms_s > 0 else 0.0
@@ -144,7 +156,7 @@ def main():
                                    % (args.base_len, args.haps, fi.n, fi.r, args.reads, L),
                        "reads_per_gpu": args.reads, "read_len": L, "parallelism": "reads sharded x%d, index replicated" % world},
             "roofline": {"bound": "hbm", "kernel": "ms_lf_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ms_bytes, "avg_launch_ms": kern[0],
                          "per_read_bytes": ms_bytes / args.reads},
             "kernels_ms": {"ms_lf": kern[0], "mem_count": kern[1], "mem_emit": kern[2], "occ_count": kern[3], "occ_fill": kern[4],

@@ -296,7 +296,7 @@ static int ms_launch(moni_ctx* c) {
             case 3: MS_LAUNCH(2, 6); break;
             case 4: MS_LAUNCH(1, 6); break;
             case 5: MS_LAUNCH(4, 4); break;
-            default: MS_LAUNCH(1, 8); break;
+            default: MS_LAUNCH(1, 6); break;   // fastest in profiles/r01d_ms_variant_sweep_fastrows.txt
         }
 #undef MS_LAUNCH
     }

@@ -32,3 +32,32 @@ for tag in ("pmc_fetch", "pmc_write", "pmc_tcc"):
     for k, d in agg.items():
         for cname, vals in d.items():
             print("%-60s %-24s n=%d mean=%.1f min=%.1f max=%.1f" % (k, cname, len(vals), sum(vals) / len(vals), min(vals), max(vals)))
+
+# HBM traffic of the dominant kernel for bench.py's roofline.traffic (bytes per launch; FETCH_SIZE/WRITE_SIZE are in KB and
+# count 64-byte requests for this kernel's per-lane gathers, see profiles/README.md)
+import json
+vals = {}
+for tag, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    v = []
+    for f in find(tag + "/**/*counter_collection.csv"):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if "ms_lf_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == cname:
+                    v.append(float(row["Counter_Value"]))
+    vals[cname] = sum(v) / len(v) if v else None
+try:
+    b = json.load(open(os.path.join(out, "bench_trace.json")))
+    import re
+    mm = re.search(r"n=(\d+), r=(\d+)", b["config"]["workload"])
+    doc = {"kernel": "ms_lf_kernel", "n": int(mm.group(1)), "r": int(mm.group(2)), "reads": b["config"]["reads_per_gpu"],
+           "read_len": b["config"]["read_len"], "fetch_bytes": vals["FETCH_SIZE"] * 1024, "write_bytes": vals["WRITE_SIZE"] * 1024,
+           "avg_launch_ms_rocprof": None, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, " + os.path.basename(out.rstrip("/"))}
+    for f in find("trace/**/*kernel_stats.csv"):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if "ms_lf_kernel" in row.get("Name", ""):
+                    doc["avg_launch_ms_rocprof"] = float(row["AverageNs"]) / 1e6
+    json.dump(doc, open(os.path.join(out, "traffic_ms_lf.json"), "w"), indent=1)
+    print("traffic:", doc)
+except Exception as e:
+    print("traffic summary failed:", e)

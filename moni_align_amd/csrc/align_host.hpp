@@ -577,6 +577,38 @@ struct Aligner {
         }
     }
 
+    // Host part of an alignment that was decided on the GPU (align_core.h): positions, MD/NM, MAPQ
+    // (aligner_ksw2.hpp:3110-3175, 2067-2076, 498-511).
+    void finish_record(uint32_t m, uint64_t off, uint32_t strand, uint64_t ref_pos, int32_t score, int32_t score2, const uint32_t* cig,
+                       uint32_t n_cig, const uint64_t* alt_pos, const int32_t* alt_score, uint32_t n_alt, Sam& S) const {
+        std::vector<uint32_t> cigar(cig, cig + n_cig);
+        uint64_t ref_len = 0;
+        for (uint32_t c : cigar) { const int op = c & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4; }
+        std::string cs;
+        for (uint32_t c : cigar) { cs += std::to_string(c >> 4); cs.push_back("MID"[c & 0xf]); }
+        std::vector<uint8_t> ref(ref_len + 1), seq(m + 1);
+        for (uint64_t k = 0; k < ref_len; ++k) ref[k] = nt4_of(ref_pos + k < ix.n_text ? ix.text[ref_pos + k] : 0);
+        for (uint32_t k = 0; k < m; ++k) seq[k] = nt4_of(strand ? compl_of(reads[off + m - 1 - k]) : reads[off + k]);
+        S.lift_cigar = cs;
+        S.lift_md.clear();
+        S.lift_nm = md_core(ref.data(), seq.data(), cigar, S.lift_md);      // the window the CIGAR spans == [ref_pos, ref_pos + rlen)
+        const auto refi = ix.index(ref_pos);
+        S.as = (size_t)(int64_t)score;
+        S.lift_pos = refi.second + 1;
+        S.lift_rname = ix.names[refi.first];
+        S.pos = S.lift_pos; S.rname = S.lift_rname; S.cigar = cs;              // null lift
+        if (ref_len > 0) { S.md = S.lift_md; S.nm = S.lift_nm; S.rlen = ref_len; }
+        else { S.pos = 0; S.rname = "*"; S.cigar = "*"; S.rlen = 0; S.unmapped_lft = true; }
+        for (uint32_t k = 0; k < n_alt; ++k) {
+            const auto r = ix.index(alt_pos[k]);
+            S.alt_haplotypes.push_back(ix.names[r.first]); S.alt_pos.push_back(r.second + 1); S.alt_scores.push_back((size_t)(int64_t)alt_score[k]);
+        }
+        S.flag = strand ? 16 : 0;
+        S.zs = (size_t)(int64_t)score2;
+        S.mapq = mapq_se_bwa((int32_t)S.as, (int32_t)S.zs, (int32_t)S.rlen, (int32_t)m, (int32_t)P.min_len, P.smatch, P.smismatch, 50.0, mapq_coeff_fac);
+        if (strand) S.rev_read = true;
+    }
+
     static void sam_write(std::string& out, const Sam& s, const std::string& name, const std::string& seq, const std::string* qual) {   // sam.hpp:144-188
         char buf[32];
         auto d = [&](size_t v) { snprintf(buf, sizeof buf, "%d", (int)v); out += buf; };

@@ -11,6 +11,7 @@
 #include "../../moni_align_amd/csrc/image.hpp"
 #include "../../moni_align_amd/csrc/seed_core.h"
 #include "../../moni_align_amd/csrc/align_host.hpp"
+#include "../../moni_align_amd/csrc/align_core.h"
 #include "../../oracle/ksw2.hpp"      // CPU stand-in for extz_kernel in this harness (tests may use the oracle)
 
 struct Sim {
@@ -191,6 +192,71 @@ char* sim_align_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint64_
     *out_len = out.size();
     if (stats5) { stats5[0] = st.reads; stats5[1] = st.aligned; stats5[2] = st.dp_tasks; stats5[3] = st.dp_cells; stats5[4] = st.dp_rounds; }
     if (getenv("MH_TIMES")) fprintf(stderr, "host_sim times: seed %.3f chain %.3f dp %.3f host %.3f s\n", st.t_seed, st.t_chain, st.t_dp, st.t_host);
+    return buf;
+}
+// ---- the device-side per-read logic (align_core.h) replayed on the host: what the align kernel's lane 0 runs ----
+char* sim_align_core_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_reads, const uint8_t* names, const uint64_t* name_off,
+                           const uint8_t* quals, uint64_t* out_len, uint64_t* stats5) {
+    Sim* S = (Sim*)s;
+    SimBackend be;
+    be.S = S; be.seq = seq; be.offs = offs; be.n_reads = n_reads;
+    moni_align_params_t P;
+    memset(&P, 0, sizeof P);
+    P.min_len = 25; P.ext_len = 100; P.check_k = 5; P.region_dist = 10; P.filter_seeds = 1; P.n_seeds_thr = 1000; P.filter_freq = 1;
+    P.left_mem_check = 1; P.freq_thr = 0.5; P.smatch = 2; P.smismatch = 4; P.gapo = 4; P.gapo2 = 13; P.gape = 2; P.gape2 = 1;
+    P.end_bonus = 400; P.w = -1; P.zdrop = -1; P.max_dist_x = 500; P.max_dist_y = 100; P.max_iter = 10; P.max_pred = 5;
+    P.min_chain_score = 40; P.min_chain_length = 1; P.host_threads = 1;
+    moni_seed_params_t sp{P.min_len, P.filter_seeds, P.n_seeds_thr, 0};
+    std::vector<moni_mem_t> gm; std::vector<uint64_t> go, rmo;
+    if (be.seed(sp, gm, go, rmo)) return nullptr;
+    ac_params_t AP;
+    AP.min_len = P.min_len; AP.ext_len = P.ext_len; AP.check_k = P.check_k; AP.region_dist = P.region_dist; AP.filter_freq = P.filter_freq;
+    AP.left_mem_check = P.left_mem_check; AP.freq_thr = P.freq_thr; AP.smatch = P.smatch; AP.gapo = P.gapo; AP.gapo2 = P.gapo2; AP.gape = P.gape;
+    AP.gape2 = P.gape2; AP.max_dist_x = P.max_dist_x; AP.max_dist_y = P.max_dist_y; AP.max_iter = P.max_iter; AP.max_pred = P.max_pred;
+    AP.min_chain_score = P.min_chain_score; AP.min_chain_length = P.min_chain_length; AP.n_text = S->hix.n_text; AP.n_seq = (uint32_t)S->hix.names.size();
+    AP.seq_starts = S->hix.seq_starts.data();
+    moni_dp_params_t dp;
+    memset(&dp, 0, sizeof dp);
+    dp.m = 5;
+    for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) dp.mat[i * 5 + j] = i == j ? P.smatch : (int8_t)-P.smismatch; }
+    dp.q = P.gapo; dp.e = P.gape; dp.w = -1; dp.zdrop = -1; dp.end_bonus = P.end_bonus;
+    mh::Aligner A(S->hix, P, seq, offs);
+    std::string out, name, sq, ql;
+    uint64_t n_aligned = 0, n_over = 0, n_tasks = 0, n_rounds = 0;
+    ac_ws_t* W = new ac_ws_t();
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        W->off = offs[r] - offs[0]; W->m = (uint32_t)(offs[r + 1] - offs[r]);
+        W->min_score = (int32_t)(20 + 8 * log((double)W->m));
+        std::vector<moni_dp_result_t> res;
+        std::vector<uint32_t> cig;
+        if (ac_init(*W, AP, gm.data(), rmo[r], rmo[r + 1], go.data())) {
+            ac_drive(*W, AP, nullptr, nullptr);
+            while (!W->overflow && W->stage != AC_DONE) {
+                std::vector<moni_dp_task_t> tasks(W->tasks, W->tasks + W->n_tasks);
+                n_tasks += tasks.size(); ++n_rounds;
+                if (be.dp(dp, tasks, res, cig)) return nullptr;
+                ac_drive(*W, AP, res.data(), cig.data());
+            }
+        }
+        mh::Sam Sm;
+        if (W->overflow) ++n_over;
+        else if (W->aligned) {
+            A.finish_record(W->m, W->off, W->fill.strand, W->fill.ref_pos, W->fill.score, W->score2, W->cigar, W->n_cigar, W->alt_pos, W->alt_score, W->n_alt, Sm);
+            ++n_aligned;
+        }
+        const uint8_t* sp0 = seq + W->off;
+        name.assign((const char*)names + name_off[r], (const char*)names + name_off[r + 1]);
+        sq.resize(W->m);
+        if (Sm.rev_read) for (uint32_t k = 0; k < W->m; ++k) sq[k] = (char)mh::compl_of(sp0[W->m - 1 - k]); else sq.assign((const char*)sp0, (const char*)sp0 + W->m);
+        if (quals) { const uint8_t* qv = quals + W->off; ql.resize(W->m); if (Sm.rev_read) for (uint32_t k = 0; k < W->m; ++k) ql[k] = (char)qv[W->m - 1 - k]; else ql.assign((const char*)qv, (const char*)qv + W->m); }
+        if (!W->aligned) Sm.flag = 4;
+        mh::Aligner::sam_write(out, Sm, name, sq, quals ? &ql : nullptr);
+    }
+    delete W;
+    char* buf = (char*)malloc(out.size() + 1);
+    memcpy(buf, out.data(), out.size() + 1);
+    *out_len = out.size();
+    if (stats5) { stats5[0] = n_reads; stats5[1] = n_aligned; stats5[2] = n_tasks; stats5[3] = n_over; stats5[4] = n_rounds; }
     return buf;
 }
 void sim_free(void* p) { free(p); }

@@ -17,7 +17,7 @@ def lib():
     if _lib is None:
         so = os.path.join(HERE, "libhost_sim.so")
         srcs = [os.path.join(HERE, "host_sim.cpp"), os.path.join(ROOT, "oracle", "ksw2.hpp")] + \
-               [os.path.join(capi.CSRC, f) for f in ("seed_core.h", "image.hpp", "layout.h", "align_host.hpp")]
+               [os.path.join(capi.CSRC, f) for f in ("seed_core.h", "image.hpp", "layout.h", "align_host.hpp", "align_core.h", "sort_emul.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(HERE, "host_sim.cpp")])
         L = C.CDLL(so)
@@ -35,6 +35,9 @@ def lib():
         L.sim_align_batch.restype = C.c_void_p
         L.sim_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.POINTER(C.c_uint64), C.c_void_p]
+        L.sim_align_core_batch.restype = C.c_void_p
+        L.sim_align_core_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_uint64), C.c_void_p]
         L.sim_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
@@ -84,6 +87,25 @@ class Sim:
                                   quals.ctypes.data if quals is not None else None, threads, C.byref(ln), st.ctypes.data)
         if not p:
             raise RuntimeError("sim_align_batch failed")
+        try:
+            return C.string_at(p, ln.value), st
+        finally:
+            lib().sim_free(p)
+
+    def align_core_batch(self, seq, offsets, names, name_off, quals=None):
+        """SAM via the device-side per-read logic (align_core.h) replayed on the host; stats = reads, aligned, dp tasks, overflowed, rounds"""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        names = np.ascontiguousarray(names, dtype=np.uint8)
+        name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
+        if quals is not None:
+            quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        ln = C.c_uint64()
+        st = np.zeros(5, dtype=np.uint64)
+        p = lib().sim_align_core_batch(self.h, seq.ctypes.data, offsets.ctypes.data, len(offsets) - 1, names.ctypes.data, name_off.ctypes.data,
+                                       quals.ctypes.data if quals is not None else None, C.byref(ln), st.ctypes.data)
+        if not p:
+            raise RuntimeError("sim_align_core_batch failed")
         try:
             return C.string_at(p, ln.value), st
         finally:

@@ -57,3 +57,25 @@ def test_sam_identical_without_quals(small_case):
     want, _ = orc.align_batch(o, reads.reshape(-1), offs, names, noff, None)
     got, _ = hs.Sim(small_case.fi).align_batch(reads.reshape(-1), offs, names, noff, None, threads=2)
     assert got == want
+
+
+def test_device_side_logic_replayed_on_host(medium_case):
+    """align_core.h (what lane 0 of the align kernel runs: STL-free chaining with the libstdc++ sort emulation, selection
+    loop, fill_chain, CIGAR stitching) must give the oracle's SAM too; reads that overflow its capacities are reported."""
+    rng = np.random.default_rng(5)
+    reads = list(medium_case.synth.make_reads(medium_case.pg, 1200, 150, seed=77))
+    base = medium_case.synth.make_reads(medium_case.pg, 300, 250, seed=9, sub_rate=0.04, indel_rate=0.006)
+    reads += [r[: int(rng.integers(30, 251))].copy() for r in base]
+    reads.append(np.frombuffer(b"N" * 60, dtype=np.uint8))
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    seq = np.concatenate(reads)
+    names, noff = orc.make_names(len(reads))
+    quals = np.full(len(seq), ord("I"), dtype=np.uint8)
+    o = orc.OracleIndex(medium_case.path)
+    want, wcnt = orc.align_batch(o, seq, offs, names, noff, quals, threads=2)
+    got, st = hs.Sim(medium_case.fi).align_core_batch(seq, offs, names, noff, quals)
+    assert int(st[3]) == 0, "reads overflowed the device capacities"
+    if got != want:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
+    assert int(st[1]) == wcnt["aligned"]

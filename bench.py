@@ -199,7 +199,8 @@ def main():
             out["full_path"] = {"workload": "BASELINE.json configs[2]: seeding + HIP ksw2 extension + chaining/MAPQ/SAM on host, %d reads, "
                                             "host buffers in / SAM text out" % nfp,
                                 "value": nfp / dtf, "unit": "reads/s", "aligned": stf["aligned"], "dp_tasks": stf["dp_tasks"],
-                                "dp_cells": stf["dp_cells"], "dp_rounds": stf["dp_rounds"], "host_threads": host_cpus(),
+                                "dp_cells": stf["dp_cells"], "dp_rounds": stf["dp_rounds"], "handed_back_to_host_pipeline": stf["handed_back"],
+                                "host_threads": host_cpus(),
                                 "seconds": {"seed": stf["t_seed"], "chain": stf["t_chain"], "dp": stf["t_dp"], "host_other": stf["t_host"],
                                             "dp_kernels": stf["t_dp_kernel"]},
                                 "gcups_dp_stage": stf["dp_cells"] / stf["t_dp"] / 1e9 if stf["t_dp"] > 0 else None,

@@ -167,7 +167,8 @@ typedef struct {
 typedef struct {
     uint64_t reads, aligned, dp_tasks, dp_cells, dp_rounds;
     double t_seed, t_chain, t_dp, t_host;                 /* seconds: seeding incl. fetch, chaining, DP batches incl. transfers, other host work */
-    double t_dp_kernel;                                   /* seconds inside extz_kernel launches (HIP events) */
+    double t_dp_kernel;                                   /* seconds inside the align / extz kernels (HIP events) */
+    uint64_t handed_back;                                 /* reads that exceeded the align kernel's capacities and went through the host pipeline */
 } moni_align_stats_t;
 
 void moni_align_params_default(moni_align_params_t *p);

@@ -12,8 +12,10 @@
 
 #if defined(__HIPCC__)
 #define AC_HD __host__ __device__ __forceinline__
+#define AC_HD_BIG __host__ __device__ __attribute__((noinline))     // real calls on the device: the kernel stays compilable
 #else
 #define AC_HD inline
+#define AC_HD_BIG inline
 #endif
 
 #ifndef DP_EZ_SCORE_ONLY
@@ -114,7 +116,7 @@ AC_HD uint64_t ac_occ(const ac_ws_t& W, uint32_t mem, uint32_t occ) { return W.m
 
 // ---- seeds -> filtered mems -> anchors -> chains (aligner_ksw2.hpp:342,382; chain.hpp:221-438) ----
 // returns false if the read is not chained (or overflowed: W.overflow)
-AC_HD bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, uint64_t a, uint64_t b, const uint64_t* occs) {
+AC_HD_BIG bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, uint64_t a, uint64_t b, const uint64_t* occs) {
     W.stage = AC_DONE; W.aligned = 0; W.overflow = 0; W.n_cigar = 0; W.n_tasks = 0;
     W.i = 0; W.n_diff = W.n_best = W.n_left = W.n_alt = 0; W.max_score = 0; W.score2 = 0; W.final_chain = 0;
     W.n_mems = W.n_anch = W.n_chains = W.pool_used = 0;
@@ -222,7 +224,7 @@ AC_HD void ac_qseg(const ac_ws_t& W, uint32_t strand, uint64_t a, uint64_t len, 
 }
 
 // returns false if the chain does not fit (overflow)
-AC_HD bool ac_fill_begin(ac_ws_t& W, const ac_params_t& P, const ac_chain_t& ch, bool score_only) {
+AC_HD_BIG bool ac_fill_begin(ac_ws_t& W, const ac_params_t& P, const ac_chain_t& ch, bool score_only) {
     ac_fill_t& F = W.fill;
     W.n_tasks = 0;
     if (ch.cnt > AC_MAX_FILL) { W.overflow = 1; return false; }
@@ -298,7 +300,7 @@ AC_HD bool ac_fill_begin(ac_ws_t& W, const ac_params_t& P, const ac_chain_t& ch,
 }
 
 // ---- fill_chain, part 2 (aligner_ksw2.hpp:2852-2886, 2975-2996); returns true if a dependent global problem was queued ----
-AC_HD bool ac_fill_after_ext(ac_ws_t& W, const ac_params_t& P, const moni_dp_result_t* res) {
+AC_HD_BIG bool ac_fill_after_ext(ac_ws_t& W, const ac_params_t& P, const moni_dp_result_t* res) {
     ac_fill_t& F = W.fill;
     const ac_mem_t& last = W.mems[F.an_mem[F.n_an - 1]];
     int score_lc = 0, score_rc = 0;
@@ -331,7 +333,7 @@ AC_HD bool ac_fill_after_ext(ac_ws_t& W, const ac_params_t& P, const moni_dp_res
 }
 
 // ---- fill_chain, part 3 (final pass): the stitched CIGAR (aligner_ksw2.hpp:3000-3108) ----
-AC_HD bool ac_fill_final(ac_ws_t& W, const ac_params_t& P, const moni_dp_result_t* res, const uint32_t* cig) {
+AC_HD_BIG bool ac_fill_final(ac_ws_t& W, const ac_params_t& P, const moni_dp_result_t* res, const uint32_t* cig) {
     ac_fill_t& F = W.fill;
     W.n_cigar = 0;
     if (!ac_valid(P, F.ref_pos, F.ref_len)) return true;
@@ -362,7 +364,7 @@ AC_HD bool ac_fill_final(ac_ws_t& W, const ac_params_t& P, const moni_dp_result_
 }
 
 // aligner_ksw2.hpp:553-597
-AC_HD bool ac_check_left_mem(ac_ws_t& W, const ac_params_t& P, uint64_t ci) {
+AC_HD_BIG bool ac_check_left_mem(ac_ws_t& W, const ac_params_t& P, uint64_t ci) {
     const ac_chain_t& ch = W.chains[ci];
     const ac_anchor_t& A = W.anch[W.pool[ch.off + ch.cnt - 1]];                    // leftmost anchor
     const uint64_t left_ref = ac_seq_off(P, ac_occ(W, A.mem, A.occ)) + 1;            // null lift: index(lift(pos)).second + 1
@@ -378,7 +380,7 @@ AC_HD bool ac_check_left_mem(ac_ws_t& W, const ac_params_t& P, uint64_t ci) {
 }
 
 // a scored chain comes back into the selection loop (aligner_ksw2.hpp:436-460, 528-548)
-AC_HD void ac_absorb(ac_ws_t& W, const ac_params_t& P, int32_t score, uint64_t pos) {
+AC_HD_BIG void ac_absorb(ac_ws_t& W, const ac_params_t& P, int32_t score, uint64_t pos) {
     const uint64_t lft = pos;                                                        // idx.lift(score.pos), null lift
     if (score > W.max_score) { W.max_score = score; W.n_alt = 0; }
     else if (score == W.max_score) {
@@ -404,7 +406,7 @@ AC_HD void ac_absorb(ac_ws_t& W, const ac_params_t& P, int32_t score, uint64_t p
 
 // Runs the selection loop until the read needs DP results (W.n_tasks > 0 or a fill without DP) or is done.
 // Returns true if a fill was started (stage AC_WAIT_A / AC_FINAL_WAIT_A).
-AC_HD bool ac_advance(ac_ws_t& W, const ac_params_t& P) {
+AC_HD_BIG bool ac_advance(ac_ws_t& W, const ac_params_t& P) {
     while (W.stage == AC_LOOP && !W.overflow) {
         if (W.i < W.n_chains && W.n_diff < P.check_k) {
             { const uint64_t v = (uint64_t)W.chains[W.i].score; bool f = false; for (uint32_t q = 0; q < W.n_diff; ++q) f = f || W.diff[q] == v; if (!f) W.diff[W.n_diff++] = v; }
@@ -435,7 +437,7 @@ AC_HD bool ac_advance(ac_ws_t& W, const ac_params_t& P) {
 
 // Drive the read: consume the results of the DP problems it queued last (res / cig index the tasks of W.tasks in order) and
 // continue until it queues new ones (returns with W.n_tasks > 0) or finishes (W.stage == AC_DONE) or overflows.
-AC_HD void ac_drive(ac_ws_t& W, const ac_params_t& P, const moni_dp_result_t* res, const uint32_t* cig) {
+AC_HD_BIG void ac_drive(ac_ws_t& W, const ac_params_t& P, const moni_dp_result_t* res, const uint32_t* cig) {
     while (!W.overflow) {
         switch (W.stage) {
             case AC_LOOP:

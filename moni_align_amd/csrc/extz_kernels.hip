@@ -61,21 +61,16 @@ __device__ __forceinline__ long long wave_max_i64(long long v) {
     return v;
 }
 
+// One DP problem on one wavefront.  qs: LDS scratch for the query codes (>= qlen bytes); dir: direction bytes of this
+// problem ((qlen+tlen-1)*tlen, CIGAR problems only); cg: CIGAR slots (qlen+tlen+2).  Every lane returns the same R.
 template <int NCH>
-__global__ void __launch_bounds__(64)
-extz_kernel(const dp_launch_t P) {
-    __shared__ uint8_t qs[DP_MAX_QLEN];
-    const int lane = threadIdx.x;
-    const uint32_t tix = P.order[blockIdx.x];
-    const moni_dp_task_t task = P.tasks[tix];
+__device__ __forceinline__ void extz_wave(const dp_launch_t& P, const moni_dp_task_t task, uint8_t* __restrict__ qs,
+                                          uint8_t* __restrict__ dir_base, uint32_t* __restrict__ cg_base, moni_dp_result_t& R) {
+    const int lane = threadIdx.x & 63;
     const int qlen = task.qlen, tlen = task.tlen, flag = task.flag;
-    moni_dp_result_t R;
     R.max = 0; R.max_q = R.max_t = R.mqe_t = R.mte_q = -1; R.mqe = R.mte = R.score = DP_NEG_INF;
     R.reach_end = 0; R.zdropped = 0; R.n_cigar = 0; R.cigar_off = 0;
-    if (qlen <= 0 || tlen <= 0) {                       // ksw_extz2_sse returns right after ksw_reset_extz
-        if (lane == 0) P.results[tix] = R;
-        return;
-    }
+    if (qlen <= 0 || tlen <= 0) return;                 // ksw_extz2_sse returns right after ksw_reset_extz
     const bool with_cigar = !(flag & DP_EZ_SCORE_ONLY);
     const bool right = (flag & DP_EZ_RIGHT) != 0;
     const int mode = task.reserved;
@@ -92,7 +87,7 @@ extz_kernel(const dp_launch_t P) {
     }
     __syncthreads();
     const int32_t qo = P.qo, e = P.e;
-    uint8_t* __restrict__ dir = with_cigar ? P.dirs + P.dir_off[tix] : nullptr;
+    uint8_t* __restrict__ dir = with_cigar ? dir_base : nullptr;
 
     int32_t H1[NCH], H2[NCH], E1[NCH], F1[NCH];
     int32_t tcode[NCH];
@@ -224,7 +219,7 @@ extz_kernel(const dp_launch_t P) {
         else if (R.mqe + P.end_bonus > R.max) { R.reach_end = 1; i0 = R.mqe_t; j0 = qlen - 1; }
         else if (R.max_t >= 0 && R.max_q >= 0) { i0 = R.max_t; j0 = R.max_q; }
         if (lane == 0 && i0 >= 0 && j0 >= 0) {
-            uint32_t* __restrict__ cg = P.cig_tmp + P.cig_off[tix];
+            uint32_t* __restrict__ cg = cg_base;
             int n = 0, i = i0, j = j0, state = 0;
             auto push = [&](uint32_t op, int len) {
                 if (n == 0 || op != (cg[n - 1] & 0xf)) cg[n++] = (uint32_t)len << 4 | op;
@@ -245,5 +240,25 @@ extz_kernel(const dp_launch_t P) {
             R.n_cigar = (uint32_t)n;
         }
     }
-    if (lane == 0) P.results[tix] = R;
+    R.n_cigar = (uint32_t)__shfl((int)R.n_cigar, 0);
+    __syncthreads();                                    // qs / dir are reused by the next problem of this wave
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(64)
+extz_kernel(const dp_launch_t P) {
+    __shared__ uint8_t qs[DP_MAX_QLEN];
+    const uint32_t tix = P.order[blockIdx.x];
+    const moni_dp_task_t task = P.tasks[tix];
+    const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
+    moni_dp_result_t R;
+    extz_wave<NCH>(P, task, qs, with_cigar ? P.dirs + P.dir_off[tix] : nullptr, with_cigar ? P.cig_tmp + P.cig_off[tix] : nullptr, R);
+    if (threadIdx.x == 0) P.results[tix] = R;
+}
+
+// out-of-line instances for callers that run many problem sizes from one kernel (align_kernel)
+template <int NCH>
+__device__ __attribute__((noinline)) void extz_wave_call(const dp_launch_t& P, const moni_dp_task_t task, uint8_t* qs, uint8_t* dir_base,
+                                                         uint32_t* cg_base, moni_dp_result_t& R) {
+    extz_wave<NCH>(P, task, qs, dir_base, cg_base, R);
 }

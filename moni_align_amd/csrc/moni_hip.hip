@@ -19,6 +19,7 @@
 #include "layout.h"
 #include "seed_kernels.hip"
 #include "extz_kernels.hip"
+#include "align_kernel.hip"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "moni_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return MONI_ENODEV; } } while (0)
 
@@ -94,6 +95,14 @@ struct moni_ctx {
     DBuf<uint32_t> dp_cig;
     DBuf<uint64_t> dp_off;
     DBuf<uint32_t> dp_ws;
+    // align kernel
+    DBuf<ak_scratch_t> ak_scratch;
+    DBuf<moni_aln_rec_t> ak_recs;
+    DBuf<uint32_t> ak_cig;
+    DBuf<moni_alt_t> ak_alt;
+    DBuf<int32_t> ak_minscore;
+    unsigned long long* d_ak_cursors = nullptr;
+    float ak_kernel_ms = 0;
 };
 
 namespace {
@@ -241,7 +250,8 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
     c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
     c->dp_q.release(); c->dp_t.release(); c->dp_dir.release(); c->dp_tasks.release(); c->dp_res.release(); c->dp_cig.release();
-    c->dp_off.release(); c->dp_ws.release();
+    c->dp_off.release(); c->dp_ws.release(); c->ak_scratch.release(); c->ak_recs.release(); c->ak_cig.release(); c->ak_alt.release(); c->ak_minscore.release();
+    if (c->d_ak_cursors) (void)hipFree(c->d_ak_cursors);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->d_counters) (void)hipFree(c->d_counters);
     for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(c->ev[i]);
@@ -547,18 +557,140 @@ void moni_align_params_default(moni_align_params_t* p) {
     p->host_threads = moni_host_cpus();
 }
 
+// The host pipeline (align_host.hpp) over a subset of the reads of the resident batch: used for reads the align kernel
+// hands back (status 2) and as the whole path when MONI_ALIGN_HOST=1.
+static int host_align_subset(moni_ctx* c, const moni_align_params_t& prm, const moni_read_batch_t& sub, const uint8_t* names,
+                             const uint64_t* name_off, const uint8_t* quals, std::string& out, mh::AlignStats& st) {
+    int rc = moni_reads_upload(c, &sub);
+    if (rc) return rc;
+    GpuBackend be(c);
+    return mh::align_batch(be, c->idx->hix, prm, c->h_seq.data(), c->h_offs.data(), c->n_reads, names, name_off, quals, out, st);
+}
+
 int moni_align_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
                      const moni_align_params_t* prm, char** sam, uint64_t* sam_len, moni_align_stats_t* stats) {
     if (!c || !b || !prm || !sam || !sam_len || (b->n_reads && (!names || !name_off))) return MONI_EINVAL;
-    int rc = moni_reads_upload(c, b);
-    if (rc) return rc;
-    GpuBackend be(c);
+    moni_index* I = c->idx;
     c->dp_kernel_ms_accum = 0;
     std::string out;
     mh::AlignStats st;
     const uint8_t* q = quals ? quals + b->offsets[0] : nullptr;
-    rc = mh::align_batch(be, c->idx->hix, *prm, c->h_seq.data(), c->h_offs.data(), c->n_reads, names, name_off, q, out, st);
-    if (rc) return rc;
+    static const bool host_only = getenv("MONI_ALIGN_HOST") != nullptr;
+    int rc;
+    if (host_only) {
+        if ((rc = host_align_subset(c, *prm, *b, names, name_off, q, out, st))) return rc;
+    } else {
+        // ---- seeds stay in HBM; one kernel takes every read from seeds to a finished alignment record ----
+        double t0 = mh::now_s();
+        if ((rc = moni_reads_upload(c, b))) return rc;
+        moni_seed_params_t sp;
+        sp.min_len = prm->min_len; sp.filter_seeds = prm->filter_seeds; sp.n_seeds_thr = prm->n_seeds_thr; sp.report_mems = 0;
+        if ((rc = moni_seed_run(c, &sp))) return rc;
+        st.t_seed += mh::now_s() - t0;
+        t0 = mh::now_s();
+        const uint64_t nr = c->n_reads;
+        int n_cu = 256;
+        { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, I->device) == hipSuccess) n_cu = pr.multiProcessorCount; }
+        uint64_t n_waves = (uint64_t)n_cu * 16;
+        if (n_waves > nr) n_waves = nr ? nr : 1;
+        std::vector<int32_t> msc(c->max_len + 2);
+        for (uint64_t l = 0; l <= c->max_len + 1; ++l) msc[l] = l ? (int32_t)(20 + 8 * log((double)l)) : INT32_MIN;   // aligner_ksw2.hpp:394
+        const uint64_t cig_cap = 64 * nr + 4096, alt_cap = 32 * nr + 4096;
+        if ((rc = c->ak_scratch.ensure(n_waves)) || (rc = c->ak_recs.ensure(nr + 1)) || (rc = c->ak_cig.ensure(cig_cap)) ||
+            (rc = c->ak_alt.ensure(alt_cap)) || (rc = c->ak_minscore.ensure(msc.size())))
+            return rc;
+        if (!c->d_ak_cursors) HIPCHK(hipMalloc((void**)&c->d_ak_cursors, 4 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(c->d_ak_cursors, 0, 4 * sizeof(unsigned long long), c->stream));
+        HIPCHK(hipMemcpyAsync(c->ak_minscore.p, msc.data(), msc.size() * 4, hipMemcpyHostToDevice, c->stream));
+        ak_args_t A;
+        memset(&A, 0, sizeof A);
+        A.P.min_len = prm->min_len; A.P.ext_len = prm->ext_len; A.P.check_k = prm->check_k; A.P.region_dist = prm->region_dist;
+        A.P.filter_freq = prm->filter_freq; A.P.left_mem_check = prm->left_mem_check; A.P.freq_thr = prm->freq_thr;
+        A.P.smatch = prm->smatch; A.P.gapo = prm->gapo; A.P.gapo2 = prm->gapo2; A.P.gape = prm->gape; A.P.gape2 = prm->gape2;
+        A.P.max_dist_x = prm->max_dist_x; A.P.max_dist_y = prm->max_dist_y; A.P.max_iter = prm->max_iter; A.P.max_pred = prm->max_pred;
+        A.P.min_chain_score = prm->min_chain_score; A.P.min_chain_length = prm->min_chain_length;
+        A.P.n_text = I->K.n_text; A.P.n_seq = I->K.n_seq; A.P.seq_starts = I->d_seq_starts;
+        A.D.sc_mch = prm->smatch; A.D.sc_mis = -prm->smismatch; A.D.sc_N = -prm->gape; A.D.wild = 4; A.D.qo = prm->gapo; A.D.e = prm->gape;
+        A.D.end_bonus = prm->end_bonus; A.D.reads = c->seq.p; A.D.text = I->d_text; A.D.n_text = I->K.n_text;
+        A.mems = c->mems.p; A.occs = c->occs.p; A.read_mem_off = c->read_mem_off.p; A.offs = c->offs.p;
+        A.min_score_of_len = c->ak_minscore.p; A.max_len = (uint32_t)c->max_len + 1; A.n_reads = nr;
+        A.scratch = c->ak_scratch.p; A.recs = c->ak_recs.p; A.cig_pool = c->ak_cig.p; A.cig_cap = cig_cap; A.alt_pool = c->ak_alt.p;
+        A.alt_cap = alt_cap; A.cursors = c->d_ak_cursors;
+        if (prm->w >= 0 || prm->zdrop >= 0) return MONI_EINVAL;
+        rec(c, EV_DP0);
+        if (nr) hipLaunchKernelGGL(align_kernel, dim3((unsigned)n_waves), dim3(64), 0, c->stream, A);
+        rec(c, EV_DP1);
+        HIPCHK(hipGetLastError());
+        std::vector<moni_aln_rec_t> recs(nr);
+        unsigned long long cur[4] = {0, 0, 0, 0};
+        if (nr) HIPCHK(hipMemcpyAsync(recs.data(), c->ak_recs.p, nr * sizeof(moni_aln_rec_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(cur, c->d_ak_cursors, sizeof cur, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[EV_DP0], c->ev[EV_DP1]) == hipSuccess) { c->dp_kernel_ms_accum += ms; c->ak_kernel_ms = ms; } }
+        const uint64_t ncig = cur[0] < cig_cap ? cur[0] : cig_cap, nalt = cur[1] < alt_cap ? cur[1] : alt_cap;
+        std::vector<uint32_t> cig(ncig + 1);
+        std::vector<moni_alt_t> alt(nalt + 1);
+        if (ncig) HIPCHK(hipMemcpy(cig.data(), c->ak_cig.p, ncig * 4, hipMemcpyDeviceToHost));
+        if (nalt) HIPCHK(hipMemcpy(alt.data(), c->ak_alt.p, nalt * sizeof(moni_alt_t), hipMemcpyDeviceToHost));
+        st.dp_tasks = cur[2]; st.dp_cells = cur[3]; st.dp_rounds = 1;
+        st.t_dp += mh::now_s() - t0;
+        t0 = mh::now_s();
+        // ---- host: MD/NM, MAPQ, SAM text (and the full host pipeline for the reads the kernel handed back) ----
+        const int T = prm->host_threads > 0 ? (int)prm->host_threads : 1;
+        mh::Pool pool(T);
+        mh::Aligner AL(I->hix, *prm, c->h_seq.data(), c->h_offs.data());
+        std::vector<std::string> line(nr);
+        std::vector<uint32_t> back;
+        for (uint64_t r = 0; r < nr; ++r) if (recs[r].status == 2) back.push_back((uint32_t)r);
+        std::vector<uint64_t> aligned_t(T, 0);
+        mh::parallel_for(pool, nr, [&](int t, size_t lo, size_t hi) {
+            std::string seq, qual, name;
+            std::vector<uint64_t> ap; std::vector<int32_t> as;
+            for (size_t r = lo; r < hi; ++r) {
+                const moni_aln_rec_t& R = recs[r];
+                if (R.status == 2) continue;
+                const uint64_t off = c->h_offs[r]; const uint32_t m = (uint32_t)(c->h_offs[r + 1] - off);
+                mh::Sam S;
+                if (R.status == 1) {
+                    ap.resize(R.n_alt); as.resize(R.n_alt);
+                    for (uint32_t k = 0; k < R.n_alt; ++k) { ap[k] = alt[R.alt_off + k].pos; as[k] = alt[R.alt_off + k].score; }
+                    AL.finish_record(m, off, R.strand, R.ref_pos, R.score, R.score2, cig.data() + R.cigar_off, R.n_cigar, ap.data(), as.data(), R.n_alt, S);
+                    aligned_t[t]++;
+                } else S.flag = 4;
+                const uint8_t* sp0 = c->h_seq.data() + off;
+                name.assign((const char*)names + name_off[r], (const char*)names + name_off[r + 1]);
+                seq.resize(m);
+                if (S.rev_read) for (uint32_t k = 0; k < m; ++k) seq[k] = (char)mh::compl_of(sp0[m - 1 - k]); else seq.assign((const char*)sp0, (const char*)sp0 + m);
+                if (q) { const uint8_t* qv = q + off; qual.resize(m); if (S.rev_read) for (uint32_t k = 0; k < m; ++k) qual[k] = (char)qv[m - 1 - k]; else qual.assign((const char*)qv, (const char*)qv + m); }
+                mh::Aligner::sam_write(line[r], S, name, seq, q ? &qual : nullptr);
+            }
+        });
+        for (int t = 0; t < T; ++t) st.aligned += aligned_t[t];
+        st.reads = nr;
+        if (!back.empty()) {
+            // rebuild a sub-batch of the handed-back reads and run them through the host pipeline
+            std::vector<uint8_t> sseq, snames, squal; std::vector<uint64_t> soff(1, 0), snoff(1, 0);
+            for (uint32_t r : back) {
+                const uint64_t off = b->offsets[r], m = b->offsets[r + 1] - b->offsets[r];
+                sseq.insert(sseq.end(), b->seq + off, b->seq + off + m); soff.push_back(sseq.size());
+                snames.insert(snames.end(), names + name_off[r], names + name_off[r + 1]); snoff.push_back(snames.size());
+                if (quals) squal.insert(squal.end(), quals + off, quals + off + m);
+            }
+            moni_read_batch_t sub{sseq.data(), soff.data(), (uint64_t)back.size()};
+            std::string sout; mh::AlignStats s2;
+            if ((rc = host_align_subset(c, *prm, sub, snames.data(), snoff.data(), quals ? squal.data() : nullptr, sout, s2))) return rc;
+            size_t p0 = 0;
+            for (uint32_t r : back) { const size_t p1 = sout.find('\n', p0); line[r] = sout.substr(p0, p1 - p0 + 1); p0 = p1 + 1; }
+            st.aligned += s2.aligned; st.dp_tasks += s2.dp_tasks; st.dp_cells += s2.dp_cells; st.dp_rounds += s2.dp_rounds;
+            st.t_chain += s2.t_chain;     // counts the whole fallback as "chain/host" time below
+        }
+        st.handed_back = back.size();
+        size_t total = 0;
+        for (auto& l : line) total += l.size();
+        out.reserve(total);
+        for (auto& l : line) out += l;
+        st.t_host += mh::now_s() - t0;
+    }
     *sam = (char*)malloc(out.size() + 1);
     if (!*sam) return MONI_ENOMEM;
     memcpy(*sam, out.data(), out.size());
@@ -568,6 +700,7 @@ int moni_align_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* n
         stats->reads = st.reads; stats->aligned = st.aligned; stats->dp_tasks = st.dp_tasks; stats->dp_cells = st.dp_cells; stats->dp_rounds = st.dp_rounds;
         stats->t_seed = st.t_seed; stats->t_chain = st.t_chain; stats->t_dp = st.t_dp; stats->t_host = st.t_host;
         stats->t_dp_kernel = c->dp_kernel_ms_accum / 1e3;
+        stats->handed_back = st.handed_back;
     }
     return MONI_OK;
 }

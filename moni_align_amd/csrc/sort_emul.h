@@ -10,8 +10,10 @@
 
 #if defined(__HIPCC__)
 #define SORT_HD __host__ __device__ __forceinline__
+#define SORT_HD_BIG __host__ __device__ __attribute__((noinline))
 #else
 #define SORT_HD inline
+#define SORT_HD_BIG inline
 #endif
 
 namespace lsort {
@@ -71,7 +73,7 @@ SORT_HD void adjust_heap(T* a, long first, long hole, long len, T value, Less le
 
 // std::__partial_sort(first, last, last): __heap_select with middle == last is just make_heap, then __sort_heap
 template <class T, class Less>
-SORT_HD void heap_sort(T* a, long first, long last, Less less) {
+SORT_HD_BIG void heap_sort(T* a, long first, long last, Less less) {
     const long len = last - first;
     if (len >= 2) {
         long parent = (len - 2) / 2;
@@ -116,7 +118,7 @@ SORT_HD void insertion_sort(T* a, long first, long last, Less less) {
 }
 
 template <class T, class Less>
-SORT_HD void sort(T* a, long n, Less less) {
+SORT_HD_BIG void sort(T* a, long n, Less less) {
     if (n <= 0) return;
     // std::__introsort_loop(first, last, std::__lg(n) * 2, comp) with the right-hand recursion on an explicit stack
     long lg = 0;

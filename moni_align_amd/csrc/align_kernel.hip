@@ -43,26 +43,37 @@ struct ak_args_t {
     moni_aln_rec_t* recs;
     uint32_t* cig_pool; uint64_t cig_cap;
     moni_alt_t* alt_pool; uint64_t alt_cap;
-    unsigned long long* cursors;             // [0] cigar pool, [1] alt pool, [2] DP problems, [3] DP cells
+    unsigned long long* cursors;             // [0] cigar pool, [1] alt pool, [2] DP problems, [3] DP cells, [4] next read, [5..7] cycles: init, drive, dp
 };
 
 extern "C" __global__ void __launch_bounds__(64)
 align_kernel(const ak_args_t A) {
-    __shared__ uint8_t qs[DP_MAX_QLEN];
+    __shared__ dp_lds_t L;
     __shared__ moni_dp_task_t s_tasks[AC_MAX_TASKS];
     __shared__ moni_dp_result_t s_res[AC_MAX_TASKS];
     __shared__ uint32_t s_n, s_go;
     const int lane = threadIdx.x;
     ak_scratch_t* __restrict__ S = A.scratch + blockIdx.x;
     ac_ws_t& W = S->ws;
-    unsigned long long n_dp = 0, n_cells = 0;
-    for (uint64_t r = blockIdx.x; r < A.n_reads; r += gridDim.x) {
+    unsigned long long n_dp = 0, n_cells = 0, cy_init = 0, cy_drive = 0, cy_dp = 0;
+    __shared__ unsigned long long s_read;
+    while (true) {
+        // dynamic read queue: reads differ a lot in the number of chains they score
+        if (lane == 0) s_read = atomicAdd(&A.cursors[4], 1ull);
+        __syncthreads();
+        const uint64_t r = s_read;
+        if (r >= A.n_reads) break;
         if (lane == 0) {
+            const long long c0 = clock64();
             W.off = A.offs[r]; W.m = (uint32_t)(A.offs[r + 1] - A.offs[r]);
             W.min_score = A.min_score_of_len[W.m <= A.max_len ? W.m : A.max_len];
             s_n = 0; s_go = 0;
-            if (ac_init(W, A.P, A.mems, A.read_mem_off[r], A.read_mem_off[r + 1], A.occs)) {
+            const bool chained = ac_init(W, A.P, A.mems, A.read_mem_off[r], A.read_mem_off[r + 1], A.occs);
+            const long long c1 = clock64();
+            cy_init += (unsigned long long)(c1 - c0);
+            if (chained) {
                 ac_drive(W, A.P, nullptr, nullptr);
+                cy_drive += (unsigned long long)(clock64() - c1);
                 if (!W.overflow && W.stage != AC_DONE) {
                     s_n = W.n_tasks; s_go = 1;
                     for (uint32_t t = 0; t < W.n_tasks; ++t) s_tasks[t] = W.tasks[t];
@@ -73,6 +84,7 @@ align_kernel(const ak_args_t A) {
         while (s_go) {
             const uint32_t nt = s_n;
             bool too_big = false;
+            const long long d0 = clock64();
             for (uint32_t t = 0; t < nt; ++t) {
                 const moni_dp_task_t task = s_tasks[t];
                 const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
@@ -80,17 +92,17 @@ align_kernel(const ak_args_t A) {
                     (with_cigar && (uint64_t)(task.qlen + task.tlen - 1) * (uint64_t)task.tlen > AK_DIRS_CAP)) { too_big = true; break; }
                 moni_dp_result_t R;
                 uint32_t* cg = S->cig + (size_t)t * AK_CIG_CAP;
-                if (task.tlen <= 64) extz_wave_call<1>(A.D, task, qs, S->dirs, cg, R);
-                else if (task.tlen <= 128) extz_wave_call<2>(A.D, task, qs, S->dirs, cg, R);
-                else if (task.tlen <= 256) extz_wave_call<4>(A.D, task, qs, S->dirs, cg, R);
-                else extz_wave_call<8>(A.D, task, qs, S->dirs, cg, R);
+                extz_wave_lds(A.D, task, L, S->dirs, cg, R);
                 R.cigar_off = t * AK_CIG_CAP;
                 if (lane == 0) { s_res[t] = R; ++n_dp; n_cells += (unsigned long long)(task.qlen > 0 ? task.qlen : 0) * (unsigned long long)(task.tlen > 0 ? task.tlen : 0); }
             }
             __syncthreads();
             if (lane == 0) {
+                const long long d1 = clock64();
+                cy_dp += (unsigned long long)(d1 - d0);
                 if (too_big) W.overflow = 1;
                 else ac_drive(W, A.P, s_res, S->cig);
+                cy_drive += (unsigned long long)(clock64() - d1);
                 s_go = (!W.overflow && W.stage != AC_DONE) ? 1u : 0u;
                 s_n = W.n_tasks;
                 if (s_go) for (uint32_t t = 0; t < W.n_tasks; ++t) s_tasks[t] = W.tasks[t];
@@ -116,5 +128,5 @@ align_kernel(const ak_args_t A) {
         }
         __syncthreads();
     }
-    if (lane == 0) { atomicAdd(&A.cursors[2], n_dp); atomicAdd(&A.cursors[3], n_cells); }
+    if (lane == 0) { atomicAdd(&A.cursors[2], n_dp); atomicAdd(&A.cursors[3], n_cells); atomicAdd(&A.cursors[5], cy_init); atomicAdd(&A.cursors[6], cy_drive); atomicAdd(&A.cursors[7], cy_dp); }
 }

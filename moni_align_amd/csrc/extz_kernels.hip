@@ -262,3 +262,189 @@ __device__ __attribute__((noinline)) void extz_wave_call(const dp_launch_t& P, c
                                                          uint32_t* cg_base, moni_dp_result_t& R) {
     extz_wave<NCH>(P, task, qs, dir_base, cg_base, R);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-tiled form of the same DP: H (two anti-diagonals), E, F and the target codes live in LDS, one entry per target row,
+// and a diagonal is swept in 64-row chunks from the bottom up, so that a chunk reads its upper neighbour's previous-
+// diagonal values before the chunk above overwrites them.  No register blocking over the target length: one code path
+// for every problem size, ~40 VGPRs, so a kernel that runs DP problems of many sizes (align_kernel) keeps its occupancy.
+// Results are bit-identical to extz_wave (same recurrence, same tie rules, same traceback).
+// ------------------------------------------------------------------------------------------------------------------
+#define DP_LDS_T 512
+struct dp_lds_t {
+    int32_t H[2][DP_LDS_T];
+    int32_t E[DP_LDS_T];
+    int32_t F[DP_LDS_T];
+    uint8_t tc[DP_LDS_T];
+    uint8_t qs[DP_MAX_QLEN];
+};
+
+__device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, const moni_dp_task_t task, dp_lds_t& L,
+                                                        uint8_t* __restrict__ dir_base, uint32_t* __restrict__ cg_base, moni_dp_result_t& R) {
+    const int lane = threadIdx.x & 63;
+    const int qlen = task.qlen, tlen = task.tlen, flag = task.flag;
+    R.max = 0; R.max_q = R.max_t = R.mqe_t = R.mte_q = -1; R.mqe = R.mte = R.score = DP_NEG_INF;
+    R.reach_end = 0; R.zdropped = 0; R.n_cigar = 0; R.cigar_off = 0;
+    if (qlen <= 0 || tlen <= 0) return;
+    const bool with_cigar = !(flag & DP_EZ_SCORE_ONLY);
+    const bool right = (flag & DP_EZ_RIGHT) != 0;
+    const int mode = task.reserved;
+    const int32_t qo = P.qo, e = P.e;
+    if (mode & DP_Q_READS) {
+        const uint8_t* __restrict__ q = P.reads + task.q_off;
+        for (int k = lane; k < qlen; k += 64) {
+            uint32_t c = dp_nt4((mode & DP_Q_REV) ? q[-(long)k] : q[k]);
+            if ((mode & DP_Q_COMP) && c < 4) c = 3 - c;
+            L.qs[k] = (uint8_t)c;
+        }
+    } else {
+        const uint8_t* __restrict__ q = P.qseq + task.q_off;
+        for (int k = lane; k < qlen; k += 64) L.qs[k] = (mode & DP_Q_REV) ? q[-(long)k] : q[k];
+    }
+    for (int i = lane; i < tlen; i += 64) {
+        uint32_t tc;
+        if (mode & DP_T_TEXT) {
+            const uint64_t a = (mode & DP_T_REV) ? task.t_off - (uint64_t)i : task.t_off + (uint64_t)i;
+            tc = dp_nt4(a < P.n_text ? P.text[a] : 0u);
+        } else tc = P.tseq[(mode & DP_T_REV) ? task.t_off - (uint64_t)i : task.t_off + (uint64_t)i];
+        L.tc[i] = (uint8_t)tc;
+        const int32_t b = dp_bound(i, qo, e);                 // H(i,-1) in both diagonal buffers
+        L.H[0][i] = b; L.H[1][i] = b; L.E[i] = DP_NEG_INF; L.F[i] = DP_NEG_INF;
+    }
+    __syncthreads();
+    uint8_t* __restrict__ dir = with_cigar ? dir_base : nullptr;
+    const int32_t wild = P.wild, scN = P.sc_N, scM = P.sc_mch, scX = P.sc_mis;     // P lives in memory: read once
+    // running maximum per lane as (value, diagonal, row); the reference's in-diagonal visiting order only decides ties
+    // inside one diagonal, resolved in the rare branch below and when the lanes are merged
+    auto rank_of = [&](int rr, int i) {
+        const int st0 = rr - qlen + 1 > 0 ? rr - qlen + 1 : 0;
+        const int en0 = rr < tlen - 1 ? rr : tlen - 1;
+        const int en1 = st0 + (en0 - st0) / 4 * 4;
+        if (rr == 0 || i == en0) return 0;
+        if (i < en1) return 1 + ((i - st0) & 3) * 4096 + ((i - st0) >> 2);
+        return 1 + 4 * 4096 + (i - en1);
+    };
+    int32_t max_z = 0, max_r = 0, max_i = -1;
+    int32_t mte_h = DP_NEG_INF, mte_q = -1, last_h = DP_NEG_INF;
+    const int en_r = (tlen - 1 + 16) / 16 * 16 - 1;
+    const int n_diag = qlen + tlen - 1;
+    const int k_top = (tlen - 1) >> 6;
+    for (int r = 0; r < n_diag; ++r) {
+        const int st0 = r - qlen + 1 > 0 ? r - qlen + 1 : 0;
+        const int en0 = r < tlen - 1 ? r : tlen - 1;
+        int32_t* __restrict__ Hn = L.H[r & 1];               // holds diagonal r-2, receives diagonal r
+        const int32_t* __restrict__ Hp = L.H[(r + 1) & 1];   // diagonal r-1
+        const int32_t b_r = dp_bound(r, qo, e), b_r1 = dp_bound(r - 1, qo, e);      // row -1: H(-1,r), H(-1,r-1)
+        for (int k = en0 >> 6; k >= (st0 >> 6); --k) {       // bottom chunk first
+            const int i = lane + 64 * k;
+            if (i >= st0 && i <= en0) {
+                const int j = r - i;
+                const int up = i > 0 ? i - 1 : 0;
+                const int32_t h_left = Hp[i];
+                const int32_t f_old = L.F[i];
+                int32_t uH1 = Hp[up], uH2 = Hn[up], uE = L.E[up];     // Hn[i-1] is still H(i-1,-1) when j == 0
+                const int32_t qc = L.qs[j];
+                const int32_t tc = L.tc[i];
+                uH1 = i > 0 ? uH1 : b_r; uH2 = i > 0 ? uH2 : b_r1; uE = i > 0 ? uE : DP_NEG_INF;
+                const int32_t Eo = uH1 - qo;
+                const int32_t E = (Eo > uE ? Eo : uE) - e;
+                const int32_t Fo = h_left - qo;
+                const int32_t F = (Fo > f_old ? Fo : f_old) - e;
+                const int32_t s = (tc == wild || qc == wild) ? scN : (tc == qc ? scM : scX);
+                int32_t z = uH2 + s;
+                if (with_cigar) {
+                    uint32_t d;
+                    if (!right) {
+                        d = E > z ? 1u : 0u; z = z > E ? z : E; d = F > z ? 2u : d; z = z > F ? z : F;
+                        d |= (E > z - qo) ? 0x08u : 0u;
+                        d |= (F > z - qo) ? 0x10u : 0u;
+                    } else {
+                        d = z > E ? 0u : 1u; z = z > E ? z : E; d = z > F ? d : 2u; z = z > F ? z : F;
+                        d |= (E >= z - qo) ? 0x08u : 0u;
+                        d |= (F >= z - qo) ? 0x10u : 0u;
+                    }
+                    dir[(uint32_t)r * (uint32_t)tlen + (uint32_t)i] = (uint8_t)d;
+                } else { z = z > E ? z : E; z = z > F ? z : F; }
+                Hn[i] = z; L.E[i] = E; L.F[i] = F;
+                if (k == k_top && i == tlen - 1) { last_h = z; if (z > mte_h) { mte_h = z; mte_q = r - en_r; } }
+                if (z > max_z) { max_z = z; max_r = r; max_i = i; }
+                else if (z == max_z && max_r == r && z > 0 && rank_of(r, i) < rank_of(r, max_i)) max_i = i;
+            }
+        }
+    }
+    __syncthreads();
+    // mqe: H(i, qlen-1) of every row is still in the buffer of the diagonal it was written on
+    int32_t mqe_h = DP_NEG_INF, mqe_i = -1;
+    for (int i = lane; i < tlen; i += 64) {
+        const int32_t h = L.H[(i + qlen - 1) & 1][i];
+        if (h > mqe_h) { mqe_h = h; mqe_i = i; }
+    }
+    long long max_key = -1;
+    if (max_i >= 0) max_key = (long long)(((unsigned long long)(uint32_t)max_z << 32) | ((unsigned long long)(0xFFFF - max_r) << 16) |
+                                          (unsigned long long)(0xFFFF - rank_of(max_r, max_i)));
+    const long long mqe_key = wave_max_i64((long long)(((unsigned long long)(long long)mqe_h << 32) |
+                                                       (unsigned long long)(uint32_t)(0x7FFFFFFF - (mqe_i < 0 ? 0x7FFFFFFF : mqe_i))));
+    R.mqe = (int32_t)(mqe_key >> 32);
+    R.mqe_t = 0x7FFFFFFF - (int32_t)(mqe_key & 0xFFFFFFFFll);
+    max_key = wave_max_i64(max_key);
+    if (max_key >= 0) {
+        R.max = (int32_t)(max_key >> 32);
+        const int rr = 0xFFFF - (int)((max_key >> 16) & 0xFFFF);
+        const int rank = 0xFFFF - (int)(max_key & 0xFFFF);
+        const int st0 = rr - qlen + 1 > 0 ? rr - qlen + 1 : 0;
+        const int en0 = rr < tlen - 1 ? rr : tlen - 1;
+        const int en1 = st0 + (en0 - st0) / 4 * 4;
+        int t;
+        if (rank == 0) t = rr == 0 ? 0 : en0;
+        else if (rank < 1 + 4 * 4096) t = st0 + ((rank - 1) / 4096) + 4 * ((rank - 1) % 4096);
+        else t = en1 + (rank - 1 - 4 * 4096);
+        R.max_t = t; R.max_q = rr - t;
+    }
+    {
+        const int owner = (tlen - 1) & 63;
+        R.mte = __shfl(mte_h, owner);
+        R.mte_q = __shfl(mte_q, owner);
+        R.score = __shfl(last_h, owner);
+    }
+    if (with_cigar) {
+        __syncthreads();
+        int i0 = -1, j0 = -1;
+        if (!(flag & DP_EZ_EXTZ_ONLY)) { i0 = tlen - 1; j0 = qlen - 1; }
+        else if (R.mqe + P.end_bonus > R.max) { R.reach_end = 1; i0 = R.mqe_t; j0 = qlen - 1; }
+        else if (R.max_t >= 0 && R.max_q >= 0) { i0 = R.max_t; j0 = R.max_q; }
+        if (lane == 0 && i0 >= 0 && j0 >= 0) {
+            uint32_t* __restrict__ cg = cg_base;
+            int n = 0, i = i0, j = j0, state = 0;
+            auto push = [&](uint32_t op, int len) {
+                if (n == 0 || op != (cg[n - 1] & 0xf)) cg[n++] = (uint32_t)len << 4 | op;
+                else cg[n - 1] += (uint32_t)len << 4;
+            };
+            while (i >= 0 && j >= 0) {
+                const uint32_t tmp = dir[(size_t)(i + j) * tlen + i];
+                if (state == 0) state = tmp & 7;
+                else if (!(tmp >> (state + 2) & 1)) state = 0;
+                if (state == 0) state = tmp & 7;
+                if (state == 0) { push(0, 1); --i; --j; }
+                else if (state == 1 || state == 3) { push(2, 1); --i; }
+                else { push(1, 1); --j; }
+            }
+            if (i >= 0) push(2, i + 1);
+            if (j >= 0) push(1, j + 1);
+            for (int a = 0; a < n >> 1; ++a) { const uint32_t t2 = cg[a]; cg[a] = cg[n - 1 - a]; cg[n - 1 - a] = t2; }
+            R.n_cigar = (uint32_t)n;
+        }
+    }
+    R.n_cigar = (uint32_t)__shfl((int)R.n_cigar, 0);
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(64)
+extz_lds_kernel(const dp_launch_t P) {
+    __shared__ dp_lds_t L;
+    const uint32_t tix = P.order[blockIdx.x];
+    const moni_dp_task_t task = P.tasks[tix];
+    const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
+    moni_dp_result_t R;
+    extz_wave_lds(P, task, L, with_cigar ? P.dirs + P.dir_off[tix] : nullptr, with_cigar ? P.cig_tmp + P.cig_off[tix] : nullptr, R);
+    if (threadIdx.x == 0) P.results[tix] = R;
+}

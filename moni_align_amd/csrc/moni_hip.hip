@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/moni_hip.h"
@@ -87,6 +89,7 @@ struct moni_ctx {
     uint32_t tmp_cap = 16;
     uint32_t pool_rows = 4096;
     double dp_kernel_ms_accum = 0;
+    int extz_lds = 0;                          // moni_extz_batch through the LDS-tiled kernel (MONI_EXTZ_LDS=1)
     int ms_variant = 0;                        // 0 = default; MONI_MS_VARIANT selects an (interleave, occupancy) variant for tuning
     // dp
     DBuf<uint8_t> dp_q, dp_t, dp_dir;
@@ -232,6 +235,7 @@ int moni_ctx_create(moni_index_t* I, moni_ctx_t** out) {
     moni_ctx* c = new moni_ctx();
     c->idx = I;
     if (const char* v = getenv("MONI_MS_VARIANT")) c->ms_variant = atoi(v);
+    if (const char* v = getenv("MONI_EXTZ_LDS")) c->extz_lds = atoi(v);
     HIPCHK(hipStreamCreate(&c->stream));
     for (int i = 0; i < EV_N; ++i) { HIPCHK(hipEventCreate(&c->ev[i])); c->ev_valid[i] = false; }
     HIPCHK(hipMalloc((void**)&c->d_small, 16));
@@ -576,99 +580,151 @@ int moni_align_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* n
     mh::AlignStats st;
     const uint8_t* q = quals ? quals + b->offsets[0] : nullptr;
     static const bool host_only = getenv("MONI_ALIGN_HOST") != nullptr;
+    bool out_done = false;
     int rc;
     if (host_only) {
         if ((rc = host_align_subset(c, *prm, *b, names, name_off, q, out, st))) return rc;
     } else {
-        // ---- seeds stay in HBM; one kernel takes every read from seeds to a finished alignment record ----
-        double t0 = mh::now_s();
-        if ((rc = moni_reads_upload(c, b))) return rc;
-        moni_seed_params_t sp;
-        sp.min_len = prm->min_len; sp.filter_seeds = prm->filter_seeds; sp.n_seeds_thr = prm->n_seeds_thr; sp.report_mems = 0;
-        if ((rc = moni_seed_run(c, &sp))) return rc;
-        st.t_seed += mh::now_s() - t0;
-        t0 = mh::now_s();
-        const uint64_t nr = c->n_reads;
+        // ---- seeds stay in HBM; one kernel takes every read from seeds to a finished alignment record.  The batch goes
+        // through in sub-batches: while the GPU seeds and aligns sub-batch k+1, the host threads turn the records of
+        // sub-batch k into SAM text (MD/NM, MAPQ, formatting) ----
+        if (prm->w >= 0 || prm->zdrop >= 0) return MONI_EINVAL;
+        const uint64_t NR = b->n_reads;
+        uint64_t sub_reads = 50000;
+        if (const char* v = getenv("MONI_ALIGN_SUB")) { const long long x = atoll(v); if (x > 0) sub_reads = (uint64_t)x; }
+        const uint64_t n_sub = NR ? (NR + sub_reads - 1) / sub_reads : 0;
+        uint64_t force_back = 0;        // test hook: treat every n-th read as handed back by the kernel (exercises that path)
+        if (const char* v = getenv("MONI_AK_FORCE_HANDBACK")) { const long long x = atoll(v); if (x > 0) force_back = (uint64_t)x; }
         int n_cu = 256;
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, I->device) == hipSuccess) n_cu = pr.multiProcessorCount; }
-        uint64_t n_waves = (uint64_t)n_cu * 16;
-        if (n_waves > nr) n_waves = nr ? nr : 1;
-        std::vector<int32_t> msc(c->max_len + 2);
-        for (uint64_t l = 0; l <= c->max_len + 1; ++l) msc[l] = l ? (int32_t)(20 + 8 * log((double)l)) : INT32_MIN;   // aligner_ksw2.hpp:394
-        const uint64_t cig_cap = 64 * nr + 4096, alt_cap = 32 * nr + 4096;
-        if ((rc = c->ak_scratch.ensure(n_waves)) || (rc = c->ak_recs.ensure(nr + 1)) || (rc = c->ak_cig.ensure(cig_cap)) ||
-            (rc = c->ak_alt.ensure(alt_cap)) || (rc = c->ak_minscore.ensure(msc.size())))
-            return rc;
-        if (!c->d_ak_cursors) HIPCHK(hipMalloc((void**)&c->d_ak_cursors, 4 * sizeof(unsigned long long)));
-        HIPCHK(hipMemsetAsync(c->d_ak_cursors, 0, 4 * sizeof(unsigned long long), c->stream));
-        HIPCHK(hipMemcpyAsync(c->ak_minscore.p, msc.data(), msc.size() * 4, hipMemcpyHostToDevice, c->stream));
-        ak_args_t A;
-        memset(&A, 0, sizeof A);
-        A.P.min_len = prm->min_len; A.P.ext_len = prm->ext_len; A.P.check_k = prm->check_k; A.P.region_dist = prm->region_dist;
-        A.P.filter_freq = prm->filter_freq; A.P.left_mem_check = prm->left_mem_check; A.P.freq_thr = prm->freq_thr;
-        A.P.smatch = prm->smatch; A.P.gapo = prm->gapo; A.P.gapo2 = prm->gapo2; A.P.gape = prm->gape; A.P.gape2 = prm->gape2;
-        A.P.max_dist_x = prm->max_dist_x; A.P.max_dist_y = prm->max_dist_y; A.P.max_iter = prm->max_iter; A.P.max_pred = prm->max_pred;
-        A.P.min_chain_score = prm->min_chain_score; A.P.min_chain_length = prm->min_chain_length;
-        A.P.n_text = I->K.n_text; A.P.n_seq = I->K.n_seq; A.P.seq_starts = I->d_seq_starts;
-        A.D.sc_mch = prm->smatch; A.D.sc_mis = -prm->smismatch; A.D.sc_N = -prm->gape; A.D.wild = 4; A.D.qo = prm->gapo; A.D.e = prm->gape;
-        A.D.end_bonus = prm->end_bonus; A.D.reads = c->seq.p; A.D.text = I->d_text; A.D.n_text = I->K.n_text;
-        A.mems = c->mems.p; A.occs = c->occs.p; A.read_mem_off = c->read_mem_off.p; A.offs = c->offs.p;
-        A.min_score_of_len = c->ak_minscore.p; A.max_len = (uint32_t)c->max_len + 1; A.n_reads = nr;
-        A.scratch = c->ak_scratch.p; A.recs = c->ak_recs.p; A.cig_pool = c->ak_cig.p; A.cig_cap = cig_cap; A.alt_pool = c->ak_alt.p;
-        A.alt_cap = alt_cap; A.cursors = c->d_ak_cursors;
-        if (prm->w >= 0 || prm->zdrop >= 0) return MONI_EINVAL;
-        rec(c, EV_DP0);
-        if (nr) hipLaunchKernelGGL(align_kernel, dim3((unsigned)n_waves), dim3(64), 0, c->stream, A);
-        rec(c, EV_DP1);
-        HIPCHK(hipGetLastError());
-        std::vector<moni_aln_rec_t> recs(nr);
-        unsigned long long cur[4] = {0, 0, 0, 0};
-        if (nr) HIPCHK(hipMemcpyAsync(recs.data(), c->ak_recs.p, nr * sizeof(moni_aln_rec_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(cur, c->d_ak_cursors, sizeof cur, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[EV_DP0], c->ev[EV_DP1]) == hipSuccess) { c->dp_kernel_ms_accum += ms; c->ak_kernel_ms = ms; } }
-        const uint64_t ncig = cur[0] < cig_cap ? cur[0] : cig_cap, nalt = cur[1] < alt_cap ? cur[1] : alt_cap;
-        std::vector<uint32_t> cig(ncig + 1);
-        std::vector<moni_alt_t> alt(nalt + 1);
-        if (ncig) HIPCHK(hipMemcpy(cig.data(), c->ak_cig.p, ncig * 4, hipMemcpyDeviceToHost));
-        if (nalt) HIPCHK(hipMemcpy(alt.data(), c->ak_alt.p, nalt * sizeof(moni_alt_t), hipMemcpyDeviceToHost));
-        st.dp_tasks = cur[2]; st.dp_cells = cur[3]; st.dp_rounds = 1;
-        st.t_dp += mh::now_s() - t0;
-        t0 = mh::now_s();
-        // ---- host: MD/NM, MAPQ, SAM text (and the full host pipeline for the reads the kernel handed back) ----
+        int per_cu = 8;       // persistent waves: exactly as many blocks as stay resident, each takes reads off a shared counter
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, align_kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
         const int T = prm->host_threads > 0 ? (int)prm->host_threads : 1;
         mh::Pool pool(T);
-        mh::Aligner AL(I->hix, *prm, c->h_seq.data(), c->h_offs.data());
-        std::vector<std::string> line(nr);
-        std::vector<uint32_t> back;
-        for (uint64_t r = 0; r < nr; ++r) if (recs[r].status == 2) back.push_back((uint32_t)r);
+        mh::Aligner AL(I->hix, *prm, b->seq, b->offsets);
+        struct SubRes { std::vector<moni_aln_rec_t> recs; std::vector<uint32_t> cig; std::vector<moni_alt_t> alt; };
+        SubRes res[2];
+        std::vector<std::vector<std::string>> text(n_sub, std::vector<std::string>(T));      // [sub-batch][thread]: SAM text in read order
+        std::vector<std::vector<uint32_t>> back_of(n_sub);
         std::vector<uint64_t> aligned_t(T, 0);
-        mh::parallel_for(pool, nr, [&](int t, size_t lo, size_t hi) {
-            std::string seq, qual, name;
-            std::vector<uint64_t> ap; std::vector<int32_t> as;
-            for (size_t r = lo; r < hi; ++r) {
-                const moni_aln_rec_t& R = recs[r];
-                if (R.status == 2) continue;
-                const uint64_t off = c->h_offs[r]; const uint32_t m = (uint32_t)(c->h_offs[r + 1] - off);
-                mh::Sam S;
-                if (R.status == 1) {
-                    ap.resize(R.n_alt); as.resize(R.n_alt);
-                    for (uint32_t k = 0; k < R.n_alt; ++k) { ap[k] = alt[R.alt_off + k].pos; as[k] = alt[R.alt_off + k].score; }
-                    AL.finish_record(m, off, R.strand, R.ref_pos, R.score, R.score2, cig.data() + R.cigar_off, R.n_cigar, ap.data(), as.data(), R.n_alt, S);
-                    aligned_t[t]++;
-                } else S.flag = 4;
-                const uint8_t* sp0 = c->h_seq.data() + off;
-                name.assign((const char*)names + name_off[r], (const char*)names + name_off[r + 1]);
-                seq.resize(m);
-                if (S.rev_read) for (uint32_t k = 0; k < m; ++k) seq[k] = (char)mh::compl_of(sp0[m - 1 - k]); else seq.assign((const char*)sp0, (const char*)sp0 + m);
-                if (q) { const uint8_t* qv = q + off; qual.resize(m); if (S.rev_read) for (uint32_t k = 0; k < m; ++k) qual[k] = (char)qv[m - 1 - k]; else qual.assign((const char*)qv, (const char*)qv + m); }
-                mh::Aligner::sam_write(line[r], S, name, seq, q ? &qual : nullptr);
+        double host_busy = 0;
+        double prof[3] = {0, 0, 0};
+        uint64_t waves_used = 0;
+
+        // GPU stage of one sub-batch (blocking): upload, seed, align kernel, records back
+        auto gpu_stage = [&](uint64_t k, SubRes& R) -> int {
+            const uint64_t r0 = k * sub_reads, nr = std::min(sub_reads, NR - r0);
+            double t0 = mh::now_s();
+            moni_read_batch_t sub{b->seq, b->offsets + r0, nr};
+            int rc2;
+            if ((rc2 = moni_reads_upload(c, &sub))) return rc2;
+            moni_seed_params_t sp;
+            sp.min_len = prm->min_len; sp.filter_seeds = prm->filter_seeds; sp.n_seeds_thr = prm->n_seeds_thr; sp.report_mems = 0;
+            if ((rc2 = moni_seed_run(c, &sp))) return rc2;
+            st.t_seed += mh::now_s() - t0;
+            t0 = mh::now_s();
+            uint64_t n_waves = (uint64_t)n_cu * (uint64_t)per_cu;
+            if (n_waves > nr) n_waves = nr;
+            waves_used = std::max(waves_used, n_waves);
+            std::vector<int32_t> msc(c->max_len + 2);
+            for (uint64_t l = 0; l <= c->max_len + 1; ++l) msc[l] = l ? (int32_t)(20 + 8 * log((double)l)) : INT32_MIN;   // aligner_ksw2.hpp:394
+            const uint64_t cig_cap = 64 * nr + 4096, alt_cap = 32 * nr + 4096;
+            if ((rc2 = c->ak_scratch.ensure(n_waves)) || (rc2 = c->ak_recs.ensure(nr + 1)) || (rc2 = c->ak_cig.ensure(cig_cap)) ||
+                (rc2 = c->ak_alt.ensure(alt_cap)) || (rc2 = c->ak_minscore.ensure(msc.size())))
+                return rc2;
+            if (!c->d_ak_cursors) HIPCHK(hipMalloc((void**)&c->d_ak_cursors, 8 * sizeof(unsigned long long)));
+            HIPCHK(hipMemsetAsync(c->d_ak_cursors, 0, 8 * sizeof(unsigned long long), c->stream));
+            HIPCHK(hipMemcpyAsync(c->ak_minscore.p, msc.data(), msc.size() * 4, hipMemcpyHostToDevice, c->stream));
+            ak_args_t A;
+            memset(&A, 0, sizeof A);
+            A.P.min_len = prm->min_len; A.P.ext_len = prm->ext_len; A.P.check_k = prm->check_k; A.P.region_dist = prm->region_dist;
+            A.P.filter_freq = prm->filter_freq; A.P.left_mem_check = prm->left_mem_check; A.P.freq_thr = prm->freq_thr;
+            A.P.smatch = prm->smatch; A.P.gapo = prm->gapo; A.P.gapo2 = prm->gapo2; A.P.gape = prm->gape; A.P.gape2 = prm->gape2;
+            A.P.max_dist_x = prm->max_dist_x; A.P.max_dist_y = prm->max_dist_y; A.P.max_iter = prm->max_iter; A.P.max_pred = prm->max_pred;
+            A.P.min_chain_score = prm->min_chain_score; A.P.min_chain_length = prm->min_chain_length;
+            A.P.n_text = I->K.n_text; A.P.n_seq = I->K.n_seq; A.P.seq_starts = I->d_seq_starts;
+            A.D.sc_mch = prm->smatch; A.D.sc_mis = -prm->smismatch; A.D.sc_N = -prm->gape; A.D.wild = 4; A.D.qo = prm->gapo; A.D.e = prm->gape;
+            A.D.end_bonus = prm->end_bonus; A.D.reads = c->seq.p; A.D.text = I->d_text; A.D.n_text = I->K.n_text;
+            A.mems = c->mems.p; A.occs = c->occs.p; A.read_mem_off = c->read_mem_off.p; A.offs = c->offs.p;
+            A.min_score_of_len = c->ak_minscore.p; A.max_len = (uint32_t)c->max_len + 1; A.n_reads = nr;
+            A.scratch = c->ak_scratch.p; A.recs = c->ak_recs.p; A.cig_pool = c->ak_cig.p; A.cig_cap = cig_cap; A.alt_pool = c->ak_alt.p;
+            A.alt_cap = alt_cap; A.cursors = c->d_ak_cursors;
+            rec(c, EV_DP0);
+            hipLaunchKernelGGL(align_kernel, dim3((unsigned)n_waves), dim3(64), 0, c->stream, A);
+            rec(c, EV_DP1);
+            HIPCHK(hipGetLastError());
+            R.recs.resize(nr);
+            unsigned long long cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            HIPCHK(hipMemcpyAsync(R.recs.data(), c->ak_recs.p, nr * sizeof(moni_aln_rec_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(cur, c->d_ak_cursors, sizeof cur, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (force_back) for (uint64_t r = 0; r < nr; ++r) if ((r0 + r) % force_back == 0) R.recs[r].status = 2;
+            { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[EV_DP0], c->ev[EV_DP1]) == hipSuccess) { c->dp_kernel_ms_accum += ms; c->ak_kernel_ms = ms; } }
+            const uint64_t ncig = cur[0] < cig_cap ? cur[0] : cig_cap, nalt = cur[1] < alt_cap ? cur[1] : alt_cap;
+            R.cig.resize(ncig + 1); R.alt.resize(nalt + 1);
+            if (ncig) HIPCHK(hipMemcpy(R.cig.data(), c->ak_cig.p, ncig * 4, hipMemcpyDeviceToHost));
+            if (nalt) HIPCHK(hipMemcpy(R.alt.data(), c->ak_alt.p, nalt * sizeof(moni_alt_t), hipMemcpyDeviceToHost));
+            st.dp_tasks += cur[2]; st.dp_cells += cur[3];
+            prof[0] += (double)cur[5]; prof[1] += (double)cur[6]; prof[2] += (double)cur[7];
+            st.t_dp += mh::now_s() - t0;
+            return MONI_OK;
+        };
+        // host stage of one sub-batch: MD/NM, MAPQ, SAM text; thread t writes the lines of its (contiguous) share of the reads
+        auto host_stage = [&](uint64_t k, const SubRes& R) {
+            const double t0 = mh::now_s();
+            const uint64_t r0 = k * sub_reads, nr = R.recs.size();
+            for (uint64_t r = 0; r < nr; ++r) if (R.recs[r].status == 2) back_of[k].push_back((uint32_t)(r0 + r));
+            mh::parallel_for(pool, nr, [&](int t, size_t lo, size_t hi) {
+                std::string seq, qual, name, ln;
+                std::string& dst = text[k][t];
+                dst.reserve((hi - lo) * 400);
+                std::vector<uint64_t> ap; std::vector<int32_t> as;
+                for (size_t r = lo; r < hi; ++r) {
+                    const moni_aln_rec_t& Rr = R.recs[r];
+                    if (Rr.status == 2) continue;                    // handed back: filled in at the end
+                    const uint64_t g = r0 + r;
+                    const uint64_t off = b->offsets[g]; const uint32_t m = (uint32_t)(b->offsets[g + 1] - off);
+                    mh::Sam S;
+                    if (Rr.status == 1) {
+                        ap.resize(Rr.n_alt); as.resize(Rr.n_alt);
+                        for (uint32_t x = 0; x < Rr.n_alt; ++x) { ap[x] = R.alt[Rr.alt_off + x].pos; as[x] = R.alt[Rr.alt_off + x].score; }
+                        AL.finish_record(m, off, Rr.strand, Rr.ref_pos, Rr.score, Rr.score2, R.cig.data() + Rr.cigar_off, Rr.n_cigar, ap.data(), as.data(), Rr.n_alt, S);
+                        aligned_t[t]++;
+                    } else S.flag = 4;
+                    const uint8_t* sp0 = b->seq + off;
+                    name.assign((const char*)names + name_off[g], (const char*)names + name_off[g + 1]);
+                    seq.resize(m);
+                    if (S.rev_read) for (uint32_t x = 0; x < m; ++x) seq[x] = (char)mh::compl_of(sp0[m - 1 - x]); else seq.assign((const char*)sp0, (const char*)sp0 + m);
+                    if (quals) { const uint8_t* qv = quals + off; qual.resize(m); if (S.rev_read) for (uint32_t x = 0; x < m; ++x) qual[x] = (char)qv[m - 1 - x]; else qual.assign((const char*)qv, (const char*)qv + m); }
+                    ln.clear();
+                    mh::Aligner::sam_write(ln, S, name, seq, quals ? &qual : nullptr);
+                    dst += ln;
+                }
+            });
+            host_busy += mh::now_s() - t0;
+        };
+        {
+            std::thread worker;
+            int rc_gpu = MONI_OK;
+            for (uint64_t k = 0; k < n_sub; ++k) {
+                rc_gpu = gpu_stage(k, res[k & 1]);
+                if (worker.joinable()) worker.join();
+                if (rc_gpu) break;
+                worker = std::thread([&, k]() { host_stage(k, res[k & 1]); });
             }
-        });
+            if (worker.joinable()) worker.join();
+            if (rc_gpu) return rc_gpu;
+        }
+        st.dp_rounds = 1;
+        if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "align_kernel: %.3f ms in %llu sub-batches, %llu waves; lane-0 cycles: init %.3g drive %.3g; wave cycles in DP %.3g\n", c->dp_kernel_ms_accum, (unsigned long long)n_sub, (unsigned long long)waves_used, prof[0], prof[1], prof[2]);
+        double t0 = mh::now_s();
         for (int t = 0; t < T; ++t) st.aligned += aligned_t[t];
-        st.reads = nr;
+        st.reads = NR;
+        std::vector<uint32_t> back;
+        for (auto& v : back_of) back.insert(back.end(), v.begin(), v.end());
+        std::vector<std::string> back_line(back.size());
         if (!back.empty()) {
-            // rebuild a sub-batch of the handed-back reads and run them through the host pipeline
+            // the reads the kernel handed back, as one batch through the host pipeline
             std::vector<uint8_t> sseq, snames, squal; std::vector<uint64_t> soff(1, 0), snoff(1, 0);
             for (uint32_t r : back) {
                 const uint64_t off = b->offsets[r], m = b->offsets[r + 1] - b->offsets[r];
@@ -680,22 +736,51 @@ int moni_align_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* n
             std::string sout; mh::AlignStats s2;
             if ((rc = host_align_subset(c, *prm, sub, snames.data(), snoff.data(), quals ? squal.data() : nullptr, sout, s2))) return rc;
             size_t p0 = 0;
-            for (uint32_t r : back) { const size_t p1 = sout.find('\n', p0); line[r] = sout.substr(p0, p1 - p0 + 1); p0 = p1 + 1; }
+            for (size_t x = 0; x < back.size(); ++x) { const size_t p1 = sout.find('\n', p0); back_line[x] = sout.substr(p0, p1 - p0 + 1); p0 = p1 + 1; }
             st.aligned += s2.aligned; st.dp_tasks += s2.dp_tasks; st.dp_cells += s2.dp_cells; st.dp_rounds += s2.dp_rounds;
             st.t_chain += s2.t_chain;     // counts the whole fallback as "chain/host" time below
         }
         st.handed_back = back.size();
-        size_t total = 0;
-        for (auto& l : line) total += l.size();
-        out.reserve(total);
-        for (auto& l : line) out += l;
-        st.t_host += mh::now_s() - t0;
+        if (back.empty()) {
+            // assemble: every piece knows its offset, copied by the pool straight into the caller's buffer
+            std::vector<size_t> at(n_sub * T + 1, 0);
+            for (uint64_t k = 0; k < n_sub; ++k) for (int t = 0; t < T; ++t) at[k * T + t + 1] = at[k * T + t] + text[k][t].size();
+            const size_t total = at[n_sub * T];
+            *sam = (char*)malloc(total + 1);
+            if (!*sam) return MONI_ENOMEM;
+            char* dst = *sam;
+            mh::parallel_for(pool, n_sub * T, [&](int, size_t lo, size_t hi) {
+                for (size_t x = lo; x < hi; ++x) { const std::string& piece = text[x / T][x % T]; if (!piece.empty()) memcpy(dst + at[x], piece.data(), piece.size()); }
+            });
+            dst[total] = 0;
+            *sam_len = total;
+            out_done = true;
+        } else {
+            // rare: splice the handed-back lines in at their read positions (a thread's piece is split at those reads)
+            size_t bi = 0;
+            for (uint64_t k = 0; k < n_sub; ++k) {
+                const uint64_t r0 = k * sub_reads, nr = std::min(sub_reads, NR - r0);
+                for (int t = 0; t < T; ++t) {
+                    const size_t lo = (nr < 2 || T <= 1) ? (t == 0 ? 0 : nr) : nr * t / T, hi = (nr < 2 || T <= 1) ? (t == 0 ? nr : nr) : nr * (t + 1) / T;
+                    const std::string& piece = text[k][t];
+                    size_t p0 = 0;
+                    for (size_t r = lo; r < hi; ++r) {
+                        if (bi < back.size() && back[bi] == r0 + r) { out += back_line[bi++]; continue; }
+                        const size_t p1 = piece.find('\n', p0);
+                        out.append(piece, p0, p1 - p0 + 1); p0 = p1 + 1;
+                    }
+                }
+            }
+        }
+        st.t_host += host_busy + (mh::now_s() - t0);
     }
+    if (!out_done) {
     *sam = (char*)malloc(out.size() + 1);
     if (!*sam) return MONI_ENOMEM;
     memcpy(*sam, out.data(), out.size());
     (*sam)[out.size()] = 0;
     *sam_len = out.size();
+    }
     if (stats) {
         stats->reads = st.reads; stats->aligned = st.aligned; stats->dp_tasks = st.dp_tasks; stats->dp_cells = st.dp_cells; stats->dp_rounds = st.dp_rounds;
         stats->t_seed = st.t_seed; stats->t_chain = st.t_chain; stats->t_dp = st.t_dp; stats->t_host = st.t_host;

@@ -30,7 +30,7 @@ def both(env, reads_list, quals=True):
     o, ctx = env
     offs = np.zeros(len(reads_list) + 1, dtype=np.uint64)
     offs[1:] = np.cumsum([len(r) for r in reads_list])
-    seq = np.concatenate(reads_list)
+    seq = np.concatenate(reads_list) if reads_list else np.zeros(0, dtype=np.uint8)
     names, noff = orc.make_names(len(reads_list))
     q = np.full(len(seq), ord("I"), dtype=np.uint8) if quals else None
     want, wcnt = orc.align_batch(o, seq, offs, names, noff, q, threads=8)
@@ -44,6 +44,21 @@ def test_sam_identical_150bp(medium_case, env):
     reads = medium_case.synth.make_reads(medium_case.pg, 20000, 150, seed=150)
     wcnt, st = both(env, list(reads))
     assert st["aligned"] == wcnt["aligned"] > 19000
+
+
+def test_sub_batches_and_handed_back_reads(medium_case, env, monkeypatch):
+    """The batch goes through the GPU in sub-batches overlapped with the host stage; reads the kernel hands back go
+    through the host pipeline and are spliced in at their positions.  Output must not depend on either."""
+    reads = list(medium_case.synth.make_reads(medium_case.pg, 7001, 150, seed=151))
+    monkeypatch.setenv("MONI_ALIGN_SUB", "1500")
+    _, st = both(env, reads)
+    assert st["handed_back"] == 0
+    monkeypatch.setenv("MONI_AK_FORCE_HANDBACK", "7")
+    _, st = both(env, reads)
+    assert st["handed_back"] == 1001
+    monkeypatch.setenv("MONI_ALIGN_SUB", "1000000")
+    both(env, reads[:1])
+    both(env, reads[:0])
 
 
 def test_sam_identical_250bp_noisy_ragged(medium_case, env):

@@ -12,11 +12,21 @@ pytestmark = pytest.mark.gpu
 FIELDS = ["max", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score", "reach_end", "zdropped", "n_cigar"]
 
 
-@pytest.fixture(scope="module")
-def ctx(small_case):
+@pytest.fixture(scope="module", params=["registers", "lds"])
+def ctx(small_case, request):
+    """Both forms of the DP: register-blocked extz_kernel<NCH> and the LDS-tiled one align_kernel runs (MONI_EXTZ_LDS=1,
+    read when the context is created)."""
     from moni_align_amd import capi
     idx = capi.Index(fi=small_case.fi)
-    c = capi.Ctx(idx)
+    old = os.environ.get("MONI_EXTZ_LDS")
+    os.environ["MONI_EXTZ_LDS"] = "1" if request.param == "lds" else "0"
+    try:
+        c = capi.Ctx(idx)
+    finally:
+        if old is None:
+            del os.environ["MONI_EXTZ_LDS"]
+        else:
+            os.environ["MONI_EXTZ_LDS"] = old
     yield c
     c.close()
     idx.close()

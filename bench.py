@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the HIP hot path on the BASELINE.json workload.
 
-One "step" = one pass of the seeding hot path (MS pointers by LF/threshold jumps -> MEMs -> phi/phi^-1
-occurrence enumeration, both strands) over one resident batch of synthetic 150 bp reads on the
-mouse-chr19-scale x12-haplotype index (BASELINE.json configs[1]).  Inputs are already in HBM when the
-timed region starts.  N > 1: one process per GPU (torch.distributed / RCCL), reads sharded, index
-replicated, no data-path collective ("weak" scaling: per-GPU batch fixed).
+One "step" = one pass of the whole single-end hot path over one resident batch of synthetic 150 bp reads on
+the mouse-chr19-scale x12-haplotype index (BASELINE.json configs[2]): MEM seeding (MS pointers by LF /
+threshold jumps -> MEMs -> phi/phi^-1 occurrence enumeration, both strands), then align_kernel (chaining,
+chain selection, ksw2 extension DP) and the host stage that turns its records into SAM text (MD/NM, MAPQ).
+The reads are already in HBM when the timed region starts; the step ends with the batch's SAM text in host
+memory.  N > 1: one process per GPU (torch.distributed / RCCL), reads sharded, index replicated, no data-path
+collective ("weak" scaling: per-GPU batch fixed).
 
-Prints ONE JSON line (rank 0) with `roofline` (ms_lf_kernel, HIP-event timed inside the library on its
-own stream) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N == 1 only).
+Prints ONE JSON line (rank 0) with `roofline` (ms_lf_kernel, the path's HBM-bound kernel, HIP-event timed inside
+the library on its own stream), `dp` (align_kernel), `seeding` (the seeding stage alone, configs[1]) and
+`cpu_baseline` (the CPU oracle's whole path on a bounded sample, rank 0, N == 1 only).
 """
 import argparse
 import json
@@ -52,8 +55,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cache", default="/tmp/moni_bench_cache")
-    ap.add_argument("--full-path-reads", type=int, default=200000,
-                    help="also time moni_align_batch (seeding + HIP ksw2 extension + host stages + SAM) on this many reads; 0 = skip")
+    ap.add_argument("--full-path-reads", type=int, default=0, help="(ignored; the step is the full path)")
     args = ap.parse_args()
 
     import torch
@@ -114,23 +116,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup + timed steps ---------------------------------------------------------------------------
+    # ---- warmup + timed steps: the whole single-end path over the resident batch ------------------------------
+    from oracle import orc as _orc          # only for read names here (make_names) and, below, as the CPU baseline / checker
+    names, noff = _orc.make_names(args.reads)
+    quals = np.full(args.reads * L, ord("I"), dtype=np.uint8)
+    threads = max(1, host_cpus() // max(1, world))          # host stage threads of this rank
     for _ in range(args.warmup):
-        ctx.seed_run(25, True, 1000)
+        ctx.align_run(names, noff, quals, host_threads=threads, want_text=False)
     sync_all()
     kern = np.zeros(7)
+    stage = {"seed": 0.0, "align_kernel": 0.0, "align_stage": 0.0, "host_stage_busy": 0.0}
+    stf = None
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.seed_run(25, True, 1000)
+        sam_len, stf = ctx.align_run(names, noff, quals, host_threads=threads, want_text=False)
         kern += [ctx.kernel_ms(w) if w != 5 else 0.0 for w in range(7)]
+        stage["seed"] += stf["t_seed"]; stage["align_kernel"] += stf["t_dp_kernel"]; stage["align_stage"] += stf["t_dp"]
+        stage["host_stage_busy"] += stf["t_host"]
     sync_all()
     elapsed = time.perf_counter() - t0
     elapsed = mdist.max_over_ranks(elapsed, dist, coll_dev)
     kern /= max(1, args.steps)
+    for k in stage:
+        stage[k] /= max(1, args.steps)
     cnt = ctx.counters()
+    sizes = mdist.gather_counts([stf["aligned"], sam_len], dist, coll_dev)     # the only result exchange: per-rank record counts
+
+    # seeding stage alone (BASELINE.json configs[1]), same resident batch
+    ts = time.perf_counter()
+    n_seed_rep = 3
+    for _ in range(n_seed_rep):
+        ctx.seed_run(25, True, 1000)
+    torch.cuda.synchronize()
+    seed_s = (time.perf_counter() - ts) / n_seed_rep
     res = ctx.seed_fetch()
     n_mems, n_occs = len(res["mems"]), len(res["occs"])
-    sizes = mdist.gather_counts([n_mems, n_occs], dist, coll_dev)     # the only result exchange: per-rank record counts
 
     out = None
     if rank == 0:
@@ -147,74 +167,70 @@ def main():
         achieved = ms_bytes / ms_s / 1e9 if ms_s > 0 else 0.0
         value = world * args.reads * args.steps / elapsed
         out = {
-            "metric": "reads/s (whole node), 150 bp SE, seeding hot path (MS/LF + MEM + phi occurrences)",
+            "metric": "aligned reads/s (whole node), 150 bp SE, mouse-chr19-scale x%d-haplotype index" % args.haps,
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: mouse-chr19-scale index (%d bp base + %d haplotypes, n=%d, r=%d), "
-                                   "%d x %d bp reads per GPU, MEM seeding stage on GPU (ksw2 extension not in this step)"
-                                   % (args.base_len, args.haps, fi.n, fi.r, args.reads, L),
+            "vs_baseline": None, "dtype": "u64/int32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: mouse-chr19-scale index (%d bp base + %d haplotypes, n=%d, r=%d), "
+                                   "%d x %d bp reads per GPU resident in HBM -> MEM seeding + HIP ksw2 extension (align_kernel) -> "
+                                   "SAM text (MD/NM/MAPQ/formatting on %d host threads per GPU, overlapped)"
+                                   % (args.base_len, args.haps, fi.n, fi.r, args.reads, L, threads),
                        "reads_per_gpu": args.reads, "read_len": L, "parallelism": "reads sharded x%d, index replicated" % world},
             "roofline": {"bound": "hbm", "kernel": "ms_lf_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ms_bytes, "avg_launch_ms": kern[0],
-                         "per_read_bytes": ms_bytes / args.reads},
+                         "per_read_bytes": ms_bytes / args.reads,
+                         "note": "the path's HBM-bound kernel (LF / threshold-jump stage of seeding), one launch per step inside the timed "
+                                 "region; the step's longest kernel, align_kernel, is integer-VALU bound: see dp"},
+            "dp": {"kernel": "align_kernel", "bound": "valu-int32", "launches_per_step": -(-args.reads // 50000),
+                   "ms_per_step": stage["align_kernel"] * 1e3, "dp_problems": stf["dp_tasks"], "dp_cells": stf["dp_cells"],
+                   "gcups": stf["dp_cells"] / stage["align_kernel"] / 1e9 if stage["align_kernel"] > 0 else None,
+                   "handed_back_to_host_pipeline": stf["handed_back"]},
+            "stages_s_per_step": stage,
+            "aligned_per_step": stf["aligned"], "sam_bytes_per_step": sam_len,
+            "aligned_all_ranks": sum(x[0] for x in sizes),
             "kernels_ms": {"ms_lf": kern[0], "mem_count": kern[1], "mem_emit": kern[2], "occ_count": kern[3], "occ_fill": kern[4],
-                           "whole_run": kern[6]},
-            "work_per_step": {"lf_steps": S, "threshold_jumps": J, "phi_steps": P, "text_bytes": C, "mems": n_mems, "occs": n_occs,
-                              "mems_all_ranks": sum(x[0] for x in sizes), "occs_all_ranks": sum(x[1] for x in sizes)},
+                           "seeding_whole": kern[6]},
+            "seeding": {"workload": "BASELINE.json configs[1]: MEM seeding stage alone on the same resident batch",
+                        "value": world * args.reads / seed_s, "unit": "reads/s", "ms_per_pass": seed_s * 1e3,
+                        "work_per_pass": {"lf_steps": S, "threshold_jumps": J, "phi_steps": P, "text_bytes": C, "mems": n_mems, "occs": n_occs}},
         }
+        out["host"] = {"cpus_usable": host_cpus(), "cpu_count": os.cpu_count(), "host_threads_per_gpu": threads}
         if world == 1 and not args.no_cpu:
-            from oracle import orc
-            oidx = orc.OracleIndex(fi=fi)
-            threads = host_cpus()
+            oidx = _orc.OracleIndex(fi=fi)
+            cpu_threads = host_cpus()
+            # full path on the CPU (oracle/align.hpp), bounded sample; the same sample is an at-scale SAM identity check
             probe = 2000
             t1 = time.perf_counter()
-            oidx.seed_batch(reads[:probe].reshape(-1), offs[:probe + 1], 25, True, 1000, threads=threads)
+            _orc.align_batch(oidx, reads[:probe].reshape(-1), offs[:probe + 1], names[:int(noff[probe])], noff[:probe + 1], quals[:probe * L],
+                             threads=cpu_threads)
             rate = probe / (time.perf_counter() - t1)
             n_cpu = int(max(probe, min(args.reads, rate * args.cpu_seconds)))
             t1 = time.perf_counter()
-            want = oidx.seed_batch(reads[:n_cpu].reshape(-1), offs[:n_cpu + 1], 25, True, 1000, threads=threads)
+            wsam, wc = _orc.align_batch(oidx, reads[:n_cpu].reshape(-1), offs[:n_cpu + 1], names[:int(noff[n_cpu])], noff[:n_cpu + 1],
+                                        quals[:n_cpu * L], threads=cpu_threads)
+            dtc = time.perf_counter() - t1
+            gsam, _ = ctx.align_batch(reads[:n_cpu].reshape(-1), offs[:n_cpu + 1], names[:int(noff[n_cpu])], noff[:n_cpu + 1], quals[:n_cpu * L],
+                                      host_threads=threads)
+            out["cpu_baseline"] = {"value": n_cpu / dtc, "unit": "reads/s", "cores": cpu_threads, "kind": "port",
+                                   "sample": "first %d reads of the same batch, whole SE path, oracle/align.hpp with %d threads" % (n_cpu, cpu_threads),
+                                   "sam_identical_on_sample": bool(gsam == wsam)}
+            # seeding stage alone on the CPU, same bounded way
+            t1 = time.perf_counter()
+            oidx.seed_batch(reads[:probe].reshape(-1), offs[:probe + 1], 25, True, 1000, threads=cpu_threads)
+            rate = probe / (time.perf_counter() - t1)
+            n_cs = int(max(probe, min(args.reads, rate * args.cpu_seconds * 0.5)))
+            t1 = time.perf_counter()
+            want = oidx.seed_batch(reads[:n_cs].reshape(-1), offs[:n_cs + 1], 25, True, 1000, threads=cpu_threads)
             dt = time.perf_counter() - t1
-            # the same sample doubles as an at-scale parity check of the GPU result
             k = int(want["read_mem_off"][-1])
-            same = (np.array_equal(res["read_mem_off"][:n_cpu + 1], want["read_mem_off"]) and
+            same = (np.array_equal(res["read_mem_off"][:n_cs + 1], want["read_mem_off"]) and
                     np.array_equal(res["mems"]["pos"][:k], want["pos"]) and np.array_equal(res["mems"]["len"][:k].astype(np.uint64), want["len"]) and
                     np.array_equal(res["mems"]["occ_cnt"][:k].astype(np.uint64), want["occ_cnt"]) and
                     np.array_equal(res["occs"][:len(want["occs"])], want["occs"]))
-            out["cpu_baseline"] = {"value": n_cpu / dt, "unit": "reads/s", "cores": threads, "kind": "port",
-                                   "sample": "first %d reads of the same batch, same stage, oracle/seed.hpp with %d threads" % (n_cpu, threads),
-                                   "gpu_matches_cpu_on_sample": bool(same)}
-        out["host"] = {"cpus_usable": host_cpus(), "cpu_count": os.cpu_count()}
-        if world == 1 and args.full_path_reads > 0:
-            # BASELINE.json configs[2]: the whole SE path (host buffers in, SAM text out: PCIe and host stages included)
-            from oracle import orc as _orc
-            nfp = min(args.full_path_reads, args.reads)
-            names, noff = _orc.make_names(nfp)
-            quals = np.full(nfp * L, ord("I"), dtype=np.uint8)
-            ctx.align_batch(reads[:2000].reshape(-1), offs[:2001], names[:int(noff[2000])], noff[:2001], quals[:2000 * L])   # warm-up
-            t1 = time.perf_counter()
-            sam, stf = ctx.align_batch(reads[:nfp].reshape(-1), offs[:nfp + 1], names, noff, quals)
-            dtf = time.perf_counter() - t1
-            out["full_path"] = {"workload": "BASELINE.json configs[2]: seeding + HIP ksw2 extension + chaining/MAPQ/SAM on host, %d reads, "
-                                            "host buffers in / SAM text out" % nfp,
-                                "value": nfp / dtf, "unit": "reads/s", "aligned": stf["aligned"], "dp_tasks": stf["dp_tasks"],
-                                "dp_cells": stf["dp_cells"], "dp_rounds": stf["dp_rounds"], "handed_back_to_host_pipeline": stf["handed_back"],
-                                "host_threads": host_cpus(),
-                                "seconds": {"seed": stf["t_seed"], "chain": stf["t_chain"], "dp": stf["t_dp"], "host_other": stf["t_host"],
-                                            "dp_kernels": stf["t_dp_kernel"]},
-                                "gcups_dp_stage": stf["dp_cells"] / stf["t_dp"] / 1e9 if stf["t_dp"] > 0 else None,
-                                "gcups_extz_kernel": stf["dp_cells"] / stf["t_dp_kernel"] / 1e9 if stf["t_dp_kernel"] > 0 else None}
-            if not args.no_cpu:
-                ncpu = min(nfp, 20000)
-                t1 = time.perf_counter()
-                wsam, wc = _orc.align_batch(oidx, reads[:ncpu].reshape(-1), offs[:ncpu + 1], names[:int(noff[ncpu])], noff[:ncpu + 1],
-                                            quals[:ncpu * L], threads=threads)
-                dtc = time.perf_counter() - t1
-                head = b"\n".join(sam.split(b"\n")[:ncpu]) + b"\n"
-                out["full_path"]["cpu_baseline"] = {"value": ncpu / dtc, "unit": "reads/s", "cores": threads, "kind": "port",
-                                                    "sample": "first %d reads, oracle/align.hpp" % ncpu,
-                                                    "sam_identical_on_sample": bool(head == wsam)}
+            out["seeding"]["cpu_baseline"] = {"value": n_cs / dt, "unit": "reads/s", "cores": cpu_threads, "kind": "port",
+                                              "sample": "first %d reads, same stage, oracle/seed.hpp" % n_cs,
+                                              "gpu_matches_cpu_on_sample": bool(same)}
         print(json.dumps(out), flush=True)
     ctx.close()
     idx.close()

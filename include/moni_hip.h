@@ -178,6 +178,9 @@ void moni_align_params_default(moni_align_params_t *p);
 int moni_align_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
                      const uint8_t *quals, const moni_align_params_t *prm, char **sam, uint64_t *sam_len,
                      moni_align_stats_t *stats);
+/* The same over the batch that moni_reads_upload made resident (reads already in HBM when the call starts). */
+int moni_align_run(moni_ctx_t *ctx, const uint8_t *names, const uint64_t *name_off, const uint8_t *quals,
+                   const moni_align_params_t *prm, char **sam, uint64_t *sam_len, moni_align_stats_t *stats);
 /* aligner::to_sam (aligner_ksw2.hpp:3213-3219): "@HD", one "@SQ" per sequence, "@PG". */
 int moni_sam_header(const moni_index_t *idx, char **sam, uint64_t *sam_len);
 

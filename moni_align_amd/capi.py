@@ -21,7 +21,7 @@ EXPORTS = [
     "moni_index_device_bytes", "moni_ctx_create", "moni_ctx_destroy", "moni_reads_upload", "moni_ms_run",
     "moni_ms_query_batch", "moni_seed_run", "moni_seed_counts", "moni_seed_fetch", "moni_seed_batch", "moni_free",
     "moni_phi_lcp_batch", "moni_extz_batch", "moni_last_kernel_ms", "moni_last_counters",
-    "moni_align_params_default", "moni_align_batch", "moni_sam_header",
+    "moni_align_params_default", "moni_align_batch", "moni_align_run", "moni_sam_header",
 ]
 
 
@@ -117,6 +117,8 @@ def lib():
         L.moni_align_params_default.restype = None
         L.moni_align_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
+        L.moni_align_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
         L.moni_sam_header.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.moni_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.moni_last_counters.argtypes = [C.c_void_p, C.c_void_p]
@@ -262,6 +264,31 @@ class Ctx:
         self.n_reads = len(offsets) - 1
         try:
             sam = C.string_at(out, ln.value)
+        finally:
+            self._L.moni_free(out)
+        return sam, {k: getattr(st, k) for k, _ in AlignStatsC._fields_}
+
+    def align_run(self, names: np.ndarray, name_off: np.ndarray, quals=None, host_threads: Optional[int] = None,
+                  want_text: bool = True, **overrides):
+        """moni_align_run over the batch made resident by upload(); want_text=False skips the copy into a Python bytes
+        object (the library has still produced the SAM text) and returns its length instead."""
+        names = np.ascontiguousarray(names, dtype=np.uint8)
+        name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
+        if quals is not None:
+            quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        prm = AlignParamsC()
+        self._L.moni_align_params_default(C.byref(prm))
+        if host_threads is not None:
+            prm.host_threads = host_threads
+        for k, v in overrides.items():
+            setattr(prm, k, v)
+        out = C.c_void_p()
+        ln = C.c_uint64()
+        st = AlignStatsC()
+        _chk(self._L.moni_align_run(self._h, names.ctypes.data, name_off.ctypes.data, quals.ctypes.data if quals is not None else None,
+                                    C.byref(prm), C.byref(out), C.byref(ln), C.byref(st)), "moni_align_run")
+        try:
+            sam = C.string_at(out, ln.value) if want_text else int(ln.value)
         finally:
             self._L.moni_free(out)
         return sam, {k: getattr(st, k) for k, _ in AlignStatsC._fields_}

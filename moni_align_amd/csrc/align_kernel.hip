@@ -38,7 +38,7 @@ struct ak_args_t {
     const uint64_t* offs;
     const int32_t* min_score_of_len;         // 20 + 8*log(l), computed on the host (libm) per read length
     uint32_t max_len;
-    uint64_t n_reads;
+    uint64_t read_lo, n_reads;               // this launch takes reads [read_lo, read_lo + n_reads) of the resident batch
     ak_scratch_t* scratch;
     moni_aln_rec_t* recs;
     uint32_t* cig_pool; uint64_t cig_cap;
@@ -61,8 +61,8 @@ align_kernel(const ak_args_t A) {
         // dynamic read queue: reads differ a lot in the number of chains they score
         if (lane == 0) s_read = atomicAdd(&A.cursors[4], 1ull);
         __syncthreads();
-        const uint64_t r = s_read;
-        if (r >= A.n_reads) break;
+        if (s_read >= A.n_reads) break;
+        const uint64_t r = A.read_lo + s_read;
         if (lane == 0) {
             const long long c0 = clock64();
             W.off = A.offs[r]; W.m = (uint32_t)(A.offs[r + 1] - A.offs[r]);
@@ -124,7 +124,7 @@ align_kernel(const ak_args_t A) {
                     for (uint32_t k = 0; k < W.n_alt; ++k) { moni_alt_t x; x.pos = W.alt_pos[k]; x.score = W.alt_score[k]; x.pad = 0; A.alt_pool[ao + k] = x; }
                 }
             }
-            A.recs[r] = rec;
+            A.recs[r - A.read_lo] = rec;
         }
         __syncthreads();
     }

@@ -263,7 +263,11 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     delete c;
 }
 
-int moni_reads_upload(moni_ctx_t* c, const moni_read_batch_t* b) {
+static int reads_upload(moni_ctx* c, const moni_read_batch_t* b, bool keep_host_copy);
+int moni_reads_upload(moni_ctx_t* c, const moni_read_batch_t* b) { return reads_upload(c, b, true); }
+
+// keep_host_copy: the host pipeline (GpuBackend) reads the batch through c->h_seq / c->h_offs
+static int reads_upload(moni_ctx* c, const moni_read_batch_t* b, bool keep_host_copy) {
     if (!c || !b || !b->offsets || (b->n_reads && !b->seq)) return MONI_EINVAL;
     HIPCHK(hipSetDevice(c->idx->device));
     const uint64_t nr = b->n_reads;
@@ -283,8 +287,8 @@ int moni_reads_upload(moni_ctx_t* c, const moni_read_batch_t* b) {
     HIPCHK(hipMemcpyAsync(c->offs.p, rel.data(), (nr + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->n_reads = nr; c->total_len = total; c->max_len = mx;
-    c->h_seq.assign(b->seq + b->offsets[0], b->seq + b->offsets[0] + total);
-    c->h_offs = rel;
+    if (keep_host_copy) { c->h_seq.assign(b->seq + b->offsets[0], b->seq + b->offsets[0] + total); c->h_offs = rel; }
+    else { c->h_seq.clear(); c->h_offs.clear(); }
     c->n_mems = c->n_occs = 0;
     return MONI_OK;
 }
@@ -571,9 +575,37 @@ static int host_align_subset(moni_ctx* c, const moni_align_params_t& prm, const 
     return mh::align_batch(be, c->idx->hix, prm, c->h_seq.data(), c->h_offs.data(), c->n_reads, names, name_off, quals, out, st);
 }
 
+static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
+                      const moni_align_params_t* prm, char** sam, uint64_t* sam_len, moni_align_stats_t* stats);
+
 int moni_align_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
                      const moni_align_params_t* prm, char** sam, uint64_t* sam_len, moni_align_stats_t* stats) {
     if (!c || !b || !prm || !sam || !sam_len || (b->n_reads && (!names || !name_off))) return MONI_EINVAL;
+    return align_core(c, b, false, names, name_off, quals, prm, sam, sam_len, stats);
+}
+
+int moni_align_run(moni_ctx_t* c, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals, const moni_align_params_t* prm,
+                   char** sam, uint64_t* sam_len, moni_align_stats_t* stats) {
+    if (!c || !prm || !sam || !sam_len || (c->n_reads && (!names || !name_off))) return MONI_EINVAL;
+    if (c->h_offs.size() != c->n_reads + 1) return MONI_EINVAL;          // no batch resident (moni_reads_upload first)
+    // the host copy of the resident batch is the view the host stage formats SEQ from; it is taken out of the context for
+    // the duration of the call because the hand-back path makes its own (small) batch resident
+    std::vector<uint8_t> hs = std::move(c->h_seq);
+    std::vector<uint64_t> ho = std::move(c->h_offs);
+    const moni_read_batch_t view{hs.data(), ho.data(), c->n_reads};
+    const uint64_t nr = c->n_reads, tl = c->total_len, ml = c->max_len;
+    int rc = align_core(c, &view, true, names, name_off, quals, prm, sam, sam_len, stats);
+    if (c->n_reads != nr || c->h_offs.size() != 0) {                     // the hand-back path replaced the resident batch: put it back
+        const int rc2 = reads_upload(c, &view, false);
+        if (!rc) rc = rc2;
+    }
+    c->h_seq = std::move(hs); c->h_offs = std::move(ho);
+    c->n_reads = nr; c->total_len = tl; c->max_len = ml;
+    return rc;
+}
+
+static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
+                      const moni_align_params_t* prm, char** sam, uint64_t* sam_len, moni_align_stats_t* stats) {
     moni_index* I = c->idx;
     c->dp_kernel_ms_accum = 0;
     std::string out;
@@ -611,18 +643,20 @@ int moni_align_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* n
         double prof[3] = {0, 0, 0};
         uint64_t waves_used = 0;
 
-        // GPU stage of one sub-batch (blocking): upload, seed, align kernel, records back
+        // seeding: the whole batch at once (the LF kernel wants millions of lanes in flight)
+        {
+            const double t0 = mh::now_s();
+            if (!resident && (rc = reads_upload(c, b, false))) return rc;
+            moni_seed_params_t sp;
+            sp.min_len = prm->min_len; sp.filter_seeds = prm->filter_seeds; sp.n_seeds_thr = prm->n_seeds_thr; sp.report_mems = 0;
+            if ((rc = moni_seed_run(c, &sp))) return rc;
+            st.t_seed += mh::now_s() - t0;
+        }
+        // GPU stage of one sub-batch (blocking): align kernel over its reads, records back
         auto gpu_stage = [&](uint64_t k, SubRes& R) -> int {
             const uint64_t r0 = k * sub_reads, nr = std::min(sub_reads, NR - r0);
             double t0 = mh::now_s();
-            moni_read_batch_t sub{b->seq, b->offsets + r0, nr};
             int rc2;
-            if ((rc2 = moni_reads_upload(c, &sub))) return rc2;
-            moni_seed_params_t sp;
-            sp.min_len = prm->min_len; sp.filter_seeds = prm->filter_seeds; sp.n_seeds_thr = prm->n_seeds_thr; sp.report_mems = 0;
-            if ((rc2 = moni_seed_run(c, &sp))) return rc2;
-            st.t_seed += mh::now_s() - t0;
-            t0 = mh::now_s();
             uint64_t n_waves = (uint64_t)n_cu * (uint64_t)per_cu;
             if (n_waves > nr) n_waves = nr;
             waves_used = std::max(waves_used, n_waves);
@@ -646,7 +680,7 @@ int moni_align_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* n
             A.D.sc_mch = prm->smatch; A.D.sc_mis = -prm->smismatch; A.D.sc_N = -prm->gape; A.D.wild = 4; A.D.qo = prm->gapo; A.D.e = prm->gape;
             A.D.end_bonus = prm->end_bonus; A.D.reads = c->seq.p; A.D.text = I->d_text; A.D.n_text = I->K.n_text;
             A.mems = c->mems.p; A.occs = c->occs.p; A.read_mem_off = c->read_mem_off.p; A.offs = c->offs.p;
-            A.min_score_of_len = c->ak_minscore.p; A.max_len = (uint32_t)c->max_len + 1; A.n_reads = nr;
+            A.min_score_of_len = c->ak_minscore.p; A.max_len = (uint32_t)c->max_len + 1; A.read_lo = r0; A.n_reads = nr;
             A.scratch = c->ak_scratch.p; A.recs = c->ak_recs.p; A.cig_pool = c->ak_cig.p; A.cig_cap = cig_cap; A.alt_pool = c->ak_alt.p;
             A.alt_cap = alt_cap; A.cursors = c->d_ak_cursors;
             rec(c, EV_DP0);

@@ -61,6 +61,27 @@ def test_sub_batches_and_handed_back_reads(medium_case, env, monkeypatch):
     both(env, reads[:0])
 
 
+def test_align_run_on_resident_batch(medium_case, env, monkeypatch):
+    """moni_align_run (reads already in HBM) gives the text moni_align_batch gives, leaves the batch resident, also
+    after reads went through the hand-back path."""
+    from oracle import orc
+    o, ctx = env
+    reads = medium_case.synth.make_reads(medium_case.pg, 3000, 150, seed=152)
+    offs = np.arange(0, 3001 * 150, 150, dtype=np.uint64)
+    names, noff = orc.make_names(3000)
+    q = np.full(reads.size, ord("I"), dtype=np.uint8)
+    want, _ = ctx.align_batch(reads.reshape(-1), offs, names, noff, q, host_threads=4)
+    ctx.upload(reads.reshape(-1), offs)
+    a, st = ctx.align_run(names, noff, q, host_threads=4)
+    assert a == want and st["reads"] == 3000
+    monkeypatch.setenv("MONI_AK_FORCE_HANDBACK", "5")
+    b, st = ctx.align_run(names, noff, q, host_threads=4)
+    assert b == want and st["handed_back"] == 600
+    monkeypatch.delenv("MONI_AK_FORCE_HANDBACK")
+    n, st = ctx.align_run(names, noff, q, host_threads=4, want_text=False)
+    assert n == len(want) and st["handed_back"] == 0
+
+
 def test_sam_identical_250bp_noisy_ragged(medium_case, env):
     rng = np.random.default_rng(17)
     base = medium_case.synth.make_reads(medium_case.pg, 4000, 250, seed=9, sub_rate=0.04, indel_rate=0.006)

@@ -185,7 +185,8 @@ def main():
             "dp": {"kernel": "align_kernel", "bound": "valu-int32", "launches_per_step": -(-args.reads // 50000),
                    "ms_per_step": stage["align_kernel"] * 1e3, "dp_problems": stf["dp_tasks"], "dp_cells": stf["dp_cells"],
                    "gcups": stf["dp_cells"] / stage["align_kernel"] / 1e9 if stage["align_kernel"] > 0 else None,
-                   "handed_back_to_host_pipeline": stf["handed_back"]},
+                   "handed_back_to_host_pipeline": stf["handed_back"],
+                   "dp_problems_reused_from_memo": stf["dp_reused"], "dp_cells_reused": stf["dp_cells_reused"]},
             "stages_s_per_step": stage,
             "aligned_per_step": stf["aligned"], "sam_bytes_per_step": sam_len,
             "aligned_all_ranks": sum(x[0] for x in sizes),

@@ -169,6 +169,7 @@ typedef struct {
     double t_seed, t_chain, t_dp, t_host;                 /* seconds: seeding incl. fetch, chaining, DP batches incl. transfers, other host work */
     double t_dp_kernel;                                   /* seconds inside the align / extz kernels (HIP events) */
     uint64_t handed_back;                                 /* reads that exceeded the align kernel's capacities and went through the host pipeline */
+    uint64_t dp_reused, dp_cells_reused;                  /* DP problems (and their cells) answered from the per-read memo of identical problems; not in dp_tasks/dp_cells */
 } moni_align_stats_t;
 
 void moni_align_params_default(moni_align_params_t *p);
@@ -178,7 +179,9 @@ void moni_align_params_default(moni_align_params_t *p);
 int moni_align_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
                      const uint8_t *quals, const moni_align_params_t *prm, char **sam, uint64_t *sam_len,
                      moni_align_stats_t *stats);
-/* The same over the batch that moni_reads_upload made resident (reads already in HBM when the call starts). */
+/* The same over the batch that moni_reads_upload made resident (reads already in HBM when the call starts).  *sam points
+ * into a buffer the context owns: valid until the next moni_align_run / moni_ctx_destroy on this context, NOT to be freed
+ * (a streaming caller writes it out and calls again; the pages stay mapped between batches). */
 int moni_align_run(moni_ctx_t *ctx, const uint8_t *names, const uint64_t *name_off, const uint8_t *quals,
                    const moni_align_params_t *prm, char **sam, uint64_t *sam_len, moni_align_stats_t *stats);
 /* aligner::to_sam (aligner_ksw2.hpp:3213-3219): "@HD", one "@SQ" per sequence, "@PG". */

@@ -55,7 +55,7 @@ class AlignParamsC(C.Structure):
 class AlignStatsC(C.Structure):
     _fields_ = [("reads", C.c_uint64), ("aligned", C.c_uint64), ("dp_tasks", C.c_uint64), ("dp_cells", C.c_uint64), ("dp_rounds", C.c_uint64),
                 ("t_seed", C.c_double), ("t_chain", C.c_double), ("t_dp", C.c_double), ("t_host", C.c_double),
-                ("t_dp_kernel", C.c_double), ("handed_back", C.c_uint64)]
+                ("t_dp_kernel", C.c_double), ("handed_back", C.c_uint64), ("dp_reused", C.c_uint64), ("dp_cells_reused", C.c_uint64)]
 
 
 class DpParamsC(C.Structure):
@@ -287,10 +287,7 @@ class Ctx:
         st = AlignStatsC()
         _chk(self._L.moni_align_run(self._h, names.ctypes.data, name_off.ctypes.data, quals.ctypes.data if quals is not None else None,
                                     C.byref(prm), C.byref(out), C.byref(ln), C.byref(st)), "moni_align_run")
-        try:
-            sam = C.string_at(out, ln.value) if want_text else int(ln.value)
-        finally:
-            self._L.moni_free(out)
+        sam = C.string_at(out, ln.value) if want_text else int(ln.value)      # the buffer belongs to the context
         return sam, {k: getattr(st, k) for k, _ in AlignStatsC._fields_}
 
     def sam_header(self) -> bytes:

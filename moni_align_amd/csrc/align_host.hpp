@@ -241,6 +241,8 @@ struct SmallVec {
     const Tp& back() const { return (*this)[n - 1]; }
 };
 
+struct moni_alt_like { uint64_t pos; int32_t score; int32_t pad; };      // layout of moni_alt_t (align_kernel.hip)
+
 struct Sam {                       // sam_t (sam.hpp:47-112), the fields the SE path sets
     bool rev_read = false;         // sam.read = &read_rev
     size_t flag = 4, pos = 0, mapq = 255;
@@ -609,6 +611,86 @@ struct Aligner {
         if (strand) S.rev_read = true;
     }
 
+    // finish_record + sam_write in one pass straight into the output text, no per-read containers: what the host stage
+    // of the align-kernel path runs per read (same bytes as the two functions above and below produce; sam.hpp:144-188,249-287).
+    struct EmitScratch { std::string cs, md; };
+    static inline void put_int(std::string& o, int v) {
+        char b[12]; int n = 0; unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+        do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+        if (v < 0) o.push_back('-');
+        while (n) o.push_back(b[--n]);
+    }
+    void emit_record(std::string& out, EmitScratch& sc, const char* name, size_t name_len, const uint8_t* rd, const uint8_t* ql, uint32_t m,
+                     bool aligned, uint32_t strand, uint64_t ref_pos, int32_t score, int32_t score2, const uint32_t* cig, uint32_t n_cig,
+                     const moni_alt_like* alts, uint32_t n_alt) const {
+        out.append(name, name_len);
+        if (!aligned) {
+            out += "\t4\t*\t0\t255\t*\t*\t0\t0\t";
+            out.append((const char*)rd, m); out.push_back('\t');
+            if (ql) out.append((const char*)ql, m); else out.push_back('*');
+            out.push_back('\n');
+            return;
+        }
+        uint64_t ref_len = 0;
+        sc.cs.clear(); sc.md.clear();
+        for (uint32_t k = 0; k < n_cig; ++k) {
+            const uint32_t c = cig[k]; const int op = c & 0xf;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
+            put_int(sc.cs, (int)(c >> 4)); sc.cs.push_back("MID"[op]);
+        }
+        // MD / NM over the window the CIGAR spans (write_MD_core)
+        int NM = 0;
+        {
+            int l_MD = 0; uint64_t t = ref_pos; uint32_t q = 0;
+            auto tb = [&](uint64_t a) -> uint8_t { return nt4_of(a < ix.n_text ? ix.text[a] : 0); };
+            auto qb = [&](uint32_t k) -> uint8_t { return nt4_of(strand ? compl_of(rd[m - 1 - k]) : rd[k]); };
+            for (uint32_t i = 0; i < n_cig; ++i) {
+                const int op = cig[i] & 0xf, len = (int)(cig[i] >> 4);
+                if (op == 0 || op == 7 || op == 8) {
+                    for (int j = 0; j < len; ++j) {
+                        const uint8_t tc = tb(t + j);
+                        if (qb(q + j) != tc) { put_int(sc.md, l_MD); sc.md.push_back("ACGTN"[tc]); l_MD = 0; ++NM; }
+                        else ++l_MD;
+                    }
+                    q += len; t += len;
+                } else if (op == 1) { q += len; NM += len; }
+                else if (op == 2) {
+                    put_int(sc.md, l_MD); sc.md.push_back('^');
+                    for (int j = 0; j < len; ++j) sc.md.push_back("ACGTN"[tb(t + j)]);
+                    l_MD = 0; t += len; NM += len;
+                } else if (op == 3) t += len;
+            }
+            if (l_MD > 0) put_int(sc.md, l_MD);
+        }
+        const auto refi = ix.index(ref_pos);
+        const std::string& lift_rname = ix.names[refi.first];
+        const int lift_pos = (int)(refi.second + 1);
+        const bool mapped = ref_len > 0;              // else: pos 0, rname/cigar "*", no MD, NM 0, tags still printed (unmapped_lft)
+        const int flag = strand ? 16 : 0;
+        const int mapq = (int)mapq_se_bwa(score, score2, (int32_t)(mapped ? ref_len : 0), (int32_t)m, (int32_t)P.min_len, P.smatch, P.smismatch, 50.0, mapq_coeff_fac);
+        out.push_back('\t'); put_int(out, flag); out.push_back('\t');
+        if (mapped) out += lift_rname; else out.push_back('*');
+        out.push_back('\t'); put_int(out, mapped ? lift_pos : 0); out.push_back('\t'); put_int(out, mapq); out.push_back('\t');
+        if (mapped) out += sc.cs; else out.push_back('*');
+        out += "\t*\t0\t0\t";
+        if (strand) { const size_t at = out.size(); out.resize(at + m); for (uint32_t k = 0; k < m; ++k) out[at + k] = (char)compl_of(rd[m - 1 - k]); }
+        else out.append((const char*)rd, m);
+        out.push_back('\t');
+        if (ql) { if (strand) { const size_t at = out.size(); out.resize(at + m); for (uint32_t k = 0; k < m; ++k) out[at + k] = (char)ql[m - 1 - k]; } else out.append((const char*)ql, m); }
+        else out.push_back('*');
+        out += "\tAS:i:"; put_int(out, score); out += "\tNM:i:"; put_int(out, mapped ? NM : 0);
+        if (score2 != 0) { out += "\tZS:i:"; put_int(out, score2); }
+        out += "\tMD:Z:"; if (mapped) out += sc.md;
+        out += "\tOA:Z:"; out += lift_rname; out.push_back(','); put_int(out, lift_pos);
+        out += strand ? ",-," : ",+,"; out += sc.cs; out.push_back(','); put_int(out, mapq); out.push_back(','); put_int(out, NM); out.push_back(';');
+        out += "\tAA:Z:";
+        for (uint32_t k = 0; k < n_alt; ++k) {
+            const auto r = ix.index(alts[k].pos);
+            out += ix.names[r.first]; out.push_back(','); put_int(out, (int)(r.second + 1)); out.push_back(','); put_int(out, alts[k].score); out.push_back(';');
+        }
+        out.push_back('\n');
+    }
+
     static void sam_write(std::string& out, const Sam& s, const std::string& name, const std::string& seq, const std::string* qual) {   // sam.hpp:144-188
         char buf[32];
         auto d = [&](size_t v) { snprintf(buf, sizeof buf, "%d", (int)v); out += buf; };
@@ -668,7 +750,7 @@ static void parallel_for(Pool& pool, size_t n, Fn fn) {
     pool.run([&](int t) { const size_t lo = n * t / T, hi = n * (t + 1) / T; if (lo < hi) fn(t, lo, hi); });
 }
 
-struct AlignStats { uint64_t reads = 0, aligned = 0, dp_tasks = 0, dp_cells = 0, dp_rounds = 0, handed_back = 0; double t_seed = 0, t_chain = 0, t_dp = 0, t_host = 0; };
+struct AlignStats { uint64_t reads = 0, aligned = 0, dp_tasks = 0, dp_cells = 0, dp_rounds = 0, handed_back = 0, dp_reused = 0, dp_cells_reused = 0; double t_seed = 0, t_chain = 0, t_dp = 0, t_host = 0; };
 
 static inline double now_s() {
     using namespace std::chrono;

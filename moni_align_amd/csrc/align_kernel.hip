@@ -12,6 +12,7 @@
 
 #define AK_CIG_CAP 1024u                     // CIGAR slots per DP problem of a round (qlen + tlen + 2 <= this)
 #define AK_DIRS_CAP (384u * 1024u)           // direction bytes of one CIGAR problem
+#define AK_MEMO 24                           // score-only DP results remembered per read
 
 struct moni_aln_rec_t {                      // one per read
     uint32_t status;                         // 0 not aligned, 1 aligned, 2 overflow (host pipeline)
@@ -27,7 +28,23 @@ struct ak_scratch_t {                        // per persistent wave, in HBM
     ac_ws_t ws;
     uint32_t cig[AC_MAX_TASKS * AK_CIG_CAP];
     uint8_t dirs[AK_DIRS_CAP];
+    moni_dp_result_t memo_res[AK_MEMO];
 };
+
+// Two DP problems of one read with the same query segment, flags and target length have the same result when their target
+// windows spell the same nt4 string - the usual case when a read's chains lie on haplotypes that agree around the read.
+// Wave-wide comparison of the two windows, addressed exactly as extz_wave_lds addresses them.
+__device__ __attribute__((noinline)) bool ak_same_target(const dp_launch_t& D, int mode, uint64_t t1, uint64_t t2, int tlen) {
+    const uint8_t* __restrict__ text = D.text;
+    const uint64_t n_text = D.n_text;
+    bool diff = false;
+    for (int i = threadIdx.x & 63; i < tlen; i += 64) {
+        const uint64_t a1 = (mode & DP_T_REV) ? t1 - (uint64_t)i : t1 + (uint64_t)i;
+        const uint64_t a2 = (mode & DP_T_REV) ? t2 - (uint64_t)i : t2 + (uint64_t)i;
+        diff |= dp_nt4(a1 < n_text ? text[a1] : 0u) != dp_nt4(a2 < n_text ? text[a2] : 0u);
+    }
+    return __ballot(diff) == 0ull;
+}
 
 struct ak_args_t {
     ac_params_t P;
@@ -43,7 +60,8 @@ struct ak_args_t {
     moni_aln_rec_t* recs;
     uint32_t* cig_pool; uint64_t cig_cap;
     moni_alt_t* alt_pool; uint64_t alt_cap;
-    unsigned long long* cursors;             // [0] cigar pool, [1] alt pool, [2] DP problems, [3] DP cells, [4] next read, [5..7] cycles: init, drive, dp
+    unsigned long long* cursors;             // [0] cigar pool, [1] alt pool, [2] DP problems run, [3] their cells, [4] next read, [5..7] cycles: init, drive, dp,
+                                             // [8] DP problems answered from the per-read memo, [9] their cells
 };
 
 extern "C" __global__ void __launch_bounds__(64)
@@ -52,10 +70,15 @@ align_kernel(const ak_args_t A) {
     __shared__ moni_dp_task_t s_tasks[AC_MAX_TASKS];
     __shared__ moni_dp_result_t s_res[AC_MAX_TASKS];
     __shared__ uint32_t s_n, s_go;
+    __shared__ uint64_t memo_key[AK_MEMO], memo_toff[AK_MEMO];
+    __shared__ uint32_t memo_n;
     const int lane = threadIdx.x;
     ak_scratch_t* __restrict__ S = A.scratch + blockIdx.x;
     ac_ws_t& W = S->ws;
-    unsigned long long n_dp = 0, n_cells = 0, cy_init = 0, cy_drive = 0, cy_dp = 0;
+    __shared__ unsigned long long s_cnt[8];       // lane 0's statistics: DP problems run, cells, memo hits, their cells, cycles in init / drive / dp
+    enum { C_DP = 0, C_CELLS, C_MEMO, C_MEMO_CELLS, C_INIT, C_DRIVE, C_CYDP };
+    if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     __shared__ unsigned long long s_read;
     while (true) {
         // dynamic read queue: reads differ a lot in the number of chains they score
@@ -67,13 +90,13 @@ align_kernel(const ak_args_t A) {
             const long long c0 = clock64();
             W.off = A.offs[r]; W.m = (uint32_t)(A.offs[r + 1] - A.offs[r]);
             W.min_score = A.min_score_of_len[W.m <= A.max_len ? W.m : A.max_len];
-            s_n = 0; s_go = 0;
+            s_n = 0; s_go = 0; memo_n = 0;
             const bool chained = ac_init(W, A.P, A.mems, A.read_mem_off[r], A.read_mem_off[r + 1], A.occs);
             const long long c1 = clock64();
-            cy_init += (unsigned long long)(c1 - c0);
+            s_cnt[C_INIT] += (unsigned long long)(c1 - c0);
             if (chained) {
                 ac_drive(W, A.P, nullptr, nullptr);
-                cy_drive += (unsigned long long)(clock64() - c1);
+                s_cnt[C_DRIVE] += (unsigned long long)(clock64() - c1);
                 if (!W.overflow && W.stage != AC_DONE) {
                     s_n = W.n_tasks; s_go = 1;
                     for (uint32_t t = 0; t < W.n_tasks; ++t) s_tasks[t] = W.tasks[t];
@@ -90,19 +113,37 @@ align_kernel(const ak_args_t A) {
                 const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
                 if (task.qlen > DP_MAX_QLEN || task.tlen > 512 || (uint32_t)(task.qlen + task.tlen + 2) > AK_CIG_CAP ||
                     (with_cigar && (uint64_t)(task.qlen + task.tlen - 1) * (uint64_t)task.tlen > AK_DIRS_CAP)) { too_big = true; break; }
-                moni_dp_result_t R;
                 uint32_t* cg = S->cig + (size_t)t * AK_CIG_CAP;
-                extz_wave_lds(A.D, task, L, S->dirs, cg, R);
-                R.cigar_off = t * AK_CIG_CAP;
-                if (lane == 0) { s_res[t] = R; ++n_dp; n_cells += (unsigned long long)(task.qlen > 0 ? task.qlen : 0) * (unsigned long long)(task.tlen > 0 ? task.tlen : 0); }
+                const unsigned long long cells = (unsigned long long)(task.qlen > 0 ? task.qlen : 0) * (unsigned long long)(task.tlen > 0 ? task.tlen : 0);
+                // memo: score-only problems on the index text (every problem of the chain-selection loop)
+                const bool memoable = !with_cigar && (task.reserved & DP_T_TEXT) && (task.reserved & DP_Q_READS) && cells > 0;
+                const uint64_t key = ((task.q_off - A.offs[r]) & 0xFFFFull) | ((uint64_t)(uint32_t)task.qlen & 0xFFFFull) << 16 |
+                                     ((uint64_t)(uint32_t)task.tlen & 0xFFFFull) << 32 | ((uint64_t)task.flag & 0xFFull) << 48 | ((uint64_t)task.reserved & 0xFFull) << 56;
+                int hit = -1;
+                if (memoable) {
+                    const uint32_t n = memo_n;
+                    for (uint32_t e = 0; e < n && hit < 0; ++e)
+                        if (memo_key[e] == key && (memo_toff[e] == task.t_off || ak_same_target(A.D, (int)task.reserved, memo_toff[e], task.t_off, task.tlen))) hit = (int)e;
+                }
+                if (hit >= 0) {
+                    if (lane == 0) { s_res[t] = S->memo_res[hit]; s_res[t].cigar_off = t * AK_CIG_CAP; s_cnt[C_MEMO]++; s_cnt[C_MEMO_CELLS] += cells; }
+                } else {
+                    extz_wave_lds(A.D, task, L, S->dirs, cg, &s_res[t]);
+                    if (lane == 0) {
+                        s_cnt[C_DP]++; s_cnt[C_CELLS] += cells;
+                        if (memoable && memo_n < AK_MEMO) { memo_key[memo_n] = key; memo_toff[memo_n] = task.t_off; S->memo_res[memo_n] = s_res[t]; ++memo_n; }
+                        s_res[t].cigar_off = t * AK_CIG_CAP;
+                    }
+                    __syncthreads();
+                }
             }
             __syncthreads();
             if (lane == 0) {
                 const long long d1 = clock64();
-                cy_dp += (unsigned long long)(d1 - d0);
+                s_cnt[C_CYDP] += (unsigned long long)(d1 - d0);
                 if (too_big) W.overflow = 1;
                 else ac_drive(W, A.P, s_res, S->cig);
-                cy_drive += (unsigned long long)(clock64() - d1);
+                s_cnt[C_DRIVE] += (unsigned long long)(clock64() - d1);
                 s_go = (!W.overflow && W.stage != AC_DONE) ? 1u : 0u;
                 s_n = W.n_tasks;
                 if (s_go) for (uint32_t t = 0; t < W.n_tasks; ++t) s_tasks[t] = W.tasks[t];
@@ -128,5 +169,8 @@ align_kernel(const ak_args_t A) {
         }
         __syncthreads();
     }
-    if (lane == 0) { atomicAdd(&A.cursors[2], n_dp); atomicAdd(&A.cursors[3], n_cells); atomicAdd(&A.cursors[5], cy_init); atomicAdd(&A.cursors[6], cy_drive); atomicAdd(&A.cursors[7], cy_dp); }
+    if (lane == 0) {
+        atomicAdd(&A.cursors[2], s_cnt[C_DP]); atomicAdd(&A.cursors[3], s_cnt[C_CELLS]); atomicAdd(&A.cursors[5], s_cnt[C_INIT]); atomicAdd(&A.cursors[6], s_cnt[C_DRIVE]);
+        atomicAdd(&A.cursors[7], s_cnt[C_CYDP]); atomicAdd(&A.cursors[8], s_cnt[C_MEMO]); atomicAdd(&A.cursors[9], s_cnt[C_MEMO_CELLS]);
+    }
 }

@@ -280,12 +280,13 @@ struct dp_lds_t {
 };
 
 __device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, const moni_dp_task_t task, dp_lds_t& L,
-                                                        uint8_t* __restrict__ dir_base, uint32_t* __restrict__ cg_base, moni_dp_result_t& R) {
+                                                        uint8_t* __restrict__ dir_base, uint32_t* __restrict__ cg_base, moni_dp_result_t* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int qlen = task.qlen, tlen = task.tlen, flag = task.flag;
+    moni_dp_result_t R;                      // lane 0 writes it to *out (LDS or global) at the end
     R.max = 0; R.max_q = R.max_t = R.mqe_t = R.mte_q = -1; R.mqe = R.mte = R.score = DP_NEG_INF;
     R.reach_end = 0; R.zdropped = 0; R.n_cigar = 0; R.cigar_off = 0;
-    if (qlen <= 0 || tlen <= 0) return;
+    if (qlen <= 0 || tlen <= 0) { if (lane == 0) *out = R; return; }
     const bool with_cigar = !(flag & DP_EZ_SCORE_ONLY);
     const bool right = (flag & DP_EZ_RIGHT) != 0;
     const int mode = task.reserved;
@@ -434,7 +435,7 @@ __device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, co
             R.n_cigar = (uint32_t)n;
         }
     }
-    R.n_cigar = (uint32_t)__shfl((int)R.n_cigar, 0);
+    if (lane == 0) *out = R;
     __syncthreads();
 }
 
@@ -444,7 +445,5 @@ extz_lds_kernel(const dp_launch_t P) {
     const uint32_t tix = P.order[blockIdx.x];
     const moni_dp_task_t task = P.tasks[tix];
     const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
-    moni_dp_result_t R;
-    extz_wave_lds(P, task, L, with_cigar ? P.dirs + P.dir_off[tix] : nullptr, with_cigar ? P.cig_tmp + P.cig_off[tix] : nullptr, R);
-    if (threadIdx.x == 0) P.results[tix] = R;
+    extz_wave_lds(P, task, L, with_cigar ? P.dirs + P.dir_off[tix] : nullptr, with_cigar ? P.cig_tmp + P.cig_off[tix] : nullptr, &P.results[tix]);
 }

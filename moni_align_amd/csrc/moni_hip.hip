@@ -105,6 +105,7 @@ struct moni_ctx {
     DBuf<moni_alt_t> ak_alt;
     DBuf<int32_t> ak_minscore;
     unsigned long long* d_ak_cursors = nullptr;
+    char* out_buf = nullptr; size_t out_cap = 0;      // moni_align_run's text buffer, kept (and kept mapped) across calls
     float ak_kernel_ms = 0;
 };
 
@@ -256,6 +257,7 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->dp_q.release(); c->dp_t.release(); c->dp_dir.release(); c->dp_tasks.release(); c->dp_res.release(); c->dp_cig.release();
     c->dp_off.release(); c->dp_ws.release(); c->ak_scratch.release(); c->ak_recs.release(); c->ak_cig.release(); c->ak_alt.release(); c->ak_minscore.release();
     if (c->d_ak_cursors) (void)hipFree(c->d_ak_cursors);
+    free(c->out_buf);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->d_counters) (void)hipFree(c->d_counters);
     for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(c->ev[i]);
@@ -575,13 +577,13 @@ static int host_align_subset(moni_ctx* c, const moni_align_params_t& prm, const 
     return mh::align_batch(be, c->idx->hix, prm, c->h_seq.data(), c->h_offs.data(), c->n_reads, names, name_off, quals, out, st);
 }
 
-static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
+static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bool ctx_out, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
                       const moni_align_params_t* prm, char** sam, uint64_t* sam_len, moni_align_stats_t* stats);
 
 int moni_align_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
                      const moni_align_params_t* prm, char** sam, uint64_t* sam_len, moni_align_stats_t* stats) {
     if (!c || !b || !prm || !sam || !sam_len || (b->n_reads && (!names || !name_off))) return MONI_EINVAL;
-    return align_core(c, b, false, names, name_off, quals, prm, sam, sam_len, stats);
+    return align_core(c, b, false, false, names, name_off, quals, prm, sam, sam_len, stats);
 }
 
 int moni_align_run(moni_ctx_t* c, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals, const moni_align_params_t* prm,
@@ -594,7 +596,7 @@ int moni_align_run(moni_ctx_t* c, const uint8_t* names, const uint64_t* name_off
     std::vector<uint64_t> ho = std::move(c->h_offs);
     const moni_read_batch_t view{hs.data(), ho.data(), c->n_reads};
     const uint64_t nr = c->n_reads, tl = c->total_len, ml = c->max_len;
-    int rc = align_core(c, &view, true, names, name_off, quals, prm, sam, sam_len, stats);
+    int rc = align_core(c, &view, true, true, names, name_off, quals, prm, sam, sam_len, stats);
     if (c->n_reads != nr || c->h_offs.size() != 0) {                     // the hand-back path replaced the resident batch: put it back
         const int rc2 = reads_upload(c, &view, false);
         if (!rc) rc = rc2;
@@ -604,7 +606,7 @@ int moni_align_run(moni_ctx_t* c, const uint8_t* names, const uint64_t* name_off
     return rc;
 }
 
-static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
+static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bool ctx_out, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
                       const moni_align_params_t* prm, char** sam, uint64_t* sam_len, moni_align_stats_t* stats) {
     moni_index* I = c->idx;
     c->dp_kernel_ms_accum = 0;
@@ -621,6 +623,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, co
         // through in sub-batches: while the GPU seeds and aligns sub-batch k+1, the host threads turn the records of
         // sub-batch k into SAM text (MD/NM, MAPQ, formatting) ----
         if (prm->w >= 0 || prm->zdrop >= 0) return MONI_EINVAL;
+        const double t_enter = mh::now_s();
+        double t_mark[4] = {0, 0, 0, 0};
         const uint64_t NR = b->n_reads;
         uint64_t sub_reads = 50000;
         if (const char* v = getenv("MONI_ALIGN_SUB")) { const long long x = atoll(v); if (x > 0) sub_reads = (uint64_t)x; }
@@ -640,6 +644,10 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, co
         std::vector<std::vector<uint32_t>> back_of(n_sub);
         std::vector<uint64_t> aligned_t(T, 0);
         double host_busy = 0;
+        // the batch's text is assembled as the sub-batches finish (inside the overlapped host stage), as long as no read
+        // has been handed back
+        char* abuf = ctx_out ? c->out_buf : nullptr; size_t acap = ctx_out ? c->out_cap : 0, alen = 0; uint64_t eager_upto = 0; bool eager_ok = true, eager_oom = false;
+        auto drop_abuf = [&]() { if (!ctx_out) free(abuf); abuf = nullptr; };
         double prof[3] = {0, 0, 0};
         uint64_t waves_used = 0;
 
@@ -652,6 +660,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, co
             if ((rc = moni_seed_run(c, &sp))) return rc;
             st.t_seed += mh::now_s() - t0;
         }
+        t_mark[0] = mh::now_s() - t_enter;
         // GPU stage of one sub-batch (blocking): align kernel over its reads, records back
         auto gpu_stage = [&](uint64_t k, SubRes& R) -> int {
             const uint64_t r0 = k * sub_reads, nr = std::min(sub_reads, NR - r0);
@@ -666,8 +675,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, co
             if ((rc2 = c->ak_scratch.ensure(n_waves)) || (rc2 = c->ak_recs.ensure(nr + 1)) || (rc2 = c->ak_cig.ensure(cig_cap)) ||
                 (rc2 = c->ak_alt.ensure(alt_cap)) || (rc2 = c->ak_minscore.ensure(msc.size())))
                 return rc2;
-            if (!c->d_ak_cursors) HIPCHK(hipMalloc((void**)&c->d_ak_cursors, 8 * sizeof(unsigned long long)));
-            HIPCHK(hipMemsetAsync(c->d_ak_cursors, 0, 8 * sizeof(unsigned long long), c->stream));
+            if (!c->d_ak_cursors) HIPCHK(hipMalloc((void**)&c->d_ak_cursors, 16 * sizeof(unsigned long long)));
+            HIPCHK(hipMemsetAsync(c->d_ak_cursors, 0, 16 * sizeof(unsigned long long), c->stream));
             HIPCHK(hipMemcpyAsync(c->ak_minscore.p, msc.data(), msc.size() * 4, hipMemcpyHostToDevice, c->stream));
             ak_args_t A;
             memset(&A, 0, sizeof A);
@@ -688,7 +697,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, co
             rec(c, EV_DP1);
             HIPCHK(hipGetLastError());
             R.recs.resize(nr);
-            unsigned long long cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned long long cur[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             HIPCHK(hipMemcpyAsync(R.recs.data(), c->ak_recs.p, nr * sizeof(moni_aln_rec_t), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipMemcpyAsync(cur, c->d_ak_cursors, sizeof cur, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
@@ -698,7 +707,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, co
             R.cig.resize(ncig + 1); R.alt.resize(nalt + 1);
             if (ncig) HIPCHK(hipMemcpy(R.cig.data(), c->ak_cig.p, ncig * 4, hipMemcpyDeviceToHost));
             if (nalt) HIPCHK(hipMemcpy(R.alt.data(), c->ak_alt.p, nalt * sizeof(moni_alt_t), hipMemcpyDeviceToHost));
-            st.dp_tasks += cur[2]; st.dp_cells += cur[3];
+            st.dp_tasks += cur[2]; st.dp_cells += cur[3]; st.dp_reused += cur[8]; st.dp_cells_reused += cur[9];
             prof[0] += (double)cur[5]; prof[1] += (double)cur[6]; prof[2] += (double)cur[7];
             st.t_dp += mh::now_s() - t0;
             return MONI_OK;
@@ -709,32 +718,38 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, co
             const uint64_t r0 = k * sub_reads, nr = R.recs.size();
             for (uint64_t r = 0; r < nr; ++r) if (R.recs[r].status == 2) back_of[k].push_back((uint32_t)(r0 + r));
             mh::parallel_for(pool, nr, [&](int t, size_t lo, size_t hi) {
-                std::string seq, qual, name, ln;
+                mh::Aligner::EmitScratch sc;
                 std::string& dst = text[k][t];
-                dst.reserve((hi - lo) * 400);
-                std::vector<uint64_t> ap; std::vector<int32_t> as;
+                dst.reserve((hi - lo) * 720);
+                static_assert(sizeof(moni_alt_t) == sizeof(mh::moni_alt_like), "alt record layout");
                 for (size_t r = lo; r < hi; ++r) {
                     const moni_aln_rec_t& Rr = R.recs[r];
                     if (Rr.status == 2) continue;                    // handed back: filled in at the end
                     const uint64_t g = r0 + r;
                     const uint64_t off = b->offsets[g]; const uint32_t m = (uint32_t)(b->offsets[g + 1] - off);
-                    mh::Sam S;
-                    if (Rr.status == 1) {
-                        ap.resize(Rr.n_alt); as.resize(Rr.n_alt);
-                        for (uint32_t x = 0; x < Rr.n_alt; ++x) { ap[x] = R.alt[Rr.alt_off + x].pos; as[x] = R.alt[Rr.alt_off + x].score; }
-                        AL.finish_record(m, off, Rr.strand, Rr.ref_pos, Rr.score, Rr.score2, R.cig.data() + Rr.cigar_off, Rr.n_cigar, ap.data(), as.data(), Rr.n_alt, S);
-                        aligned_t[t]++;
-                    } else S.flag = 4;
-                    const uint8_t* sp0 = b->seq + off;
-                    name.assign((const char*)names + name_off[g], (const char*)names + name_off[g + 1]);
-                    seq.resize(m);
-                    if (S.rev_read) for (uint32_t x = 0; x < m; ++x) seq[x] = (char)mh::compl_of(sp0[m - 1 - x]); else seq.assign((const char*)sp0, (const char*)sp0 + m);
-                    if (quals) { const uint8_t* qv = quals + off; qual.resize(m); if (S.rev_read) for (uint32_t x = 0; x < m; ++x) qual[x] = (char)qv[m - 1 - x]; else qual.assign((const char*)qv, (const char*)qv + m); }
-                    ln.clear();
-                    mh::Aligner::sam_write(ln, S, name, seq, quals ? &qual : nullptr);
-                    dst += ln;
+                    AL.emit_record(dst, sc, (const char*)names + name_off[g], (size_t)(name_off[g + 1] - name_off[g]), b->seq + off, quals ? quals + off : nullptr, m,
+                                   Rr.status == 1, Rr.strand, Rr.ref_pos, Rr.score, Rr.score2, R.cig.data() + Rr.cigar_off, Rr.n_cigar,
+                                   (const mh::moni_alt_like*)R.alt.data() + Rr.alt_off, Rr.n_alt);
+                    if (Rr.status == 1) aligned_t[t]++;
                 }
             });
+            if (eager_ok && back_of[k].empty() && !eager_oom) {
+                std::vector<size_t> at(T + 1, alen);
+                for (int t = 0; t < T; ++t) at[t + 1] = at[t] + text[k][t].size();
+                const size_t need = at[T];
+                if (need + 1 > acap) {
+                    const size_t sub_bytes = need - alen, rest = NR - (r0 + nr);
+                    size_t cap = need + (size_t)((double)sub_bytes / (double)(nr ? nr : 1) * (double)rest * 1.06) + 65536;
+                    char* nb = (char*)realloc(abuf, cap);
+                    if (!nb) eager_oom = true; else { abuf = nb; acap = cap; if (ctx_out) { c->out_buf = nb; c->out_cap = cap; } }
+                }
+                if (!eager_oom) {
+                    mh::parallel_for(pool, (size_t)T, [&](int, size_t lo, size_t hi) {
+                        for (size_t x = lo; x < hi; ++x) { std::string& piece = text[k][x]; if (!piece.empty()) memcpy(abuf + at[x], piece.data(), piece.size()); std::string().swap(piece); }
+                    });
+                    alen = need; eager_upto = k + 1;
+                }
+            } else eager_ok = false;
             host_busy += mh::now_s() - t0;
         };
         {
@@ -746,8 +761,10 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, co
                 if (rc_gpu) break;
                 worker = std::thread([&, k]() { host_stage(k, res[k & 1]); });
             }
+            t_mark[1] = mh::now_s() - t_enter;
             if (worker.joinable()) worker.join();
-            if (rc_gpu) return rc_gpu;
+            t_mark[2] = mh::now_s() - t_enter;
+            if (rc_gpu) { drop_abuf(); return rc_gpu; }
         }
         st.dp_rounds = 1;
         if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "align_kernel: %.3f ms in %llu sub-batches, %llu waves; lane-0 cycles: init %.3g drive %.3g; wave cycles in DP %.3g\n", c->dp_kernel_ms_accum, (unsigned long long)n_sub, (unsigned long long)waves_used, prof[0], prof[1], prof[2]);
@@ -768,31 +785,24 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, co
             }
             moni_read_batch_t sub{sseq.data(), soff.data(), (uint64_t)back.size()};
             std::string sout; mh::AlignStats s2;
-            if ((rc = host_align_subset(c, *prm, sub, snames.data(), snoff.data(), quals ? squal.data() : nullptr, sout, s2))) return rc;
+            if ((rc = host_align_subset(c, *prm, sub, snames.data(), snoff.data(), quals ? squal.data() : nullptr, sout, s2))) { drop_abuf(); return rc; }
             size_t p0 = 0;
             for (size_t x = 0; x < back.size(); ++x) { const size_t p1 = sout.find('\n', p0); back_line[x] = sout.substr(p0, p1 - p0 + 1); p0 = p1 + 1; }
             st.aligned += s2.aligned; st.dp_tasks += s2.dp_tasks; st.dp_cells += s2.dp_cells; st.dp_rounds += s2.dp_rounds;
             st.t_chain += s2.t_chain;     // counts the whole fallback as "chain/host" time below
         }
         st.handed_back = back.size();
-        if (back.empty()) {
-            // assemble: every piece knows its offset, copied by the pool straight into the caller's buffer
-            std::vector<size_t> at(n_sub * T + 1, 0);
-            for (uint64_t k = 0; k < n_sub; ++k) for (int t = 0; t < T; ++t) at[k * T + t + 1] = at[k * T + t] + text[k][t].size();
-            const size_t total = at[n_sub * T];
-            *sam = (char*)malloc(total + 1);
-            if (!*sam) return MONI_ENOMEM;
-            char* dst = *sam;
-            mh::parallel_for(pool, n_sub * T, [&](int, size_t lo, size_t hi) {
-                for (size_t x = lo; x < hi; ++x) { const std::string& piece = text[x / T][x % T]; if (!piece.empty()) memcpy(dst + at[x], piece.data(), piece.size()); }
-            });
-            dst[total] = 0;
-            *sam_len = total;
+        if (eager_oom) { drop_abuf(); return MONI_ENOMEM; }
+        if (back.empty() && eager_upto == n_sub && (abuf || NR == 0)) {
+            if (!abuf) { abuf = (char*)malloc(64); if (!abuf) return MONI_ENOMEM; if (ctx_out) { c->out_buf = abuf; c->out_cap = 64; } }
+            abuf[alen] = 0;
+            *sam = abuf; *sam_len = alen;
             out_done = true;
         } else {
             // rare: splice the handed-back lines in at their read positions (a thread's piece is split at those reads)
+            if (abuf) { out.assign(abuf, alen); drop_abuf(); }
             size_t bi = 0;
-            for (uint64_t k = 0; k < n_sub; ++k) {
+            for (uint64_t k = eager_upto; k < n_sub; ++k) {
                 const uint64_t r0 = k * sub_reads, nr = std::min(sub_reads, NR - r0);
                 for (int t = 0; t < T; ++t) {
                     const size_t lo = (nr < 2 || T <= 1) ? (t == 0 ? 0 : nr) : nr * t / T, hi = (nr < 2 || T <= 1) ? (t == 0 ? nr : nr) : nr * (t + 1) / T;
@@ -807,19 +817,24 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, co
             }
         }
         st.t_host += host_busy + (mh::now_s() - t0);
+        if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "align_core wall: seeded at %.1f ms, last kernel done at %.1f, last host stage done at %.1f, text ready at %.1f\n",
+                                               t_mark[0] * 1e3, t_mark[1] * 1e3, t_mark[2] * 1e3, (mh::now_s() - t_enter) * 1e3);
     }
     if (!out_done) {
-    *sam = (char*)malloc(out.size() + 1);
-    if (!*sam) return MONI_ENOMEM;
-    memcpy(*sam, out.data(), out.size());
-    (*sam)[out.size()] = 0;
-    *sam_len = out.size();
+        char* dst;
+        if (ctx_out) {
+            if (c->out_cap < out.size() + 1) { char* nb = (char*)realloc(c->out_buf, out.size() + 1); if (!nb) return MONI_ENOMEM; c->out_buf = nb; c->out_cap = out.size() + 1; }
+            dst = c->out_buf;
+        } else if (!(dst = (char*)malloc(out.size() + 1))) return MONI_ENOMEM;
+        memcpy(dst, out.data(), out.size());
+        dst[out.size()] = 0;
+        *sam = dst; *sam_len = out.size();
     }
     if (stats) {
         stats->reads = st.reads; stats->aligned = st.aligned; stats->dp_tasks = st.dp_tasks; stats->dp_cells = st.dp_cells; stats->dp_rounds = st.dp_rounds;
         stats->t_seed = st.t_seed; stats->t_chain = st.t_chain; stats->t_dp = st.t_dp; stats->t_host = st.t_host;
         stats->t_dp_kernel = c->dp_kernel_ms_accum / 1e3;
-        stats->handed_back = st.handed_back;
+        stats->handed_back = st.handed_back; stats->dp_reused = st.dp_reused; stats->dp_cells_reused = st.dp_cells_reused;
     }
     return MONI_OK;
 }

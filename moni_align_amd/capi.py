@@ -14,7 +14,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libmoni_hip.so")
+LIB_PATH = os.environ.get("MONI_HIP_LIB") or os.path.join(CSRC, "libmoni_hip.so")      # override: kernel-variant sweeps
 
 EXPORTS = [
     "moni_version", "moni_index_create", "moni_index_load", "moni_index_destroy", "moni_index_n", "moni_index_r",

@@ -70,7 +70,15 @@ struct ac_fill_t {
     uint64_t score_pos;
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AC_CLOCK() ((unsigned long long)clock64())
+#else
+#define AC_CLOCK() 0ull
+#endif
+
 struct ac_ws_t {
+    lsort::frame sort_stack[lsort::STACK_FRAMES];
+    unsigned long long prof[6];      // device only: cycles in ac_init's parts (load, sort, chain DP, backtrack) 
     // read
     uint64_t off; uint32_t m; int32_t min_score;
     // seeds after the frequency filter, anchors, chaining scratch, chains
@@ -120,6 +128,7 @@ AC_HD_BIG bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, u
     W.stage = AC_DONE; W.aligned = 0; W.overflow = 0; W.n_cigar = 0; W.n_tasks = 0;
     W.i = 0; W.n_diff = W.n_best = W.n_left = W.n_alt = 0; W.max_score = 0; W.score2 = 0; W.final_chain = 0;
     W.n_mems = W.n_anch = W.n_chains = W.pool_used = 0;
+    unsigned long long pc0 = AC_CLOCK();
     size_t total = 0;
     for (uint64_t k = a; k < b; ++k) total += gm[k].occ_cnt;
     for (uint64_t k = a; k < b; ++k) {
@@ -136,7 +145,9 @@ AC_HD_BIG bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, u
     for (uint32_t i = 0; i < W.n_mems; ++i)
         for (uint32_t j = 0; j < W.mems[i].nocc; ++j) { ac_anchor_t& A = W.anch[W.n_anch++]; A.mem = i; A.occ = j; A.x = W.mems[i].occs[j] + W.mems[i].len - 1; }
     const float avg_mem_length = (float)tot_mem_length / na;
-    lsort::sort(W.anch, (long)na, [](const ac_anchor_t& x, const ac_anchor_t& y) { return x.x < y.x; });
+    { const unsigned long long x = AC_CLOCK(); W.prof[0] += x - pc0; pc0 = x; }
+    lsort::sort(W.anch, (long)na, [](const ac_anchor_t& x, const ac_anchor_t& y) { return x.x < y.x; }, W.sort_stack);
+    { const unsigned long long x = AC_CLOCK(); W.prof[1] += x - pc0; pc0 = x; }
     for (size_t i = 0; i < na; ++i) W.t[i] = 0;               // std::vector<ll> t(n, 0)
     long long lb = 0;
     for (size_t i = 0; i < na; ++i) {
@@ -173,6 +184,7 @@ AC_HD_BIG bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, u
         W.f[i] = (int32_t)max_f; W.p[i] = (int32_t)max_j;
         W.msc[i] = (max_j >= 0 && W.msc[max_j] > max_f) ? W.msc[max_j] : (int32_t)max_f;
     }
+    { const unsigned long long x = AC_CLOCK(); W.prof[2] += x - pc0; pc0 = x; }
     for (size_t i = 0; i < na; ++i) W.t[i] = 0;
     for (size_t i = 0; i < na; ++i) if (W.p[i] >= 0) W.t[W.p[i]] = 1;
     uint32_t ns = 0;
@@ -185,7 +197,7 @@ AC_HD_BIG bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, u
         }
     }
     if (ns == 0) return false;
-    lsort::sort(W.starts, (long)ns, [](const ac_start_t& x, const ac_start_t& y) { return x.f > y.f || (x.f == y.f && x.j > y.j); });   // std::greater<pair>
+    lsort::sort(W.starts, (long)ns, [](const ac_start_t& x, const ac_start_t& y) { return x.f > y.f || (x.f == y.f && x.j > y.j); }, W.sort_stack);   // std::greater<pair>
     for (size_t i = 0; i < na; ++i) W.t[i] = 0;
     for (uint32_t i = 0; i < ns; ++i) {
         long long j = (long long)W.starts[i].j;
@@ -203,8 +215,9 @@ AC_HD_BIG bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, u
         else if (W.starts[i].f - W.f[j] >= P.min_chain_score) keep = (long long)c.cnt >= P.min_chain_length;
         if (keep) W.chains[W.n_chains++] = c;            // (a dropped chain leaves its anchors in the pool; harmless)
     }
-    lsort::sort(W.chains, (long)W.n_chains, [](const ac_chain_t& x, const ac_chain_t& y) { return x.score > y.score; });
+    lsort::sort(W.chains, (long)W.n_chains, [](const ac_chain_t& x, const ac_chain_t& y) { return x.score > y.score; }, W.sort_stack);
     for (uint32_t i = 0; i < W.n_chains; ++i) W.score_cache[i] = INT32_MIN;
+    { const unsigned long long x = AC_CLOCK(); W.prof[3] += x - pc0; pc0 = x; }
     W.stage = AC_LOOP;
     return true;
 }
@@ -423,7 +436,7 @@ AC_HD_BIG bool ac_advance(ac_ws_t& W, const ac_params_t& P) {
         while (W.n_best < 2) { W.best[W.n_best].score = 0; W.best[W.n_best].lft = 0; W.best[W.n_best].idx = W.n_chains; ++W.n_best; }
         lsort::sort(W.best, (long)W.n_best, [](const ac_best_t& x, const ac_best_t& y) {
             return x.score > y.score || (x.score == y.score && (x.lft > y.lft || (x.lft == y.lft && x.idx > y.idx)));        // std::greater<tuple>
-        });
+        }, W.sort_stack);
         if (W.best[0].score < W.min_score) { W.stage = AC_DONE; return false; }
         W.score2 = W.best[1].score;
         W.final_chain = W.best[0].idx;

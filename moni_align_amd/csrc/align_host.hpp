@@ -307,9 +307,11 @@ struct Aligner {
     const uint8_t* reads;            // host copy of the resident batch
     const uint64_t* offs;
     int32_t mapq_coeff_fac;
+    size_t max_name_len = 1;
 
     Aligner(const HostIndex& ix_, const moni_align_params_t& p, const uint8_t* r, const uint64_t* o) : ix(ix_), P(p), reads(r), offs(o) {
         mapq_coeff_fac = (int32_t)log(50.0f);        // aligner_ksw2.hpp:3250-3251
+        for (const auto& nm : ix.names) max_name_len = std::max(max_name_len, nm.size());
     }
 
     uint64_t occ_of(const ReadState& R, const std::pair<uint32_t, uint32_t>& a) const { return R.mems[a.first].occs[a.second]; }
@@ -613,32 +615,51 @@ struct Aligner {
 
     // finish_record + sam_write in one pass straight into the output text, no per-read containers: what the host stage
     // of the align-kernel path runs per read (same bytes as the two functions above and below produce; sam.hpp:144-188,249-287).
-    struct EmitScratch { std::string cs, md; };
-    static inline void put_int(std::string& o, int v) {
+    struct OutBuf {                    // grow-only text buffer (kept by the caller across batches: its pages stay mapped)
+        char* base = nullptr; size_t len = 0, cap = 0;
+        bool ensure(size_t extra) {
+            if (len + extra <= cap) return true;
+            size_t nc = cap ? cap + cap / 2 : (size_t)1 << 20;
+            while (nc < len + extra) nc += nc / 2;
+            char* nb = (char*)realloc(base, nc);
+            if (!nb) return false;
+            base = nb; cap = nc; return true;
+        }
+        void release() { free(base); base = nullptr; len = cap = 0; }
+    };
+    static inline char* put_int(char* p, int v) {
         char b[12]; int n = 0; unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
         do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
-        if (v < 0) o.push_back('-');
-        while (n) o.push_back(b[--n]);
+        if (v < 0) *p++ = '-';
+        while (n) *p++ = b[--n];
+        return p;
     }
-    void emit_record(std::string& out, EmitScratch& sc, const char* name, size_t name_len, const uint8_t* rd, const uint8_t* ql, uint32_t m,
+#define PUT_LIT(p, lit) put_str(p, lit, sizeof(lit) - 1)
+    static inline char* put_str(char* p, const char* s, size_t n) { memcpy(p, s, n); return p + n; }
+    static inline char* put_str(char* p, const std::string& s) { memcpy(p, s.data(), s.size()); return p + s.size(); }
+    // upper bound of one record's text
+    size_t record_bound(size_t name_len, uint32_t m, uint32_t n_cig, uint32_t n_alt) const {
+        return name_len + 2 * (size_t)m + 22 * (size_t)n_cig + 4 * (size_t)m + 64 * (size_t)n_cig + (size_t)n_alt * (max_name_len + 26) + 2 * max_name_len + 256;
+    }
+    bool emit_record(OutBuf& ob, std::vector<char>& md_scratch, const char* name, size_t name_len, const uint8_t* rd, const uint8_t* ql, uint32_t m,
                      bool aligned, uint32_t strand, uint64_t ref_pos, int32_t score, int32_t score2, const uint32_t* cig, uint32_t n_cig,
                      const moni_alt_like* alts, uint32_t n_alt) const {
-        out.append(name, name_len);
+        uint64_t ref_len = 0, del_len = 0;
+        for (uint32_t k = 0; k < n_cig; ++k) { const uint32_t c = cig[k]; const int op = c & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4; if (op == 2) del_len += c >> 4; }
+        if (!ob.ensure(record_bound(name_len, m, n_cig, n_alt) + 2 * del_len)) return false;
+        char* p = ob.base + ob.len;
+        p = put_str(p, name, name_len);
         if (!aligned) {
-            out += "\t4\t*\t0\t255\t*\t*\t0\t0\t";
-            out.append((const char*)rd, m); out.push_back('\t');
-            if (ql) out.append((const char*)ql, m); else out.push_back('*');
-            out.push_back('\n');
-            return;
+            p = PUT_LIT(p, "\t4\t*\t0\t255\t*\t*\t0\t0\t");
+            p = put_str(p, (const char*)rd, m); *p++ = '\t';
+            if (ql) p = put_str(p, (const char*)ql, m); else *p++ = '*';
+            *p++ = '\n';
+            ob.len = (size_t)(p - ob.base);
+            return true;
         }
-        uint64_t ref_len = 0;
-        sc.cs.clear(); sc.md.clear();
-        for (uint32_t k = 0; k < n_cig; ++k) {
-            const uint32_t c = cig[k]; const int op = c & 0xf;
-            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
-            put_int(sc.cs, (int)(c >> 4)); sc.cs.push_back("MID"[op]);
-        }
-        // MD / NM over the window the CIGAR spans (write_MD_core)
+        // MD / NM over the window the CIGAR spans (write_MD_core); NM is printed before MD, so MD goes through a scratch
+        { const size_t need = 3 * (size_t)m + 2 * del_len + 40 * (size_t)n_cig + 64; if (md_scratch.size() < need) md_scratch.resize(need); }
+        char* const md0 = md_scratch.data(); char* md = md0;
         int NM = 0;
         {
             int l_MD = 0; uint64_t t = ref_pos; uint32_t q = 0;
@@ -649,46 +670,52 @@ struct Aligner {
                 if (op == 0 || op == 7 || op == 8) {
                     for (int j = 0; j < len; ++j) {
                         const uint8_t tc = tb(t + j);
-                        if (qb(q + j) != tc) { put_int(sc.md, l_MD); sc.md.push_back("ACGTN"[tc]); l_MD = 0; ++NM; }
+                        if (qb(q + j) != tc) { md = put_int(md, l_MD); *md++ = "ACGTN"[tc]; l_MD = 0; ++NM; }
                         else ++l_MD;
                     }
                     q += len; t += len;
                 } else if (op == 1) { q += len; NM += len; }
                 else if (op == 2) {
-                    put_int(sc.md, l_MD); sc.md.push_back('^');
-                    for (int j = 0; j < len; ++j) sc.md.push_back("ACGTN"[tb(t + j)]);
+                    md = put_int(md, l_MD); *md++ = '^';
+                    for (int j = 0; j < len; ++j) *md++ = "ACGTN"[tb(t + j)];
                     l_MD = 0; t += len; NM += len;
                 } else if (op == 3) t += len;
             }
-            if (l_MD > 0) put_int(sc.md, l_MD);
+            if (l_MD > 0) md = put_int(md, l_MD);
         }
+        const size_t md_len = (size_t)(md - md0);
+        char* const cs0 = md;                         // CIGAR text behind the MD text in the scratch (printed twice: column 6 and OA)
+        for (uint32_t k = 0; k < n_cig; ++k) { md = put_int(md, (int)(cig[k] >> 4)); *md++ = "MID"[cig[k] & 0xf]; }
+        const size_t cs_len = (size_t)(md - cs0);
         const auto refi = ix.index(ref_pos);
         const std::string& lift_rname = ix.names[refi.first];
         const int lift_pos = (int)(refi.second + 1);
         const bool mapped = ref_len > 0;              // else: pos 0, rname/cigar "*", no MD, NM 0, tags still printed (unmapped_lft)
         const int flag = strand ? 16 : 0;
         const int mapq = (int)mapq_se_bwa(score, score2, (int32_t)(mapped ? ref_len : 0), (int32_t)m, (int32_t)P.min_len, P.smatch, P.smismatch, 50.0, mapq_coeff_fac);
-        out.push_back('\t'); put_int(out, flag); out.push_back('\t');
-        if (mapped) out += lift_rname; else out.push_back('*');
-        out.push_back('\t'); put_int(out, mapped ? lift_pos : 0); out.push_back('\t'); put_int(out, mapq); out.push_back('\t');
-        if (mapped) out += sc.cs; else out.push_back('*');
-        out += "\t*\t0\t0\t";
-        if (strand) { const size_t at = out.size(); out.resize(at + m); for (uint32_t k = 0; k < m; ++k) out[at + k] = (char)compl_of(rd[m - 1 - k]); }
-        else out.append((const char*)rd, m);
-        out.push_back('\t');
-        if (ql) { if (strand) { const size_t at = out.size(); out.resize(at + m); for (uint32_t k = 0; k < m; ++k) out[at + k] = (char)ql[m - 1 - k]; } else out.append((const char*)ql, m); }
-        else out.push_back('*');
-        out += "\tAS:i:"; put_int(out, score); out += "\tNM:i:"; put_int(out, mapped ? NM : 0);
-        if (score2 != 0) { out += "\tZS:i:"; put_int(out, score2); }
-        out += "\tMD:Z:"; if (mapped) out += sc.md;
-        out += "\tOA:Z:"; out += lift_rname; out.push_back(','); put_int(out, lift_pos);
-        out += strand ? ",-," : ",+,"; out += sc.cs; out.push_back(','); put_int(out, mapq); out.push_back(','); put_int(out, NM); out.push_back(';');
-        out += "\tAA:Z:";
+        *p++ = '\t'; p = put_int(p, flag); *p++ = '\t';
+        if (mapped) p = put_str(p, lift_rname); else *p++ = '*';
+        *p++ = '\t'; p = put_int(p, mapped ? lift_pos : 0); *p++ = '\t'; p = put_int(p, mapq); *p++ = '\t';
+        if (mapped) p = put_str(p, cs0, cs_len); else *p++ = '*';
+        p = PUT_LIT(p, "\t*\t0\t0\t");
+        if (strand) { for (uint32_t k = 0; k < m; ++k) p[k] = (char)compl_of(rd[m - 1 - k]); p += m; }
+        else p = put_str(p, (const char*)rd, m);
+        *p++ = '\t';
+        if (ql) { if (strand) { for (uint32_t k = 0; k < m; ++k) p[k] = (char)ql[m - 1 - k]; p += m; } else p = put_str(p, (const char*)ql, m); }
+        else *p++ = '*';
+        p = PUT_LIT(p, "\tAS:i:"); p = put_int(p, score); p = PUT_LIT(p, "\tNM:i:"); p = put_int(p, mapped ? NM : 0);
+        if (score2 != 0) { p = PUT_LIT(p, "\tZS:i:"); p = put_int(p, score2); }
+        p = PUT_LIT(p, "\tMD:Z:"); if (mapped) p = put_str(p, md0, md_len);
+        p = PUT_LIT(p, "\tOA:Z:"); p = put_str(p, lift_rname); *p++ = ','; p = put_int(p, lift_pos);
+        p = put_str(p, strand ? ",-," : ",+,", 3); p = put_str(p, cs0, cs_len); *p++ = ','; p = put_int(p, mapq); *p++ = ','; p = put_int(p, NM); *p++ = ';';
+        p = PUT_LIT(p, "\tAA:Z:");
         for (uint32_t k = 0; k < n_alt; ++k) {
             const auto r = ix.index(alts[k].pos);
-            out += ix.names[r.first]; out.push_back(','); put_int(out, (int)(r.second + 1)); out.push_back(','); put_int(out, alts[k].score); out.push_back(';');
+            p = put_str(p, ix.names[r.first]); *p++ = ','; p = put_int(p, (int)(r.second + 1)); *p++ = ','; p = put_int(p, alts[k].score); *p++ = ';';
         }
-        out.push_back('\n');
+        *p++ = '\n';
+        ob.len = (size_t)(p - ob.base);
+        return true;
     }
 
     static void sam_write(std::string& out, const Sam& s, const std::string& name, const std::string& seq, const std::string* qual) {   // sam.hpp:144-188

@@ -24,12 +24,22 @@ struct moni_aln_rec_t {                      // one per read
 };
 struct moni_alt_t { uint64_t pos; int32_t score; int32_t pad; };
 
-struct ak_scratch_t {                        // per persistent wave, in HBM
+#ifndef AK_NL
+#define AK_NL 16                             // reads in flight per wavefront: lanes 0..AK_NL-1 each run one read's state machine
+#endif
+#ifndef AK_START_MIN
+#define AK_START_MIN (AK_NL / 2)             // free lanes take new reads together, once this many are free (or nobody waits for DP):
+#endif                                       // seeds -> chains is the long lane-private part, it has to run on many lanes at once
+
+struct ak_slot_t {                           // per read in flight, in HBM
     ac_ws_t ws;
+    moni_dp_result_t res[AC_MAX_TASKS];      // results of the round's DP problems
     uint32_t cig[AC_MAX_TASKS * AK_CIG_CAP];
-    uint8_t dirs[AK_DIRS_CAP];
+    uint64_t memo_key[AK_MEMO], memo_toff[AK_MEMO];
     moni_dp_result_t memo_res[AK_MEMO];
+    uint32_t memo_n, pad;
 };
+struct ak_wave_t { uint8_t dirs[AK_DIRS_CAP]; };      // per wavefront: direction bytes of the CIGAR problem being solved
 
 // Two DP problems of one read with the same query segment, flags and target length have the same result when their target
 // windows spell the same nt4 string - the usual case when a read's chains lie on haplotypes that agree around the read.
@@ -56,119 +66,133 @@ struct ak_args_t {
     const int32_t* min_score_of_len;         // 20 + 8*log(l), computed on the host (libm) per read length
     uint32_t max_len;
     uint64_t read_lo, n_reads;               // this launch takes reads [read_lo, read_lo + n_reads) of the resident batch
-    ak_scratch_t* scratch;
+    ak_slot_t* slots;                        // gridDim.x * AK_NL
+    ak_wave_t* waves;                        // gridDim.x
     moni_aln_rec_t* recs;
     uint32_t* cig_pool; uint64_t cig_cap;
     moni_alt_t* alt_pool; uint64_t alt_cap;
-    unsigned long long* cursors;             // [0] cigar pool, [1] alt pool, [2] DP problems run, [3] their cells, [4] next read, [5..7] cycles: init, drive, dp,
-                                             // [8] DP problems answered from the per-read memo, [9] their cells
+    unsigned long long* cursors;             // [0] cigar pool, [1] alt pool, [2] DP problems run, [3] their cells, [4] next read, [5..7] wave cycles: serial
+                                             // phases (init+first drive, later drives), dp, [8] DP problems answered from the per-read memo, [9] their cells
 };
+
+// the record of a finished read (lane-private)
+__device__ __attribute__((noinline)) void ak_write_record(const ak_args_t& A, const ac_ws_t& W, uint64_t slot_in_launch) {
+    moni_aln_rec_t rec;
+    rec.status = W.overflow ? 2u : (W.aligned ? 1u : 0u);
+    rec.strand = W.fill.strand; rec.ref_pos = W.fill.ref_pos; rec.score = W.fill.score; rec.score2 = W.score2;
+    rec.n_cigar = 0; rec.n_alt = 0; rec.cigar_off = 0; rec.alt_off = 0;
+    if (rec.status == 1) {
+        const unsigned long long co = atomicAdd(&A.cursors[0], (unsigned long long)W.n_cigar);
+        const unsigned long long ao = atomicAdd(&A.cursors[1], (unsigned long long)W.n_alt);
+        if (co + W.n_cigar > A.cig_cap || ao + W.n_alt > A.alt_cap) rec.status = 2;      // pool too small: let the host pipeline redo the read
+        else {
+            rec.n_cigar = W.n_cigar; rec.cigar_off = co; rec.n_alt = W.n_alt; rec.alt_off = ao;
+            for (uint32_t k = 0; k < W.n_cigar; ++k) A.cig_pool[co + k] = W.cigar[k];
+            for (uint32_t k = 0; k < W.n_alt; ++k) { moni_alt_t x; x.pos = W.alt_pos[k]; x.score = W.alt_score[k]; x.pad = 0; A.alt_pool[ao + k] = x; }
+        }
+    }
+    A.recs[slot_in_launch] = rec;
+}
 
 extern "C" __global__ void __launch_bounds__(64)
 align_kernel(const ak_args_t A) {
     __shared__ dp_lds_t L;
     __shared__ moni_dp_task_t s_tasks[AC_MAX_TASKS];
-    __shared__ moni_dp_result_t s_res[AC_MAX_TASKS];
-    __shared__ uint32_t s_n, s_go;
-    __shared__ uint64_t memo_key[AK_MEMO], memo_toff[AK_MEMO];
-    __shared__ uint32_t memo_n;
-    const int lane = threadIdx.x;
-    ak_scratch_t* __restrict__ S = A.scratch + blockIdx.x;
-    ac_ws_t& W = S->ws;
-    __shared__ unsigned long long s_cnt[8];       // lane 0's statistics: DP problems run, cells, memo hits, their cells, cycles in init / drive / dp
+    __shared__ unsigned long long s_cnt[8];       // statistics: DP problems run, cells, memo hits, their cells, wave cycles in the phases
     enum { C_DP = 0, C_CELLS, C_MEMO, C_MEMO_CELLS, C_INIT, C_DRIVE, C_CYDP };
-    if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+    const int lane = threadIdx.x;
+    if (lane < 8) s_cnt[lane] = 0;
     __syncthreads();
-    __shared__ unsigned long long s_read;
+    ak_slot_t* __restrict__ S = A.slots + (size_t)blockIdx.x * AK_NL + (lane < AK_NL ? lane : 0);
+    ac_ws_t& W = S->ws;
+    uint8_t* __restrict__ dirs = A.waves[blockIdx.x].dirs;
+    if (lane < AK_NL) for (int k = 0; k < 6; ++k) W.prof[k] = 0;
+    int state = lane < AK_NL ? 0 : 2;             // 0: wants a read, 1: waits for DP results, 2: no more reads
+    uint64_t r_in = 0;                            // read index inside the launch
     while (true) {
-        // dynamic read queue: reads differ a lot in the number of chains they score
-        if (lane == 0) s_read = atomicAdd(&A.cursors[4], 1ull);
-        __syncthreads();
-        if (s_read >= A.n_reads) break;
-        const uint64_t r = A.read_lo + s_read;
-        if (lane == 0) {
-            const long long c0 = clock64();
-            W.off = A.offs[r]; W.m = (uint32_t)(A.offs[r + 1] - A.offs[r]);
-            W.min_score = A.min_score_of_len[W.m <= A.max_len ? W.m : A.max_len];
-            s_n = 0; s_go = 0; memo_n = 0;
-            const bool chained = ac_init(W, A.P, A.mems, A.read_mem_off[r], A.read_mem_off[r + 1], A.occs);
-            const long long c1 = clock64();
-            s_cnt[C_INIT] += (unsigned long long)(c1 - c0);
-            if (chained) {
-                ac_drive(W, A.P, nullptr, nullptr);
-                s_cnt[C_DRIVE] += (unsigned long long)(clock64() - c1);
-                if (!W.overflow && W.stage != AC_DONE) {
-                    s_n = W.n_tasks; s_go = 1;
-                    for (uint32_t t = 0; t < W.n_tasks; ++t) s_tasks[t] = W.tasks[t];
-                }
+        // ---- phase 1 (lane-private): take a read; seeds -> chains -> first DP request ----
+        const long long c0 = clock64();
+        const bool start = __popcll(__ballot(state == 0)) >= AK_START_MIN || __ballot(state == 1) == 0ull;
+        if (state == 0 && start) {
+            r_in = atomicAdd(&A.cursors[4], 1ull);
+            if (r_in >= A.n_reads) state = 2;
+            else {
+                const uint64_t r = A.read_lo + r_in;
+                W.off = A.offs[r]; W.m = (uint32_t)(A.offs[r + 1] - A.offs[r]);
+                W.min_score = A.min_score_of_len[W.m <= A.max_len ? W.m : A.max_len];
+                S->memo_n = 0;
+                const bool chained = ac_init(W, A.P, A.mems, A.read_mem_off[r], A.read_mem_off[r + 1], A.occs);
+                if (chained) ac_drive(W, A.P, nullptr, nullptr);
+                if (chained && !W.overflow && W.stage != AC_DONE) state = 1;
+                else ak_write_record(A, W, r_in);
             }
         }
-        __syncthreads();
-        while (s_go) {
-            const uint32_t nt = s_n;
+        const unsigned long long waiting = __ballot(state == 1);
+        const long long c1 = clock64();
+        if (lane == 0) s_cnt[C_INIT] += (unsigned long long)(c1 - c0);
+        if (waiting == 0ull) { if (__ballot(state == 0) == 0ull) break; continue; }
+        __threadfence();
+        // ---- phase 2 (whole wave): the DP problems of every waiting read, one read after the other ----
+        for (unsigned long long todo = waiting; todo; todo &= todo - 1) {
+            const int src = __ffsll((long long)todo) - 1;
+            ak_slot_t* __restrict__ Q = A.slots + (size_t)blockIdx.x * AK_NL + src;
+            const uint32_t nt = Q->ws.n_tasks;
+            const uint64_t read_off = Q->ws.off;
+            __syncthreads();
+            for (uint32_t k = lane; k < nt * (uint32_t)(sizeof(moni_dp_task_t) / 4); k += 64) ((uint32_t*)s_tasks)[k] = ((const uint32_t*)Q->ws.tasks)[k];
+            uint32_t memo_n = Q->memo_n;
+            uint64_t mk = (uint32_t)lane < memo_n ? Q->memo_key[lane] : ~0ull;      // lane e holds memo entry e
+            uint64_t mt = (uint32_t)lane < memo_n ? Q->memo_toff[lane] : 0ull;
+            __syncthreads();
             bool too_big = false;
-            const long long d0 = clock64();
             for (uint32_t t = 0; t < nt; ++t) {
                 const moni_dp_task_t task = s_tasks[t];
                 const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
                 if (task.qlen > DP_MAX_QLEN || task.tlen > 512 || (uint32_t)(task.qlen + task.tlen + 2) > AK_CIG_CAP ||
                     (with_cigar && (uint64_t)(task.qlen + task.tlen - 1) * (uint64_t)task.tlen > AK_DIRS_CAP)) { too_big = true; break; }
-                uint32_t* cg = S->cig + (size_t)t * AK_CIG_CAP;
+                uint32_t* cg = Q->cig + (size_t)t * AK_CIG_CAP;
                 const unsigned long long cells = (unsigned long long)(task.qlen > 0 ? task.qlen : 0) * (unsigned long long)(task.tlen > 0 ? task.tlen : 0);
                 // memo: score-only problems on the index text (every problem of the chain-selection loop)
                 const bool memoable = !with_cigar && (task.reserved & DP_T_TEXT) && (task.reserved & DP_Q_READS) && cells > 0;
-                const uint64_t key = ((task.q_off - A.offs[r]) & 0xFFFFull) | ((uint64_t)(uint32_t)task.qlen & 0xFFFFull) << 16 |
+                const uint64_t key = ((task.q_off - read_off) & 0xFFFFull) | ((uint64_t)(uint32_t)task.qlen & 0xFFFFull) << 16 |
                                      ((uint64_t)(uint32_t)task.tlen & 0xFFFFull) << 32 | ((uint64_t)task.flag & 0xFFull) << 48 | ((uint64_t)task.reserved & 0xFFull) << 56;
                 int hit = -1;
                 if (memoable) {
-                    const uint32_t n = memo_n;
-                    for (uint32_t e = 0; e < n && hit < 0; ++e)
-                        if (memo_key[e] == key && (memo_toff[e] == task.t_off || ak_same_target(A.D, (int)task.reserved, memo_toff[e], task.t_off, task.tlen))) hit = (int)e;
+                    for (unsigned long long cand = __ballot(mk == key); cand && hit < 0; cand &= cand - 1) {
+                        const int e = __ffsll((long long)cand) - 1;
+                        const uint64_t toff_e = ((uint64_t)(uint32_t)__shfl((int)(mt >> 32), e) << 32) | (uint64_t)(uint32_t)__shfl((int)(mt & 0xFFFFFFFFull), e);
+                        if (toff_e == task.t_off || ak_same_target(A.D, (int)task.reserved, toff_e, task.t_off, task.tlen)) hit = e;
+                    }
                 }
                 if (hit >= 0) {
-                    if (lane == 0) { s_res[t] = S->memo_res[hit]; s_res[t].cigar_off = t * AK_CIG_CAP; s_cnt[C_MEMO]++; s_cnt[C_MEMO_CELLS] += cells; }
+                    if (lane == 0) { moni_dp_result_t x = Q->memo_res[hit]; x.cigar_off = t * AK_CIG_CAP; Q->res[t] = x; s_cnt[C_MEMO]++; s_cnt[C_MEMO_CELLS] += cells; }
                 } else {
-                    extz_wave_lds(A.D, task, L, S->dirs, cg, &s_res[t]);
+                    extz_wave_lds(A.D, task, L, dirs, cg, &Q->res[t]);
                     if (lane == 0) {
                         s_cnt[C_DP]++; s_cnt[C_CELLS] += cells;
-                        if (memoable && memo_n < AK_MEMO) { memo_key[memo_n] = key; memo_toff[memo_n] = task.t_off; S->memo_res[memo_n] = s_res[t]; ++memo_n; }
-                        s_res[t].cigar_off = t * AK_CIG_CAP;
+                        moni_dp_result_t x = Q->res[t];
+                        if (memoable && memo_n < AK_MEMO) { Q->memo_key[memo_n] = key; Q->memo_toff[memo_n] = task.t_off; Q->memo_res[memo_n] = x; }
+                        x.cigar_off = t * AK_CIG_CAP; Q->res[t] = x;
                     }
+                    if (memoable && memo_n < AK_MEMO) { if ((uint32_t)lane == memo_n) { mk = key; mt = task.t_off; } ++memo_n; }
                     __syncthreads();
                 }
             }
-            __syncthreads();
-            if (lane == 0) {
-                const long long d1 = clock64();
-                s_cnt[C_CYDP] += (unsigned long long)(d1 - d0);
-                if (too_big) W.overflow = 1;
-                else ac_drive(W, A.P, s_res, S->cig);
-                s_cnt[C_DRIVE] += (unsigned long long)(clock64() - d1);
-                s_go = (!W.overflow && W.stage != AC_DONE) ? 1u : 0u;
-                s_n = W.n_tasks;
-                if (s_go) for (uint32_t t = 0; t < W.n_tasks; ++t) s_tasks[t] = W.tasks[t];
-            }
-            __syncthreads();
+            if (lane == 0) { Q->memo_n = memo_n; if (too_big) Q->ws.overflow = 1; }
         }
-        if (lane == 0) {
-            moni_aln_rec_t rec;
-            rec.status = W.overflow ? 2u : (W.aligned ? 1u : 0u);
-            rec.strand = W.fill.strand; rec.ref_pos = W.fill.ref_pos; rec.score = W.fill.score; rec.score2 = W.score2;
-            rec.n_cigar = 0; rec.n_alt = 0; rec.cigar_off = 0; rec.alt_off = 0;
-            if (rec.status == 1) {
-                const unsigned long long co = atomicAdd(&A.cursors[0], (unsigned long long)W.n_cigar);
-                const unsigned long long ao = atomicAdd(&A.cursors[1], (unsigned long long)W.n_alt);
-                if (co + W.n_cigar > A.cig_cap || ao + W.n_alt > A.alt_cap) rec.status = 2;      // pool too small: let the host pipeline redo the read
-                else {
-                    rec.n_cigar = W.n_cigar; rec.cigar_off = co; rec.n_alt = W.n_alt; rec.alt_off = ao;
-                    for (uint32_t k = 0; k < W.n_cigar; ++k) A.cig_pool[co + k] = W.cigar[k];
-                    for (uint32_t k = 0; k < W.n_alt; ++k) { moni_alt_t x; x.pos = W.alt_pos[k]; x.score = W.alt_score[k]; x.pad = 0; A.alt_pool[ao + k] = x; }
-                }
-            }
-            A.recs[r - A.read_lo] = rec;
-        }
+        __threadfence();
         __syncthreads();
+        const long long c2 = clock64();
+        if (lane == 0) s_cnt[C_CYDP] += (unsigned long long)(c2 - c1);
+        // ---- phase 3 (lane-private): results -> next DP request, or the finished record ----
+        if (state == 1) {
+            if (!W.overflow) ac_drive(W, A.P, S->res, S->cig);
+            if (W.overflow || W.stage == AC_DONE) { ak_write_record(A, W, r_in); state = 0; }
+        }
+        if (lane == 0) s_cnt[C_DRIVE] += (unsigned long long)(clock64() - c2);
     }
+    __syncthreads();
+    if (lane < AK_NL) for (int k = 0; k < 4; ++k) atomicAdd(&A.cursors[10 + k], W.prof[k]);
     if (lane == 0) {
         atomicAdd(&A.cursors[2], s_cnt[C_DP]); atomicAdd(&A.cursors[3], s_cnt[C_CELLS]); atomicAdd(&A.cursors[5], s_cnt[C_INIT]); atomicAdd(&A.cursors[6], s_cnt[C_DRIVE]);
         atomicAdd(&A.cursors[7], s_cnt[C_CYDP]); atomicAdd(&A.cursors[8], s_cnt[C_MEMO]); atomicAdd(&A.cursors[9], s_cnt[C_MEMO_CELLS]);

@@ -62,6 +62,20 @@ struct DBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+template <class Tp>
+struct HBuf {                  // pinned host buffer, grow-only
+    Tp* p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return MONI_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = n + n / 4;
+        if (hipHostMalloc((void**)&p, want * sizeof(Tp), hipHostMallocDefault) != hipSuccess) { p = nullptr; return MONI_ENOMEM; }
+        cap = want; return MONI_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct moni_ctx {
     moni_index* idx = nullptr;
     hipStream_t stream = nullptr;
@@ -99,7 +113,15 @@ struct moni_ctx {
     DBuf<uint64_t> dp_off;
     DBuf<uint32_t> dp_ws;
     // align kernel
-    DBuf<ak_scratch_t> ak_scratch;
+    DBuf<ak_slot_t> ak_slots;
+    DBuf<ak_wave_t> ak_waves;
+    DBuf<unsigned long long> ak_cursors;
+    uint64_t ak_waves_full = 0;
+    hipStream_t ak_stream[2] = {nullptr, nullptr}, copy_stream = nullptr;
+    std::vector<hipEvent_t> ak_begin, ak_done;
+    HBuf<moni_aln_rec_t> h_recs; HBuf<uint32_t> h_cig; HBuf<moni_alt_t> h_alt;      // pinned staging of one sub-batch's records
+    std::vector<mh::Aligner::OutBuf> pieces;          // per host thread: the text it is writing (kept across batches)
+    std::vector<std::vector<char>> md_scratch;
     DBuf<moni_aln_rec_t> ak_recs;
     DBuf<uint32_t> ak_cig;
     DBuf<moni_alt_t> ak_alt;
@@ -255,7 +277,13 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
     c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
     c->dp_q.release(); c->dp_t.release(); c->dp_dir.release(); c->dp_tasks.release(); c->dp_res.release(); c->dp_cig.release();
-    c->dp_off.release(); c->dp_ws.release(); c->ak_scratch.release(); c->ak_recs.release(); c->ak_cig.release(); c->ak_alt.release(); c->ak_minscore.release();
+    c->dp_off.release(); c->dp_ws.release(); c->ak_slots.release(); c->ak_waves.release(); c->ak_cursors.release(); c->h_recs.release(); c->h_cig.release(); c->h_alt.release();
+    for (auto& ob : c->pieces) ob.release();
+    for (int x = 0; x < 2; ++x) if (c->ak_stream[x]) (void)hipStreamDestroy(c->ak_stream[x]);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (auto e : c->ak_begin) (void)hipEventDestroy(e);
+    for (auto e : c->ak_done) (void)hipEventDestroy(e);
+    c->ak_recs.release(); c->ak_cig.release(); c->ak_alt.release(); c->ak_minscore.release();
     if (c->d_ak_cursors) (void)hipFree(c->d_ak_cursors);
     free(c->out_buf);
     if (c->d_small) (void)hipFree(c->d_small);
@@ -619,28 +647,32 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
     if (host_only) {
         if ((rc = host_align_subset(c, *prm, *b, names, name_off, q, out, st))) return rc;
     } else {
-        // ---- seeds stay in HBM; one kernel takes every read from seeds to a finished alignment record.  The batch goes
-        // through in sub-batches: while the GPU seeds and aligns sub-batch k+1, the host threads turn the records of
-        // sub-batch k into SAM text (MD/NM, MAPQ, formatting) ----
+        // ---- seeds stay in HBM; align_kernel takes every read from seeds to a finished alignment record.  The batch goes
+        // through in sub-batches whose launches are all queued up front, alternating between two streams (each with its
+        // own set of in-flight read slots) so that the next launch fills the CUs the previous one's stragglers leave;
+        // a host thread follows behind: as a sub-batch's launch completes it fetches the records and the host threads turn
+        // them into SAM text (MD/NM, MAPQ, formatting) while the GPU works on the later sub-batches ----
         if (prm->w >= 0 || prm->zdrop >= 0) return MONI_EINVAL;
         const double t_enter = mh::now_s();
         double t_mark[4] = {0, 0, 0, 0};
         const uint64_t NR = b->n_reads;
-        uint64_t sub_reads = 50000;
+        uint64_t sub_reads = 125000;
         if (const char* v = getenv("MONI_ALIGN_SUB")) { const long long x = atoll(v); if (x > 0) sub_reads = (uint64_t)x; }
         const uint64_t n_sub = NR ? (NR + sub_reads - 1) / sub_reads : 0;
         uint64_t force_back = 0;        // test hook: treat every n-th read as handed back by the kernel (exercises that path)
         if (const char* v = getenv("MONI_AK_FORCE_HANDBACK")) { const long long x = atoll(v); if (x > 0) force_back = (uint64_t)x; }
-        int n_cu = 256;
-        { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, I->device) == hipSuccess) n_cu = pr.multiProcessorCount; }
-        int per_cu = 8;       // persistent waves: exactly as many blocks as stay resident, each takes reads off a shared counter
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, align_kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+        if (!c->ak_waves_full) {      // persistent waves: exactly as many blocks as stay resident, each lane takes reads off a shared counter
+            int n_cu = 256, per_cu = 8;
+            { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, I->device) == hipSuccess) n_cu = pr.multiProcessorCount; }
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, align_kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+            c->ak_waves_full = (uint64_t)n_cu * (uint64_t)per_cu;
+        }
+        const uint64_t waves_full = c->ak_waves_full;
         const int T = prm->host_threads > 0 ? (int)prm->host_threads : 1;
         mh::Pool pool(T);
         mh::Aligner AL(I->hix, *prm, b->seq, b->offsets);
-        struct SubRes { std::vector<moni_aln_rec_t> recs; std::vector<uint32_t> cig; std::vector<moni_alt_t> alt; };
-        SubRes res[2];
-        std::vector<std::vector<std::string>> text(n_sub, std::vector<std::string>(T));      // [sub-batch][thread]: SAM text in read order
+        if ((int)c->pieces.size() < T) c->pieces.resize(T);
+        std::vector<std::vector<std::string>> kept(n_sub);           // text of sub-batches that could not be assembled eagerly (hand-back path)
         std::vector<std::vector<uint32_t>> back_of(n_sub);
         std::vector<uint64_t> aligned_t(T, 0);
         double host_busy = 0;
@@ -648,7 +680,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         // has been handed back
         char* abuf = ctx_out ? c->out_buf : nullptr; size_t acap = ctx_out ? c->out_cap : 0, alen = 0; uint64_t eager_upto = 0; bool eager_ok = true, eager_oom = false;
         auto drop_abuf = [&]() { if (!ctx_out) free(abuf); abuf = nullptr; };
-        double prof[3] = {0, 0, 0};
+        double prof[7] = {0, 0, 0, 0, 0, 0, 0};
         uint64_t waves_used = 0;
 
         // seeding: the whole batch at once (the LF kernel wants millions of lanes in flight)
@@ -661,23 +693,31 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             st.t_seed += mh::now_s() - t0;
         }
         t_mark[0] = mh::now_s() - t_enter;
-        // GPU stage of one sub-batch (blocking): align kernel over its reads, records back
-        auto gpu_stage = [&](uint64_t k, SubRes& R) -> int {
+        const double t_gpu0 = mh::now_s();
+        double t_launch[3] = {0, 0, 0};
+        // device side of the align stage
+        std::vector<int32_t> msc(c->max_len + 2);
+        for (uint64_t l = 0; l <= c->max_len + 1; ++l) msc[l] = l ? (int32_t)(20 + 8 * log((double)l)) : INT32_MIN;   // aligner_ksw2.hpp:394
+        // records, CIGARs and alternative hits are written by the kernel straight into pinned host memory (a few hundred
+        // bytes per read over PCIe): no copy has to find room next to the persistent kernels.  Pool share of one sub-batch
+        // below; a launch that runs out hands the affected reads back (status 2)
+        const uint64_t cig_per = 16 * sub_reads + 4096, alt_per = 24 * sub_reads + 4096;
+        if ((rc = c->ak_slots.ensure(2 * waves_full * AK_NL)) || (rc = c->ak_waves.ensure(2 * waves_full)) || (rc = c->h_recs.ensure(NR + 1)) ||
+            (rc = c->h_cig.ensure(cig_per * n_sub + 1)) || (rc = c->h_alt.ensure(alt_per * n_sub + 1)) || (rc = c->ak_minscore.ensure(msc.size())) ||
+            (rc = c->ak_cursors.ensure(16 * n_sub + 16)))
+            return rc;
+        for (int x = 0; x < 2; ++x) if (!c->ak_stream[x]) HIPCHK(hipStreamCreateWithFlags(&c->ak_stream[x], hipStreamNonBlocking));
+        if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        while (c->ak_done.size() < n_sub) { hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); c->ak_begin.push_back(e0); c->ak_done.push_back(e1); }
+        HIPCHK(hipMemsetAsync(c->ak_cursors.p, 0, (16 * n_sub + 16) * sizeof(unsigned long long), c->stream));
+        HIPCHK(hipMemcpyAsync(c->ak_minscore.p, msc.data(), msc.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        t_launch[0] = mh::now_s() - t_enter;
+        for (uint64_t k = 0; k < n_sub; ++k) {
             const uint64_t r0 = k * sub_reads, nr = std::min(sub_reads, NR - r0);
-            double t0 = mh::now_s();
-            int rc2;
-            uint64_t n_waves = (uint64_t)n_cu * (uint64_t)per_cu;
-            if (n_waves > nr) n_waves = nr;
+            uint64_t n_waves = waves_full;
+            if (n_waves * AK_NL > nr) n_waves = (nr + AK_NL - 1) / AK_NL;
             waves_used = std::max(waves_used, n_waves);
-            std::vector<int32_t> msc(c->max_len + 2);
-            for (uint64_t l = 0; l <= c->max_len + 1; ++l) msc[l] = l ? (int32_t)(20 + 8 * log((double)l)) : INT32_MIN;   // aligner_ksw2.hpp:394
-            const uint64_t cig_cap = 64 * nr + 4096, alt_cap = 32 * nr + 4096;
-            if ((rc2 = c->ak_scratch.ensure(n_waves)) || (rc2 = c->ak_recs.ensure(nr + 1)) || (rc2 = c->ak_cig.ensure(cig_cap)) ||
-                (rc2 = c->ak_alt.ensure(alt_cap)) || (rc2 = c->ak_minscore.ensure(msc.size())))
-                return rc2;
-            if (!c->d_ak_cursors) HIPCHK(hipMalloc((void**)&c->d_ak_cursors, 16 * sizeof(unsigned long long)));
-            HIPCHK(hipMemsetAsync(c->d_ak_cursors, 0, 16 * sizeof(unsigned long long), c->stream));
-            HIPCHK(hipMemcpyAsync(c->ak_minscore.p, msc.data(), msc.size() * 4, hipMemcpyHostToDevice, c->stream));
             ak_args_t A;
             memset(&A, 0, sizeof A);
             A.P.min_len = prm->min_len; A.P.ext_len = prm->ext_len; A.P.check_k = prm->check_k; A.P.region_dist = prm->region_dist;
@@ -690,52 +730,55 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             A.D.end_bonus = prm->end_bonus; A.D.reads = c->seq.p; A.D.text = I->d_text; A.D.n_text = I->K.n_text;
             A.mems = c->mems.p; A.occs = c->occs.p; A.read_mem_off = c->read_mem_off.p; A.offs = c->offs.p;
             A.min_score_of_len = c->ak_minscore.p; A.max_len = (uint32_t)c->max_len + 1; A.read_lo = r0; A.n_reads = nr;
-            A.scratch = c->ak_scratch.p; A.recs = c->ak_recs.p; A.cig_pool = c->ak_cig.p; A.cig_cap = cig_cap; A.alt_pool = c->ak_alt.p;
-            A.alt_cap = alt_cap; A.cursors = c->d_ak_cursors;
-            rec(c, EV_DP0);
-            hipLaunchKernelGGL(align_kernel, dim3((unsigned)n_waves), dim3(64), 0, c->stream, A);
-            rec(c, EV_DP1);
+            A.slots = c->ak_slots.p + (k & 1) * waves_full * AK_NL; A.waves = c->ak_waves.p + (k & 1) * waves_full;
+            A.recs = c->h_recs.p + r0; A.cig_pool = c->h_cig.p + k * cig_per; A.cig_cap = cig_per; A.alt_pool = c->h_alt.p + k * alt_per;
+            A.alt_cap = alt_per; A.cursors = c->ak_cursors.p + 16 * k;
+            hipStream_t sx = c->ak_stream[k & 1];
+            HIPCHK(hipEventRecord(c->ak_begin[k], sx));
+            hipLaunchKernelGGL(align_kernel, dim3((unsigned)n_waves), dim3(64), 0, sx, A);
+            HIPCHK(hipEventRecord(c->ak_done[k], sx));
             HIPCHK(hipGetLastError());
-            R.recs.resize(nr);
-            unsigned long long cur[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            HIPCHK(hipMemcpyAsync(R.recs.data(), c->ak_recs.p, nr * sizeof(moni_aln_rec_t), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(cur, c->d_ak_cursors, sizeof cur, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        t_launch[1] = mh::now_s() - t_enter;
+        // host side: follows the launches
+        struct SubRes { moni_aln_rec_t* recs = nullptr; uint32_t* cig = nullptr; moni_alt_t* alt = nullptr; uint64_t nr = 0; };
+        int rc_host = MONI_OK;
+        auto fetch = [&](uint64_t k, SubRes& R) -> int {            // records of sub-batch k into pinned host memory
+            const uint64_t r0 = k * sub_reads, nr = std::min(sub_reads, NR - r0);
+            const double f0 = mh::now_s();
+            HIPCHK(hipEventSynchronize(c->ak_done[k]));
+            const double f1 = mh::now_s();
+            R.recs = c->h_recs.p + r0; R.cig = c->h_cig.p + k * cig_per; R.alt = c->h_alt.p + k * alt_per; R.nr = nr;
+            if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "  sub-batch %llu: waited for the launch from %.1f to %.1f ms\n", (unsigned long long)k, (f0 - t_enter) * 1e3, (f1 - t_enter) * 1e3);
             if (force_back) for (uint64_t r = 0; r < nr; ++r) if ((r0 + r) % force_back == 0) R.recs[r].status = 2;
-            { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[EV_DP0], c->ev[EV_DP1]) == hipSuccess) { c->dp_kernel_ms_accum += ms; c->ak_kernel_ms = ms; } }
-            const uint64_t ncig = cur[0] < cig_cap ? cur[0] : cig_cap, nalt = cur[1] < alt_cap ? cur[1] : alt_cap;
-            R.cig.resize(ncig + 1); R.alt.resize(nalt + 1);
-            if (ncig) HIPCHK(hipMemcpy(R.cig.data(), c->ak_cig.p, ncig * 4, hipMemcpyDeviceToHost));
-            if (nalt) HIPCHK(hipMemcpy(R.alt.data(), c->ak_alt.p, nalt * sizeof(moni_alt_t), hipMemcpyDeviceToHost));
-            st.dp_tasks += cur[2]; st.dp_cells += cur[3]; st.dp_reused += cur[8]; st.dp_cells_reused += cur[9];
-            prof[0] += (double)cur[5]; prof[1] += (double)cur[6]; prof[2] += (double)cur[7];
-            st.t_dp += mh::now_s() - t0;
+            { float ms = 0; if (hipEventElapsedTime(&ms, c->ak_begin[k], c->ak_done[k]) == hipSuccess) { c->dp_kernel_ms_accum += ms; c->ak_kernel_ms = ms; } }
             return MONI_OK;
         };
         // host stage of one sub-batch: MD/NM, MAPQ, SAM text; thread t writes the lines of its (contiguous) share of the reads
         auto host_stage = [&](uint64_t k, const SubRes& R) {
             const double t0 = mh::now_s();
-            const uint64_t r0 = k * sub_reads, nr = R.recs.size();
+            const uint64_t r0 = k * sub_reads, nr = R.nr;
             for (uint64_t r = 0; r < nr; ++r) if (R.recs[r].status == 2) back_of[k].push_back((uint32_t)(r0 + r));
+            bool oom = false;
             mh::parallel_for(pool, nr, [&](int t, size_t lo, size_t hi) {
-                mh::Aligner::EmitScratch sc;
-                std::string& dst = text[k][t];
-                dst.reserve((hi - lo) * 720);
+                mh::Aligner::OutBuf& ob = c->pieces[t];
                 static_assert(sizeof(moni_alt_t) == sizeof(mh::moni_alt_like), "alt record layout");
+                std::vector<char>& mds = c->md_scratch[t];
                 for (size_t r = lo; r < hi; ++r) {
                     const moni_aln_rec_t& Rr = R.recs[r];
                     if (Rr.status == 2) continue;                    // handed back: filled in at the end
                     const uint64_t g = r0 + r;
                     const uint64_t off = b->offsets[g]; const uint32_t m = (uint32_t)(b->offsets[g + 1] - off);
-                    AL.emit_record(dst, sc, (const char*)names + name_off[g], (size_t)(name_off[g + 1] - name_off[g]), b->seq + off, quals ? quals + off : nullptr, m,
-                                   Rr.status == 1, Rr.strand, Rr.ref_pos, Rr.score, Rr.score2, R.cig.data() + Rr.cigar_off, Rr.n_cigar,
-                                   (const mh::moni_alt_like*)R.alt.data() + Rr.alt_off, Rr.n_alt);
+                    if (!AL.emit_record(ob, mds, (const char*)names + name_off[g], (size_t)(name_off[g + 1] - name_off[g]), b->seq + off, quals ? quals + off : nullptr, m,
+                                        Rr.status == 1, Rr.strand, Rr.ref_pos, Rr.score, Rr.score2, R.cig + Rr.cigar_off, Rr.n_cigar,
+                                        (const mh::moni_alt_like*)R.alt + Rr.alt_off, Rr.n_alt)) { oom = true; break; }
                     if (Rr.status == 1) aligned_t[t]++;
                 }
             });
+            if (oom) eager_oom = true;
             if (eager_ok && back_of[k].empty() && !eager_oom) {
                 std::vector<size_t> at(T + 1, alen);
-                for (int t = 0; t < T; ++t) at[t + 1] = at[t] + text[k][t].size();
+                for (int t = 0; t < T; ++t) at[t + 1] = at[t] + c->pieces[t].len;
                 const size_t need = at[T];
                 if (need + 1 > acap) {
                     const size_t sub_bytes = need - alen, rest = NR - (r0 + nr);
@@ -745,29 +788,40 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 }
                 if (!eager_oom) {
                     mh::parallel_for(pool, (size_t)T, [&](int, size_t lo, size_t hi) {
-                        for (size_t x = lo; x < hi; ++x) { std::string& piece = text[k][x]; if (!piece.empty()) memcpy(abuf + at[x], piece.data(), piece.size()); std::string().swap(piece); }
+                        for (size_t x = lo; x < hi; ++x) { mh::Aligner::OutBuf& ob = c->pieces[x]; if (ob.len) memcpy(abuf + at[x], ob.base, ob.len); ob.len = 0; }
                     });
                     alen = need; eager_upto = k + 1;
                 }
-            } else eager_ok = false;
+            } else {
+                eager_ok = false;
+                kept[k].resize(T);
+                for (int t = 0; t < T; ++t) { kept[k][t].assign(c->pieces[t].base ? c->pieces[t].base : "", c->pieces[t].len); c->pieces[t].len = 0; }
+            }
             host_busy += mh::now_s() - t0;
         };
-        {
-            std::thread worker;
-            int rc_gpu = MONI_OK;
-            for (uint64_t k = 0; k < n_sub; ++k) {
-                rc_gpu = gpu_stage(k, res[k & 1]);
-                if (worker.joinable()) worker.join();
-                if (rc_gpu) break;
-                worker = std::thread([&, k]() { host_stage(k, res[k & 1]); });
-            }
-            t_mark[1] = mh::now_s() - t_enter;
-            if (worker.joinable()) worker.join();
-            t_mark[2] = mh::now_s() - t_enter;
-            if (rc_gpu) { drop_abuf(); return rc_gpu; }
+        if ((int)c->md_scratch.size() < T) c->md_scratch.resize(T);
+        for (int t = 0; t < T; ++t) c->pieces[t].len = 0;
+        for (uint64_t k = 0; k < n_sub && !rc_host; ++k) {
+            SubRes R;
+            if ((rc_host = fetch(k, R))) break;
+            if (k + 1 == n_sub) { t_mark[1] = mh::now_s() - t_enter; st.t_dp += mh::now_s() - t_gpu0; }
+            host_stage(k, R);
         }
+        if (rc_host) { for (int x = 0; x < 2; ++x) (void)hipStreamSynchronize(c->ak_stream[x]); drop_abuf(); return rc_host; }
+        t_mark[2] = mh::now_s() - t_enter;
         st.dp_rounds = 1;
-        if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "align_kernel: %.3f ms in %llu sub-batches, %llu waves; lane-0 cycles: init %.3g drive %.3g; wave cycles in DP %.3g\n", c->dp_kernel_ms_accum, (unsigned long long)n_sub, (unsigned long long)waves_used, prof[0], prof[1], prof[2]);
+        if (n_sub) {        // statistics of all launches, once the GPU is idle
+            std::vector<unsigned long long> cur(16 * n_sub);
+            HIPCHK(hipMemcpy(cur.data(), c->ak_cursors.p, cur.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            for (uint64_t k = 0; k < n_sub; ++k) {
+                const unsigned long long* q = cur.data() + 16 * k;
+                st.dp_tasks += q[2]; st.dp_cells += q[3]; st.dp_reused += q[8]; st.dp_cells_reused += q[9];
+                prof[0] += (double)q[5]; prof[1] += (double)q[6]; prof[2] += (double)q[7]; for (int x = 0; x < 4; ++x) prof[3 + x] += (double)q[10 + x];
+            }
+        }
+        double ak_sum_ms = c->dp_kernel_ms_accum;
+        if (n_sub) { float ms = 0; if (hipEventElapsedTime(&ms, c->ak_begin[0], c->ak_done[n_sub - 1]) == hipSuccess) c->dp_kernel_ms_accum = ms; }      // launches overlap: report the span
+        if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "align_kernel: %.3f ms span (%.3f ms summed) in %llu launches, %llu waves x %d reads in flight; wave cycles: take+chain %.3g, later drives %.3g, DP %.3g; lane cycles in ac_init: load %.3g sort %.3g chain-dp %.3g backtrack %.3g\n", c->dp_kernel_ms_accum, ak_sum_ms, (unsigned long long)n_sub, (unsigned long long)waves_used, (int)AK_NL, prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[6]);
         double t0 = mh::now_s();
         for (int t = 0; t < T; ++t) st.aligned += aligned_t[t];
         st.reads = NR;
@@ -806,7 +860,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 const uint64_t r0 = k * sub_reads, nr = std::min(sub_reads, NR - r0);
                 for (int t = 0; t < T; ++t) {
                     const size_t lo = (nr < 2 || T <= 1) ? (t == 0 ? 0 : nr) : nr * t / T, hi = (nr < 2 || T <= 1) ? (t == 0 ? nr : nr) : nr * (t + 1) / T;
-                    const std::string& piece = text[k][t];
+                    const std::string& piece = kept[k][t];
                     size_t p0 = 0;
                     for (size_t r = lo; r < hi; ++r) {
                         if (bi < back.size() && back[bi] == r0 + r) { out += back_line[bi++]; continue; }
@@ -817,7 +871,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             }
         }
         st.t_host += host_busy + (mh::now_s() - t0);
-        if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "align_core wall: seeded at %.1f ms, last kernel done at %.1f, last host stage done at %.1f, text ready at %.1f\n",
+        if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "align_core wall: launches queued from %.1f to %.1f ms\n", t_launch[0] * 1e3, t_launch[1] * 1e3);
+        if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "align_core wall: seeded at %.1f ms, last launch done at %.1f, last host stage done at %.1f, text ready at %.1f\n",
                                                t_mark[0] * 1e3, t_mark[1] * 1e3, t_mark[2] * 1e3, (mh::now_s() - t_enter) * 1e3);
     }
     if (!out_done) {

@@ -117,16 +117,18 @@ SORT_HD void insertion_sort(T* a, long first, long last, Less less) {
     }
 }
 
+struct frame { int first, last, depth; };      // a pending range of the introsort loop
+enum { STACK_FRAMES = 72 };                      // at most 2*floor(log2 n) + 1 ranges are ever pending (n < 2^31)
+
+// st: STACK_FRAMES frames of working memory (device callers keep it out of the kernel's private segment)
 template <class T, class Less>
-SORT_HD_BIG void sort(T* a, long n, Less less) {
+SORT_HD_BIG void sort(T* a, long n, Less less, frame* st) {
     if (n <= 0) return;
     // std::__introsort_loop(first, last, std::__lg(n) * 2, comp) with the right-hand recursion on an explicit stack
     long lg = 0;
     for (long v = n; v > 1; v >>= 1) ++lg;
-    struct frame { long first, last, depth; };
-    frame st[130];
     int sp = 0;
-    st[sp++] = frame{0, n, lg * 2};
+    st[sp++] = frame{0, (int)n, (int)(lg * 2)};
     while (sp > 0) {
         frame f = st[--sp];
         long first = f.first, last = f.last, depth = f.depth;
@@ -138,7 +140,7 @@ SORT_HD_BIG void sort(T* a, long n, Less less) {
             const long cut = unguarded_partition(a, first + 1, last, first, less);
             // the reference recurses into [cut, last) first and then loops on [first, cut): the two ranges are disjoint, so
             // finishing the left loop before the deferred right range gives the same result
-            st[sp++] = frame{cut, last, depth};
+            st[sp++] = frame{(int)cut, (int)last, (int)depth};
             last = cut;
         }
     }
@@ -148,5 +150,10 @@ SORT_HD_BIG void sort(T* a, long n, Less less) {
         for (long i = 16; i != n; ++i) unguarded_linear_insert(a, i, less);
     } else insertion_sort(a, 0, n, less);
 }
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+template <class T, class Less>
+inline void sort(T* a, long n, Less less) { frame st[STACK_FRAMES]; sort(a, n, less, st); }
+#endif
 
 }  // namespace lsort

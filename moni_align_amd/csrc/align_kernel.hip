@@ -10,7 +10,7 @@
 
 #include "align_core.h"
 
-#define AK_CIG_CAP 1024u                     // CIGAR slots per DP problem of a round (qlen + tlen + 2 <= this)
+#define AK_CIG_CAP 4096u                     // CIGAR entries of one round's traceback problems (each takes qlen + tlen + 2)
 #define AK_DIRS_CAP (384u * 1024u)           // direction bytes of one CIGAR problem
 #define AK_MEMO 24                           // score-only DP results remembered per read
 
@@ -25,7 +25,7 @@ struct moni_aln_rec_t {                      // one per read
 struct moni_alt_t { uint64_t pos; int32_t score; int32_t pad; };
 
 #ifndef AK_NL
-#define AK_NL 16                             // reads in flight per wavefront: lanes 0..AK_NL-1 each run one read's state machine
+#define AK_NL 32                             // reads in flight per wavefront: lanes 0..AK_NL-1 each run one read's state machine
 #endif
 #ifndef AK_START_MIN
 #define AK_START_MIN (AK_NL / 2)             // free lanes take new reads together, once this many are free (or nobody waits for DP):
@@ -34,7 +34,7 @@ struct moni_alt_t { uint64_t pos; int32_t score; int32_t pad; };
 struct ak_slot_t {                           // per read in flight, in HBM
     ac_ws_t ws;
     moni_dp_result_t res[AC_MAX_TASKS];      // results of the round's DP problems
-    uint32_t cig[AC_MAX_TASKS * AK_CIG_CAP];
+    uint32_t cig[AK_CIG_CAP];
     uint64_t memo_key[AK_MEMO], memo_toff[AK_MEMO];
     moni_dp_result_t memo_res[AK_MEMO];
     uint32_t memo_n, pad;
@@ -145,12 +145,16 @@ align_kernel(const ak_args_t A) {
             uint64_t mt = (uint32_t)lane < memo_n ? Q->memo_toff[lane] : 0ull;
             __syncthreads();
             bool too_big = false;
+            uint32_t cig_used = 0;
             for (uint32_t t = 0; t < nt; ++t) {
                 const moni_dp_task_t task = s_tasks[t];
                 const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
-                if (task.qlen > DP_MAX_QLEN || task.tlen > 512 || (uint32_t)(task.qlen + task.tlen + 2) > AK_CIG_CAP ||
+                const uint32_t cig_need = with_cigar && task.qlen > 0 && task.tlen > 0 ? (uint32_t)(task.qlen + task.tlen + 2) : 0u;
+                if (task.qlen > DP_MAX_QLEN || task.tlen > 512 || cig_used + cig_need > AK_CIG_CAP ||
                     (with_cigar && (uint64_t)(task.qlen + task.tlen - 1) * (uint64_t)task.tlen > AK_DIRS_CAP)) { too_big = true; break; }
-                uint32_t* cg = Q->cig + (size_t)t * AK_CIG_CAP;
+                const uint32_t cig_at = cig_used;
+                cig_used += cig_need;
+                uint32_t* cg = Q->cig + cig_at;
                 const unsigned long long cells = (unsigned long long)(task.qlen > 0 ? task.qlen : 0) * (unsigned long long)(task.tlen > 0 ? task.tlen : 0);
                 // memo: score-only problems on the index text (every problem of the chain-selection loop)
                 const bool memoable = !with_cigar && (task.reserved & DP_T_TEXT) && (task.reserved & DP_Q_READS) && cells > 0;
@@ -165,14 +169,14 @@ align_kernel(const ak_args_t A) {
                     }
                 }
                 if (hit >= 0) {
-                    if (lane == 0) { moni_dp_result_t x = Q->memo_res[hit]; x.cigar_off = t * AK_CIG_CAP; Q->res[t] = x; s_cnt[C_MEMO]++; s_cnt[C_MEMO_CELLS] += cells; }
+                    if (lane == 0) { moni_dp_result_t x = Q->memo_res[hit]; x.cigar_off = cig_at; Q->res[t] = x; s_cnt[C_MEMO]++; s_cnt[C_MEMO_CELLS] += cells; }
                 } else {
                     extz_wave_lds(A.D, task, L, dirs, cg, &Q->res[t]);
                     if (lane == 0) {
                         s_cnt[C_DP]++; s_cnt[C_CELLS] += cells;
                         moni_dp_result_t x = Q->res[t];
                         if (memoable && memo_n < AK_MEMO) { Q->memo_key[memo_n] = key; Q->memo_toff[memo_n] = task.t_off; Q->memo_res[memo_n] = x; }
-                        x.cigar_off = t * AK_CIG_CAP; Q->res[t] = x;
+                        x.cigar_off = cig_at; Q->res[t] = x;
                     }
                     if (memoable && memo_n < AK_MEMO) { if ((uint32_t)lane == memo_n) { mk = key; mt = task.t_off; } ++memo_n; }
                     __syncthreads();

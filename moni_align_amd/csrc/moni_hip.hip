@@ -656,7 +656,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         const double t_enter = mh::now_s();
         double t_mark[4] = {0, 0, 0, 0};
         const uint64_t NR = b->n_reads;
-        uint64_t sub_reads = 125000;
+        uint64_t sub_reads = 125000;      // with AK_NL = 32 reads in flight on each of ~3000 waves: a handful of reads per lane and launch
         if (const char* v = getenv("MONI_ALIGN_SUB")) { const long long x = atoll(v); if (x > 0) sub_reads = (uint64_t)x; }
         const uint64_t n_sub = NR ? (NR + sub_reads - 1) / sub_reads : 0;
         uint64_t force_back = 0;        // test hook: treat every n-th read as handed back by the kernel (exercises that path)

@@ -6,7 +6,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-MINE = ("ms_lf_kernel", "mem_kernel", "occ_kernel", "extz_kernel", "read_totals", "occ_cnt", "occ_off", "phi_batch")
+MINE = ("ms_lf_kernel", "mem_kernel", "occ_kernel", "extz_kernel", "extz_lds_kernel", "align_kernel", "pack_kernel", "read_totals", "occ_cnt", "occ_off", "phi_batch")
 
 
 def find(pattern):
@@ -34,7 +34,7 @@ for f in find("trace/**/*kernel_trace.csv"):
         d = [x[1] for x in v if x[0] == g]
         FULL[k] = sum(d) / len(d)
         print("%-60s grid=%d launches=%d avg_ns=%.0f min_ns=%d max_ns=%d" % (k, g, len(d), FULL[k], min(d), max(d)))
-for tag in ("pmc_fetch", "pmc_write", "pmc_tcc"):
+for tag in ("pmc_fetch", "pmc_write", "pmc_tcc", "pmc_sq"):
     print("== %s ==" % tag)
     agg = defaultdict(lambda: defaultdict(list))
     for f in find(tag + "/**/*counter_collection.csv"):

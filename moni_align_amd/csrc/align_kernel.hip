@@ -94,7 +94,7 @@ __device__ __attribute__((noinline)) void ak_write_record(const ak_args_t& A, co
     A.recs[slot_in_launch] = rec;
 }
 
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 align_kernel(const ak_args_t A) {
     __shared__ dp_lds_t L;
     __shared__ moni_dp_task_t s_tasks[AC_MAX_TASKS];
@@ -150,7 +150,7 @@ align_kernel(const ak_args_t A) {
                 const moni_dp_task_t task = s_tasks[t];
                 const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
                 const uint32_t cig_need = with_cigar && task.qlen > 0 && task.tlen > 0 ? (uint32_t)(task.qlen + task.tlen + 2) : 0u;
-                if (task.qlen > DP_MAX_QLEN || task.tlen > 512 || cig_used + cig_need > AK_CIG_CAP ||
+                if (task.qlen > DP_LDS_Q || task.tlen > DP_LDS_T || cig_used + cig_need > AK_CIG_CAP ||
                     (with_cigar && (uint64_t)(task.qlen + task.tlen - 1) * (uint64_t)task.tlen > AK_DIRS_CAP)) { too_big = true; break; }
                 const uint32_t cig_at = cig_used;
                 cig_used += cig_need;

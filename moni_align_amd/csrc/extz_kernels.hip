@@ -10,6 +10,7 @@
 // global scratch row-major by anti-diagonal, and lane 0 backtracks them exactly like ksw_backtrack.
 // Integer DP: VALU-bound, reported in GCUPS; no MFMA.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "../../include/moni_hip.h"
@@ -271,12 +272,13 @@ __device__ __attribute__((noinline)) void extz_wave_call(const dp_launch_t& P, c
 // Results are bit-identical to extz_wave (same recurrence, same tie rules, same traceback).
 // ------------------------------------------------------------------------------------------------------------------
 #define DP_LDS_T 512
+#define DP_LDS_Q 512                         // longest query of the LDS-tiled form
 struct dp_lds_t {
     int32_t H[2][DP_LDS_T];
     int32_t E[DP_LDS_T];
     int32_t F[DP_LDS_T];
     uint8_t tc[DP_LDS_T];
-    uint8_t qs[DP_MAX_QLEN];
+    uint8_t qs[DP_LDS_Q];
 };
 
 __device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, const moni_dp_task_t task, dp_lds_t& L,
@@ -315,6 +317,10 @@ __device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, co
     __syncthreads();
     uint8_t* __restrict__ dir = with_cigar ? dir_base : nullptr;
     const int32_t wild = P.wild, scN = P.sc_N, scM = P.sc_mch, scX = P.sc_mis;     // P lives in memory: read once
+    bool any_wild = false;                                    // most problems have no N on either side
+    for (int k = lane; k < qlen; k += 64) any_wild |= L.qs[k] == wild;
+    for (int i = lane; i < tlen; i += 64) any_wild |= L.tc[i] == wild;
+    const bool has_wild = __ballot(any_wild) != 0ull;
     // running maximum per lane as (value, diagonal, row); the reference's in-diagonal visiting order only decides ties
     // inside one diagonal, resolved in the rare branch below and when the lanes are merged
     auto rank_of = [&](int rr, int i) {
@@ -326,32 +332,34 @@ __device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, co
         return 1 + 4 * 4096 + (i - en1);
     };
     int32_t max_z = 0, max_r = 0, max_i = -1;
-    int32_t mte_h = DP_NEG_INF, mte_q = -1, last_h = DP_NEG_INF;
+    int32_t mte_h = DP_NEG_INF, mte_q = -1, last_h = DP_NEG_INF;      // uniform: read back from the last row after each diagonal
     const int en_r = (tlen - 1 + 16) / 16 * 16 - 1;
     const int n_diag = qlen + tlen - 1;
-    const int k_top = (tlen - 1) >> 6;
-    for (int r = 0; r < n_diag; ++r) {
+    // one anti-diagonal: its cells st0..en0 are laid over the lanes from st0 upwards (the state lives in LDS, so the
+    // row -> lane map may slide), 64 rows at a time from the bottom up.  PAR = r & 1 picks the H buffer at compile time.
+    auto diag = [&](const int r, auto PAR) __attribute__((always_inline)) {
+        constexpr int par = decltype(PAR)::value;
+        int32_t* __restrict__ Hn = L.H[par];                 // holds diagonal r-2, receives diagonal r
+        const int32_t* __restrict__ Hp = L.H[par ^ 1];       // diagonal r-1
         const int st0 = r - qlen + 1 > 0 ? r - qlen + 1 : 0;
         const int en0 = r < tlen - 1 ? r : tlen - 1;
-        int32_t* __restrict__ Hn = L.H[r & 1];               // holds diagonal r-2, receives diagonal r
-        const int32_t* __restrict__ Hp = L.H[(r + 1) & 1];   // diagonal r-1
         const int32_t b_r = dp_bound(r, qo, e), b_r1 = dp_bound(r - 1, qo, e);      // row -1: H(-1,r), H(-1,r-1)
-        for (int k = en0 >> 6; k >= (st0 >> 6); --k) {       // bottom chunk first
-            const int i = lane + 64 * k;
-            if (i >= st0 && i <= en0) {
-                const int j = r - i;
+        for (int c = (en0 - st0) >> 6; c >= 0; --c) {
+            const int i = st0 + 64 * c + lane;
+            if (i <= en0) {
                 const int up = i > 0 ? i - 1 : 0;
                 const int32_t h_left = Hp[i];
                 const int32_t f_old = L.F[i];
                 int32_t uH1 = Hp[up], uH2 = Hn[up], uE = L.E[up];     // Hn[i-1] is still H(i-1,-1) when j == 0
-                const int32_t qc = L.qs[j];
+                const int32_t qc = L.qs[r - i];
                 const int32_t tc = L.tc[i];
                 uH1 = i > 0 ? uH1 : b_r; uH2 = i > 0 ? uH2 : b_r1; uE = i > 0 ? uE : DP_NEG_INF;
                 const int32_t Eo = uH1 - qo;
                 const int32_t E = (Eo > uE ? Eo : uE) - e;
                 const int32_t Fo = h_left - qo;
                 const int32_t F = (Fo > f_old ? Fo : f_old) - e;
-                const int32_t s = (tc == wild || qc == wild) ? scN : (tc == qc ? scM : scX);
+                int32_t s = tc == qc ? scM : scX;
+                if (has_wild) s = (tc == wild || qc == wild) ? scN : s;
                 int32_t z = uH2 + s;
                 if (with_cigar) {
                     uint32_t d;
@@ -367,11 +375,20 @@ __device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, co
                     dir[(uint32_t)r * (uint32_t)tlen + (uint32_t)i] = (uint8_t)d;
                 } else { z = z > E ? z : E; z = z > F ? z : F; }
                 Hn[i] = z; L.E[i] = E; L.F[i] = F;
-                if (k == k_top && i == tlen - 1) { last_h = z; if (z > mte_h) { mte_h = z; mte_q = r - en_r; } }
                 if (z > max_z) { max_z = z; max_r = r; max_i = i; }
                 else if (z == max_z && max_r == r && z > 0 && rank_of(r, i) < rank_of(r, max_i)) max_i = i;
             }
         }
+        if (en0 == tlen - 1) {                               // the last row's cell of this diagonal (mte, score)
+            const int32_t z = Hn[tlen - 1];
+            last_h = z;
+            if (z > mte_h) { mte_h = z; mte_q = r - en_r; }
+        }
+    };
+    {
+        int r = 0;
+        for (; r + 1 < n_diag; r += 2) { diag(r, std::integral_constant<int, 0>{}); diag(r + 1, std::integral_constant<int, 1>{}); }
+        if (r < n_diag) diag(r, std::integral_constant<int, 0>{});
     }
     __syncthreads();
     // mqe: H(i, qlen-1) of every row is still in the buffer of the diagonal it was written on
@@ -401,12 +418,7 @@ __device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, co
         else t = en1 + (rank - 1 - 4 * 4096);
         R.max_t = t; R.max_q = rr - t;
     }
-    {
-        const int owner = (tlen - 1) & 63;
-        R.mte = __shfl(mte_h, owner);
-        R.mte_q = __shfl(mte_q, owner);
-        R.score = __shfl(last_h, owner);
-    }
+    R.mte = mte_h; R.mte_q = mte_q; R.score = last_h;
     if (with_cigar) {
         __syncthreads();
         int i0 = -1, j0 = -1;

@@ -182,7 +182,7 @@ def main():
                          "per_read_bytes": ms_bytes / args.reads,
                          "note": "the path's HBM-bound kernel (LF / threshold-jump stage of seeding), one launch per step inside the timed "
                                  "region; the step's longest kernel, align_kernel, is integer-VALU bound: see dp"},
-            "dp": {"kernel": "align_kernel", "bound": "valu-int32", "launches_per_step": -(-args.reads // int(os.environ.get("MONI_ALIGN_SUB", 125000))),
+            "dp": {"kernel": "align_kernel", "bound": "valu-int32", "launches_per_step": stf["dp_rounds"],
                    "ms_per_step": stage["align_kernel"] * 1e3, "dp_problems": stf["dp_tasks"], "dp_cells": stf["dp_cells"],
                    "gcups": stf["dp_cells"] / stage["align_kernel"] / 1e9 if stage["align_kernel"] > 0 else None,
                    "handed_back_to_host_pipeline": stf["handed_back"],

@@ -656,9 +656,20 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         const double t_enter = mh::now_s();
         double t_mark[4] = {0, 0, 0, 0};
         const uint64_t NR = b->n_reads;
-        uint64_t sub_reads = 125000;      // with AK_NL = 32 reads in flight on each of ~3000 waves: a handful of reads per lane and launch
-        if (const char* v = getenv("MONI_ALIGN_SUB")) { const long long x = atoll(v); if (x > 0) sub_reads = (uint64_t)x; }
-        const uint64_t n_sub = NR ? (NR + sub_reads - 1) / sub_reads : 0;
+        // sub-batch schedule: a small first launch (the host stage starts after it), larger ones in the middle (a launch wants
+        // several reads per lane in flight: ~4000 waves x AK_NL lanes), a small last one (the host stage left over after it is short)
+        uint64_t sub_min = 125000, sub_mid = 125000;      // measured: equal pieces do as well as larger middle ones (profiles/sweep_align_nl.sh)
+        if (const char* v = getenv("MONI_ALIGN_SUB")) { const long long x = atoll(v); if (x > 0) sub_min = sub_mid = (uint64_t)x; }
+        std::vector<uint64_t> sub_lo(1, 0);
+        while (sub_lo.back() < NR) {
+            const uint64_t done = sub_lo.back(), rest = NR - done;
+            uint64_t take = done == 0 ? sub_min : (rest >= sub_mid + sub_min ? sub_mid : (rest > sub_min + sub_min / 2 ? rest - sub_min : rest));
+            if (take > rest) take = rest;
+            sub_lo.push_back(done + take);
+        }
+        const uint64_t n_sub = sub_lo.size() - 1;
+        uint64_t sub_reads = 0;                                   // the largest sub-batch (pool shares are sized for it)
+        for (uint64_t k = 0; k < n_sub; ++k) sub_reads = std::max(sub_reads, sub_lo[k + 1] - sub_lo[k]);
         uint64_t force_back = 0;        // test hook: treat every n-th read as handed back by the kernel (exercises that path)
         if (const char* v = getenv("MONI_AK_FORCE_HANDBACK")) { const long long x = atoll(v); if (x > 0) force_back = (uint64_t)x; }
         if (!c->ak_waves_full) {      // persistent waves: exactly as many blocks as stay resident, each lane takes reads off a shared counter
@@ -714,7 +725,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         HIPCHK(hipStreamSynchronize(c->stream));
         t_launch[0] = mh::now_s() - t_enter;
         for (uint64_t k = 0; k < n_sub; ++k) {
-            const uint64_t r0 = k * sub_reads, nr = std::min(sub_reads, NR - r0);
+            const uint64_t r0 = sub_lo[k], nr = sub_lo[k + 1] - sub_lo[k];
             uint64_t n_waves = waves_full;
             if (n_waves * AK_NL > nr) n_waves = (nr + AK_NL - 1) / AK_NL;
             waves_used = std::max(waves_used, n_waves);
@@ -744,7 +755,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         struct SubRes { moni_aln_rec_t* recs = nullptr; uint32_t* cig = nullptr; moni_alt_t* alt = nullptr; uint64_t nr = 0; };
         int rc_host = MONI_OK;
         auto fetch = [&](uint64_t k, SubRes& R) -> int {            // records of sub-batch k into pinned host memory
-            const uint64_t r0 = k * sub_reads, nr = std::min(sub_reads, NR - r0);
+            const uint64_t r0 = sub_lo[k], nr = sub_lo[k + 1] - sub_lo[k];
             const double f0 = mh::now_s();
             HIPCHK(hipEventSynchronize(c->ak_done[k]));
             const double f1 = mh::now_s();
@@ -757,7 +768,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         // host stage of one sub-batch: MD/NM, MAPQ, SAM text; thread t writes the lines of its (contiguous) share of the reads
         auto host_stage = [&](uint64_t k, const SubRes& R) {
             const double t0 = mh::now_s();
-            const uint64_t r0 = k * sub_reads, nr = R.nr;
+            const uint64_t r0 = sub_lo[k], nr = R.nr;
             for (uint64_t r = 0; r < nr; ++r) if (R.recs[r].status == 2) back_of[k].push_back((uint32_t)(r0 + r));
             bool oom = false;
             mh::parallel_for(pool, nr, [&](int t, size_t lo, size_t hi) {
@@ -809,7 +820,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         }
         if (rc_host) { for (int x = 0; x < 2; ++x) (void)hipStreamSynchronize(c->ak_stream[x]); drop_abuf(); return rc_host; }
         t_mark[2] = mh::now_s() - t_enter;
-        st.dp_rounds = 1;
+        st.dp_rounds = n_sub;          // align_kernel launches
         if (n_sub) {        // statistics of all launches, once the GPU is idle
             std::vector<unsigned long long> cur(16 * n_sub);
             HIPCHK(hipMemcpy(cur.data(), c->ak_cursors.p, cur.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -857,7 +868,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             if (abuf) { out.assign(abuf, alen); drop_abuf(); }
             size_t bi = 0;
             for (uint64_t k = eager_upto; k < n_sub; ++k) {
-                const uint64_t r0 = k * sub_reads, nr = std::min(sub_reads, NR - r0);
+                const uint64_t r0 = sub_lo[k], nr = sub_lo[k + 1] - sub_lo[k];
                 for (int t = 0; t < T; ++t) {
                     const size_t lo = (nr < 2 || T <= 1) ? (t == 0 ? 0 : nr) : nr * t / T, hi = (nr < 2 || T <= 1) ? (t == 0 ? nr : nr) : nr * (t + 1) / T;
                     const std::string& piece = kept[k][t];

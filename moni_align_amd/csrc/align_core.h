@@ -42,6 +42,7 @@
 
 struct ac_mem_t { uint64_t pos; const uint64_t* occs; uint32_t len, idx, rpos, mate, nocc; };
 struct ac_anchor_t { uint64_t x; uint32_t mem, occ; };                 // x = reference end of the anchor (the sort key)
+struct ac_node_t { uint64_t x; uint16_t rpos, len; uint8_t mate, pad0; uint16_t pad1; int32_t f, p, t, msc; };      // 32 bytes
 struct ac_chain_t { long long score; uint32_t mate, off, cnt; };      // anchors (right to left) at pool[off .. off+cnt)
 struct ac_start_t { long long f; uint64_t j; };
 struct ac_best_t { int32_t score; uint64_t lft; uint64_t idx; };
@@ -85,7 +86,7 @@ struct ac_ws_t {
     uint32_t n_mems, n_anch, n_chains, pool_used;
     ac_mem_t mems[AC_MAX_MEMS];
     ac_anchor_t anch[AC_MAX_ANCH];
-    int32_t f[AC_MAX_ANCH], p[AC_MAX_ANCH], msc[AC_MAX_ANCH], t[AC_MAX_ANCH];
+    ac_node_t node[AC_MAX_ANCH];
     ac_start_t starts[AC_MAX_CHAINS];
     ac_chain_t chains[AC_MAX_CHAINS];
     uint32_t pool[AC_MAX_POOL];
@@ -148,19 +149,27 @@ AC_HD_BIG bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, u
     { const unsigned long long x = AC_CLOCK(); W.prof[0] += x - pc0; pc0 = x; }
     lsort::sort(W.anch, (long)na, [](const ac_anchor_t& x, const ac_anchor_t& y) { return x.x < y.x; }, W.sort_stack);
     { const unsigned long long x = AC_CLOCK(); W.prof[1] += x - pc0; pc0 = x; }
-    for (size_t i = 0; i < na; ++i) W.t[i] = 0;               // std::vector<ll> t(n, 0)
+    // one 32-byte node per anchor: everything the chaining loops read or write about it (position, read coordinates, mate
+    // and the f / p / t / msc arrays of chain.hpp:254-263) comes with one request
+    for (size_t i = 0; i < na; ++i) {
+        const ac_mem_t& m = W.mems[W.anch[i].mem];
+        ac_node_t nd;
+        nd.x = W.anch[i].x; nd.rpos = (uint16_t)m.rpos; nd.len = (uint16_t)m.len; nd.mate = (uint8_t)m.mate; nd.pad0 = 0; nd.pad1 = 0;
+        nd.f = 0; nd.p = 0; nd.t = 0; nd.msc = 0;               // std::vector<ll> t(n, 0)
+        W.node[i] = nd;
+    }
     long long lb = 0;
     for (size_t i = 0; i < na; ++i) {
-        const ac_mem_t& mi = W.mems[W.anch[i].mem];
-        const long long x_i = (long long)W.anch[i].x, y_i = mi.rpos, w_i = mi.len;
-        const uint32_t mate_i = mi.mate;
+        const ac_node_t ni = W.node[i];
+        const long long x_i = (long long)ni.x, y_i = ni.rpos, w_i = ni.len;
+        const uint32_t mate_i = ni.mate;
         long long max_f = w_i, max_j = -1;
         size_t n_pred = 0;
         if (i - (size_t)lb > (size_t)P.max_iter) lb = (long long)i - P.max_iter;
         for (long long j = (long long)i - 1; j >= lb; --j) {
-            const ac_mem_t& mj = W.mems[W.anch[j].mem];
-            const long long x_j = (long long)W.anch[j].x, y_j = mj.rpos;
-            const uint32_t mate_j = mj.mate;
+            const ac_node_t nj = W.node[j];
+            const long long x_j = (long long)nj.x, y_j = nj.rpos;
+            const uint32_t mate_j = nj.mate;
             if (mate_i != mate_j && ((mate_i ^ mate_j) != 3)) continue;
             if (x_i > x_j + P.max_dist_x) { lb = j; continue; }
             const long long x_d = x_i - x_j, y_d = y_i - y_j;
@@ -176,43 +185,43 @@ AC_HD_BIG bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, u
             } else {
                 beta = l > 0 ? ((long long)(.01 * l * avg_mem_length) + ilog_l) >> 1 : 0;
             }
-            const long long score = W.f[j] + (alpha - beta);
+            const long long score = nj.f + (alpha - beta);
             if (score > max_f) { max_f = score; max_j = j; if (n_pred > 0) --n_pred; }
-            else if ((size_t)(long long)W.t[j] == i && (++n_pred > (size_t)P.max_pred)) break;
-            if (W.p[j] > 0) W.t[W.p[j]] = (int32_t)i;
+            else if ((size_t)(long long)nj.t == i && (++n_pred > (size_t)P.max_pred)) break;
+            if (nj.p > 0) W.node[nj.p].t = (int32_t)i;
         }
-        W.f[i] = (int32_t)max_f; W.p[i] = (int32_t)max_j;
-        W.msc[i] = (max_j >= 0 && W.msc[max_j] > max_f) ? W.msc[max_j] : (int32_t)max_f;
+        W.node[i].f = (int32_t)max_f; W.node[i].p = (int32_t)max_j;
+        W.node[i].msc = (max_j >= 0 && W.node[max_j].msc > max_f) ? W.node[max_j].msc : (int32_t)max_f;
     }
     { const unsigned long long x = AC_CLOCK(); W.prof[2] += x - pc0; pc0 = x; }
-    for (size_t i = 0; i < na; ++i) W.t[i] = 0;
-    for (size_t i = 0; i < na; ++i) if (W.p[i] >= 0) W.t[W.p[i]] = 1;
+    for (size_t i = 0; i < na; ++i) W.node[i].t = 0;
+    for (size_t i = 0; i < na; ++i) if (W.node[i].p >= 0) W.node[W.node[i].p].t = 1;
     uint32_t ns = 0;
     for (size_t i = 0; i < na; ++i) {
-        if (W.t[i] == 0 && W.msc[i] > P.min_chain_score) {
+        if (W.node[i].t == 0 && W.node[i].msc > P.min_chain_score) {
             size_t j = i;
-            while (W.f[j] < W.msc[j]) j = (size_t)W.p[j];
+            while (W.node[j].f < W.node[j].msc) j = (size_t)W.node[j].p;
             if (ns >= AC_MAX_CHAINS) { W.overflow = 1; return false; }
-            W.starts[ns].f = W.f[j]; W.starts[ns].j = j; ++ns;
+            W.starts[ns].f = W.node[j].f; W.starts[ns].j = j; ++ns;
         }
     }
     if (ns == 0) return false;
     lsort::sort(W.starts, (long)ns, [](const ac_start_t& x, const ac_start_t& y) { return x.f > y.f || (x.f == y.f && x.j > y.j); }, W.sort_stack);   // std::greater<pair>
-    for (size_t i = 0; i < na; ++i) W.t[i] = 0;
+    for (size_t i = 0; i < na; ++i) W.node[i].t = 0;
     for (uint32_t i = 0; i < ns; ++i) {
         long long j = (long long)W.starts[i].j;
         ac_chain_t c;
-        c.mate = W.mems[W.anch[j].mem].mate;
+        c.mate = W.node[j].mate;
         c.score = W.starts[i].f;
         c.off = W.pool_used; c.cnt = 0;
         do {
             if (W.pool_used >= AC_MAX_POOL) { W.overflow = 1; return false; }
             W.pool[W.pool_used++] = (uint32_t)j; c.cnt++;
-            W.t[j] = 1; j = W.p[j];
-        } while (j >= 0 && W.t[j] == 0);
+            W.node[j].t = 1; j = W.node[j].p;
+        } while (j >= 0 && W.node[j].t == 0);
         bool keep = false;
         if (j < 0) keep = (long long)c.cnt >= P.min_chain_length;
-        else if (W.starts[i].f - W.f[j] >= P.min_chain_score) keep = (long long)c.cnt >= P.min_chain_length;
+        else if (W.starts[i].f - W.node[j].f >= P.min_chain_score) keep = (long long)c.cnt >= P.min_chain_length;
         if (keep) W.chains[W.n_chains++] = c;            // (a dropped chain leaves its anchors in the pool; harmless)
     }
     lsort::sort(W.chains, (long)W.n_chains, [](const ac_chain_t& x, const ac_chain_t& y) { return x.score > y.score; }, W.sort_stack);

@@ -117,8 +117,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warmup + timed steps: the whole single-end path over the resident batch ------------------------------
-    from oracle import orc as _orc          # only for read names here (make_names) and, below, as the CPU baseline / checker
-    names, noff = _orc.make_names(args.reads)
+    names, noff = synth.make_names(args.reads)
     quals = np.full(args.reads * L, ord("I"), dtype=np.uint8)
     threads = max(1, host_cpus() // max(1, world))          # host stage threads of this rank
     for _ in range(args.warmup):
@@ -198,6 +197,7 @@ def main():
         }
         out["host"] = {"cpus_usable": host_cpus(), "cpu_count": os.cpu_count(), "host_threads_per_gpu": threads}
         if world == 1 and not args.no_cpu:
+            from oracle import orc as _orc          # the CPU baseline / at-scale checker: the only use of oracle/ in this file
             oidx = _orc.OracleIndex(fi=fi)
             cpu_threads = host_cpus()
             # full path on the CPU (oracle/align.hpp), bounded sample; the same sample is an at-scale SAM identity check

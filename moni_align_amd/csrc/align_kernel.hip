@@ -12,6 +12,7 @@
 
 #define AK_CIG_CAP 4096u                     // CIGAR entries of one round's traceback problems (each takes qlen + tlen + 2)
 #define AK_DIRS_CAP (384u * 1024u)           // direction bytes of one CIGAR problem
+#define AK_CUR 32                            // statistics / cursor words per launch
 #define AK_MEMO 24                           // score-only DP results remembered per read
 
 struct moni_aln_rec_t {                      // one per read
@@ -98,10 +99,11 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
 align_kernel(const ak_args_t A) {
     __shared__ dp_lds_t L;
     __shared__ moni_dp_task_t s_tasks[AC_MAX_TASKS];
-    __shared__ unsigned long long s_cnt[8];       // statistics: DP problems run, cells, memo hits, their cells, wave cycles in the phases
+    __shared__ unsigned long long s_cnt[8];
+    __shared__ unsigned long long s_hist[8];       // statistics: DP problems run, cells, memo hits, their cells, wave cycles in the phases
     enum { C_DP = 0, C_CELLS, C_MEMO, C_MEMO_CELLS, C_INIT, C_DRIVE, C_CYDP };
     const int lane = threadIdx.x;
-    if (lane < 8) s_cnt[lane] = 0;
+    if (lane < 8) { s_cnt[lane] = 0; s_hist[lane] = 0; }
     __syncthreads();
     ak_slot_t* __restrict__ S = A.slots + (size_t)blockIdx.x * AK_NL + (lane < AK_NL ? lane : 0);
     ac_ws_t& W = S->ws;
@@ -174,6 +176,7 @@ align_kernel(const ak_args_t A) {
                     extz_wave_lds(A.D, task, L, dirs, cg, &Q->res[t]);
                     if (lane == 0) {
                         s_cnt[C_DP]++; s_cnt[C_CELLS] += cells;
+                        { const int lr = task.qlen < task.tlen ? task.qlen : task.tlen; const int b = lr <= 16 ? 0 : lr <= 32 ? 1 : lr <= 64 ? 2 : 3; s_hist[b]++; s_hist[4 + b] += cells; }
                         moni_dp_result_t x = Q->res[t];
                         if (memoable && memo_n < AK_MEMO) { Q->memo_key[memo_n] = key; Q->memo_toff[memo_n] = task.t_off; Q->memo_res[memo_n] = x; }
                         x.cigar_off = cig_at; Q->res[t] = x;
@@ -199,6 +202,7 @@ align_kernel(const ak_args_t A) {
     if (lane < AK_NL) for (int k = 0; k < 4; ++k) atomicAdd(&A.cursors[10 + k], W.prof[k]);
     if (lane == 0) {
         atomicAdd(&A.cursors[2], s_cnt[C_DP]); atomicAdd(&A.cursors[3], s_cnt[C_CELLS]); atomicAdd(&A.cursors[5], s_cnt[C_INIT]); atomicAdd(&A.cursors[6], s_cnt[C_DRIVE]);
-        atomicAdd(&A.cursors[7], s_cnt[C_CYDP]); atomicAdd(&A.cursors[8], s_cnt[C_MEMO]); atomicAdd(&A.cursors[9], s_cnt[C_MEMO_CELLS]);
+        atomicAdd(&A.cursors[7], s_cnt[C_CYDP]);
+        for (int k = 0; k < 8; ++k) atomicAdd(&A.cursors[16 + k], s_hist[k]); atomicAdd(&A.cursors[8], s_cnt[C_MEMO]); atomicAdd(&A.cursors[9], s_cnt[C_MEMO_CELLS]);
     }
 }

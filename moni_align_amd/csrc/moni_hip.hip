@@ -658,7 +658,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         const uint64_t NR = b->n_reads;
         // sub-batch schedule: a small first launch (the host stage starts after it), larger ones in the middle (a launch wants
         // several reads per lane in flight: ~4000 waves x AK_NL lanes), a small last one (the host stage left over after it is short)
-        uint64_t sub_min = 125000, sub_mid = 125000;      // measured: equal pieces do as well as larger middle ones (profiles/sweep_align_nl.sh)
+        uint64_t sub_min = 125000, sub_mid = 125000;      // measured: equal pieces do as well as larger middle or smaller end pieces (profiles/sweep_align_nl.sh)
         if (const char* v = getenv("MONI_ALIGN_SUB")) { const long long x = atoll(v); if (x > 0) sub_min = sub_mid = (uint64_t)x; }
         std::vector<uint64_t> sub_lo(1, 0);
         while (sub_lo.back() < NR) {
@@ -692,6 +692,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         char* abuf = ctx_out ? c->out_buf : nullptr; size_t acap = ctx_out ? c->out_cap : 0, alen = 0; uint64_t eager_upto = 0; bool eager_ok = true, eager_oom = false;
         auto drop_abuf = [&]() { if (!ctx_out) free(abuf); abuf = nullptr; };
         double prof[7] = {0, 0, 0, 0, 0, 0, 0};
+        double hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         uint64_t waves_used = 0;
 
         // seeding: the whole batch at once (the LF kernel wants millions of lanes in flight)
@@ -715,12 +716,12 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         const uint64_t cig_per = 16 * sub_reads + 4096, alt_per = 24 * sub_reads + 4096;
         if ((rc = c->ak_slots.ensure(2 * waves_full * AK_NL)) || (rc = c->ak_waves.ensure(2 * waves_full)) || (rc = c->h_recs.ensure(NR + 1)) ||
             (rc = c->h_cig.ensure(cig_per * n_sub + 1)) || (rc = c->h_alt.ensure(alt_per * n_sub + 1)) || (rc = c->ak_minscore.ensure(msc.size())) ||
-            (rc = c->ak_cursors.ensure(16 * n_sub + 16)))
+            (rc = c->ak_cursors.ensure(AK_CUR * n_sub + AK_CUR)))
             return rc;
         for (int x = 0; x < 2; ++x) if (!c->ak_stream[x]) HIPCHK(hipStreamCreateWithFlags(&c->ak_stream[x], hipStreamNonBlocking));
         if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         while (c->ak_done.size() < n_sub) { hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); c->ak_begin.push_back(e0); c->ak_done.push_back(e1); }
-        HIPCHK(hipMemsetAsync(c->ak_cursors.p, 0, (16 * n_sub + 16) * sizeof(unsigned long long), c->stream));
+        HIPCHK(hipMemsetAsync(c->ak_cursors.p, 0, (AK_CUR * n_sub + AK_CUR) * sizeof(unsigned long long), c->stream));
         HIPCHK(hipMemcpyAsync(c->ak_minscore.p, msc.data(), msc.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         t_launch[0] = mh::now_s() - t_enter;
@@ -743,7 +744,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             A.min_score_of_len = c->ak_minscore.p; A.max_len = (uint32_t)c->max_len + 1; A.read_lo = r0; A.n_reads = nr;
             A.slots = c->ak_slots.p + (k & 1) * waves_full * AK_NL; A.waves = c->ak_waves.p + (k & 1) * waves_full;
             A.recs = c->h_recs.p + r0; A.cig_pool = c->h_cig.p + k * cig_per; A.cig_cap = cig_per; A.alt_pool = c->h_alt.p + k * alt_per;
-            A.alt_cap = alt_per; A.cursors = c->ak_cursors.p + 16 * k;
+            A.alt_cap = alt_per; A.cursors = c->ak_cursors.p + AK_CUR * k;
             hipStream_t sx = c->ak_stream[k & 1];
             HIPCHK(hipEventRecord(c->ak_begin[k], sx));
             hipLaunchKernelGGL(align_kernel, dim3((unsigned)n_waves), dim3(64), 0, sx, A);
@@ -822,17 +823,20 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         t_mark[2] = mh::now_s() - t_enter;
         st.dp_rounds = n_sub;          // align_kernel launches
         if (n_sub) {        // statistics of all launches, once the GPU is idle
-            std::vector<unsigned long long> cur(16 * n_sub);
+            std::vector<unsigned long long> cur(AK_CUR * n_sub);
             HIPCHK(hipMemcpy(cur.data(), c->ak_cursors.p, cur.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             for (uint64_t k = 0; k < n_sub; ++k) {
-                const unsigned long long* q = cur.data() + 16 * k;
+                const unsigned long long* q = cur.data() + AK_CUR * k;
                 st.dp_tasks += q[2]; st.dp_cells += q[3]; st.dp_reused += q[8]; st.dp_cells_reused += q[9];
                 prof[0] += (double)q[5]; prof[1] += (double)q[6]; prof[2] += (double)q[7]; for (int x = 0; x < 4; ++x) prof[3 + x] += (double)q[10 + x];
+                for (int x = 0; x < 8; ++x) hist[x] += (double)q[16 + x];
             }
         }
         double ak_sum_ms = c->dp_kernel_ms_accum;
         if (n_sub) { float ms = 0; if (hipEventElapsedTime(&ms, c->ak_begin[0], c->ak_done[n_sub - 1]) == hipSuccess) c->dp_kernel_ms_accum = ms; }      // launches overlap: report the span
         if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "align_kernel: %.3f ms span (%.3f ms summed) in %llu launches, %llu waves x %d reads in flight; wave cycles: take+chain %.3g, later drives %.3g, DP %.3g; lane cycles in ac_init: load %.3g sort %.3g chain-dp %.3g backtrack %.3g\n", c->dp_kernel_ms_accum, ak_sum_ms, (unsigned long long)n_sub, (unsigned long long)waves_used, (int)AK_NL, prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[6]);
+        if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "DP problems run, by live rows min(qlen,tlen) <=16 / <=32 / <=64 / >64: count %.3g %.3g %.3g %.3g, cells %.3g %.3g %.3g %.3g\n",
+                                               hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
         double t0 = mh::now_s();
         for (int t = 0; t < T; ++t) st.aligned += aligned_t[t];
         st.reads = NR;

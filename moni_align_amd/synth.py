@@ -168,3 +168,11 @@ def write_fasta(path: str, pg: Pangenome, width: int = 60) -> None:
             for i in range(0, len(b), width):
                 f.write(b[i:i + width])
                 f.write(b"\n")
+
+
+def make_names(n: int, prefix: str = "simulated"):
+    """Read names `simulated.<i>` as ragged bytes + offsets, the layout moni_align_batch takes."""
+    names = [("%s.%d" % (prefix, i)).encode() for i in range(n)]
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in names])
+    return np.frombuffer(b"".join(names), dtype=np.uint8).copy(), off

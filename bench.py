@@ -180,8 +180,8 @@ def main():
                          "algorithmic_bytes_per_launch": ms_bytes, "avg_launch_ms": kern[0],
                          "per_read_bytes": ms_bytes / args.reads,
                          "note": "the path's HBM-bound kernel (LF / threshold-jump stage of seeding), one launch per step inside the timed "
-                                 "region; the step's longest kernel, align_kernel, is integer-VALU bound: see dp"},
-            "dp": {"kernel": "align_kernel", "bound": "valu-int32", "launches_per_step": stf["dp_rounds"],
+                                 "region; the step's longest kernel, align_kernel, is bound by dependent-access latency and the DP's integer VALU chain: see dp"},
+            "dp": {"kernel": "align_kernel", "bound": "latency + valu-int32 (no HBM or MFMA roofline applies)", "launches_per_step": stf["dp_rounds"],
                    "ms_per_step": stage["align_kernel"] * 1e3, "dp_problems": stf["dp_tasks"], "dp_cells": stf["dp_cells"],
                    "gcups": stf["dp_cells"] / stage["align_kernel"] / 1e9 if stage["align_kernel"] > 0 else None,
                    "handed_back_to_host_pipeline": stf["handed_back"],

@@ -284,3 +284,132 @@ def build_flat_index(text: np.ndarray, seq_starts: np.ndarray, names: List[str],
 
 def build_from_pangenome(pg, device: Optional[str] = None, log=None) -> FlatIndex:
     return build_flat_index(pg.text, pg.seq_starts, pg.names, pg.w, device=device, log=log)
+
+
+# ---- the reference builder's raw per-run files ("raw builder inputs") ------------------------------------
+# `moni build` runs bigbwt + pfp-thresholds and then packs their outputs into `<prefix>.thrbv.full.lcp.ms`; the packed
+# file needs sdsl/r-index to read, the raw ones are flat arrays of 1- and 5-byte little-endian integers:
+#   <prefix>.bwt.heads   1 B per run, bytes <= 1 mean the terminator          (moni.hpp:253-282, ms_rle_string.hpp:245-303)
+#   <prefix>.bwt.len     5 B per run
+#   <prefix>.ssa / .esa  r x (5 B BWT position, 5 B SA value); used value = SA ? SA - 1 : n - 1   (moni.hpp:148-184)
+#   <prefix>.thr_pos     5 B per run, 0 = no threshold                         (thresholds_ds.hpp:393-430)
+#   <prefix>.slcp        5 B per entry (r or r + 1 entries)                    (moni_lcp.hpp:117-145)
+# plus the text the index was built over and the `.lidx` listing of `name length+w` per sequence (seqidx.hpp, fixture
+# data/Chr21.10.lidx).  Reading them gives a FlatIndex without sdsl.  Parity note: no raw files of an upstream build are
+# available here, so this reader is pinned only by the reference's loading code cited above and by a write/read round trip.
+SSABYTES = 5
+
+
+def _read5(path: str) -> np.ndarray:
+    raw = np.fromfile(path, dtype=np.uint8)
+    if raw.size % SSABYTES:
+        raise ValueError("invalid file %s: size is not a multiple of %d" % (path, SSABYTES))
+    a = np.zeros((raw.size // SSABYTES, 8), dtype=np.uint8)
+    a[:, :SSABYTES] = raw.reshape(-1, SSABYTES)
+    return a.view("<u8").reshape(-1)
+
+
+def _write5(path: str, vals) -> None:
+    v = np.ascontiguousarray(vals, dtype="<u8")
+    if v.size and int(v.max()) >= 1 << 40:
+        raise ValueError("value does not fit 5 bytes")
+    v.view(np.uint8).reshape(-1, 8)[:, :SSABYTES].tofile(path)
+
+
+def read_lidx(path: str, w: int):
+    """`.lidx`: one `name length+w` line per sequence -> (names, onsets[k+1])."""
+    names, on = [], [0]
+    for line in open(path).read().splitlines():
+        if not line.strip():
+            continue
+        nm, ln = line.split()
+        if int(ln) < w:
+            raise ValueError("lidx entry shorter than the separator width")
+        names.append(nm)
+        on.append(on[-1] + int(ln))
+    return names, np.asarray(on, dtype=np.uint64)
+
+
+def from_raw_files(prefix: str, text_path: str, lidx_path: str, w: int = 10) -> FlatIndex:
+    heads = np.fromfile(prefix + ".bwt.heads", dtype=np.uint8).copy()
+    heads[heads <= TERMINATOR] = TERMINATOR
+    lens = _read5(prefix + ".bwt.len")
+    r = int(heads.size)
+    if lens.size != r:
+        raise ValueError(".bwt.heads and .bwt.len disagree on the number of runs")
+    if r and int(lens.min()) == 0:
+        raise ValueError("empty run in .bwt.len")
+    starts = np.zeros(r + 1, dtype=np.uint64)
+    np.cumsum(lens, out=starts[1:])
+    n = int(starts[r])
+
+    def samples(path):
+        pairs = _read5(path)
+        if pairs.size != 2 * r:
+            raise ValueError("%s does not hold %d (position, sample) pairs" % (path, r))
+        sa = pairs[1::2]
+        return np.where(sa > 0, sa - np.uint64(1), np.uint64(n - 1)).astype(np.uint64)
+
+    ssa, esa = samples(prefix + ".ssa"), samples(prefix + ".esa")
+    thr = _read5(prefix + ".thr_pos")
+    if thr.size != r:
+        raise ValueError(".thr_pos does not hold one entry per run")
+    slcp = _read5(prefix + ".slcp")
+    if slcp.size not in (r, r + 1):
+        raise ValueError(".slcp holds %d entries for %d runs" % (slcp.size, r))
+    slcp = slcp[:r].copy()
+    # F exactly as build_F_ (moni.hpp:253-282)
+    cnt = np.zeros(256, dtype=np.uint64)
+    np.add.at(cnt, heads, lens)
+    F = np.zeros(256, dtype=np.uint64)
+    F[1:] = np.cumsum(cnt)[:-1]
+    text = np.fromfile(text_path, dtype=np.uint8)
+    if text.size != n - 1:
+        raise ValueError("text has %d bytes, the BWT %d" % (text.size, n))
+    names, on = read_lidx(lidx_path, w)
+    if int(on[-1]) + (w - 1 if w else 0) != text.size and int(on[-1]) != text.size:
+        raise ValueError(".lidx does not describe this text")
+    return FlatIndex(n=n, r=r, w=int(w), F=F, heads=heads, starts=starts, ssa=ssa, esa=esa, thr=thr.astype(np.uint64),
+                     slcp=slcp.astype(np.uint64), text=text, seq_starts=on, names=names)
+
+
+def to_raw_files(fi: FlatIndex, prefix: str, text_path: str, lidx_path: str) -> None:
+    """The inverse of from_raw_files (tests; also lets upstream's `moni build --no-parse`-style tooling consume our index)."""
+    fi.heads.astype(np.uint8).tofile(prefix + ".bwt.heads")
+    lens = (fi.starts[1:] - fi.starts[:-1]).astype(np.uint64)
+    _write5(prefix + ".bwt.len", lens)
+    n = np.uint64(fi.n)
+
+    def pairs(pos, val):
+        sa = np.where(val == n - np.uint64(1), np.uint64(0), val + np.uint64(1))      # SA value: the reader takes SA ? SA-1 : n-1
+        out = np.empty(2 * len(pos), dtype=np.uint64)
+        out[0::2] = pos
+        out[1::2] = sa
+        return out
+
+    _write5(prefix + ".ssa", pairs(fi.starts[:-1], fi.ssa))
+    _write5(prefix + ".esa", pairs(fi.starts[1:] - np.uint64(1), fi.esa))
+    _write5(prefix + ".thr_pos", fi.thr)
+    _write5(prefix + ".slcp", fi.slcp)
+    fi.text.tofile(text_path)
+    with open(lidx_path, "w") as f:
+        for k, nm in enumerate(fi.names):
+            f.write("%s %d\n" % (nm, int(fi.seq_starts[k + 1] - fi.seq_starts[k])))
+
+
+def _main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="raw r-index files of the reference's builder -> flat index (.mfi) for moni-hip-align")
+    ap.add_argument("prefix", help="<prefix>.bwt.heads/.bwt.len/.ssa/.esa/.thr_pos/.slcp")
+    ap.add_argument("--text", required=True, help="the text the index was built over (no terminator)")
+    ap.add_argument("--lidx", required=True, help="<prefix>.lidx (name, length + w per sequence)")
+    ap.add_argument("-w", type=int, default=10)
+    ap.add_argument("-o", "--output", required=True)
+    a = ap.parse_args(argv)
+    fi = from_raw_files(a.prefix, a.text, a.lidx, a.w)
+    fi.save(a.output)
+    print("n=%d r=%d sequences=%d -> %s" % (fi.n, fi.r, len(fi.names), a.output))
+
+
+if __name__ == "__main__":
+    _main()

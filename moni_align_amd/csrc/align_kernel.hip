@@ -100,10 +100,11 @@ align_kernel(const ak_args_t A) {
     __shared__ dp_lds_t L;
     __shared__ moni_dp_task_t s_tasks[AC_MAX_TASKS];
     __shared__ unsigned long long s_cnt[8];
-    __shared__ unsigned long long s_hist[8];       // statistics: DP problems run, cells, memo hits, their cells, wave cycles in the phases
+    __shared__ unsigned long long s_hist[8];
+    __shared__ unsigned long long s_cy[8];        // wave cycles inside phase 2: per-read setup, memo lookups, DP by live-row class (<=16, <=32, <=64, >64)       // statistics: DP problems run, cells, memo hits, their cells, wave cycles in the phases
     enum { C_DP = 0, C_CELLS, C_MEMO, C_MEMO_CELLS, C_INIT, C_DRIVE, C_CYDP };
     const int lane = threadIdx.x;
-    if (lane < 8) { s_cnt[lane] = 0; s_hist[lane] = 0; }
+    if (lane < 8) { s_cnt[lane] = 0; s_hist[lane] = 0; s_cy[lane] = 0; }
     __syncthreads();
     ak_slot_t* __restrict__ S = A.slots + (size_t)blockIdx.x * AK_NL + (lane < AK_NL ? lane : 0);
     ac_ws_t& W = S->ws;
@@ -137,6 +138,7 @@ align_kernel(const ak_args_t A) {
         // ---- phase 2 (whole wave): the DP problems of every waiting read, one read after the other ----
         for (unsigned long long todo = waiting; todo; todo &= todo - 1) {
             const int src = __ffsll((long long)todo) - 1;
+            const long long y0 = clock64();
             ak_slot_t* __restrict__ Q = A.slots + (size_t)blockIdx.x * AK_NL + src;
             const uint32_t nt = Q->ws.n_tasks;
             const uint64_t read_off = Q->ws.off;
@@ -148,6 +150,7 @@ align_kernel(const ak_args_t A) {
             __syncthreads();
             bool too_big = false;
             uint32_t cig_used = 0;
+            if (lane == 0) s_cy[0] += (unsigned long long)(clock64() - y0);
             for (uint32_t t = 0; t < nt; ++t) {
                 const moni_dp_task_t task = s_tasks[t];
                 const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
@@ -162,7 +165,29 @@ align_kernel(const ak_args_t A) {
                 const bool memoable = !with_cigar && (task.reserved & DP_T_TEXT) && (task.reserved & DP_Q_READS) && cells > 0;
                 const uint64_t key = ((task.q_off - read_off) & 0xFFFFull) | ((uint64_t)(uint32_t)task.qlen & 0xFFFFull) << 16 |
                                      ((uint64_t)(uint32_t)task.tlen & 0xFFFFull) << 32 | ((uint64_t)task.flag & 0xFFull) << 48 | ((uint64_t)task.reserved & 0xFFull) << 56;
+                // one query base against one target base, globally: when the diagonal move beats both gap moves the result is
+                // that substitution score and "1M" (the gap between two MEMs that a single mismatch separates: the commonest problem)
+                if (task.qlen == 1 && task.tlen == 1 && !(task.flag & DP_EZ_EXTZ_ONLY) && (task.reserved & DP_Q_READS) && (task.reserved & DP_T_TEXT)) {
+                    uint32_t qc = dp_nt4(A.D.reads[task.q_off]);
+                    if ((task.reserved & DP_Q_COMP) && qc < 4) qc = 3 - qc;
+                    const uint32_t tc = dp_nt4(task.t_off < A.D.n_text ? A.D.text[task.t_off] : 0u);
+                    const int32_t z = (tc == (uint32_t)A.D.wild || qc == (uint32_t)A.D.wild) ? A.D.sc_N : (tc == qc ? A.D.sc_mch : A.D.sc_mis);
+                    const int32_t gap = dp_bound(0, A.D.qo, A.D.e) - A.D.qo - A.D.e;        // E(0,0) = F(0,0)
+                    if (z > gap) {
+                        if (lane == 0) {
+                            moni_dp_result_t x;
+                            x.max = z > 0 ? z : 0; x.max_q = x.max_t = z > 0 ? 0 : -1;
+                            x.mqe = z; x.mqe_t = 0; x.mte = z; x.mte_q = -15; x.score = z;      // mte_q = r - ((tlen-1+16)/16*16 - 1) at r = 0
+                            x.reach_end = 0; x.zdropped = 0; x.n_cigar = with_cigar ? 1u : 0u; x.cigar_off = cig_at;
+                            if (with_cigar) cg[0] = 1u << 4;
+                            Q->res[t] = x;
+                            s_cy[6]++;
+                        }
+                        continue;
+                    }
+                }
                 int hit = -1;
+                const long long y1 = clock64();
                 if (memoable) {
                     for (unsigned long long cand = __ballot(mk == key); cand && hit < 0; cand &= cand - 1) {
                         const int e = __ffsll((long long)cand) - 1;
@@ -170,6 +195,8 @@ align_kernel(const ak_args_t A) {
                         if (toff_e == task.t_off || ak_same_target(A.D, (int)task.reserved, toff_e, task.t_off, task.tlen)) hit = e;
                     }
                 }
+                const long long y2 = clock64();
+                if (lane == 0) s_cy[1] += (unsigned long long)(y2 - y1);
                 if (hit >= 0) {
                     if (lane == 0) { moni_dp_result_t x = Q->memo_res[hit]; x.cigar_off = cig_at; Q->res[t] = x; s_cnt[C_MEMO]++; s_cnt[C_MEMO_CELLS] += cells; }
                 } else {
@@ -183,6 +210,7 @@ align_kernel(const ak_args_t A) {
                     }
                     if (memoable && memo_n < AK_MEMO) { if ((uint32_t)lane == memo_n) { mk = key; mt = task.t_off; } ++memo_n; }
                     __syncthreads();
+                    if (lane == 0) { const int lr = task.qlen < task.tlen ? task.qlen : task.tlen; s_cy[2 + (lr <= 16 ? 0 : lr <= 32 ? 1 : lr <= 64 ? 2 : 3)] += (unsigned long long)(clock64() - y2); }
                 }
             }
             if (lane == 0) { Q->memo_n = memo_n; if (too_big) Q->ws.overflow = 1; }
@@ -203,6 +231,7 @@ align_kernel(const ak_args_t A) {
     if (lane == 0) {
         atomicAdd(&A.cursors[2], s_cnt[C_DP]); atomicAdd(&A.cursors[3], s_cnt[C_CELLS]); atomicAdd(&A.cursors[5], s_cnt[C_INIT]); atomicAdd(&A.cursors[6], s_cnt[C_DRIVE]);
         atomicAdd(&A.cursors[7], s_cnt[C_CYDP]);
-        for (int k = 0; k < 8; ++k) atomicAdd(&A.cursors[16 + k], s_hist[k]); atomicAdd(&A.cursors[8], s_cnt[C_MEMO]); atomicAdd(&A.cursors[9], s_cnt[C_MEMO_CELLS]);
+        for (int k = 0; k < 8; ++k) atomicAdd(&A.cursors[16 + k], s_hist[k]);
+        for (int k = 0; k < 7; ++k) atomicAdd(&A.cursors[24 + k], s_cy[k]); atomicAdd(&A.cursors[8], s_cnt[C_MEMO]); atomicAdd(&A.cursors[9], s_cnt[C_MEMO_CELLS]);
     }
 }

@@ -344,40 +344,59 @@ __device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, co
         const int st0 = r - qlen + 1 > 0 ? r - qlen + 1 : 0;
         const int en0 = r < tlen - 1 ? r : tlen - 1;
         const int32_t b_r = dp_bound(r, qo, e), b_r1 = dp_bound(r - 1, qo, e);      // row -1: H(-1,r), H(-1,r-1)
-        for (int c = (en0 - st0) >> 6; c >= 0; --c) {
-            const int i = st0 + 64 * c + lane;
-            if (i <= en0) {
-                const int up = i > 0 ? i - 1 : 0;
-                const int32_t h_left = Hp[i];
-                const int32_t f_old = L.F[i];
-                int32_t uH1 = Hp[up], uH2 = Hn[up], uE = L.E[up];     // Hn[i-1] is still H(i-1,-1) when j == 0
-                const int32_t qc = L.qs[r - i];
-                const int32_t tc = L.tc[i];
-                uH1 = i > 0 ? uH1 : b_r; uH2 = i > 0 ? uH2 : b_r1; uE = i > 0 ? uE : DP_NEG_INF;
-                const int32_t Eo = uH1 - qo;
-                const int32_t E = (Eo > uE ? Eo : uE) - e;
-                const int32_t Fo = h_left - qo;
-                const int32_t F = (Fo > f_old ? Fo : f_old) - e;
-                int32_t s = tc == qc ? scM : scX;
-                if (has_wild) s = (tc == wild || qc == wild) ? scN : s;
-                int32_t z = uH2 + s;
-                if (with_cigar) {
-                    uint32_t d;
-                    if (!right) {
-                        d = E > z ? 1u : 0u; z = z > E ? z : E; d = F > z ? 2u : d; z = z > F ? z : F;
-                        d |= (E > z - qo) ? 0x08u : 0u;
-                        d |= (F > z - qo) ? 0x10u : 0u;
-                    } else {
-                        d = z > E ? 0u : 1u; z = z > E ? z : E; d = z > F ? d : 2u; z = z > F ? z : F;
-                        d |= (E >= z - qo) ? 0x08u : 0u;
-                        d |= (F >= z - qo) ? 0x10u : 0u;
-                    }
-                    dir[(uint32_t)r * (uint32_t)tlen + (uint32_t)i] = (uint8_t)d;
-                } else { z = z > E ? z : E; z = z > F ? z : F; }
+        struct cell_in { int32_t h_left, f_old, uH1, uH2, uE, qc, tc; };
+        auto load = [&](const int i) __attribute__((always_inline)) {      // i: a live row of this diagonal
+            cell_in c;
+            const int up = i > 0 ? i - 1 : 0;
+            c.h_left = Hp[i];
+            c.f_old = L.F[i];
+            c.uH1 = Hp[up]; c.uH2 = Hn[up]; c.uE = L.E[up];                  // Hn[i-1] is still H(i-1,-1) when j == 0
+            c.qc = L.qs[r - i];
+            c.tc = L.tc[i];
+            return c;
+        };
+        auto finish = [&](const int i, const bool act, const cell_in& c) __attribute__((always_inline)) {
+            const int32_t uH1 = i > 0 ? c.uH1 : b_r, uH2 = i > 0 ? c.uH2 : b_r1, uE = i > 0 ? c.uE : DP_NEG_INF;
+            const int32_t Eo = uH1 - qo;
+            const int32_t E = (Eo > uE ? Eo : uE) - e;
+            const int32_t Fo = c.h_left - qo;
+            const int32_t F = (Fo > c.f_old ? Fo : c.f_old) - e;
+            int32_t s = c.tc == c.qc ? scM : scX;
+            if (has_wild) s = (c.tc == wild || c.qc == wild) ? scN : s;
+            int32_t z = uH2 + s;
+            uint32_t d = 0;
+            if (with_cigar) {
+                if (!right) {
+                    d = E > z ? 1u : 0u; z = z > E ? z : E; d = F > z ? 2u : d; z = z > F ? z : F;
+                    d |= (E > z - qo) ? 0x08u : 0u;
+                    d |= (F > z - qo) ? 0x10u : 0u;
+                } else {
+                    d = z > E ? 0u : 1u; z = z > E ? z : E; d = z > F ? d : 2u; z = z > F ? z : F;
+                    d |= (E >= z - qo) ? 0x08u : 0u;
+                    d |= (F >= z - qo) ? 0x10u : 0u;
+                }
+            } else { z = z > E ? z : E; z = z > F ? z : F; }
+            if (act) {
+                if (with_cigar) dir[(uint32_t)r * (uint32_t)tlen + (uint32_t)i] = (uint8_t)d;
                 Hn[i] = z; L.E[i] = E; L.F[i] = F;
                 if (z > max_z) { max_z = z; max_r = r; max_i = i; }
                 else if (z == max_z && max_r == r && z > 0 && rank_of(r, i) < rank_of(r, max_i)) max_i = i;
             }
+        };
+        int c = (en0 - st0) >> 6;
+        for (; c >= 1; c -= 2) {            // two 64-row chunks at a time: both read before either writes, their chains overlap
+            const int i_hi = st0 + 64 * c + lane, i_lo = i_hi - 64;
+            const bool act_hi = i_hi <= en0;                                  // the lower chunk is full
+            const cell_in in_hi = load(act_hi ? i_hi : en0);
+            const cell_in in_lo = load(i_lo);
+            finish(i_hi, act_hi, in_hi);
+            finish(i_lo, true, in_lo);
+        }
+        if (c == 0) {
+            const int i = st0 + lane;
+            const bool act = i <= en0;
+            const cell_in in = load(act ? i : en0);
+            finish(i, act, in);
         }
         if (en0 == tlen - 1) {                               // the last row's cell of this diagonal (mte, score)
             const int32_t z = Hn[tlen - 1];
@@ -425,25 +444,44 @@ __device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, co
         if (!(flag & DP_EZ_EXTZ_ONLY)) { i0 = tlen - 1; j0 = qlen - 1; }
         else if (R.mqe + P.end_bonus > R.max) { R.reach_end = 1; i0 = R.mqe_t; j0 = qlen - 1; }
         else if (R.max_t >= 0 && R.max_q >= 0) { i0 = R.max_t; j0 = R.max_q; }
-        if (lane == 0 && i0 >= 0 && j0 >= 0) {
+        if (i0 >= 0 && j0 >= 0) {
+            // traceback, the whole wave in step (i, j and the state are uniform): direction bytes come through LDS in tiles of
+            // 64 anti-diagonals x 32 rows ending at the current cell (one round trip to HBM per tile instead of one per step);
+            // the CIGAR run being built stays in registers, lane 0 stores an entry when the operation changes
+            uint8_t* __restrict__ tile = reinterpret_cast<uint8_t*>(&L.H[0][0]);      // 2 KB of the H buffers, free by now
             uint32_t* __restrict__ cg = cg_base;
             int n = 0, i = i0, j = j0, state = 0;
+            uint32_t cur_op = 0xFu, cur_len = 0;
             auto push = [&](uint32_t op, int len) {
-                if (n == 0 || op != (cg[n - 1] & 0xf)) cg[n++] = (uint32_t)len << 4 | op;
-                else cg[n - 1] += (uint32_t)len << 4;
+                if (op == cur_op) cur_len += (uint32_t)len;
+                else { if (cur_op != 0xFu) { if (lane == 0) cg[n] = cur_len << 4 | cur_op; ++n; } cur_op = op; cur_len = (uint32_t)len; }
             };
             while (i >= 0 && j >= 0) {
-                const uint32_t tmp = dir[(size_t)(i + j) * tlen + i];
-                if (state == 0) state = tmp & 7;
-                else if (!(tmp >> (state + 2) & 1)) state = 0;
-                if (state == 0) state = tmp & 7;
-                if (state == 0) { push(0, 1); --i; --j; }
-                else if (state == 1 || state == 3) { push(2, 1); --i; }
-                else { push(1, 1); --j; }
+                const int r_top = i + j, i_lo = i > 31 ? i - 31 : 0;
+                __syncthreads();
+                _Pragma("unroll 8")
+                for (int s2 = 0; s2 < 32; ++s2) {                   // lane: diagonal r_top - (2*s2 + lane/32), row i_lo + lane%32
+                    const int d = 2 * s2 + (lane >> 5), rd = r_top - d, row = i_lo + (lane & 31);
+                    uint8_t v = 0;
+                    if (rd >= 0 && row <= i) v = dir[(uint32_t)rd * (uint32_t)tlen + (uint32_t)row];
+                    tile[d * 32 + (lane & 31)] = v;
+                }
+                __syncthreads();
+                while (i >= i_lo && j >= 0 && i + j > r_top - 64) {
+                    const uint32_t tmp = tile[(r_top - (i + j)) * 32 + (i - i_lo)];
+                    if (state == 0) state = tmp & 7;
+                    else if (!(tmp >> (state + 2) & 1)) state = 0;
+                    if (state == 0) state = tmp & 7;
+                    if (state == 0) { push(0, 1); --i; --j; }
+                    else if (state == 1 || state == 3) { push(2, 1); --i; }
+                    else { push(1, 1); --j; }
+                }
             }
             if (i >= 0) push(2, i + 1);
             if (j >= 0) push(1, j + 1);
-            for (int a = 0; a < n >> 1; ++a) { const uint32_t t2 = cg[a]; cg[a] = cg[n - 1 - a]; cg[n - 1 - a] = t2; }
+            if (cur_op != 0xFu) { if (lane == 0) cg[n] = cur_len << 4 | cur_op; ++n; }
+            __syncthreads();
+            if (lane == 0) for (int a2 = 0; a2 < n >> 1; ++a2) { const uint32_t t2 = cg[a2]; cg[a2] = cg[n - 1 - a2]; cg[n - 1 - a2] = t2; }
             R.n_cigar = (uint32_t)n;
         }
     }

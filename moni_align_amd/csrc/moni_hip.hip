@@ -692,7 +692,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         char* abuf = ctx_out ? c->out_buf : nullptr; size_t acap = ctx_out ? c->out_cap : 0, alen = 0; uint64_t eager_upto = 0; bool eager_ok = true, eager_oom = false;
         auto drop_abuf = [&]() { if (!ctx_out) free(abuf); abuf = nullptr; };
         double prof[7] = {0, 0, 0, 0, 0, 0, 0};
-        double hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double hist[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cyc[7] = {0, 0, 0, 0, 0, 0, 0};
         uint64_t waves_used = 0;
 
         // seeding: the whole batch at once (the LF kernel wants millions of lanes in flight)
@@ -830,6 +830,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 st.dp_tasks += q[2]; st.dp_cells += q[3]; st.dp_reused += q[8]; st.dp_cells_reused += q[9];
                 prof[0] += (double)q[5]; prof[1] += (double)q[6]; prof[2] += (double)q[7]; for (int x = 0; x < 4; ++x) prof[3 + x] += (double)q[10 + x];
                 for (int x = 0; x < 8; ++x) hist[x] += (double)q[16 + x];
+                for (int x = 0; x < 7; ++x) cyc[x] += (double)q[24 + x];
             }
         }
         double ak_sum_ms = c->dp_kernel_ms_accum;
@@ -837,6 +838,9 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "align_kernel: %.3f ms span (%.3f ms summed) in %llu launches, %llu waves x %d reads in flight; wave cycles: take+chain %.3g, later drives %.3g, DP %.3g; lane cycles in ac_init: load %.3g sort %.3g chain-dp %.3g backtrack %.3g\n", c->dp_kernel_ms_accum, ak_sum_ms, (unsigned long long)n_sub, (unsigned long long)waves_used, (int)AK_NL, prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[6]);
         if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "DP problems run, by live rows min(qlen,tlen) <=16 / <=32 / <=64 / >64: count %.3g %.3g %.3g %.3g, cells %.3g %.3g %.3g %.3g\n",
                                                hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
+        if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "wave cycles inside the DP phase: per-read setup %.3g, memo lookups %.3g, DP by live rows <=16 / <=32 / <=64 / >64: %.3g %.3g %.3g %.3g; 1x1 problems answered in closed form: %.3g\n",
+                                               cyc[0], cyc[1], cyc[2], cyc[3], cyc[4], cyc[5], cyc[6]);
+        st.dp_reused += (uint64_t)cyc[6];
         double t0 = mh::now_s();
         for (int t = 0; t < T; ++t) st.aligned += aligned_t[t];
         st.reads = NR;

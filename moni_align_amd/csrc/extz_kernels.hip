@@ -279,10 +279,14 @@ struct dp_lds_t {
     int32_t F[DP_LDS_T];
     uint8_t tc[DP_LDS_T];
     uint8_t qs[DP_LDS_Q];
+    static constexpr bool in_lds = true;
 };
 
-__device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, const moni_dp_task_t task, dp_lds_t& L,
-                                                        uint8_t* __restrict__ dir_base, uint32_t* __restrict__ cg_base, moni_dp_result_t* __restrict__ out) {
+// ST: where the per-row state lives - dp_lds_t (LDS; align_kernel, extz_lds_kernel) or dp_big_t (HBM; problems too large for it).
+// tile: 2 KB of LDS for the traceback (may overlay ST's H buffers when those are in LDS: they are dead by then).
+template <class ST>
+__device__ __forceinline__ void extz_wave_tiled(const dp_launch_t& P, const moni_dp_task_t task, ST& L, uint8_t* __restrict__ tile,
+                                                uint8_t* __restrict__ dir_base, uint32_t* __restrict__ cg_base, moni_dp_result_t* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int qlen = task.qlen, tlen = task.tlen, flag = task.flag;
     moni_dp_result_t R;                      // lane 0 writes it to *out (LDS or global) at the end
@@ -398,6 +402,7 @@ __device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, co
             const cell_in in = load(act ? i : en0);
             finish(i, act, in);
         }
+        if (!ST::in_lds) __threadfence_block();
         if (en0 == tlen - 1) {                               // the last row's cell of this diagonal (mte, score)
             const int32_t z = Hn[tlen - 1];
             last_h = z;
@@ -448,7 +453,6 @@ __device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, co
             // traceback, the whole wave in step (i, j and the state are uniform): direction bytes come through LDS in tiles of
             // 64 anti-diagonals x 32 rows ending at the current cell (one round trip to HBM per tile instead of one per step);
             // the CIGAR run being built stays in registers, lane 0 stores an entry when the operation changes
-            uint8_t* __restrict__ tile = reinterpret_cast<uint8_t*>(&L.H[0][0]);      // 2 KB of the H buffers, free by now
             uint32_t* __restrict__ cg = cg_base;
             int n = 0, i = i0, j = j0, state = 0;
             uint32_t cur_op = 0xFu, cur_len = 0;
@@ -487,6 +491,32 @@ __device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, co
     }
     if (lane == 0) *out = R;
     __syncthreads();
+}
+
+__device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, const moni_dp_task_t task, dp_lds_t& L,
+                                                        uint8_t* __restrict__ dir_base, uint32_t* __restrict__ cg_base, moni_dp_result_t* __restrict__ out) {
+    extz_wave_tiled(P, task, L, reinterpret_cast<uint8_t*>(&L.H[0][0]), dir_base, cg_base, out);
+}
+
+// problems beyond the LDS form's 512 target rows / 512 query bases (long reads in the host pipeline): same code, state in HBM
+#define DP_BIG_T 4096
+#define DP_BIG_Q 8192
+struct dp_big_t {
+    int32_t H[2][DP_BIG_T];
+    int32_t E[DP_BIG_T];
+    int32_t F[DP_BIG_T];
+    uint8_t tc[DP_BIG_T];
+    uint8_t qs[DP_BIG_Q];
+    static constexpr bool in_lds = false;     // lanes hand rows to each other through HBM: drain the stores after every diagonal
+};
+
+__global__ void __launch_bounds__(64)
+extz_big_kernel(const dp_launch_t P, dp_big_t* __restrict__ states) {
+    __shared__ uint8_t tile[2048];
+    const uint32_t tix = P.order[blockIdx.x];
+    const moni_dp_task_t task = P.tasks[tix];
+    const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
+    extz_wave_tiled(P, task, states[blockIdx.x], tile, with_cigar ? P.dirs + P.dir_off[tix] : nullptr, with_cigar ? P.cig_tmp + P.cig_off[tix] : nullptr, &P.results[tix]);
 }
 
 __global__ void __launch_bounds__(64)

@@ -113,6 +113,8 @@ struct moni_ctx {
     DBuf<uint64_t> dp_off;
     DBuf<uint32_t> dp_ws;
     // align kernel
+    DBuf<dp_big_t> dp_big;
+    DBuf<uint8_t> dp_dir_big;
     DBuf<ak_slot_t> ak_slots;
     DBuf<ak_wave_t> ak_waves;
     DBuf<unsigned long long> ak_cursors;
@@ -277,7 +279,7 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
     c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
     c->dp_q.release(); c->dp_t.release(); c->dp_dir.release(); c->dp_tasks.release(); c->dp_res.release(); c->dp_cig.release();
-    c->dp_off.release(); c->dp_ws.release(); c->ak_slots.release(); c->ak_waves.release(); c->ak_cursors.release(); c->h_recs.release(); c->h_cig.release(); c->h_alt.release();
+    c->dp_off.release(); c->dp_ws.release(); c->dp_big.release(); c->dp_dir_big.release(); c->ak_slots.release(); c->ak_waves.release(); c->ak_cursors.release(); c->h_recs.release(); c->h_cig.release(); c->h_alt.release();
     for (auto& ob : c->pieces) ob.release();
     for (int x = 0; x < 2; ++x) if (c->ak_stream[x]) (void)hipStreamDestroy(c->ak_stream[x]);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);

@@ -94,6 +94,23 @@ def test_sam_identical_250bp_noisy_ragged(medium_case, env):
     both(env, reads)
 
 
+def test_long_reads_go_through_the_hand_back_path(medium_case, env):
+    """Reads whose flanks exceed the align kernel's DP capacities (query > 512) are handed back to the host pipeline by the
+    kernel itself; the output must still be the oracle's."""
+    rng = np.random.default_rng(23)
+    base = list(medium_case.synth.make_reads(medium_case.pg, 300, 150, seed=31))
+    text = medium_case.fi.text
+    for ln in (600, 900, 1500):
+        for _ in range(3):
+            p0 = int(rng.integers(1000, len(medium_case.pg.seqs[0]) - 3000))
+            r = np.array(text[p0:p0 + ln], dtype=np.uint8).copy()
+            k = rng.integers(0, ln, size=ln // 60)
+            r[k] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(k))]
+            base.insert(int(rng.integers(0, len(base))), r)
+    _, st = both(env, base)
+    assert st["handed_back"] >= 1
+
+
 def test_sam_identical_fasta_reads(medium_case, env):
     reads = medium_case.synth.make_reads(medium_case.pg, 500, 100, seed=3)
     both(env, list(reads), quals=False)

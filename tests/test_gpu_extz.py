@@ -94,6 +94,18 @@ def test_extz_multi_chunk(ctx):
     check(ctx, q, t, tasks)
 
 
+def test_extz_oversize_problems(ctx):
+    """Beyond the one-wave kernels' 512 target rows (2048 / 512 query bases): extz_big_kernel, state rows in HBM."""
+    from oracle import orc
+    rng = np.random.default_rng(5)
+    flags = [orc.FLAG_SCORE_ONLY, orc.FLAG_EXTZ_ONLY | orc.FLAG_RIGHT, orc.FLAG_RIGHT, 0]
+    q, t, tasks = make_tasks(rng, 16, 1300, 1500, flags)
+    assert (tasks["tlen"] > 512).sum() >= 4
+    check(ctx, q, t, tasks)
+    q, t, tasks = make_tasks(rng, 3, 2600, 700, flags)      # query beyond 2048 as well
+    check(ctx, q, t, tasks)
+
+
 def test_extz_reference_comment_example(ctx):
     from moni_align_amd import capi
     from oracle import orc

@@ -111,6 +111,45 @@ def test_long_reads_go_through_the_hand_back_path(medium_case, env):
     assert st["handed_back"] >= 1
 
 
+def test_repeats_overflow_the_kernel_capacities(tmp_path):
+    """A tandem-repeat region gives reads hundreds of seed occurrences: more anchors / chains than the align kernel's per-read
+    capacities, so those reads take the host pipeline; the SAM text must not change."""
+    from moni_align_amd import capi, index_build, synth
+    from oracle import orc
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    unit = acgt[rng.integers(0, 4, size=180)]
+    copies = []
+    for _ in range(70):
+        u = unit.copy()
+        k = rng.integers(0, 180, size=2)
+        u[k] = acgt[rng.integers(0, 4, size=2)]
+        copies.append(u)
+    base = np.concatenate([acgt[rng.integers(0, 4, size=15000)]] + copies + [acgt[rng.integers(0, 4, size=15000)]])
+    hap = base.copy()
+    k = rng.integers(0, len(hap), size=40)
+    hap[k] = acgt[rng.integers(0, 4, size=40)]
+    pg = synth.Pangenome(seqs=[base, hap], names=["chrR", "S1_H1_chrR"], w=10)
+    fi = index_build.build_from_pangenome(pg, device="cpu")
+    path = str(tmp_path / "rep.mfi")
+    fi.save(path)
+    reads = []
+    for _ in range(150):
+        p0 = int(rng.integers(14000, 15000 + 70 * 180))
+        r = base[p0:p0 + 150].copy()
+        k = rng.integers(0, 150, size=2)
+        r[k] = acgt[rng.integers(0, 4, size=2)]
+        reads.append(r if rng.random() < 0.5 else synth.revcomp(r[None, :])[0])
+    idx = capi.Index(fi=fi)
+    ctx = capi.Ctx(idx)
+    try:
+        _, st = both((orc.OracleIndex(path), ctx), reads)
+        assert st["handed_back"] >= 1
+    finally:
+        ctx.close()
+        idx.close()
+
+
 def test_sam_identical_fasta_reads(medium_case, env):
     reads = medium_case.synth.make_reads(medium_case.pg, 500, 100, seed=3)
     both(env, list(reads), quals=False)

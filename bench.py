@@ -161,6 +161,11 @@ def main():
                 traffic, traffic_src = tj["fetch_bytes"] + tj["write_bytes"], tj["source"]
         except Exception:
             pass
+        sq = None
+        try:        # issue counters of align_kernel from the SQ pass of the same recipe
+            sq = json.load(open(os.path.join(ROOT, "profiles", "align_kernel_sq.json")))
+        except Exception:
+            pass
         ms_bytes = 128 * S + 64 * J                 # algorithmic bytes of the LF stage
         ms_s = kern[0] / 1e3
         achieved = ms_bytes / ms_s / 1e9 if ms_s > 0 else 0.0
@@ -195,6 +200,16 @@ def main():
                         "value": world * args.reads / seed_s, "unit": "reads/s", "ms_per_pass": seed_s * 1e3,
                         "work_per_pass": {"lf_steps": S, "threshold_jumps": J, "phi_steps": P, "text_bytes": C, "mems": n_mems, "occs": n_occs}},
         }
+        if sq and stage["align_kernel"] > 0:
+            # integer-VALU view of align_kernel: wave-instructions counted by rocprofv3 (per launch of sq["reads_per_launch"] reads),
+            # priced against 256 CUs x 4 SIMDs x 32 lanes/cycle (MI355X_MICROARCH.md: a wave64 VALU op retires in 2 cycles) at 2.4 GHz
+            insts = sq["valu_wave_insts_per_launch"] * args.reads / sq["reads_per_launch"]
+            peak = 256 * 4 * 32 * 2.4e9
+            out["dp"]["valu"] = {"wave_insts_per_step": insts, "achieved_lane_ops_per_s": insts * 64 / stage["align_kernel"], "peak_lane_ops_per_s": peak,
+                                 "frac": insts * 64 / stage["align_kernel"] / peak,
+                                 "waves_parked_frac": sq["sq_wait_any_quad"] / sq["sq_wave_cycles_quad"],
+                                 "hbm_bytes_per_step": (sq["fetch_bytes_per_launch"] + sq["write_bytes_per_launch"]) * args.reads / sq["reads_per_launch"],
+                                 "source": sq["source"]}
         out["host"] = {"cpus_usable": host_cpus(), "cpu_count": os.cpu_count(), "host_threads_per_gpu": threads}
         if world == 1 and not args.no_cpu:
             from oracle import orc as _orc          # the CPU baseline / at-scale checker: the only use of oracle/ in this file

@@ -643,7 +643,8 @@ struct Aligner {
     }
     bool emit_record(OutBuf& ob, std::vector<char>& md_scratch, const char* name, size_t name_len, const uint8_t* rd, const uint8_t* ql, uint32_t m,
                      bool aligned, uint32_t strand, uint64_t ref_pos, int32_t score, int32_t score2, const uint32_t* cig, uint32_t n_cig,
-                     const moni_alt_like* alts, uint32_t n_alt) const {
+                     const moni_alt_like* alts, uint32_t n_alt, const char* md_given = nullptr, uint32_t md_given_len = 0, int nm_given = 0) const {
+        // md_given: MD:Z text and NM computed by the align kernel (same rule, where read and text are resident); else computed here
         uint64_t ref_len = 0, del_len = 0;
         for (uint32_t k = 0; k < n_cig; ++k) { const uint32_t c = cig[k]; const int op = c & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4; if (op == 2) del_len += c >> 4; }
         if (!ob.ensure(record_bound(name_len, m, n_cig, n_alt) + 2 * del_len)) return false;
@@ -658,10 +659,14 @@ struct Aligner {
             return true;
         }
         // MD / NM over the window the CIGAR spans (write_MD_core); NM is printed before MD, so MD goes through a scratch
-        { const size_t need = 3 * (size_t)m + 2 * del_len + 40 * (size_t)n_cig + 64; if (md_scratch.size() < need) md_scratch.resize(need); }
+        { const size_t need = 3 * (size_t)m + 2 * del_len + 40 * (size_t)n_cig + 64 + (md_given ? (size_t)md_given_len : 0); if (md_scratch.size() < need) md_scratch.resize(need); }
         char* const md0 = md_scratch.data(); char* md = md0;
         int NM = 0;
-        {
+        if (md_given) {
+            memcpy(md, md_given, md_given_len);
+            md += md_given_len;
+            NM = nm_given;
+        } else {
             int l_MD = 0; uint64_t t = ref_pos; uint32_t q = 0;
             auto tb = [&](uint64_t a) -> uint8_t { return nt4_of(a < ix.n_text ? ix.text[a] : 0); };
             auto qb = [&](uint32_t k) -> uint8_t { return nt4_of(strand ? compl_of(rd[m - 1 - k]) : rd[k]); };

@@ -13,6 +13,7 @@
 #define AK_CIG_CAP 4096u                     // CIGAR entries of one round's traceback problems (each takes qlen + tlen + 2)
 #define AK_DIRS_CAP (384u * 1024u)           // direction bytes of one CIGAR problem
 #define AK_CUR 32                            // statistics / cursor words per launch
+#define AK_MD_CAP 1536                       // bytes of MD text per read (longer: the host pipeline takes the read)
 #define AK_MEMO 24                           // score-only DP results remembered per read
 
 struct moni_aln_rec_t {                      // one per read
@@ -22,6 +23,9 @@ struct moni_aln_rec_t {                      // one per read
     int32_t score, score2;
     uint32_t n_cigar, n_alt;
     uint64_t cigar_off, alt_off;             // into the pools
+    int32_t nm;                              // NM and the MD:Z text (write_MD_core, sam.hpp:249-287), computed where the read and the text are resident
+    uint32_t md_len;
+    uint64_t md_off;                         // into the MD pool (8-byte aligned)
 };
 struct moni_alt_t { uint64_t pos; int32_t score; int32_t pad; };
 
@@ -36,6 +40,7 @@ struct ak_slot_t {                           // per read in flight, in HBM
     ac_ws_t ws;
     moni_dp_result_t res[AC_MAX_TASKS];      // results of the round's DP problems
     uint32_t cig[AK_CIG_CAP];
+    uint64_t md_tmp[AK_MD_CAP / 8];
     uint64_t memo_key[AK_MEMO], memo_toff[AK_MEMO];
     moni_dp_result_t memo_res[AK_MEMO];
     uint32_t memo_n, pad;
@@ -72,24 +77,88 @@ struct ak_args_t {
     moni_aln_rec_t* recs;
     uint32_t* cig_pool; uint64_t cig_cap;
     moni_alt_t* alt_pool; uint64_t alt_cap;
+    uint64_t* md_pool; uint64_t md_cap;          // in 8-byte words
     unsigned long long* cursors;             // [0] cigar pool, [1] alt pool, [2] DP problems run, [3] their cells, [4] next read, [5..7] wave cycles: serial
-                                             // phases (init+first drive, later drives), dp, [8] DP problems answered from the per-read memo, [9] their cells
+                                             // phases (init+first drive, later drives), dp, [8] DP problems answered from the per-read memo, [9] their cells,
+                                             // [14] MD pool (words)
 };
 
+// MD:Z text and NM of the final alignment (write_MD_core, sam.hpp:249-287), lane-private: read and text bytes through one-word
+// register caches, text staged in the slot.  Returns the length, or -1 when it does not fit AK_MD_CAP.
+__device__ __attribute__((noinline)) int ak_md(const ak_args_t& A, const ac_ws_t& W, uint8_t* __restrict__ md, int32_t& nm_out) {
+    const uint8_t* __restrict__ text = A.D.text;
+    const uint8_t* __restrict__ reads = A.D.reads;
+    const uint64_t n_text = A.D.n_text, off = W.off;
+    const uint32_t m = W.m, strand = W.fill.strand;
+    // byte streams through two-word register caches: the word after the current one is requested as soon as the current one is
+    // entered, so its latency overlaps the comparison of eight bases (dir = +1 text and forward reads, -1 reverse-strand reads)
+    struct stream_t { const uint8_t* base; uint64_t w, word, nw, nword; };
+    auto get = [](stream_t& c, uint64_t a, long dir) -> uint32_t {
+        const uint64_t w = a >> 3;
+        if (w != c.w) {
+            if (w == c.nw) c.word = c.nword; else c.word = *reinterpret_cast<const uint64_t*>(c.base + (w << 3));
+            c.w = w;
+            if (dir < 0 && w == 0) c.nw = ~0ull;                  // nothing before the first word (buffers are padded at the end only)
+            else { c.nw = (uint64_t)((long long)w + dir); c.nword = *reinterpret_cast<const uint64_t*>(c.base + (c.nw << 3)); }
+        }
+        return (uint32_t)(c.word >> (8 * (a & 7))) & 0xFFu;
+    };
+    stream_t ts; ts.base = text; ts.w = ts.nw = ~0ull; ts.word = ts.nword = 0;
+    stream_t rs; rs.base = reads; rs.w = rs.nw = ~0ull; rs.word = rs.nword = 0;
+    auto tb = [&](uint64_t a) -> uint32_t { return dp_nt4(a < n_text ? get(ts, a, 1) : 0u); };
+    auto qb = [&](uint32_t k) -> uint32_t {
+        if (!strand) return dp_nt4(get(rs, off + k, 1));
+        uint32_t b = get(rs, off + m - 1 - k, -1);                                // compl_of (kpbseq.h:120-137), then nt4
+        const uint32_t u = b & 0xDFu;
+        b = u == 'A' ? 'T' : u == 'C' ? 'G' : u == 'G' ? 'C' : u == 'T' ? 'A' : b;
+        return dp_nt4(b);
+    };
+    int n = 0, NM = 0, l_MD = 0;
+    bool ovf = false;
+    auto putc = [&](uint8_t ch) { if (n < AK_MD_CAP) md[n++] = ch; else ovf = true; };
+    auto puti = [&](int v) { char b[12]; int k = 0; unsigned u = (unsigned)v; do { b[k++] = (char)('0' + u % 10); u /= 10; } while (u); while (k) putc((uint8_t)b[--k]); };
+    uint64_t t = W.fill.ref_pos; uint32_t q = 0;
+    for (uint32_t i = 0; i < W.n_cigar; ++i) {
+        const int op = W.cigar[i] & 0xf, len = (int)(W.cigar[i] >> 4);
+        if (op == 0) {
+            for (int j = 0; j < len; ++j) {
+                const uint32_t tc = tb(t + j);
+                if (qb(q + j) != tc) { puti(l_MD); putc((uint8_t)"ACGTN"[tc]); l_MD = 0; ++NM; }
+                else ++l_MD;
+            }
+            q += len; t += len;
+        } else if (op == 1) { q += len; NM += len; }
+        else if (op == 2) {
+            puti(l_MD); putc('^');
+            for (int j = 0; j < len; ++j) putc((uint8_t)"ACGTN"[tb(t + j)]);
+            l_MD = 0; t += len; NM += len;
+        }
+    }
+    if (l_MD > 0) puti(l_MD);
+    nm_out = NM;
+    return ovf ? -1 : n;
+}
+
 // the record of a finished read (lane-private)
-__device__ __attribute__((noinline)) void ak_write_record(const ak_args_t& A, const ac_ws_t& W, uint64_t slot_in_launch) {
+__device__ __attribute__((noinline)) void ak_write_record(const ak_args_t& A, const ac_ws_t& W, uint64_t* __restrict__ md_tmp, uint64_t slot_in_launch) {
     moni_aln_rec_t rec;
     rec.status = W.overflow ? 2u : (W.aligned ? 1u : 0u);
     rec.strand = W.fill.strand; rec.ref_pos = W.fill.ref_pos; rec.score = W.fill.score; rec.score2 = W.score2;
-    rec.n_cigar = 0; rec.n_alt = 0; rec.cigar_off = 0; rec.alt_off = 0;
+    rec.n_cigar = 0; rec.n_alt = 0; rec.cigar_off = 0; rec.alt_off = 0; rec.nm = 0; rec.md_len = 0; rec.md_off = 0;
     if (rec.status == 1) {
+        int32_t nm = 0;
+        const int md_len = ak_md(A, W, reinterpret_cast<uint8_t*>(md_tmp), nm);
+        const unsigned long long md_words = md_len > 0 ? (unsigned long long)((md_len + 7) >> 3) : 0ull;
         const unsigned long long co = atomicAdd(&A.cursors[0], (unsigned long long)W.n_cigar);
         const unsigned long long ao = atomicAdd(&A.cursors[1], (unsigned long long)W.n_alt);
-        if (co + W.n_cigar > A.cig_cap || ao + W.n_alt > A.alt_cap) rec.status = 2;      // pool too small: let the host pipeline redo the read
+        const unsigned long long mo = atomicAdd(&A.cursors[14], md_words);
+        if (md_len < 0 || co + W.n_cigar > A.cig_cap || ao + W.n_alt > A.alt_cap || mo + md_words > A.md_cap) rec.status = 2;      // pool too small: let the host pipeline redo the read
         else {
             rec.n_cigar = W.n_cigar; rec.cigar_off = co; rec.n_alt = W.n_alt; rec.alt_off = ao;
+            rec.nm = nm; rec.md_len = (uint32_t)md_len; rec.md_off = mo;
             for (uint32_t k = 0; k < W.n_cigar; ++k) A.cig_pool[co + k] = W.cigar[k];
             for (uint32_t k = 0; k < W.n_alt; ++k) { moni_alt_t x; x.pos = W.alt_pos[k]; x.score = W.alt_score[k]; x.pad = 0; A.alt_pool[ao + k] = x; }
+            for (unsigned long long k = 0; k < md_words; ++k) A.md_pool[mo + k] = md_tmp[k];
         }
     }
     A.recs[slot_in_launch] = rec;
@@ -110,12 +179,14 @@ align_kernel(const ak_args_t A) {
     ac_ws_t& W = S->ws;
     uint8_t* __restrict__ dirs = A.waves[blockIdx.x].dirs;
     if (lane < AK_NL) for (int k = 0; k < 6; ++k) W.prof[k] = 0;
-    int state = lane < AK_NL ? 0 : 2;             // 0: wants a read, 1: waits for DP results, 2: no more reads
+    int state = lane < AK_NL ? 0 : 2;             // 0: wants a read, 1: waits for DP results, 2: no more reads, 3: finished, record not yet written
     uint64_t r_in = 0;                            // read index inside the launch
     while (true) {
         // ---- phase 1 (lane-private): take a read; seeds -> chains -> first DP request ----
         const long long c0 = clock64();
-        const bool start = __popcll(__ballot(state == 0)) >= AK_START_MIN || __ballot(state == 1) == 0ull;
+        const bool start = __popcll(__ballot(state == 0 || state == 3)) >= AK_START_MIN || __ballot(state == 1) == 0ull;
+        // finished reads write their records (MD/NM, pool entries) together, like the starts: it is lane-private work too
+        if (state == 3 && start) { ak_write_record(A, W, S->md_tmp, r_in); state = 0; }
         if (state == 0 && start) {
             r_in = atomicAdd(&A.cursors[4], 1ull);
             if (r_in >= A.n_reads) state = 2;
@@ -127,13 +198,13 @@ align_kernel(const ak_args_t A) {
                 const bool chained = ac_init(W, A.P, A.mems, A.read_mem_off[r], A.read_mem_off[r + 1], A.occs);
                 if (chained) ac_drive(W, A.P, nullptr, nullptr);
                 if (chained && !W.overflow && W.stage != AC_DONE) state = 1;
-                else ak_write_record(A, W, r_in);
+                else ak_write_record(A, W, S->md_tmp, r_in);
             }
         }
         const unsigned long long waiting = __ballot(state == 1);
         const long long c1 = clock64();
         if (lane == 0) s_cnt[C_INIT] += (unsigned long long)(c1 - c0);
-        if (waiting == 0ull) { if (__ballot(state == 0) == 0ull) break; continue; }
+        if (waiting == 0ull) { if (__ballot(state == 0 || state == 3) == 0ull) break; continue; }
         __threadfence();
         // ---- phase 2 (whole wave): the DP problems of every waiting read, one read after the other ----
         for (unsigned long long todo = waiting; todo; todo &= todo - 1) {
@@ -222,7 +293,7 @@ align_kernel(const ak_args_t A) {
         // ---- phase 3 (lane-private): results -> next DP request, or the finished record ----
         if (state == 1) {
             if (!W.overflow) ac_drive(W, A.P, S->res, S->cig);
-            if (W.overflow || W.stage == AC_DONE) { ak_write_record(A, W, r_in); state = 0; }
+            if (W.overflow || W.stage == AC_DONE) state = 3;
         }
         if (lane == 0) s_cnt[C_DRIVE] += (unsigned long long)(clock64() - c2);
     }

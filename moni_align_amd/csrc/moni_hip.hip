@@ -121,7 +121,7 @@ struct moni_ctx {
     uint64_t ak_waves_full = 0;
     hipStream_t ak_stream[2] = {nullptr, nullptr}, copy_stream = nullptr;
     std::vector<hipEvent_t> ak_begin, ak_done;
-    HBuf<moni_aln_rec_t> h_recs; HBuf<uint32_t> h_cig; HBuf<moni_alt_t> h_alt;      // pinned staging of one sub-batch's records
+    HBuf<moni_aln_rec_t> h_recs; HBuf<uint32_t> h_cig; HBuf<moni_alt_t> h_alt; HBuf<uint64_t> h_md;      // pinned staging of one sub-batch's records
     std::vector<mh::Aligner::OutBuf> pieces;          // per host thread: the text it is writing (kept across batches)
     std::vector<std::vector<char>> md_scratch;
     DBuf<moni_aln_rec_t> ak_recs;
@@ -279,7 +279,7 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
     c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
     c->dp_q.release(); c->dp_t.release(); c->dp_dir.release(); c->dp_tasks.release(); c->dp_res.release(); c->dp_cig.release();
-    c->dp_off.release(); c->dp_ws.release(); c->dp_big.release(); c->dp_dir_big.release(); c->ak_slots.release(); c->ak_waves.release(); c->ak_cursors.release(); c->h_recs.release(); c->h_cig.release(); c->h_alt.release();
+    c->dp_off.release(); c->dp_ws.release(); c->dp_big.release(); c->dp_dir_big.release(); c->ak_slots.release(); c->ak_waves.release(); c->ak_cursors.release(); c->h_recs.release(); c->h_cig.release(); c->h_alt.release(); c->h_md.release();
     for (auto& ob : c->pieces) ob.release();
     for (int x = 0; x < 2; ++x) if (c->ak_stream[x]) (void)hipStreamDestroy(c->ak_stream[x]);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -715,9 +715,9 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         // records, CIGARs and alternative hits are written by the kernel straight into pinned host memory (a few hundred
         // bytes per read over PCIe): no copy has to find room next to the persistent kernels.  Pool share of one sub-batch
         // below; a launch that runs out hands the affected reads back (status 2)
-        const uint64_t cig_per = 16 * sub_reads + 4096, alt_per = 24 * sub_reads + 4096;
+        const uint64_t cig_per = 16 * sub_reads + 4096, alt_per = 24 * sub_reads + 4096, md_per = 8 * sub_reads + 4096;      // md: 8-byte words
         if ((rc = c->ak_slots.ensure(2 * waves_full * AK_NL)) || (rc = c->ak_waves.ensure(2 * waves_full)) || (rc = c->h_recs.ensure(NR + 1)) ||
-            (rc = c->h_cig.ensure(cig_per * n_sub + 1)) || (rc = c->h_alt.ensure(alt_per * n_sub + 1)) || (rc = c->ak_minscore.ensure(msc.size())) ||
+            (rc = c->h_cig.ensure(cig_per * n_sub + 1)) || (rc = c->h_alt.ensure(alt_per * n_sub + 1)) || (rc = c->h_md.ensure(md_per * n_sub + 1)) || (rc = c->ak_minscore.ensure(msc.size())) ||
             (rc = c->ak_cursors.ensure(AK_CUR * n_sub + AK_CUR)))
             return rc;
         for (int x = 0; x < 2; ++x) if (!c->ak_stream[x]) HIPCHK(hipStreamCreateWithFlags(&c->ak_stream[x], hipStreamNonBlocking));
@@ -746,7 +746,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             A.min_score_of_len = c->ak_minscore.p; A.max_len = (uint32_t)c->max_len + 1; A.read_lo = r0; A.n_reads = nr;
             A.slots = c->ak_slots.p + (k & 1) * waves_full * AK_NL; A.waves = c->ak_waves.p + (k & 1) * waves_full;
             A.recs = c->h_recs.p + r0; A.cig_pool = c->h_cig.p + k * cig_per; A.cig_cap = cig_per; A.alt_pool = c->h_alt.p + k * alt_per;
-            A.alt_cap = alt_per; A.cursors = c->ak_cursors.p + AK_CUR * k;
+            A.alt_cap = alt_per; A.md_pool = c->h_md.p + k * md_per; A.md_cap = md_per; A.cursors = c->ak_cursors.p + AK_CUR * k;
             hipStream_t sx = c->ak_stream[k & 1];
             HIPCHK(hipEventRecord(c->ak_begin[k], sx));
             hipLaunchKernelGGL(align_kernel, dim3((unsigned)n_waves), dim3(64), 0, sx, A);
@@ -755,14 +755,14 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         }
         t_launch[1] = mh::now_s() - t_enter;
         // host side: follows the launches
-        struct SubRes { moni_aln_rec_t* recs = nullptr; uint32_t* cig = nullptr; moni_alt_t* alt = nullptr; uint64_t nr = 0; };
+        struct SubRes { moni_aln_rec_t* recs = nullptr; uint32_t* cig = nullptr; moni_alt_t* alt = nullptr; const uint64_t* md = nullptr; uint64_t nr = 0; };
         int rc_host = MONI_OK;
         auto fetch = [&](uint64_t k, SubRes& R) -> int {            // records of sub-batch k into pinned host memory
             const uint64_t r0 = sub_lo[k], nr = sub_lo[k + 1] - sub_lo[k];
             const double f0 = mh::now_s();
             HIPCHK(hipEventSynchronize(c->ak_done[k]));
             const double f1 = mh::now_s();
-            R.recs = c->h_recs.p + r0; R.cig = c->h_cig.p + k * cig_per; R.alt = c->h_alt.p + k * alt_per; R.nr = nr;
+            R.recs = c->h_recs.p + r0; R.cig = c->h_cig.p + k * cig_per; R.alt = c->h_alt.p + k * alt_per; R.md = c->h_md.p + k * md_per; R.nr = nr;
             if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "  sub-batch %llu: waited for the launch from %.1f to %.1f ms\n", (unsigned long long)k, (f0 - t_enter) * 1e3, (f1 - t_enter) * 1e3);
             if (force_back) for (uint64_t r = 0; r < nr; ++r) if ((r0 + r) % force_back == 0) R.recs[r].status = 2;
             { float ms = 0; if (hipEventElapsedTime(&ms, c->ak_begin[k], c->ak_done[k]) == hipSuccess) { c->dp_kernel_ms_accum += ms; c->ak_kernel_ms = ms; } }
@@ -785,7 +785,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                     const uint64_t off = b->offsets[g]; const uint32_t m = (uint32_t)(b->offsets[g + 1] - off);
                     if (!AL.emit_record(ob, mds, (const char*)names + name_off[g], (size_t)(name_off[g + 1] - name_off[g]), b->seq + off, quals ? quals + off : nullptr, m,
                                         Rr.status == 1, Rr.strand, Rr.ref_pos, Rr.score, Rr.score2, R.cig + Rr.cigar_off, Rr.n_cigar,
-                                        (const mh::moni_alt_like*)R.alt + Rr.alt_off, Rr.n_alt)) { oom = true; break; }
+                                        (const mh::moni_alt_like*)R.alt + Rr.alt_off, Rr.n_alt,
+                                        Rr.status == 1 ? (const char*)(R.md + Rr.md_off) : nullptr, Rr.md_len, Rr.nm)) { oom = true; break; }
                     if (Rr.status == 1) aligned_t[t]++;
                 }
             });

@@ -171,7 +171,7 @@ def main():
         achieved = ms_bytes / ms_s / 1e9 if ms_s > 0 else 0.0
         value = world * args.reads * args.steps / elapsed
         out = {
-            "metric": "aligned reads/s (whole node), 150 bp SE, mouse-chr19-scale x%d-haplotype index" % args.haps,
+            "metric": "aligned reads/s (whole node), %d bp SE, mouse-chr19-scale x%d-haplotype index" % (L, args.haps),
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64/int32", "data": "synthetic",
@@ -200,7 +200,7 @@ def main():
                         "value": world * args.reads / seed_s, "unit": "reads/s", "ms_per_pass": seed_s * 1e3,
                         "work_per_pass": {"lf_steps": S, "threshold_jumps": J, "phi_steps": P, "text_bytes": C, "mems": n_mems, "occs": n_occs}},
         }
-        if sq and stage["align_kernel"] > 0:
+        if sq and stage["align_kernel"] > 0 and traffic is not None:        # same workload as the profiled one (traffic matched n / reads / read_len)
             # integer-VALU view of align_kernel: wave-instructions counted by rocprofv3 (per launch of sq["reads_per_launch"] reads),
             # priced against 256 CUs x 4 SIMDs x 32 lanes/cycle (MI355X_MICROARCH.md: a wave64 VALU op retires in 2 cycles) at 2.4 GHz
             insts = sq["valu_wave_insts_per_launch"] * args.reads / sq["reads_per_launch"]

@@ -271,7 +271,7 @@ align_kernel(const ak_args_t A) {
                 if (hit >= 0) {
                     if (lane == 0) { moni_dp_result_t x = Q->memo_res[hit]; x.cigar_off = cig_at; Q->res[t] = x; s_cnt[C_MEMO]++; s_cnt[C_MEMO_CELLS] += cells; }
                 } else {
-                    extz_wave_lds(A.D, task, L, dirs, cg, &Q->res[t]);
+                    extz_wave_lds_lite(A.D, task, L, dirs, cg, &Q->res[t]);
                     if (lane == 0) {
                         s_cnt[C_DP]++; s_cnt[C_CELLS] += cells;
                         { const int lr = task.qlen < task.tlen ? task.qlen : task.tlen; const int b = lr <= 16 ? 0 : lr <= 32 ? 1 : lr <= 64 ? 2 : 3; s_hist[b]++; s_hist[4 + b] += cells; }

@@ -284,15 +284,19 @@ struct dp_lds_t {
 
 // ST: where the per-row state lives - dp_lds_t (LDS; align_kernel, extz_lds_kernel) or dp_big_t (HBM; problems too large for it).
 // tile: 2 KB of LDS for the traceback (may overlay ST's H buffers when those are in LDS: they are dead by then).
-template <class ST>
-__device__ __forceinline__ void extz_wave_tiled(const dp_launch_t& P, const moni_dp_task_t task, ST& L, uint8_t* __restrict__ tile,
+// TRACK: what is kept about the maximum cell (ez->max, max_t, max_q).  2 = everything, as ksw2 does (the stand-alone kernels);
+// 1 = its value only - enough to decide reach_end, the function returns true when the traceback would have to start at the
+// maximum cell and the caller runs it again with TRACK = 2; 0 = nothing (score-only problems of align_kernel, whose logic
+// reads mqe / mqe_t / score only: the max fields of the result are then 0 / -1).
+template <class ST, int TRACK>
+__device__ __forceinline__ bool extz_wave_tiled(const dp_launch_t& P, const moni_dp_task_t task, ST& L, uint8_t* __restrict__ tile,
                                                 uint8_t* __restrict__ dir_base, uint32_t* __restrict__ cg_base, moni_dp_result_t* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int qlen = task.qlen, tlen = task.tlen, flag = task.flag;
     moni_dp_result_t R;                      // lane 0 writes it to *out (LDS or global) at the end
     R.max = 0; R.max_q = R.max_t = R.mqe_t = R.mte_q = -1; R.mqe = R.mte = R.score = DP_NEG_INF;
     R.reach_end = 0; R.zdropped = 0; R.n_cigar = 0; R.cigar_off = 0;
-    if (qlen <= 0 || tlen <= 0) { if (lane == 0) *out = R; return; }
+    if (qlen <= 0 || tlen <= 0) { if (lane == 0) *out = R; return false; }
     const bool with_cigar = !(flag & DP_EZ_SCORE_ONLY);
     const bool right = (flag & DP_EZ_RIGHT) != 0;
     const int mode = task.reserved;
@@ -383,8 +387,10 @@ __device__ __forceinline__ void extz_wave_tiled(const dp_launch_t& P, const moni
             if (act) {
                 if (with_cigar) dir[(uint32_t)r * (uint32_t)tlen + (uint32_t)i] = (uint8_t)d;
                 Hn[i] = z; L.E[i] = E; L.F[i] = F;
-                if (z > max_z) { max_z = z; max_r = r; max_i = i; }
-                else if (z == max_z && max_r == r && z > 0 && rank_of(r, i) < rank_of(r, max_i)) max_i = i;
+                if (TRACK == 2) {
+                    if (z > max_z) { max_z = z; max_r = r; max_i = i; }
+                    else if (z == max_z && max_r == r && z > 0 && rank_of(r, i) < rank_of(r, max_i)) max_i = i;
+                } else if (TRACK == 1) max_z = z > max_z ? z : max_z;
             }
         };
         int c = (en0 - st0) >> 6;
@@ -403,7 +409,7 @@ __device__ __forceinline__ void extz_wave_tiled(const dp_launch_t& P, const moni
             finish(i, act, in);
         }
         if (!ST::in_lds) __threadfence_block();
-        if (en0 == tlen - 1) {                               // the last row's cell of this diagonal (mte, score)
+        if (TRACK == 2 ? en0 == tlen - 1 : r == n_diag - 1) {    // the last row's cell of this diagonal (mte; score is its last value)
             const int32_t z = Hn[tlen - 1];
             last_h = z;
             if (z > mte_h) { mte_h = z; mte_q = r - en_r; }
@@ -428,8 +434,13 @@ __device__ __forceinline__ void extz_wave_tiled(const dp_launch_t& P, const moni
                                                        (unsigned long long)(uint32_t)(0x7FFFFFFF - (mqe_i < 0 ? 0x7FFFFFFF : mqe_i))));
     R.mqe = (int32_t)(mqe_key >> 32);
     R.mqe_t = 0x7FFFFFFF - (int32_t)(mqe_key & 0xFFFFFFFFll);
-    max_key = wave_max_i64(max_key);
-    if (max_key >= 0) {
+    if (TRACK == 1) {
+        int32_t v = max_z;
+        for (int o = 32; o > 0; o >>= 1) { const int32_t w2 = __shfl_xor(v, o); v = w2 > v ? w2 : v; }
+        R.max = v;
+    }
+    if (TRACK == 2) max_key = wave_max_i64(max_key);
+    if (TRACK == 2 && max_key >= 0) {
         R.max = (int32_t)(max_key >> 32);
         const int rr = 0xFFFF - (int)((max_key >> 16) & 0xFFFF);
         const int rank = 0xFFFF - (int)(max_key & 0xFFFF);
@@ -448,6 +459,7 @@ __device__ __forceinline__ void extz_wave_tiled(const dp_launch_t& P, const moni
         int i0 = -1, j0 = -1;
         if (!(flag & DP_EZ_EXTZ_ONLY)) { i0 = tlen - 1; j0 = qlen - 1; }
         else if (R.mqe + P.end_bonus > R.max) { R.reach_end = 1; i0 = R.mqe_t; j0 = qlen - 1; }
+        else if (TRACK != 2) return true;                   // the traceback starts at the maximum cell: its position is needed
         else if (R.max_t >= 0 && R.max_q >= 0) { i0 = R.max_t; j0 = R.max_q; }
         if (i0 >= 0 && j0 >= 0) {
             // traceback, the whole wave in step (i, j and the state are uniform): direction bytes come through LDS in tiles of
@@ -491,11 +503,23 @@ __device__ __forceinline__ void extz_wave_tiled(const dp_launch_t& P, const moni
     }
     if (lane == 0) *out = R;
     __syncthreads();
+    return false;
 }
 
 __device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, const moni_dp_task_t task, dp_lds_t& L,
                                                         uint8_t* __restrict__ dir_base, uint32_t* __restrict__ cg_base, moni_dp_result_t* __restrict__ out) {
-    extz_wave_tiled(P, task, L, reinterpret_cast<uint8_t*>(&L.H[0][0]), dir_base, cg_base, out);
+    extz_wave_tiled<dp_lds_t, 2>(P, task, L, reinterpret_cast<uint8_t*>(&L.H[0][0]), dir_base, cg_base, out);
+}
+// align_kernel's form: no maximum-cell bookkeeping for score-only problems, its value only for traceback problems (and the full
+// run again in the rare case the traceback has to start there)
+__device__ __attribute__((noinline)) void extz_wave_lds_lite(const dp_launch_t& P, const moni_dp_task_t task, dp_lds_t& L,
+                                                             uint8_t* __restrict__ dir_base, uint32_t* __restrict__ cg_base, moni_dp_result_t* __restrict__ out) {
+    uint8_t* tile = reinterpret_cast<uint8_t*>(&L.H[0][0]);
+    if (task.flag & DP_EZ_SCORE_ONLY) { extz_wave_tiled<dp_lds_t, 0>(P, task, L, tile, dir_base, cg_base, out); return; }
+    if (extz_wave_tiled<dp_lds_t, 1>(P, task, L, tile, dir_base, cg_base, out)) {
+        __syncthreads();
+        extz_wave_tiled<dp_lds_t, 2>(P, task, L, tile, dir_base, cg_base, out);
+    }
 }
 
 // problems beyond the LDS form's 512 target rows / 512 query bases (long reads in the host pipeline): same code, state in HBM
@@ -516,7 +540,7 @@ extz_big_kernel(const dp_launch_t P, dp_big_t* __restrict__ states) {
     const uint32_t tix = P.order[blockIdx.x];
     const moni_dp_task_t task = P.tasks[tix];
     const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
-    extz_wave_tiled(P, task, states[blockIdx.x], tile, with_cigar ? P.dirs + P.dir_off[tix] : nullptr, with_cigar ? P.cig_tmp + P.cig_off[tix] : nullptr, &P.results[tix]);
+    extz_wave_tiled<dp_big_t, 2>(P, task, states[blockIdx.x], tile, with_cigar ? P.dirs + P.dir_off[tix] : nullptr, with_cigar ? P.cig_tmp + P.cig_off[tix] : nullptr, &P.results[tix]);
 }
 
 __global__ void __launch_bounds__(64)

@@ -30,9 +30,9 @@
 #endif
 
 #define AC_MAX_MEMS 96
-#define AC_MAX_ANCH 768
+#define AC_MAX_ANCH 512
 #define AC_MAX_CHAINS 256
-#define AC_MAX_POOL 2048        // anchors of all chains
+#define AC_MAX_POOL 1024        // anchors of all chains
 #define AC_MAX_BEST 64
 #define AC_MAX_LEFT 256
 #define AC_MAX_ALT 64

@@ -30,7 +30,7 @@ struct moni_aln_rec_t {                      // one per read
 struct moni_alt_t { uint64_t pos; int32_t score; int32_t pad; };
 
 #ifndef AK_NL
-#define AK_NL 32                             // reads in flight per wavefront: lanes 0..AK_NL-1 each run one read's state machine
+#define AK_NL 64                             // reads in flight per wavefront: lanes 0..AK_NL-1 each run one read's state machine
 #endif
 #ifndef AK_START_MIN
 #define AK_START_MIN (AK_NL / 2)             // free lanes take new reads together, once this many are free (or nobody waits for DP):

@@ -660,7 +660,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         const uint64_t NR = b->n_reads;
         // sub-batch schedule: a small first launch (the host stage starts after it), larger ones in the middle (a launch wants
         // several reads per lane in flight: ~4000 waves x AK_NL lanes), a small last one (the host stage left over after it is short)
-        uint64_t sub_min = 125000, sub_mid = 125000;      // measured: equal pieces do as well as larger middle or smaller end pieces (profiles/sweep_align_nl.sh)
+        uint64_t sub_min = 250000, sub_mid = 250000;      // ~one read per lane and launch (4096 waves x AK_NL = 64 lanes); equal pieces: measured, profiles/sweep_align_nl.sh
         if (const char* v = getenv("MONI_ALIGN_SUB")) { const long long x = atoll(v); if (x > 0) sub_min = sub_mid = (uint64_t)x; }
         std::vector<uint64_t> sub_lo(1, 0);
         while (sub_lo.back() < NR) {

@@ -42,7 +42,7 @@ struct ak_slot_t {                           // per read in flight, in HBM
     uint32_t cig[AK_CIG_CAP];
     uint64_t md_tmp[AK_MD_CAP / 8];
     uint64_t memo_key[AK_MEMO], memo_toff[AK_MEMO];
-    moni_dp_result_t memo_res[AK_MEMO];
+    dp_brief_t memo_val[AK_MEMO];           // mqe, mqe_t, score of the remembered problem
     uint32_t memo_n, pad;
 };
 struct ak_wave_t { uint8_t dirs[AK_DIRS_CAP]; };      // per wavefront: direction bytes of the CIGAR problem being solved
@@ -211,13 +211,21 @@ align_kernel(const ak_args_t A) {
             const int src = __ffsll((long long)todo) - 1;
             const long long y0 = clock64();
             ak_slot_t* __restrict__ Q = A.slots + (size_t)blockIdx.x * AK_NL + src;
+            // everything phase 2 needs of this read in one round trip: its DP requests (all AC_MAX_TASKS slots, the count decides
+            // later) and its memo (lane e holds entry e: key, target offset, the three result words)
+            const uint32_t* __restrict__ tsrc = reinterpret_cast<const uint32_t*>(Q->ws.tasks);
+            constexpr uint32_t TW = AC_MAX_TASKS * (uint32_t)(sizeof(moni_dp_task_t) / 4);
+            const uint32_t tw0 = tsrc[lane], tw1 = tsrc[lane + 64], tw2 = (uint32_t)lane + 128 < TW ? tsrc[lane + 128] : 0u;
+            static_assert(TW > 128 && TW <= 192, "task staging assumes three words per lane");
             const uint32_t nt = Q->ws.n_tasks;
             const uint64_t read_off = Q->ws.off;
-            __syncthreads();
-            for (uint32_t k = lane; k < nt * (uint32_t)(sizeof(moni_dp_task_t) / 4); k += 64) ((uint32_t*)s_tasks)[k] = ((const uint32_t*)Q->ws.tasks)[k];
             uint32_t memo_n = Q->memo_n;
-            uint64_t mk = (uint32_t)lane < memo_n ? Q->memo_key[lane] : ~0ull;      // lane e holds memo entry e
-            uint64_t mt = (uint32_t)lane < memo_n ? Q->memo_toff[lane] : 0ull;
+            uint64_t mk = lane < AK_MEMO ? Q->memo_key[lane] : ~0ull;
+            uint64_t mt = lane < AK_MEMO ? Q->memo_toff[lane] : 0ull;
+            dp_brief_t mv = Q->memo_val[lane < AK_MEMO ? lane : 0];
+            __syncthreads();
+            ((uint32_t*)s_tasks)[lane] = tw0; ((uint32_t*)s_tasks)[lane + 64] = tw1; if ((uint32_t)lane + 128 < TW) ((uint32_t*)s_tasks)[lane + 128] = tw2;
+            if ((uint32_t)lane >= memo_n) mk = ~0ull;
             __syncthreads();
             bool too_big = false;
             uint32_t cig_used = 0;
@@ -269,17 +277,21 @@ align_kernel(const ak_args_t A) {
                 const long long y2 = clock64();
                 if (lane == 0) s_cy[1] += (unsigned long long)(y2 - y1);
                 if (hit >= 0) {
-                    if (lane == 0) { moni_dp_result_t x = Q->memo_res[hit]; x.cigar_off = cig_at; Q->res[t] = x; s_cnt[C_MEMO]++; s_cnt[C_MEMO_CELLS] += cells; }
+                    if (lane == hit) {          // the lane that holds the entry writes the result: no load on this path
+                        moni_dp_result_t x;
+                        x.max = 0; x.max_q = x.max_t = -1; x.mqe = mv.mqe; x.mqe_t = mv.mqe_t; x.mte = DP_NEG_INF; x.mte_q = -1; x.score = mv.score;
+                        x.reach_end = 0; x.zdropped = 0; x.n_cigar = 0; x.cigar_off = cig_at;
+                        Q->res[t] = x;
+                    }
+                    if (lane == 0) { s_cnt[C_MEMO]++; s_cnt[C_MEMO_CELLS] += cells; }
                 } else {
-                    extz_wave_lds_lite(A.D, task, L, dirs, cg, &Q->res[t]);
+                    const dp_brief_t br = extz_wave_lds_lite(A.D, task, L, dirs, cg, &Q->res[t], cig_at);
                     if (lane == 0) {
                         s_cnt[C_DP]++; s_cnt[C_CELLS] += cells;
                         { const int lr = task.qlen < task.tlen ? task.qlen : task.tlen; const int b = lr <= 16 ? 0 : lr <= 32 ? 1 : lr <= 64 ? 2 : 3; s_hist[b]++; s_hist[4 + b] += cells; }
-                        moni_dp_result_t x = Q->res[t];
-                        if (memoable && memo_n < AK_MEMO) { Q->memo_key[memo_n] = key; Q->memo_toff[memo_n] = task.t_off; Q->memo_res[memo_n] = x; }
-                        x.cigar_off = cig_at; Q->res[t] = x;
+                        if (memoable && memo_n < AK_MEMO) { Q->memo_key[memo_n] = key; Q->memo_toff[memo_n] = task.t_off; Q->memo_val[memo_n] = br; }
                     }
-                    if (memoable && memo_n < AK_MEMO) { if ((uint32_t)lane == memo_n) { mk = key; mt = task.t_off; } ++memo_n; }
+                    if (memoable && memo_n < AK_MEMO) { if ((uint32_t)lane == memo_n) { mk = key; mt = task.t_off; mv = br; } ++memo_n; }
                     __syncthreads();
                     if (lane == 0) { const int lr = task.qlen < task.tlen ? task.qlen : task.tlen; s_cy[2 + (lr <= 16 ? 0 : lr <= 32 ? 1 : lr <= 64 ? 2 : 3)] += (unsigned long long)(clock64() - y2); }
                 }

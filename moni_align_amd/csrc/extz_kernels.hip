@@ -288,14 +288,18 @@ struct dp_lds_t {
 // 1 = its value only - enough to decide reach_end, the function returns true when the traceback would have to start at the
 // maximum cell and the caller runs it again with TRACK = 2; 0 = nothing (score-only problems of align_kernel, whose logic
 // reads mqe / mqe_t / score only: the max fields of the result are then 0 / -1).
+struct dp_brief_t { int32_t mqe, mqe_t, score; };      // what the aligner's logic reads of a score-only result
+
 template <class ST, int TRACK>
 __device__ __forceinline__ bool extz_wave_tiled(const dp_launch_t& P, const moni_dp_task_t task, ST& L, uint8_t* __restrict__ tile,
-                                                uint8_t* __restrict__ dir_base, uint32_t* __restrict__ cg_base, moni_dp_result_t* __restrict__ out) {
+                                                uint8_t* __restrict__ dir_base, uint32_t* __restrict__ cg_base, moni_dp_result_t* __restrict__ out,
+                                                uint32_t cigar_off = 0, dp_brief_t* brief = nullptr) {
     const int lane = threadIdx.x & 63;
     const int qlen = task.qlen, tlen = task.tlen, flag = task.flag;
     moni_dp_result_t R;                      // lane 0 writes it to *out (LDS or global) at the end
     R.max = 0; R.max_q = R.max_t = R.mqe_t = R.mte_q = -1; R.mqe = R.mte = R.score = DP_NEG_INF;
-    R.reach_end = 0; R.zdropped = 0; R.n_cigar = 0; R.cigar_off = 0;
+    R.reach_end = 0; R.zdropped = 0; R.n_cigar = 0; R.cigar_off = cigar_off;
+    if (brief) { brief->mqe = R.mqe; brief->mqe_t = R.mqe_t; brief->score = R.score; }
     if (qlen <= 0 || tlen <= 0) { if (lane == 0) *out = R; return false; }
     const bool with_cigar = !(flag & DP_EZ_SCORE_ONLY);
     const bool right = (flag & DP_EZ_RIGHT) != 0;
@@ -501,6 +505,7 @@ __device__ __forceinline__ bool extz_wave_tiled(const dp_launch_t& P, const moni
             R.n_cigar = (uint32_t)n;
         }
     }
+    if (brief) { brief->mqe = R.mqe; brief->mqe_t = R.mqe_t; brief->score = R.score; }      // uniform across the wave
     if (lane == 0) *out = R;
     __syncthreads();
     return false;
@@ -512,14 +517,17 @@ __device__ __attribute__((noinline)) void extz_wave_lds(const dp_launch_t& P, co
 }
 // align_kernel's form: no maximum-cell bookkeeping for score-only problems, its value only for traceback problems (and the full
 // run again in the rare case the traceback has to start there)
-__device__ __attribute__((noinline)) void extz_wave_lds_lite(const dp_launch_t& P, const moni_dp_task_t task, dp_lds_t& L,
-                                                             uint8_t* __restrict__ dir_base, uint32_t* __restrict__ cg_base, moni_dp_result_t* __restrict__ out) {
+__device__ __attribute__((noinline)) dp_brief_t extz_wave_lds_lite(const dp_launch_t& P, const moni_dp_task_t task, dp_lds_t& L,
+                                                                   uint8_t* __restrict__ dir_base, uint32_t* __restrict__ cg_base, moni_dp_result_t* __restrict__ out,
+                                                                   uint32_t cigar_off) {
     uint8_t* tile = reinterpret_cast<uint8_t*>(&L.H[0][0]);
-    if (task.flag & DP_EZ_SCORE_ONLY) { extz_wave_tiled<dp_lds_t, 0>(P, task, L, tile, dir_base, cg_base, out); return; }
-    if (extz_wave_tiled<dp_lds_t, 1>(P, task, L, tile, dir_base, cg_base, out)) {
+    dp_brief_t b;
+    if (task.flag & DP_EZ_SCORE_ONLY) { extz_wave_tiled<dp_lds_t, 0>(P, task, L, tile, dir_base, cg_base, out, cigar_off, &b); return b; }
+    if (extz_wave_tiled<dp_lds_t, 1>(P, task, L, tile, dir_base, cg_base, out, cigar_off, &b)) {
         __syncthreads();
-        extz_wave_tiled<dp_lds_t, 2>(P, task, L, tile, dir_base, cg_base, out);
+        extz_wave_tiled<dp_lds_t, 2>(P, task, L, tile, dir_base, cg_base, out, cigar_off, &b);
     }
+    return b;
 }
 
 // problems beyond the LDS form's 512 target rows / 512 query bases (long reads in the host pipeline): same code, state in HBM

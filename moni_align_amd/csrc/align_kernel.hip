@@ -195,7 +195,10 @@ align_kernel(const ak_args_t A) {
                 W.off = A.offs[r]; W.m = (uint32_t)(A.offs[r + 1] - A.offs[r]);
                 W.min_score = A.min_score_of_len[W.m <= A.max_len ? W.m : A.max_len];
                 S->memo_n = 0;
-                const bool chained = ac_init(W, A.P, A.mems, A.read_mem_off[r], A.read_mem_off[r + 1], A.occs);
+                bool chained = false;
+                if (W.m >= 4096) {                      // far beyond what the kernel's DP takes, and the chaining nodes keep read coordinates in 16 bits
+                    W.stage = AC_DONE; W.aligned = 0; W.overflow = 1; W.n_cigar = 0; W.n_tasks = 0; W.n_alt = 0; W.score2 = 0;
+                } else chained = ac_init(W, A.P, A.mems, A.read_mem_off[r], A.read_mem_off[r + 1], A.occs);
                 if (chained) ac_drive(W, A.P, nullptr, nullptr);
                 if (chained && !W.overflow && W.stage != AC_DONE) state = 1;
                 else ak_write_record(A, W, S->md_tmp, r_in);

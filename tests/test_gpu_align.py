@@ -107,8 +107,13 @@ def test_long_reads_go_through_the_hand_back_path(medium_case, env):
             k = rng.integers(0, ln, size=ln // 60)
             r[k] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(k))]
             base.insert(int(rng.integers(0, len(base))), r)
+    p0 = 5000
+    base.insert(7, np.array(text[p0:p0 + 4200], dtype=np.uint8).copy())      # >= 4096 bases: the kernel declines it outright
+    r = np.array(text[p0 + 9000:p0 + 12000], dtype=np.uint8).copy()
+    r[1500] = ord("A") if r[1500] != ord("A") else ord("C")
+    base.insert(50, r)
     _, st = both(env, base)
-    assert st["handed_back"] >= 1
+    assert st["handed_back"] >= 2
 
 
 def test_repeats_overflow_the_kernel_capacities(tmp_path):

@@ -1,9 +1,9 @@
-// Per-read logic of the full single-end path, STL-free, compiled for the device (one wavefront per read: lane 0 runs
-// this code, all 64 lanes run the DP problems it asks for) and for the host (tests/host_sim replays it).  It is the
+// Per-read logic of the full single-end path, STL-free, compiled for the device (align_kernel: every lane runs this code
+// for its own read, the whole wave runs the DP problems the reads ask for) and for the host (tests/host_sim replays it).  It is the
 // same algorithm as align_host.hpp — frequency filter, chaining, the chain-selection loop, fill_chain, CIGAR stitching —
 // over fixed-capacity arrays; a read that does not fit the capacities is flagged and goes through the host pipeline.
 //   chain.hpp:221-438, aligner_ksw2.hpp:328-521, 528-597, 1905-1933, 2018-2098, 2752-3108
-// What stays on the host for every read: MD/NM, MAPQ (double log), names, SAM text.
+// What stays on the host for every read: MAPQ (double log), names, SAM text (MD/NM are computed in align_kernel).
 #pragma once
 #include <stdint.h>
 

@@ -1,9 +1,10 @@
-// align_kernel: the whole per-read path after seeding in ONE launch, one wavefront per read (persistent waves, reads taken
-// in a grid-stride loop).  Lane 0 runs the read's state machine (align_core.h: frequency filter, chaining with the
-// libstdc++ sort emulation, chain-selection loop, fill_chain, CIGAR stitching); whenever it needs DP results all 64 lanes
-// run those problems (extz_wave), operands taken in place from the resident reads and the index text.  Seeds are read
-// where the seeding kernels left them in HBM: nothing goes to the host between stages.  Output per read: a fixed record
-// plus CIGAR / alternative-hit entries in bump-allocated pools; MD/NM, MAPQ and SAM text are host work.
+// align_kernel: the whole per-read path after seeding, persistent waves, AK_NL reads in flight per wavefront.  Every lane
+// runs one read's state machine (align_core.h: frequency filter, chaining with the libstdc++ sort emulation, chain-selection
+// loop, fill_chain, CIGAR stitching) out of its own slot in HBM; whenever reads need DP results the whole wave solves their
+// problems one after the other (extz_wave_lds_lite: LDS H/E/F tiles), operands taken in place from the resident reads and
+// the index text, identical problems of a read answered from a memo.  Seeds are read where the seeding kernels left them in
+// HBM: nothing goes to the host between stages.  Output per read: a fixed record plus CIGAR / alternative-hit / MD text
+// entries in bump-allocated pools (pinned host memory); MAPQ and SAM text are host work.
 // A read that does not fit the kernel's capacities is marked (status 2) and taken by the host pipeline (align_host.hpp).
 #include <hip/hip_runtime.h>
 #include <stdint.h>

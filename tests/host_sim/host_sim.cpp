@@ -224,6 +224,7 @@ char* sim_align_core_batch(void* s, const uint8_t* seq, const uint64_t* offs, ui
     std::string out, name, sq, ql;
     uint64_t n_aligned = 0, n_over = 0, n_tasks = 0, n_rounds = 0;
     ac_ws_t* W = new ac_ws_t();
+    mh::Aligner::OutBuf emit_ob; std::vector<char> emit_md; uint64_t n_emit_diff = 0;
     for (uint64_t r = 0; r < n_reads; ++r) {
         W->off = offs[r] - offs[0]; W->m = (uint32_t)(offs[r + 1] - offs[r]);
         W->min_score = (int32_t)(20 + 8 * log((double)W->m));
@@ -250,8 +251,29 @@ char* sim_align_core_batch(void* s, const uint8_t* seq, const uint64_t* offs, ui
         if (Sm.rev_read) for (uint32_t k = 0; k < W->m; ++k) sq[k] = (char)mh::compl_of(sp0[W->m - 1 - k]); else sq.assign((const char*)sp0, (const char*)sp0 + W->m);
         if (quals) { const uint8_t* qv = quals + W->off; ql.resize(W->m); if (Sm.rev_read) for (uint32_t k = 0; k < W->m; ++k) ql[k] = (char)qv[W->m - 1 - k]; else ql.assign((const char*)qv, (const char*)qv + W->m); }
         if (!W->aligned) Sm.flag = 4;
+        const size_t line_at = out.size();
         mh::Aligner::sam_write(out, Sm, name, sq, quals ? &ql : nullptr);
+        // the host stage's one-pass emitter (what moni_align_batch runs behind align_kernel) must spell the same record, with MD/NM
+        // computed here and with MD/NM handed in (as the kernel does)
+        if (!W->overflow) {
+            mh::moni_alt_like alts[AC_MAX_ALT];
+            for (uint32_t k = 0; k < W->n_alt; ++k) { alts[k].pos = W->alt_pos[k]; alts[k].score = W->alt_score[k]; alts[k].pad = 0; }
+            const bool al = W->aligned != 0;
+            emit_ob.len = 0;
+            if (!A.emit_record(emit_ob, emit_md, name.data(), name.size(), seq + W->off, quals ? quals + W->off : nullptr, W->m, al, W->fill.strand, W->fill.ref_pos,
+                               W->fill.score, W->score2, W->cigar, al ? W->n_cigar : 0, alts, al ? W->n_alt : 0)) return nullptr;
+            if (emit_ob.len != out.size() - line_at || memcmp(emit_ob.base, out.data() + line_at, emit_ob.len) != 0) ++n_emit_diff;
+            if (al) {
+                const std::string mdz = Sm.lift_md;
+                emit_ob.len = 0;
+                if (!A.emit_record(emit_ob, emit_md, name.data(), name.size(), seq + W->off, quals ? quals + W->off : nullptr, W->m, al, W->fill.strand, W->fill.ref_pos,
+                                   W->fill.score, W->score2, W->cigar, W->n_cigar, alts, W->n_alt, mdz.data(), (uint32_t)mdz.size(), (int)Sm.lift_nm)) return nullptr;
+                if (emit_ob.len != out.size() - line_at || memcmp(emit_ob.base, out.data() + line_at, emit_ob.len) != 0) ++n_emit_diff;
+            }
+        }
     }
+    emit_ob.release();
+    if (n_emit_diff) { delete W; return nullptr; }
     delete W;
     char* buf = (char*)malloc(out.size() + 1);
     memcpy(buf, out.data(), out.size() + 1);

@@ -93,7 +93,7 @@ class Sim:
             lib().sim_free(p)
 
     def align_core_batch(self, seq, offsets, names, name_off, quals=None):
-        """SAM via the device-side per-read logic (align_core.h) replayed on the host; stats = reads, aligned, dp tasks, overflowed, rounds"""
+        """SAM via the device-side per-read logic (align_core.h) replayed on the host; stats = reads, aligned, dp tasks, overflowed, rounds.  The harness also checks, per read, that the host stage's one-pass emitter (emit_record) spells the same record as finish_record + sam_write, with MD/NM computed and handed in; it fails on any difference."""
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         names = np.ascontiguousarray(names, dtype=np.uint8)

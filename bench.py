@@ -231,6 +231,12 @@ def main():
             out["cpu_baseline"] = {"value": n_cpu / dtc, "unit": "reads/s", "cores": cpu_threads, "kind": "port",
                                    "sample": "first %d reads of the same batch, whole SE path, oracle/align.hpp with %d threads" % (n_cpu, cpu_threads),
                                    "sam_identical_on_sample": bool(gsam == wsam)}
+            # BASELINE.json configs[0]: the CPU path on one thread (the plumbing / SAM-diff baseline), small sample
+            n1 = min(2000, n_cpu)
+            t1 = time.perf_counter()
+            w1, _ = _orc.align_batch(oidx, reads[:n1].reshape(-1), offs[:n1 + 1], names[:int(noff[n1])], noff[:n1 + 1], quals[:n1 * L], threads=1)
+            out["cpu_baseline"]["single_thread"] = {"value": n1 / (time.perf_counter() - t1), "unit": "reads/s", "cores": 1,
+                                                    "sample": "first %d reads" % n1, "same_text_as_16_threads": bool(w1 == wsam[:len(w1)])}
             # seeding stage alone on the CPU, same bounded way
             t1 = time.perf_counter()
             oidx.seed_batch(reads[:probe].reshape(-1), offs[:probe + 1], 25, True, 1000, threads=cpu_threads)

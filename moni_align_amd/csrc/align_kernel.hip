@@ -14,6 +14,7 @@
 #define AK_CIG_CAP 4096u                     // CIGAR entries of one round's traceback problems (each takes qlen + tlen + 2)
 #define AK_DIRS_CAP (384u * 1024u)           // direction bytes of one CIGAR problem
 #define AK_CUR 32                            // statistics / cursor words per launch
+#define AK_TXT_CAP 4096                      // bytes of SAM text per read formatted in the kernel (longer: the host formats the record)
 #define AK_MD_CAP 1536                       // bytes of MD text per read (longer: the host pipeline takes the read)
 #define AK_MEMO 24                           // score-only DP results remembered per read
 
@@ -27,6 +28,8 @@ struct moni_aln_rec_t {                      // one per read
     int32_t nm;                              // NM and the MD:Z text (write_MD_core, sam.hpp:249-287), computed where the read and the text are resident
     uint32_t md_len;
     uint64_t md_off;                         // into the MD pool (8-byte aligned)
+    uint32_t txt_len, txt_pad;               // the finished SAM line, when the kernel formats text (ak_args_t::fmt.txt_pool)
+    uint64_t txt_off;                        // into the text pool, in 8-byte words
 };
 struct moni_alt_t { uint64_t pos; int32_t score; int32_t pad; };
 
@@ -42,6 +45,7 @@ struct ak_slot_t {                           // per read in flight, in HBM
     moni_dp_result_t res[AC_MAX_TASKS];      // results of the round's DP problems
     uint32_t cig[AK_CIG_CAP];
     uint64_t md_tmp[AK_MD_CAP / 8];
+    uint64_t txt_tmp[AK_TXT_CAP / 8];
     uint64_t memo_key[AK_MEMO], memo_toff[AK_MEMO];
     dp_brief_t memo_val[AK_MEMO];           // mqe, mqe_t, score of the remembered problem
     uint32_t memo_n, pad;
@@ -63,6 +67,15 @@ __device__ __attribute__((noinline)) bool ak_same_target(const dp_launch_t& D, i
     return __ballot(diff) == 0ull;
 }
 
+struct ak_fmt_t {                            // what the kernel needs to spell a SAM line (sam.hpp:144-188): all device memory
+    const uint8_t* rnames; const uint64_t* rname_off;    // read names of the resident batch, ragged
+    const uint8_t* quals;                                // qualities, same offsets as the reads, or nullptr ('*')
+    const uint8_t* snames; const uint32_t* sname_off;    // sequence names of the index, ragged [n_seq + 1]
+    const double* mapq_tab; uint32_t mapq_tab_n;         // coeff_fac / log(l) for l < mapq_tab_n (libm on the host), mapq.hpp:146-184
+    int32_t min_len, smatch, smismatch, pad;
+    uint64_t* txt_pool; uint64_t txt_cap;                // in 8-byte words; cursor = cursors[15]
+};
+
 struct ak_args_t {
     ac_params_t P;
     dp_launch_t D;                           // scoring + reads/text pointers (order/tasks/results unused)
@@ -79,6 +92,7 @@ struct ak_args_t {
     uint32_t* cig_pool; uint64_t cig_cap;
     moni_alt_t* alt_pool; uint64_t alt_cap;
     uint64_t* md_pool; uint64_t md_cap;          // in 8-byte words
+    ak_fmt_t fmt;                                // SAM text in the kernel (txt_pool == nullptr: records only, the host formats)
     unsigned long long* cursors;             // [0] cigar pool, [1] alt pool, [2] DP problems run, [3] their cells, [4] next read, [5..7] wave cycles: serial
                                              // phases (init+first drive, later drives), dp, [8] DP problems answered from the per-read memo, [9] their cells,
                                              // [14] MD pool (words)
@@ -140,15 +154,123 @@ __device__ __attribute__((noinline)) int ak_md(const ak_args_t& A, const ac_ws_t
     return ovf ? -1 : n;
 }
 
+// One SAM line (sam.hpp:144-188 as Aligner::emit_record spells it), lane-private, into the slot's text staging; MD text and NM
+// come from ak_md.  Returns the length or -1 when it does not fit AK_TXT_CAP.
+struct ak_writer_t {                          // eight characters per store
+    uint64_t* p; uint64_t acc; int n; bool ovf;
+    __device__ __forceinline__ void c(uint8_t ch) {
+        acc |= (uint64_t)ch << ((n & 7) * 8);
+        if (((++n) & 7) == 0) { if (n <= AK_TXT_CAP) p[(n >> 3) - 1] = acc; else ovf = true; acc = 0; }
+    }
+    __device__ __forceinline__ void flush() { if (n & 7) { if (n < AK_TXT_CAP) p[n >> 3] = acc; else ovf = true; } }
+    __device__ __forceinline__ void lit(const char* q) { while (*q) c((uint8_t)*q++); }
+    __device__ __forceinline__ void i(int v) {
+        char b[12]; int k = 0; unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+        do { b[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+        if (v < 0) c('-');
+        while (k) c((uint8_t)b[--k]);
+    }
+};
+// bytes [a, a + len) of a padded device buffer (or the same backwards), through one-word register caches
+struct ak_reader_t {
+    const uint8_t* base; uint64_t w, word;
+    __device__ __forceinline__ uint8_t at(uint64_t a) {
+        const uint64_t x = a >> 3;
+        if (x != w) { word = *reinterpret_cast<const uint64_t*>(base + (x << 3)); w = x; }
+        return (uint8_t)(word >> (8 * (a & 7)));
+    }
+};
+
+__device__ __forceinline__ uint8_t ak_compl(uint8_t b) {        // kpbseq.h:120-137
+    const uint8_t u = b & 0xDFu;
+    return u == 'A' ? 'T' : u == 'C' ? 'G' : u == 'G' ? 'C' : u == 'T' ? 'A' : b;
+}
+
+__device__ __attribute__((noinline)) int ak_emit(const ak_args_t& A, const ac_ws_t& W, uint64_t r, bool aligned, const uint8_t* md, int md_len, int32_t nm,
+                                                 uint8_t* __restrict__ out) {
+    const ak_fmt_t& F = A.fmt;
+    ak_writer_t w; w.p = reinterpret_cast<uint64_t*>(out); w.acc = 0; w.n = 0; w.ovf = false;
+    const uint64_t rd = W.off;                                   // offsets into the (padded) device buffers
+    const bool ql = F.quals != nullptr;
+    const uint32_t m = W.m;
+    ak_reader_t R_reads{A.D.reads, ~0ull, 0}, R_quals{F.quals, ~0ull, 0}, R_rn{F.rnames, ~0ull, 0}, R_sn{F.snames, ~0ull, 0};
+    auto put = [&](ak_reader_t& R, uint64_t a0, size_t len) { for (size_t k = 0; k < len; ++k) w.c(R.at(a0 + k)); };
+    put(R_rn, F.rname_off[r], (size_t)(F.rname_off[r + 1] - F.rname_off[r]));
+    if (!aligned) {
+        w.lit("\t4\t*\t0\t255\t*\t*\t0\t0\t");
+        put(R_reads, rd, m); w.c('\t');
+        if (ql) put(R_quals, rd, m); else w.c('*');
+        w.c('\n');
+        w.flush();
+        return w.ovf ? -1 : w.n;
+    }
+    const uint32_t strand = W.fill.strand;
+    const int32_t score = W.fill.score, score2 = W.score2;
+    uint64_t ref_len = 0;
+    for (uint32_t k = 0; k < W.n_cigar; ++k) { const int op = W.cigar[k] & 0xf; if (op == 0 || op == 2) ref_len += W.cigar[k] >> 4; }
+    const uint64_t rk = ac_rank1(A.P, W.fill.ref_pos + 1);
+    const uint32_t sid = (uint32_t)(rk - 1);
+    const int lift_pos = (int)(W.fill.ref_pos - A.P.seq_starts[rk - 1] + 1);
+    const bool mapped = ref_len > 0;
+    // compute_mapq_se_bwa (mapq.hpp:146-184), the operations in the host's order, none contracted
+    int mapq = 0;
+    {
+        const int32_t rl = mapped ? (int32_t)ref_len : 0;
+        const int32_t l = rl > (int32_t)m ? rl : (int32_t)m;
+        const int32_t sub = score2 ? score2 : F.min_len * F.smatch;
+        if (sub < score) {
+            const double identity = __dsub_rn(1., __ddiv_rn(__ddiv_rn((double)(l * F.smatch - score), (double)(F.smatch + F.smismatch)), (double)l));
+            if (score != 0) {
+                double tmp = (double)l < 50.0 ? 1. : ((uint32_t)l < F.mapq_tab_n ? F.mapq_tab[l] : F.mapq_tab[F.mapq_tab_n - 1]);
+                tmp = __dmul_rn(tmp, __dmul_rn(identity, identity));
+                const double v = __dadd_rn(__dmul_rn(__dmul_rn(__ddiv_rn(__dmul_rn(6.02, (double)(score - sub)), (double)F.smatch), tmp), tmp), .499);
+                mapq = (int)v;
+            }
+            if (mapq > 60) mapq = 60;
+            if (mapq < 0) mapq = 0;
+            mapq = (int)__dadd_rn(__dmul_rn((double)mapq, 1.), .499);
+        }
+    }
+    const uint64_t sn = F.sname_off[sid];
+    const size_t sn_len = F.sname_off[sid + 1] - F.sname_off[sid];
+    w.c('\t'); w.i(strand ? 16 : 0); w.c('\t');
+    if (mapped) put(R_sn, sn, sn_len); else w.c('*');
+    w.c('\t'); w.i(mapped ? lift_pos : 0); w.c('\t'); w.i(mapq); w.c('\t');
+    if (mapped) { for (uint32_t k = 0; k < W.n_cigar; ++k) { w.i((int)(W.cigar[k] >> 4)); w.c((uint8_t)"MID"[W.cigar[k] & 0xf]); } } else w.c('*');
+    w.lit("\t*\t0\t0\t");
+    if (strand) for (uint32_t k = 0; k < m; ++k) w.c(ak_compl(R_reads.at(rd + m - 1 - k))); else put(R_reads, rd, m);
+    w.c('\t');
+    if (ql) { if (strand) for (uint32_t k = 0; k < m; ++k) w.c(R_quals.at(rd + m - 1 - k)); else put(R_quals, rd, m); } else w.c('*');
+    w.lit("\tAS:i:"); w.i(score); w.lit("\tNM:i:"); w.i(mapped ? nm : 0);
+    if (score2 != 0) { w.lit("\tZS:i:"); w.i(score2); }
+    w.lit("\tMD:Z:"); if (mapped) for (int k = 0; k < md_len; ++k) w.c(md[k]);
+    w.lit("\tOA:Z:"); put(R_sn, sn, sn_len); w.c(','); w.i(lift_pos); w.lit(strand ? ",-," : ",+,");
+    for (uint32_t k = 0; k < W.n_cigar; ++k) { w.i((int)(W.cigar[k] >> 4)); w.c((uint8_t)"MID"[W.cigar[k] & 0xf]); }
+    w.c(','); w.i(mapq); w.c(','); w.i(nm); w.c(';');
+    w.lit("\tAA:Z:");
+    for (uint32_t k = 0; k < W.n_alt; ++k) {
+        const uint64_t rk2 = ac_rank1(A.P, W.alt_pos[k] + 1);
+        const uint32_t s2 = (uint32_t)(rk2 - 1);
+        put(R_sn, F.sname_off[s2], (size_t)(F.sname_off[s2 + 1] - F.sname_off[s2]));
+        w.c(','); w.i((int)(W.alt_pos[k] - A.P.seq_starts[rk2 - 1] + 1)); w.c(','); w.i(W.alt_score[k]); w.c(';');
+    }
+    w.c('\n');
+    w.flush();
+    return w.ovf ? -1 : w.n;
+}
+
 // the record of a finished read (lane-private)
-__device__ __attribute__((noinline)) void ak_write_record(const ak_args_t& A, const ac_ws_t& W, uint64_t* __restrict__ md_tmp, uint64_t slot_in_launch) {
+__device__ __attribute__((noinline)) void ak_write_record(const ak_args_t& A, const ac_ws_t& W, uint64_t* __restrict__ md_tmp, uint64_t* __restrict__ txt_tmp,
+                                                          uint64_t slot_in_launch) {
     moni_aln_rec_t rec;
     rec.status = W.overflow ? 2u : (W.aligned ? 1u : 0u);
     rec.strand = W.fill.strand; rec.ref_pos = W.fill.ref_pos; rec.score = W.fill.score; rec.score2 = W.score2;
     rec.n_cigar = 0; rec.n_alt = 0; rec.cigar_off = 0; rec.alt_off = 0; rec.nm = 0; rec.md_len = 0; rec.md_off = 0;
+    rec.txt_len = 0; rec.txt_pad = 0; rec.txt_off = 0;
+    int32_t nm = 0;
+    int md_len = 0;
     if (rec.status == 1) {
-        int32_t nm = 0;
-        const int md_len = ak_md(A, W, reinterpret_cast<uint8_t*>(md_tmp), nm);
+        md_len = ak_md(A, W, reinterpret_cast<uint8_t*>(md_tmp), nm);
         const unsigned long long md_words = md_len > 0 ? (unsigned long long)((md_len + 7) >> 3) : 0ull;
         const unsigned long long co = atomicAdd(&A.cursors[0], (unsigned long long)W.n_cigar);
         const unsigned long long ao = atomicAdd(&A.cursors[1], (unsigned long long)W.n_alt);
@@ -160,6 +282,18 @@ __device__ __attribute__((noinline)) void ak_write_record(const ak_args_t& A, co
             for (uint32_t k = 0; k < W.n_cigar; ++k) A.cig_pool[co + k] = W.cigar[k];
             for (uint32_t k = 0; k < W.n_alt; ++k) { moni_alt_t x; x.pos = W.alt_pos[k]; x.score = W.alt_score[k]; x.pad = 0; A.alt_pool[ao + k] = x; }
             for (unsigned long long k = 0; k < md_words; ++k) A.md_pool[mo + k] = md_tmp[k];
+        }
+    }
+    if (A.fmt.txt_pool && rec.status != 2) {
+        // the finished SAM line; when it does not fit (staging or pool) the host formats this record from the fields above
+        const int n = ak_emit(A, W, A.read_lo + slot_in_launch, rec.status == 1, reinterpret_cast<const uint8_t*>(md_tmp), md_len, nm, reinterpret_cast<uint8_t*>(txt_tmp));
+        if (n > 0) {
+            const unsigned long long words = (unsigned long long)((n + 7) >> 3);
+            const unsigned long long to = atomicAdd(&A.cursors[15], words);
+            if (to + words <= A.fmt.txt_cap) {
+                for (unsigned long long k = 0; k < words; ++k) A.fmt.txt_pool[to + k] = txt_tmp[k];
+                rec.txt_len = (uint32_t)n; rec.txt_off = to;
+            }
         }
     }
     A.recs[slot_in_launch] = rec;
@@ -187,7 +321,7 @@ align_kernel(const ak_args_t A) {
         const long long c0 = clock64();
         const bool start = __popcll(__ballot(state == 0 || state == 3)) >= AK_START_MIN || __ballot(state == 1) == 0ull;
         // finished reads write their records (MD/NM, pool entries) together, like the starts: it is lane-private work too
-        if (state == 3 && start) { ak_write_record(A, W, S->md_tmp, r_in); state = 0; }
+        if (state == 3 && start) { ak_write_record(A, W, S->md_tmp, S->txt_tmp, r_in); state = 0; }
         if (state == 0 && start) {
             r_in = atomicAdd(&A.cursors[4], 1ull);
             if (r_in >= A.n_reads) state = 2;
@@ -202,7 +336,7 @@ align_kernel(const ak_args_t A) {
                 } else chained = ac_init(W, A.P, A.mems, A.read_mem_off[r], A.read_mem_off[r + 1], A.occs);
                 if (chained) ac_drive(W, A.P, nullptr, nullptr);
                 if (chained && !W.overflow && W.stage != AC_DONE) state = 1;
-                else ak_write_record(A, W, S->md_tmp, r_in);
+                else ak_write_record(A, W, S->md_tmp, S->txt_tmp, r_in);
             }
         }
         const unsigned long long waiting = __ballot(state == 1);

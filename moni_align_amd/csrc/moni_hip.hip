@@ -40,6 +40,7 @@ struct moni_index {
     uint8_t* d_text = nullptr;
     uint64_t* d_seq_starts = nullptr;
     uint32_t* d_name_id = nullptr;
+    uint8_t* d_snames = nullptr; uint32_t* d_sname_off = nullptr;      // sequence names, ragged (SAM text in align_kernel)
     uint64_t bytes = 0;
     // host copies for the host stages of the full path (chaining, MD/NM, SAM)
     std::vector<uint8_t> h_text;
@@ -118,6 +119,9 @@ struct moni_ctx {
     DBuf<ak_slot_t> ak_slots;
     DBuf<ak_wave_t> ak_waves;
     DBuf<unsigned long long> ak_cursors;
+    bool mapq_tab_ready = false;
+    DBuf<uint8_t> ak_rnames, ak_quals; DBuf<uint64_t> ak_rname_off, ak_txt; DBuf<double> ak_mapq_tab;      // SAM text in the kernel
+    HBuf<uint64_t> h_txt;                                 // pinned staging of one sub-batch's text
     uint64_t ak_waves_full = 0;
     hipStream_t ak_stream[2] = {nullptr, nullptr}, copy_stream = nullptr;
     std::vector<hipEvent_t> ak_begin, ak_done;
@@ -190,6 +194,9 @@ int moni_index_create(const moni_flat_index_t* f, int device, moni_index_t** out
             I->hix.names.push_back(nm);
         }
     }
+    std::vector<uint8_t> sname_blob; std::vector<uint32_t> sname_off(1, 0);
+    for (const auto& nm : I->hix.names) { sname_blob.insert(sname_blob.end(), nm.begin(), nm.end()); sname_off.push_back((uint32_t)sname_blob.size()); }
+    sname_blob.resize(sname_blob.size() + 8, 0);
     I->h_text.assign(f->text, f->text + (f->n - 1));
     I->hix.n_text = f->n - 1; I->hix.w = f->w; I->hix.text = I->h_text.data();
     I->hix.seq_starts.assign(f->seq_starts, f->seq_starts + f->n_seq + 1);
@@ -198,7 +205,7 @@ int moni_index_create(const moni_flat_index_t* f, int device, moni_index_t** out
         (rc = upload(&I->d_phi, img.phi, I->bytes)) || (rc = upload(&I->d_phi_inv, img.phi_inv, I->bytes)) ||
         (rc = upload(&I->d_phi_dir, img.phi_dir, I->bytes)) || (rc = upload(&I->d_phi_inv_dir, img.phi_inv_dir, I->bytes)) ||
         (rc = upload(&I->d_text, text, I->bytes)) || (rc = upload(&I->d_seq_starts, img.seq_starts, I->bytes)) ||
-        (rc = upload(&I->d_name_id, name_id, I->bytes))) {
+        (rc = upload(&I->d_name_id, name_id, I->bytes)) || (rc = upload(&I->d_snames, sname_blob, I->bytes)) || (rc = upload(&I->d_sname_off, sname_off, I->bytes))) {
         moni_index_destroy(I);
         return rc;
     }
@@ -246,7 +253,7 @@ int moni_index_load(const char* path, int device, moni_index_t** out) {
 void moni_index_destroy(moni_index_t* I) {
     if (!I) return;
     (void)hipSetDevice(I->device);
-    void* ps[] = {I->d_tables, I->d_rows, I->d_frows, I->d_cr, I->d_recs, I->d_phi, I->d_phi_inv, I->d_phi_dir, I->d_phi_inv_dir, I->d_text, I->d_seq_starts, I->d_name_id};
+    void* ps[] = {I->d_tables, I->d_rows, I->d_frows, I->d_cr, I->d_recs, I->d_phi, I->d_phi_inv, I->d_phi_dir, I->d_phi_inv_dir, I->d_text, I->d_seq_starts, I->d_name_id, I->d_snames, I->d_sname_off};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete I;
 }
@@ -279,9 +286,9 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
     c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
     c->dp_q.release(); c->dp_t.release(); c->dp_dir.release(); c->dp_tasks.release(); c->dp_res.release(); c->dp_cig.release();
-    c->dp_off.release(); c->dp_ws.release(); c->dp_big.release(); c->dp_dir_big.release(); c->ak_slots.release(); c->ak_waves.release(); c->ak_cursors.release(); c->h_recs.release(); c->h_cig.release(); c->h_alt.release(); c->h_md.release();
+    c->dp_off.release(); c->dp_ws.release(); c->dp_big.release(); c->dp_dir_big.release(); c->ak_slots.release(); c->ak_waves.release(); c->ak_cursors.release(); c->ak_rnames.release(); c->ak_quals.release(); c->ak_rname_off.release(); c->ak_txt.release(); c->ak_mapq_tab.release(); c->h_txt.release(); c->h_recs.release(); c->h_cig.release(); c->h_alt.release(); c->h_md.release();
     for (auto& ob : c->pieces) ob.release();
-    for (int x = 0; x < 2; ++x) if (c->ak_stream[x]) (void)hipStreamDestroy(c->ak_stream[x]);
+    if (c->ak_stream[1]) (void)hipStreamDestroy(c->ak_stream[1]);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto e : c->ak_begin) (void)hipEventDestroy(e);
     for (auto e : c->ak_done) (void)hipEventDestroy(e);
@@ -697,6 +704,26 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         double hist[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cyc[7] = {0, 0, 0, 0, 0, 0, 0};
         uint64_t waves_used = 0;
 
+        // SAM text in the kernel (default; MONI_ALIGN_HOST_FORMAT=1 leaves the formatting to the host stage): read names and
+        // qualities go to the device while the seeding runs
+        const bool gpu_text = getenv("MONI_ALIGN_HOST_FORMAT") == nullptr && NR > 0;
+        std::thread uploader;
+        int rc_up = MONI_OK;
+        if (gpu_text) {
+            const uint64_t nb_names = name_off[NR] - name_off[0], nb_q = quals ? b->offsets[NR] - b->offsets[0] : 0;
+            if ((rc = c->ak_rnames.ensure(nb_names + 16)) || (rc = c->ak_rname_off.ensure(NR + 1)) || (rc = c->ak_quals.ensure(nb_q + 16))) return rc;
+            if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+            uploader = std::thread([&, nb_names, nb_q]() {
+                if (hipSetDevice(I->device) != hipSuccess) { rc_up = MONI_ENODEV; return; }
+                std::vector<uint64_t> rel(NR + 1);
+                for (uint64_t r = 0; r <= NR; ++r) rel[r] = name_off[r] - name_off[0];
+                if (hipMemcpyAsync(c->ak_rnames.p, names + name_off[0], nb_names, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+                    hipMemcpyAsync(c->ak_rname_off.p, rel.data(), (NR + 1) * 8, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+                    (nb_q && hipMemcpyAsync(c->ak_quals.p, quals + b->offsets[0], nb_q, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) ||
+                    hipStreamSynchronize(c->copy_stream) != hipSuccess) rc_up = MONI_ENODEV;
+            });
+        }
+        struct JoinGuard { std::thread& t; ~JoinGuard() { if (t.joinable()) t.join(); } } join_guard{uploader};
         // seeding: the whole batch at once (the LF kernel wants millions of lanes in flight)
         {
             const double t0 = mh::now_s();
@@ -716,11 +743,28 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         // bytes per read over PCIe): no copy has to find room next to the persistent kernels.  Pool share of one sub-batch
         // below; a launch that runs out hands the affected reads back (status 2)
         const uint64_t cig_per = 16 * sub_reads + 4096, alt_per = 24 * sub_reads + 4096, md_per = 8 * sub_reads + 4096;      // md: 8-byte words
+        const uint64_t txt_per = gpu_text ? 160 * sub_reads + 4096 : 0;                        // text: 8-byte words (1.25 KB per read on average)
+        if (uploader.joinable()) uploader.join();
+        if (rc_up) return rc_up;
+        if (gpu_text) {
+            const uint32_t TAB = 8192;
+            if ((rc = c->ak_txt.ensure(txt_per * n_sub + 8)) || (rc = c->h_txt.ensure(txt_per + 8)) || (rc = c->ak_mapq_tab.ensure(TAB))) return rc;
+            if (!c->mapq_tab_ready) {
+                std::vector<double> tab(TAB, 1.);
+                const int32_t coeff_fac = (int32_t)log(50.0f);                                 // aligner_ksw2.hpp:3250-3251
+                for (int32_t l = 2; l < (int32_t)TAB; ++l) tab[l] = coeff_fac / log(l);         // the expression of mapq.hpp:170, libm on the host
+                HIPCHK(hipMemcpy(c->ak_mapq_tab.p, tab.data(), TAB * sizeof(double), hipMemcpyHostToDevice));
+                c->mapq_tab_ready = true;
+            }
+        }
         if ((rc = c->ak_slots.ensure(2 * waves_full * AK_NL)) || (rc = c->ak_waves.ensure(2 * waves_full)) || (rc = c->h_recs.ensure(NR + 1)) ||
             (rc = c->h_cig.ensure(cig_per * n_sub + 1)) || (rc = c->h_alt.ensure(alt_per * n_sub + 1)) || (rc = c->h_md.ensure(md_per * n_sub + 1)) || (rc = c->ak_minscore.ensure(msc.size())) ||
             (rc = c->ak_cursors.ensure(AK_CUR * n_sub + AK_CUR)))
             return rc;
-        for (int x = 0; x < 2; ++x) if (!c->ak_stream[x]) HIPCHK(hipStreamCreateWithFlags(&c->ak_stream[x], hipStreamNonBlocking));
+        // the launches alternate between the context's stream and one more: HIP multiplexes streams onto a handful of hardware queues
+        // (4 by default), and two streams that land on the same queue run their kernels one after the other
+        c->ak_stream[0] = c->stream;
+        if (!c->ak_stream[1]) HIPCHK(hipStreamCreateWithFlags(&c->ak_stream[1], hipStreamNonBlocking));
         if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         while (c->ak_done.size() < n_sub) { hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); c->ak_begin.push_back(e0); c->ak_done.push_back(e1); }
         HIPCHK(hipMemsetAsync(c->ak_cursors.p, 0, (AK_CUR * n_sub + AK_CUR) * sizeof(unsigned long long), c->stream));
@@ -747,6 +791,12 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             A.slots = c->ak_slots.p + (k & 1) * waves_full * AK_NL; A.waves = c->ak_waves.p + (k & 1) * waves_full;
             A.recs = c->h_recs.p + r0; A.cig_pool = c->h_cig.p + k * cig_per; A.cig_cap = cig_per; A.alt_pool = c->h_alt.p + k * alt_per;
             A.alt_cap = alt_per; A.md_pool = c->h_md.p + k * md_per; A.md_cap = md_per; A.cursors = c->ak_cursors.p + AK_CUR * k;
+            if (gpu_text) {
+                A.fmt.rnames = c->ak_rnames.p; A.fmt.rname_off = c->ak_rname_off.p; A.fmt.quals = quals ? c->ak_quals.p : nullptr;
+                A.fmt.snames = I->d_snames; A.fmt.sname_off = I->d_sname_off; A.fmt.mapq_tab = c->ak_mapq_tab.p; A.fmt.mapq_tab_n = 8192;
+                A.fmt.min_len = (int32_t)prm->min_len; A.fmt.smatch = prm->smatch; A.fmt.smismatch = prm->smismatch;
+                A.fmt.txt_pool = c->ak_txt.p + k * txt_per; A.fmt.txt_cap = txt_per;
+            }
             hipStream_t sx = c->ak_stream[k & 1];
             HIPCHK(hipEventRecord(c->ak_begin[k], sx));
             hipLaunchKernelGGL(align_kernel, dim3((unsigned)n_waves), dim3(64), 0, sx, A);
@@ -755,7 +805,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         }
         t_launch[1] = mh::now_s() - t_enter;
         // host side: follows the launches
-        struct SubRes { moni_aln_rec_t* recs = nullptr; uint32_t* cig = nullptr; moni_alt_t* alt = nullptr; const uint64_t* md = nullptr; uint64_t nr = 0; };
+        struct SubRes { moni_aln_rec_t* recs = nullptr; uint32_t* cig = nullptr; moni_alt_t* alt = nullptr; const uint64_t* md = nullptr; const uint64_t* txt = nullptr; uint64_t nr = 0; };
         int rc_host = MONI_OK;
         auto fetch = [&](uint64_t k, SubRes& R) -> int {            // records of sub-batch k into pinned host memory
             const uint64_t r0 = sub_lo[k], nr = sub_lo[k + 1] - sub_lo[k];
@@ -765,6 +815,16 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             R.recs = c->h_recs.p + r0; R.cig = c->h_cig.p + k * cig_per; R.alt = c->h_alt.p + k * alt_per; R.md = c->h_md.p + k * md_per; R.nr = nr;
             if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "  sub-batch %llu: waited for the launch from %.1f to %.1f ms\n", (unsigned long long)k, (f0 - t_enter) * 1e3, (f1 - t_enter) * 1e3);
             if (force_back) for (uint64_t r = 0; r < nr; ++r) if ((r0 + r) % force_back == 0) R.recs[r].status = 2;
+            if (gpu_text) {        // the text the launch wrote: one copy engine transfer next to the running kernels
+                uint64_t words = 0;
+                for (uint64_t r = 0; r < nr; ++r) if (R.recs[r].txt_len) words = std::max<uint64_t>(words, R.recs[r].txt_off + ((R.recs[r].txt_len + 7) >> 3));
+                if (words > txt_per) return MONI_EINVAL;
+                if (words) {
+                    HIPCHK(hipMemcpyAsync(c->h_txt.p, c->ak_txt.p + k * txt_per, words * 8, hipMemcpyDeviceToHost, c->copy_stream));
+                    HIPCHK(hipStreamSynchronize(c->copy_stream));
+                }
+                R.txt = c->h_txt.p;
+            }
             { float ms = 0; if (hipEventElapsedTime(&ms, c->ak_begin[k], c->ak_done[k]) == hipSuccess) { c->dp_kernel_ms_accum += ms; c->ak_kernel_ms = ms; } }
             return MONI_OK;
         };
@@ -783,6 +843,13 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                     if (Rr.status == 2) continue;                    // handed back: filled in at the end
                     const uint64_t g = r0 + r;
                     const uint64_t off = b->offsets[g]; const uint32_t m = (uint32_t)(b->offsets[g + 1] - off);
+                    if (R.txt && Rr.txt_len) {       // formatted by the kernel
+                        if (!ob.ensure(Rr.txt_len)) { oom = true; break; }
+                        memcpy(ob.base + ob.len, (const char*)(R.txt + Rr.txt_off), Rr.txt_len);
+                        ob.len += Rr.txt_len;
+                        if (Rr.status == 1) aligned_t[t]++;
+                        continue;
+                    }
                     if (!AL.emit_record(ob, mds, (const char*)names + name_off[g], (size_t)(name_off[g + 1] - name_off[g]), b->seq + off, quals ? quals + off : nullptr, m,
                                         Rr.status == 1, Rr.strand, Rr.ref_pos, Rr.score, Rr.score2, R.cig + Rr.cigar_off, Rr.n_cigar,
                                         (const mh::moni_alt_like*)R.alt + Rr.alt_off, Rr.n_alt,

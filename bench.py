@@ -4,7 +4,7 @@
 One "step" = one pass of the whole single-end hot path over one resident batch of synthetic 150 bp reads on
 the mouse-chr19-scale x12-haplotype index (BASELINE.json configs[2]): MEM seeding (MS pointers by LF /
 threshold jumps -> MEMs -> phi/phi^-1 occurrence enumeration, both strands), then align_kernel (chaining,
-chain selection, ksw2 extension DP, MD/NM) and the host stage that turns its records into SAM text (MAPQ, formatting).
+chain selection, ksw2 extension DP, MD/NM, MAPQ, the SAM line of every read) and the host stage that puts the lines in read order.
 The reads are already in HBM when the timed region starts; the step ends with the batch's SAM text in host
 memory.  N > 1: one process per GPU (torch.distributed / RCCL), reads sharded, index replicated, no data-path
 collective ("weak" scaling: per-GPU batch fixed).
@@ -177,7 +177,7 @@ def main():
             "vs_baseline": None, "dtype": "u64/int32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: mouse-chr19-scale index (%d bp base + %d haplotypes, n=%d, r=%d), "
                                    "%d x %d bp reads per GPU resident in HBM -> MEM seeding + HIP ksw2 extension (align_kernel) -> "
-                                   "SAM text (MAPQ + formatting on %d host threads per GPU, overlapped)"
+                                   "SAM text (lines spelled in align_kernel, put in read order by %d host threads per GPU, overlapped)"
                                    % (args.base_len, args.haps, fi.n, fi.r, args.reads, L, threads),
                        "reads_per_gpu": args.reads, "read_len": L, "parallelism": "reads sharded x%d, index replicated" % world},
             "roofline": {"bound": "hbm", "kernel": "ms_lf_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -61,6 +61,17 @@ def test_sub_batches_and_handed_back_reads(medium_case, env, monkeypatch):
     both(env, reads[:0])
 
 
+def test_host_formatting_mode(medium_case, env, monkeypatch):
+    """By default align_kernel spells the SAM lines (ak_emit) and the host only orders them; MONI_ALIGN_HOST_FORMAT=1 makes the host
+    stage format them from the records (emit_record).  Both must give the oracle's text, FASTA reads (no qualities) included."""
+    reads = list(medium_case.synth.make_reads(medium_case.pg, 3000, 150, seed=153, sub_rate=0.03, indel_rate=0.004))
+    both(env, reads)
+    both(env, reads[:500], quals=False)
+    monkeypatch.setenv("MONI_ALIGN_HOST_FORMAT", "1")
+    both(env, reads)
+    both(env, reads[:500], quals=False)
+
+
 def test_align_run_on_resident_batch(medium_case, env, monkeypatch):
     """moni_align_run (reads already in HBM) gives the text moni_align_batch gives, leaves the batch resident, also
     after reads went through the hand-back path."""

@@ -19,6 +19,11 @@ import os
 import sys
 import time
 
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); the align stage runs its launches on
+# two streams next to a copy stream, and with RCCL's own streams in the process (N > 1) two of them could share a queue and
+# serialise.  Read by the HIP runtime when it starts, so it is set before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -51,6 +51,15 @@ typedef struct {
     const uint8_t *text;     /* [n-1] */
     const uint64_t *seq_starts; /* [n_seq+1] onsets in text coordinates */
     const char *seq_names;   /* n_seq NUL-terminated names back to back (seqidx names), or NULL */
+    /* liftidx::lifts (include/aligner/liftidx.hpp:131-143), one lift::Lift per sequence, or all NULL for a FASTA-built
+     * index (null lifts, liftidx.hpp:150-157): lift_second[i] = start of the target contig in the concatenation,
+     * lift_len[i] = alignment columns, sorted positions of the ones of the levioSAM ins / del bit-vectors (ragged). */
+    const uint64_t *lift_second;  /* [n_seq] */
+    const uint64_t *lift_len;     /* [n_seq] */
+    const uint64_t *lift_ins_off; /* [n_seq+1] */
+    const uint64_t *lift_ins;
+    const uint64_t *lift_del_off; /* [n_seq+1] */
+    const uint64_t *lift_del;
 } moni_flat_index_t;
 
 /* Ragged batch of reads: read i is seq[offsets[i] .. offsets[i+1]).  Replaces the kseq_t batches of

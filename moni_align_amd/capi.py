@@ -29,7 +29,9 @@ class FlatIndexC(C.Structure):
     _fields_ = [("n", C.c_uint64), ("r", C.c_uint64), ("w", C.c_uint64), ("n_seq", C.c_uint64),
                 ("F", C.c_void_p), ("heads", C.c_void_p), ("starts", C.c_void_p), ("ssa", C.c_void_p),
                 ("esa", C.c_void_p), ("thr", C.c_void_p), ("slcp", C.c_void_p), ("text", C.c_void_p),
-                ("seq_starts", C.c_void_p), ("seq_names", C.c_char_p)]
+                ("seq_starts", C.c_void_p), ("seq_names", C.c_char_p),
+                ("lift_second", C.c_void_p), ("lift_len", C.c_void_p), ("lift_ins_off", C.c_void_p), ("lift_ins", C.c_void_p),
+                ("lift_del_off", C.c_void_p), ("lift_del", C.c_void_p)]
 
 
 class ReadBatchC(C.Structure):
@@ -141,6 +143,11 @@ def flat_struct(fi) -> FlatIndexC:
         setattr(s, k, a.ctypes.data)
     s._names_keep = b"".join(x.encode() + b"\0" for x in fi.names)
     s.seq_names = s._names_keep
+    lf = getattr(fi, "lifts", None)
+    if lf is not None:           # VCF-built index: one lift per sequence (liftidx.hpp:131-143); absent = null lifts
+        s.lift_second, s.lift_len = lf.second.ctypes.data, lf.len.ctypes.data
+        s.lift_ins_off, s.lift_ins = lf.ins_off.ctypes.data, lf.ins.ctypes.data
+        s.lift_del_off, s.lift_del = lf.del_off.ctypes.data, lf.dele.ctypes.data
     return s
 
 

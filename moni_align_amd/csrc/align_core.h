@@ -9,6 +9,7 @@
 
 #include "../../include/moni_hip.h"
 #include "sort_emul.h"
+#include "lift_core.h"
 
 #if defined(__HIPCC__)
 #define AC_HD __host__ __device__ __forceinline__
@@ -56,6 +57,8 @@ struct ac_params_t {
     uint64_t n_text;
     uint32_t n_seq;
     const uint64_t* seq_starts;      // n_seq + 1 onsets
+    const moni_lift_seq_t* lift_seqs; // one lift per sequence (lift_core.h)
+    const moni_lift_run_t* lift_runs;
 };
 
 enum { AC_LOOP = 0, AC_WAIT_A, AC_WAIT_B, AC_FINAL_WAIT_A, AC_FINAL_WAIT_B, AC_DONE };
@@ -120,6 +123,13 @@ AC_HD uint64_t ac_rank1(const ac_params_t& P, uint64_t i) {           // number 
 }
 AC_HD uint64_t ac_seq_off(const ac_params_t& P, uint64_t pos) { const uint64_t rk = ac_rank1(P, pos + 1); return pos - P.seq_starts[rk - 1]; }   // index(pos).second
 AC_HD bool ac_valid(const ac_params_t& P, uint64_t pos, uint64_t len) { const uint64_t rk = ac_rank1(P, pos + 1); return pos + len <= P.seq_starts[rk]; }
+
+// liftidx::lift (liftidx.hpp:89-95)
+AC_HD uint64_t ac_lift(const ac_params_t& P, uint64_t pos) {
+    const uint64_t rk = ac_rank1(P, pos + 1);
+    const moni_lift_seq_t L = P.lift_seqs[rk - 1];
+    return L.second + lift_pos(P.lift_runs + L.run_off, L.n_runs, pos - P.seq_starts[rk - 1]);
+}
 
 AC_HD uint64_t ac_occ(const ac_ws_t& W, uint32_t mem, uint32_t occ) { return W.mems[mem].occs[occ]; }
 
@@ -389,7 +399,7 @@ AC_HD_BIG bool ac_fill_final(ac_ws_t& W, const ac_params_t& P, const moni_dp_res
 AC_HD_BIG bool ac_check_left_mem(ac_ws_t& W, const ac_params_t& P, uint64_t ci) {
     const ac_chain_t& ch = W.chains[ci];
     const ac_anchor_t& A = W.anch[W.pool[ch.off + ch.cnt - 1]];                    // leftmost anchor
-    const uint64_t left_ref = ac_seq_off(P, ac_occ(W, A.mem, A.occ)) + 1;            // null lift: index(lift(pos)).second + 1
+    const uint64_t left_ref = ac_seq_off(P, ac_lift(P, ac_occ(W, A.mem, A.occ))) + 1;  // index(lift(pos)).second + 1
     bool seen = false;
     for (uint32_t k = 0; k < W.n_left; ++k) {
         const uint64_t d = W.left[k].ref > left_ref ? W.left[k].ref - left_ref : left_ref - W.left[k].ref;
@@ -403,7 +413,7 @@ AC_HD_BIG bool ac_check_left_mem(ac_ws_t& W, const ac_params_t& P, uint64_t ci) 
 
 // a scored chain comes back into the selection loop (aligner_ksw2.hpp:436-460, 528-548)
 AC_HD_BIG void ac_absorb(ac_ws_t& W, const ac_params_t& P, int32_t score, uint64_t pos) {
-    const uint64_t lft = pos;                                                        // idx.lift(score.pos), null lift
+    const uint64_t lft = ac_lift(P, pos);                                            // idx.lift(score.pos)
     if (score > W.max_score) { W.max_score = score; W.n_alt = 0; }
     else if (score == W.max_score) {
         if (W.n_alt >= AC_MAX_ALT) { W.overflow = 1; return; }

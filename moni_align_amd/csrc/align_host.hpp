@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "../../include/moni_hip.h"
+#include "lift_core.h"
 
 #ifndef DP_EZ_SCORE_ONLY
 #define DP_EZ_SCORE_ONLY 0x01
@@ -56,6 +57,8 @@ struct HostIndex {                 // host copies of what the host stages read (
     std::vector<uint64_t> seq_starts;
     std::vector<std::string> names;
     const uint8_t* text = nullptr;
+    std::vector<moni_lift_seq_t> lift_seqs;        // liftidx::lifts in the run form of lift_core.h (lift_build.hpp)
+    std::vector<moni_lift_run_t> lift_runs;
 
     size_t rank1(uint64_t i) const { return (size_t)(std::lower_bound(seq_starts.begin(), seq_starts.end(), i) - seq_starts.begin()); }
     uint64_t select1(size_t k) const { return seq_starts[k - 1]; }
@@ -64,7 +67,22 @@ struct HostIndex {                 // host copies of what the host stages read (
         return std::make_pair(rk - 1, pos - select1(rk));
     }
     bool valid(uint64_t pos, uint64_t len) const { return pos + len <= select1(rank1(pos + 1) + 1); }   // seqidx.hpp:164-167
-    uint64_t lift(uint64_t pos) const { return pos; }                 // liftidx.hpp:89-95 for a null lift over text coordinates
+    uint64_t lift(uint64_t pos) const {                                // liftidx.hpp:89-95
+        const size_t rk = rank1(pos + 1);
+        const moni_lift_seq_t& L = lift_seqs[rk - 1];
+        return L.second + lift_pos(lift_runs.data() + L.run_off, L.n_runs, pos - select1(rk));
+    }
+    // liftidx.hpp:159-164: the CIGAR of an alignment that starts at text position pos, lifted
+    void lift_cigar_at(uint64_t pos, const uint32_t* cig, uint32_t n_cig, std::vector<uint32_t>& out) const {
+        const size_t rk = rank1(pos + 1);
+        const moni_lift_seq_t& L = lift_seqs[rk - 1];
+        uint64_t units = 0;
+        for (uint32_t k = 0; k < n_cig; ++k) units += cig[k] >> 4;
+        out.resize(2 * (size_t)n_cig + 2 * (size_t)L.n_runs + 4);
+        const int n = lift_cigar(lift_runs.data() + L.run_off, L.n_runs, pos - select1(rk), cig, n_cig, out.data(), (uint32_t)out.size());
+        out.resize(n < 0 ? 0 : (size_t)n);
+        (void)units;
+    }
     uint64_t seq_length(size_t i) const { return select1(i + 2) - select1(i + 1) - w; }
     std::string sam_header() const {                                   // aligner_ksw2.hpp:3213-3219, seqidx.hpp:174-180
         std::string res = "@HD\tVN:1.6\tSO:unknown\n";
@@ -492,18 +510,21 @@ struct Aligner {
         S.as = (size_t)(int64_t)F.score.score;
         S.lift_pos = refi.second + 1;
         S.lift_rname = ix.names[refi.first];
-        const uint64_t lifted = ix.lift(F.ref_pos);                                     // null lift: identity, lift_cigar leaves the CIGAR alone
+        const uint64_t lifted = ix.lift(F.ref_pos);                                     // aligner_ksw2.hpp:3133-3160
+        std::vector<uint32_t> lcig;
+        ix.lift_cigar_at(F.ref_pos, cigar.data(), (uint32_t)cigar.size(), lcig);
         const auto lft_ref = ix.index(lifted);
         S.pos = lft_ref.second + 1;
         S.rname = ix.names[lft_ref.first];
-        S.cigar = S.lift_cigar;
+        S.cigar.clear();
+        for (uint32_t c : lcig) { S.cigar += std::to_string(c >> 4); S.cigar.push_back("MID"[c & 0xf]); }
         uint64_t rl = 0;
-        for (uint32_t c : cigar) { const int op = c & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += c >> 4; }
+        for (uint32_t c : lcig) { const int op = c & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += c >> 4; }
         if (rl > 0) {
             std::vector<uint8_t> lref(rl + 1);
             for (uint64_t k = 0; k < rl; ++k) lref[k] = nt4_of(lifted + k < ix.n_text ? ix.text[lifted + k] : 0);
             S.md.clear();
-            S.nm = md_core(lref.data(), seq.data(), cigar, S.md);
+            S.nm = md_core(lref.data(), seq.data(), lcig, S.md);
             S.rlen = rl;
         } else {
             S.pos = 0; S.rname = "*"; S.cigar = "*"; S.rlen = 0; S.unmapped_lft = true;
@@ -600,8 +621,22 @@ struct Aligner {
         S.as = (size_t)(int64_t)score;
         S.lift_pos = refi.second + 1;
         S.lift_rname = ix.names[refi.first];
-        S.pos = S.lift_pos; S.rname = S.lift_rname; S.cigar = cs;              // null lift
-        if (ref_len > 0) { S.md = S.lift_md; S.nm = S.lift_nm; S.rlen = ref_len; }
+        const uint64_t lifted = ix.lift(ref_pos);                              // aligner_ksw2.hpp:3133-3160
+        std::vector<uint32_t> lcig;
+        ix.lift_cigar_at(ref_pos, cig, n_cig, lcig);
+        const auto lft_ref = ix.index(lifted);
+        S.pos = lft_ref.second + 1; S.rname = ix.names[lft_ref.first];
+        S.cigar.clear();
+        for (uint32_t c : lcig) { S.cigar += std::to_string(c >> 4); S.cigar.push_back("MID"[c & 0xf]); }
+        uint64_t rl = 0;
+        for (uint32_t c : lcig) { const int op = c & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += c >> 4; }
+        if (rl > 0) {
+            std::vector<uint8_t> lref(rl + 1);
+            for (uint64_t k = 0; k < rl; ++k) lref[k] = nt4_of(lifted + k < ix.n_text ? ix.text[lifted + k] : 0);
+            S.md.clear();
+            S.nm = md_core(lref.data(), seq.data(), lcig, S.md);
+            S.rlen = rl;
+        }
         else { S.pos = 0; S.rname = "*"; S.cigar = "*"; S.rlen = 0; S.unmapped_lft = true; }
         for (uint32_t k = 0; k < n_alt; ++k) {
             const auto r = ix.index(alt_pos[k]);
@@ -643,14 +678,14 @@ struct Aligner {
     }
     bool emit_record(OutBuf& ob, std::vector<char>& md_scratch, const char* name, size_t name_len, const uint8_t* rd, const uint8_t* ql, uint32_t m,
                      bool aligned, uint32_t strand, uint64_t ref_pos, int32_t score, int32_t score2, const uint32_t* cig, uint32_t n_cig,
-                     const moni_alt_like* alts, uint32_t n_alt, const char* md_given = nullptr, uint32_t md_given_len = 0, int nm_given = 0) const {
-        // md_given: MD:Z text and NM computed by the align kernel (same rule, where read and text are resident); else computed here
-        uint64_t ref_len = 0, del_len = 0;
-        for (uint32_t k = 0; k < n_cig; ++k) { const uint32_t c = cig[k]; const int op = c & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4; if (op == 2) del_len += c >> 4; }
-        if (!ob.ensure(record_bound(name_len, m, n_cig, n_alt) + 2 * del_len)) return false;
-        char* p = ob.base + ob.len;
-        p = put_str(p, name, name_len);
+                     const moni_alt_like* alts, uint32_t n_alt, const char* md_given = nullptr, uint32_t md_given_len = 0, int nm_given = 0,
+                     int lift_nm_given = 0) const {
+        // cig / ref_pos: the alignment on the pangenome text (the OA tag); columns 3, 4, 6 and MD / NM are its lift (aligner_ksw2.hpp:3133-3160).
+        // md_given: MD:Z text and NM of the lifted alignment and NM of the unlifted one, computed by the align kernel; else computed here
         if (!aligned) {
+            if (!ob.ensure(name_len + 2 * (size_t)m + 64)) return false;
+            char* p = ob.base + ob.len;
+            p = put_str(p, name, name_len);
             p = PUT_LIT(p, "\t4\t*\t0\t255\t*\t*\t0\t0\t");
             p = put_str(p, (const char*)rd, m); *p++ = '\t';
             if (ql) p = put_str(p, (const char*)ql, m); else *p++ = '*';
@@ -658,49 +693,66 @@ struct Aligner {
             ob.len = (size_t)(p - ob.base);
             return true;
         }
-        // MD / NM over the window the CIGAR spans (write_MD_core); NM is printed before MD, so MD goes through a scratch
-        { const size_t need = 3 * (size_t)m + 2 * del_len + 40 * (size_t)n_cig + 64 + (md_given ? (size_t)md_given_len : 0); if (md_scratch.size() < need) md_scratch.resize(need); }
+        static thread_local std::vector<uint32_t> lcig;
+        ix.lift_cigar_at(ref_pos, cig, n_cig, lcig);
+        const uint32_t n_lcig = (uint32_t)lcig.size();
+        const uint64_t lifted = ix.lift(ref_pos);
+        uint64_t ref_len = 0, del_len = 0;
+        for (uint32_t k = 0; k < n_lcig; ++k) { const uint32_t c = lcig[k]; const int op = c & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4; if (op == 2) del_len += c >> 4; }
+        if (!ob.ensure(record_bound(name_len, m, n_cig + n_lcig, n_alt) + 2 * del_len)) return false;
+        char* p = ob.base + ob.len;
+        p = put_str(p, name, name_len);
+        // MD / NM over the window a CIGAR spans (write_MD_core); NM is printed before MD, so MD goes through a scratch
+        { const size_t need = 3 * (size_t)m + 2 * del_len + 40 * (size_t)(n_cig + n_lcig) + 64 + (md_given ? (size_t)md_given_len : 0); if (md_scratch.size() < need) md_scratch.resize(need); }
         char* const md0 = md_scratch.data(); char* md = md0;
-        int NM = 0;
+        int NM = 0, NM_unlifted = 0;
         if (md_given) {
             memcpy(md, md_given, md_given_len);
             md += md_given_len;
-            NM = nm_given;
+            NM = nm_given; NM_unlifted = lift_nm_given;
         } else {
-            int l_MD = 0; uint64_t t = ref_pos; uint32_t q = 0;
             auto tb = [&](uint64_t a) -> uint8_t { return nt4_of(a < ix.n_text ? ix.text[a] : 0); };
             auto qb = [&](uint32_t k) -> uint8_t { return nt4_of(strand ? compl_of(rd[m - 1 - k]) : rd[k]); };
-            for (uint32_t i = 0; i < n_cig; ++i) {
-                const int op = cig[i] & 0xf, len = (int)(cig[i] >> 4);
-                if (op == 0 || op == 7 || op == 8) {
-                    for (int j = 0; j < len; ++j) {
-                        const uint8_t tc = tb(t + j);
-                        if (qb(q + j) != tc) { md = put_int(md, l_MD); *md++ = "ACGTN"[tc]; l_MD = 0; ++NM; }
-                        else ++l_MD;
-                    }
-                    q += len; t += len;
-                } else if (op == 1) { q += len; NM += len; }
-                else if (op == 2) {
-                    md = put_int(md, l_MD); *md++ = '^';
-                    for (int j = 0; j < len; ++j) *md++ = "ACGTN"[tb(t + j)];
-                    l_MD = 0; t += len; NM += len;
-                } else if (op == 3) t += len;
-            }
-            if (l_MD > 0) md = put_int(md, l_MD);
+            auto pass = [&](const uint32_t* cg, uint32_t ncg, uint64_t t, char* out) -> int {          // out == nullptr: count only
+                int l_MD = 0, nm = 0; uint32_t q = 0;
+                for (uint32_t i = 0; i < ncg; ++i) {
+                    const int op = cg[i] & 0xf, len = (int)(cg[i] >> 4);
+                    if (op == 0 || op == 7 || op == 8) {
+                        for (int j = 0; j < len; ++j) {
+                            const uint8_t tc = tb(t + j);
+                            if (qb(q + j) != tc) { if (out) { out = put_int(out, l_MD); *out++ = "ACGTN"[tc]; } l_MD = 0; ++nm; }
+                            else ++l_MD;
+                        }
+                        q += len; t += len;
+                    } else if (op == 1) { q += len; nm += len; }
+                    else if (op == 2) {
+                        if (out) { out = put_int(out, l_MD); *out++ = '^'; for (int j = 0; j < len; ++j) *out++ = "ACGTN"[tb(t + j)]; }
+                        l_MD = 0; t += len; nm += len;
+                    } else if (op == 3) t += len;
+                }
+                if (out) { if (l_MD > 0) out = put_int(out, l_MD); md = out; }
+                return nm;
+            };
+            NM_unlifted = pass(cig, n_cig, ref_pos, nullptr);
+            if (ref_len > 0) NM = pass(lcig.data(), n_lcig, lifted, md);
         }
         const size_t md_len = (size_t)(md - md0);
-        char* const cs0 = md;                         // CIGAR text behind the MD text in the scratch (printed twice: column 6 and OA)
-        for (uint32_t k = 0; k < n_cig; ++k) { md = put_int(md, (int)(cig[k] >> 4)); *md++ = "MID"[cig[k] & 0xf]; }
+        char* const cs0 = md;                         // lifted CIGAR text, then the unlifted one, behind the MD text in the scratch
+        for (uint32_t k = 0; k < n_lcig; ++k) { md = put_int(md, (int)(lcig[k] >> 4)); *md++ = "MID"[lcig[k] & 0xf]; }
         const size_t cs_len = (size_t)(md - cs0);
+        char* const os0 = md;
+        for (uint32_t k = 0; k < n_cig; ++k) { md = put_int(md, (int)(cig[k] >> 4)); *md++ = "MID"[cig[k] & 0xf]; }
+        const size_t os_len = (size_t)(md - os0);
         const auto refi = ix.index(ref_pos);
         const std::string& lift_rname = ix.names[refi.first];
-        const int lift_pos = (int)(refi.second + 1);
+        const int lift_pos_1 = (int)(refi.second + 1);
+        const auto lfti = ix.index(lifted);
         const bool mapped = ref_len > 0;              // else: pos 0, rname/cigar "*", no MD, NM 0, tags still printed (unmapped_lft)
         const int flag = strand ? 16 : 0;
         const int mapq = (int)mapq_se_bwa(score, score2, (int32_t)(mapped ? ref_len : 0), (int32_t)m, (int32_t)P.min_len, P.smatch, P.smismatch, 50.0, mapq_coeff_fac);
         *p++ = '\t'; p = put_int(p, flag); *p++ = '\t';
-        if (mapped) p = put_str(p, lift_rname); else *p++ = '*';
-        *p++ = '\t'; p = put_int(p, mapped ? lift_pos : 0); *p++ = '\t'; p = put_int(p, mapq); *p++ = '\t';
+        if (mapped) p = put_str(p, ix.names[lfti.first]); else *p++ = '*';
+        *p++ = '\t'; p = put_int(p, mapped ? (int)(lfti.second + 1) : 0); *p++ = '\t'; p = put_int(p, mapq); *p++ = '\t';
         if (mapped) p = put_str(p, cs0, cs_len); else *p++ = '*';
         p = PUT_LIT(p, "\t*\t0\t0\t");
         if (strand) { for (uint32_t k = 0; k < m; ++k) p[k] = (char)compl_of(rd[m - 1 - k]); p += m; }
@@ -711,8 +763,8 @@ struct Aligner {
         p = PUT_LIT(p, "\tAS:i:"); p = put_int(p, score); p = PUT_LIT(p, "\tNM:i:"); p = put_int(p, mapped ? NM : 0);
         if (score2 != 0) { p = PUT_LIT(p, "\tZS:i:"); p = put_int(p, score2); }
         p = PUT_LIT(p, "\tMD:Z:"); if (mapped) p = put_str(p, md0, md_len);
-        p = PUT_LIT(p, "\tOA:Z:"); p = put_str(p, lift_rname); *p++ = ','; p = put_int(p, lift_pos);
-        p = put_str(p, strand ? ",-," : ",+,", 3); p = put_str(p, cs0, cs_len); *p++ = ','; p = put_int(p, mapq); *p++ = ','; p = put_int(p, NM); *p++ = ';';
+        p = PUT_LIT(p, "\tOA:Z:"); p = put_str(p, lift_rname); *p++ = ','; p = put_int(p, lift_pos_1);
+        p = put_str(p, strand ? ",-," : ",+,", 3); p = put_str(p, os0, os_len); *p++ = ','; p = put_int(p, mapq); *p++ = ','; p = put_int(p, NM_unlifted); *p++ = ';';
         p = PUT_LIT(p, "\tAA:Z:");
         for (uint32_t k = 0; k < n_alt; ++k) {
             const auto r = ix.index(alts[k].pos);

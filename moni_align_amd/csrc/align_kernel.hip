@@ -25,10 +25,10 @@ struct moni_aln_rec_t {                      // one per read
     int32_t score, score2;
     uint32_t n_cigar, n_alt;
     uint64_t cigar_off, alt_off;             // into the pools
-    int32_t nm;                              // NM and the MD:Z text (write_MD_core, sam.hpp:249-287), computed where the read and the text are resident
+    int32_t nm;                              // NM and the MD:Z text of the lifted alignment (write_MD_core, sam.hpp:249-287), computed where the read and the text are resident
     uint32_t md_len;
     uint64_t md_off;                         // into the MD pool (8-byte aligned)
-    uint32_t txt_len, txt_pad;               // the finished SAM line, when the kernel formats text (ak_args_t::fmt.txt_pool)
+    uint32_t txt_len; int32_t lift_nm;       // the finished SAM line, when the kernel formats text (ak_args_t::fmt.txt_pool); NM of the unlifted alignment (OA tag)
     uint64_t txt_off;                        // into the text pool, in 8-byte words
 };
 struct moni_alt_t { uint64_t pos; int32_t score; int32_t pad; };
@@ -44,6 +44,7 @@ struct ak_slot_t {                           // per read in flight, in HBM
     ac_ws_t ws;
     moni_dp_result_t res[AC_MAX_TASKS];      // results of the round's DP problems
     uint32_t cig[AK_CIG_CAP];
+    uint32_t lcig[AC_MAX_CIGAR];             // the final CIGAR lifted to the reference contig (liftidx::lift_cigar)
     uint64_t md_tmp[AK_MD_CAP / 8];
     uint64_t txt_tmp[AK_TXT_CAP / 8];
     uint64_t memo_key[AK_MEMO], memo_toff[AK_MEMO];
@@ -100,7 +101,9 @@ struct ak_args_t {
 
 // MD:Z text and NM of the final alignment (write_MD_core, sam.hpp:249-287), lane-private: read and text bytes through one-word
 // register caches, text staged in the slot.  Returns the length, or -1 when it does not fit AK_MD_CAP.
-__device__ __attribute__((noinline)) int ak_md(const ak_args_t& A, const ac_ws_t& W, uint8_t* __restrict__ md, int32_t& nm_out) {
+// cig / n_cig / t0: the CIGAR and the text position of its first column; md == nullptr: NM only.
+__device__ __attribute__((noinline)) int ak_md(const ak_args_t& A, const ac_ws_t& W, const uint32_t* __restrict__ cig, uint32_t n_cig, uint64_t t0,
+                                               uint8_t* __restrict__ md, int32_t& nm_out) {
     const uint8_t* __restrict__ text = A.D.text;
     const uint8_t* __restrict__ reads = A.D.reads;
     const uint64_t n_text = A.D.n_text, off = W.off;
@@ -130,11 +133,11 @@ __device__ __attribute__((noinline)) int ak_md(const ak_args_t& A, const ac_ws_t
     };
     int n = 0, NM = 0, l_MD = 0;
     bool ovf = false;
-    auto putc = [&](uint8_t ch) { if (n < AK_MD_CAP) md[n++] = ch; else ovf = true; };
+    auto putc = [&](uint8_t ch) { if (!md) return; if (n < AK_MD_CAP) md[n++] = ch; else ovf = true; };
     auto puti = [&](int v) { char b[12]; int k = 0; unsigned u = (unsigned)v; do { b[k++] = (char)('0' + u % 10); u /= 10; } while (u); while (k) putc((uint8_t)b[--k]); };
-    uint64_t t = W.fill.ref_pos; uint32_t q = 0;
-    for (uint32_t i = 0; i < W.n_cigar; ++i) {
-        const int op = W.cigar[i] & 0xf, len = (int)(W.cigar[i] >> 4);
+    uint64_t t = t0; uint32_t q = 0;
+    for (uint32_t i = 0; i < n_cig; ++i) {
+        const int op = cig[i] & 0xf, len = (int)(cig[i] >> 4);
         if (op == 0) {
             for (int j = 0; j < len; ++j) {
                 const uint32_t tc = tb(t + j);
@@ -186,8 +189,10 @@ __device__ __forceinline__ uint8_t ak_compl(uint8_t b) {        // kpbseq.h:120-
     return u == 'A' ? 'T' : u == 'C' ? 'G' : u == 'G' ? 'C' : u == 'T' ? 'A' : b;
 }
 
+// lcig / n_lcig / lifted: the alignment lifted to the reference contig (columns 3, 4, 6, MD, NM); W.cigar / W.fill.ref_pos: the
+// alignment on the pangenome text (OA tag, with lift_nm); aligner_ksw2.hpp:3116-3175
 __device__ __attribute__((noinline)) int ak_emit(const ak_args_t& A, const ac_ws_t& W, uint64_t r, bool aligned, const uint8_t* md, int md_len, int32_t nm,
-                                                 uint8_t* __restrict__ out) {
+                                                 int32_t lift_nm, const uint32_t* __restrict__ lcig, uint32_t n_lcig, uint64_t lifted, uint8_t* __restrict__ out) {
     const ak_fmt_t& F = A.fmt;
     ak_writer_t w; w.p = reinterpret_cast<uint64_t*>(out); w.acc = 0; w.n = 0; w.ovf = false;
     const uint64_t rd = W.off;                                   // offsets into the (padded) device buffers
@@ -207,10 +212,13 @@ __device__ __attribute__((noinline)) int ak_emit(const ak_args_t& A, const ac_ws
     const uint32_t strand = W.fill.strand;
     const int32_t score = W.fill.score, score2 = W.score2;
     uint64_t ref_len = 0;
-    for (uint32_t k = 0; k < W.n_cigar; ++k) { const int op = W.cigar[k] & 0xf; if (op == 0 || op == 2) ref_len += W.cigar[k] >> 4; }
+    for (uint32_t k = 0; k < n_lcig; ++k) { const int op = lcig[k] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += lcig[k] >> 4; }
     const uint64_t rk = ac_rank1(A.P, W.fill.ref_pos + 1);
     const uint32_t sid = (uint32_t)(rk - 1);
-    const int lift_pos = (int)(W.fill.ref_pos - A.P.seq_starts[rk - 1] + 1);
+    const int oa_pos = (int)(W.fill.ref_pos - A.P.seq_starts[rk - 1] + 1);         // sam->lift_pos: the position on the pangenome sequence
+    const uint64_t lrk = ac_rank1(A.P, lifted + 1);
+    const uint32_t lsid = (uint32_t)(lrk - 1);
+    const int pos1 = (int)(lifted - A.P.seq_starts[lrk - 1] + 1);                   // sam->pos
     const bool mapped = ref_len > 0;
     // compute_mapq_se_bwa (mapq.hpp:146-184), the operations in the host's order, none contracted
     int mapq = 0;
@@ -234,9 +242,9 @@ __device__ __attribute__((noinline)) int ak_emit(const ak_args_t& A, const ac_ws
     const uint64_t sn = F.sname_off[sid];
     const size_t sn_len = F.sname_off[sid + 1] - F.sname_off[sid];
     w.c('\t'); w.i(strand ? 16 : 0); w.c('\t');
-    if (mapped) put(R_sn, sn, sn_len); else w.c('*');
-    w.c('\t'); w.i(mapped ? lift_pos : 0); w.c('\t'); w.i(mapq); w.c('\t');
-    if (mapped) { for (uint32_t k = 0; k < W.n_cigar; ++k) { w.i((int)(W.cigar[k] >> 4)); w.c((uint8_t)"MID"[W.cigar[k] & 0xf]); } } else w.c('*');
+    if (mapped) put(R_sn, F.sname_off[lsid], (size_t)(F.sname_off[lsid + 1] - F.sname_off[lsid])); else w.c('*');
+    w.c('\t'); w.i(mapped ? pos1 : 0); w.c('\t'); w.i(mapq); w.c('\t');
+    if (mapped) { for (uint32_t k = 0; k < n_lcig; ++k) { w.i((int)(lcig[k] >> 4)); w.c((uint8_t)"MID"[lcig[k] & 0xf]); } } else w.c('*');
     w.lit("\t*\t0\t0\t");
     if (strand) for (uint32_t k = 0; k < m; ++k) w.c(ak_compl(R_reads.at(rd + m - 1 - k))); else put(R_reads, rd, m);
     w.c('\t');
@@ -244,9 +252,9 @@ __device__ __attribute__((noinline)) int ak_emit(const ak_args_t& A, const ac_ws
     w.lit("\tAS:i:"); w.i(score); w.lit("\tNM:i:"); w.i(mapped ? nm : 0);
     if (score2 != 0) { w.lit("\tZS:i:"); w.i(score2); }
     w.lit("\tMD:Z:"); if (mapped) for (int k = 0; k < md_len; ++k) w.c(md[k]);
-    w.lit("\tOA:Z:"); put(R_sn, sn, sn_len); w.c(','); w.i(lift_pos); w.lit(strand ? ",-," : ",+,");
+    w.lit("\tOA:Z:"); put(R_sn, sn, sn_len); w.c(','); w.i(oa_pos); w.lit(strand ? ",-," : ",+,");
     for (uint32_t k = 0; k < W.n_cigar; ++k) { w.i((int)(W.cigar[k] >> 4)); w.c((uint8_t)"MID"[W.cigar[k] & 0xf]); }
-    w.c(','); w.i(mapq); w.c(','); w.i(nm); w.c(';');
+    w.c(','); w.i(mapq); w.c(','); w.i(lift_nm); w.c(';');
     w.lit("\tAA:Z:");
     for (uint32_t k = 0; k < W.n_alt; ++k) {
         const uint64_t rk2 = ac_rank1(A.P, W.alt_pos[k] + 1);
@@ -261,24 +269,38 @@ __device__ __attribute__((noinline)) int ak_emit(const ak_args_t& A, const ac_ws
 
 // the record of a finished read (lane-private)
 __device__ __attribute__((noinline)) void ak_write_record(const ak_args_t& A, const ac_ws_t& W, uint64_t* __restrict__ md_tmp, uint64_t* __restrict__ txt_tmp,
-                                                          uint64_t slot_in_launch) {
+                                                          uint32_t* __restrict__ lcig, uint64_t slot_in_launch) {
     moni_aln_rec_t rec;
     rec.status = W.overflow ? 2u : (W.aligned ? 1u : 0u);
     rec.strand = W.fill.strand; rec.ref_pos = W.fill.ref_pos; rec.score = W.fill.score; rec.score2 = W.score2;
     rec.n_cigar = 0; rec.n_alt = 0; rec.cigar_off = 0; rec.alt_off = 0; rec.nm = 0; rec.md_len = 0; rec.md_off = 0;
-    rec.txt_len = 0; rec.txt_pad = 0; rec.txt_off = 0;
-    int32_t nm = 0;
-    int md_len = 0;
+    rec.txt_len = 0; rec.lift_nm = 0; rec.txt_off = 0;
+    int32_t nm = 0, lift_nm = 0;
+    int md_len = 0, n_lcig = 0;
+    uint64_t lifted = 0;
     if (rec.status == 1) {
-        md_len = ak_md(A, W, reinterpret_cast<uint8_t*>(md_tmp), nm);
+        // the alignment lifted to the reference contig (aligner_ksw2.hpp:3133-3160): CIGAR, position, MD / NM over the lifted window;
+        // NM of the alignment on the pangenome text stays for the OA tag
+        const uint64_t rk = ac_rank1(A.P, W.fill.ref_pos + 1);
+        const moni_lift_seq_t L = A.P.lift_seqs[rk - 1];
+        const moni_lift_run_t* __restrict__ runs = A.P.lift_runs + L.run_off;
+        const uint64_t start = W.fill.ref_pos - A.P.seq_starts[rk - 1];
+        n_lcig = lift_cigar(runs, L.n_runs, start, W.cigar, W.n_cigar, lcig, AC_MAX_CIGAR);
+        lifted = L.second + lift_pos(runs, L.n_runs, start);
+        bool same = n_lcig == (int)W.n_cigar && lifted == W.fill.ref_pos;
+        for (uint32_t k = 0; same && k < W.n_cigar; ++k) same = lcig[k] == W.cigar[k];
+        uint64_t lref = 0;
+        for (int k = 0; k < n_lcig; ++k) { const int op = lcig[k] & 0xf; if (op == 0 || op == 2 || op == 3) lref += lcig[k] >> 4; }
+        if (n_lcig >= 0 && lref > 0) md_len = ak_md(A, W, lcig, (uint32_t)n_lcig, lifted, reinterpret_cast<uint8_t*>(md_tmp), nm);
+        if (same) lift_nm = nm; else (void)ak_md(A, W, W.cigar, W.n_cigar, W.fill.ref_pos, nullptr, lift_nm);
         const unsigned long long md_words = md_len > 0 ? (unsigned long long)((md_len + 7) >> 3) : 0ull;
         const unsigned long long co = atomicAdd(&A.cursors[0], (unsigned long long)W.n_cigar);
         const unsigned long long ao = atomicAdd(&A.cursors[1], (unsigned long long)W.n_alt);
         const unsigned long long mo = atomicAdd(&A.cursors[14], md_words);
-        if (md_len < 0 || co + W.n_cigar > A.cig_cap || ao + W.n_alt > A.alt_cap || mo + md_words > A.md_cap) rec.status = 2;      // pool too small: let the host pipeline redo the read
+        if (md_len < 0 || n_lcig < 0 || co + W.n_cigar > A.cig_cap || ao + W.n_alt > A.alt_cap || mo + md_words > A.md_cap) rec.status = 2;      // pool too small: let the host pipeline redo the read
         else {
             rec.n_cigar = W.n_cigar; rec.cigar_off = co; rec.n_alt = W.n_alt; rec.alt_off = ao;
-            rec.nm = nm; rec.md_len = (uint32_t)md_len; rec.md_off = mo;
+            rec.nm = nm; rec.lift_nm = lift_nm; rec.md_len = (uint32_t)md_len; rec.md_off = mo;
             for (uint32_t k = 0; k < W.n_cigar; ++k) A.cig_pool[co + k] = W.cigar[k];
             for (uint32_t k = 0; k < W.n_alt; ++k) { moni_alt_t x; x.pos = W.alt_pos[k]; x.score = W.alt_score[k]; x.pad = 0; A.alt_pool[ao + k] = x; }
             for (unsigned long long k = 0; k < md_words; ++k) A.md_pool[mo + k] = md_tmp[k];
@@ -286,7 +308,8 @@ __device__ __attribute__((noinline)) void ak_write_record(const ak_args_t& A, co
     }
     if (A.fmt.txt_pool && rec.status != 2) {
         // the finished SAM line; when it does not fit (staging or pool) the host formats this record from the fields above
-        const int n = ak_emit(A, W, A.read_lo + slot_in_launch, rec.status == 1, reinterpret_cast<const uint8_t*>(md_tmp), md_len, nm, reinterpret_cast<uint8_t*>(txt_tmp));
+        const int n = ak_emit(A, W, A.read_lo + slot_in_launch, rec.status == 1, reinterpret_cast<const uint8_t*>(md_tmp), md_len, nm, lift_nm, lcig,
+                              (uint32_t)(n_lcig > 0 ? n_lcig : 0), lifted, reinterpret_cast<uint8_t*>(txt_tmp));
         if (n > 0) {
             const unsigned long long words = (unsigned long long)((n + 7) >> 3);
             const unsigned long long to = atomicAdd(&A.cursors[15], words);
@@ -321,7 +344,7 @@ align_kernel(const ak_args_t A) {
         const long long c0 = clock64();
         const bool start = __popcll(__ballot(state == 0 || state == 3)) >= AK_START_MIN || __ballot(state == 1) == 0ull;
         // finished reads write their records (MD/NM, pool entries) together, like the starts: it is lane-private work too
-        if (state == 3 && start) { ak_write_record(A, W, S->md_tmp, S->txt_tmp, r_in); state = 0; }
+        if (state == 3 && start) { ak_write_record(A, W, S->md_tmp, S->txt_tmp, S->lcig, r_in); state = 0; }
         if (state == 0 && start) {
             r_in = atomicAdd(&A.cursors[4], 1ull);
             if (r_in >= A.n_reads) state = 2;
@@ -336,7 +359,7 @@ align_kernel(const ak_args_t A) {
                 } else chained = ac_init(W, A.P, A.mems, A.read_mem_off[r], A.read_mem_off[r + 1], A.occs);
                 if (chained) ac_drive(W, A.P, nullptr, nullptr);
                 if (chained && !W.overflow && W.stage != AC_DONE) state = 1;
-                else ak_write_record(A, W, S->md_tmp, S->txt_tmp, r_in);
+                else ak_write_record(A, W, S->md_tmp, S->txt_tmp, S->lcig, r_in);
             }
         }
         const unsigned long long waiting = __ballot(state == 1);

@@ -17,6 +17,7 @@
 
 #include "../../include/moni_hip.h"
 #include "image.hpp"
+#include "lift_build.hpp"
 #include "align_host.hpp"
 #include "layout.h"
 #include "seed_kernels.hip"
@@ -41,6 +42,8 @@ struct moni_index {
     uint64_t* d_seq_starts = nullptr;
     uint32_t* d_name_id = nullptr;
     uint8_t* d_snames = nullptr; uint32_t* d_sname_off = nullptr;      // sequence names, ragged (SAM text in align_kernel)
+    moni_lift_seq_t* d_lift_seqs = nullptr; moni_lift_run_t* d_lift_runs = nullptr;   // liftidx::lifts (lift_core.h)
+    bool lifts_null = true;
     uint64_t bytes = 0;
     // host copies for the host stages of the full path (chaining, MD/NM, SAM)
     std::vector<uint8_t> h_text;
@@ -174,12 +177,16 @@ int moni_index_create(const moni_flat_index_t* f, int device, moni_index_t** out
         return MONI_ENODEV;
     }
     HIPCHK(hipSetDevice(device));
+    if (f->n < 2 || f->r < 1 || f->n_seq < 1) return MONI_EINVAL;
     HostImage img;
     int rc = img.build(*f);
     if (rc) { fprintf(stderr, "moni_hip: index rejected: %s\n", img.err.c_str()); return rc; }
+    LiftTables lt;
+    { std::string lerr; if ((rc = lt.build(*f, lerr))) { fprintf(stderr, "moni_hip: index rejected: %s\n", lerr.c_str()); return rc; } }
     moni_index* I = new moni_index();
     I->device = device;
     I->K = img.K;
+    I->lifts_null = lt.all_null;
     std::vector<moni_tables_t> tv(1, img.T);
     std::vector<uint8_t> text(f->text, f->text + (f->n - 1));
     text.resize(text.size() + 16, 0);            // text_byte() reads aligned 8-byte words
@@ -200,7 +207,8 @@ int moni_index_create(const moni_flat_index_t* f, int device, moni_index_t** out
     I->h_text.assign(f->text, f->text + (f->n - 1));
     I->hix.n_text = f->n - 1; I->hix.w = f->w; I->hix.text = I->h_text.data();
     I->hix.seq_starts.assign(f->seq_starts, f->seq_starts + f->n_seq + 1);
-    if ((rc = upload(&I->d_tables, tv, I->bytes)) || (rc = upload(&I->d_rows, img.rows, I->bytes)) || (rc = upload(&I->d_frows, img.frows, I->bytes)) ||
+    I->hix.lift_seqs = lt.seqs; I->hix.lift_runs = lt.runs;
+    if ((rc = upload(&I->d_lift_seqs, lt.seqs, I->bytes)) || (rc = upload(&I->d_lift_runs, lt.runs, I->bytes)) || (rc = upload(&I->d_tables, tv, I->bytes)) || (rc = upload(&I->d_rows, img.rows, I->bytes)) || (rc = upload(&I->d_frows, img.frows, I->bytes)) ||
         (rc = upload(&I->d_cr, img.cr, I->bytes)) || (rc = upload(&I->d_recs, img.recs, I->bytes)) ||
         (rc = upload(&I->d_phi, img.phi, I->bytes)) || (rc = upload(&I->d_phi_inv, img.phi_inv, I->bytes)) ||
         (rc = upload(&I->d_phi_dir, img.phi_dir, I->bytes)) || (rc = upload(&I->d_phi_inv_dir, img.phi_inv_dir, I->bytes)) ||
@@ -214,46 +222,81 @@ int moni_index_create(const moni_flat_index_t* f, int device, moni_index_t** out
 }
 
 int moni_index_load(const char* path, int device, moni_index_t** out) {
+    if (!path || !out) return MONI_EINVAL;
     FILE* fp = fopen(path, "rb");
     if (!fp) return MONI_EIO;
     char magic[8];
     uint64_t hdr[6];
     if (fread(magic, 1, 8, fp) != 8 || memcmp(magic, "MONIFLT2", 8) != 0 || fread(hdr, 8, 6, fp) != 6) { fclose(fp); return MONI_EIO; }
     const uint64_t n = hdr[0], r = hdr[1], w = hdr[2], nseq = hdr[3], nblob = hdr[4];
-    std::vector<uint64_t> F(256), starts(r + 1), ssa(r), esa(r), thr(r), slcp(r), seq_starts(nseq + 1);
-    std::vector<uint8_t> heads(r), text(n - 1);
-    auto get = [&](void* dst, size_t bytes) {
-        if (bytes && fread(dst, 1, bytes, fp) != bytes) return false;
-        size_t pad = (8 - bytes % 8) % 8;
-        char t8[8];
-        if (pad && fread(t8, 1, pad, fp) != pad) return false;
-        return true;
-    };
-    bool ok = get(F.data(), 256 * 8) && get(heads.data(), r) && get(starts.data(), (r + 1) * 8) && get(ssa.data(), r * 8) &&
-              get(esa.data(), r * 8) && get(thr.data(), r * 8) && get(slcp.data(), r * 8) && get(text.data(), n - 1) &&
-              get(seq_starts.data(), (nseq + 1) * 8);
-    std::vector<char> blob(nblob + 8), names_flat;
-    ok = ok && get(blob.data(), nblob);
-    fclose(fp);
-    if (!ok) return MONI_EIO;
-    for (uint64_t i = 0, p = 0; i < nseq; ++i) {
-        uint64_t ln;
-        memcpy(&ln, blob.data() + p, 8);
-        names_flat.insert(names_flat.end(), blob.data() + p + 8, blob.data() + p + 8 + ln);
-        names_flat.push_back(0);
-        p += 8 + ln;
+    const bool has_lifts = hdr[5] != 0;
+    // the header is not trusted: every count is checked against the file size before anything is allocated
+    uint64_t fsize = 0;
+    { const long at = ftell(fp); if (at < 0 || fseek(fp, 0, SEEK_END) != 0) { fclose(fp); return MONI_EIO; } fsize = (uint64_t)ftell(fp); if (fseek(fp, at, SEEK_SET) != 0) { fclose(fp); return MONI_EIO; } }
+    auto pad8 = [](uint64_t b) { return (b + 7) & ~7ull; };
+    if (n < 2 || r < 1 || r > n || nseq < 1 || nseq > n || n > fsize || nblob > fsize ||
+        56 + 256 * 8 + pad8(r) + (r + 1) * 8 + 4 * r * 8 + pad8(n - 1) + (nseq + 1) * 8 + pad8(nblob) > fsize) { fclose(fp); return MONI_EIO; }
+    try {
+        std::vector<uint64_t> F(256), starts(r + 1), ssa(r), esa(r), thr(r), slcp(r), seq_starts(nseq + 1);
+        std::vector<uint8_t> heads(r), text(n - 1);
+        auto get = [&](void* dst, size_t bytes) {
+            if (bytes && fread(dst, 1, bytes, fp) != bytes) return false;
+            size_t pad = (8 - bytes % 8) % 8;
+            char t8[8];
+            if (pad && fread(t8, 1, pad, fp) != pad) return false;
+            return true;
+        };
+        bool ok = get(F.data(), 256 * 8) && get(heads.data(), r) && get(starts.data(), (r + 1) * 8) && get(ssa.data(), r * 8) &&
+                  get(esa.data(), r * 8) && get(thr.data(), r * 8) && get(slcp.data(), r * 8) && get(text.data(), n - 1) &&
+                  get(seq_starts.data(), (nseq + 1) * 8);
+        std::vector<char> blob(nblob + 8), names_flat;
+        ok = ok && get(blob.data(), nblob);
+        // lifts (liftidx.hpp:131-143): per sequence second, columns, #ins, #del, then the two lists of ones
+        std::vector<uint64_t> l_second, l_len, l_ins_off(1, 0), l_del_off(1, 0), l_ins, l_del;
+        if (ok && has_lifts) {
+            for (uint64_t i = 0; i < nseq && ok; ++i) {
+                uint64_t h4[4];
+                ok = get(h4, 32) && h4[2] <= fsize / 8 && h4[3] <= fsize / 8;
+                if (!ok) break;
+                l_second.push_back(h4[0]); l_len.push_back(h4[1]);
+                const size_t a0 = l_ins.size(), d0 = l_del.size();
+                l_ins.resize(a0 + h4[2]); l_del.resize(d0 + h4[3]);
+                ok = get(l_ins.data() + a0, h4[2] * 8) && get(l_del.data() + d0, h4[3] * 8);
+                l_ins_off.push_back(l_ins.size()); l_del_off.push_back(l_del.size());
+            }
+        }
+        fclose(fp); fp = nullptr;
+        if (!ok) return MONI_EIO;
+        for (uint64_t i = 0, p = 0; i < nseq; ++i) {
+            uint64_t ln;
+            if (p + 8 > nblob) return MONI_EIO;
+            memcpy(&ln, blob.data() + p, 8);
+            if (ln > nblob || p + 8 + ln > nblob) return MONI_EIO;
+            names_flat.insert(names_flat.end(), blob.data() + p + 8, blob.data() + p + 8 + ln);
+            names_flat.push_back(0);
+            p += 8 + ln;
+        }
+        moni_flat_index_t f;
+        memset(&f, 0, sizeof f);
+        f.n = n; f.r = r; f.w = w; f.n_seq = nseq;
+        f.F = F.data(); f.heads = heads.data(); f.starts = starts.data(); f.ssa = ssa.data(); f.esa = esa.data();
+        f.thr = thr.data(); f.slcp = slcp.data(); f.text = text.data(); f.seq_starts = seq_starts.data(); f.seq_names = names_flat.data();
+        l_ins.push_back(0); l_del.push_back(0);      // never empty: the pointers stay valid
+        if (has_lifts) {
+            f.lift_second = l_second.data(); f.lift_len = l_len.data(); f.lift_ins_off = l_ins_off.data(); f.lift_ins = l_ins.data();
+            f.lift_del_off = l_del_off.data(); f.lift_del = l_del.data();
+        }
+        return moni_index_create(&f, device, out);
+    } catch (const std::bad_alloc&) {
+        if (fp) fclose(fp);
+        return MONI_ENOMEM;
     }
-    moni_flat_index_t f;
-    f.n = n; f.r = r; f.w = w; f.n_seq = nseq;
-    f.F = F.data(); f.heads = heads.data(); f.starts = starts.data(); f.ssa = ssa.data(); f.esa = esa.data();
-    f.thr = thr.data(); f.slcp = slcp.data(); f.text = text.data(); f.seq_starts = seq_starts.data(); f.seq_names = names_flat.data();
-    return moni_index_create(&f, device, out);
 }
 
 void moni_index_destroy(moni_index_t* I) {
     if (!I) return;
     (void)hipSetDevice(I->device);
-    void* ps[] = {I->d_tables, I->d_rows, I->d_frows, I->d_cr, I->d_recs, I->d_phi, I->d_phi_inv, I->d_phi_dir, I->d_phi_inv_dir, I->d_text, I->d_seq_starts, I->d_name_id, I->d_snames, I->d_sname_off};
+    void* ps[] = {I->d_tables, I->d_rows, I->d_frows, I->d_cr, I->d_recs, I->d_phi, I->d_phi_inv, I->d_phi_dir, I->d_phi_inv_dir, I->d_text, I->d_seq_starts, I->d_name_id, I->d_snames, I->d_sname_off, I->d_lift_seqs, I->d_lift_runs};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete I;
 }
@@ -268,12 +311,12 @@ int moni_ctx_create(moni_index_t* I, moni_ctx_t** out) {
     c->idx = I;
     if (const char* v = getenv("MONI_MS_VARIANT")) c->ms_variant = atoi(v);
     if (const char* v = getenv("MONI_EXTZ_LDS")) c->extz_lds = atoi(v);
-    HIPCHK(hipStreamCreate(&c->stream));
-    for (int i = 0; i < EV_N; ++i) { HIPCHK(hipEventCreate(&c->ev[i])); c->ev_valid[i] = false; }
-    HIPCHK(hipMalloc((void**)&c->d_small, 16));
-    HIPCHK(hipMalloc((void**)&c->d_counters, 4 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(c->d_small, 0, 16));
-    HIPCHK(hipMemset(c->d_counters, 0, 4 * sizeof(unsigned long long)));
+    for (int i = 0; i < EV_N; ++i) { c->ev[i] = nullptr; c->ev_valid[i] = false; }
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess;
+    for (int i = 0; ok && i < EV_N; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_small, 16) == hipSuccess && hipMalloc((void**)&c->d_counters, 4 * sizeof(unsigned long long)) == hipSuccess &&
+         hipMemset(c->d_small, 0, 16) == hipSuccess && hipMemset(c->d_counters, 0, 4 * sizeof(unsigned long long)) == hipSuccess;
+    if (!ok) { fprintf(stderr, "moni_hip: context creation failed on device %d\n", I->device); moni_ctx_destroy(c); return MONI_ENODEV; }
     *out = c;
     return MONI_OK;
 }
@@ -281,7 +324,7 @@ int moni_ctx_create(moni_index_t* I, moni_ctx_t** out) {
 void moni_ctx_destroy(moni_ctx_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->idx->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->seq.release(); c->offs.release(); c->ptr.release(); c->pat.release(); c->cnt_m.release(); c->cnt_s.release(); c->mem_slots.release(); c->tot.release();
     c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
     c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
@@ -297,8 +340,8 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     free(c->out_buf);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->d_counters) (void)hipFree(c->d_counters);
-    for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(c->ev[i]);
-    (void)hipStreamDestroy(c->stream);
+    for (int i = 0; i < EV_N; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -521,16 +564,15 @@ int moni_phi_lcp_batch(moni_ctx_t* c, const uint64_t* pos, uint64_t n, int inver
     if (!n) return MONI_OK;
     uint64_t* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, 3 * n * 8));
-    HIPCHK(hipMemcpy(d, pos, n * 8, hipMemcpyHostToDevice));
+    if (hipMemcpy(d, pos, n * 8, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return MONI_ENODEV; }
     phi_tab_t P;
     P.recs = inverse ? I->d_phi_inv : I->d_phi;
     P.dir = inverse ? I->d_phi_inv_dir : I->d_phi_dir;
     hipLaunchKernelGGL(phi_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, I->K, P, d, n, d + n, d + 2 * n);
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out_pos, d + n, n * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out_lcp, d + 2 * n, n * 8, hipMemcpyDeviceToHost));
+    const bool ok = hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(out_pos, d + n, n * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+                    hipMemcpy(out_lcp, d + 2 * n, n * 8, hipMemcpyDeviceToHost) == hipSuccess;
     (void)hipFree(d);
-    return MONI_OK;
+    return ok ? MONI_OK : MONI_ENODEV;
 }
 
 int moni_last_kernel_ms(moni_ctx_t* c, int which, float* ms) {
@@ -646,6 +688,7 @@ int moni_align_run(moni_ctx_t* c, const uint8_t* names, const uint64_t* name_off
 static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bool ctx_out, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
                       const moni_align_params_t* prm, char** sam, uint64_t* sam_len, moni_align_stats_t* stats) {
     moni_index* I = c->idx;
+    HIPCHK(hipSetDevice(I->device));          // a worker thread of moni-hip-align starts on device 0: every allocation below must land on this index's GPU
     c->dp_kernel_ms_accum = 0;
     std::string out;
     mh::AlignStats st;
@@ -784,6 +827,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             A.P.max_dist_x = prm->max_dist_x; A.P.max_dist_y = prm->max_dist_y; A.P.max_iter = prm->max_iter; A.P.max_pred = prm->max_pred;
             A.P.min_chain_score = prm->min_chain_score; A.P.min_chain_length = prm->min_chain_length;
             A.P.n_text = I->K.n_text; A.P.n_seq = I->K.n_seq; A.P.seq_starts = I->d_seq_starts;
+            A.P.lift_seqs = I->d_lift_seqs; A.P.lift_runs = I->d_lift_runs;
             A.D.sc_mch = prm->smatch; A.D.sc_mis = -prm->smismatch; A.D.sc_N = -prm->gape; A.D.wild = 4; A.D.qo = prm->gapo; A.D.e = prm->gape;
             A.D.end_bonus = prm->end_bonus; A.D.reads = c->seq.p; A.D.text = I->d_text; A.D.n_text = I->K.n_text;
             A.mems = c->mems.p; A.occs = c->occs.p; A.read_mem_off = c->read_mem_off.p; A.offs = c->offs.p;
@@ -853,7 +897,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                     if (!AL.emit_record(ob, mds, (const char*)names + name_off[g], (size_t)(name_off[g + 1] - name_off[g]), b->seq + off, quals ? quals + off : nullptr, m,
                                         Rr.status == 1, Rr.strand, Rr.ref_pos, Rr.score, Rr.score2, R.cig + Rr.cigar_off, Rr.n_cigar,
                                         (const mh::moni_alt_like*)R.alt + Rr.alt_off, Rr.n_alt,
-                                        Rr.status == 1 ? (const char*)(R.md + Rr.md_off) : nullptr, Rr.md_len, Rr.nm)) { oom = true; break; }
+                                        Rr.status == 1 ? (const char*)(R.md + Rr.md_off) : nullptr, Rr.md_len, Rr.nm, Rr.lift_nm)) { oom = true; break; }
                     if (Rr.status == 1) aligned_t[t]++;
                 }
             });

@@ -36,6 +36,33 @@ MAGIC = b"MONIFLT2"
 
 
 @dataclasses.dataclass
+class Lifts:
+    """liftidx::lifts (include/aligner/liftidx.hpp:131-143) as flat arrays, one lift per sequence: `second` (start of the
+    target contig in the concatenation), the number of alignment columns and the sorted positions of the ones of the
+    levioSAM ins / del bit-vectors (ragged; offsets have n_seq + 1 entries).  The snp vector is not used by this path."""
+    second: np.ndarray           # uint64[nseq]
+    len: np.ndarray              # uint64[nseq]
+    ins_off: np.ndarray          # uint64[nseq+1]
+    ins: np.ndarray              # uint64[]
+    del_off: np.ndarray          # uint64[nseq+1]
+    dele: np.ndarray             # uint64[]
+
+    @staticmethod
+    def from_lists(second, length, ins_list, del_list) -> "Lifts":
+        u = np.uint64
+        io = np.zeros(len(ins_list) + 1, dtype=u)
+        do = np.zeros(len(del_list) + 1, dtype=u)
+        io[1:] = np.cumsum([len(x) for x in ins_list])
+        do[1:] = np.cumsum([len(x) for x in del_list])
+        cat = lambda L: (np.concatenate([np.asarray(x, dtype=u) for x in L]) if sum(len(x) for x in L) else np.zeros(0, dtype=u))
+        return Lifts(np.asarray(second, dtype=u), np.asarray(length, dtype=u), io, np.ascontiguousarray(cat(ins_list)), do,
+                     np.ascontiguousarray(cat(del_list)))
+
+    def ins_of(self, i): return self.ins[int(self.ins_off[i]):int(self.ins_off[i + 1])]
+    def del_of(self, i): return self.dele[int(self.del_off[i]):int(self.del_off[i + 1])]
+
+
+@dataclasses.dataclass
 class FlatIndex:
     n: int                       # BWT length = len(text) + 1
     r: int
@@ -50,6 +77,7 @@ class FlatIndex:
     text: np.ndarray             # uint8[n-1]
     seq_starts: np.ndarray       # uint64[nseq+1]
     names: List[str]
+    lifts: Optional[Lifts] = None  # None = FASTA-built index (null lifts, liftidx.hpp:150-157)
 
     # ---- (de)serialisation: one flat little-endian file ----
     def save(self, path: str) -> None:
@@ -57,7 +85,7 @@ class FlatIndex:
         with open(path, "wb") as f:
             f.write(MAGIC)
             f.write(struct.pack("<6Q", self.n, self.r, self.w, len(self.seq_starts) - 1,
-                                len(names_blob), 0))
+                                len(names_blob), 1 if self.lifts is not None else 0))
             def put(a, dt):
                 b = np.ascontiguousarray(a, dtype=dt).tobytes()
                 f.write(b)
@@ -73,6 +101,13 @@ class FlatIndex:
             put(self.seq_starts, np.uint64)
             f.write(names_blob)
             f.write(b"\0" * ((-len(names_blob)) % 8))
+            if self.lifts is not None:       # per sequence: second, columns, #ins, #del, then the two lists of ones
+                lf = self.lifts
+                for i in range(len(self.seq_starts) - 1):
+                    a, b = lf.ins_of(i), lf.del_of(i)
+                    f.write(struct.pack("<4Q", int(lf.second[i]), int(lf.len[i]), len(a), len(b)))
+                    put(a, np.uint64)
+                    put(b, np.uint64)
 
     @staticmethod
     def load(path: str) -> "FlatIndex":
@@ -80,7 +115,7 @@ class FlatIndex:
             buf = f.read()
         if buf[:8] != MAGIC:
             raise ValueError("not a MONIFLT2 file: " + path)
-        n, r, w, nseq, nblob, _ = struct.unpack_from("<6Q", buf, 8)
+        n, r, w, nseq, nblob, has_lifts = struct.unpack_from("<6Q", buf, 8)
         off = 8 + 48
         def get(count, dt):
             nonlocal off
@@ -103,7 +138,17 @@ class FlatIndex:
             (ln,) = struct.unpack_from("<Q", buf, p)
             names.append(buf[p + 8:p + 8 + ln].decode())
             p += 8 + ln
-        return FlatIndex(n, r, w, F, heads, starts, ssa, esa, thr, slcp, text, seq_starts, names)
+        lifts = None
+        if has_lifts:
+            off += nblob + ((-nblob) % 8)
+            sec, ln_, il, dl = [], [], [], []
+            for _ in range(nseq):
+                a, b, c, d = struct.unpack_from("<4Q", buf, off)
+                off += 32
+                sec.append(a); ln_.append(b)
+                il.append(get(c, np.uint64)); dl.append(get(d, np.uint64))
+            lifts = Lifts.from_lists(sec, ln_, il, dl)
+        return FlatIndex(n, r, w, F, heads, starts, ssa, esa, thr, slcp, text, seq_starts, names, lifts)
 
 
 # --------------------------------------------------------------------------------------
@@ -193,7 +238,7 @@ def lcp_from_levels(sa: torch.Tensor, key0: torch.Tensor, k0: int, bits: int, le
 # --------------------------------------------------------------------------------------
 
 def build_flat_index(text: np.ndarray, seq_starts: np.ndarray, names: List[str], w: int,
-                     device: Optional[str] = None, log=None) -> FlatIndex:
+                     device: Optional[str] = None, log=None, lifts: Optional[Lifts] = None) -> FlatIndex:
     if device is None:
         device = "cuda" if torch.cuda.is_available() else "cpu"
     dev = torch.device(device)
@@ -279,11 +324,15 @@ def build_flat_index(text: np.ndarray, seq_starts: np.ndarray, names: List[str],
         text=text,
         seq_starts=np.asarray(seq_starts, dtype=np.uint64),
         names=list(names),
+        lifts=lifts,
     )
 
 
-def build_from_pangenome(pg, device: Optional[str] = None, log=None) -> FlatIndex:
-    return build_flat_index(pg.text, pg.seq_starts, pg.names, pg.w, device=device, log=log)
+def build_from_pangenome(pg, device: Optional[str] = None, log=None, lifted: bool = True) -> FlatIndex:
+    """lifted: carry the pangenome's VCF-style lifts (a `moni build -r ref -v vcf -H12` index: haplotypes lift onto the
+    reference contig); False = the FASTA-built form of the same text (null lifts)."""
+    lifts = pg.lifts() if (lifted and getattr(pg, "variants", None) is not None) else None
+    return build_flat_index(pg.text, pg.seq_starts, pg.names, pg.w, device=device, log=log, lifts=lifts)
 
 
 # ---- the reference builder's raw per-run files (SURVEY.md App. B, "raw builder inputs") ------------------------------------

@@ -17,7 +17,7 @@ This is test/bench infrastructure, not the product path.
 from __future__ import annotations
 
 import dataclasses
-from typing import List
+from typing import List, Optional
 
 import numpy as np
 
@@ -35,6 +35,29 @@ class Pangenome:
     seqs: List[np.ndarray]          # uint8 ASCII, one per sequence
     names: List[str]
     w: int
+    # per haplotype (sequences 1..): the variants it carries against sequence 0 as (pos[], kind[], length[]) with kind
+    # 0 = SNP, 1 = insertion of `length` bases before reference base pos, 2 = deletion of reference bases [pos, pos + length);
+    # None = unrelated sequences (FASTA-style pangenome)
+    variants: Optional[List[tuple]] = None
+
+    def lifts(self):
+        """levioSAM-style lifts of a `-r ref -v vcf` build (liftidx.hpp:131-143): sequence 0 carries a null lift, every
+        haplotype the ins / del column sets of its alignment to sequence 0 (columns = reference bases + inserted bases;
+        an insertion's columns precede the reference base it is placed before), all lifting onto sequence 0 (second = 0)."""
+        from .index_build import Lifts
+        second, length, ins_l, del_l = [0], [len(self.seqs[0])], [np.zeros(0, np.uint64)], [np.zeros(0, np.uint64)]
+        for (pos, kind, ln) in self.variants:
+            pos = np.asarray(pos, dtype=np.int64); kind = np.asarray(kind); ln = np.asarray(ln, dtype=np.int64)
+            is_ins, is_del = kind == 1, kind == 2
+            ins_before = np.cumsum(np.where(is_ins, ln, 0)) - np.where(is_ins, ln, 0)      # inserted columns before each event
+            col = pos + ins_before
+            ins_cols = [np.arange(c, c + l, dtype=np.int64) for c, l in zip(col[is_ins], ln[is_ins])]
+            del_cols = [np.arange(c, c + l, dtype=np.int64) for c, l in zip(col[is_del], ln[is_del])]
+            ins_l.append(np.concatenate(ins_cols).astype(np.uint64) if ins_cols else np.zeros(0, np.uint64))
+            del_l.append(np.concatenate(del_cols).astype(np.uint64) if del_cols else np.zeros(0, np.uint64))
+            second.append(0)
+            length.append(len(self.seqs[0]) + int(ln[is_ins].sum()))
+        return Lifts.from_lists(second, length, ins_l, del_l)
 
     @property
     def text(self) -> np.ndarray:
@@ -74,27 +97,33 @@ def make_pangenome(base_len: int, n_haps: int, seed: int = 19, var_seed: int = 1
     ins_bases = _ACGT[vr.integers(0, 4, size=(n_sites, 50), dtype=np.uint8)]
     code = np.full(256, 255, dtype=np.uint8)
     code[_ACGT] = np.arange(4, dtype=np.uint8)
+    variants = []
     for h in range(n_haps):
         carry = vr.random(n_sites) < af
         pieces = []
         prev = 0
+        vp, vk, vl = [], [], []
         for s in np.nonzero(carry)[0]:
             p = int(pos[s])
             if kind[s] < 0.85:
                 pieces.append(g0[prev:p])
                 pieces.append(_ACGT[[(int(code[g0[p]]) + int(snp_shift[s])) & 3]])
                 prev = p + 1
+                vp.append(p); vk.append(0); vl.append(1)
             elif kind[s] < 0.925:
                 pieces.append(g0[prev:p])
                 pieces.append(ins_bases[s, : int(ilen[s])])
                 prev = p
+                vp.append(p); vk.append(1); vl.append(int(ilen[s]))
             else:
                 pieces.append(g0[prev:p])
                 prev = p + int(ilen[s])
+                vp.append(p); vk.append(2); vl.append(int(ilen[s]))
         pieces.append(g0[prev:])
         seqs.append(np.concatenate(pieces))
         names.append("S%d_H%d_%s" % (h // 2 + 1, h % 2 + 1, contig))
-    return Pangenome(seqs=seqs, names=names, w=w)
+        variants.append((np.asarray(vp, dtype=np.int64), np.asarray(vk, dtype=np.int8), np.asarray(vl, dtype=np.int64)))
+    return Pangenome(seqs=seqs, names=names, w=w, variants=variants)
 
 
 def revcomp(reads: np.ndarray) -> np.ndarray:

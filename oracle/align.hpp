@@ -12,8 +12,8 @@
 // Deliberately literal about the reference's arithmetic quirks (unsigned wrap, `%d` of size_t, the
 // deletion shortcut that computes l = 0, the left-context length when mem_pos <= ext_len, unstable
 // std::sort on the same initial order with the same comparators, libstdc++).
-// Lift-over: only the FASTA-built (null lift) case is restated: lift(pos) = pos, lift_cigar = identity
-// (levioSAM is an absent submodule; VCF-built lifts are SURVEY §8(f) item 1).
+// Lift-over (aligner_ksw2.hpp:3133-3175, liftidx.hpp:89-95,159-164): FlatIndex::lift / lift_cigar restate levioSAM's
+// lift_pos (pinned by the reference's .ldx/.lft fixture) and lift_cigar ([UPSTREAM-RECALL], unpinned).
 #pragma once
 #include <climits>
 #include <cmath>
@@ -501,20 +501,21 @@ struct aligner {
             sam->lift_pos = refi.second + 1;
             sam->lift_rname = ix.names[refi.first];
             sam->lift_rlen = ref_len;
-            // bam_set1 + idx.lift_cigar: identity for a null lift
+            // bam_set1(.., pos = ref.second, .., n_cigar, cigar, ..) + idx.lift_cigar(bam, ref_pos)
+            const std::vector<uint32_t> lft_cigar = ix.lift_cigar(cigar, n_cigar, ref_pos);
             const auto lift = ix.lift(ref_pos);
             const auto lft_ref = ix.index(lift);
             sam->pos = lft_ref.second + 1;
             sam->rname = ix.names[lft_ref.first];
             sam->cigar = "";
-            for (size_t i = 0; i < n_cigar; ++i) sam->cigar += std::to_string(cigar[i] >> 4) + "MID"[cigar[i] & 0xf];
+            for (size_t i = 0; i < lft_cigar.size(); ++i) sam->cigar += std::to_string(lft_cigar[i] >> 4) + "MID"[lft_cigar[i] & 0xf];
             ref_pos = lift;
             ref_len = 0;                                   // bam_cigar2rlen: M, D, N, =, X consume the reference
-            for (size_t i = 0; i < n_cigar; ++i) { int op = cigar[i] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += cigar[i] >> 4; }
+            for (size_t i = 0; i < lft_cigar.size(); ++i) { int op = lft_cigar[i] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += lft_cigar[i] >> 4; }
             if (ref_len > 0) {
                 std::vector<uint8_t> l_ref(ref_len + 1);
                 expand_nt4(ref_pos, ref_len, l_ref.data());
-                sam->nm = write_MD_core(l_ref.data(), seq, cigar, n_cigar, sam->md);
+                sam->nm = write_MD_core(l_ref.data(), seq, lft_cigar.data(), lft_cigar.size(), sam->md);
                 sam->rlen = ref_len;
                 score.score = ez.score;                    // as in the reference: ez is the (possibly never used) global result
                 score.pos = ref_pos;

@@ -25,6 +25,48 @@ namespace oracle {
 
 typedef uint64_t ulint;
 
+// lift::Lift of levioSAM (absent submodule; SURVEY.md App. B [UPSTREAM-RECALL]): three sd_vectors over the columns of the
+// haplotype-vs-reference alignment: ins[x] = the column is an insertion (no reference base), del[x] = the column is a
+// deletion (no haplotype base), snp (not needed by this path).  Kept as the sorted positions of the ones; rank/select are
+// the sd_vector operations spelled naively.  Pinned by the reference's fixture data/Chr21.10.ldx + data/lifts/*.lft through
+// lift_pos only (tests/test_ldx_fixture.py restating test/src/lifting_test.cpp:57-141); lift_cigar is UNPINNED.
+struct Lift {
+    ulint second = 0;                 // liftidx::lifts[i].second: start of the target contig in the concatenation
+    ulint len = 0;                    // number of alignment columns
+    std::vector<ulint> ins, del;      // positions of the ones
+    static ulint rank1(const std::vector<ulint>& v, ulint i) { return (ulint)(std::lower_bound(v.begin(), v.end(), i) - v.begin()); }
+    static bool at(const std::vector<ulint>& v, ulint i) { return std::binary_search(v.begin(), v.end(), i); }
+    static ulint select0(const std::vector<ulint>& v, ulint k) {     // position of the k-th zero, k >= 1
+        ulint lo = 0, hi = v.size();                                  // j = number of ones before it: zeros before v[j] is v[j] - j
+        while (lo < hi) { ulint mid = (lo + hi) >> 1; if (v[mid] - mid < k) lo = mid + 1; else hi = mid; }
+        return k - 1 + lo;
+    }
+    ulint lift_pos(ulint p) const { return del_select0_then_ins_rank0(p); }
+    ulint del_select0_then_ins_rank0(ulint p) const { const ulint x = select0(del, p + 1); return x - rank1(ins, x); }   // ins_rs0(del_sls0(p + 1))
+    // lift::Lift::lift_cigar / cigar_s2_to_s1 (levioSAM, [UPSTREAM-RECALL]): the CIGAR is expanded to unit operations and
+    // walked together with the alignment columns from x = del_sls0(pos + 1): a deleted column emits D and consumes nothing
+    // of the read's CIGAR; I stays I; M becomes I on an inserted column, M otherwise; D is dropped on an inserted column.
+    std::vector<uint32_t> lift_cigar(const uint32_t* cigar, size_t n_cigar, ulint pos) const {
+        std::vector<uint32_t> ops, out_ops, out;
+        for (size_t i = 0; i < n_cigar; ++i) for (uint32_t j = 0; j < (cigar[i] >> 4); ++j) ops.push_back(cigar[i] & 0xf);
+        ulint x = select0(del, pos + 1);
+        size_t y = 0;
+        while (y < ops.size()) {
+            const uint32_t cop = ops[y];
+            if (at(del, x)) { out_ops.push_back(2); ++x; }
+            else if (cop == 1) { out_ops.push_back(1); ++y; }
+            else if (cop == 0 || cop == 7 || cop == 8) { out_ops.push_back(at(ins, x) ? 1u : 0u); ++x; ++y; }
+            else if (cop == 2 || cop == 3) { if (!at(ins, x)) out_ops.push_back(cop); ++x; ++y; }
+            else ++y;
+        }
+        for (size_t i = 0; i < out_ops.size(); ++i) {
+            if (!out.empty() && (out.back() & 0xf) == out_ops[i]) out.back() += 1u << 4;
+            else out.push_back((1u << 4) | out_ops[i]);
+        }
+        return out;
+    }
+};
+
 struct FlatIndex {
     ulint n = 0;        // bwt.size()  (text length + terminator)
     ulint r = 0;        // number of BWT runs
@@ -40,6 +82,7 @@ struct FlatIndex {
     std::vector<uint8_t> text;            // ra
     std::vector<ulint> seq_starts;        // seqidx onsets (k+1)
     std::vector<std::string> names;
+    std::vector<Lift> lifts;              // liftidx::lifts, one per sequence; empty = FASTA-built index (null lifts)
 
     // derived, mirroring the reference's members
     std::vector<ulint> n_letter;                       // runs_per_letter[c].size()
@@ -164,8 +207,20 @@ struct FlatIndex {
         return std::make_pair(rk - 1, pos - select1(rk));
     }
     bool valid(ulint pos, ulint len) const { return pos + len <= select1(rank1(pos + 1) + 1); }
-    // liftidx.hpp:89-95 with null lifts over text coordinates (FASTA-built index): identity
-    ulint lift(ulint pos) const { return pos; }
+    // liftidx.hpp:89-95.  A FASTA-built index (no lifts stored here) carries null lifts over text coordinates: identity.
+    ulint lift(ulint pos) const {
+        if (lifts.empty()) return pos;
+        const ulint rk = rank1(pos + 1);
+        const ulint start = pos - select1(rk);
+        const Lift& L = lifts[rk - 1];
+        return L.second + L.lift_pos(start);
+    }
+    // liftidx.hpp:159-164 (bam1_t carries the CIGAR and core.pos = offset in its sequence)
+    std::vector<uint32_t> lift_cigar(const uint32_t* cigar, size_t n_cigar, ulint pos) const {
+        if (lifts.empty()) return Lift().lift_cigar(cigar, n_cigar, 0);      // a null lift still goes through levioSAM's walk: zero-length
+        const ulint rk = rank1(pos + 1);                                     // operations disappear and equal neighbours merge
+        return lifts[rk - 1].lift_cigar(cigar, n_cigar, pos - select1(rk));
+    }
 
     bool load(const char* path);
 };
@@ -179,6 +234,7 @@ inline bool FlatIndex::load(const char* path) {
     if (fread(hdr, 8, 6, f) != 6) { fclose(f); return false; }
     n = hdr[0]; r = hdr[1]; w = hdr[2];
     ulint nseq = hdr[3], nblob = hdr[4];
+    const bool has_lifts = hdr[5] != 0;
     auto get = [&](void* dst, size_t bytes) {
         if (bytes && fread(dst, 1, bytes, f) != bytes) return false;
         size_t pad = (8 - bytes % 8) % 8;
@@ -193,6 +249,18 @@ inline bool FlatIndex::load(const char* path) {
               get(slcp.data(), r * 8) && get(text.data(), n - 1) && get(seq_starts.data(), (nseq + 1) * 8);
     std::vector<char> blob(nblob);
     ok = ok && get(blob.data(), nblob);
+    lifts.clear();
+    if (ok && has_lifts) {
+        lifts.resize(nseq);
+        for (ulint i = 0; i < nseq && ok; ++i) {
+            uint64_t h4[4];
+            ok = get(h4, 32);
+            if (!ok) break;
+            lifts[i].second = h4[0]; lifts[i].len = h4[1];
+            lifts[i].ins.resize(h4[2]); lifts[i].del.resize(h4[3]);
+            ok = get(lifts[i].ins.data(), h4[2] * 8) && get(lifts[i].del.data(), h4[3] * 8);
+        }
+    }
     fclose(f);
     if (!ok) return false;
     names.clear();

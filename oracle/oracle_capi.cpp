@@ -66,6 +66,26 @@ void* orc_index_create(uint64_t n, uint64_t r, uint64_t w, uint64_t n_seq, const
     ix->finalize();
     return ix;
 }
+// liftidx::lifts as flat arrays (one lift per sequence): second, number of alignment columns, sorted positions of the ones of
+// the ins / del bit-vectors (ragged, offsets n_seq + 1)
+void orc_index_set_lifts(void* h, uint64_t n_seq, const uint64_t* second, const uint64_t* len, const uint64_t* ins_off, const uint64_t* ins,
+                         const uint64_t* del_off, const uint64_t* del) {
+    FlatIndex* ix = (FlatIndex*)h;
+    ix->lifts.assign(n_seq, Lift());
+    for (uint64_t i = 0; i < n_seq; ++i) {
+        Lift& L = ix->lifts[i];
+        L.second = second[i]; L.len = len[i];
+        L.ins.assign(ins + ins_off[i], ins + ins_off[i + 1]);
+        L.del.assign(del + del_off[i], del + del_off[i + 1]);
+    }
+}
+uint64_t orc_lift(void* h, uint64_t pos) { return ((FlatIndex*)h)->lift(pos); }
+// lifted CIGAR of an alignment that starts at text position pos; returns the number of operations (out has room for cap)
+uint64_t orc_lift_cigar(void* h, const uint32_t* cigar, uint64_t n_cigar, uint64_t pos, uint32_t* out, uint64_t cap) {
+    const std::vector<uint32_t> v = ((FlatIndex*)h)->lift_cigar(cigar, n_cigar, pos);
+    for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+    return v.size();
+}
 void orc_index_free(void* h) { delete (FlatIndex*)h; }
 uint64_t orc_index_n(void* h) { return ((FlatIndex*)h)->n; }
 uint64_t orc_index_r(void* h) { return ((FlatIndex*)h)->r; }

@@ -34,6 +34,11 @@ def lib():
         L.orc_index_create.restype = ctypes.c_void_p
         L.orc_index_create.argtypes = [ctypes.c_uint64] * 4 + [ctypes.c_void_p] * 9 + [ctypes.c_char_p]
         L.orc_index_free.argtypes = [ctypes.c_void_p]
+        L.orc_index_set_lifts.argtypes = [ctypes.c_void_p, ctypes.c_uint64] + [ctypes.c_void_p] * 6
+        L.orc_lift.restype = ctypes.c_uint64
+        L.orc_lift.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+        L.orc_lift_cigar.restype = ctypes.c_uint64
+        L.orc_lift_cigar.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
         L.orc_index_n.restype = ctypes.c_uint64
         L.orc_index_n.argtypes = [ctypes.c_void_p]
         L.orc_index_r.restype = ctypes.c_uint64
@@ -68,6 +73,10 @@ class OracleIndex:
             self._h = self._L.orc_index_create(fi.n, fi.r, fi.w, len(fi.seq_starts) - 1, fi.F.ctypes.data, fi.heads.ctypes.data,
                                                fi.starts.ctypes.data, fi.ssa.ctypes.data, fi.esa.ctypes.data, fi.thr.ctypes.data,
                                                fi.slcp.ctypes.data, fi.text.ctypes.data, fi.seq_starts.ctypes.data, names)
+            lf = getattr(fi, "lifts", None)
+            if self._h and lf is not None:
+                self._L.orc_index_set_lifts(self._h, len(fi.seq_starts) - 1, lf.second.ctypes.data, lf.len.ctypes.data, lf.ins_off.ctypes.data,
+                                            lf.ins.ctypes.data, lf.del_off.ctypes.data, lf.dele.ctypes.data)
         else:
             self._h = self._L.orc_index_load(path.encode())
         if not self._h:
@@ -82,6 +91,16 @@ class OracleIndex:
 
     def __del__(self):
         self.close()
+
+    def lift(self, pos: int) -> int:
+        return int(self._L.orc_lift(self._h, pos))
+
+    def lift_cigar(self, cigar: np.ndarray, pos: int) -> np.ndarray:
+        cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+        cap = int((cigar >> 4).sum()) * 2 + 16
+        out = np.zeros(cap, dtype=np.uint32)
+        n = self._L.orc_lift_cigar(self._h, cigar.ctypes.data, len(cigar), pos, out.ctypes.data, cap)
+        return out[:n].copy()
 
     def ms_query(self, pattern: bytes) -> np.ndarray:
         out = np.empty(len(pattern), dtype=np.uint64)

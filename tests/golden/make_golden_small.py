@@ -22,7 +22,7 @@ def inputs():
 
 def main():
     pg, reads = inputs()
-    fi = index_build.build_from_pangenome(pg, device="cpu")
+    fi = index_build.build_from_pangenome(pg, device="cpu", lifted=False)      # FASTA-built form: null lifts
     o = orc.OracleIndex(fi=fi)
     offs = np.arange(0, 65 * 120, 120, dtype=np.uint64)
     seeds = o.seed_batch(reads.reshape(-1), offs, 25, True, 1000)
@@ -34,6 +34,11 @@ def main():
                         **{"seed_" + k: v for k, v in seeds.items()})
     with open(os.path.join(HERE, "align_small.sam"), "wb") as f:
         f.write(sam)
+    # the same text as a `-r ref -v vcf` build: haplotypes lift onto the reference contig (liftidx.hpp:89-95,159-164)
+    fl = index_build.build_from_pangenome(pg, device="cpu", lifted=True)
+    sam_l, _ = orc.align_batch(orc.OracleIndex(fi=fl), reads.reshape(-1), offs, names, noff, quals, with_header=True)
+    with open(os.path.join(HERE, "align_small_lifted.sam"), "wb") as f:
+        f.write(sam_l)
     print("wrote", len(seeds["pos"]), "MEMs,", len(seeds["occs"]), "occurrences,", sam.count(b"\n"), "SAM lines")
 
 

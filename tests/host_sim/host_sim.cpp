@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../moni_align_amd/csrc/image.hpp"
+#include "../../moni_align_amd/csrc/lift_build.hpp"
 #include "../../moni_align_amd/csrc/seed_core.h"
 #include "../../moni_align_amd/csrc/align_host.hpp"
 #include "../../moni_align_amd/csrc/align_core.h"
@@ -48,6 +49,8 @@ void* sim_create(const moni_flat_index_t* f) {
     S->hix.seq_starts.assign(f->seq_starts, f->seq_starts + f->n_seq + 1);
     const char* p = f->seq_names;
     for (uint64_t i = 0; i < f->n_seq; ++i) { std::string nm = p ? std::string(p) : ("seq" + std::to_string(i)); if (p) p += nm.size() + 1; S->hix.names.push_back(nm); }
+    { LiftTables LT; std::string err; if (LT.build(*f, err)) { fprintf(stderr, "host_sim: %s\n", err.c_str()); delete S; return nullptr; }
+      S->hix.lift_seqs = LT.seqs; S->hix.lift_runs = LT.runs; }
     return S;
 }
 void sim_destroy(void* s) { delete (Sim*)s; }
@@ -215,6 +218,7 @@ char* sim_align_core_batch(void* s, const uint8_t* seq, const uint64_t* offs, ui
     AP.gape2 = P.gape2; AP.max_dist_x = P.max_dist_x; AP.max_dist_y = P.max_dist_y; AP.max_iter = P.max_iter; AP.max_pred = P.max_pred;
     AP.min_chain_score = P.min_chain_score; AP.min_chain_length = P.min_chain_length; AP.n_text = S->hix.n_text; AP.n_seq = (uint32_t)S->hix.names.size();
     AP.seq_starts = S->hix.seq_starts.data();
+    AP.lift_seqs = S->hix.lift_seqs.data(); AP.lift_runs = S->hix.lift_runs.data();
     moni_dp_params_t dp;
     memset(&dp, 0, sizeof dp);
     dp.m = 5;
@@ -264,10 +268,10 @@ char* sim_align_core_batch(void* s, const uint8_t* seq, const uint64_t* offs, ui
                                W->fill.score, W->score2, W->cigar, al ? W->n_cigar : 0, alts, al ? W->n_alt : 0)) return nullptr;
             if (emit_ob.len != out.size() - line_at || memcmp(emit_ob.base, out.data() + line_at, emit_ob.len) != 0) ++n_emit_diff;
             if (al) {
-                const std::string mdz = Sm.lift_md;
+                const std::string mdz = Sm.md;
                 emit_ob.len = 0;
                 if (!A.emit_record(emit_ob, emit_md, name.data(), name.size(), seq + W->off, quals ? quals + W->off : nullptr, W->m, al, W->fill.strand, W->fill.ref_pos,
-                                   W->fill.score, W->score2, W->cigar, W->n_cigar, alts, W->n_alt, mdz.data(), (uint32_t)mdz.size(), (int)Sm.lift_nm)) return nullptr;
+                                   W->fill.score, W->score2, W->cigar, W->n_cigar, alts, W->n_alt, mdz.data(), (uint32_t)mdz.size(), (int)Sm.nm, (int)Sm.lift_nm)) return nullptr;
                 if (emit_ob.len != out.size() - line_at || memcmp(emit_ob.base, out.data() + line_at, emit_ob.len) != 0) ++n_emit_diff;
             }
         }
@@ -282,5 +286,31 @@ char* sim_align_core_batch(void* s, const uint8_t* seq, const uint64_t* offs, ui
     return buf;
 }
 void sim_free(void* p) { free(p); }
+
+// ---- the product's lift tables (lift_build.hpp + lift_core.h) on their own: positions and CIGARs ----
+struct LiftSim { LiftTables lt; std::vector<uint64_t> seq_starts; };
+void* liftsim_create(const moni_flat_index_t* f) {
+    LiftSim* L = new LiftSim();
+    std::string err;
+    if (L->lt.build(*f, err)) { fprintf(stderr, "host_sim: %s\n", err.c_str()); delete L; return nullptr; }
+    L->seq_starts.assign(f->seq_starts, f->seq_starts + f->n_seq + 1);
+    return L;
+}
+void liftsim_destroy(void* h) { delete (LiftSim*)h; }
+uint64_t liftsim_n_runs(void* h, uint64_t seq) { return ((LiftSim*)h)->lt.seqs[seq].n_runs; }
+static const moni_lift_seq_t& liftsim_seq(LiftSim* L, uint64_t pos, uint64_t& start) {
+    const size_t rk = (size_t)(std::lower_bound(L->seq_starts.begin(), L->seq_starts.end(), pos + 1) - L->seq_starts.begin());
+    start = pos - L->seq_starts[rk - 1];
+    return L->lt.seqs[rk - 1];
+}
+void liftsim_lift(void* h, const uint64_t* pos, uint64_t n, uint64_t* out) {
+    LiftSim* L = (LiftSim*)h;
+    for (uint64_t i = 0; i < n; ++i) { uint64_t st; const moni_lift_seq_t& S = liftsim_seq(L, pos[i], st); out[i] = S.second + lift_pos(L->lt.runs.data() + S.run_off, S.n_runs, st); }
+}
+int64_t liftsim_cigar(void* h, uint64_t pos, const uint32_t* cig, uint32_t n_cig, uint32_t* out, uint32_t cap) {
+    LiftSim* L = (LiftSim*)h;
+    uint64_t st; const moni_lift_seq_t& S = liftsim_seq(L, pos, st);
+    return lift_cigar(L->lt.runs.data() + S.run_off, S.n_runs, st, cig, n_cig, out, cap);
+}
 
 }  // extern "C"

@@ -17,7 +17,7 @@ def lib():
     if _lib is None:
         so = os.path.join(HERE, "libhost_sim.so")
         srcs = [os.path.join(HERE, "host_sim.cpp"), os.path.join(ROOT, "oracle", "ksw2.hpp")] + \
-               [os.path.join(capi.CSRC, f) for f in ("seed_core.h", "image.hpp", "layout.h", "align_host.hpp", "align_core.h", "sort_emul.h")]
+               [os.path.join(capi.CSRC, f) for f in ("seed_core.h", "image.hpp", "layout.h", "align_host.hpp", "align_core.h", "sort_emul.h", "lift_core.h", "lift_build.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(HERE, "host_sim.cpp")])
         L = C.CDLL(so)
@@ -39,6 +39,14 @@ def lib():
         L.sim_align_core_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.POINTER(C.c_uint64), C.c_void_p]
         L.sim_free.argtypes = [C.c_void_p]
+        L.liftsim_create.restype = C.c_void_p
+        L.liftsim_create.argtypes = [C.POINTER(capi.FlatIndexC)]
+        L.liftsim_destroy.argtypes = [C.c_void_p]
+        L.liftsim_n_runs.restype = C.c_uint64
+        L.liftsim_n_runs.argtypes = [C.c_void_p, C.c_uint64]
+        L.liftsim_lift.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.liftsim_cigar.restype = C.c_int64
+        L.liftsim_cigar.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         _lib = L
     return _lib
 
@@ -110,3 +118,42 @@ class Sim:
             return C.string_at(p, ln.value), st
         finally:
             lib().sim_free(p)
+
+
+class LiftSim:
+    """The product's lift tables (lift_build.hpp + lift_core.h) built from seq_starts / w / lifts alone."""
+
+    def __init__(self, seq_starts, w, lifts):
+        st = capi.FlatIndexC()
+        self._keep = (np.ascontiguousarray(seq_starts, dtype=np.uint64), lifts)
+        st.n_seq, st.w = len(seq_starts) - 1, w
+        st.seq_starts = self._keep[0].ctypes.data
+        if lifts is not None:
+            st.lift_second, st.lift_len = lifts.second.ctypes.data, lifts.len.ctypes.data
+            st.lift_ins_off, st.lift_ins = lifts.ins_off.ctypes.data, lifts.ins.ctypes.data
+            st.lift_del_off, st.lift_del = lifts.del_off.ctypes.data, lifts.dele.ctypes.data
+        self.h = lib().liftsim_create(C.byref(st))
+        if not self.h:
+            raise RuntimeError("lift tables rejected")
+
+    def n_runs(self, seq):
+        return int(lib().liftsim_n_runs(self.h, seq))
+
+    def lift(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        out = np.empty(len(pos), dtype=np.uint64)
+        lib().liftsim_lift(self.h, pos.ctypes.data, len(pos), out.ctypes.data)
+        return out
+
+    def lift_cigar(self, pos, cigar):
+        cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+        cap = 4 * len(cigar) + 4096
+        out = np.zeros(cap, dtype=np.uint32)
+        n = lib().liftsim_cigar(self.h, int(pos), cigar.ctypes.data, len(cigar), out.ctypes.data, cap)
+        assert n >= 0
+        return out[:n].copy()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().liftsim_destroy(self.h)
+            self.h = None

@@ -166,6 +166,41 @@ def test_repeats_overflow_the_kernel_capacities(tmp_path):
         idx.close()
 
 
+def test_sam_identical_on_fasta_built_index(medium_case, tmp_path):
+    """The same pangenome text as a FASTA-built index (null lifts, liftidx.hpp:150-157): one RNAME per haplotype, and the CIGAR of
+    column 6 still goes through levioSAM's walk (zero-length operations disappear)."""
+    from moni_align_amd import capi, index_build
+    from oracle import orc
+    fi = index_build.build_from_pangenome(medium_case.pg, device="cpu", lifted=False)
+    path = str(tmp_path / "fasta.mfi")
+    fi.save(path)
+    idx = capi.Index(fi=fi)
+    ctx = capi.Ctx(idx)
+    try:
+        reads = medium_case.synth.make_reads(medium_case.pg, 6000, 150, seed=154, sub_rate=0.02, indel_rate=0.003)
+        both((orc.OracleIndex(path), ctx), list(reads))
+        assert ctx.sam_header().count(b"@SQ") == 7
+    finally:
+        ctx.close()
+        idx.close()
+
+
+def test_lifted_records_name_the_reference_contig(medium_case, env):
+    """medium_case is built `-r ref -v vcf` style: haplotypes lift onto chr19 (aligner_ksw2.hpp:3133-3160); OA keeps the haplotype."""
+    from oracle import orc
+    o, ctx = env
+    reads = medium_case.synth.make_reads(medium_case.pg, 4000, 150, seed=155)
+    offs = np.arange(0, 4001 * 150, 150, dtype=np.uint64)
+    names, noff = orc.make_names(4000)
+    sam, st = ctx.align_batch(reads.reshape(-1), offs, names, noff, None, host_threads=4)
+    rn = [l.split(b"\t") for l in sam.split(b"\n") if l]
+    assert all(f[2] in (b"chr19", b"*") for f in rn)
+    oa = [[x for x in f if x.startswith(b"OA:Z:")][0][5:].split(b",")[0] for f in rn if f[2] == b"chr19"]
+    assert len(set(oa)) == 7            # all seven sequences occur as the pangenome-side name
+    lifted_differs = sum(1 for f in rn if f[2] == b"chr19" and f[5] != [x for x in f if x.startswith(b"OA:Z:")][0].split(b",")[3])
+    assert lifted_differs > 20          # reads across haplotype indels get I / D in the lifted CIGAR
+
+
 def test_sam_identical_fasta_reads(medium_case, env):
     reads = medium_case.synth.make_reads(medium_case.pg, 500, 100, seed=3)
     both(env, list(reads), quals=False)

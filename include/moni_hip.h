@@ -179,6 +179,7 @@ typedef struct {
     double t_dp_kernel;                                   /* seconds inside the align / extz kernels (HIP events) */
     uint64_t handed_back;                                 /* reads that exceeded the align kernel's capacities and went through the host pipeline */
     uint64_t dp_reused, dp_cells_reused;                  /* DP problems (and their cells) answered from the per-read memo of identical problems; not in dp_tasks/dp_cells */
+    uint64_t kernel_fallback;                             /* reads outside the staged kernels' common case, taken by the general align kernel */
 } moni_align_stats_t;
 
 void moni_align_params_default(moni_align_params_t *p);

@@ -57,7 +57,8 @@ class AlignParamsC(C.Structure):
 class AlignStatsC(C.Structure):
     _fields_ = [("reads", C.c_uint64), ("aligned", C.c_uint64), ("dp_tasks", C.c_uint64), ("dp_cells", C.c_uint64), ("dp_rounds", C.c_uint64),
                 ("t_seed", C.c_double), ("t_chain", C.c_double), ("t_dp", C.c_double), ("t_host", C.c_double),
-                ("t_dp_kernel", C.c_double), ("handed_back", C.c_uint64), ("dp_reused", C.c_uint64), ("dp_cells_reused", C.c_uint64)]
+                ("t_dp_kernel", C.c_double), ("handed_back", C.c_uint64), ("dp_reused", C.c_uint64), ("dp_cells_reused", C.c_uint64),
+                ("kernel_fallback", C.c_uint64)]
 
 
 class DpParamsC(C.Structure):

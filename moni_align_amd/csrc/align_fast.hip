@@ -1,0 +1,974 @@
+// The align stage as a sequence of specialised kernels with on-chip state (the common case of aligner::align after seeding,
+// include/aligner/aligner_ksw2.hpp:328-521).  align_kernel.hip runs every read as a lane-private state machine out of a 75 KB
+// slot in HBM and lets the whole wave solve DP problems one at a time; here each phase has the mapping that suits it:
+//
+//   chain_plan_kernel   one wavefront per read, the read's seeds / anchors / chaining arrays in LDS: frequency filter, anchors,
+//                       the libstdc++ sort emulation, chaining DP, backtracking (chain.hpp:221-438), then the chain-selection
+//                       loop run ahead of its DP results (which chains get scored does not depend on the scores except in one
+//                       rare case that is detected later), and for every chain to score the problems of fill_chain
+//                       (aligner_ksw2.hpp:2782-2979) appended to a task list binned by query length.  A ~1 KB plan per read is
+//                       all that goes to HBM.
+//   dp_lane_kernel      ksw_extz2_sse, one LANE per problem: the target (<= 104 rows) lives in registers, the kernel walks the
+//                       query, 64 independent problems per wavefront with no cross-lane traffic and no LDS in the recurrence;
+//                       direction bytes (right-aligned gap rule) stream to HBM, coalesced across the 64 lanes.  Scores do not
+//                       depend on the gap-placement rule, so one pass serves both the score-only and the CIGAR call of chain_score.
+//   select_kernel       one lane per read: consumes the results in the reference's order (fill_chain's score arithmetic,
+//                       validity, lift, the best_scores / alternative-hit bookkeeping), picks the final chain.
+//   traceback_kernel    one lane per problem of a final chain: ksw_backtrack over the stored direction bytes.
+//   finish_kernel       one lane per read: CIGAR stitching (aligner_ksw2.hpp:3049-3108), then the shared record writer
+//                       (lift, MD/NM, MAPQ, SAM text: ak_write_record).
+//
+// Anything outside the common case (more anchors / chains than the LDS arrays hold, overlapping anchors that need the global
+// realignment, wildcard bases in a DP operand, problems larger than the register tile, the rare dependence of the selection loop
+// on a score, an extension that would not reach the query end) is not approximated: the read is put on a list and
+// align_kernel takes it as before.  Results are bit-identical either way.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "align_core.h"
+
+#define AF_MAX_MEMS 64
+#define AF_MAX_ANCH 256
+#define AF_MAX_CHAINS 128
+#define AF_MAX_CAND 8
+#define AF_MAX_AN 6
+#define AF_MAX_READ 512          // longest read of the staged path
+#define AF_QCAP 256              // longest query of a DP task
+#define AF_TB 104                // target rows of the large register tile
+#define AF_TS 32                 // ... of the small one (gap fills)
+#define AF_GPASS 3                // target blocks of a global problem (overlapping anchors): up to AF_GPASS * AF_TB target rows
+#define AF_NBIN 33               // 16 query-length bins of the large tile, the small tile, 16 query-length bins of global problems
+#define AF_BIN_SMALL 16u
+#define AF_BIN_GLOBAL 17u
+#define AF_TB_CIG 24             // CIGAR operations kept per traced problem
+#define AF_FIN_CIG 96            // ... of a stitched alignment
+#define AF_FIN_LCIG 160          // ... after lifting
+#define AF_NEG_INF (-0x40000000)
+
+enum { AF_GAP_NONE = 0, AF_GAP_INS, AF_GAP_DEL0, AF_GAP_TASK, AF_GAP_1X1 };
+enum { AF_ST_UNALIGNED = 0, AF_ST_CAND = 1, AF_ST_FALLBACK = 2, AF_ST_FINAL = 3 };
+
+struct af_anchor_t {             // one anchor of a chain to score, and the gap between it and the next one (16 bytes)
+    uint64_t occ;
+    uint16_t len, idx;           // mem_t::len, mem_t::idx
+    int16_t gap_val;             // AF_GAP_INS: the insertion's length; AF_GAP_DEL0 / AF_GAP_1X1: the score (closed forms, aligner_ksw2.hpp:2917-2945)
+    uint8_t gap_kind, pad;
+};
+__device__ __forceinline__ int32_t af_ins_score(const ac_params_t& P, uint64_t l) {      // -min(gapo + l*gape, gapo2 + l*gape2), size_t arithmetic
+    const uint64_t c1 = (uint64_t)(int64_t)P.gapo + l * (uint64_t)(int64_t)P.gape, c2 = (uint64_t)(int64_t)P.gapo2 + l * (uint64_t)(int64_t)P.gape2;
+    return (int32_t)(0 - (c1 < c2 ? c1 : c2));
+}
+struct af_cand_t {               // one chain the selection loop scores (in loop order)
+    int32_t chain_score;
+    uint16_t chain_idx;
+    uint8_t n_an, strand;
+    uint32_t task0;              // its DP tasks: [left ext][right ext][gap fills in anchor order]
+    uint8_t has_lc, has_rc, n_gap_tasks, overlap;      // overlap: anchors overlap, the chain is scored by one global problem (gtask) over the window the extensions give
+    int32_t score;               // filled by select_kernel
+    uint32_t gtask; uint32_t pad;
+    af_anchor_t an[AF_MAX_AN];
+};
+struct af_plan_t {
+    uint8_t status, n_cand; uint16_t n_chains;
+    int32_t min_score;
+    uint8_t final_cand, n_alt; uint16_t pad;
+    int32_t score2;
+    uint64_t ref_pos, ref_len;   // window of the final chain
+    uint32_t tb0, pad2;          // first traced problem of the final chain: [left ext][right ext][gap fills]
+    uint64_t alt_pos[AF_MAX_CAND];
+    int32_t alt_score[AF_MAX_CAND];
+    af_cand_t cand[AF_MAX_CAND];
+};
+struct af_res_t { int32_t mqe, mqe_t, score, flags; };      // flags: 1 = a wildcard base in an operand (not computed)
+struct af_chunk_t { uint32_t bin, start, n, qhi; uint64_t dir_off; };
+struct af_tb_t { uint32_t n_ops; uint32_t ops[AF_TB_CIG]; };      // raw backtrack order (end -> start); n_ops = ~0u: did not fit
+
+struct af_args_t {
+    ak_args_t A;                             // reads / text / seeds / record pools: as align_kernel
+    af_plan_t* plans;                        // per read of the launch
+    moni_dp_task_t* tasks; uint32_t task_cap;
+    af_res_t* res;
+    uint32_t* bin_q; uint32_t bin_cap;       // AF_NBIN queues of task indices
+    uint32_t* task_pos;                      // where a task sits: position in its bin's queue | bin << 26
+    af_chunk_t* chunks; uint32_t chunk_cap;  // 64-task chunks of the two tiles: large first
+    uint8_t* dirs; uint64_t dirs_cap;
+    uint32_t* tb_task; af_tb_t* tb; uint32_t tb_cap;      // problems to trace
+    uint32_t* fb_list;                       // reads handed to align_kernel
+    uint8_t* fin_scratch; uint64_t fin_stride;            // per finish lane: stitched CIGAR, lifted CIGAR, MD and text staging
+    uint64_t* bnd;                           // per resident DP wave: (H, E) of a target block's last row for every query position (global problems)
+    uint32_t* ctr;                           // AF_NCTR counters, see the AFC_* indices
+    unsigned long long* prof;                // AF_PROFILE builds: wave cycles per phase
+};
+#ifdef AF_PROFILE
+#define AF_STAMP(var) const long long var = clock64()
+#define AF_PROF(G, slot, t0, t1) do { if (threadIdx.x == 0 && (G).prof) atomicAdd(&(G).prof[slot], (unsigned long long)((t1) - (t0))); } while (0)
+#else
+#define AF_STAMP(var) do {} while (0)
+#define AF_PROF(G, slot, t0, t1) do {} while (0)
+#endif
+enum { AFC_TASKS = 0, AFC_FALLBACK = 1, AFC_TRACED = 2, AFC_READ_CUR = 3, AFC_DIRS_OVF = 4, AFC_CELLS = 6 /* 64 bit */, AFC_DIROFF = 8 /* 64 bit */,
+       AFC_NCHUNKS = 10 /* + group */, AFC_CURSOR = 13 /* + group */, AFC_BINS = 16 /* + bin */, AFC_WHY = 52 /* + reason */, AF_NCTR = 64 };
+enum { AF_GRP_LARGE = 0, AF_GRP_SMALL = 1, AF_GRP_GLOBAL = 2 };
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// chain_plan_kernel
+// ------------------------------------------------------------------------------------------------------------------------------
+struct af_mem_t { uint64_t occ_off; uint32_t nocc; uint16_t len, idx, rpos; uint8_t mate, pad; };
+struct af_chain_t { int32_t score; uint16_t off, cnt; uint32_t mate; };
+struct af_start_t { int32_t f, j; };
+struct af_left_t { uint64_t ref; int64_t score; };
+struct af_wave_t {
+    lsort::frame stack[24];
+    af_mem_t mem[AF_MAX_MEMS];
+    uint64_t anch[AF_MAX_ANCH];          // x (reference end, 40 bits) | mem << 40
+    int32_t f[AF_MAX_ANCH], msc[AF_MAX_ANCH];
+    int16_t p[AF_MAX_ANCH], t[AF_MAX_ANCH];
+    af_start_t starts[AF_MAX_CHAINS];
+    af_chain_t chains[AF_MAX_CHAINS];
+    uint16_t pool[AF_MAX_ANCH + AF_MAX_CHAINS];
+    af_left_t left[AF_MAX_CHAINS];
+    uint16_t run_start[AF_MAX_ANCH + 1];
+    uint16_t s_off[AF_MAX_CHAINS], s_cnt[AF_MAX_CHAINS];       // per sorted start: where its chain's anchors are in the pool, how many (0: chain dropped)
+    uint64_t left_ref[AF_MAX_CHAINS];    // check_left_MEM's lifted coordinate of every chain (lanes in parallel: each lift is a chain of dependent loads)
+    int64_t diff[8];
+    uint32_t n_chains_sh, status_sh;
+    af_plan_t plan;
+    moni_dp_task_t tasks[AF_MAX_CAND * (AF_MAX_AN + 1)];
+    uint32_t n_tasks;
+};
+
+// why a read left the staged path (counted in ctr[AFC_WHY + reason])
+enum { AF_WHY_LONG = 0, AF_WHY_ANCHORS, AF_WHY_CHAINS, AF_WHY_CANDS, AF_WHY_CHAIN_LEN, AF_WHY_TASK_SIZE, AF_WHY_OVERLAP, AF_WHY_WILDCARD, AF_WHY_LOOP, AF_WHY_REACH_END,
+       AF_WHY_CAPACITY, AF_WHY_CIGAR, AF_WHY_N };
+#define AF_FALLBACK(G, why) (atomicAdd(&(G).ctr[AFC_WHY + (why)], 1u), (uint32_t)AF_ST_FALLBACK)
+#define AF_X(a) ((a) & MONI_POS_MASK_)
+#define MONI_POS_MASK_ ((1ull << 40) - 1)
+
+__device__ __forceinline__ uint32_t af_bin_of(int qlen, int tlen) { return (qlen <= AF_TS && tlen <= AF_TS) ? AF_BIN_SMALL : (uint32_t)((qlen - 1) >> 4); }
+
+// std::sort of n <= 16 elements is one insertion sort, i.e. a stable sort: every lane places one element by its stable rank
+template <class T, class Less>
+__device__ __forceinline__ void af_small_sort(T* a, uint32_t n, Less less, int lane) {
+    T v; uint32_t rank = 0;
+    if ((uint32_t)lane < n) { v = a[lane]; for (uint32_t k = 0; k < n; ++k) { const T w = a[k]; rank += (less(w, v) || (!less(v, w) && k < (uint32_t)lane)) ? 1u : 0u; } }
+    __syncthreads();
+    if ((uint32_t)lane < n) a[rank] = v;
+    __syncthreads();
+}
+
+// The whole wave: anchors -> chains (chain.hpp:221-438) over the wave's LDS arrays.  The sorts are the libstdc++ emulation where
+// ties exist (one lane; short arrays by stable rank); the chaining DP and the backtracking run one lane per RUN of anchors: a run
+// is a maximal stretch of the sorted anchors whose consecutive reference ends are at most max_dist_x apart, pairs from different
+// runs never pass the distance test of chain.hpp:300 (or are skipped for their mates before it), so runs share nothing but the
+// lower bound `lb`, which only ever excludes anchors that are too far anyway.  Returns the plan status (uniform).
+__device__ __forceinline__ uint32_t af_chain(const af_args_t& G, af_wave_t& L, uint32_t na, float avg_mem_length) {
+    const ac_params_t& P = G.A.P;
+    const int lane = threadIdx.x;
+    // ---- std::sort of the anchors by reference end (chain.hpp:246) ----
+    AF_STAMP(s0);
+    if (na <= 16) af_small_sort(L.anch, na, [](const uint64_t& a, const uint64_t& b) { return AF_X(a) < AF_X(b); }, lane);
+    else { if (lane == 0) lsort::sort(L.anch, (long)na, [](const uint64_t& a, const uint64_t& b) { return AF_X(a) < AF_X(b); }, L.stack); __syncthreads(); }
+    AF_STAMP(s1); AF_PROF(G, 5, s0, s1);
+    // ---- runs ----
+    uint32_t n_runs = 0;
+    for (uint32_t i0 = 0; i0 < na; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const bool brk = i < na && (i == 0 || (long long)AF_X(L.anch[i]) > (long long)AF_X(L.anch[i - 1]) + P.max_dist_x);
+        const unsigned long long bal = __ballot(brk);
+        if (brk) L.run_start[n_runs + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        n_runs += (uint32_t)__popcll(bal);
+    }
+    if (lane == 0) L.run_start[n_runs] = (uint16_t)na;
+    __syncthreads();
+    // ---- chaining DP (chain.hpp:278-362), one lane per run ----
+    for (uint32_t k = lane; k < n_runs; k += 64) {
+        const uint32_t fb = L.run_start[k], fe = L.run_start[k + 1];
+        long long lb = fb;
+        for (uint32_t i = fb; i < fe; ++i) {
+            const uint64_t aw = L.anch[i];
+            const af_mem_t mi = L.mem[aw >> 40];
+            const long long x_i = (long long)AF_X(aw), y_i = mi.rpos, w_i = mi.len;
+            const uint32_t mate_i = mi.mate;
+            long long max_f = w_i, max_j = -1;
+            size_t n_pred = 0;
+            if ((size_t)i - (size_t)lb > (size_t)P.max_iter) lb = (long long)i - P.max_iter;
+            for (long long j = (long long)i - 1; j >= lb; --j) {
+                const uint64_t awj = L.anch[j];
+                const af_mem_t mj = L.mem[awj >> 40];
+                const long long x_j = (long long)AF_X(awj), y_j = mj.rpos;
+                const uint32_t mate_j = mj.mate;
+                if (mate_i != mate_j && ((mate_i ^ mate_j) != 3)) continue;
+                if (x_i > x_j + P.max_dist_x) { lb = j; continue; }
+                const long long x_d = x_i - x_j, y_d = y_i - y_j;
+                const int32_t l = (int32_t)(y_d > x_d ? (y_d - x_d) : (x_d - y_d));
+                const uint32_t ilog_l = l > 0 ? (uint32_t)(31 - __clz(l)) : 0;
+                if (mate_i == mate_j && (y_j >= y_i || y_d > P.max_dist_y)) continue;
+                const long long mn = y_d < x_d ? y_d : x_d;
+                const long long alpha = mn < w_i ? mn : w_i;
+                long long beta = 0;
+                if (mate_i != mate_j) {
+                    if (x_d == 0) ++beta;
+                    else { const int c_lin = (int)(l * .01 * avg_mem_length); beta = c_lin < (long long)ilog_l ? c_lin : (long long)ilog_l; }
+                } else {
+                    beta = l > 0 ? ((long long)(.01 * l * avg_mem_length) + ilog_l) >> 1 : 0;
+                }
+                const long long score = L.f[j] + (alpha - beta);
+                if (score > max_f) { max_f = score; max_j = j; if (n_pred > 0) --n_pred; }
+                else if ((size_t)(long long)L.t[j] == (size_t)i && (++n_pred > (size_t)P.max_pred)) break;
+                if (L.p[j] > 0) L.t[L.p[j]] = (int16_t)i;
+            }
+            L.f[i] = (int32_t)max_f; L.p[i] = (int16_t)max_j;
+            L.msc[i] = (max_j >= 0 && L.msc[max_j] > max_f) ? L.msc[max_j] : (int32_t)max_f;
+        }
+    }
+    __syncthreads();
+    AF_STAMP(s2); AF_PROF(G, 6, s1, s2);
+    // ---- chain ends and starts (chain.hpp:115-164) ----
+    for (uint32_t i = lane; i < na; i += 64) L.t[i] = 0;
+    __syncthreads();
+    for (uint32_t i = lane; i < na; i += 64) if (L.p[i] >= 0) L.t[L.p[i]] = 1;
+    __syncthreads();
+    uint32_t ns = 0;
+    for (uint32_t i0 = 0; i0 < na; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const bool is_end = i < na && L.t[i] == 0 && L.msc[i] > P.min_chain_score;
+        af_start_t st; st.f = 0; st.j = 0;
+        if (is_end) { uint32_t j = i; while (L.f[j] < L.msc[j]) j = (uint32_t)L.p[j]; st.f = L.f[j]; st.j = (int32_t)j; }
+        const unsigned long long bal = __ballot(is_end);
+        const uint32_t at = ns + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (is_end && at < AF_MAX_CHAINS) L.starts[at] = st;
+        ns += (uint32_t)__popcll(bal);
+    }
+    if (ns > AF_MAX_CHAINS) { uint32_t rc = AF_ST_FALLBACK; if (lane == 0) rc = AF_FALLBACK(G, AF_WHY_CHAINS); return rc; }
+    if (ns == 0) return AF_ST_UNALIGNED;
+    __syncthreads();
+    // std::sort(chain_starts, greater<pair>) (chain.hpp:376): elements that compare equal are identical pairs (two chain ends can
+    // lead back to the same start), so any sort gives the reference's array: by rank, equal elements in index order
+    {
+        af_start_t v[(AF_MAX_CHAINS + 63) / 64]; uint32_t rk[(AF_MAX_CHAINS + 63) / 64];
+#pragma unroll
+        for (int q = 0; q < (AF_MAX_CHAINS + 63) / 64; ++q) {
+            const uint32_t s = (uint32_t)lane + 64u * q;
+            rk[q] = 0;
+            if (s < ns) { v[q] = L.starts[s]; for (uint32_t k = 0; k < ns; ++k) { const af_start_t w = L.starts[k]; rk[q] += (w.f > v[q].f || (w.f == v[q].f && (w.j > v[q].j || (w.j == v[q].j && k < s)))) ? 1u : 0u; } }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < (AF_MAX_CHAINS + 63) / 64; ++q) if ((uint32_t)lane + 64u * q < ns) L.starts[rk[q]] = v[q];
+        __syncthreads();
+    }
+    // ---- backtracking (chain.hpp:166-200), one lane per run, every lane over the sorted starts of its run in order ----
+    for (uint32_t i = lane; i < na; i += 64) L.t[i] = 0;
+    __syncthreads();
+    for (uint32_t k = lane; k < n_runs; k += 64) {
+        const uint32_t fb = L.run_start[k], fe = L.run_start[k + 1];
+        uint32_t used = fb;                                   // a run's chains use at most one pool entry per anchor and one more per start
+        for (uint32_t s = 0; s < ns; ++s) used += (uint32_t)L.starts[s].j < fb ? 1u : 0u;
+        for (uint32_t s = 0; s < ns; ++s) {
+            const af_start_t st = L.starts[s];
+            if ((uint32_t)st.j < fb || (uint32_t)st.j >= fe) continue;
+            long long j = st.j;
+            uint32_t cnt = 0;
+            const uint32_t off = used;
+            do { L.pool[used++] = (uint16_t)j; cnt++; L.t[j] = 1; j = L.p[j]; } while (j >= 0 && L.t[j] == 0);
+            bool keep = false;
+            if (j < 0) keep = (long long)cnt >= P.min_chain_length;
+            else if ((long long)st.f - L.f[j] >= P.min_chain_score) keep = (long long)cnt >= P.min_chain_length;
+            L.s_off[s] = (uint16_t)off; L.s_cnt[s] = (uint16_t)(keep ? cnt : 0u);
+        }
+    }
+    __syncthreads();
+    uint32_t n_chains = 0;
+    for (uint32_t s0 = 0; s0 < ns; s0 += 64) {
+        const uint32_t sx = s0 + lane;
+        const bool keep = sx < ns && L.s_cnt[sx] > 0;
+        const unsigned long long bal = __ballot(keep);
+        if (keep) {
+            af_chain_t c;
+            c.score = L.starts[sx].f; c.mate = L.mem[L.anch[L.starts[sx].j] >> 40].mate; c.off = L.s_off[sx]; c.cnt = L.s_cnt[sx];
+            L.chains[n_chains + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = c;
+        }
+        n_chains += (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    // std::sort of the chains by score (chain.hpp:402): ties
+    if (n_chains <= 16) af_small_sort(L.chains, n_chains, [](const af_chain_t& x, const af_chain_t& y) { return x.score > y.score; }, lane);
+    else { if (lane == 0) lsort::sort(L.chains, (long)n_chains, [](const af_chain_t& x, const af_chain_t& y) { return x.score > y.score; }, L.stack); __syncthreads(); }
+    if (lane == 0) L.n_chains_sh = n_chains;
+    __syncthreads();
+    AF_STAMP(s3); AF_PROF(G, 7, s2, s3);
+    return AF_ST_CAND;
+}
+
+// query segment R[a .. a+len) of the strand-oriented read, optionally reversed (ac_qseg)
+__device__ __forceinline__ void af_qseg(uint64_t off, uint32_t m, uint32_t strand, uint64_t a, uint64_t len, bool reversed, uint64_t& q_off, int& qmode) {
+    if (!strand) { q_off = reversed ? off + a + len - 1 : off + a; qmode = reversed ? DP_Q_REV : 0; }
+    else { q_off = reversed ? off + (m - (a + len)) : off + (m - 1 - a); qmode = DP_Q_COMP | (reversed ? 0 : DP_Q_REV); }
+}
+__device__ __forceinline__ bool af_add_task(af_wave_t& L, uint64_t q_off, uint64_t qlen, int qmode, uint64_t t_off, uint64_t tlen, int tmode, int flag) {
+    if (qlen == 0 || tlen == 0 || qlen > AF_QCAP || tlen > AF_TB) return false;
+    moni_dp_task_t t;
+    t.q_off = q_off; t.t_off = t_off; t.qlen = (int32_t)qlen; t.tlen = (int32_t)tlen; t.flag = flag; t.reserved = DP_Q_READS | DP_T_TEXT | qmode | tmode;
+    L.tasks[L.n_tasks++] = t;
+    return true;
+}
+
+// lane 0, after the lanes have lifted every chain's leftmost anchor: the chain-selection loop ahead of its scores
+// (aligner_ksw2.hpp:409-462): which chains it scores, and their problems
+__device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, af_wave_t& L, uint64_t off, uint32_t m) {
+    const ac_params_t& P = G.A.P;
+    const uint32_t n_chains = L.n_chains_sh;
+    af_plan_t& PL = L.plan;
+    PL.n_chains = (uint16_t)n_chains; PL.n_cand = 0;
+    L.n_tasks = 0;
+    const uint64_t n_text = P.n_text, ext_len = P.ext_len;
+    int64_t* diff = L.diff; uint32_t n_diff = 0, n_left = 0;
+    for (uint32_t ci = 0; ci < n_chains && n_diff < P.check_k; ++ci) {
+        const af_chain_t ch = L.chains[ci];
+        { bool f = false; for (uint32_t q = 0; q < n_diff; ++q) f = f || diff[q] == (int64_t)ch.score; if (!f) diff[n_diff++] = ch.score; }
+        if (P.left_mem_check) {                                  // check_left_MEM (aligner_ksw2.hpp:553-597)
+            const uint64_t left_ref = L.left_ref[ci];
+            bool seen = false;
+            for (uint32_t k = 0; k < n_left; ++k) {
+                const uint64_t d = L.left[k].ref > left_ref ? L.left[k].ref - left_ref : left_ref - L.left[k].ref;
+                if (d < P.region_dist && L.left[k].score == (int64_t)ch.score) seen = true;
+            }
+            if (seen) continue;
+            L.left[n_left].ref = left_ref; L.left[n_left].score = ch.score; ++n_left;      // n_left <= n_chains <= AF_MAX_CHAINS
+        }
+        if (n_diff >= P.check_k) continue;                       // not scored; the loop condition ends the loop
+        // ---- fill_chain, part 1 (aligner_ksw2.hpp:2782-2979): the problems of this chain ----
+        if (PL.n_cand >= AF_MAX_CAND) return AF_FALLBACK(G, AF_WHY_CANDS);
+        if (ch.cnt > AF_MAX_AN) return AF_FALLBACK(G, AF_WHY_CHAIN_LEN);
+        af_cand_t& C = PL.cand[PL.n_cand];
+        C.chain_score = ch.score; C.chain_idx = (uint16_t)ci; C.n_an = (uint8_t)ch.cnt; C.task0 = L.n_tasks; C.has_lc = C.has_rc = C.n_gap_tasks = 0; C.overlap = 0; C.score = 0; C.gtask = 0; C.pad = 0;
+        for (uint32_t k = 0; k < ch.cnt; ++k) {                  // stored right to left (chain.hpp:166-200); fill_chain wants left to right
+            const uint64_t aw = L.anch[L.pool[ch.off + ch.cnt - 1 - k]];
+            const af_mem_t mk = L.mem[aw >> 40];
+            af_anchor_t& A = C.an[k];
+            A.occ = AF_X(aw) - mk.len + 1; A.len = mk.len; A.idx = mk.idx; A.gap_val = 0; A.gap_kind = AF_GAP_NONE; A.pad = 0;
+            if (k == 0) C.strand = (mk.mate & 2) ? 1 : 0;
+        }
+        const af_anchor_t first = C.an[0], last = C.an[ch.cnt - 1];
+        const uint32_t strand = C.strand;
+#define qseg(a, len, reversed, q_off, qmode) af_qseg(off, m, strand, (a), (len), (reversed), (q_off), (qmode))
+#define add(q_off, qlen, qmode, t_off, tlen, tmode, flag) af_add_task(L, (q_off), (qlen), (qmode), (t_off), (tlen), (tmode), (flag))
+        const uint64_t lcs_len = first.idx, rcs_occ = (uint64_t)last.idx + last.len, rcs_len = m - rcs_occ;
+        const uint64_t mem_pos = first.occ;
+        if (lcs_len > 0) {
+            const uint64_t lc_occ = mem_pos > ext_len ? mem_pos - ext_len : 0;
+            const uint64_t lc_len = mem_pos > ext_len ? ext_len : ext_len - mem_pos;     // sic (aligner_ksw2.hpp:2796)
+            uint64_t q_off; int qmode;
+            qseg(0, lcs_len, true, q_off, qmode);
+            if (!add(q_off, lcs_len, qmode, lc_len ? lc_occ + lc_len - 1 : 0, lc_len, DP_T_REV, DP_EZ_EXTZ_ONLY | DP_EZ_RIGHT)) return AF_FALLBACK(G, AF_WHY_TASK_SIZE);
+            C.has_lc = 1;
+        }
+        if (rcs_len > 0) {
+            const uint64_t rc_occ = last.occ + last.len;
+            const uint64_t rc_len = rc_occ < n_text - ext_len ? ext_len : n_text - rc_occ;
+            uint64_t q_off; int qmode;
+            qseg(rcs_occ, rcs_len, false, q_off, qmode);
+            if (!add(q_off, rcs_len, qmode, rc_occ, rc_len, 0, DP_EZ_EXTZ_ONLY | DP_EZ_RIGHT)) return AF_FALLBACK(G, AF_WHY_TASK_SIZE);
+            C.has_rc = 1;
+        }
+        uint64_t last_ref = mem_pos + first.len, last_seq = (uint64_t)first.idx + first.len;
+        for (uint32_t k = 1; k < ch.cnt; ++k) {                  // overlapping anchors: the global realignment of the whole read (aligner_ksw2.hpp:2888-2900, 2984-2996)
+            const af_anchor_t ak = C.an[k];
+            if (last_ref > ak.occ || last_seq > ak.idx) C.overlap = 1;
+            last_ref = ak.occ + ak.len; last_seq = (uint64_t)ak.idx + ak.len;
+        }
+        if (C.overlap && m > AF_QCAP) return AF_FALLBACK(G, AF_WHY_TASK_SIZE);
+        last_ref = mem_pos + first.len; last_seq = (uint64_t)first.idx + first.len;
+        for (uint32_t k = 1; k < ch.cnt && !C.overlap; ++k) {
+            const af_anchor_t ak = C.an[k], ap = C.an[k - 1];
+            af_anchor_t& GP = C.an[k - 1];
+            const uint64_t ref_occ = ak.occ, seq_occ = ak.idx;
+            if (last_ref == ref_occ) {
+                if (last_seq < seq_occ) {                                              // pure insertion
+                    GP.gap_val = (int16_t)(seq_occ - last_seq); GP.gap_kind = AF_GAP_INS;       // < AF_MAX_READ
+                }
+            } else if (last_seq == seq_occ) {                                          // "deletion": l is computed as 0 (aligner_ksw2.hpp:2939)
+                GP.gap_val = (int16_t)af_ins_score(P, 0); GP.gap_kind = AF_GAP_DEL0;
+            } else {
+                const uint64_t cc_occ = ap.occ + ap.len, cc_len = ref_occ - cc_occ;
+                const uint64_t ccs_pos = (uint64_t)ap.idx + ap.len, ccs_len = seq_occ - ccs_pos;
+                uint64_t q_off; int qmode;
+                qseg(ccs_pos, ccs_len, false, q_off, qmode);
+                bool closed = false;
+                if (ccs_len == 1 && cc_len == 1) {       // one base against one base: the diagonal move wins unless both gaps beat it
+                    uint32_t qc = dp_nt4(G.A.D.reads[q_off]);
+                    if ((qmode & DP_Q_COMP) && qc < 4) qc = 3 - qc;
+                    const uint32_t tc = dp_nt4(cc_occ < n_text ? G.A.D.text[cc_occ] : 0u);
+                    if (qc < 4 && tc < 4) {
+                        const int32_t z = tc == qc ? G.A.D.sc_mch : G.A.D.sc_mis;
+                        const int32_t gap = dp_bound(0, G.A.D.qo, G.A.D.e) - G.A.D.qo - G.A.D.e;
+                        if (z > gap) { GP.gap_val = (int16_t)z; GP.gap_kind = AF_GAP_1X1; closed = true; }
+                    }
+                }
+                if (!closed) {
+                    if (!add(q_off, ccs_len, qmode, cc_occ, cc_len, 0, DP_EZ_RIGHT)) return AF_FALLBACK(G, AF_WHY_TASK_SIZE);
+                    GP.gap_kind = AF_GAP_TASK; C.n_gap_tasks++;
+                }
+            }
+            last_ref = ref_occ + ak.len; last_seq = seq_occ + ak.len;
+        }
+        PL.n_cand++;
+    }
+#undef qseg
+#undef add
+    return AF_ST_CAND;
+}
+
+__global__ void __launch_bounds__(64) chain_plan_kernel(const af_args_t G) {
+    __shared__ af_wave_t L;                   // one wavefront per workgroup: __syncthreads() orders the wave's own LDS traffic
+    const int lane = threadIdx.x;
+    const ak_args_t& A = G.A;
+    while (true) {
+        uint32_t r_in = 0;
+        if (lane == 0) r_in = atomicAdd(&G.ctr[AFC_READ_CUR], 1u);
+        r_in = (uint32_t)__shfl((int)r_in, 0);
+        if (r_in >= A.n_reads) break;
+        AF_STAMP(c0);
+        const uint64_t r = A.read_lo + r_in;
+        const uint64_t off = A.offs[r];
+        const uint32_t m = (uint32_t)(A.offs[r + 1] - off);
+        const uint64_t a = A.read_mem_off[r], b = A.read_mem_off[r + 1];
+        uint32_t status = AF_ST_UNALIGNED;
+        af_plan_t& PL = L.plan;
+        if (lane == 0) { PL.status = 0; PL.n_cand = 0; PL.n_chains = 0; PL.final_cand = 0; PL.n_alt = 0; PL.pad = 0; PL.score2 = 0; PL.ref_pos = PL.ref_len = 0; PL.tb0 = 0; PL.pad2 = 0;
+                         PL.min_score = A.min_score_of_len[m <= A.max_len ? m : A.max_len]; L.n_tasks = 0; }
+        bool fallback = m >= AF_MAX_READ || (b - a) > 4 * AF_MAX_MEMS;
+        uint32_t n_mems = 0, na = 0;
+        float avg = 0.f;
+        if (!fallback && b > a) {
+            // ---- seed_freq_filter (aligner_ksw2.hpp:1905-1933): lanes over the read's seeds ----
+            unsigned long long total = 0;
+            for (uint64_t k = a + lane; k < b; k += 64) total += A.mems[k].occ_cnt;
+            for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+            unsigned long long tot_len = 0, n_anch = 0;
+            for (uint64_t k0 = a; k0 < b; k0 += 64) {
+                const uint64_t k = k0 + lane;
+                bool keep = false;
+                moni_mem_t g;
+                if (k < b) {
+                    g = A.mems[k];
+                    keep = true;
+                    if (A.P.filter_freq) { const double fr = static_cast<double>(g.occ_cnt) / (double)(size_t)total; if (fr > A.P.freq_thr) keep = false; }
+                }
+                const unsigned long long bal = __ballot(keep);
+                const uint32_t at = n_mems + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                if (keep && at < AF_MAX_MEMS) {
+                    af_mem_t x; x.occ_off = g.occ_off; x.nocc = g.occ_cnt; x.len = (uint16_t)g.len; x.idx = (uint16_t)g.idx; x.rpos = (uint16_t)g.rpos; x.mate = (uint8_t)g.mate; x.pad = 0;
+                    L.mem[at] = x;
+                }
+                if (keep) { tot_len += (unsigned long long)g.len * g.occ_cnt; n_anch += g.occ_cnt; }
+                n_mems += (uint32_t)__popcll(bal);
+            }
+            for (int o = 32; o > 0; o >>= 1) { tot_len += __shfl_xor(tot_len, o); n_anch += __shfl_xor(n_anch, o); }
+            if (n_mems > AF_MAX_MEMS || n_anch > AF_MAX_ANCH) fallback = true;
+            na = (uint32_t)n_anch;
+            if (!fallback && na > 0) {
+                avg = (float)(size_t)tot_len / (size_t)n_anch;
+                __syncthreads();
+                // ---- populate_anchors (chain.hpp:83-95): mem by mem, occurrence by occurrence ----
+                uint32_t base = 0;
+                for (uint32_t i = 0; i < n_mems; ++i) {
+                    const af_mem_t mi = L.mem[i];
+                    for (uint32_t j = lane; j < mi.nocc; j += 64) L.anch[base + j] = (A.occs[mi.occ_off + j] + mi.len - 1) | ((uint64_t)i << 40);
+                    base += mi.nocc;
+                }
+                for (uint32_t i = lane; i < na; i += 64) { L.f[i] = 0; L.msc[i] = 0; L.p[i] = 0; L.t[i] = 0; }
+            }
+        }
+        __syncthreads();
+        AF_STAMP(c1); AF_PROF(G, 0, c0, c1);
+        if (fallback) { status = AF_ST_FALLBACK; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + (m >= AF_MAX_READ ? AF_WHY_LONG : AF_WHY_ANCHORS)], 1u); }
+        else if (na > 0) {
+            status = af_chain(G, L, na, avg);
+            status = (uint32_t)__shfl((int)status, 0);
+            __syncthreads();
+            AF_STAMP(c2); AF_PROF(G, 1, c1, c2);
+            if (status == AF_ST_CAND) {
+                // check_left_MEM's coordinate of every chain: index(lift(leftmost anchor)).second + 1 (aligner_ksw2.hpp:565-576)
+                for (uint32_t ci = lane; ci < L.n_chains_sh; ci += 64) {
+                    const af_chain_t ch = L.chains[ci];
+                    const uint64_t aw = L.anch[L.pool[ch.off + ch.cnt - 1]];
+                    const af_mem_t ml = L.mem[aw >> 40];
+                    L.left_ref[ci] = ac_seq_off(A.P, ac_lift(A.P, AF_X(aw) - ml.len + 1)) + 1;
+                }
+                __syncthreads();
+                AF_STAMP(c3); AF_PROF(G, 2, c2, c3);
+                if (lane == 0) L.status_sh = af_plan_cands(G, L, off, m);
+                __syncthreads();
+                AF_STAMP(c4); AF_PROF(G, 3, c3, c4);
+                status = L.status_sh;
+            }
+        }
+        __syncthreads();
+        // ---- the read's tasks go to the batch's list and the bins of their tile / query length; the plan goes to HBM ----
+        const uint32_t nt = status == AF_ST_CAND ? L.n_tasks : 0u;
+        uint32_t t0 = 0;
+        if (lane == 0 && nt) t0 = atomicAdd(&G.ctr[AFC_TASKS], nt);
+        t0 = (uint32_t)__shfl((int)t0, 0);
+        if (nt && t0 + nt > G.task_cap) { status = AF_ST_FALLBACK; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CAPACITY], 1u); }
+        if (status == AF_ST_CAND) {
+            if ((uint32_t)lane < nt) {
+                const moni_dp_task_t t = L.tasks[lane];
+                G.tasks[t0 + lane] = t;
+                const uint32_t bin = af_bin_of(t.qlen, t.tlen);
+                const uint32_t at = atomicAdd(&G.ctr[AFC_BINS + bin], 1u);
+                G.bin_q[(size_t)bin * G.bin_cap + at] = t0 + lane;        // bin_cap == task_cap: cannot overflow
+                G.task_pos[t0 + lane] = at | (bin << 26);
+            }
+            if ((uint32_t)lane < PL.n_cand) PL.cand[lane].task0 += t0;
+        }
+        if (lane == 0) {
+            PL.status = (uint8_t)status;
+            if (status == AF_ST_FALLBACK) G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)r;
+        }
+        __syncthreads();
+        {   // plan: only the part in use
+            const uint32_t words = (uint32_t)((offsetof(af_plan_t, cand) + (status == AF_ST_CAND ? PL.n_cand : 0u) * sizeof(af_cand_t)) / 4);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&PL);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(G.plans + r_in);
+            for (uint32_t w = lane; w < words; w += 64) dst[w] = src[w];
+        }
+        __syncthreads();
+        AF_STAMP(c5); AF_PROF(G, 4, c0, c5);
+    }
+}
+
+// 64-task chunks of a group of bins with the offsets of their direction bytes (one thread; a few thousand chunks).  Runs once for
+// the extension / gap problems (groups large and small) and once more, after global_task_kernel, for the global problems.
+__global__ void af_chunk_kernel(const af_args_t G, const uint32_t first_group, const uint32_t last_group) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t nc = 0;
+    for (uint32_t g = 0; g < first_group; ++g) nc += G.ctr[AFC_NCHUNKS + g];
+    uint64_t doff;
+    memcpy(&doff, &G.ctr[AFC_DIROFF], 8);
+    for (uint32_t grp = first_group; grp <= last_group; ++grp) {
+        const uint32_t b0 = grp == AF_GRP_LARGE ? 0u : grp == AF_GRP_SMALL ? AF_BIN_SMALL : AF_BIN_GLOBAL, b1 = grp == AF_GRP_LARGE ? 16u : grp == AF_GRP_SMALL ? 17u : 33u;
+        const uint32_t nc0 = nc;
+        for (uint32_t bin = b0; bin < b1; ++bin) {
+            const uint32_t cnt = G.ctr[AFC_BINS + bin];
+            const uint32_t qhi = grp == AF_GRP_SMALL ? AF_TS : ((bin - b0) + 1) * 16, tb = grp == AF_GRP_SMALL ? AF_TS : AF_TB, np = grp == AF_GRP_GLOBAL ? AF_GPASS : 1;
+            for (uint32_t s = 0; s < cnt; s += 64) {
+                if (nc >= G.chunk_cap) break;
+                const uint64_t bytes = (uint64_t)np * qhi * tb * 64;
+                af_chunk_t c; c.bin = bin; c.start = s; c.n = cnt - s < 64 ? cnt - s : 64; c.qhi = qhi;
+                if (doff + bytes > G.dirs_cap) { c.dir_off = ~0ull; G.ctr[AFC_DIRS_OVF] = 1; } else { c.dir_off = doff; doff += bytes; }
+                G.chunks[nc++] = c;
+            }
+        }
+        G.ctr[AFC_NCHUNKS + grp] = nc - nc0;
+    }
+    memcpy(&G.ctr[AFC_DIROFF], &doff, 8);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// dp_lane_kernel: ksw_extz2_sse (thirdparty/ksw2, absent; call sites aligner_ksw2.hpp:2812,2844,2965,2988,3015), one
+// lane per problem.  Outer loop over the query (wave-uniform trip count), inner loop over a block of TB target rows fully unrolled:
+// H(i, j-1) and F(i, j) of every row of the block in registers, E and the diagonal carried along the block.  NP > 1: targets longer
+// than TB are taken block by block; (H, E) of a block's last row go through a per-wave buffer to the next block.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int TB, int QC, int NP>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) dp_lane_kernel(const af_args_t G, const uint32_t grp) {
+    __shared__ uint8_t qs[QC][64];
+    const int lane = threadIdx.x;
+    const dp_launch_t& D = G.A.D;
+    const int32_t qo = D.qo, e = D.e, scM = D.sc_mch, scX = D.sc_mis;
+    constexpr int NW = (TB + 15) / 16;
+    uint64_t* __restrict__ bnd = NP > 1 ? G.bnd + (size_t)blockIdx.x * QC * 64 + lane : nullptr;
+    uint32_t chunk0 = 0;
+    for (uint32_t g = 0; g < grp; ++g) chunk0 += G.ctr[AFC_NCHUNKS + g];
+    const uint32_t n_chunks = G.ctr[AFC_NCHUNKS + grp];
+    while (true) {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(&G.ctr[AFC_CURSOR + grp], 1u);
+        c = (uint32_t)__shfl((int)c, 0);
+        if (c >= n_chunks) break;
+        const af_chunk_t ch = G.chunks[chunk0 + c];
+        const bool has = (uint32_t)lane < ch.n;
+        const bool nodir = ch.dir_off == ~0ull;           // the direction bytes did not fit: the chunk's problems are flagged, their reads take align_kernel
+        uint32_t tid = 0;
+        moni_dp_task_t task; task.qlen = 0; task.tlen = 0; task.q_off = 0; task.t_off = 0; task.reserved = 0; task.flag = 0;
+        if (has) { tid = G.bin_q[(size_t)ch.bin * G.bin_cap + ch.start + lane]; task = G.tasks[tid]; }
+        const int qlen = task.qlen, tlen = task.tlen, mode = task.reserved;
+        int maxq = qlen, maxt = tlen;
+        for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(maxq, o); maxq = w > maxq ? w : maxq; const int w2 = __shfl_xor(maxt, o); maxt = w2 > maxt ? w2 : maxt; }
+        bool wild = nodir;
+        {   // query codes -> LDS: sixteen independent byte loads in flight per lane (addresses clamped into the padded buffer)
+            const uint8_t* __restrict__ q = D.reads + task.q_off;
+            for (int j0 = 0; j0 < maxq; j0 += 16) {
+                uint32_t b[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int j = j0 + u < qlen ? j0 + u : 0; b[u] = (mode & DP_Q_REV) ? q[-(long)j] : q[j]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    uint32_t cq = dp_nt4(b[u]);
+                    if ((mode & DP_Q_COMP) && cq < 4) cq = 3 - cq;
+                    if (j0 + u < qlen) { wild |= cq > 3; qs[j0 + u][lane] = (uint8_t)cq; }
+                }
+            }
+        }
+        if (NP > 1) {       // a wildcard anywhere in the target: known before the first block runs
+            for (int i = 0; i < maxt; ++i) if (i < tlen) { const uint64_t a = (mode & DP_T_REV) ? task.t_off - (uint64_t)i : task.t_off + (uint64_t)i; wild |= dp_nt4(a < D.n_text ? D.text[a] : 0u) > 3; }
+        }
+        af_res_t R; R.mqe = AF_NEG_INF; R.mqe_t = -1; R.score = AF_NEG_INF; R.flags = 0;
+        for (int pass = 0; pass < NP && pass * TB < maxt; ++pass) {
+            const int i0 = pass * TB;
+            uint32_t tp[NW];      // target codes of the block -> registers (2 bits each); the byte loads are unconditional and independent
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tp[w] = 0;
+            {
+                uint32_t tbyte[TB];
+#pragma unroll
+                for (int i = 0; i < TB; ++i) {
+                    const int ii = i0 + i < tlen ? i0 + i : 0;
+                    const uint64_t a = (mode & DP_T_REV) ? task.t_off - (uint64_t)ii : task.t_off + (uint64_t)ii;
+                    tbyte[i] = D.text[a < D.n_text ? a : 0];
+                }
+#pragma unroll
+                for (int i = 0; i < TB; ++i) {
+                    const uint32_t ct = dp_nt4(tbyte[i]);
+                    const bool in = i0 + i < tlen;
+                    wild |= in && ct > 3;
+                    tp[i >> 4] |= (in ? (ct & 3u) : 0u) << (2 * (i & 15));
+                }
+            }
+            int32_t Hc[TB], Fc[TB];
+#pragma unroll
+            for (int i = 0; i < TB; ++i) { Hc[i] = -(qo + (i0 + i + 1) * e); Fc[i] = AF_NEG_INF; }
+            uint32_t* __restrict__ dir = reinterpret_cast<uint32_t*>(G.dirs + (nodir ? 0ull : ch.dir_off) + (size_t)pass * ch.qhi * TB * 64) + lane;
+            const bool run = has && !wild && i0 < tlen;
+            int32_t prev_hb = -(qo + i0 * e);                           // H(i0 - 1, -1)
+            for (int j = 0; j < maxq; ++j) {
+                if (run && j < qlen) {
+                    const int32_t qc = qs[j][lane];
+                    int32_t diag, h_up, e_run;
+                    if (NP > 1 && pass > 0) {
+                        const uint64_t be = bnd[(size_t)j * 64];
+                        h_up = (int32_t)(uint32_t)be; e_run = (int32_t)(uint32_t)(be >> 32);      // H(i0 - 1, j), E(i0 - 1, j)
+                        diag = prev_hb;                                                            // H(i0 - 1, j - 1)
+                        prev_hb = h_up;
+                    } else {
+                        diag = j == 0 ? 0 : -(qo + j * e);              // H(-1, j-1)
+                        h_up = -(qo + (j + 1) * e);                     // H(-1, j)
+                        e_run = AF_NEG_INF;
+                    }
+                    uint32_t pack = 0;
+                    uint32_t* __restrict__ drow = dir + (size_t)j * (TB / 4) * 64;
+#pragma unroll
+                    for (int i = 0; i < TB; ++i) {
+                        const int32_t tc = (int32_t)((tp[i >> 4] >> (2 * (i & 15))) & 3u);
+                        const int32_t h_old = Hc[i];
+                        const int32_t Eo = h_up - qo;
+                        const int32_t E = (Eo > e_run ? Eo : e_run) - e;
+                        const int32_t Fo = h_old - qo;
+                        const int32_t F = (Fo > Fc[i] ? Fo : Fc[i]) - e;
+                        int32_t z = diag + (tc == qc ? scM : scX);
+                        uint32_t d = z > E ? 0u : 1u; z = z > E ? z : E;
+                        d = z > F ? d : 2u; z = z > F ? z : F;
+                        const int32_t zq = z - qo;
+                        d |= (E >= zq) ? 0x08u : 0u;
+                        d |= (F >= zq) ? 0x10u : 0u;
+                        Hc[i] = z; Fc[i] = F; diag = h_old; h_up = z; e_run = E;
+                        pack |= d << (8 * (i & 3));
+                        if ((i & 3) == 3) { drow[(i >> 2) * 64] = pack; pack = 0; }
+                    }
+                    if (NP > 1) bnd[(size_t)j * 64] = (uint64_t)(uint32_t)h_up | ((uint64_t)(uint32_t)e_run << 32);      // (H, E) of the block's last row
+                }
+            }
+            if (run) {
+#pragma unroll
+                for (int i = 0; i < TB; ++i) {
+                    const int32_t h = Hc[i];
+                    if (i0 + i < tlen) { if (h > R.mqe) { R.mqe = h; R.mqe_t = i0 + i; } if (i0 + i == tlen - 1) R.score = h; }
+                }
+            }
+        }
+        if (has) {
+            if (wild) { R.mqe = AF_NEG_INF; R.mqe_t = -1; R.score = AF_NEG_INF; R.flags = 1; }
+            G.res[tid] = R;
+        }
+        unsigned long long cells = wild ? 0ull : (unsigned long long)qlen * (unsigned long long)tlen;
+        for (int o = 32; o > 0; o >>= 1) cells += __shfl_xor(cells, o);
+        if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_CELLS]), cells);
+        __syncthreads();
+    }
+}
+
+// where the direction byte of cell (i, j) of a task is: its chunk, its lane there, the target block of i
+struct af_dirs_t { const uint8_t* base; uint32_t tb; uint64_t pass_stride; };
+__device__ __forceinline__ af_dirs_t af_dir_of(const af_args_t& G, uint32_t bin, uint32_t pos_in_bin) {
+    const uint32_t grp = bin < AF_BIN_SMALL ? AF_GRP_LARGE : bin == AF_BIN_SMALL ? AF_GRP_SMALL : AF_GRP_GLOBAL;
+    const uint32_t b0 = grp == AF_GRP_LARGE ? 0u : grp == AF_GRP_SMALL ? AF_BIN_SMALL : AF_BIN_GLOBAL;
+    uint32_t ci = 0;
+    for (uint32_t g = 0; g < grp; ++g) ci += G.ctr[AFC_NCHUNKS + g];
+    for (uint32_t b2 = b0; b2 < bin; ++b2) ci += (G.ctr[AFC_BINS + b2] + 63) >> 6;
+    ci += pos_in_bin >> 6;
+    const af_chunk_t ch = G.chunks[ci];
+    af_dirs_t X;
+    X.tb = grp == AF_GRP_SMALL ? AF_TS : AF_TB;
+    X.pass_stride = (uint64_t)ch.qhi * X.tb * 64;
+    X.base = G.dirs + ch.dir_off + (size_t)(pos_in_bin & 63) * 4;
+    return X;
+}
+
+// the window of a chain from its extensions (aligner_ksw2.hpp:2852-2886)
+__device__ __forceinline__ void af_window(const af_cand_t& C, uint32_t m, int lc_t, int rc_t, uint64_t& ref_pos, uint64_t& ref_len) {
+    const af_anchor_t first = C.an[0], last = C.an[C.n_an - 1];
+    const uint64_t mem_pos = first.occ, mem_len = last.occ + last.len - mem_pos;
+    const uint64_t lq = (uint64_t)(int64_t)(first.idx > 0 ? lc_t + 1 : 0);
+    const uint64_t rcs_len = m - ((uint64_t)last.idx + last.len);
+    const uint64_t rq = (uint64_t)(int64_t)(rcs_len > 0 ? rc_t + 1 : 0);
+    ref_pos = lq > mem_pos ? 0 : mem_pos - lq; ref_len = lq + mem_len + rq;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// global_task_kernel: chains with overlapping anchors are scored by one global alignment of the whole read against the window
+// their extensions give (aligner_ksw2.hpp:2984-2996, 3009-3015); one lane per read queues those problems
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) global_task_kernel(const af_args_t G) {
+    const uint64_t r_in = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const ak_args_t& A = G.A;
+    if (r_in >= A.n_reads) return;
+    af_plan_t& PL = G.plans[r_in];
+    if (PL.status != AF_ST_CAND) return;
+    const uint64_t r = A.read_lo + r_in;
+    const uint64_t off = A.offs[r];
+    const uint32_t m = (uint32_t)(A.offs[r + 1] - off);
+    uint32_t why = AF_WHY_N;
+    for (uint32_t c = 0; c < PL.n_cand && why == AF_WHY_N; ++c) {
+        af_cand_t& C = PL.cand[c];
+        if (!C.overlap) continue;
+        uint32_t t = C.task0;
+        int lc_t = -1, rc_t = -1;
+        if (C.has_lc) { const af_res_t R = G.res[t++]; if (R.flags) why = AF_WHY_WILDCARD; lc_t = R.mqe_t; }
+        if (C.has_rc) { const af_res_t R = G.res[t++]; if (R.flags) why = AF_WHY_WILDCARD; rc_t = R.mqe_t; }
+        uint64_t ref_pos, ref_len;
+        af_window(C, m, lc_t, rc_t, ref_pos, ref_len);
+        if (why != AF_WHY_N) break;
+        C.gtask = ~0u;
+        if (!ac_valid(A.P, ref_pos, ref_len)) continue;                    // scored INT32_MIN whatever the DP says; never the final chain
+        if (ref_len == 0 || ref_len > (uint64_t)AF_GPASS * AF_TB) { why = AF_WHY_TASK_SIZE; break; }
+        const uint32_t tid = atomicAdd(&G.ctr[AFC_TASKS], 1u);
+        if (tid >= G.task_cap) { why = AF_WHY_CAPACITY; break; }
+        moni_dp_task_t T;
+        if (!C.strand) { T.q_off = off; T.reserved = DP_Q_READS | DP_T_TEXT; } else { T.q_off = off + m - 1; T.reserved = DP_Q_READS | DP_T_TEXT | DP_Q_REV | DP_Q_COMP; }
+        T.t_off = ref_pos; T.qlen = (int32_t)m; T.tlen = (int32_t)ref_len; T.flag = DP_EZ_RIGHT;
+        G.tasks[tid] = T;
+        const uint32_t bin = AF_BIN_GLOBAL + ((m - 1) >> 4);
+        const uint32_t at = atomicAdd(&G.ctr[AFC_BINS + bin], 1u);
+        G.bin_q[(size_t)bin * G.bin_cap + at] = tid;
+        G.task_pos[tid] = at | (bin << 26);
+        C.gtask = tid;
+    }
+    if (why != AF_WHY_N) { PL.status = AF_ST_FALLBACK; G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)r; atomicAdd(&G.ctr[AFC_WHY + why], 1u); }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// select_kernel: the results come back into the selection loop (aligner_ksw2.hpp:436-474, 528-548, 2852-2886, 2975-2999)
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) select_kernel(const af_args_t G) {
+    const uint64_t r_in = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const ak_args_t& A = G.A;
+    if (r_in >= A.n_reads) return;
+    af_plan_t& PL = G.plans[r_in];
+    if (PL.status != AF_ST_CAND) return;
+    const ac_params_t& P = A.P;
+    const uint64_t r = A.read_lo + r_in;
+    const uint32_t m = (uint32_t)(A.offs[r + 1] - A.offs[r]);
+    const uint32_t n_cand = PL.n_cand;
+    int32_t max_score = 0; uint32_t n_alt = 0;
+    struct best_t { int32_t score; uint64_t lft; uint64_t idx; } best[AF_MAX_CAND + 2];
+    uint32_t n_best = 0;
+    bool fallback = false;
+    uint32_t why = AF_WHY_WILDCARD;
+    for (uint32_t c = 0; c < n_cand && !fallback; ++c) {
+        af_cand_t& C = PL.cand[c];
+        uint32_t t = C.task0;
+        int score_lc = 0, score_rc = 0, lc_t = -1, rc_t = -1;
+        if (C.has_lc) { const af_res_t R = G.res[t++]; fallback |= R.flags != 0; score_lc = R.mqe; lc_t = R.mqe_t; }
+        if (C.has_rc) { const af_res_t R = G.res[t++]; fallback |= R.flags != 0; score_rc = R.mqe; rc_t = R.mqe_t; }
+        const uint32_t n_an = C.n_an;
+        uint64_t ref_pos, ref_len;
+        af_window(C, m, lc_t, rc_t, ref_pos, ref_len);
+        int32_t score;
+        if (C.overlap) {
+            score = INT32_MIN;                                              // gtask == ~0u: the window is not inside one sequence
+            if (C.gtask != ~0u) { const af_res_t R = G.res[C.gtask]; fallback |= R.flags != 0; score = R.score; }
+        } else {
+            uint32_t sc = (uint32_t)score_lc + (uint32_t)score_rc;
+            for (uint32_t k = 1; k < n_an; ++k) {
+                const af_anchor_t ap = C.an[k - 1];
+                int32_t gs = ap.gap_val;                                        // AF_GAP_NONE: 0
+                if (ap.gap_kind == AF_GAP_INS) gs = af_ins_score(P, (uint64_t)(uint16_t)ap.gap_val);
+                else if (ap.gap_kind == AF_GAP_TASK) { const af_res_t R = G.res[t++]; fallback |= R.flags != 0; gs = R.score; }
+                sc += (uint32_t)((uint64_t)ap.len * (uint64_t)(int64_t)P.smatch + (uint64_t)(int64_t)gs);
+            }
+            sc += (uint32_t)((uint64_t)C.an[n_an - 1].len * (uint64_t)(int64_t)P.smatch);
+            score = (int32_t)sc;
+            if (!ac_valid(P, ref_pos, ref_len)) score = INT32_MIN;
+        }
+        C.score = score;
+        // check_max_score + the best_scores update (ac_absorb), W.i = C.chain_idx
+        const uint64_t lft = ac_lift(P, ref_pos);
+        if (score > max_score) { max_score = score; n_alt = 0; }
+        else if (score == max_score) { PL.alt_pos[n_alt] = ref_pos; PL.alt_score[n_alt] = score; ++n_alt; }      // n_alt <= n_cand
+        uint64_t wi = C.chain_idx;
+        bool replaced = false;
+        for (uint32_t j = 0; j < n_best; ++j) {
+            const uint64_t bl = best[j].lft;
+            const uint64_t d = bl > lft ? bl - lft : lft - bl;
+            if (d < P.region_dist) {
+                if (score > best[j].score) {
+                    if (replaced) { best[j].score = 0; best[j].lft = 0; best[j].idx = wi - 1; }
+                    else { best[j].score = score; best[j].lft = lft; best[j].idx = wi; wi++; replaced = true; }
+                } else { j = n_best; replaced = true; wi++; }
+            }
+        }
+        if (!replaced) { best[n_best].score = score; best[n_best].lft = lft; best[n_best].idx = wi; ++n_best; wi++; }
+        if (wi != (uint64_t)C.chain_idx + 1 && !fallback) { fallback = true; why = AF_WHY_LOOP; }        // the loop skipped a chain because of this score: the run-ahead list is not the loop's
+    }
+    uint32_t status = AF_ST_UNALIGNED;
+    uint32_t final_c = 0;
+    int32_t score2 = 0;
+    if (!fallback) {
+        while (n_best < 2) { best[n_best].score = 0; best[n_best].lft = 0; best[n_best].idx = PL.n_chains; ++n_best; }
+        // std::sort(greater<tuple>) of at most AF_MAX_CAND + 2 elements: the insertion-sort range of std::sort (n <= 16), i.e. a stable sort
+        for (uint32_t i = 1; i < n_best; ++i) {
+            const best_t v = best[i];
+            uint32_t k = i;
+            auto gt = [](const best_t& x, const best_t& y) { return x.score > y.score || (x.score == y.score && (x.lft > y.lft || (x.lft == y.lft && x.idx > y.idx))); };
+            while (k > 0 && gt(v, best[k - 1])) { best[k] = best[k - 1]; --k; }
+            best[k] = v;
+        }
+        if (best[0].score >= PL.min_score) {
+            score2 = best[1].score;
+            const uint64_t fc = best[0].idx;
+            int found = -1;
+            for (uint32_t c = 0; c < n_cand; ++c) if (PL.cand[c].chain_idx == fc) found = (int)c;
+            if (fc < PL.n_chains && found >= 0 && PL.cand[found].score >= PL.min_score) { status = AF_ST_FINAL; final_c = (uint32_t)found; }
+            else if (fc < PL.n_chains && found < 0) { fallback = true; why = AF_WHY_LOOP; }      // cannot happen (a positive score belongs to a scored chain); stay exact
+        }
+    }
+    if (!fallback && status == AF_ST_FINAL) {
+        // the final call of chain_score repeats the chain's problems with EXTZ_ONLY | RIGHT and a traceback (aligner_ksw2.hpp:2062-2076);
+        // the direction bytes are there already; an extension must reach the query end for its traceback to start at (mqe_t, qlen - 1)
+        af_cand_t& C = PL.cand[final_c];
+        uint32_t t = C.task0;
+        int lc_t = -1, rc_t = -1;
+        for (uint32_t k = 0; k < (uint32_t)C.has_lc + C.has_rc; ++k) {
+            const af_res_t R = G.res[t + k];
+            const moni_dp_task_t T = G.tasks[t + k];
+            const int32_t bound = (T.qlen < T.tlen ? T.qlen : T.tlen) * (int32_t)A.D.sc_mch;             // ez->max <= sc_mch * min(qlen, tlen)
+            if (!C.overlap && !(R.mqe + A.D.end_bonus > bound) && !fallback) { fallback = true; why = AF_WHY_REACH_END; }
+            if (k == 0 && C.has_lc) lc_t = R.mqe_t; else rc_t = R.mqe_t;
+        }
+        af_window(C, m, lc_t, rc_t, PL.ref_pos, PL.ref_len);
+        const uint32_t n_tb = C.overlap ? 1u : (uint32_t)C.has_lc + C.has_rc + C.n_gap_tasks;
+        if (!fallback && n_tb) {
+            const uint32_t tb0 = atomicAdd(&G.ctr[AFC_TRACED], n_tb);
+            if (tb0 + n_tb > G.tb_cap) { fallback = true; why = AF_WHY_CAPACITY; }
+            else { PL.tb0 = tb0; if (C.overlap) G.tb_task[tb0] = C.gtask; else for (uint32_t k = 0; k < n_tb; ++k) G.tb_task[tb0 + k] = t + k; }
+        }
+    }
+    if (fallback) { PL.status = AF_ST_FALLBACK; G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)r; atomicAdd(&G.ctr[AFC_WHY + why], 1u); return; }
+    PL.status = (uint8_t)status; PL.final_cand = (uint8_t)final_c; PL.score2 = score2; PL.n_alt = (uint8_t)n_alt;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// traceback_kernel: ksw_backtrack (is_rot) over the direction bytes of one problem per lane
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) traceback_kernel(const af_args_t G) {
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= G.ctr[AFC_TRACED] || x >= G.tb_cap) return;
+    const uint32_t tid = G.tb_task[x];
+    const moni_dp_task_t T = G.tasks[tid];
+    const af_res_t R = G.res[tid];
+    const uint32_t bin = G.task_pos[tid] >> 26, pos = G.task_pos[tid] & ((1u << 26) - 1);
+    af_tb_t& O = G.tb[x];
+    const af_dirs_t X = af_dir_of(G, bin, pos);
+    const uint32_t tb = X.tb;
+    int i, j;
+    if (T.flag & DP_EZ_EXTZ_ONLY) { i = R.mqe_t; j = T.qlen - 1; } else { i = T.tlen - 1; j = T.qlen - 1; }
+    uint32_t n = 0, cur_op = 0xFu, cur_len = 0;
+    bool ovf = false;
+    auto push = [&](uint32_t op, uint32_t len) {
+        if (op == cur_op) { cur_len += len; return; }
+        if (cur_op != 0xFu) { if (n < AF_TB_CIG) O.ops[n++] = cur_len << 4 | cur_op; else ovf = true; }
+        cur_op = op; cur_len = len;
+    };
+    int state = 0;
+    while (i >= 0 && j >= 0) {
+        const uint32_t ps = (uint32_t)i / tb, ii = (uint32_t)i - ps * tb;
+        const uint32_t tmp = X.base[ps * X.pass_stride + ((size_t)j * (tb / 4) + (size_t)(ii >> 2)) * 256 + (ii & 3)];
+        if (state == 0) state = tmp & 7;
+        else if (!(tmp >> (state + 2) & 1)) state = 0;
+        if (state == 0) state = tmp & 7;
+        if (state == 0) { push(0, 1); --i; --j; }
+        else if (state == 1 || state == 3) { push(2, 1); --i; }
+        else { push(1, 1); --j; }
+    }
+    if (i >= 0) push(2, (uint32_t)(i + 1));
+    if (j >= 0) push(1, (uint32_t)(j + 1));
+    if (cur_op != 0xFu) { if (n < AF_TB_CIG) O.ops[n++] = cur_len << 4 | cur_op; else ovf = true; }
+    O.n_ops = ovf ? ~0u : n;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// finish_kernel: stitched CIGAR of the final chain (aligner_ksw2.hpp:3049-3108) and the record / SAM line (ak_write_record)
+// ------------------------------------------------------------------------------------------------------------------------------
+struct af_fin_t { uint32_t cig[AF_FIN_CIG]; uint32_t lcig[AF_FIN_LCIG]; uint64_t md_tmp[AK_MD_CAP / 8]; uint64_t txt_tmp[AK_TXT_CAP / 8]; };
+
+__global__ void __launch_bounds__(64) finish_kernel(const af_args_t G) {
+    const ak_args_t& A = G.A;
+    af_fin_t& S = *reinterpret_cast<af_fin_t*>(G.fin_scratch + ((size_t)blockIdx.x * 64 + threadIdx.x) * G.fin_stride);
+    for (uint64_t r_in = (uint64_t)blockIdx.x * 64 + threadIdx.x; r_in < A.n_reads; r_in += (uint64_t)gridDim.x * 64) {
+        af_plan_t& PL = G.plans[r_in];
+        if (PL.status == AF_ST_FALLBACK) continue;
+        const uint64_t r = A.read_lo + r_in;
+        ak_final_t V;
+        V.off = A.offs[r]; V.m = (uint32_t)(A.offs[r + 1] - A.offs[r]); V.strand = 0; V.ref_pos = 0; V.score = 0; V.score2 = 0;
+        V.cigar = S.cig; V.n_cigar = 0; V.alt_pos = PL.alt_pos; V.alt_score = PL.alt_score; V.n_alt = 0; V.aligned = 0; V.overflow = 0;
+        if (PL.status == AF_ST_FINAL) {
+            const af_cand_t& C = PL.cand[PL.final_cand];
+            uint32_t n = 0; bool ovf = false;
+            auto push = [&](uint32_t op) { if (n < AF_FIN_CIG) S.cig[n++] = op; else ovf = true; };
+            auto push_merge_first = [&](uint32_t op, bool first) { if (first && (op & 0xf) == 0 && n > 0) S.cig[n - 1] += op; else push(op); };
+            uint32_t tbx = PL.tb0;
+            if (C.overlap) {             // the CIGAR of the global realignment (aligner_ksw2.hpp:3009-3020)
+                const af_tb_t& T = G.tb[tbx];
+                if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push(T.ops[T.n_ops - 1 - k]);
+            } else {
+                if (C.has_lc) {              // the CIGAR of the reversed problem, reversed again: the traceback's own order
+                    const af_tb_t& T = G.tb[tbx++];
+                    if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push(T.ops[k]);
+                }
+                const uint32_t rc_x = C.has_rc ? tbx++ : 0u;
+                for (uint32_t j = 0; j < C.n_an; ++j) {
+                    const uint32_t mlen = C.an[j].len;
+                    if (n > 0 && (S.cig[n - 1] & 0xf) == 0) S.cig[n - 1] += mlen << 4; else push(mlen << 4);
+                    if (j + 1 < C.n_an) {
+                        const af_anchor_t g = C.an[j];
+                        if (g.gap_kind == AF_GAP_TASK) {
+                            const af_tb_t& T = G.tb[tbx++];
+                            if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push_merge_first(T.ops[T.n_ops - 1 - k], k == 0);
+                        } else if (g.gap_kind == AF_GAP_INS) push_merge_first(((uint32_t)(uint16_t)g.gap_val << 4) | 1u, true);
+                        else if (g.gap_kind == AF_GAP_DEL0) push_merge_first(2u, true);
+                        else if (g.gap_kind == AF_GAP_1X1) push_merge_first(1u << 4, true);
+                    }
+                }
+                if (C.has_rc) {
+                    const af_tb_t& T = G.tb[rc_x];
+                    if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push_merge_first(T.ops[T.n_ops - 1 - k], k == 0);
+                }
+            }
+            if (ovf) { PL.status = AF_ST_FALLBACK; G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)r; atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CIGAR], 1u); continue; }
+            V.strand = C.strand; V.ref_pos = PL.ref_pos; V.score = C.score; V.score2 = PL.score2; V.n_cigar = n; V.n_alt = PL.n_alt; V.aligned = 1;
+        }
+        ak_write_record(A, V, S.md_tmp, S.txt_tmp, S.lcig, AF_FIN_LCIG, r_in, r);      // a record that does not fit the pools is marked for the host pipeline, as in align_kernel
+    }
+}

@@ -86,7 +86,9 @@ struct ak_args_t {
     const uint64_t* offs;
     const int32_t* min_score_of_len;         // 20 + 8*log(l), computed on the host (libm) per read length
     uint32_t max_len;
-    uint64_t read_lo, n_reads;               // this launch takes reads [read_lo, read_lo + n_reads) of the resident batch
+    uint64_t read_lo, n_reads;               // this launch takes reads [read_lo, read_lo + n_reads) of the resident batch,
+    const uint32_t* n_reads_dev;             // when set: the number of reads is read from here (a list filled by earlier kernels of the stream)
+    const uint32_t* read_list;               // or, when set, the n_reads reads it names (the reads the staged kernels hand over); records go to recs[read - read_lo]
     ak_slot_t* slots;                        // gridDim.x * AK_NL
     ak_wave_t* waves;                        // gridDim.x
     moni_aln_rec_t* recs;
@@ -99,15 +101,32 @@ struct ak_args_t {
                                              // [14] MD pool (words)
 };
 
+// What the record / text writers read of a finished read: a view, so that every align kernel (the persistent per-lane
+// state machines below, the staged kernels of align_fast.hip) ends in the same code.
+struct ak_final_t {
+    uint64_t off; uint32_t m, strand;
+    uint64_t ref_pos; int32_t score, score2;
+    const uint32_t* cigar; uint32_t n_cigar;
+    const uint64_t* alt_pos; const int32_t* alt_score; uint32_t n_alt;
+    uint32_t aligned, overflow;
+};
+__device__ __forceinline__ ak_final_t ak_view(const ac_ws_t& W) {
+    ak_final_t V;
+    V.off = W.off; V.m = W.m; V.strand = W.fill.strand; V.ref_pos = W.fill.ref_pos; V.score = W.fill.score; V.score2 = W.score2;
+    V.cigar = W.cigar; V.n_cigar = W.n_cigar; V.alt_pos = W.alt_pos; V.alt_score = W.alt_score; V.n_alt = W.n_alt;
+    V.aligned = W.aligned; V.overflow = W.overflow;
+    return V;
+}
+
 // MD:Z text and NM of the final alignment (write_MD_core, sam.hpp:249-287), lane-private: read and text bytes through one-word
 // register caches, text staged in the slot.  Returns the length, or -1 when it does not fit AK_MD_CAP.
 // cig / n_cig / t0: the CIGAR and the text position of its first column; md == nullptr: NM only.
-__device__ __attribute__((noinline)) int ak_md(const ak_args_t& A, const ac_ws_t& W, const uint32_t* __restrict__ cig, uint32_t n_cig, uint64_t t0,
+__device__ __attribute__((noinline)) int ak_md(const ak_args_t& A, const ak_final_t& W, const uint32_t* __restrict__ cig, uint32_t n_cig, uint64_t t0,
                                                uint8_t* __restrict__ md, int32_t& nm_out) {
     const uint8_t* __restrict__ text = A.D.text;
     const uint8_t* __restrict__ reads = A.D.reads;
     const uint64_t n_text = A.D.n_text, off = W.off;
-    const uint32_t m = W.m, strand = W.fill.strand;
+    const uint32_t m = W.m, strand = W.strand;
     // byte streams through two-word register caches: the word after the current one is requested as soon as the current one is
     // entered, so its latency overlaps the comparison of eight bases (dir = +1 text and forward reads, -1 reverse-strand reads)
     struct stream_t { const uint8_t* base; uint64_t w, word, nw, nword; };
@@ -189,9 +208,9 @@ __device__ __forceinline__ uint8_t ak_compl(uint8_t b) {        // kpbseq.h:120-
     return u == 'A' ? 'T' : u == 'C' ? 'G' : u == 'G' ? 'C' : u == 'T' ? 'A' : b;
 }
 
-// lcig / n_lcig / lifted: the alignment lifted to the reference contig (columns 3, 4, 6, MD, NM); W.cigar / W.fill.ref_pos: the
+// lcig / n_lcig / lifted: the alignment lifted to the reference contig (columns 3, 4, 6, MD, NM); W.cigar / W.ref_pos: the
 // alignment on the pangenome text (OA tag, with lift_nm); aligner_ksw2.hpp:3116-3175
-__device__ __attribute__((noinline)) int ak_emit(const ak_args_t& A, const ac_ws_t& W, uint64_t r, bool aligned, const uint8_t* md, int md_len, int32_t nm,
+__device__ __attribute__((noinline)) int ak_emit(const ak_args_t& A, const ak_final_t& W, uint64_t r, bool aligned, const uint8_t* md, int md_len, int32_t nm,
                                                  int32_t lift_nm, const uint32_t* __restrict__ lcig, uint32_t n_lcig, uint64_t lifted, uint8_t* __restrict__ out) {
     const ak_fmt_t& F = A.fmt;
     ak_writer_t w; w.p = reinterpret_cast<uint64_t*>(out); w.acc = 0; w.n = 0; w.ovf = false;
@@ -209,13 +228,13 @@ __device__ __attribute__((noinline)) int ak_emit(const ak_args_t& A, const ac_ws
         w.flush();
         return w.ovf ? -1 : w.n;
     }
-    const uint32_t strand = W.fill.strand;
-    const int32_t score = W.fill.score, score2 = W.score2;
+    const uint32_t strand = W.strand;
+    const int32_t score = W.score, score2 = W.score2;
     uint64_t ref_len = 0;
     for (uint32_t k = 0; k < n_lcig; ++k) { const int op = lcig[k] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += lcig[k] >> 4; }
-    const uint64_t rk = ac_rank1(A.P, W.fill.ref_pos + 1);
+    const uint64_t rk = ac_rank1(A.P, W.ref_pos + 1);
     const uint32_t sid = (uint32_t)(rk - 1);
-    const int oa_pos = (int)(W.fill.ref_pos - A.P.seq_starts[rk - 1] + 1);         // sam->lift_pos: the position on the pangenome sequence
+    const int oa_pos = (int)(W.ref_pos - A.P.seq_starts[rk - 1] + 1);         // sam->lift_pos: the position on the pangenome sequence
     const uint64_t lrk = ac_rank1(A.P, lifted + 1);
     const uint32_t lsid = (uint32_t)(lrk - 1);
     const int pos1 = (int)(lifted - A.P.seq_starts[lrk - 1] + 1);                   // sam->pos
@@ -268,11 +287,11 @@ __device__ __attribute__((noinline)) int ak_emit(const ak_args_t& A, const ac_ws
 }
 
 // the record of a finished read (lane-private)
-__device__ __attribute__((noinline)) void ak_write_record(const ak_args_t& A, const ac_ws_t& W, uint64_t* __restrict__ md_tmp, uint64_t* __restrict__ txt_tmp,
-                                                          uint32_t* __restrict__ lcig, uint64_t slot_in_launch) {
+__device__ __attribute__((noinline)) void ak_write_record(const ak_args_t& A, const ak_final_t& W, uint64_t* __restrict__ md_tmp, uint64_t* __restrict__ txt_tmp,
+                                                          uint32_t* __restrict__ lcig, uint32_t lcig_cap, uint64_t slot_in_launch, uint64_t read_index) {
     moni_aln_rec_t rec;
     rec.status = W.overflow ? 2u : (W.aligned ? 1u : 0u);
-    rec.strand = W.fill.strand; rec.ref_pos = W.fill.ref_pos; rec.score = W.fill.score; rec.score2 = W.score2;
+    rec.strand = W.strand; rec.ref_pos = W.ref_pos; rec.score = W.score; rec.score2 = W.score2;
     rec.n_cigar = 0; rec.n_alt = 0; rec.cigar_off = 0; rec.alt_off = 0; rec.nm = 0; rec.md_len = 0; rec.md_off = 0;
     rec.txt_len = 0; rec.lift_nm = 0; rec.txt_off = 0;
     int32_t nm = 0, lift_nm = 0;
@@ -281,18 +300,18 @@ __device__ __attribute__((noinline)) void ak_write_record(const ak_args_t& A, co
     if (rec.status == 1) {
         // the alignment lifted to the reference contig (aligner_ksw2.hpp:3133-3160): CIGAR, position, MD / NM over the lifted window;
         // NM of the alignment on the pangenome text stays for the OA tag
-        const uint64_t rk = ac_rank1(A.P, W.fill.ref_pos + 1);
+        const uint64_t rk = ac_rank1(A.P, W.ref_pos + 1);
         const moni_lift_seq_t L = A.P.lift_seqs[rk - 1];
         const moni_lift_run_t* __restrict__ runs = A.P.lift_runs + L.run_off;
-        const uint64_t start = W.fill.ref_pos - A.P.seq_starts[rk - 1];
-        n_lcig = lift_cigar(runs, L.n_runs, start, W.cigar, W.n_cigar, lcig, AC_MAX_CIGAR);
+        const uint64_t start = W.ref_pos - A.P.seq_starts[rk - 1];
+        n_lcig = lift_cigar(runs, L.n_runs, start, W.cigar, W.n_cigar, lcig, lcig_cap);
         lifted = L.second + lift_pos(runs, L.n_runs, start);
-        bool same = n_lcig == (int)W.n_cigar && lifted == W.fill.ref_pos;
+        bool same = n_lcig == (int)W.n_cigar && lifted == W.ref_pos;
         for (uint32_t k = 0; same && k < W.n_cigar; ++k) same = lcig[k] == W.cigar[k];
         uint64_t lref = 0;
         for (int k = 0; k < n_lcig; ++k) { const int op = lcig[k] & 0xf; if (op == 0 || op == 2 || op == 3) lref += lcig[k] >> 4; }
         if (n_lcig >= 0 && lref > 0) md_len = ak_md(A, W, lcig, (uint32_t)n_lcig, lifted, reinterpret_cast<uint8_t*>(md_tmp), nm);
-        if (same) lift_nm = nm; else (void)ak_md(A, W, W.cigar, W.n_cigar, W.fill.ref_pos, nullptr, lift_nm);
+        if (same) lift_nm = nm; else (void)ak_md(A, W, W.cigar, W.n_cigar, W.ref_pos, nullptr, lift_nm);
         const unsigned long long md_words = md_len > 0 ? (unsigned long long)((md_len + 7) >> 3) : 0ull;
         const unsigned long long co = atomicAdd(&A.cursors[0], (unsigned long long)W.n_cigar);
         const unsigned long long ao = atomicAdd(&A.cursors[1], (unsigned long long)W.n_alt);
@@ -308,7 +327,7 @@ __device__ __attribute__((noinline)) void ak_write_record(const ak_args_t& A, co
     }
     if (A.fmt.txt_pool && rec.status != 2) {
         // the finished SAM line; when it does not fit (staging or pool) the host formats this record from the fields above
-        const int n = ak_emit(A, W, A.read_lo + slot_in_launch, rec.status == 1, reinterpret_cast<const uint8_t*>(md_tmp), md_len, nm, lift_nm, lcig,
+        const int n = ak_emit(A, W, read_index, rec.status == 1, reinterpret_cast<const uint8_t*>(md_tmp), md_len, nm, lift_nm, lcig,
                               (uint32_t)(n_lcig > 0 ? n_lcig : 0), lifted, reinterpret_cast<uint8_t*>(txt_tmp));
         if (n > 0) {
             const unsigned long long words = (unsigned long long)((n + 7) >> 3);
@@ -331,6 +350,7 @@ align_kernel(const ak_args_t A) {
     __shared__ unsigned long long s_cy[8];        // wave cycles inside phase 2: per-read setup, memo lookups, DP by live-row class (<=16, <=32, <=64, >64)       // statistics: DP problems run, cells, memo hits, their cells, wave cycles in the phases
     enum { C_DP = 0, C_CELLS, C_MEMO, C_MEMO_CELLS, C_INIT, C_DRIVE, C_CYDP };
     const int lane = threadIdx.x;
+    if (A.n_reads_dev && *A.n_reads_dev == 0) return;        // nothing was handed over by the staged kernels
     if (lane < 8) { s_cnt[lane] = 0; s_hist[lane] = 0; s_cy[lane] = 0; }
     __syncthreads();
     ak_slot_t* __restrict__ S = A.slots + (size_t)blockIdx.x * AK_NL + (lane < AK_NL ? lane : 0);
@@ -339,17 +359,19 @@ align_kernel(const ak_args_t A) {
     if (lane < AK_NL) for (int k = 0; k < 6; ++k) W.prof[k] = 0;
     int state = lane < AK_NL ? 0 : 2;             // 0: wants a read, 1: waits for DP results, 2: no more reads, 3: finished, record not yet written
     uint64_t r_in = 0;                            // read index inside the launch
+    uint64_t r_slot = 0, r_read = 0;              // its record slot and its index in the resident batch
     while (true) {
         // ---- phase 1 (lane-private): take a read; seeds -> chains -> first DP request ----
         const long long c0 = clock64();
         const bool start = __popcll(__ballot(state == 0 || state == 3)) >= AK_START_MIN || __ballot(state == 1) == 0ull;
         // finished reads write their records (MD/NM, pool entries) together, like the starts: it is lane-private work too
-        if (state == 3 && start) { ak_write_record(A, W, S->md_tmp, S->txt_tmp, S->lcig, r_in); state = 0; }
+        if (state == 3 && start) { ak_write_record(A, ak_view(W), S->md_tmp, S->txt_tmp, S->lcig, AC_MAX_CIGAR, r_slot, r_read); state = 0; }
         if (state == 0 && start) {
             r_in = atomicAdd(&A.cursors[4], 1ull);
-            if (r_in >= A.n_reads) state = 2;
+            if (r_in >= (A.n_reads_dev ? (uint64_t)*A.n_reads_dev : A.n_reads)) state = 2;
             else {
-                const uint64_t r = A.read_lo + r_in;
+                const uint64_t r = A.read_list ? (uint64_t)A.read_list[r_in] : A.read_lo + r_in;
+                r_read = r; r_slot = r - A.read_lo;
                 W.off = A.offs[r]; W.m = (uint32_t)(A.offs[r + 1] - A.offs[r]);
                 W.min_score = A.min_score_of_len[W.m <= A.max_len ? W.m : A.max_len];
                 S->memo_n = 0;
@@ -359,7 +381,7 @@ align_kernel(const ak_args_t A) {
                 } else chained = ac_init(W, A.P, A.mems, A.read_mem_off[r], A.read_mem_off[r + 1], A.occs);
                 if (chained) ac_drive(W, A.P, nullptr, nullptr);
                 if (chained && !W.overflow && W.stage != AC_DONE) state = 1;
-                else ak_write_record(A, W, S->md_tmp, S->txt_tmp, S->lcig, r_in);
+                else ak_write_record(A, ak_view(W), S->md_tmp, S->txt_tmp, S->lcig, AC_MAX_CIGAR, r_slot, r_read);
             }
         }
         const unsigned long long waiting = __ballot(state == 1);

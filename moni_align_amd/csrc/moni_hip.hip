@@ -23,6 +23,7 @@
 #include "seed_kernels.hip"
 #include "extz_kernels.hip"
 #include "align_kernel.hip"
+#include "align_fast.hip"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "moni_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return MONI_ENODEV; } } while (0)
 
@@ -119,6 +120,13 @@ struct moni_ctx {
     // align kernel
     DBuf<dp_big_t> dp_big;
     DBuf<uint8_t> dp_dir_big;
+    struct AfSet {          // device buffers of the staged align kernels (align_fast.hip), one set per launch stream
+        DBuf<af_plan_t> plans; DBuf<moni_dp_task_t> tasks; DBuf<af_res_t> res; DBuf<uint32_t> bin_q, task_pos, tb_task, fb_list, ctr;
+        DBuf<af_chunk_t> chunks; DBuf<uint8_t> dirs, fin; DBuf<af_tb_t> tb; DBuf<uint64_t> bnd; DBuf<unsigned long long> prof;
+        void release() { bnd.release(); prof.release(); plans.release(); tasks.release(); res.release(); bin_q.release(); task_pos.release(); tb_task.release(); fb_list.release(); ctr.release();
+                         chunks.release(); dirs.release(); fin.release(); tb.release(); }
+    } af[2];
+    HBuf<uint32_t> af_ctr_host;             // counters of the last batch's launches (64 words per sub-batch), pinned
     DBuf<ak_slot_t> ak_slots;
     DBuf<ak_wave_t> ak_waves;
     DBuf<unsigned long long> ak_cursors;
@@ -328,6 +336,7 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->seq.release(); c->offs.release(); c->ptr.release(); c->pat.release(); c->cnt_m.release(); c->cnt_s.release(); c->mem_slots.release(); c->tot.release();
     c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
     c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
+    c->af[0].release(); c->af[1].release(); c->af_ctr_host.release();
     c->dp_q.release(); c->dp_t.release(); c->dp_dir.release(); c->dp_tasks.release(); c->dp_res.release(); c->dp_cig.release();
     c->dp_off.release(); c->dp_ws.release(); c->dp_big.release(); c->dp_dir_big.release(); c->ak_slots.release(); c->ak_waves.release(); c->ak_cursors.release(); c->ak_rnames.release(); c->ak_quals.release(); c->ak_rname_off.release(); c->ak_txt.release(); c->ak_mapq_tab.release(); c->h_txt.release(); c->h_recs.release(); c->h_cig.release(); c->h_alt.release(); c->h_md.release();
     for (auto& ob : c->pieces) ob.release();
@@ -800,10 +809,27 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 c->mapq_tab_ready = true;
             }
         }
-        if ((rc = c->ak_slots.ensure(2 * waves_full * AK_NL)) || (rc = c->ak_waves.ensure(2 * waves_full)) || (rc = c->h_recs.ensure(NR + 1)) ||
+        // The staged kernels (align_fast.hip) take the common case; align_kernel takes the reads they hand over (MONI_ALIGN_V1=1: every read)
+        static const bool use_fast = getenv("MONI_ALIGN_V1") == nullptr;
+        int n_cu = 256;
+        { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, I->device) == hipSuccess) n_cu = pr.multiProcessorCount; }
+        const uint64_t ak_waves = use_fast ? std::min<uint64_t>(waves_full, 1024) : waves_full;       // in-flight read slots of align_kernel (75 KB each)
+        if ((rc = c->ak_slots.ensure(2 * ak_waves * AK_NL)) || (rc = c->ak_waves.ensure(2 * ak_waves)) || (rc = c->h_recs.ensure(NR + 1)) ||
             (rc = c->h_cig.ensure(cig_per * n_sub + 1)) || (rc = c->h_alt.ensure(alt_per * n_sub + 1)) || (rc = c->h_md.ensure(md_per * n_sub + 1)) || (rc = c->ak_minscore.ensure(msc.size())) ||
             (rc = c->ak_cursors.ensure(AK_CUR * n_sub + AK_CUR)))
             return rc;
+        const uint32_t af_task_cap = (uint32_t)std::min<uint64_t>(12 * sub_reads + 4096, (1ull << 26) - 1), af_tb_cap = (uint32_t)std::min<uint64_t>(4 * sub_reads + 1024, 0x7FFFFFFFull);
+        const uint32_t af_chunk_cap = af_task_cap / 64 + 2 * AF_NBIN;
+        const uint64_t af_dirs_cap = 65536ull * sub_reads + (16ull << 20);
+        const unsigned af_dp_grid = (unsigned)n_cu * 8;
+        const unsigned af_fin_grid = (unsigned)std::min<uint64_t>((sub_reads + 63) / 64, (uint64_t)n_cu * 8);
+        if (use_fast) for (int x = 0; x < (n_sub > 1 ? 2 : 1); ++x) {
+            moni_ctx::AfSet& S = c->af[x];
+            if ((rc = S.plans.ensure(sub_reads + 1)) || (rc = S.tasks.ensure(af_task_cap)) || (rc = S.res.ensure(af_task_cap)) || (rc = S.bin_q.ensure((size_t)AF_NBIN * af_task_cap)) ||
+                (rc = S.task_pos.ensure(af_task_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.fb_list.ensure(sub_reads + 1)) ||
+                (rc = S.ctr.ensure(AF_NCTR)) || (rc = S.bnd.ensure((size_t)af_dp_grid * AF_QCAP * 64)) || (rc = S.chunks.ensure(af_chunk_cap)) || (rc = S.dirs.ensure(af_dirs_cap)) || (rc = S.fin.ensure((size_t)af_fin_grid * 64 * sizeof(af_fin_t))))
+                return rc;
+        }
         // the launches alternate between the context's stream and one more: HIP multiplexes streams onto a handful of hardware queues
         // (4 by default), and two streams that land on the same queue run their kernels one after the other
         c->ak_stream[0] = c->stream;
@@ -814,10 +840,12 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         HIPCHK(hipMemcpyAsync(c->ak_minscore.p, msc.data(), msc.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         t_launch[0] = mh::now_s() - t_enter;
+        if ((rc = c->af_ctr_host.ensure(64 * n_sub + 64))) return rc;
+        memset(c->af_ctr_host.p, 0, 64 * n_sub * sizeof(uint32_t));
         for (uint64_t k = 0; k < n_sub; ++k) {
             const uint64_t r0 = sub_lo[k], nr = sub_lo[k + 1] - sub_lo[k];
-            uint64_t n_waves = waves_full;
-            if (n_waves * AK_NL > nr) n_waves = (nr + AK_NL - 1) / AK_NL;
+            uint64_t n_waves = ak_waves;
+            if (!use_fast && n_waves * AK_NL > nr) n_waves = (nr + AK_NL - 1) / AK_NL;
             waves_used = std::max(waves_used, n_waves);
             ak_args_t A;
             memset(&A, 0, sizeof A);
@@ -832,7 +860,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             A.D.end_bonus = prm->end_bonus; A.D.reads = c->seq.p; A.D.text = I->d_text; A.D.n_text = I->K.n_text;
             A.mems = c->mems.p; A.occs = c->occs.p; A.read_mem_off = c->read_mem_off.p; A.offs = c->offs.p;
             A.min_score_of_len = c->ak_minscore.p; A.max_len = (uint32_t)c->max_len + 1; A.read_lo = r0; A.n_reads = nr;
-            A.slots = c->ak_slots.p + (k & 1) * waves_full * AK_NL; A.waves = c->ak_waves.p + (k & 1) * waves_full;
+            A.slots = c->ak_slots.p + (k & 1) * ak_waves * AK_NL; A.waves = c->ak_waves.p + (k & 1) * ak_waves;
             A.recs = c->h_recs.p + r0; A.cig_pool = c->h_cig.p + k * cig_per; A.cig_cap = cig_per; A.alt_pool = c->h_alt.p + k * alt_per;
             A.alt_cap = alt_per; A.md_pool = c->h_md.p + k * md_per; A.md_cap = md_per; A.cursors = c->ak_cursors.p + AK_CUR * k;
             if (gpu_text) {
@@ -843,7 +871,38 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             }
             hipStream_t sx = c->ak_stream[k & 1];
             HIPCHK(hipEventRecord(c->ak_begin[k], sx));
-            hipLaunchKernelGGL(align_kernel, dim3((unsigned)n_waves), dim3(64), 0, sx, A);
+            if (use_fast && nr > 0) {
+                moni_ctx::AfSet& S = c->af[k & 1];
+                af_args_t G;
+                memset(&G, 0, sizeof G);
+                G.A = A;
+                G.plans = S.plans.p; G.tasks = S.tasks.p; G.task_cap = af_task_cap; G.res = S.res.p; G.bin_q = S.bin_q.p; G.bin_cap = af_task_cap; G.task_pos = S.task_pos.p;
+                G.chunks = S.chunks.p; G.chunk_cap = af_chunk_cap; G.dirs = S.dirs.p; G.dirs_cap = af_dirs_cap; G.tb_task = S.tb_task.p; G.tb = S.tb.p; G.tb_cap = af_tb_cap;
+                G.fb_list = S.fb_list.p; G.fin_scratch = S.fin.p; G.fin_stride = sizeof(af_fin_t); G.ctr = S.ctr.p;
+                G.bnd = S.bnd.p;
+#ifdef AF_PROFILE
+                if ((rc = S.prof.ensure(32))) return rc;
+                if (k < 2) HIPCHK(hipMemsetAsync(S.prof.p, 0, 32 * 8, sx));
+                G.prof = S.prof.p;
+#endif
+                static_assert(AF_NCTR == 64, "the counters of a sub-batch are fetched as 64 words");
+                HIPCHK(hipMemsetAsync(S.ctr.p, 0, AF_NCTR * sizeof(uint32_t), sx));
+                hipLaunchKernelGGL(chain_plan_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 10)), dim3(64), 0, sx, G);
+                hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_SMALL);
+                hipLaunchKernelGGL((dp_lane_kernel<AF_TB, AF_QCAP, 1>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE);
+                hipLaunchKernelGGL((dp_lane_kernel<AF_TS, AF_TS, 1>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_SMALL);
+                hipLaunchKernelGGL(global_task_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
+                hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL, (uint32_t)AF_GRP_GLOBAL);
+                hipLaunchKernelGGL((dp_lane_kernel<AF_TB, AF_QCAP, AF_GPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL);
+                hipLaunchKernelGGL(select_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
+                hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)((af_tb_cap + 255) / 256)), dim3(256), 0, sx, G);
+                hipLaunchKernelGGL(finish_kernel, dim3((unsigned)std::min<uint64_t>((nr + 63) / 64, af_fin_grid)), dim3(64), 0, sx, G);
+                A.read_list = S.fb_list.p; A.n_reads_dev = S.ctr.p + AFC_FALLBACK;       // the reads the staged kernels handed over
+                hipLaunchKernelGGL(align_kernel, dim3((unsigned)ak_waves), dim3(64), 0, sx, A);
+                HIPCHK(hipMemcpyAsync(c->af_ctr_host.p + 64 * k, S.ctr.p, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, sx));
+            } else if (nr > 0) {
+                hipLaunchKernelGGL(align_kernel, dim3((unsigned)n_waves), dim3(64), 0, sx, A);
+            }
             HIPCHK(hipEventRecord(c->ak_done[k], sx));
             HIPCHK(hipGetLastError());
         }
@@ -942,11 +1001,26 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             for (uint64_t k = 0; k < n_sub; ++k) {
                 const unsigned long long* q = cur.data() + AK_CUR * k;
                 st.dp_tasks += q[2]; st.dp_cells += q[3]; st.dp_reused += q[8]; st.dp_cells_reused += q[9];
+                if (use_fast) {         // the staged kernels' own counters
+                    const uint32_t* fc = c->af_ctr_host.p + 64 * k;
+                    unsigned long long cells; memcpy(&cells, fc + AFC_CELLS, 8);
+                    st.dp_tasks += fc[AFC_TASKS]; st.dp_cells += cells; st.kernel_fallback += fc[AFC_FALLBACK];
+                    if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "  staged kernels, sub-batch %llu: %u DP tasks, %llu cells, %u traced, %u large + %u small + %u global chunks, %u reads to align_kernel%s\n",
+                                                           (unsigned long long)k, fc[AFC_TASKS], cells, fc[AFC_TRACED], fc[AFC_NCHUNKS], fc[AFC_NCHUNKS + 1], fc[AFC_NCHUNKS + 2], fc[AFC_FALLBACK], fc[AFC_DIRS_OVF] ? " (direction bytes overflowed)" : "");
+                    if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "    handed over because: long read %u, anchors/seeds %u, chains %u, chains to score %u, chain length %u, DP size %u, overlapping anchors %u, wildcard %u, "
+                                                           "loop depends on a score %u, extension short of the query end %u, capacity %u, CIGAR %u\n",
+                                                           fc[AFC_WHY + 0], fc[AFC_WHY + 1], fc[AFC_WHY + 2], fc[AFC_WHY + 3], fc[AFC_WHY + 4], fc[AFC_WHY + 5], fc[AFC_WHY + 6], fc[AFC_WHY + 7], fc[AFC_WHY + 8], fc[AFC_WHY + 9], fc[AFC_WHY + 10], fc[AFC_WHY + 11]);
+                }
                 prof[0] += (double)q[5]; prof[1] += (double)q[6]; prof[2] += (double)q[7]; for (int x = 0; x < 4; ++x) prof[3 + x] += (double)q[10 + x];
                 for (int x = 0; x < 8; ++x) hist[x] += (double)q[16 + x];
                 for (int x = 0; x < 7; ++x) cyc[x] += (double)q[24 + x];
             }
         }
+#ifdef AF_PROFILE
+        if (use_fast && n_sub) { unsigned long long pf[32]; for (int x = 0; x < (n_sub > 1 ? 2 : 1); ++x) { HIPCHK(hipMemcpy(pf, c->af[x].prof.p, sizeof pf, hipMemcpyDeviceToHost));
+            fprintf(stderr, "chain_plan_kernel wave cycles (set %d): load+filter+anchors %.3g, chain %.3g (sort %.3g, dp %.3g, ends+backtrack %.3g), lifts %.3g, plan %.3g, whole read %.3g\n", x,
+                    (double)pf[0], (double)pf[1], (double)pf[5], (double)pf[6], (double)pf[7], (double)pf[2], (double)pf[3], (double)pf[4]); } }
+#endif
         double ak_sum_ms = c->dp_kernel_ms_accum;
         if (n_sub) { float ms = 0; if (hipEventElapsedTime(&ms, c->ak_begin[0], c->ak_done[n_sub - 1]) == hipSuccess) c->dp_kernel_ms_accum = ms; }      // launches overlap: report the span
         if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "align_kernel: %.3f ms span (%.3f ms summed) in %llu launches, %llu waves x %d reads in flight; wave cycles: take+chain %.3g, later drives %.3g, DP %.3g; lane cycles in ac_init: load %.3g sort %.3g chain-dp %.3g backtrack %.3g\n", c->dp_kernel_ms_accum, ak_sum_ms, (unsigned long long)n_sub, (unsigned long long)waves_used, (int)AK_NL, prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[6]);
@@ -1023,6 +1097,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         stats->t_seed = st.t_seed; stats->t_chain = st.t_chain; stats->t_dp = st.t_dp; stats->t_host = st.t_host;
         stats->t_dp_kernel = c->dp_kernel_ms_accum / 1e3;
         stats->handed_back = st.handed_back; stats->dp_reused = st.dp_reused; stats->dp_cells_reused = st.dp_cells_reused;
+        stats->kernel_fallback = st.kernel_fallback;
     }
     return MONI_OK;
 }

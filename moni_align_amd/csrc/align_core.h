@@ -59,6 +59,7 @@ struct ac_params_t {
     const uint64_t* seq_starts;      // n_seq + 1 onsets
     const moni_lift_seq_t* lift_seqs; // one lift per sequence (lift_core.h)
     const moni_lift_run_t* lift_runs;
+    const uint64_t* pdir;            // position directory (lift_core.h) or nullptr (binary searches)
 };
 
 enum { AC_LOOP = 0, AC_WAIT_A, AC_WAIT_B, AC_FINAL_WAIT_A, AC_FINAL_WAIT_B, AC_DONE };
@@ -121,14 +122,42 @@ AC_HD uint64_t ac_rank1(const ac_params_t& P, uint64_t i) {           // number 
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (P.seq_starts[mid] < i) lo = mid + 1; else hi = mid; }
     return lo;
 }
-AC_HD uint64_t ac_seq_off(const ac_params_t& P, uint64_t pos) { const uint64_t rk = ac_rank1(P, pos + 1); return pos - P.seq_starts[rk - 1]; }   // index(pos).second
-AC_HD bool ac_valid(const ac_params_t& P, uint64_t pos, uint64_t len) { const uint64_t rk = ac_rank1(P, pos + 1); return pos + len <= P.seq_starts[rk]; }
+// the sequence a text position lies in (seqidx: rank1(pos + 1) - 1), and with run_hint the lift run at or before its haplotype position
+AC_HD uint32_t ac_seq_of(const ac_params_t& P, uint64_t pos, uint32_t* run_hint = nullptr) {
+    if (!P.pdir) { if (run_hint) *run_hint = 0xFFFFFFFFu; return (uint32_t)(ac_rank1(P, pos + 1) - 1); }
+    uint64_t b = pos >> MONI_PDIR_SHIFT;
+    const uint64_t nb = (P.n_text >> MONI_PDIR_SHIFT) + 1;
+    if (b > nb) b = nb;
+    const uint64_t e = P.pdir[b];
+    uint32_t sid = (uint32_t)e;
+    bool moved = false;
+    while (sid + 1 < P.n_seq && pos >= P.lift_seqs[sid + 1].start) { ++sid; moved = true; }
+    if (run_hint) *run_hint = moved ? 0xFFFFFFFFu : (uint32_t)(e >> 32);
+    return sid;
+}
+AC_HD uint64_t ac_seq_off(const ac_params_t& P, uint64_t pos) {          // index(pos).second
+    if (!P.pdir) { const uint64_t rk = ac_rank1(P, pos + 1); return pos - P.seq_starts[rk - 1]; }
+    return pos - P.lift_seqs[ac_seq_of(P, pos)].start;
+}
+AC_HD bool ac_valid(const ac_params_t& P, uint64_t pos, uint64_t len) {
+    if (!P.pdir) { const uint64_t rk = ac_rank1(P, pos + 1); return pos + len <= P.seq_starts[rk]; }
+    return pos + len <= P.lift_seqs[ac_seq_of(P, pos)].end;
+}
 
 // liftidx::lift (liftidx.hpp:89-95)
 AC_HD uint64_t ac_lift(const ac_params_t& P, uint64_t pos) {
-    const uint64_t rk = ac_rank1(P, pos + 1);
-    const moni_lift_seq_t L = P.lift_seqs[rk - 1];
-    return L.second + lift_pos(P.lift_runs + L.run_off, L.n_runs, pos - P.seq_starts[rk - 1]);
+    uint32_t hint;
+    const uint32_t sid = ac_seq_of(P, pos, &hint);
+    const moni_lift_seq_t L = P.lift_seqs[sid];
+    const uint64_t start = pos - L.start;
+    if (hint == 0xFFFFFFFFu) return L.second + lift_pos(P.lift_runs + L.run_off, L.n_runs, start);
+    // the directory's run holds a haplotype position <= start: walk forward to the last such run (lift_find)
+    uint32_t k = hint;
+    const uint32_t last = L.run_off + L.n_runs;
+    moni_lift_run_t R = P.lift_runs[k];
+    while (k + 1 < last) { const moni_lift_run_t N = P.lift_runs[k + 1]; if ((uint64_t)N.hap > start) break; R = N; ++k; }
+    const uint64_t x = (uint64_t)R.col + (start - (uint64_t)R.hap);
+    return L.second + (uint64_t)R.ref + ((R.flags & MONI_LIFT_INS) ? 0ull : x - (uint64_t)R.col);
 }
 
 AC_HD uint64_t ac_occ(const ac_ws_t& W, uint32_t mem, uint32_t occ) { return W.mems[mem].occs[occ]; }

@@ -35,9 +35,12 @@
 #define AF_MAX_AN 6
 #define AF_MAX_READ 512          // longest read of the staged path
 #define AF_QCAP 256              // longest query of a DP task
-#define AF_TB 104                // target rows of the large register tile
-#define AF_TS 32                 // ... of the small one (gap fills)
-#define AF_GPASS 3                // target blocks of a global problem (overlapping anchors): up to AF_GPASS * AF_TB target rows
+#define AF_TB 104                // longest target of an extension / gap problem
+#define AF_BLK 52                // target rows a lane keeps in registers at a time (H and F of a block: 104 registers, three waves per SIMD)
+#define AF_LPASS (AF_TB / AF_BLK) // blocks of an extension / gap problem
+#define AF_TS 32                 // target rows (one block) and longest query of the small tile (gap fills)
+#define AF_GBLK 104               // register block of the global problems (overlapping anchors)
+#define AF_GPASS 3                // their target blocks: up to AF_GPASS * AF_GBLK target rows
 #define AF_NBIN 33               // 16 query-length bins of the large tile, the small tile, 16 query-length bins of global problems
 #define AF_BIN_SMALL 16u
 #define AF_BIN_GLOBAL 17u
@@ -99,6 +102,7 @@ struct af_args_t {
     uint64_t* bnd;                           // per resident DP wave: (H, E) of a target block's last row for every query position (global problems)
     uint32_t* ctr;                           // AF_NCTR counters, see the AFC_* indices
     unsigned long long* prof;                // AF_PROFILE builds: wave cycles per phase
+    uint32_t dbg;                            // AF_PROFILE builds: 1 = no direction stores, 2 = no DP rows (timing experiments; results are wrong)
 };
 #ifdef AF_PROFILE
 #define AF_STAMP(var) const long long var = clock64()
@@ -550,9 +554,9 @@ __global__ void af_chunk_kernel(const af_args_t G, const uint32_t first_group, c
     for (uint32_t grp = first_group; grp <= last_group; ++grp) {
         const uint32_t b0 = grp == AF_GRP_LARGE ? 0u : grp == AF_GRP_SMALL ? AF_BIN_SMALL : AF_BIN_GLOBAL, b1 = grp == AF_GRP_LARGE ? 16u : grp == AF_GRP_SMALL ? 17u : 33u;
         const uint32_t nc0 = nc;
-        for (uint32_t bin = b0; bin < b1; ++bin) {
+        for (uint32_t bin = b1; bin-- > b0;) {          // longest queries first: the persistent DP waves take chunks in this order, the short ones fill the tail
             const uint32_t cnt = G.ctr[AFC_BINS + bin];
-            const uint32_t qhi = grp == AF_GRP_SMALL ? AF_TS : ((bin - b0) + 1) * 16, tb = grp == AF_GRP_SMALL ? AF_TS : AF_TB, np = grp == AF_GRP_GLOBAL ? AF_GPASS : 1;
+            const uint32_t qhi = grp == AF_GRP_SMALL ? AF_TS : ((bin - b0) + 1) * 16, tb = grp == AF_GRP_SMALL ? AF_TS : grp == AF_GRP_GLOBAL ? AF_GBLK : AF_BLK, np = grp == AF_GRP_GLOBAL ? AF_GPASS : grp == AF_GRP_LARGE ? AF_LPASS : 1;
             for (uint32_t s = 0; s < cnt; s += 64) {
                 if (nc >= G.chunk_cap) break;
                 const uint64_t bytes = (uint64_t)np * qhi * tb * 64;
@@ -566,6 +570,26 @@ __global__ void af_chunk_kernel(const af_args_t G, const uint32_t first_group, c
     memcpy(&G.ctr[AFC_DIROFF], &doff, 8);
 }
 
+// A lane's operand bytes come as aligned 8-byte words (one request per eight bases instead of one per base: with 64 lanes on 64
+// different cache lines the byte form is bound by request rate).  Sequence element k is at byte start + k (forward) or start - k
+// (reverse); af_group returns elements 8g .. 8g+7 as one word, element 8g+u in byte u.  Words outside [0, limit) read as zero.
+struct af_bytes_t { const uint8_t* base; int64_t start, limit; bool rev; uint64_t carry; int64_t carry_addr; };
+__device__ __forceinline__ af_bytes_t af_bytes(const uint8_t* base, uint64_t start, uint64_t limit, bool rev) {
+    af_bytes_t S; S.base = base; S.start = (int64_t)start; S.limit = (int64_t)limit; S.rev = rev; S.carry = 0; S.carry_addr = -8; return S;
+}
+__device__ __forceinline__ uint64_t af_group(af_bytes_t& S, int g) {
+    const int64_t lo = S.rev ? S.start - 8 * g - 7 : S.start + 8 * g;
+    const int64_t wa = lo & ~7ll;
+    const int sh = (int)(lo & 7);
+    uint64_t a = S.carry, b = S.carry;
+    if (S.carry_addr != wa) a = (wa >= 0 && wa < S.limit) ? *reinterpret_cast<const uint64_t*>(S.base + wa) : 0ull;
+    if (sh && S.carry_addr != wa + 8) b = (wa + 8 >= 0 && wa + 8 < S.limit) ? *reinterpret_cast<const uint64_t*>(S.base + wa + 8) : 0ull;
+    uint64_t v = sh ? (a >> (8 * sh)) | (b << (64 - 8 * sh)) : a;
+    if (S.rev) { S.carry = a; S.carry_addr = wa; v = __builtin_bswap64(v); }        // the next group ends where this one's first word ends
+    else if (sh) { S.carry = b; S.carry_addr = wa + 8; }
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // dp_lane_kernel: ksw_extz2_sse (thirdparty/ksw2, absent; call sites aligner_ksw2.hpp:2812,2844,2965,2988,3015), one
 // lane per problem.  Outer loop over the query (wave-uniform trip count), inner loop over a block of TB target rows fully unrolled:
@@ -573,7 +597,7 @@ __global__ void af_chunk_kernel(const af_args_t G, const uint32_t first_group, c
 // than TB are taken block by block; (H, E) of a block's last row go through a per-wave buffer to the next block.
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int TB, int QC, int NP>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) dp_lane_kernel(const af_args_t G, const uint32_t grp) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64 ? 1 : 3, TB > 64 ? 1 : 3))) dp_lane_kernel(const af_args_t G, const uint32_t grp) {
     __shared__ uint8_t qs[QC][64];
     const int lane = threadIdx.x;
     const dp_launch_t& D = G.A.D;
@@ -598,22 +622,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
         int maxq = qlen, maxt = tlen;
         for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(maxq, o); maxq = w > maxq ? w : maxq; const int w2 = __shfl_xor(maxt, o); maxt = w2 > maxt ? w2 : maxt; }
         bool wild = nodir;
-        {   // query codes -> LDS: sixteen independent byte loads in flight per lane (addresses clamped into the padded buffer)
-            const uint8_t* __restrict__ q = D.reads + task.q_off;
-            for (int j0 = 0; j0 < maxq; j0 += 16) {
-                uint32_t b[16];
+        {   // query codes -> LDS, eight bases per load
+            af_bytes_t QS = af_bytes(D.reads, task.q_off, D.reads_limit, (mode & DP_Q_REV) != 0);
+            for (int g = 0; 8 * g < maxq; ++g) {
+                const uint64_t v = 8 * g < qlen ? af_group(QS, g) : 0ull;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) { const int j = j0 + u < qlen ? j0 + u : 0; b[u] = (mode & DP_Q_REV) ? q[-(long)j] : q[j]; }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    uint32_t cq = dp_nt4(b[u]);
+                for (int u = 0; u < 8; ++u) {
+                    uint32_t cq = dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu);
                     if ((mode & DP_Q_COMP) && cq < 4) cq = 3 - cq;
-                    if (j0 + u < qlen) { wild |= cq > 3; qs[j0 + u][lane] = (uint8_t)cq; }
+                    if (8 * g + u < qlen) { wild |= cq > 3; qs[8 * g + u][lane] = (uint8_t)cq; }
                 }
             }
         }
         if (NP > 1) {       // a wildcard anywhere in the target: known before the first block runs
-            for (int i = 0; i < maxt; ++i) if (i < tlen) { const uint64_t a = (mode & DP_T_REV) ? task.t_off - (uint64_t)i : task.t_off + (uint64_t)i; wild |= dp_nt4(a < D.n_text ? D.text[a] : 0u) > 3; }
+            af_bytes_t TS = af_bytes(D.text, task.t_off, D.text_limit, (mode & DP_T_REV) != 0);
+            for (int g = 0; 8 * g < maxt; ++g) {
+                const uint64_t v = 8 * g < tlen ? af_group(TS, g) : 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wild |= 8 * g + u < tlen && dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu) > 3;
+            }
         }
         af_res_t R; R.mqe = AF_NEG_INF; R.mqe_t = -1; R.score = AF_NEG_INF; R.flags = 0;
         for (int pass = 0; pass < NP && pass * TB < maxt; ++pass) {
@@ -622,19 +649,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #pragma unroll
             for (int w = 0; w < NW; ++w) tp[w] = 0;
             {
-                uint32_t tbyte[TB];
+                af_bytes_t TS = af_bytes(D.text, (mode & DP_T_REV) ? task.t_off - (uint64_t)i0 : task.t_off + (uint64_t)i0, D.text_limit, (mode & DP_T_REV) != 0);
 #pragma unroll
-                for (int i = 0; i < TB; ++i) {
-                    const int ii = i0 + i < tlen ? i0 + i : 0;
-                    const uint64_t a = (mode & DP_T_REV) ? task.t_off - (uint64_t)ii : task.t_off + (uint64_t)ii;
-                    tbyte[i] = D.text[a < D.n_text ? a : 0];
-                }
+                for (int g = 0; g < (TB + 7) / 8; ++g) {
+                    const uint64_t v = i0 + 8 * g < tlen ? af_group(TS, g) : 0ull;
 #pragma unroll
-                for (int i = 0; i < TB; ++i) {
-                    const uint32_t ct = dp_nt4(tbyte[i]);
-                    const bool in = i0 + i < tlen;
-                    wild |= in && ct > 3;
-                    tp[i >> 4] |= (in ? (ct & 3u) : 0u) << (2 * (i & 15));
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = 8 * g + u;
+                        if (i < TB) {
+                            const uint32_t ct = dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu);
+                            const bool in = i0 + i < tlen;
+                            wild |= in && ct > 3;
+                            tp[i >> 4] |= (in ? (ct & 3u) : 0u) << (2 * (i & 15));
+                        }
+                    }
                 }
             }
             int32_t Hc[TB], Fc[TB];
@@ -643,6 +671,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
             uint32_t* __restrict__ dir = reinterpret_cast<uint32_t*>(G.dirs + (nodir ? 0ull : ch.dir_off) + (size_t)pass * ch.qhi * TB * 64) + lane;
             const bool run = has && !wild && i0 < tlen;
             int32_t prev_hb = -(qo + i0 * e);                           // H(i0 - 1, -1)
+#ifdef AF_PROFILE
+            if (G.dbg & 2) maxq = 0;
+#endif
             for (int j = 0; j < maxq; ++j) {
                 if (run && j < qlen) {
                     const int32_t qc = qs[j][lane];
@@ -675,7 +706,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
                         d |= (F >= zq) ? 0x10u : 0u;
                         Hc[i] = z; Fc[i] = F; diag = h_old; h_up = z; e_run = E;
                         pack |= d << (8 * (i & 3));
+#ifdef AF_PROFILE
+                        if ((i & 3) == 3) { if (!(G.dbg & 1)) drow[(i >> 2) * 64] = pack; pack = 0; }
+#else
                         if ((i & 3) == 3) { drow[(i >> 2) * 64] = pack; pack = 0; }
+#endif
                     }
                     if (NP > 1) bnd[(size_t)j * 64] = (uint64_t)(uint32_t)h_up | ((uint64_t)(uint32_t)e_run << 32);      // (H, E) of the block's last row
                 }
@@ -703,14 +738,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 struct af_dirs_t { const uint8_t* base; uint32_t tb; uint64_t pass_stride; };
 __device__ __forceinline__ af_dirs_t af_dir_of(const af_args_t& G, uint32_t bin, uint32_t pos_in_bin) {
     const uint32_t grp = bin < AF_BIN_SMALL ? AF_GRP_LARGE : bin == AF_BIN_SMALL ? AF_GRP_SMALL : AF_GRP_GLOBAL;
-    const uint32_t b0 = grp == AF_GRP_LARGE ? 0u : grp == AF_GRP_SMALL ? AF_BIN_SMALL : AF_BIN_GLOBAL;
+    const uint32_t b1 = grp == AF_GRP_LARGE ? 16u : grp == AF_GRP_SMALL ? 17u : 33u;
     uint32_t ci = 0;
     for (uint32_t g = 0; g < grp; ++g) ci += G.ctr[AFC_NCHUNKS + g];
-    for (uint32_t b2 = b0; b2 < bin; ++b2) ci += (G.ctr[AFC_BINS + b2] + 63) >> 6;
+    for (uint32_t b2 = bin + 1; b2 < b1; ++b2) ci += (G.ctr[AFC_BINS + b2] + 63) >> 6;        // chunks are laid out from the group's last bin down
     ci += pos_in_bin >> 6;
     const af_chunk_t ch = G.chunks[ci];
     af_dirs_t X;
-    X.tb = grp == AF_GRP_SMALL ? AF_TS : AF_TB;
+    X.tb = grp == AF_GRP_SMALL ? AF_TS : grp == AF_GRP_GLOBAL ? AF_GBLK : AF_BLK;
     X.pass_stride = (uint64_t)ch.qhi * X.tb * 64;
     X.base = G.dirs + ch.dir_off + (size_t)(pos_in_bin & 63) * 4;
     return X;
@@ -752,7 +787,7 @@ __global__ void __launch_bounds__(256) global_task_kernel(const af_args_t G) {
         if (why != AF_WHY_N) break;
         C.gtask = ~0u;
         if (!ac_valid(A.P, ref_pos, ref_len)) continue;                    // scored INT32_MIN whatever the DP says; never the final chain
-        if (ref_len == 0 || ref_len > (uint64_t)AF_GPASS * AF_TB) { why = AF_WHY_TASK_SIZE; break; }
+        if (ref_len == 0 || ref_len > (uint64_t)AF_GPASS * AF_GBLK) { why = AF_WHY_TASK_SIZE; break; }
         const uint32_t tid = atomicAdd(&G.ctr[AFC_TASKS], 1u);
         if (tid >= G.task_cap) { why = AF_WHY_CAPACITY; break; }
         moni_dp_task_t T;
@@ -923,7 +958,7 @@ __global__ void __launch_bounds__(256) traceback_kernel(const af_args_t G) {
 // ------------------------------------------------------------------------------------------------------------------------------
 struct af_fin_t { uint32_t cig[AF_FIN_CIG]; uint32_t lcig[AF_FIN_LCIG]; uint64_t md_tmp[AK_MD_CAP / 8]; uint64_t txt_tmp[AK_TXT_CAP / 8]; };
 
-__global__ void __launch_bounds__(64) finish_kernel(const af_args_t G) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) finish_kernel(const af_args_t G) {
     const ak_args_t& A = G.A;
     af_fin_t& S = *reinterpret_cast<af_fin_t*>(G.fin_scratch + ((size_t)blockIdx.x * 64 + threadIdx.x) * G.fin_stride);
     for (uint64_t r_in = (uint64_t)blockIdx.x * 64 + threadIdx.x; r_in < A.n_reads; r_in += (uint64_t)gridDim.x * 64) {
@@ -970,5 +1005,271 @@ __global__ void __launch_bounds__(64) finish_kernel(const af_args_t G) {
             V.strand = C.strand; V.ref_pos = PL.ref_pos; V.score = C.score; V.score2 = PL.score2; V.n_cigar = n; V.n_alt = PL.n_alt; V.aligned = 1;
         }
         ak_write_record(A, V, S.md_tmp, S.txt_tmp, S.lcig, AF_FIN_LCIG, r_in, r);      // a record that does not fit the pools is marked for the host pipeline, as in align_kernel
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// finish_wave_kernel: the same work as finish_kernel, one wavefront per read, the SAM line assembled in LDS and written out with
+// coalesced stores.  The lanes stage the strand-oriented read, compare it with the reference window 64 columns at a time (MD / NM,
+// write_MD_core, sam.hpp:249-287), copy name / SEQ / QUAL; lane 0 stitches the CIGAR, lifts it, and spells the numeric fields and tags
+// (sam.hpp:144-188, aligner_ksw2.hpp:3116-3175, mapq.hpp:146-184).  Needs the kernel-side text pool (ak_fmt_t::txt_pool); a line that
+// does not fit is marked for the host pipeline like everywhere else.
+// ------------------------------------------------------------------------------------------------------------------------------
+struct af_finw_t {
+    uint8_t line[AK_TXT_CAP];
+    uint8_t seq[AF_MAX_READ];            // the read in alignment orientation (ASCII, kpbseq.h:120-137 complement)
+    uint8_t qc[AF_MAX_READ];             // its nt4 codes
+    uint32_t cig[AF_FIN_CIG], lcig[AF_FIN_LCIG];
+    uint32_t n_cig, n_lcig, pos, ovf;    // pos: write cursor in line[]
+    uint64_t out_off;
+};
+
+__device__ __forceinline__ void afw_c(af_finw_t& L, uint32_t& p, uint8_t ch) { if (p < AK_TXT_CAP) L.line[p] = ch; ++p; }
+__device__ __forceinline__ void afw_i(af_finw_t& L, uint32_t& p, int v) {
+    char b[12]; int k = 0; unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    do { b[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) afw_c(L, p, '-');
+    while (k) afw_c(L, p, (uint8_t)b[--k]);
+}
+__device__ __forceinline__ void afw_lit(af_finw_t& L, uint32_t& p, const char* q) { while (*q) afw_c(L, p, (uint8_t)*q++); }
+__device__ __forceinline__ void afw_cigar(af_finw_t& L, uint32_t& p, const uint32_t* cg, uint32_t n) { for (uint32_t k = 0; k < n; ++k) { afw_i(L, p, (int)(cg[k] >> 4)); afw_c(L, p, (uint8_t)"MID"[cg[k] & 0xf]); } }
+
+// MD / NM of one CIGAR over the window that starts at text position t0 (write_MD_core); with_text: the MD string goes to line[] at the
+// cursor.  All lanes call it (uniform control flow); lane 0 writes.  Returns NM (uniform).
+__device__ __forceinline__ int afw_md(const af_args_t& G, af_finw_t& L, const uint32_t* cg, uint32_t n_cig, uint64_t t0, bool with_text, uint32_t& p) {
+    const int lane = threadIdx.x;
+    const dp_launch_t& D = G.A.D;
+    int NM = 0, l_MD = 0;
+    uint64_t t = t0; uint32_t q = 0;
+    for (uint32_t i = 0; i < n_cig; ++i) {
+        const uint32_t op = cg[i] & 0xf, len = cg[i] >> 4;
+        if (op == 0 || op == 7 || op == 8) {
+            for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                uint32_t tc = 0; bool mis = false;
+                if (k < len) { const uint64_t a = t + k; tc = dp_nt4(a < D.n_text ? D.text[a] : 0u); mis = (uint32_t)L.qc[q + k] != tc; }
+                unsigned long long bal = __ballot(mis);
+                const uint32_t span = len - k0 < 64 ? len - k0 : 64;
+                uint32_t done = 0;                       // columns of this chunk already counted
+                while (bal) {
+                    const int b = __ffsll((long long)bal) - 1;
+                    l_MD += b - (int)done;
+                    const uint32_t tcb = (uint32_t)__shfl((int)tc, b);
+                    if (with_text && lane == 0) { afw_i(L, p, l_MD); afw_c(L, p, (uint8_t)"ACGTN"[tcb]); }
+                    if (with_text) p = (uint32_t)__shfl((int)p, 0);
+                    l_MD = 0; ++NM; done = (uint32_t)b + 1;
+                    bal &= bal - 1;
+                }
+                l_MD += (int)(span - done);
+            }
+            q += len; t += len;
+        } else if (op == 1) { q += len; NM += (int)len; }
+        else if (op == 2) {
+            if (with_text) {
+                if (lane == 0) { afw_i(L, p, l_MD); afw_c(L, p, '^'); }
+                p = (uint32_t)__shfl((int)p, 0);
+                for (uint32_t k = lane; k < len; k += 64) { const uint64_t a = t + k; const uint32_t tc = dp_nt4(a < D.n_text ? D.text[a] : 0u); if (p + k < AK_TXT_CAP) L.line[p + k] = (uint8_t)"ACGTN"[tc]; }
+                p += len;
+            }
+            l_MD = 0; t += len; NM += (int)len;
+        } else if (op == 3) t += len;
+    }
+    if (with_text && l_MD > 0) { if (lane == 0) afw_i(L, p, l_MD); p = (uint32_t)__shfl((int)p, 0); }
+    return NM;
+}
+
+__global__ void __launch_bounds__(64) finish_wave_kernel(const af_args_t G) {
+    __shared__ af_finw_t L;
+    const int lane = threadIdx.x;
+    const ak_args_t& A = G.A;
+    const ak_fmt_t& F = A.fmt;
+    for (uint64_t r_in = blockIdx.x; r_in < A.n_reads; r_in += gridDim.x) {
+        af_plan_t& PL = G.plans[r_in];
+        const uint32_t st = PL.status;
+        if (st == AF_ST_FALLBACK) continue;
+        const uint64_t r = A.read_lo + r_in;
+        const uint64_t off = A.offs[r];
+        const uint32_t m = (uint32_t)(A.offs[r + 1] - off);
+        const bool aligned = st == AF_ST_FINAL;
+        const af_cand_t* C = aligned ? &PL.cand[PL.final_cand] : nullptr;
+        const uint32_t strand = aligned ? C->strand : 0u;
+        __syncthreads();
+        // ---- the read in alignment orientation ----
+        for (uint32_t k = lane; k < m; k += 64) {
+            uint8_t b = strand ? ak_compl(A.D.reads[off + m - 1 - k]) : A.D.reads[off + k];
+            L.seq[k] = b; L.qc[k] = (uint8_t)dp_nt4(b);
+        }
+        bool ovf = false;
+        uint64_t lifted = 0;
+        if (aligned && lane == 0) {
+            // ---- CIGAR stitching (aligner_ksw2.hpp:3049-3108) ----
+            uint32_t n = 0;
+            auto push = [&](uint32_t op) { if (n < AF_FIN_CIG) L.cig[n++] = op; else ovf = true; };
+            auto push_merge_first = [&](uint32_t op, bool first) { if (first && (op & 0xf) == 0 && n > 0) L.cig[n - 1] += op; else push(op); };
+            uint32_t tbx = PL.tb0;
+            if (C->overlap) {
+                const af_tb_t& T = G.tb[tbx];
+                if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push(T.ops[T.n_ops - 1 - k]);
+            } else {
+                if (C->has_lc) { const af_tb_t& T = G.tb[tbx++]; if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push(T.ops[k]); }
+                const uint32_t rc_x = C->has_rc ? tbx++ : 0u;
+                for (uint32_t j = 0; j < C->n_an; ++j) {
+                    const uint32_t mlen = C->an[j].len;
+                    if (n > 0 && (L.cig[n - 1] & 0xf) == 0) L.cig[n - 1] += mlen << 4; else push(mlen << 4);
+                    if (j + 1 < C->n_an) {
+                        const af_anchor_t g = C->an[j];
+                        if (g.gap_kind == AF_GAP_TASK) { const af_tb_t& T = G.tb[tbx++]; if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push_merge_first(T.ops[T.n_ops - 1 - k], k == 0); }
+                        else if (g.gap_kind == AF_GAP_INS) push_merge_first(((uint32_t)(uint16_t)g.gap_val << 4) | 1u, true);
+                        else if (g.gap_kind == AF_GAP_DEL0) push_merge_first(2u, true);
+                        else if (g.gap_kind == AF_GAP_1X1) push_merge_first(1u << 4, true);
+                    }
+                }
+                if (C->has_rc) { const af_tb_t& T = G.tb[rc_x]; if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push_merge_first(T.ops[T.n_ops - 1 - k], k == 0); }
+            }
+            // ---- the alignment lifted to the reference contig (aligner_ksw2.hpp:3133-3160) ----
+            const uint32_t sid = ac_seq_of(A.P, PL.ref_pos);
+            const moni_lift_seq_t LS = A.P.lift_seqs[sid];
+            const moni_lift_run_t* __restrict__ runs = A.P.lift_runs + LS.run_off;
+            const uint64_t start = PL.ref_pos - LS.start;
+            const int nl = ovf ? -1 : lift_cigar(runs, LS.n_runs, start, L.cig, n, L.lcig, AF_FIN_LCIG);
+            if (nl < 0) ovf = true;
+            lifted = LS.second + lift_pos(runs, LS.n_runs, start);
+            L.n_cig = n; L.n_lcig = nl < 0 ? 0u : (uint32_t)nl; L.ovf = ovf ? 1u : 0u;
+        }
+        __syncthreads();
+        if (aligned) { ovf = L.ovf != 0; lifted = ((uint64_t)(uint32_t)__shfl((int)(lifted >> 32), 0) << 32) | (uint32_t)__shfl((int)(lifted & 0xFFFFFFFFull), 0); }
+        if (aligned && ovf) {
+            if (lane == 0) { PL.status = AF_ST_FALLBACK; G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)r; atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CIGAR], 1u); }
+            continue;
+        }
+        // ---- the line ----
+        uint32_t p = 0;
+        const uint64_t n0 = F.rname_off[r], n1 = F.rname_off[r + 1];
+        for (uint64_t k = lane; k < n1 - n0; k += 64) if (k < AK_TXT_CAP) L.line[k] = F.rnames[n0 + k];
+        p = (uint32_t)(n1 - n0);
+        moni_aln_rec_t rec;
+        rec.status = aligned ? 1u : 0u; rec.strand = strand; rec.ref_pos = aligned ? PL.ref_pos : 0; rec.score = aligned ? C->score : 0; rec.score2 = aligned ? PL.score2 : 0;
+        rec.n_cigar = 0; rec.n_alt = 0; rec.cigar_off = 0; rec.alt_off = 0; rec.nm = 0; rec.md_len = 0; rec.md_off = 0; rec.txt_len = 0; rec.lift_nm = 0; rec.txt_off = 0;
+        if (!aligned) {
+            if (lane == 0) afw_lit(L, p, "\t4\t*\t0\t255\t*\t*\t0\t0\t");
+            p = (uint32_t)__shfl((int)p, 0);
+            __syncthreads();
+            for (uint32_t k = lane; k < m; k += 64) if (p + k < AK_TXT_CAP) L.line[p + k] = A.D.reads[off + k];
+            p += m;
+            if (lane == 0 && p < AK_TXT_CAP) L.line[p] = '\t';
+            ++p;
+            if (F.quals) { for (uint32_t k = lane; k < m; k += 64) if (p + k < AK_TXT_CAP) L.line[p + k] = F.quals[off + k]; p += m; }
+            else { if (lane == 0 && p < AK_TXT_CAP) L.line[p] = '*'; ++p; }
+            if (lane == 0 && p < AK_TXT_CAP) L.line[p] = '\n';
+            ++p;
+        } else {
+            const uint32_t n_cig = L.n_cig, n_lcig = L.n_lcig;
+            const int32_t score = C->score, score2 = PL.score2;
+            uint64_t ref_len = 0;
+            for (uint32_t k = 0; k < n_lcig; ++k) { const int op = L.lcig[k] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += L.lcig[k] >> 4; }
+            const bool mapped = ref_len > 0;
+            const uint32_t sid = ac_seq_of(A.P, PL.ref_pos), lsid = ac_seq_of(A.P, lifted);
+            const int oa_pos = (int)(PL.ref_pos - A.P.lift_seqs[sid].start + 1);
+            const int pos1 = (int)(lifted - A.P.lift_seqs[lsid].start + 1);
+            // compute_mapq_se_bwa (mapq.hpp:146-184), the operations in the host's order, none contracted
+            int mapq = 0;
+            {
+                const int32_t rl = mapped ? (int32_t)ref_len : 0;
+                const int32_t l = rl > (int32_t)m ? rl : (int32_t)m;
+                const int32_t sub = score2 ? score2 : F.min_len * F.smatch;
+                if (sub < score) {
+                    const double identity = __dsub_rn(1., __ddiv_rn(__ddiv_rn((double)(l * F.smatch - score), (double)(F.smatch + F.smismatch)), (double)l));
+                    if (score != 0) {
+                        double tmp = (double)l < 50.0 ? 1. : ((uint32_t)l < F.mapq_tab_n ? F.mapq_tab[l] : F.mapq_tab[F.mapq_tab_n - 1]);
+                        tmp = __dmul_rn(tmp, __dmul_rn(identity, identity));
+                        const double v = __dadd_rn(__dmul_rn(__dmul_rn(__ddiv_rn(__dmul_rn(6.02, (double)(score - sub)), (double)F.smatch), tmp), tmp), .499);
+                        mapq = (int)v;
+                    }
+                    if (mapq > 60) mapq = 60;
+                    if (mapq < 0) mapq = 0;
+                    mapq = (int)__dadd_rn(__dmul_rn((double)mapq, 1.), .499);
+                }
+            }
+            // NM of the alignment on the pangenome text (OA tag) and, further down, MD / NM of the lifted one
+            uint32_t dummy = 0;
+            bool same = n_lcig == n_cig && lifted == PL.ref_pos;
+            for (uint32_t k = 0; same && k < n_cig; ++k) same = L.lcig[k] == L.cig[k];
+            int lift_nm = same ? 0 : afw_md(G, L, L.cig, n_cig, PL.ref_pos, false, dummy);
+            if (lane == 0) {
+                afw_c(L, p, '\t'); afw_i(L, p, strand ? 16 : 0); afw_c(L, p, '\t');
+                if (mapped) { for (uint32_t k = F.sname_off[lsid]; k < F.sname_off[lsid + 1]; ++k) afw_c(L, p, F.snames[k]); } else afw_c(L, p, '*');
+                afw_c(L, p, '\t'); afw_i(L, p, mapped ? pos1 : 0); afw_c(L, p, '\t'); afw_i(L, p, mapq); afw_c(L, p, '\t');
+                if (mapped) afw_cigar(L, p, L.lcig, n_lcig); else afw_c(L, p, '*');
+                afw_lit(L, p, "\t*\t0\t0\t");
+            }
+            p = (uint32_t)__shfl((int)p, 0);
+            __syncthreads();
+            for (uint32_t k = lane; k < m; k += 64) if (p + k < AK_TXT_CAP) L.line[p + k] = L.seq[k];
+            p += m;
+            if (lane == 0 && p < AK_TXT_CAP) L.line[p] = '\t';
+            ++p;
+            if (F.quals) { for (uint32_t k = lane; k < m; k += 64) if (p + k < AK_TXT_CAP) L.line[p + k] = F.quals[strand ? off + m - 1 - k : off + k]; p += m; }
+            else { if (lane == 0 && p < AK_TXT_CAP) L.line[p] = '*'; ++p; }
+            const uint32_t p_nm = p;           // "\tAS:i:<score>\tNM:i:" then NM, which needs the MD walk: MD goes to a scratch place first
+            // MD text: behind everything else it could collide with; build it at the end of the buffer region then move
+            uint32_t pm = AK_TXT_CAP / 2;      // MD staging area: second half of the line buffer
+            int nm = 0;
+            if (mapped) nm = afw_md(G, L, L.lcig, n_lcig, lifted, true, pm);
+            if (same) lift_nm = nm;
+            __syncthreads();
+            const uint32_t md_len = pm - AK_TXT_CAP / 2;
+            p = p_nm;
+            if (lane == 0) {
+                afw_lit(L, p, "\tAS:i:"); afw_i(L, p, score); afw_lit(L, p, "\tNM:i:"); afw_i(L, p, mapped ? nm : 0);
+                if (score2 != 0) { afw_lit(L, p, "\tZS:i:"); afw_i(L, p, score2); }
+                afw_lit(L, p, "\tMD:Z:");
+            }
+            p = (uint32_t)__shfl((int)p, 0);
+            __syncthreads();
+            bool too_long = pm > AK_TXT_CAP || p + md_len + 64 > AK_TXT_CAP / 2;      // the head of the line must not reach the MD staging area
+            if (!too_long && mapped) {
+                uint8_t tmpb[(AK_TXT_CAP / 2 + 63) / 64];
+                int cnt = 0;
+                for (uint32_t k = lane; k < md_len; k += 64) tmpb[cnt++] = L.line[AK_TXT_CAP / 2 + k];
+                __syncthreads();
+                cnt = 0;
+                for (uint32_t k = lane; k < md_len; k += 64) L.line[p + k] = tmpb[cnt++];
+                p += md_len;
+            }
+            __syncthreads();
+            if (lane == 0) {
+                afw_lit(L, p, "\tOA:Z:");
+                for (uint32_t k = F.sname_off[sid]; k < F.sname_off[sid + 1]; ++k) afw_c(L, p, F.snames[k]);
+                afw_c(L, p, ','); afw_i(L, p, oa_pos); afw_lit(L, p, strand ? ",-," : ",+,");
+                afw_cigar(L, p, L.cig, n_cig);
+                afw_c(L, p, ','); afw_i(L, p, mapq); afw_c(L, p, ','); afw_i(L, p, lift_nm); afw_c(L, p, ';');
+                afw_lit(L, p, "\tAA:Z:");
+                for (uint32_t k = 0; k < PL.n_alt; ++k) {
+                    const uint64_t ap = PL.alt_pos[k];
+                    const uint32_t s2 = ac_seq_of(A.P, ap);
+                    for (uint32_t x = F.sname_off[s2]; x < F.sname_off[s2 + 1]; ++x) afw_c(L, p, F.snames[x]);
+                    afw_c(L, p, ','); afw_i(L, p, (int)(ap - A.P.lift_seqs[s2].start + 1)); afw_c(L, p, ','); afw_i(L, p, PL.alt_score[k]); afw_c(L, p, ';');
+                }
+                afw_c(L, p, '\n');
+            }
+            p = (uint32_t)__shfl((int)p, 0);
+            if (too_long) p = AK_TXT_CAP + 1;
+        }
+        __syncthreads();
+        // ---- out: the text pool (8-byte words, bump-allocated), coalesced; the record ----
+        if (p > AK_TXT_CAP) rec.status = 2;           // does not fit the staging: the host pipeline redoes the read
+        else {
+            const unsigned long long words = (unsigned long long)((p + 7) >> 3);
+            unsigned long long to = 0;
+            if (lane == 0) to = atomicAdd(&A.cursors[15], words);
+            to = ((unsigned long long)(uint32_t)__shfl((int)(to >> 32), 0) << 32) | (uint32_t)__shfl((int)(to & 0xFFFFFFFFull), 0);
+            if (to + words > F.txt_cap) rec.status = 2;
+            else {
+                const uint64_t* src = reinterpret_cast<const uint64_t*>(L.line);
+                for (unsigned long long k = lane; k < words; k += 64) F.txt_pool[to + k] = src[k];
+                rec.txt_len = p; rec.txt_off = to;
+            }
+        }
+        if (lane == 0) A.recs[r_in] = rec;
     }
 }

@@ -42,6 +42,7 @@ struct dp_launch_t {
     const uint8_t* reads;         // resident read batch (DP_Q_READS)
     const uint8_t* text;          // index text (DP_T_TEXT)
     uint64_t n_text;
+    uint64_t reads_limit, text_limit;   // bytes of the two buffers that may be read as aligned 8-byte words (their padding included)
 };
 
 __device__ __forceinline__ uint32_t dp_nt4(uint32_t b) {      // seq_nt4_table, aligner_ksw2.hpp:3272-3288

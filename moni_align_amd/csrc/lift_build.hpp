@@ -11,6 +11,7 @@
 struct LiftTables {
     std::vector<moni_lift_seq_t> seqs;     // one per sequence
     std::vector<moni_lift_run_t> runs;
+    std::vector<uint64_t> pdir;            // position directory (lift_core.h), (n_text >> MONI_PDIR_SHIFT) + 2 entries
     bool all_null = true;                  // every lift is a null lift onto its own sequence (FASTA-built index)
 
     // Returns MONI_OK or MONI_ERANGE / MONI_EINVAL with err set.
@@ -23,6 +24,7 @@ struct LiftTables {
             moni_lift_seq_t S;
             S.second = given ? f.lift_second[i] : f.seq_starts[i];       // liftidx.hpp:150-157 null lift: lift(pos) = pos over text coordinates
             S.run_off = (uint32_t)runs.size();
+            S.start = f.seq_starts[i]; S.end = f.seq_starts[i + 1];
             const uint64_t len = given ? f.lift_len[i] : seq_len;
             const uint64_t* ins = given && f.lift_ins ? f.lift_ins + f.lift_ins_off[i] : nullptr;
             const uint64_t* del = given && f.lift_del ? f.lift_del + f.lift_del_off[i] : nullptr;
@@ -58,6 +60,21 @@ struct LiftTables {
             seqs.push_back(S);
         }
         if (runs.size() >= (1ull << 32)) { err = "too many lift runs"; return MONI_ERANGE; }
+        // position directory
+        const uint64_t n_text = f.n ? f.n - 1 : f.seq_starts[f.n_seq];
+        const uint64_t nb = (n_text >> MONI_PDIR_SHIFT) + 2;
+        pdir.assign(nb, 0);
+        uint64_t sid = 0; uint32_t k = seqs.empty() ? 0 : seqs[0].run_off;
+        for (uint64_t b = 0; b < nb; ++b) {
+            const uint64_t pos = b << MONI_PDIR_SHIFT;
+            bool moved = false;
+            while (sid + 1 < f.n_seq && pos >= f.seq_starts[sid + 1]) { ++sid; moved = true; }
+            if (moved) k = seqs[sid].run_off;
+            const uint64_t st = pos >= f.seq_starts[sid] ? pos - f.seq_starts[sid] : 0;
+            const uint32_t last = seqs[sid].run_off + seqs[sid].n_runs;
+            while (k + 1 < last && (uint64_t)runs[k + 1].hap <= st) ++k;
+            pdir[b] = (uint64_t)sid | ((uint64_t)k << 32);
+        }
         return MONI_OK;
     }
 };

@@ -24,7 +24,13 @@ struct moni_lift_run_t { uint32_t col, hap, ref, flags; };      // first column 
 struct moni_lift_seq_t {
     uint64_t second;          // liftidx::lifts[i].second: where the target contig starts in the concatenation
     uint32_t run_off, n_runs; // runs[run_off .. run_off + n_runs); the last one is a sentinel at column = number of columns
-};                            // (flags 0: positions past the end continue as matches; the reference reads past its bit-vectors there)
+                              // (flags 0: positions past the end continue as matches; the reference reads past its bit-vectors there)
+    uint64_t start, end;      // the sequence's onset in the text and the next sequence's (seqidx::starts)
+};
+// Position directory: for every 2^shift-th text position the sequence it lies in (low 32 bits) and the lift run that holds its
+// haplotype position (high 32 bits, index into the run array): seqidx::index and liftidx::lift of any position cost one directory
+// entry, one moni_lift_seq_t and one or two runs instead of two binary searches of dependent loads.
+#define MONI_PDIR_SHIFT 12
 
 // the run that holds haplotype position p (a run without the del flag), and the column of p
 LIFT_HD uint32_t lift_find(const moni_lift_run_t* __restrict runs, uint32_t n_runs, uint64_t p, uint64_t& x) {

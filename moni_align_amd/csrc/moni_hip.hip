@@ -44,6 +44,7 @@ struct moni_index {
     uint32_t* d_name_id = nullptr;
     uint8_t* d_snames = nullptr; uint32_t* d_sname_off = nullptr;      // sequence names, ragged (SAM text in align_kernel)
     moni_lift_seq_t* d_lift_seqs = nullptr; moni_lift_run_t* d_lift_runs = nullptr;   // liftidx::lifts (lift_core.h)
+    uint64_t* d_pdir = nullptr;
     bool lifts_null = true;
     uint64_t bytes = 0;
     // host copies for the host stages of the full path (chaining, MD/NM, SAM)
@@ -134,7 +135,8 @@ struct moni_ctx {
     DBuf<uint8_t> ak_rnames, ak_quals; DBuf<uint64_t> ak_rname_off, ak_txt; DBuf<double> ak_mapq_tab;      // SAM text in the kernel
     HBuf<uint64_t> h_txt;                                 // pinned staging of one sub-batch's text
     uint64_t ak_waves_full = 0;
-    hipStream_t ak_stream[2] = {nullptr, nullptr}, copy_stream = nullptr;
+    hipStream_t ak_stream[2] = {nullptr, nullptr}, copy_stream = nullptr, fb_stream[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ak_fin;                // staged kernels of a sub-batch queued; the handed-over reads follow on fb_stream
     std::vector<hipEvent_t> ak_begin, ak_done;
     HBuf<moni_aln_rec_t> h_recs; HBuf<uint32_t> h_cig; HBuf<moni_alt_t> h_alt; HBuf<uint64_t> h_md;      // pinned staging of one sub-batch's records
     std::vector<mh::Aligner::OutBuf> pieces;          // per host thread: the text it is writing (kept across batches)
@@ -216,7 +218,7 @@ int moni_index_create(const moni_flat_index_t* f, int device, moni_index_t** out
     I->hix.n_text = f->n - 1; I->hix.w = f->w; I->hix.text = I->h_text.data();
     I->hix.seq_starts.assign(f->seq_starts, f->seq_starts + f->n_seq + 1);
     I->hix.lift_seqs = lt.seqs; I->hix.lift_runs = lt.runs;
-    if ((rc = upload(&I->d_lift_seqs, lt.seqs, I->bytes)) || (rc = upload(&I->d_lift_runs, lt.runs, I->bytes)) || (rc = upload(&I->d_tables, tv, I->bytes)) || (rc = upload(&I->d_rows, img.rows, I->bytes)) || (rc = upload(&I->d_frows, img.frows, I->bytes)) ||
+    if ((rc = upload(&I->d_pdir, lt.pdir, I->bytes)) || (rc = upload(&I->d_lift_seqs, lt.seqs, I->bytes)) || (rc = upload(&I->d_lift_runs, lt.runs, I->bytes)) || (rc = upload(&I->d_tables, tv, I->bytes)) || (rc = upload(&I->d_rows, img.rows, I->bytes)) || (rc = upload(&I->d_frows, img.frows, I->bytes)) ||
         (rc = upload(&I->d_cr, img.cr, I->bytes)) || (rc = upload(&I->d_recs, img.recs, I->bytes)) ||
         (rc = upload(&I->d_phi, img.phi, I->bytes)) || (rc = upload(&I->d_phi_inv, img.phi_inv, I->bytes)) ||
         (rc = upload(&I->d_phi_dir, img.phi_dir, I->bytes)) || (rc = upload(&I->d_phi_inv_dir, img.phi_inv_dir, I->bytes)) ||
@@ -304,7 +306,7 @@ int moni_index_load(const char* path, int device, moni_index_t** out) {
 void moni_index_destroy(moni_index_t* I) {
     if (!I) return;
     (void)hipSetDevice(I->device);
-    void* ps[] = {I->d_tables, I->d_rows, I->d_frows, I->d_cr, I->d_recs, I->d_phi, I->d_phi_inv, I->d_phi_dir, I->d_phi_inv_dir, I->d_text, I->d_seq_starts, I->d_name_id, I->d_snames, I->d_sname_off, I->d_lift_seqs, I->d_lift_runs};
+    void* ps[] = {I->d_tables, I->d_rows, I->d_frows, I->d_cr, I->d_recs, I->d_phi, I->d_phi_inv, I->d_phi_dir, I->d_phi_inv_dir, I->d_text, I->d_seq_starts, I->d_name_id, I->d_snames, I->d_sname_off, I->d_lift_seqs, I->d_lift_runs, I->d_pdir};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete I;
 }
@@ -341,6 +343,8 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->dp_off.release(); c->dp_ws.release(); c->dp_big.release(); c->dp_dir_big.release(); c->ak_slots.release(); c->ak_waves.release(); c->ak_cursors.release(); c->ak_rnames.release(); c->ak_quals.release(); c->ak_rname_off.release(); c->ak_txt.release(); c->ak_mapq_tab.release(); c->h_txt.release(); c->h_recs.release(); c->h_cig.release(); c->h_alt.release(); c->h_md.release();
     for (auto& ob : c->pieces) ob.release();
     if (c->ak_stream[1]) (void)hipStreamDestroy(c->ak_stream[1]);
+    for (int x = 0; x < 2; ++x) if (c->fb_stream[x]) (void)hipStreamDestroy(c->fb_stream[x]);
+    for (auto e : c->ak_fin) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto e : c->ak_begin) (void)hipEventDestroy(e);
     for (auto e : c->ak_done) (void)hipEventDestroy(e);
@@ -821,8 +825,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         const uint32_t af_task_cap = (uint32_t)std::min<uint64_t>(12 * sub_reads + 4096, (1ull << 26) - 1), af_tb_cap = (uint32_t)std::min<uint64_t>(4 * sub_reads + 1024, 0x7FFFFFFFull);
         const uint32_t af_chunk_cap = af_task_cap / 64 + 2 * AF_NBIN;
         const uint64_t af_dirs_cap = 65536ull * sub_reads + (16ull << 20);
-        const unsigned af_dp_grid = (unsigned)n_cu * 8;
-        const unsigned af_fin_grid = (unsigned)std::min<uint64_t>((sub_reads + 63) / 64, (uint64_t)n_cu * 8);
+        const unsigned af_dp_grid = (unsigned)n_cu * 12;
+        const unsigned af_fin_grid = (unsigned)std::min<uint64_t>((sub_reads + 63) / 64, (uint64_t)n_cu * 16);
         if (use_fast) for (int x = 0; x < (n_sub > 1 ? 2 : 1); ++x) {
             moni_ctx::AfSet& S = c->af[x];
             if ((rc = S.plans.ensure(sub_reads + 1)) || (rc = S.tasks.ensure(af_task_cap)) || (rc = S.res.ensure(af_task_cap)) || (rc = S.bin_q.ensure((size_t)AF_NBIN * af_task_cap)) ||
@@ -835,7 +839,9 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         c->ak_stream[0] = c->stream;
         if (!c->ak_stream[1]) HIPCHK(hipStreamCreateWithFlags(&c->ak_stream[1], hipStreamNonBlocking));
         if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        while (c->ak_done.size() < n_sub) { hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); c->ak_begin.push_back(e0); c->ak_done.push_back(e1); }
+        while (c->ak_done.size() < n_sub) { hipEvent_t e0, e1, e2; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+                                            c->ak_begin.push_back(e0); c->ak_done.push_back(e1); c->ak_fin.push_back(e2); }
+        for (int x = 0; x < 2; ++x) if (use_fast && !c->fb_stream[x]) HIPCHK(hipStreamCreateWithFlags(&c->fb_stream[x], hipStreamNonBlocking));
         HIPCHK(hipMemsetAsync(c->ak_cursors.p, 0, (AK_CUR * n_sub + AK_CUR) * sizeof(unsigned long long), c->stream));
         HIPCHK(hipMemcpyAsync(c->ak_minscore.p, msc.data(), msc.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -855,9 +861,10 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             A.P.max_dist_x = prm->max_dist_x; A.P.max_dist_y = prm->max_dist_y; A.P.max_iter = prm->max_iter; A.P.max_pred = prm->max_pred;
             A.P.min_chain_score = prm->min_chain_score; A.P.min_chain_length = prm->min_chain_length;
             A.P.n_text = I->K.n_text; A.P.n_seq = I->K.n_seq; A.P.seq_starts = I->d_seq_starts;
-            A.P.lift_seqs = I->d_lift_seqs; A.P.lift_runs = I->d_lift_runs;
+            A.P.lift_seqs = I->d_lift_seqs; A.P.lift_runs = I->d_lift_runs; A.P.pdir = I->d_pdir;
             A.D.sc_mch = prm->smatch; A.D.sc_mis = -prm->smismatch; A.D.sc_N = -prm->gape; A.D.wild = 4; A.D.qo = prm->gapo; A.D.e = prm->gape;
             A.D.end_bonus = prm->end_bonus; A.D.reads = c->seq.p; A.D.text = I->d_text; A.D.n_text = I->K.n_text;
+            A.D.reads_limit = (c->total_len + 8) & ~7ull; A.D.text_limit = (I->K.n_text + 8) & ~7ull;       // both buffers carry 16 bytes of padding
             A.mems = c->mems.p; A.occs = c->occs.p; A.read_mem_off = c->read_mem_off.p; A.offs = c->offs.p;
             A.min_score_of_len = c->ak_minscore.p; A.max_len = (uint32_t)c->max_len + 1; A.read_lo = r0; A.n_reads = nr;
             A.slots = c->ak_slots.p + (k & 1) * ak_waves * AK_NL; A.waves = c->ak_waves.p + (k & 1) * ak_waves;
@@ -870,7 +877,9 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 A.fmt.txt_pool = c->ak_txt.p + k * txt_per; A.fmt.txt_cap = txt_per;
             }
             hipStream_t sx = c->ak_stream[k & 1];
+            if (use_fast && k >= 2) HIPCHK(hipStreamWaitEvent(sx, c->ak_done[k - 2], 0));      // the set's buffers are free once its previous sub-batch is through align_kernel too
             HIPCHK(hipEventRecord(c->ak_begin[k], sx));
+            bool done_recorded = false;
             if (use_fast && nr > 0) {
                 moni_ctx::AfSet& S = c->af[k & 1];
                 af_args_t G;
@@ -884,26 +893,35 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 if ((rc = S.prof.ensure(32))) return rc;
                 if (k < 2) HIPCHK(hipMemsetAsync(S.prof.p, 0, 32 * 8, sx));
                 G.prof = S.prof.p;
+                if (const char* v = getenv("MONI_AF_DBG")) G.dbg = (uint32_t)atoi(v);
 #endif
                 static_assert(AF_NCTR == 64, "the counters of a sub-batch are fetched as 64 words");
                 HIPCHK(hipMemsetAsync(S.ctr.p, 0, AF_NCTR * sizeof(uint32_t), sx));
                 hipLaunchKernelGGL(chain_plan_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 10)), dim3(64), 0, sx, G);
                 hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_SMALL);
-                hipLaunchKernelGGL((dp_lane_kernel<AF_TB, AF_QCAP, 1>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE);
+                hipLaunchKernelGGL((dp_lane_kernel<AF_BLK, AF_QCAP, AF_LPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE);
                 hipLaunchKernelGGL((dp_lane_kernel<AF_TS, AF_TS, 1>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_SMALL);
                 hipLaunchKernelGGL(global_task_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
                 hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL, (uint32_t)AF_GRP_GLOBAL);
-                hipLaunchKernelGGL((dp_lane_kernel<AF_TB, AF_QCAP, AF_GPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL);
+                hipLaunchKernelGGL((dp_lane_kernel<AF_GBLK, AF_QCAP, AF_GPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL);
                 hipLaunchKernelGGL(select_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
                 hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)((af_tb_cap + 255) / 256)), dim3(256), 0, sx, G);
-                hipLaunchKernelGGL(finish_kernel, dim3((unsigned)std::min<uint64_t>((nr + 63) / 64, af_fin_grid)), dim3(64), 0, sx, G);
-                A.read_list = S.fb_list.p; A.n_reads_dev = S.ctr.p + AFC_FALLBACK;       // the reads the staged kernels handed over
-                hipLaunchKernelGGL(align_kernel, dim3((unsigned)ak_waves), dim3(64), 0, sx, A);
-                HIPCHK(hipMemcpyAsync(c->af_ctr_host.p + 64 * k, S.ctr.p, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, sx));
+                // the record and the SAM line of every read that stayed on the staged path: one wave per read when the kernel spells the text
+                if (gpu_text) hipLaunchKernelGGL(finish_wave_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 20)), dim3(64), 0, sx, G);
+                else hipLaunchKernelGGL(finish_kernel, dim3((unsigned)std::min<uint64_t>((nr + 63) / 64, af_fin_grid)), dim3(64), 0, sx, G);
+                // the reads the staged kernels handed over: few, but each a long serial job; they run beside the next sub-batch's kernels
+                A.read_list = S.fb_list.p; A.n_reads_dev = S.ctr.p + AFC_FALLBACK;
+                hipStream_t sf = c->fb_stream[k & 1];
+                HIPCHK(hipEventRecord(c->ak_fin[k], sx));
+                HIPCHK(hipStreamWaitEvent(sf, c->ak_fin[k], 0));
+                hipLaunchKernelGGL(align_kernel, dim3((unsigned)ak_waves), dim3(64), 0, sf, A);
+                HIPCHK(hipMemcpyAsync(c->af_ctr_host.p + 64 * k, S.ctr.p, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, sf));
+                HIPCHK(hipEventRecord(c->ak_done[k], sf));
+                done_recorded = true;
             } else if (nr > 0) {
                 hipLaunchKernelGGL(align_kernel, dim3((unsigned)n_waves), dim3(64), 0, sx, A);
             }
-            HIPCHK(hipEventRecord(c->ak_done[k], sx));
+            if (!done_recorded) HIPCHK(hipEventRecord(c->ak_done[k], sx));
             HIPCHK(hipGetLastError());
         }
         t_launch[1] = mh::now_s() - t_enter;
@@ -992,7 +1010,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             if (k + 1 == n_sub) { t_mark[1] = mh::now_s() - t_enter; st.t_dp += mh::now_s() - t_gpu0; }
             host_stage(k, R);
         }
-        if (rc_host) { for (int x = 0; x < 2; ++x) (void)hipStreamSynchronize(c->ak_stream[x]); drop_abuf(); return rc_host; }
+        if (rc_host) { for (int x = 0; x < 2; ++x) { (void)hipStreamSynchronize(c->ak_stream[x]); if (c->fb_stream[x]) (void)hipStreamSynchronize(c->fb_stream[x]); } drop_abuf(); return rc_host; }
         t_mark[2] = mh::now_s() - t_enter;
         st.dp_rounds = n_sub;          // align_kernel launches
         if (n_sub) {        // statistics of all launches, once the GPU is idle

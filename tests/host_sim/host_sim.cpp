@@ -27,6 +27,7 @@ struct Sim {
     uint64_t counters[4];
     uint64_t max_len = 0, n_reads = 0;
     mh::HostIndex hix;
+    std::vector<uint64_t> pdir;
 };
 
 extern "C" {
@@ -50,7 +51,7 @@ void* sim_create(const moni_flat_index_t* f) {
     const char* p = f->seq_names;
     for (uint64_t i = 0; i < f->n_seq; ++i) { std::string nm = p ? std::string(p) : ("seq" + std::to_string(i)); if (p) p += nm.size() + 1; S->hix.names.push_back(nm); }
     { LiftTables LT; std::string err; if (LT.build(*f, err)) { fprintf(stderr, "host_sim: %s\n", err.c_str()); delete S; return nullptr; }
-      S->hix.lift_seqs = LT.seqs; S->hix.lift_runs = LT.runs; }
+      S->hix.lift_seqs = LT.seqs; S->hix.lift_runs = LT.runs; S->pdir = LT.pdir; }
     return S;
 }
 void sim_destroy(void* s) { delete (Sim*)s; }
@@ -218,7 +219,7 @@ char* sim_align_core_batch(void* s, const uint8_t* seq, const uint64_t* offs, ui
     AP.gape2 = P.gape2; AP.max_dist_x = P.max_dist_x; AP.max_dist_y = P.max_dist_y; AP.max_iter = P.max_iter; AP.max_pred = P.max_pred;
     AP.min_chain_score = P.min_chain_score; AP.min_chain_length = P.min_chain_length; AP.n_text = S->hix.n_text; AP.n_seq = (uint32_t)S->hix.names.size();
     AP.seq_starts = S->hix.seq_starts.data();
-    AP.lift_seqs = S->hix.lift_seqs.data(); AP.lift_runs = S->hix.lift_runs.data();
+    AP.lift_seqs = S->hix.lift_seqs.data(); AP.lift_runs = S->hix.lift_runs.data(); AP.pdir = S->pdir.data();
     moni_dp_params_t dp;
     memset(&dp, 0, sizeof dp);
     dp.m = 5;

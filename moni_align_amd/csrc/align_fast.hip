@@ -47,6 +47,7 @@
 #define AF_TB_CIG 24             // CIGAR operations kept per traced problem
 #define AF_FIN_CIG 96            // ... of a stitched alignment
 #define AF_FIN_LCIG 160          // ... after lifting
+#define AF_TXT_SHARDS 32
 #define AF_NEG_INF (-0x40000000)
 
 enum { AF_GAP_NONE = 0, AF_GAP_INS, AF_GAP_DEL0, AF_GAP_TASK, AF_GAP_1X1 };
@@ -98,6 +99,9 @@ struct af_args_t {
     uint8_t* dirs; uint64_t dirs_cap;
     uint32_t* tb_task; af_tb_t* tb; uint32_t tb_cap;      // problems to trace
     uint32_t* fb_list;                       // reads handed to align_kernel
+    uint32_t* big_list;                      // reads (indices in the launch) that need the large instance of chain_plan_kernel
+    unsigned long long* txt_cur;             // AF_TXT_SHARDS cursors (one per 64 bytes) of the text pool's shard regions: a device-scope atomic on ONE address
+    uint64_t txt_shard_words;                // sustains only ~50 M/s; region s + 1 of the pool (txt_shard_words each) belongs to shard s, region 0 to cursors[15]
     uint8_t* fin_scratch; uint64_t fin_stride;            // per finish lane: stitched CIGAR, lifted CIGAR, MD and text staging
     uint64_t* bnd;                           // per resident DP wave: (H, E) of a target block's last row for every query position (global problems)
     uint32_t* ctr;                           // AF_NCTR counters, see the AFC_* indices
@@ -112,7 +116,7 @@ struct af_args_t {
 #define AF_PROF(G, slot, t0, t1) do {} while (0)
 #endif
 enum { AFC_TASKS = 0, AFC_FALLBACK = 1, AFC_TRACED = 2, AFC_READ_CUR = 3, AFC_DIRS_OVF = 4, AFC_CELLS = 6 /* 64 bit */, AFC_DIROFF = 8 /* 64 bit */,
-       AFC_NCHUNKS = 10 /* + group */, AFC_CURSOR = 13 /* + group */, AFC_BINS = 16 /* + bin */, AFC_WHY = 52 /* + reason */, AF_NCTR = 64 };
+       AFC_NCHUNKS = 10 /* + group */, AFC_CURSOR = 13 /* + group */, AFC_BINS = 16 /* + bin */, AFC_BIG = 49, AFC_BIG_CUR = 50, AFC_WHY = 52 /* + reason */, AF_NCTR = 64 };
 enum { AF_GRP_LARGE = 0, AF_GRP_SMALL = 1, AF_GRP_GLOBAL = 2 };
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -122,25 +126,38 @@ struct af_mem_t { uint64_t occ_off; uint32_t nocc; uint16_t len, idx, rpos; uint
 struct af_chain_t { int32_t score; uint16_t off, cnt; uint32_t mate; };
 struct af_start_t { int32_t f, j; };
 struct af_left_t { uint64_t ref; int64_t score; };
-struct af_wave_t {
-    lsort::frame stack[24];
-    af_mem_t mem[AF_MAX_MEMS];
-    uint64_t anch[AF_MAX_ANCH];          // x (reference end, 40 bits) | mem << 40
-    int32_t f[AF_MAX_ANCH], msc[AF_MAX_ANCH];
-    int16_t p[AF_MAX_ANCH], t[AF_MAX_ANCH];
-    af_start_t starts[AF_MAX_CHAINS];
-    af_chain_t chains[AF_MAX_CHAINS];
-    uint16_t pool[AF_MAX_ANCH + AF_MAX_CHAINS];
-    af_left_t left[AF_MAX_CHAINS];
-    uint16_t run_start[AF_MAX_ANCH + 1];
-    uint16_t s_off[AF_MAX_CHAINS], s_cnt[AF_MAX_CHAINS];       // per sorted start: where its chain's anchors are in the pool, how many (0: chain dropped)
-    uint64_t left_ref[AF_MAX_CHAINS];    // check_left_MEM's lifted coordinate of every chain (lanes in parallel: each lift is a chain of dependent loads)
+#define AF_MAX_TASKS_READ 32       // DP tasks of one read (beyond: align_kernel)
+// LDS of one read.  MA / MC / MM: capacities for anchors, chains, seeds.  Two instances are launched: a small one that most reads
+// fit (more reads in flight per CU: the kernel is bound by the latency of its serial parts), and a large one for the reads that
+// overflow it.  Arrays that are dead by the time the plan is written share their space with it.
+template <int MA_, int MC_, int MM_>
+struct af_wave_tt {
+    static constexpr int MA = MA_, MC = MC_, MM = MM_;
+    af_mem_t mem[MM_];
+    uint64_t anch[MA_];                  // x (reference end, 40 bits) | mem << 40
+    af_chain_t chains[MC_];
+    uint16_t pool[MA_ + MC_];
+    uint64_t left_ref[MC_];              // check_left_MEM's lifted coordinate of every chain (lanes in parallel: each lift is a chain of dependent loads)
+    uint8_t left_idx[MC_];               // the chains check_left_MEM has recorded
     int64_t diff[8];
-    uint32_t n_chains_sh, status_sh;
-    af_plan_t plan;
-    moni_dp_task_t tasks[AF_MAX_CAND * (AF_MAX_AN + 1)];
-    uint32_t n_tasks;
+    uint32_t n_chains_sh, status_sh, n_tasks;
+    union {
+        struct {                         // chaining
+            lsort::frame stack[24];
+            int32_t f[MA_], msc[MA_];
+            int16_t p[MA_], t[MA_];
+            af_start_t starts[MC_];
+            uint16_t run_start[MA_ + 1];
+            uint16_t s_off[MC_], s_cnt[MC_];       // per sorted start: where its chain's anchors are in the pool, how many (0: chain dropped)
+        };
+        struct {                         // the plan and its tasks
+            af_plan_t plan;
+            moni_dp_task_t tasks[AF_MAX_TASKS_READ];
+        };
+    };
 };
+typedef af_wave_tt<AF_MAX_ANCH, AF_MAX_CHAINS, AF_MAX_MEMS> af_wave_t;
+typedef af_wave_tt<96, 48, 24> af_wave_small_t;
 
 // why a read left the staged path (counted in ctr[AFC_WHY + reason])
 enum { AF_WHY_LONG = 0, AF_WHY_ANCHORS, AF_WHY_CHAINS, AF_WHY_CANDS, AF_WHY_CHAIN_LEN, AF_WHY_TASK_SIZE, AF_WHY_OVERLAP, AF_WHY_WILDCARD, AF_WHY_LOOP, AF_WHY_REACH_END,
@@ -166,7 +183,8 @@ __device__ __forceinline__ void af_small_sort(T* a, uint32_t n, Less less, int l
 // is a maximal stretch of the sorted anchors whose consecutive reference ends are at most max_dist_x apart, pairs from different
 // runs never pass the distance test of chain.hpp:300 (or are skipped for their mates before it), so runs share nothing but the
 // lower bound `lb`, which only ever excludes anchors that are too far anyway.  Returns the plan status (uniform).
-__device__ __forceinline__ uint32_t af_chain(const af_args_t& G, af_wave_t& L, uint32_t na, float avg_mem_length) {
+template <class WT>
+__device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t na, float avg_mem_length) {
     const ac_params_t& P = G.A.P;
     const int lane = threadIdx.x;
     // ---- std::sort of the anchors by reference end (chain.hpp:246) ----
@@ -241,25 +259,25 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, af_wave_t& L, u
         if (is_end) { uint32_t j = i; while (L.f[j] < L.msc[j]) j = (uint32_t)L.p[j]; st.f = L.f[j]; st.j = (int32_t)j; }
         const unsigned long long bal = __ballot(is_end);
         const uint32_t at = ns + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (is_end && at < AF_MAX_CHAINS) L.starts[at] = st;
+        if (is_end && at < (uint32_t)WT::MC) L.starts[at] = st;
         ns += (uint32_t)__popcll(bal);
     }
-    if (ns > AF_MAX_CHAINS) { uint32_t rc = AF_ST_FALLBACK; if (lane == 0) rc = AF_FALLBACK(G, AF_WHY_CHAINS); return rc; }
+    if (ns > (uint32_t)WT::MC) return 0xFFu;          // does not fit this instance
     if (ns == 0) return AF_ST_UNALIGNED;
     __syncthreads();
     // std::sort(chain_starts, greater<pair>) (chain.hpp:376): elements that compare equal are identical pairs (two chain ends can
     // lead back to the same start), so any sort gives the reference's array: by rank, equal elements in index order
     {
-        af_start_t v[(AF_MAX_CHAINS + 63) / 64]; uint32_t rk[(AF_MAX_CHAINS + 63) / 64];
+        af_start_t v[(WT::MC + 63) / 64]; uint32_t rk[(WT::MC + 63) / 64];
 #pragma unroll
-        for (int q = 0; q < (AF_MAX_CHAINS + 63) / 64; ++q) {
+        for (int q = 0; q < (WT::MC + 63) / 64; ++q) {
             const uint32_t s = (uint32_t)lane + 64u * q;
             rk[q] = 0;
             if (s < ns) { v[q] = L.starts[s]; for (uint32_t k = 0; k < ns; ++k) { const af_start_t w = L.starts[k]; rk[q] += (w.f > v[q].f || (w.f == v[q].f && (w.j > v[q].j || (w.j == v[q].j && k < s)))) ? 1u : 0u; } }
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < (AF_MAX_CHAINS + 63) / 64; ++q) if ((uint32_t)lane + 64u * q < ns) L.starts[rk[q]] = v[q];
+        for (int q = 0; q < (WT::MC + 63) / 64; ++q) if ((uint32_t)lane + 64u * q < ns) L.starts[rk[q]] = v[q];
         __syncthreads();
     }
     // ---- backtracking (chain.hpp:166-200), one lane per run, every lane over the sorted starts of its run in order ----
@@ -310,8 +328,9 @@ __device__ __forceinline__ void af_qseg(uint64_t off, uint32_t m, uint32_t stran
     if (!strand) { q_off = reversed ? off + a + len - 1 : off + a; qmode = reversed ? DP_Q_REV : 0; }
     else { q_off = reversed ? off + (m - (a + len)) : off + (m - 1 - a); qmode = DP_Q_COMP | (reversed ? 0 : DP_Q_REV); }
 }
-__device__ __forceinline__ bool af_add_task(af_wave_t& L, uint64_t q_off, uint64_t qlen, int qmode, uint64_t t_off, uint64_t tlen, int tmode, int flag) {
-    if (qlen == 0 || tlen == 0 || qlen > AF_QCAP || tlen > AF_TB) return false;
+template <class WT>
+__device__ __forceinline__ bool af_add_task(WT& L, uint64_t q_off, uint64_t qlen, int qmode, uint64_t t_off, uint64_t tlen, int tmode, int flag) {
+    if (qlen == 0 || tlen == 0 || qlen > AF_QCAP || tlen > AF_TB || L.n_tasks >= AF_MAX_TASKS_READ) return false;
     moni_dp_task_t t;
     t.q_off = q_off; t.t_off = t_off; t.qlen = (int32_t)qlen; t.tlen = (int32_t)tlen; t.flag = flag; t.reserved = DP_Q_READS | DP_T_TEXT | qmode | tmode;
     L.tasks[L.n_tasks++] = t;
@@ -320,7 +339,8 @@ __device__ __forceinline__ bool af_add_task(af_wave_t& L, uint64_t q_off, uint64
 
 // lane 0, after the lanes have lifted every chain's leftmost anchor: the chain-selection loop ahead of its scores
 // (aligner_ksw2.hpp:409-462): which chains it scores, and their problems
-__device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, af_wave_t& L, uint64_t off, uint32_t m) {
+template <class WT>
+__device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, WT& L, uint64_t off, uint32_t m) {
     const ac_params_t& P = G.A.P;
     const uint32_t n_chains = L.n_chains_sh;
     af_plan_t& PL = L.plan;
@@ -335,11 +355,12 @@ __device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, af_wave_t&
             const uint64_t left_ref = L.left_ref[ci];
             bool seen = false;
             for (uint32_t k = 0; k < n_left; ++k) {
-                const uint64_t d = L.left[k].ref > left_ref ? L.left[k].ref - left_ref : left_ref - L.left[k].ref;
-                if (d < P.region_dist && L.left[k].score == (int64_t)ch.score) seen = true;
+                const uint64_t lr = L.left_ref[L.left_idx[k]];
+                const uint64_t d = lr > left_ref ? lr - left_ref : left_ref - lr;
+                if (d < P.region_dist && L.chains[L.left_idx[k]].score == ch.score) seen = true;
             }
             if (seen) continue;
-            L.left[n_left].ref = left_ref; L.left[n_left].score = ch.score; ++n_left;      // n_left <= n_chains <= AF_MAX_CHAINS
+            L.left_idx[n_left++] = (uint8_t)ci;                                         // n_left <= n_chains <= 255
         }
         if (n_diff >= P.check_k) continue;                       // not scored; the loop condition ends the loop
         // ---- fill_chain, part 1 (aligner_ksw2.hpp:2782-2979): the problems of this chain ----
@@ -424,25 +445,34 @@ __device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, af_wave_t&
     return AF_ST_CAND;
 }
 
-__global__ void __launch_bounds__(64) chain_plan_kernel(const af_args_t G) {
-    __shared__ af_wave_t L;                   // one wavefront per workgroup: __syncthreads() orders the wave's own LDS traffic
+// WT: the LDS instance (capacities).  BIG = false: every read of the launch, reads that overflow the small instance go to big_list;
+// BIG = true: the reads of big_list, reads that overflow go to align_kernel.
+template <class WT, bool BIG, int OCC = (BIG ? 3 : 6)>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) chain_plan_kernel(const af_args_t G) {
+    __shared__ WT L;                          // one wavefront per workgroup: __syncthreads() orders the wave's own LDS traffic
     const int lane = threadIdx.x;
     const ak_args_t& A = G.A;
+    const uint32_t n_work = BIG ? G.ctr[AFC_BIG] : (uint32_t)A.n_reads;
+    constexpr uint32_t GRAB = BIG ? 1u : 8u;          // reads taken per visit to the shared cursor
+    uint32_t w_next = 0, w_end = 0;
     while (true) {
-        uint32_t r_in = 0;
-        if (lane == 0) r_in = atomicAdd(&G.ctr[AFC_READ_CUR], 1u);
-        r_in = (uint32_t)__shfl((int)r_in, 0);
-        if (r_in >= A.n_reads) break;
+        if (w_next >= w_end) {
+            if (lane == 0) w_next = atomicAdd(&G.ctr[BIG ? AFC_BIG_CUR : AFC_READ_CUR], GRAB);
+            w_next = (uint32_t)__shfl((int)w_next, 0);
+            w_end = w_next + GRAB;
+        }
+        const uint32_t w_in = w_next++;
+        if (w_in >= n_work) break;
+        const uint32_t r_in = BIG ? G.big_list[w_in] : w_in;
         AF_STAMP(c0);
         const uint64_t r = A.read_lo + r_in;
         const uint64_t off = A.offs[r];
         const uint32_t m = (uint32_t)(A.offs[r + 1] - off);
         const uint64_t a = A.read_mem_off[r], b = A.read_mem_off[r + 1];
         uint32_t status = AF_ST_UNALIGNED;
-        af_plan_t& PL = L.plan;
-        if (lane == 0) { PL.status = 0; PL.n_cand = 0; PL.n_chains = 0; PL.final_cand = 0; PL.n_alt = 0; PL.pad = 0; PL.score2 = 0; PL.ref_pos = PL.ref_len = 0; PL.tb0 = 0; PL.pad2 = 0;
-                         PL.min_score = A.min_score_of_len[m <= A.max_len ? m : A.max_len]; L.n_tasks = 0; }
-        bool fallback = m >= AF_MAX_READ || (b - a) > 4 * AF_MAX_MEMS;
+        if (lane == 0) L.n_tasks = 0;
+        bool fallback = m >= AF_MAX_READ || (b - a) > 4 * AF_MAX_MEMS;      // not for any instance
+        bool too_big = false;                                              // not for this instance
         uint32_t n_mems = 0, na = 0;
         float avg = 0.f;
         if (!fallback && b > a) {
@@ -462,7 +492,7 @@ __global__ void __launch_bounds__(64) chain_plan_kernel(const af_args_t G) {
                 }
                 const unsigned long long bal = __ballot(keep);
                 const uint32_t at = n_mems + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                if (keep && at < AF_MAX_MEMS) {
+                if (keep && at < (uint32_t)WT::MM) {
                     af_mem_t x; x.occ_off = g.occ_off; x.nocc = g.occ_cnt; x.len = (uint16_t)g.len; x.idx = (uint16_t)g.idx; x.rpos = (uint16_t)g.rpos; x.mate = (uint8_t)g.mate; x.pad = 0;
                     L.mem[at] = x;
                 }
@@ -470,9 +500,9 @@ __global__ void __launch_bounds__(64) chain_plan_kernel(const af_args_t G) {
                 n_mems += (uint32_t)__popcll(bal);
             }
             for (int o = 32; o > 0; o >>= 1) { tot_len += __shfl_xor(tot_len, o); n_anch += __shfl_xor(n_anch, o); }
-            if (n_mems > AF_MAX_MEMS || n_anch > AF_MAX_ANCH) fallback = true;
+            if (n_mems > (uint32_t)WT::MM || n_anch > (unsigned long long)WT::MA) too_big = true;
             na = (uint32_t)n_anch;
-            if (!fallback && na > 0) {
+            if (!too_big && na > 0) {
                 avg = (float)(size_t)tot_len / (size_t)n_anch;
                 __syncthreads();
                 // ---- populate_anchors (chain.hpp:83-95): mem by mem, occurrence by occurrence ----
@@ -487,13 +517,13 @@ __global__ void __launch_bounds__(64) chain_plan_kernel(const af_args_t G) {
         }
         __syncthreads();
         AF_STAMP(c1); AF_PROF(G, 0, c0, c1);
-        if (fallback) { status = AF_ST_FALLBACK; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + (m >= AF_MAX_READ ? AF_WHY_LONG : AF_WHY_ANCHORS)], 1u); }
-        else if (na > 0) {
+        if (!fallback && !too_big && na > 0) {
             status = af_chain(G, L, na, avg);
             status = (uint32_t)__shfl((int)status, 0);
             __syncthreads();
             AF_STAMP(c2); AF_PROF(G, 1, c1, c2);
-            if (status == AF_ST_CAND) {
+            if (status == 0xFFu) too_big = true;
+            else if (status == AF_ST_CAND) {
                 // check_left_MEM's coordinate of every chain: index(lift(leftmost anchor)).second + 1 (aligner_ksw2.hpp:565-576)
                 for (uint32_t ci = lane; ci < L.n_chains_sh; ci += 64) {
                     const af_chain_t ch = L.chains[ci];
@@ -510,7 +540,13 @@ __global__ void __launch_bounds__(64) chain_plan_kernel(const af_args_t G) {
             }
         }
         __syncthreads();
+        if (too_big) {
+            if (!BIG) { if (lane == 0) G.big_list[atomicAdd(&G.ctr[AFC_BIG], 1u)] = r_in; continue; }      // the large instance takes it
+            fallback = true;
+        }
+        if (fallback) { status = AF_ST_FALLBACK; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + (m >= AF_MAX_READ ? AF_WHY_LONG : AF_WHY_ANCHORS)], 1u); }
         // ---- the read's tasks go to the batch's list and the bins of their tile / query length; the plan goes to HBM ----
+        af_plan_t& PL = L.plan;
         const uint32_t nt = status == AF_ST_CAND ? L.n_tasks : 0u;
         uint32_t t0 = 0;
         if (lane == 0 && nt) t0 = atomicAdd(&G.ctr[AFC_TASKS], nt);
@@ -528,7 +564,9 @@ __global__ void __launch_bounds__(64) chain_plan_kernel(const af_args_t G) {
             if ((uint32_t)lane < PL.n_cand) PL.cand[lane].task0 += t0;
         }
         if (lane == 0) {
-            PL.status = (uint8_t)status;
+            if (status != AF_ST_CAND) { PL.n_cand = 0; PL.n_chains = 0; }
+            PL.status = (uint8_t)status; PL.final_cand = 0; PL.n_alt = 0; PL.pad = 0; PL.score2 = 0; PL.ref_pos = PL.ref_len = 0; PL.tb0 = 0; PL.pad2 = 0;
+            PL.min_score = A.min_score_of_len[m <= A.max_len ? m : A.max_len];
             if (status == AF_ST_FALLBACK) G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)r;
         }
         __syncthreads();
@@ -1078,7 +1116,7 @@ __device__ __forceinline__ int afw_md(const af_args_t& G, af_finw_t& L, const ui
     return NM;
 }
 
-__global__ void __launch_bounds__(64) finish_wave_kernel(const af_args_t G) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) finish_wave_kernel(const af_args_t G) {
     __shared__ af_finw_t L;
     const int lane = threadIdx.x;
     const ak_args_t& A = G.A;
@@ -1260,11 +1298,13 @@ __global__ void __launch_bounds__(64) finish_wave_kernel(const af_args_t G) {
         if (p > AK_TXT_CAP) rec.status = 2;           // does not fit the staging: the host pipeline redoes the read
         else {
             const unsigned long long words = (unsigned long long)((p + 7) >> 3);
+            const uint32_t shard = blockIdx.x % AF_TXT_SHARDS;
             unsigned long long to = 0;
-            if (lane == 0) to = atomicAdd(&A.cursors[15], words);
+            if (lane == 0) to = atomicAdd(&G.txt_cur[shard * 8], words);
             to = ((unsigned long long)(uint32_t)__shfl((int)(to >> 32), 0) << 32) | (uint32_t)__shfl((int)(to & 0xFFFFFFFFull), 0);
-            if (to + words > F.txt_cap) rec.status = 2;
+            if (to + words > G.txt_shard_words) rec.status = 2;
             else {
+                to += (unsigned long long)(shard + 1) * G.txt_shard_words;
                 const uint64_t* src = reinterpret_cast<const uint64_t*>(L.line);
                 for (unsigned long long k = lane; k < words; k += 64) F.txt_pool[to + k] = src[k];
                 rec.txt_len = p; rec.txt_off = to;

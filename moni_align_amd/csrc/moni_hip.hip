@@ -122,9 +122,9 @@ struct moni_ctx {
     DBuf<dp_big_t> dp_big;
     DBuf<uint8_t> dp_dir_big;
     struct AfSet {          // device buffers of the staged align kernels (align_fast.hip), one set per launch stream
-        DBuf<af_plan_t> plans; DBuf<moni_dp_task_t> tasks; DBuf<af_res_t> res; DBuf<uint32_t> bin_q, task_pos, tb_task, fb_list, ctr;
-        DBuf<af_chunk_t> chunks; DBuf<uint8_t> dirs, fin; DBuf<af_tb_t> tb; DBuf<uint64_t> bnd; DBuf<unsigned long long> prof;
-        void release() { bnd.release(); prof.release(); plans.release(); tasks.release(); res.release(); bin_q.release(); task_pos.release(); tb_task.release(); fb_list.release(); ctr.release();
+        DBuf<af_plan_t> plans; DBuf<moni_dp_task_t> tasks; DBuf<af_res_t> res; DBuf<uint32_t> bin_q, task_pos, tb_task, fb_list, big_list, ctr;
+        DBuf<af_chunk_t> chunks; DBuf<uint8_t> dirs, fin; DBuf<af_tb_t> tb; DBuf<uint64_t> bnd; DBuf<unsigned long long> prof, txt_cur;
+        void release() { bnd.release(); prof.release(); big_list.release(); txt_cur.release(); plans.release(); tasks.release(); res.release(); bin_q.release(); task_pos.release(); tb_task.release(); fb_list.release(); ctr.release();
                          chunks.release(); dirs.release(); fin.release(); tb.release(); }
     } af[2];
     HBuf<uint32_t> af_ctr_host;             // counters of the last batch's launches (64 words per sub-batch), pinned
@@ -830,8 +830,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         if (use_fast) for (int x = 0; x < (n_sub > 1 ? 2 : 1); ++x) {
             moni_ctx::AfSet& S = c->af[x];
             if ((rc = S.plans.ensure(sub_reads + 1)) || (rc = S.tasks.ensure(af_task_cap)) || (rc = S.res.ensure(af_task_cap)) || (rc = S.bin_q.ensure((size_t)AF_NBIN * af_task_cap)) ||
-                (rc = S.task_pos.ensure(af_task_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.fb_list.ensure(sub_reads + 1)) ||
-                (rc = S.ctr.ensure(AF_NCTR)) || (rc = S.bnd.ensure((size_t)af_dp_grid * AF_QCAP * 64)) || (rc = S.chunks.ensure(af_chunk_cap)) || (rc = S.dirs.ensure(af_dirs_cap)) || (rc = S.fin.ensure((size_t)af_fin_grid * 64 * sizeof(af_fin_t))))
+                (rc = S.task_pos.ensure(af_task_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.fb_list.ensure(sub_reads + 1)) || (rc = S.big_list.ensure(sub_reads + 1)) ||
+                (rc = S.ctr.ensure(AF_NCTR)) || (rc = S.txt_cur.ensure(AF_TXT_SHARDS * 8)) || (rc = S.bnd.ensure((size_t)af_dp_grid * AF_QCAP * 64)) || (rc = S.chunks.ensure(af_chunk_cap)) || (rc = S.dirs.ensure(af_dirs_cap)) || (rc = S.fin.ensure((size_t)af_fin_grid * 64 * sizeof(af_fin_t))))
                 return rc;
         }
         // the launches alternate between the context's stream and one more: HIP multiplexes streams onto a handful of hardware queues
@@ -874,7 +874,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 A.fmt.rnames = c->ak_rnames.p; A.fmt.rname_off = c->ak_rname_off.p; A.fmt.quals = quals ? c->ak_quals.p : nullptr;
                 A.fmt.snames = I->d_snames; A.fmt.sname_off = I->d_sname_off; A.fmt.mapq_tab = c->ak_mapq_tab.p; A.fmt.mapq_tab_n = 8192;
                 A.fmt.min_len = (int32_t)prm->min_len; A.fmt.smatch = prm->smatch; A.fmt.smismatch = prm->smismatch;
-                A.fmt.txt_pool = c->ak_txt.p + k * txt_per; A.fmt.txt_cap = txt_per;
+                A.fmt.txt_pool = c->ak_txt.p + k * txt_per; A.fmt.txt_cap = (use_fast && nr > 0) ? txt_per / (AF_TXT_SHARDS + 1) : txt_per;
             }
             hipStream_t sx = c->ak_stream[k & 1];
             if (use_fast && k >= 2) HIPCHK(hipStreamWaitEvent(sx, c->ak_done[k - 2], 0));      // the set's buffers are free once its previous sub-batch is through align_kernel too
@@ -887,8 +887,10 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 G.A = A;
                 G.plans = S.plans.p; G.tasks = S.tasks.p; G.task_cap = af_task_cap; G.res = S.res.p; G.bin_q = S.bin_q.p; G.bin_cap = af_task_cap; G.task_pos = S.task_pos.p;
                 G.chunks = S.chunks.p; G.chunk_cap = af_chunk_cap; G.dirs = S.dirs.p; G.dirs_cap = af_dirs_cap; G.tb_task = S.tb_task.p; G.tb = S.tb.p; G.tb_cap = af_tb_cap;
-                G.fb_list = S.fb_list.p; G.fin_scratch = S.fin.p; G.fin_stride = sizeof(af_fin_t); G.ctr = S.ctr.p;
+                G.fb_list = S.fb_list.p; G.big_list = S.big_list.p; G.fin_scratch = S.fin.p; G.fin_stride = sizeof(af_fin_t); G.ctr = S.ctr.p;
                 G.bnd = S.bnd.p;
+                G.txt_cur = S.txt_cur.p; G.txt_shard_words = txt_per / (AF_TXT_SHARDS + 1);
+                HIPCHK(hipMemsetAsync(S.txt_cur.p, 0, AF_TXT_SHARDS * 8 * sizeof(unsigned long long), sx));
 #ifdef AF_PROFILE
                 if ((rc = S.prof.ensure(32))) return rc;
                 if (k < 2) HIPCHK(hipMemsetAsync(S.prof.p, 0, 32 * 8, sx));
@@ -897,7 +899,15 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
 #endif
                 static_assert(AF_NCTR == 64, "the counters of a sub-batch are fetched as 64 words");
                 HIPCHK(hipMemsetAsync(S.ctr.p, 0, AF_NCTR * sizeof(uint32_t), sx));
-                hipLaunchKernelGGL(chain_plan_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 10)), dim3(64), 0, sx, G);
+                {
+                    static const int k1occ = getenv("MONI_AF_K1OCC") ? atoi(getenv("MONI_AF_K1OCC")) : 6;
+                    const dim3 g1((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 4 * k1occ));
+                    if (k1occ == 4) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 4>), g1, dim3(64), 0, sx, G);
+                    else if (k1occ == 5) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 5>), g1, dim3(64), 0, sx, G);
+                    else if (k1occ == 8) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 8>), g1, dim3(64), 0, sx, G);
+                    else hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 6>), g1, dim3(64), 0, sx, G);
+                }
+                hipLaunchKernelGGL((chain_plan_kernel<af_wave_t, true>), dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 10)), dim3(64), 0, sx, G);
                 hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_SMALL);
                 hipLaunchKernelGGL((dp_lane_kernel<AF_BLK, AF_QCAP, AF_LPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE);
                 hipLaunchKernelGGL((dp_lane_kernel<AF_TS, AF_TS, 1>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_SMALL);
@@ -907,7 +917,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 hipLaunchKernelGGL(select_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
                 hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)((af_tb_cap + 255) / 256)), dim3(256), 0, sx, G);
                 // the record and the SAM line of every read that stayed on the staged path: one wave per read when the kernel spells the text
-                if (gpu_text) hipLaunchKernelGGL(finish_wave_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 20)), dim3(64), 0, sx, G);
+                if (gpu_text) hipLaunchKernelGGL(finish_wave_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 24)), dim3(64), 0, sx, G);
                 else hipLaunchKernelGGL(finish_kernel, dim3((unsigned)std::min<uint64_t>((nr + 63) / 64, af_fin_grid)), dim3(64), 0, sx, G);
                 // the reads the staged kernels handed over: few, but each a long serial job; they run beside the next sub-batch's kernels
                 A.read_list = S.fb_list.p; A.n_reads_dev = S.ctr.p + AFC_FALLBACK;
@@ -936,14 +946,22 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             R.recs = c->h_recs.p + r0; R.cig = c->h_cig.p + k * cig_per; R.alt = c->h_alt.p + k * alt_per; R.md = c->h_md.p + k * md_per; R.nr = nr;
             if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "  sub-batch %llu: waited for the launch from %.1f to %.1f ms\n", (unsigned long long)k, (f0 - t_enter) * 1e3, (f1 - t_enter) * 1e3);
             if (force_back) for (uint64_t r = 0; r < nr; ++r) if ((r0 + r) % force_back == 0) R.recs[r].status = 2;
-            if (gpu_text) {        // the text the launch wrote: one copy engine transfer next to the running kernels
-                uint64_t words = 0;
-                for (uint64_t r = 0; r < nr; ++r) if (R.recs[r].txt_len) words = std::max<uint64_t>(words, R.recs[r].txt_off + ((R.recs[r].txt_len + 7) >> 3));
-                if (words > txt_per) return MONI_EINVAL;
-                if (words) {
-                    HIPCHK(hipMemcpyAsync(c->h_txt.p, c->ak_txt.p + k * txt_per, words * 8, hipMemcpyDeviceToHost, c->copy_stream));
-                    HIPCHK(hipStreamSynchronize(c->copy_stream));
+            if (gpu_text) {        // the text the launch wrote: copy engine transfers next to the running kernels, one per used region of the pool
+                const uint64_t n_reg = use_fast ? AF_TXT_SHARDS + 1 : 1, reg_words = use_fast ? txt_per / (AF_TXT_SHARDS + 1) : txt_per;
+                uint64_t used[AF_TXT_SHARDS + 1];
+                for (uint64_t g = 0; g < n_reg; ++g) used[g] = 0;
+                for (uint64_t r = 0; r < nr; ++r) if (R.recs[r].txt_len) {
+                    const uint64_t end = R.recs[r].txt_off + ((R.recs[r].txt_len + 7) >> 3);
+                    const uint64_t g = R.recs[r].txt_off / reg_words;
+                    if (g >= n_reg || end > (g + 1) * reg_words) return MONI_EINVAL;
+                    used[g] = std::max(used[g], end - g * reg_words);
                 }
+                bool any = false;
+                for (uint64_t g = 0; g < n_reg; ++g) if (used[g]) {
+                    HIPCHK(hipMemcpyAsync(c->h_txt.p + g * reg_words, c->ak_txt.p + k * txt_per + g * reg_words, used[g] * 8, hipMemcpyDeviceToHost, c->copy_stream));
+                    any = true;
+                }
+                if (any) HIPCHK(hipStreamSynchronize(c->copy_stream));
                 R.txt = c->h_txt.p;
             }
             { float ms = 0; if (hipEventElapsedTime(&ms, c->ak_begin[k], c->ak_done[k]) == hipSuccess) { c->dp_kernel_ms_accum += ms; c->ak_kernel_ms = ms; } }

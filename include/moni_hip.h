@@ -180,6 +180,9 @@ typedef struct {
     uint64_t handed_back;                                 /* reads that exceeded the align kernel's capacities and went through the host pipeline */
     uint64_t dp_reused, dp_cells_reused;                  /* DP problems (and their cells) answered from the per-read memo of identical problems; not in dp_tasks/dp_cells */
     uint64_t kernel_fallback;                             /* reads outside the staged kernels' common case, taken by the general align kernel */
+    uint64_t dp_ref_bytes;                                /* text bytes of the DP targets (the R of SURVEY.md 8(d)) */
+    double t_k_chain, t_k_dp, t_k_select, t_k_finish;     /* HIP-event seconds of the staged kernels by group, summed over the sub-batches (launches of two
+                                                             streams overlap: the sum exceeds the span t_dp_kernel) */
 } moni_align_stats_t;
 
 void moni_align_params_default(moni_align_params_t *p);
@@ -196,6 +199,14 @@ int moni_align_run(moni_ctx_t *ctx, const uint8_t *names, const uint64_t *name_o
                    const moni_align_params_t *prm, char **sam, uint64_t *sam_len, moni_align_stats_t *stats);
 /* aligner::to_sam (aligner_ksw2.hpp:3213-3219): "@HD", one "@SQ" per sequence, "@PG". */
 int moni_sam_header(const moni_index_t *idx, char **sam, uint64_t *sam_len);
+
+/* ---- the reference's on-disk liftidx (<prefix>.ldx: include/aligner/liftidx.hpp:117-143 over include/common/seqidx.hpp:197-238) ---- */
+/* Both layouts load: the current one (u64 w after u) and the older one the reference's fixture data/Chr21.10.ldx has. */
+int moni_ldx_info(const char *path, uint64_t *n_seq, uint64_t *u, uint64_t *w, int *has_w);
+/* Load and write again (with_w: current layout).  Writing is sdsl-exact: the fixture round-trips byte for byte. */
+int moni_ldx_rewrite(const char *in_path, const char *out_path, int with_w);
+/* liftidx::lift (liftidx.hpp:89-95) of n text positions with the lifts of an .ldx file, on the GPU (lift_core.h tables). */
+int moni_ldx_lift_batch(const char *path, int device, const uint64_t *pos, uint64_t n, uint64_t *out);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 /* HIP-event time (ms) of the kernels of the last *_run on this ctx's stream.

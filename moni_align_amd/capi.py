@@ -22,6 +22,7 @@ EXPORTS = [
     "moni_ms_query_batch", "moni_seed_run", "moni_seed_counts", "moni_seed_fetch", "moni_seed_batch", "moni_free",
     "moni_phi_lcp_batch", "moni_extz_batch", "moni_last_kernel_ms", "moni_last_counters",
     "moni_align_params_default", "moni_align_batch", "moni_align_run", "moni_sam_header",
+    "moni_ldx_info", "moni_ldx_rewrite", "moni_ldx_lift_batch",
 ]
 
 
@@ -58,7 +59,8 @@ class AlignStatsC(C.Structure):
     _fields_ = [("reads", C.c_uint64), ("aligned", C.c_uint64), ("dp_tasks", C.c_uint64), ("dp_cells", C.c_uint64), ("dp_rounds", C.c_uint64),
                 ("t_seed", C.c_double), ("t_chain", C.c_double), ("t_dp", C.c_double), ("t_host", C.c_double),
                 ("t_dp_kernel", C.c_double), ("handed_back", C.c_uint64), ("dp_reused", C.c_uint64), ("dp_cells_reused", C.c_uint64),
-                ("kernel_fallback", C.c_uint64)]
+                ("kernel_fallback", C.c_uint64), ("dp_ref_bytes", C.c_uint64),
+                ("t_k_chain", C.c_double), ("t_k_dp", C.c_double), ("t_k_select", C.c_double), ("t_k_finish", C.c_double)]
 
 
 class DpParamsC(C.Structure):
@@ -125,6 +127,9 @@ def lib():
         L.moni_sam_header.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.moni_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.moni_last_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.moni_ldx_info.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        L.moni_ldx_rewrite.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        L.moni_ldx_lift_batch.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _lib = L
     return _lib
 
@@ -316,3 +321,20 @@ class Ctx:
         out = np.zeros(4, dtype=np.uint64)
         _chk(self._L.moni_last_counters(self._h, out.ctypes.data), "moni_last_counters")
         return out
+
+
+def ldx_info(path: str):
+    n_seq, u, w, has_w = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
+    _chk(lib().moni_ldx_info(path.encode(), C.byref(n_seq), C.byref(u), C.byref(w), C.byref(has_w)), "moni_ldx_info")
+    return {"n_seq": n_seq.value, "u": u.value, "w": w.value, "has_w": bool(has_w.value)}
+
+
+def ldx_rewrite(src: str, dst: str, with_w: bool):
+    _chk(lib().moni_ldx_rewrite(src.encode(), dst.encode(), int(with_w)), "moni_ldx_rewrite")
+
+
+def ldx_lift_batch(path: str, pos: np.ndarray, device: int = 0) -> np.ndarray:
+    pos = np.ascontiguousarray(pos, dtype=np.uint64)
+    out = np.empty(len(pos), dtype=np.uint64)
+    _chk(lib().moni_ldx_lift_batch(path.encode(), device, pos.ctypes.data, len(pos), out.ctypes.data), "moni_ldx_lift_batch")
+    return out

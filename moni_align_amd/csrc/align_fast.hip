@@ -116,7 +116,8 @@ struct af_args_t {
 #define AF_PROF(G, slot, t0, t1) do {} while (0)
 #endif
 enum { AFC_TASKS = 0, AFC_FALLBACK = 1, AFC_TRACED = 2, AFC_READ_CUR = 3, AFC_DIRS_OVF = 4, AFC_CELLS = 6 /* 64 bit */, AFC_DIROFF = 8 /* 64 bit */,
-       AFC_NCHUNKS = 10 /* + group */, AFC_CURSOR = 13 /* + group */, AFC_BINS = 16 /* + bin */, AFC_BIG = 49, AFC_BIG_CUR = 50, AFC_WHY = 52 /* + reason */, AF_NCTR = 64 };
+       AFC_NCHUNKS = 10 /* + group */, AFC_CURSOR = 13 /* + group */, AFC_BINS = 16 /* + bin */, AFC_BIG = 49, AFC_BIG_CUR = 50, AFC_WHY = 52 /* + reason */, AFC_RBYTES = 64 /* 64 bit: text bytes of the DP targets, the R of SURVEY.md 8(d) */,
+       AFC_QBYTES = 66 /* 64 bit: read bytes of the DP queries */, AF_NCTR = 96 };
 enum { AF_GRP_LARGE = 0, AF_GRP_SMALL = 1, AF_GRP_GLOBAL = 2 };
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -766,8 +767,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
             G.res[tid] = R;
         }
         unsigned long long cells = wild ? 0ull : (unsigned long long)qlen * (unsigned long long)tlen;
-        for (int o = 32; o > 0; o >>= 1) cells += __shfl_xor(cells, o);
-        if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_CELLS]), cells);
+        unsigned long long rq = wild ? 0ull : ((unsigned long long)tlen << 32) | (unsigned long long)qlen;      // both operand sizes in one reduction (< 2^32 each per wave)
+        for (int o = 32; o > 0; o >>= 1) { cells += __shfl_xor(cells, o); rq += __shfl_xor(rq, o); }
+        if (lane == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_CELLS]), cells);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_RBYTES]), rq >> 32);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_QBYTES]), rq & 0xFFFFFFFFull);
+        }
         __syncthreads();
     }
 }

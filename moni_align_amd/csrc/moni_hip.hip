@@ -18,6 +18,7 @@
 #include "../../include/moni_hip.h"
 #include "image.hpp"
 #include "lift_build.hpp"
+#include "ref_index_io.hpp"
 #include "align_host.hpp"
 #include "layout.h"
 #include "seed_kernels.hip"
@@ -137,6 +138,7 @@ struct moni_ctx {
     uint64_t ak_waves_full = 0;
     hipStream_t ak_stream[2] = {nullptr, nullptr}, copy_stream = nullptr, fb_stream[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ak_fin;                // staged kernels of a sub-batch queued; the handed-over reads follow on fb_stream
+    std::vector<hipEvent_t> af_ev;                 // per sub-batch: after the chaining kernels, after the DP kernels, after selection + traceback (HIP-event kernel times)
     std::vector<hipEvent_t> ak_begin, ak_done;
     HBuf<moni_aln_rec_t> h_recs; HBuf<uint32_t> h_cig; HBuf<moni_alt_t> h_alt; HBuf<uint64_t> h_md;      // pinned staging of one sub-batch's records
     std::vector<mh::Aligner::OutBuf> pieces;          // per host thread: the text it is writing (kept across batches)
@@ -345,6 +347,7 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     if (c->ak_stream[1]) (void)hipStreamDestroy(c->ak_stream[1]);
     for (int x = 0; x < 2; ++x) if (c->fb_stream[x]) (void)hipStreamDestroy(c->fb_stream[x]);
     for (auto e : c->ak_fin) (void)hipEventDestroy(e);
+    for (auto e : c->af_ev) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto e : c->ak_begin) (void)hipEventDestroy(e);
     for (auto e : c->ak_done) (void)hipEventDestroy(e);
@@ -672,10 +675,76 @@ static int host_align_subset(moni_ctx* c, const moni_align_params_t& prm, const 
 static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bool ctx_out, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
                       const moni_align_params_t* prm, char** sam, uint64_t* sam_len, moni_align_stats_t* stats);
 
+// Reads of MONI_LONG_READ bases or more do not go through the batch with the others: the seeding workspace is strided by the longest
+// read of a batch, so one long read among 262144 short ones would multiply its size (a 100 kb read: hundreds of GB).  They are
+// aligned as a batch of their own (host pipeline over the same kernels) and spliced back in; a read beyond the largest DP the
+// kernels take (8192 bases) is reported unaligned, with a notice, instead of failing the batch.
+#define MONI_LONG_READ 4096u
+#define MONI_MAX_READ 8192u
+
 int moni_align_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
                      const moni_align_params_t* prm, char** sam, uint64_t* sam_len, moni_align_stats_t* stats) {
     if (!c || !b || !prm || !sam || !sam_len || (b->n_reads && (!names || !name_off))) return MONI_EINVAL;
-    return align_core(c, b, false, false, names, name_off, quals, prm, sam, sam_len, stats);
+    const uint64_t NR = b->n_reads;
+    std::vector<uint32_t> longs;
+    for (uint64_t r = 0; r < NR; ++r) if (b->offsets[r + 1] - b->offsets[r] >= MONI_LONG_READ) longs.push_back((uint32_t)r);
+    if (longs.empty()) return align_core(c, b, false, false, names, name_off, quals, prm, sam, sam_len, stats);
+    try {
+        // the short reads as a batch of their own
+        std::vector<uint8_t> sseq, snm, sq; std::vector<uint64_t> soff(1, 0), snoff(1, 0);
+        std::vector<uint8_t> lseq, lnm, lq; std::vector<uint64_t> loff(1, 0), lnoff(1, 0);
+        std::vector<std::string> long_line(longs.size());
+        size_t li = 0;
+        for (uint64_t r = 0; r < NR; ++r) {
+            const uint64_t off = b->offsets[r], m = b->offsets[r + 1] - off;
+            const bool is_long = li < longs.size() && longs[li] == r;
+            if (is_long && m > MONI_MAX_READ) {        // no kernel takes it: unaligned record (sam.hpp:144-188, flag 4)
+                fprintf(stderr, "moni_hip: read %llu has %llu bases (more than %u): reported unaligned\n", (unsigned long long)r, (unsigned long long)m, MONI_MAX_READ);
+                std::string& ln = long_line[li];
+                ln.assign((const char*)names + name_off[r], (const char*)names + name_off[r + 1]);
+                ln += "\t4\t*\t0\t255\t*\t*\t0\t0\t";
+                ln.append((const char*)b->seq + off, m); ln.push_back('\t');
+                if (quals) ln.append((const char*)quals + off, m); else ln.push_back('*');
+                ln.push_back('\n');
+                ++li;
+                continue;
+            }
+            std::vector<uint8_t>& S = is_long ? lseq : sseq; std::vector<uint8_t>& N = is_long ? lnm : snm; std::vector<uint8_t>& Q = is_long ? lq : sq;
+            std::vector<uint64_t>& O = is_long ? loff : soff; std::vector<uint64_t>& NO = is_long ? lnoff : snoff;
+            S.insert(S.end(), b->seq + off, b->seq + off + m); O.push_back(S.size());
+            N.insert(N.end(), names + name_off[r], names + name_off[r + 1]); NO.push_back(N.size());
+            if (quals) Q.insert(Q.end(), quals + off, quals + off + m);
+            if (is_long) ++li;
+        }
+        char* ssam = nullptr; uint64_t slen = 0;
+        moni_align_stats_t st_s; memset(&st_s, 0, sizeof st_s);
+        const moni_read_batch_t sb{sseq.data(), soff.data(), (uint64_t)soff.size() - 1};
+        int rc = align_core(c, &sb, false, false, snm.data(), snoff.data(), quals ? sq.data() : nullptr, prm, &ssam, &slen, &st_s);
+        if (rc) return rc;
+        std::string lsam; mh::AlignStats st_l;
+        if (loff.size() > 1) {
+            const moni_read_batch_t lb{lseq.data(), loff.data(), (uint64_t)loff.size() - 1};
+            if ((rc = host_align_subset(c, *prm, lb, lnm.data(), lnoff.data(), quals ? lq.data() : nullptr, lsam, st_l))) { free(ssam); return rc; }
+        }
+        // splice in input order
+        std::string out;
+        out.reserve(slen + lsam.size() + 64 * longs.size());
+        size_t ps = 0, pl = 0; li = 0;
+        for (uint64_t r = 0; r < NR; ++r) {
+            if (li < longs.size() && longs[li] == r) {
+                if (!long_line[li].empty()) out += long_line[li];
+                else { const size_t e = lsam.find('\n', pl); out.append(lsam, pl, e - pl + 1); pl = e + 1; }
+                ++li;
+            } else { const char* e = (const char*)memchr(ssam + ps, '\n', slen - ps); const size_t n = (size_t)(e - (ssam + ps)) + 1; out.append(ssam + ps, n); ps += n; }
+        }
+        free(ssam);
+        char* dst = (char*)malloc(out.size() + 1);
+        if (!dst) return MONI_ENOMEM;
+        memcpy(dst, out.data(), out.size()); dst[out.size()] = 0;
+        *sam = dst; *sam_len = out.size();
+        if (stats) { *stats = st_s; stats->reads = NR; stats->aligned += st_l.aligned; stats->dp_tasks += st_l.dp_tasks; stats->dp_cells += st_l.dp_cells; stats->handed_back += (uint64_t)loff.size() - 1; }
+        return MONI_OK;
+    } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
 }
 
 int moni_align_run(moni_ctx_t* c, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals, const moni_align_params_t* prm,
@@ -839,15 +908,16 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         c->ak_stream[0] = c->stream;
         if (!c->ak_stream[1]) HIPCHK(hipStreamCreateWithFlags(&c->ak_stream[1], hipStreamNonBlocking));
         if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        while (c->ak_done.size() < n_sub) { hipEvent_t e0, e1, e2; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+        while (c->ak_done.size() < n_sub) { hipEvent_t e0, e1, e2; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
                                             c->ak_begin.push_back(e0); c->ak_done.push_back(e1); c->ak_fin.push_back(e2); }
         for (int x = 0; x < 2; ++x) if (use_fast && !c->fb_stream[x]) HIPCHK(hipStreamCreateWithFlags(&c->fb_stream[x], hipStreamNonBlocking));
+        while (c->af_ev.size() < 3 * n_sub) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->af_ev.push_back(e); }
         HIPCHK(hipMemsetAsync(c->ak_cursors.p, 0, (AK_CUR * n_sub + AK_CUR) * sizeof(unsigned long long), c->stream));
         HIPCHK(hipMemcpyAsync(c->ak_minscore.p, msc.data(), msc.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         t_launch[0] = mh::now_s() - t_enter;
-        if ((rc = c->af_ctr_host.ensure(64 * n_sub + 64))) return rc;
-        memset(c->af_ctr_host.p, 0, 64 * n_sub * sizeof(uint32_t));
+        if ((rc = c->af_ctr_host.ensure(AF_NCTR * n_sub + AF_NCTR))) return rc;
+        memset(c->af_ctr_host.p, 0, AF_NCTR * n_sub * sizeof(uint32_t));
         for (uint64_t k = 0; k < n_sub; ++k) {
             const uint64_t r0 = sub_lo[k], nr = sub_lo[k + 1] - sub_lo[k];
             uint64_t n_waves = ak_waves;
@@ -897,7 +967,6 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 G.prof = S.prof.p;
                 if (const char* v = getenv("MONI_AF_DBG")) G.dbg = (uint32_t)atoi(v);
 #endif
-                static_assert(AF_NCTR == 64, "the counters of a sub-batch are fetched as 64 words");
                 HIPCHK(hipMemsetAsync(S.ctr.p, 0, AF_NCTR * sizeof(uint32_t), sx));
                 {
                     static const int k1occ = getenv("MONI_AF_K1OCC") ? atoi(getenv("MONI_AF_K1OCC")) : 6;
@@ -908,14 +977,17 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                     else hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 6>), g1, dim3(64), 0, sx, G);
                 }
                 hipLaunchKernelGGL((chain_plan_kernel<af_wave_t, true>), dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 10)), dim3(64), 0, sx, G);
+                HIPCHK(hipEventRecord(c->af_ev[3 * k], sx));
                 hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_SMALL);
                 hipLaunchKernelGGL((dp_lane_kernel<AF_BLK, AF_QCAP, AF_LPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE);
                 hipLaunchKernelGGL((dp_lane_kernel<AF_TS, AF_TS, 1>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_SMALL);
                 hipLaunchKernelGGL(global_task_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
                 hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL, (uint32_t)AF_GRP_GLOBAL);
                 hipLaunchKernelGGL((dp_lane_kernel<AF_GBLK, AF_QCAP, AF_GPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL);
+                HIPCHK(hipEventRecord(c->af_ev[3 * k + 1], sx));
                 hipLaunchKernelGGL(select_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
                 hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)((af_tb_cap + 255) / 256)), dim3(256), 0, sx, G);
+                HIPCHK(hipEventRecord(c->af_ev[3 * k + 2], sx));
                 // the record and the SAM line of every read that stayed on the staged path: one wave per read when the kernel spells the text
                 if (gpu_text) hipLaunchKernelGGL(finish_wave_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 24)), dim3(64), 0, sx, G);
                 else hipLaunchKernelGGL(finish_kernel, dim3((unsigned)std::min<uint64_t>((nr + 63) / 64, af_fin_grid)), dim3(64), 0, sx, G);
@@ -925,7 +997,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 HIPCHK(hipEventRecord(c->ak_fin[k], sx));
                 HIPCHK(hipStreamWaitEvent(sf, c->ak_fin[k], 0));
                 hipLaunchKernelGGL(align_kernel, dim3((unsigned)ak_waves), dim3(64), 0, sf, A);
-                HIPCHK(hipMemcpyAsync(c->af_ctr_host.p + 64 * k, S.ctr.p, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, sf));
+                HIPCHK(hipMemcpyAsync(c->af_ctr_host.p + AF_NCTR * k, S.ctr.p, AF_NCTR * sizeof(uint32_t), hipMemcpyDeviceToHost, sf));
                 HIPCHK(hipEventRecord(c->ak_done[k], sf));
                 done_recorded = true;
             } else if (nr > 0) {
@@ -1037,10 +1109,17 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             for (uint64_t k = 0; k < n_sub; ++k) {
                 const unsigned long long* q = cur.data() + AK_CUR * k;
                 st.dp_tasks += q[2]; st.dp_cells += q[3]; st.dp_reused += q[8]; st.dp_cells_reused += q[9];
+                if (use_fast && sub_lo[k + 1] > sub_lo[k]) {         // HIP-event times of the staged kernels' groups (they overlap with the other stream's: sums, not spans)
+                    float ms = 0;
+                    if (hipEventElapsedTime(&ms, c->ak_begin[k], c->af_ev[3 * k]) == hipSuccess) st.t_k_chain += ms / 1e3;
+                    if (hipEventElapsedTime(&ms, c->af_ev[3 * k], c->af_ev[3 * k + 1]) == hipSuccess) st.t_k_dp += ms / 1e3;
+                    if (hipEventElapsedTime(&ms, c->af_ev[3 * k + 1], c->af_ev[3 * k + 2]) == hipSuccess) st.t_k_select += ms / 1e3;
+                    if (hipEventElapsedTime(&ms, c->af_ev[3 * k + 2], c->ak_fin[k]) == hipSuccess) st.t_k_finish += ms / 1e3;
+                }
                 if (use_fast) {         // the staged kernels' own counters
-                    const uint32_t* fc = c->af_ctr_host.p + 64 * k;
-                    unsigned long long cells; memcpy(&cells, fc + AFC_CELLS, 8);
-                    st.dp_tasks += fc[AFC_TASKS]; st.dp_cells += cells; st.kernel_fallback += fc[AFC_FALLBACK];
+                    const uint32_t* fc = c->af_ctr_host.p + AF_NCTR * k;
+                    unsigned long long cells, rb; memcpy(&cells, fc + AFC_CELLS, 8); memcpy(&rb, fc + AFC_RBYTES, 8);
+                    st.dp_tasks += fc[AFC_TASKS]; st.dp_cells += cells; st.kernel_fallback += fc[AFC_FALLBACK]; st.dp_ref_bytes += rb;
                     if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "  staged kernels, sub-batch %llu: %u DP tasks, %llu cells, %u traced, %u large + %u small + %u global chunks, %u reads to align_kernel%s\n",
                                                            (unsigned long long)k, fc[AFC_TASKS], cells, fc[AFC_TRACED], fc[AFC_NCHUNKS], fc[AFC_NCHUNKS + 1], fc[AFC_NCHUNKS + 2], fc[AFC_FALLBACK], fc[AFC_DIRS_OVF] ? " (direction bytes overflowed)" : "");
                     if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "    handed over because: long read %u, anchors/seeds %u, chains %u, chains to score %u, chain length %u, DP size %u, overlapping anchors %u, wildcard %u, "
@@ -1133,9 +1212,65 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         stats->t_seed = st.t_seed; stats->t_chain = st.t_chain; stats->t_dp = st.t_dp; stats->t_host = st.t_host;
         stats->t_dp_kernel = c->dp_kernel_ms_accum / 1e3;
         stats->handed_back = st.handed_back; stats->dp_reused = st.dp_reused; stats->dp_cells_reused = st.dp_cells_reused;
-        stats->kernel_fallback = st.kernel_fallback;
+        stats->kernel_fallback = st.kernel_fallback; stats->dp_ref_bytes = st.dp_ref_bytes;
+        stats->t_k_chain = st.t_k_chain; stats->t_k_dp = st.t_k_dp; stats->t_k_select = st.t_k_select; stats->t_k_finish = st.t_k_finish;
     }
     return MONI_OK;
+}
+
+// ---- the reference's .ldx (liftidx) --------------------------------------------------------------------------------------------
+__global__ void lift_batch_kernel(const ac_params_t P, const uint64_t* __restrict__ pos, uint64_t n, uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ac_lift(P, pos[i]);
+}
+
+int moni_ldx_rewrite(const char* in_path, const char* out_path, int with_w) {
+    if (!in_path || !out_path) return MONI_EINVAL;
+    refio::Ldx L;
+    int rc = refio::load_ldx(in_path, L);
+    if (rc) return rc;
+    if (with_w && !L.has_w) L.w = 10;          // the older layout has no field for it: the separator width of every build of the reference
+    return refio::save_ldx(out_path, L, with_w != 0);
+}
+
+int moni_ldx_info(const char* path, uint64_t* n_seq, uint64_t* u, uint64_t* w, int* has_w) {
+    if (!path) return MONI_EINVAL;
+    refio::Ldx L;
+    int rc = refio::load_ldx(path, L);
+    if (rc) return rc;
+    if (n_seq) *n_seq = L.names.size();
+    if (u) *u = L.u;
+    if (w) *w = L.w;
+    if (has_w) *has_w = L.has_w ? 1 : 0;
+    return MONI_OK;
+}
+
+int moni_ldx_lift_batch(const char* path, int device, const uint64_t* pos, uint64_t n, uint64_t* out) {
+    if (!path || (n && (!pos || !out))) return MONI_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) return MONI_ENODEV;
+    HIPCHK(hipSetDevice(device));
+    refio::Ldx L;
+    int rc = refio::load_ldx(path, L);
+    if (rc) return rc;
+    refio::LdxFlat F; F.from(L);
+    moni_flat_index_t f; memset(&f, 0, sizeof f);
+    F.fill(f, L.has_w ? L.w : 10);
+    f.n = F.seq_starts.back() + 1;
+    LiftTables lt; std::string err;
+    if ((rc = lt.build(f, err))) { fprintf(stderr, "moni_hip: %s\n", err.c_str()); return rc; }
+    uint64_t bytes = 0;
+    moni_lift_seq_t* d_seqs = nullptr; moni_lift_run_t* d_runs = nullptr; uint64_t *d_pdir = nullptr, *d_starts = nullptr, *d_io = nullptr;
+    auto done = [&](int code) { void* ps[] = {d_seqs, d_runs, d_pdir, d_starts, d_io}; for (void* p : ps) if (p) (void)hipFree(p); return code; };
+    if ((rc = upload(&d_seqs, lt.seqs, bytes)) || (rc = upload(&d_runs, lt.runs, bytes)) || (rc = upload(&d_pdir, lt.pdir, bytes)) || (rc = upload(&d_starts, F.seq_starts, bytes))) return done(rc);
+    if (!n) return done(MONI_OK);
+    if (hipMalloc((void**)&d_io, 2 * n * 8) != hipSuccess) return done(MONI_ENOMEM);
+    if (hipMemcpy(d_io, pos, n * 8, hipMemcpyHostToDevice) != hipSuccess) return done(MONI_ENODEV);
+    ac_params_t P; memset(&P, 0, sizeof P);
+    P.n_text = f.n - 1; P.n_seq = (uint32_t)f.n_seq; P.seq_starts = d_starts; P.lift_seqs = d_seqs; P.lift_runs = d_runs; P.pdir = d_pdir;
+    hipLaunchKernelGGL(lift_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, P, (const uint64_t*)d_io, n, d_io + n);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d_io + n, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return done(MONI_ENODEV);
+    return done(MONI_OK);
 }
 
 int moni_sam_header(const moni_index_t* I, char** sam, uint64_t* sam_len) {

@@ -79,9 +79,31 @@ class Pangenome:
 
 def make_pangenome(base_len: int, n_haps: int, seed: int = 19, var_seed: int = 12,
                    site_spacing: int = 1800, w: int = 10,
-                   contig: str = "chr19") -> Pangenome:
+                   contig: str = "chr19", repeat_frac: float = 0.0, rep_seed: int = 1919) -> Pangenome:
+    """repeat_frac > 0: interspersed repeats: segments of 300-3000 bp are copied to random places with 5 %
+    divergence until that fraction of the base genome is repeat copies, so that MEMs have many occurrences and the phi walks,
+    the per-genome cap and the chaining see more than one locus per haplotype."""
     rng = np.random.Generator(np.random.MT19937(seed))
     g0 = _ACGT[rng.integers(0, 4, size=base_len, dtype=np.uint8)]
+    if repeat_frac > 0:
+        rr = np.random.Generator(np.random.MT19937(rep_seed))
+        code0 = np.full(256, 0, dtype=np.uint8)
+        code0[_ACGT] = np.arange(4, dtype=np.uint8)
+        covered = 0
+        n_fam = max(1, int(base_len * repeat_frac / 1650 / 8))       # families of ~8 copies each
+        for _ in range(n_fam):
+            ln = int(rr.integers(300, 3001))
+            src = int(rr.integers(0, base_len - ln))
+            unit = g0[src:src + ln].copy()
+            for _c in range(8):
+                if covered >= base_len * repeat_frac:
+                    break
+                dst = int(rr.integers(0, base_len - ln))
+                cp = unit.copy()
+                k = rr.random(ln) < 0.05
+                cp[k] = _ACGT[(code0[cp[k]] + rr.integers(1, 4, size=int(k.sum()), dtype=np.uint8)) & 3]
+                g0[dst:dst + ln] = cp
+                covered += ln
     seqs = [g0]
     names = [contig]
     vr = np.random.Generator(np.random.MT19937(var_seed))

@@ -127,3 +127,26 @@ def test_round_trip_properties_large(gpu_pair, medium_case):
         s = (rc if e["mate"] & 2 else reads)[e["read"]][e["idx"]:e["idx"] + e["len"]]
         for occ in got["occs"][int(e["occ_off"]):int(e["occ_off"]) + int(e["occ_cnt"])]:
             assert np.array_equal(text[int(occ):int(occ) + int(e["len"])], s)
+
+
+def test_long_runs_take_the_general_path():
+    """BWT runs of 4095 positions and more, offsets that leave the 12-bit fields of the fast rows, a letter without a hot slot: the
+    LF kernel's general path (rows / cr / recs with absolute positions) on the GPU against the oracle."""
+    from moni_align_amd import capi
+    from oracle import orc
+    from tests.test_host_sim import long_run_case, ragged
+    fi, reads = long_run_case()
+    sq, offs = ragged(reads)
+    idx = capi.Index(fi=fi)
+    ctx = capi.Ctx(idx)
+    try:
+        o = orc.OracleIndex(fi=fi)
+        ctx.upload(sq, offs)
+        ctx.seed_run(20, True, 100)
+        assert_seeds_equal(ctx.seed_fetch(), o.seed_batch(sq, offs, 20, True, 100))
+        ptr = ctx.ms_query_batch(sq, offs)
+        for i in range(0, 400, 11):
+            assert np.array_equal(ptr[int(offs[i]) * 2:int(offs[i]) * 2 + 150], o.ms_query(reads[i].tobytes()))
+    finally:
+        ctx.close()
+        idx.close()

@@ -85,10 +85,9 @@ def test_phi_records(medium_case, pair):
             assert s.phi(i, True) == o.phi_lcp(i, True)
 
 
-def test_long_run_onto_many_short_runs():
-    """A BWT run longer than the 12-bit length field whose LF image spans thousands of short runs: exercises the
-    saturated-length check and the galloping search of settle_run, and cold symbols without a hot slot."""
-    import tempfile, os
+def long_run_case():
+    """A text whose BWT has a run longer than the 12-bit length field, with an LF image that spans thousands of short runs, and a fifth
+    letter without a hot slot; reads that cross the junctions.  Returns (flat index, reads)."""
     from moni_align_amd import index_build, synth
     rng = np.random.default_rng(8)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -107,22 +106,26 @@ def test_long_run_onto_many_short_runs():
     fi = index_build.build_from_pangenome(pg, device="cpu")
     lens = np.diff(fi.starts.astype(np.int64))
     assert lens.max() >= 4095
+    reads = []
+    for _ in range(400):                                          # random windows of the text with a few errors
+        a = int(rng.integers(0, len(seq) - 150))
+        r = seq[a:a + 150].copy()
+        for e in rng.integers(0, 150, size=2):
+            r[int(e)] = acgt[int(rng.integers(0, 4))]
+        reads.append(r)
+    return fi, reads
+
+
+def test_long_run_onto_many_short_runs():
+    """A BWT run longer than the 12-bit length field whose LF image spans thousands of short runs: exercises the
+    saturated-length check and the galloping search of settle_run, and cold symbols without a hot slot."""
+    import tempfile, os
+    fi, reads = long_run_case()
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "long.mfi")
         fi.save(path)
         o = orc.OracleIndex(path)
         s = hs.Sim(fi)
-        reads = []
-        L = 67
-        for k in rng.integers(0, K, size=300):
-            st = int(k) * 67 + (int(k) // 500 + 1) * 4 - 4 if False else None
-        # reads = random windows of the text (each crosses an x_k C W junction) with a few errors, plus N-containing ones
-        for _ in range(400):
-            a = int(rng.integers(0, len(seq) - 150))
-            r = seq[a:a + 150].copy()
-            for e in rng.integers(0, 150, size=2):
-                r[int(e)] = acgt[int(rng.integers(0, 4))]
-            reads.append(r)
         sq, offs = ragged(reads)
         got = s.seed_run(sq, offs, min_len=20, n_seeds_thr=100, pool_rows=100000)
         want = o.seed_batch(sq, offs, 20, True, 100)

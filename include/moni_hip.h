@@ -138,6 +138,10 @@ int moni_ms_run(moni_ctx_t *ctx);
 /* Host-buffer form: pointers[2*offsets[i] + s*len_i + k] = pointer k of strand s (0 fwd, 1 rc) of read i. */
 int moni_ms_query_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, uint64_t *pointers);
 
+/* Legacy `moni ms` / `moni mems` (src/matching_statistics.cpp:236-278, src/mems.cpp:236-280): pointers and matching-statistics
+ * lengths of every read as given (forward strand), pointers[offsets[i] - offsets[0] + k] / lengths[...] for read offset k. */
+int moni_ms_lengths_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, uint64_t *pointers, uint64_t *lengths);
+
 /* ---- seeds: seed_finder::find_mems + populate_seeds (seed_finder.hpp:126-166, 258-318) ----- */
 /* Device-only run (ms + mems + occurrences) over the resident batch. */
 int moni_seed_run(moni_ctx_t *ctx, const moni_seed_params_t *prm);
@@ -197,6 +201,9 @@ int moni_align_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint
  * (a streaming caller writes it out and calls again; the pages stay mapped between batches). */
 int moni_align_run(moni_ctx_t *ctx, const uint8_t *names, const uint64_t *name_off, const uint8_t *quals,
                    const moni_align_params_t *prm, char **sam, uint64_t *sam_len, moni_align_stats_t *stats);
+/* aligner::align with report_mems (-m; aligner_ksw2.hpp:346-373): one secondary record per MEM occurrence.  *sam is malloc'ed. */
+int moni_report_mems_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
+                           const uint8_t *quals, const moni_align_params_t *prm, char **sam, uint64_t *sam_len);
 /* aligner::to_sam (aligner_ksw2.hpp:3213-3219): "@HD", one "@SQ" per sequence, "@PG". */
 int moni_sam_header(const moni_index_t *idx, char **sam, uint64_t *sam_len);
 

@@ -22,7 +22,7 @@ EXPORTS = [
     "moni_ms_query_batch", "moni_seed_run", "moni_seed_counts", "moni_seed_fetch", "moni_seed_batch", "moni_free",
     "moni_phi_lcp_batch", "moni_extz_batch", "moni_last_kernel_ms", "moni_last_counters",
     "moni_align_params_default", "moni_align_batch", "moni_align_run", "moni_sam_header",
-    "moni_ldx_info", "moni_ldx_rewrite", "moni_ldx_lift_batch",
+    "moni_ldx_info", "moni_ldx_rewrite", "moni_ldx_lift_batch", "moni_ms_lengths_batch", "moni_report_mems_batch",
 ]
 
 
@@ -127,6 +127,9 @@ def lib():
         L.moni_sam_header.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.moni_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.moni_last_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.moni_ms_lengths_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p]
+        L.moni_report_mems_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.moni_ldx_info.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.moni_ldx_rewrite.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         L.moni_ldx_lift_batch.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
@@ -302,6 +305,35 @@ class Ctx:
                                     C.byref(prm), C.byref(out), C.byref(ln), C.byref(st)), "moni_align_run")
         sam = C.string_at(out, ln.value) if want_text else int(ln.value)      # the buffer belongs to the context
         return sam, {k: getattr(st, k) for k, _ in AlignStatsC._fields_}
+
+    def ms_lengths_batch(self, seq: np.ndarray, offsets: np.ndarray):
+        """legacy `moni ms`: (pointers, lengths) of the forward strand of every read"""
+        b, keep = self._batch(seq, offsets)
+        total = int(keep[1][-1] - keep[1][0])
+        ptr = np.empty(total, dtype=np.uint64)
+        ln = np.empty(total, dtype=np.uint64)
+        _chk(self._L.moni_ms_lengths_batch(self._h, C.byref(b), ptr.ctypes.data, ln.ctypes.data), "moni_ms_lengths_batch")
+        self.n_reads = len(offsets) - 1
+        return ptr, ln
+
+    def report_mems_batch(self, seq, offsets, names, name_off, quals=None, **overrides) -> bytes:
+        b, keep = self._batch(seq, offsets)
+        names = np.ascontiguousarray(names, dtype=np.uint8)
+        name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
+        if quals is not None:
+            quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        prm = AlignParamsC()
+        self._L.moni_align_params_default(C.byref(prm))
+        for k, v in overrides.items():
+            setattr(prm, k, v)
+        out, ln = C.c_void_p(), C.c_uint64()
+        _chk(self._L.moni_report_mems_batch(self._h, C.byref(b), names.ctypes.data, name_off.ctypes.data, quals.ctypes.data if quals is not None else None,
+                                            C.byref(prm), C.byref(out), C.byref(ln)), "moni_report_mems_batch")
+        self.n_reads = len(offsets) - 1
+        try:
+            return C.string_at(out, ln.value)
+        finally:
+            self._L.moni_free(out)
 
     def sam_header(self) -> bytes:
         out = C.c_void_p()

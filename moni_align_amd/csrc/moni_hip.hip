@@ -451,6 +451,33 @@ int moni_ms_query_batch(moni_ctx_t* c, const moni_read_batch_t* b, uint64_t* poi
     return MONI_OK;
 }
 
+// Legacy `moni ms` (src/matching_statistics.cpp:236-278): pointers and lengths of the forward strand of every read
+int moni_ms_lengths_batch(moni_ctx_t* c, const moni_read_batch_t* b, uint64_t* pointers, uint64_t* lengths) {
+    if (!pointers || !lengths) return MONI_EINVAL;
+    int rc = moni_reads_upload(c, b);
+    if (rc) return rc;
+    if ((rc = moni_ms_run(c))) return rc;
+    moni_index* I = c->idx;
+    const uint64_t nr = c->n_reads, n_tasks = 2 * nr;
+    if (!nr) return MONI_OK;
+    DBuf<uint32_t> lens;
+    if ((rc = lens.ensure(c->total_len + 1))) return rc;
+    hipLaunchKernelGGL(ms_len_kernel, dim3((unsigned)((nr + MS_BLOCK - 1) / MS_BLOCK)), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, c->pat.p, c->offs.p, nr,
+                       c->ptr.p, lens.p);
+    std::vector<uint64_t> h(n_tasks * c->max_len);
+    std::vector<uint32_t> hl(c->total_len + 1);
+    bool ok = hipStreamSynchronize(c->stream) == hipSuccess && (h.empty() || hipMemcpy(h.data(), c->ptr.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) &&
+              hipMemcpy(hl.data(), lens.p, c->total_len * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    lens.release();
+    if (!ok) return MONI_ENODEV;
+    const uint64_t base = b->offsets[0];
+    for (uint64_t rd = 0; rd < nr; ++rd) {
+        const uint64_t off = b->offsets[rd] - base, m = b->offsets[rd + 1] - b->offsets[rd];
+        for (uint64_t k = 0; k < m; ++k) { pointers[off + k] = h[(m - 1 - k) * n_tasks + 2 * rd]; lengths[off + k] = hl[off + k]; }
+    }
+    return MONI_OK;
+}
+
 int moni_seed_run(moni_ctx_t* c, const moni_seed_params_t* prm) {
     if (!c || !prm) return MONI_EINVAL;
     moni_index* I = c->idx;
@@ -1216,6 +1243,54 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         stats->t_k_chain = st.t_k_chain; stats->t_k_dp = st.t_k_dp; stats->t_k_select = st.t_k_select; stats->t_k_finish = st.t_k_finish;
     }
     return MONI_OK;
+}
+
+// aligner::align with report_mems (aligner_ksw2.hpp:346-373): one secondary SAM record per occurrence of every MEM (no halves), the
+// record's SEQ / QUAL being the MEM's part of the read (of its reverse complement for the other strand)
+int moni_report_mems_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
+                           const moni_align_params_t* prm, char** sam, uint64_t* sam_len) {
+    if (!c || !b || !prm || !sam || !sam_len || (b->n_reads && (!names || !name_off))) return MONI_EINVAL;
+    int rc = moni_reads_upload(c, b);
+    if (rc) return rc;
+    moni_seed_params_t sp;
+    sp.min_len = prm->min_len; sp.filter_seeds = prm->filter_seeds; sp.n_seeds_thr = prm->n_seeds_thr; sp.report_mems = 1;
+    if ((rc = moni_seed_run(c, &sp))) return rc;
+    try {
+        std::vector<moni_mem_t> mems(c->n_mems); std::vector<uint64_t> occs(c->n_occs), rmo(c->n_reads + 1);
+        if ((rc = moni_seed_fetch(c, mems.data(), occs.data(), rmo.data()))) return rc;
+        const mh::HostIndex& ix = c->idx->hix;
+        std::string out;
+        char num[32];
+        for (uint64_t r = 0; r < c->n_reads; ++r) {
+            const uint64_t off = b->offsets[r], m = b->offsets[r + 1] - off;
+            size_t total = 0;
+            for (uint64_t k = rmo[r]; k < rmo[r + 1]; ++k) total += mems[k].occ_cnt;
+            for (uint64_t k = rmo[r]; k < rmo[r + 1]; ++k) {
+                const moni_mem_t& M = mems[k];
+                if (prm->filter_freq) { const double fr = static_cast<double>(M.occ_cnt) / total; if (fr > prm->freq_thr) continue; }      // seed_freq_filter
+                const bool rc_strand = (M.mate & 2) != 0;
+                std::string seq(M.len, 'N'), ql;
+                for (uint32_t x = 0; x < M.len; ++x) seq[x] = rc_strand ? (char)mh::compl_of(b->seq[off + m - 1 - (M.idx + x)]) : (char)b->seq[off + M.idx + x];
+                if (quals) { ql.resize(M.len); for (uint32_t x = 0; x < M.len; ++x) ql[x] = rc_strand ? (char)quals[off + m - 1 - (M.idx + x)] : (char)quals[off + M.idx + x]; }
+                for (uint32_t j = 0; j < M.occ_cnt; ++j) {
+                    const auto ref = ix.index(occs[M.occ_off + j]);
+                    out.append((const char*)names + name_off[r], (size_t)(name_off[r + 1] - name_off[r]));
+                    out += rc_strand ? "\t272\t" : "\t256\t";
+                    out += ix.names[ref.first]; out.push_back('\t');
+                    snprintf(num, sizeof num, "%d", (int)(ref.second + 1)); out += num;
+                    out += "\t255\t"; snprintf(num, sizeof num, "%d", (int)M.len); out += num; out += "M\t*\t0\t0\t";
+                    out += seq; out.push_back('\t');
+                    if (quals) out += ql; else out.push_back('*');
+                    out += "\tAS:i:0\tNM:i:0\tMD:Z:\tOA:Z:*,0,"; out += rc_strand ? "-" : "+"; out += ",*,255,0;\tAA:Z:\n";
+                }
+            }
+        }
+        char* dst = (char*)malloc(out.size() + 1);
+        if (!dst) return MONI_ENOMEM;
+        memcpy(dst, out.data(), out.size()); dst[out.size()] = 0;
+        *sam = dst; *sam_len = out.size();
+        return MONI_OK;
+    } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
 }
 
 // ---- the reference's .ldx (liftidx) --------------------------------------------------------------------------------------------

@@ -111,3 +111,32 @@ extern "C" __global__ void occ_off_scatter_kernel(moni_mem_t* __restrict__ mems,
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g < n) mems[g].occ_off = off[g];
 }
+
+
+// Matching-statistics lengths of the forward strand (src/matching_statistics.cpp:242-256, src/mems.cpp:241-258: the loop both legacy
+// front ends run over ms.query's pointers): lane = read, lens[offs[read] - offs[0] + i] = l at read offset i.
+__global__ void __launch_bounds__(MS_BLOCK)
+ms_len_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const uint8_t* __restrict__ text, const uint64_t* __restrict__ pat,
+              const uint64_t* __restrict__ offs, uint64_t n_reads, const uint64_t* __restrict__ ptr, uint32_t* __restrict__ lens) {
+    __shared__ lds_tables_t L;
+    load_tables(L, T, K);
+    const uint64_t read = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
+    if (read >= n_reads) return;
+    const uint64_t n_tasks = 2 * n_reads, task = 2 * read;
+    const uint64_t off = offs[read];
+    const uint32_t m = (uint32_t)(offs[read + 1] - off);
+    const uint64_t n = K.n_text;
+    uint64_t l = 0, prev_pos_plus_one = n + 1;
+    pat_cache_t pc; pc.w = 0xFFFFFFFFu; pc.word = 0;
+    text_cache_t tc; tc.w = ~0ull; tc.word = 0;
+    for (uint32_t i = 0; i < m; ++i) {
+        const uint64_t pos = ptr[(uint64_t)(m - 1 - i) * n_tasks + task];
+        while (pos != prev_pos_plus_one && (i + l) < m && (pos + l) < n) {
+            if (pat_byte(pat, n_tasks, task, m, (uint32_t)(i + l), pc) != text_byte(text, pos + l, tc)) break;
+            ++l;
+        }
+        lens[off - offs[0] + i] = (uint32_t)l;
+        l = (l == 0 ? 0 : (l - 1));
+        prev_pos_plus_one = pos + 1;
+    }
+}

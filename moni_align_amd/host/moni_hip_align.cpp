@@ -6,10 +6,18 @@
 // Same getopt string, flag meanings, struct defaults and default output name as the reference, so the `moni align` wrapper
 // (pipeline/moni.in:494-546) can call it unchanged.  Index: <prefix>.mfi (the flat arrays moni_align_amd/index_build.py
 // writes; reading the reference's sdsl-serialised files is SURVEY §8(f) item 1).  Reads are streamed in large batches (the
-// reference's -b is a per-thread batch of 512; a GPU wants ~10^5), one worker thread and one index replica per GPU, output
-// written in input order.  Not implemented here (exit 1 with a message): paired-end (-1/-2), -m, -c, -q, -n, -Z.
+// reference's -b is a per-thread batch of 512; a GPU wants ~10^5): a reader thread parses ahead into a bounded queue (plain files
+// are mapped and split with memchr, a few GB/s; gzip files go through zlib), two worker threads per GPU each with its own context
+// keep two batches in flight per GPU (upload + seeding of one beside the align kernels of the other), a writer thread puts the
+// finished blocks out in input order from a bounded window.  -m writes the report-MEMs records (aligner_ksw2.hpp:346-373);
+// --ms / --mems write the legacy `moni ms` / `moni mems` text outputs (src/matching_statistics.cpp:520-610, src/mems.cpp:520-600).
+// Not implemented here (exit 1 with a message): paired-end (-1/-2), -c, -q, -n, -Z.
+#include <fcntl.h>
 #include <getopt.h>
 #include <libgen.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <chrono>
@@ -17,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -86,11 +95,75 @@ struct Reader {
     }
 };
 
+// Plain (uncompressed) four-line FASTQ / two-line FASTA mapped into memory: records are split with memchr.  Anything else (gzip, wrapped
+// sequences) takes the kseq-style Reader above.
+struct MappedReader {
+    const char* p = nullptr; size_t n = 0, at = 0; int fd = -1;
+    bool open(const std::string& path) {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size < 4) { ::close(fd); fd = -1; return false; }
+        n = (size_t)st.st_size;
+        void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { ::close(fd); fd = -1; return false; }
+        madvise(m, n, MADV_SEQUENTIAL);
+        p = (const char*)m;
+        if ((unsigned char)p[0] == 0x1f && (unsigned char)p[1] == 0x8b) { close(); return false; }     // gzip
+        // the fast path needs one-line sequences: check the first record
+        const char* l1 = (const char*)memchr(p, '\n', n);
+        if (!l1 || (p[0] != '@' && p[0] != '>')) { close(); return false; }
+        const char* l2 = (const char*)memchr(l1 + 1, '\n', n - (size_t)(l1 + 1 - p));
+        if (!l2) { close(); return false; }
+        if (p[0] == '@' && (l2 + 1 >= p + n || l2[1] != '+')) { close(); return false; }
+        return true;
+    }
+    void close() { if (p) munmap((void*)p, n); p = nullptr; if (fd >= 0) ::close(fd); fd = -1; }
+    ~MappedReader() { close(); }
+    static const char* eol(const char* s, const char* end) { const char* e = (const char*)memchr(s, '\n', (size_t)(end - s)); return e ? e : end; }
+    bool next(Batch& b) {
+        const char* end = p + n;
+        const char* s = p + at;
+        while (s < end && (*s == '\n' || *s == '\r')) ++s;
+        if (s >= end) return false;
+        const bool fq = *s == '@';
+        if (!fq && *s != '>') die("malformed record in the reads file");
+        const char* e1 = eol(s, end);
+        const char* w = s + 1;
+        while (w < e1 && !isspace((unsigned char)*w)) ++w;
+        b.names.insert(b.names.end(), (const uint8_t*)s + 1, (const uint8_t*)w);
+        b.name_off.push_back(b.names.size());
+        const char* q = e1 < end ? e1 + 1 : end;
+        const char* e2 = eol(q, end);
+        size_t slen = (size_t)(e2 - q);
+        if (slen && q[slen - 1] == '\r') --slen;
+        b.seq.insert(b.seq.end(), (const uint8_t*)q, (const uint8_t*)q + slen);
+        b.off.push_back(b.seq.size());
+        const char* nx = e2 < end ? e2 + 1 : end;
+        if (fq) {
+            const char* e3 = eol(nx, end);                     // '+' line
+            const char* ql = e3 < end ? e3 + 1 : end;
+            const char* e4 = eol(ql, end);
+            size_t qlen = (size_t)(e4 - ql);
+            if (qlen && ql[qlen - 1] == '\r') --qlen;
+            if (qlen != slen) die("truncated quality string");
+            b.qual.insert(b.qual.end(), (const uint8_t*)ql, (const uint8_t*)ql + qlen);
+            nx = e4 < end ? e4 + 1 : end;
+        } else {
+            b.has_qual = false;
+            b.qual.resize(b.seq.size(), (uint8_t)'*');
+        }
+        at = (size_t)(nx - p);
+        return true;
+    }
+};
+
 struct Args {
     std::string filename, patterns, mate1, mate2, output;
     size_t b = 512, th = 1;
     moni_align_params_t P;
     bool report_mems = false, csv = false, no_lcp = false, shaped_slp = false, secondary = false;
+    bool legacy_ms = false, legacy_mems = false;      // --ms / --mems
     int gpus = 1;
     size_t gpu_batch = 262144;
     bool dry_run = false;
@@ -104,6 +177,8 @@ static void parse(int argc, char** argv, Args& a) {
         if (!strcmp(argv[i], "--gpus") && i + 1 < argc) { a.gpus = atoi(argv[++i]); continue; }
         if (!strcmp(argv[i], "--gpu-batch") && i + 1 < argc) { a.gpu_batch = strtoull(argv[++i], nullptr, 10); continue; }
         if (!strcmp(argv[i], "--dry-run")) { a.dry_run = true; continue; }
+        if (!strcmp(argv[i], "--ms")) { a.legacy_ms = true; continue; }
+        if (!strcmp(argv[i], "--mems")) { a.legacy_mems = true; continue; }
         av.push_back(argv[i]);
     }
     const std::string usage = "usage: " + std::string(argv[0]) + " infile [-p patterns] [-o output] [-t threads] [-b batch] [-l len] [-L ext_l] [-A smatch] "
@@ -158,18 +233,23 @@ int main(int argc, char** argv) {
     Args a;
     parse(argc, argv, a);
     if (!a.mate1.empty() || !a.mate2.empty()) die("paired-end alignment (-1/-2) is not implemented in moni-hip-align yet");
-    if (a.report_mems || a.csv || a.no_lcp || a.shaped_slp || a.secondary) die("options -m, -c, -n, -q, -Z are not implemented in moni-hip-align yet");
+    if (a.csv || a.no_lcp || a.shaped_slp || a.secondary) die("options -c, -n, -q, -Z are not implemented in moni-hip-align yet");
     if (a.patterns.empty()) die("no reads given (-p)");
     std::string fn = a.filename;
     std::vector<char> tmp(fn.begin(), fn.end()); tmp.push_back(0);
     const std::string base_name = basename(tmp.data());
     std::string sam_filename = a.patterns + "_" + base_name + "_" + std::to_string(a.P.min_len) + ".sam";   // align_full_ksw2.cpp:347-349
     if (!a.output.empty()) sam_filename = a.output;
+    const bool legacy = a.legacy_ms || a.legacy_mems;
+    if (legacy && a.output.empty()) sam_filename = a.patterns + "_" + base_name;       // mems.cpp / matching_statistics.cpp: <patterns>_<index> + .mems / .pointers / .lengths
     info("Output file: " + sam_filename);
+    MappedReader mrd;
+    const bool mapped = mrd.open(a.patterns);
+    Reader* zrd = mapped ? nullptr : new Reader(a.patterns);
+    auto next_record = [&](Batch& b) { return mapped ? mrd.next(b) : zrd->next(b); };
     if (a.dry_run) {
-        Reader rd(a.patterns);
         Batch b; size_t n = 0, bases = 0;
-        while (rd.next(b)) { ++n; }
+        while (next_record(b)) { ++n; }
         bases = b.seq.size();
         printf("dry-run: reads=%zu bases=%zu min_len=%u ext_len=%u S=%u F=%.2f O=%d,%d E=%d,%d threads=%zu gpus=%d out=%s first=%.*s\n", n, bases, a.P.min_len,
                a.P.ext_len, a.P.n_seeds_thr, a.P.freq_thr, a.P.gapo, a.P.gapo2, a.P.gape, a.P.gape2, a.th, a.gpus, sam_filename.c_str(),
@@ -177,49 +257,130 @@ int main(int argc, char** argv) {
         return 0;
     }
     const std::string idx_path = a.filename + ".mfi";
+    const int per_gpu = legacy ? 1 : 2;                      // contexts (batches in flight) per GPU
     std::vector<moni_index_t*> idx(a.gpus, nullptr);
-    std::vector<moni_ctx_t*> ctx(a.gpus, nullptr);
+    std::vector<moni_ctx_t*> ctx((size_t)a.gpus * per_gpu, nullptr);
     for (int g = 0; g < a.gpus; ++g) {
         if (moni_index_load(idx_path.c_str(), g, &idx[g])) die("cannot load " + idx_path + " on GPU " + std::to_string(g) + " (moni-hip has no CPU path)");
-        if (moni_ctx_create(idx[g], &ctx[g])) die("cannot create a context on GPU " + std::to_string(g));
+        for (int k = 0; k < per_gpu; ++k) if (moni_ctx_create(idx[g], &ctx[(size_t)g * per_gpu + k])) die("cannot create a context on GPU " + std::to_string(g));
     }
-    FILE* out = fopen(sam_filename.c_str(), "w");
-    if (!out) die("open() file " + sam_filename + " failed");
-    { char* h; uint64_t hl; if (moni_sam_header(idx[0], &h, &hl)) die("header"); fwrite(h, 1, hl, out); moni_free(h); }
+    FILE* out = nullptr; FILE* out2 = nullptr;
+    if (a.legacy_ms) { out = fopen((sam_filename + ".pointers").c_str(), "w"); out2 = fopen((sam_filename + ".lengths").c_str(), "w"); if (!out || !out2) die("open() file " + sam_filename + ".pointers/.lengths failed"); }
+    else if (a.legacy_mems) { out = fopen((sam_filename + ".mems").c_str(), "w"); if (!out) die("open() file " + sam_filename + ".mems failed"); }
+    else {
+        out = fopen(sam_filename.c_str(), "w");
+        if (!out) die("open() file " + sam_filename + " failed");
+        char* h; uint64_t hl; if (moni_sam_header(idx[0], &h, &hl)) die("header"); fwrite(h, 1, hl, out); moni_free(h);
+    }
     auto t0 = std::chrono::steady_clock::now();
-    Reader rd(a.patterns);
-    std::mutex mu_in, mu_out;
-    std::condition_variable cv_out;
-    size_t next_in = 0, next_out = 0, processed = 0, aligned = 0;
-    std::map<size_t, std::string> done;
-    auto worker = [&](int g) {
+    // ---- reader thread -> bounded queue of parsed batches -> workers -> bounded in-order window -> writer thread ----
+    struct Item { size_t id; Batch* b; };
+    struct Done { char* a = nullptr; uint64_t la = 0; std::string b; };      // a: malloc'ed block of the library; b: a second stream (.lengths)
+    std::mutex mu_q, mu_out;
+    std::condition_variable cv_q_put, cv_q_get, cv_out, cv_window;
+    std::deque<Item> queue;
+    bool reader_done = false;
+    const size_t q_cap = (size_t)a.gpus * per_gpu + 2, window = 2 * (size_t)a.gpus * per_gpu + 2;
+    size_t next_out = 0, n_batches = 0, processed = 0, aligned = 0;
+    bool workers_done = false;
+    std::map<size_t, Done> done;
+    std::thread reader([&]() {
+        size_t id = 0;
         while (true) {
-            Batch b;
-            size_t id;
+            Batch* b = new Batch();
+            b->seq.reserve(a.gpu_batch * 160); b->qual.reserve(a.gpu_batch * 160); b->names.reserve(a.gpu_batch * 24);
+            while (b->n() < a.gpu_batch && next_record(*b)) {}
+            if (b->n() == 0) { delete b; break; }
+            std::unique_lock<std::mutex> lk(mu_q);
+            cv_q_put.wait(lk, [&] { return queue.size() < q_cap; });
+            queue.push_back(Item{id++, b});
+            cv_q_get.notify_one();
+        }
+        std::lock_guard<std::mutex> lk(mu_q);
+        reader_done = true; n_batches = id;
+        cv_q_get.notify_all();
+    });
+    std::thread writer([&]() {
+        while (true) {
+            Done d;
             {
-                std::lock_guard<std::mutex> lk(mu_in);                    // mt_kbseq_read (align_reads_dispatcher.hpp:74-84)
-                while (b.n() < a.gpu_batch && rd.next(b)) {}
-                if (b.n() == 0) return;
-                id = next_in++;
+                std::unique_lock<std::mutex> lk(mu_out);
+                cv_out.wait(lk, [&] { return (!done.empty() && done.begin()->first == next_out) || workers_done; });
+                if (done.empty() || done.begin()->first != next_out) { if (workers_done && done.empty()) return; if (workers_done) die("a batch is missing from the output"); continue; }
+                d = std::move(done.begin()->second);
+                done.erase(done.begin());
+                ++next_out;
+                cv_window.notify_all();
             }
+            if (d.la) fwrite(d.a, 1, d.la, out);
+            if (d.a) moni_free(d.a);
+            if (out2 && !d.b.empty()) fwrite(d.b.data(), 1, d.b.size(), out2);
+        }
+    });
+    auto worker = [&](int w) {
+        moni_ctx_t* C = ctx[w];
+        while (true) {
+            Item it;
+            {
+                std::unique_lock<std::mutex> lk(mu_q);
+                cv_q_get.wait(lk, [&] { return !queue.empty() || reader_done; });
+                if (queue.empty()) return;
+                it = queue.front(); queue.pop_front();
+                cv_q_put.notify_one();
+            }
+            Batch& b = *it.b;
             moni_read_batch_t rb{b.seq.data(), b.off.data(), b.n()};
-            char* sam; uint64_t len; moni_align_stats_t st;
-            if (moni_align_batch(ctx[g], &rb, b.names.data(), b.name_off.data(), b.has_qual ? b.qual.data() : nullptr, &a.P, &sam, &len, &st))
-                die("moni_align_batch failed");
+            Done d;
+            size_t n_al = 0;
+            if (legacy) {
+                std::vector<uint64_t> ptr(b.seq.size() + 1), len(b.seq.size() + 1);
+                if (moni_ms_lengths_batch(C, &rb, ptr.data(), len.data())) die("moni_ms_lengths_batch failed");
+                std::string sa, sb;
+                for (size_t r = 0; r < b.n(); ++r) {
+                    const std::string hdr = ">" + std::string((const char*)b.names.data() + b.name_off[r], (size_t)(b.name_off[r + 1] - b.name_off[r])) + "\n";
+                    sa += hdr;
+                    const size_t o = b.off[r], m = b.off[r + 1] - o;
+                    if (a.legacy_ms) {          // matching_statistics.cpp:565-600: values followed by a blank, one line per read
+                        sb += hdr;
+                        for (size_t k = 0; k < m; ++k) { sa += std::to_string(ptr[o + k]); sa.push_back(' '); sb += std::to_string(len[o + k]); sb.push_back(' '); }
+                        sb.push_back('\n');
+                    } else {                    // mems.cpp:241-262, 585-590: (offset,length) of every position whose length does not drop
+                        for (size_t k = 0; k < m; ++k) if (k == 0 || len[o + k] >= len[o + k - 1]) { sa += "(" + std::to_string(k) + "," + std::to_string(len[o + k]) + ") "; }
+                    }
+                    sa.push_back('\n');
+                }
+                d.a = (char*)malloc(sa.size() + 1); memcpy(d.a, sa.data(), sa.size()); d.la = sa.size(); d.b = std::move(sb);
+            } else if (a.report_mems) {
+                if (moni_report_mems_batch(C, &rb, b.names.data(), b.name_off.data(), b.has_qual ? b.qual.data() : nullptr, &a.P, &d.a, &d.la)) die("moni_report_mems_batch failed");
+                n_al = b.n();
+            } else {
+                moni_align_stats_t st;
+                if (moni_align_batch(C, &rb, b.names.data(), b.name_off.data(), b.has_qual ? b.qual.data() : nullptr, &a.P, &d.a, &d.la, &st)) die("moni_align_batch failed");
+                n_al = st.aligned;
+            }
+            const size_t n_reads = b.n();
+            delete it.b;
             std::unique_lock<std::mutex> lk(mu_out);
-            done[id] = std::string(sam, len);
-            moni_free(sam);
-            processed += st.reads; aligned += st.aligned;
-            while (!done.empty() && done.begin()->first == next_out) { fwrite(done.begin()->second.data(), 1, done.begin()->second.size(), out); done.erase(done.begin()); ++next_out; }
+            cv_window.wait(lk, [&] { return it.id < next_out + window; });      // bounded: a slow writer holds the workers back instead of the heap growing
+            done[it.id] = std::move(d);
+            processed += n_reads; aligned += n_al;
+            cv_out.notify_one();
         }
     };
     std::vector<std::thread> th;
-    for (int g = 0; g < a.gpus; ++g) th.emplace_back(worker, g);
+    for (size_t w = 0; w < ctx.size(); ++w) th.emplace_back(worker, (int)w);
+    reader.join();
     for (auto& t : th) t.join();
+    { std::lock_guard<std::mutex> lk(mu_out); workers_done = true; cv_out.notify_all(); }
+    writer.join();
     fclose(out);
+    if (out2) fclose(out2);
+    delete zrd;
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     info("Number of aligned reads: " + std::to_string(aligned) + "/" + std::to_string(processed));
     info("Elapsed time (s): " + std::to_string(el));
-    for (int g = 0; g < a.gpus; ++g) { moni_ctx_destroy(ctx[g]); moni_index_destroy(idx[g]); }
+    info("Reads per second: " + std::to_string(processed / (el > 0 ? el : 1)));
+    for (size_t w = 0; w < ctx.size(); ++w) moni_ctx_destroy(ctx[w]);
+    for (int g = 0; g < a.gpus; ++g) moni_index_destroy(idx[g]);
     return 0;
 }

@@ -582,6 +582,7 @@ struct aligner {
         std::vector<mem_t> mems;
         std::vector<std::pair<size_t, size_t>> anchors;
         std::vector<chain_t> chains;
+        std::string mems_sam;          // report_mems: the records of aligner_ksw2.hpp:346-373
     };
 
     // aligner_ksw2.hpp:553-597
@@ -630,6 +631,27 @@ struct aligner {
         mem_finder.find_mems(al.read_rev.seq.data(), al.read_rev.seq.size(), al.mems, 0, MATE_1 | MATE_RC);
         mem_finder.populate_seeds(al.mems, cfg.report_mems);
         if (cfg.filter_freq) seed_freq_filter(al.mems, cfg.freq_thr);
+        if (cfg.report_mems) {                      // aligner_ksw2.hpp:346-373: one secondary record per occurrence of every MEM
+            for (size_t i = 0; i < al.mems.size(); ++i) {
+                const read_t& src = (al.mems[i].mate & MATE_RC) ? al.read_rev : *al.read;
+                read_t part;                        // copy_partial_kseq_t (kpbseq.h:197-205)
+                part.name = src.name; part.has_qual = src.has_qual;
+                part.seq = src.seq.substr(al.mems[i].idx, al.mems[i].len);
+                if (src.has_qual) part.qual = src.qual.substr(al.mems[i].idx, al.mems[i].len);
+                for (size_t j = 0; j < al.mems[i].occs.size(); ++j) {
+                    sam_t rs;
+                    rs.read = &part;
+                    rs.cigar = std::to_string(al.mems[i].len) + "M";
+                    const auto ref = ix.index(al.mems[i].occs[j]);
+                    rs.pos = ref.second + 1;
+                    rs.rname = ix.names[ref.first];
+                    rs.flag = (al.mems[i].mate & MATE_RC) ? (256 | 16) : 256;
+                    write_sam(al.mems_sam, rs);
+                }
+            }
+            al.aligned = true;
+            return true;
+        }
         al.chained = find_chains(al.mems, al.anchors, al.chains, cfg.chain);
         if (not al.chained) return false;
         int32_t min_score = 20 + 8 * log(al.read->seq.size());
@@ -712,6 +734,7 @@ struct aligner {
         al.read_rev.qual.assign(read.qual.rbegin(), read.qual.rend());
         if (not align(al)) al.sam.flag = 4;               // set_sam_not_aligned
         if (!cfg.report_mems) write_sam(out, al.sam);
+        else out += al.mems_sam;
         return al.aligned;
     }
 

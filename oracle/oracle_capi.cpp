@@ -202,6 +202,42 @@ char* orc_align_batch(void* h, const uint8_t* seqs, const uint64_t* offsets, uin
     *out_len = all.size();
     return buf;
 }
+// aligner::align with report_mems (-m): SAM text of the MEM records of a ragged batch
+char* orc_report_mems_batch(void* h, const uint8_t* seqs, const uint64_t* offsets, uint64_t n_reads, const uint8_t* names,
+                            const uint64_t* name_off, const uint8_t* quals, uint64_t* out_len) {
+    const FlatIndex& ix = *(FlatIndex*)h;
+    align_config_t cfg;
+    cfg.report_mems = true;
+    aligner A(ix, cfg);
+    std::string all;
+    for (uint64_t rd = 0; rd < n_reads; ++rd) {
+        read_t r;
+        r.name.assign((const char*)names + name_off[rd], (const char*)names + name_off[rd + 1]);
+        r.seq.assign((const char*)seqs + offsets[rd], (const char*)seqs + offsets[rd + 1]);
+        if (quals) { r.qual.assign((const char*)quals + offsets[rd], (const char*)quals + offsets[rd + 1]); r.has_qual = true; }
+        A.align_read(r, all);
+    }
+    char* buf = (char*)malloc(all.size() + 1);
+    memcpy(buf, all.data(), all.size());
+    buf[all.size()] = 0;
+    *out_len = all.size();
+    return buf;
+}
+
+// legacy `moni ms` (src/matching_statistics.cpp:242-256): pointers of ms.query and the lengths loop
+void orc_ms_lengths(void* h, const char* p, uint64_t m, uint64_t* ptr_out, uint64_t* len_out) {
+    const FlatIndex& ix = *(FlatIndex*)h;
+    auto pointers = ms_query(ix, p, m);
+    const uint64_t n = ix.n_text;
+    uint64_t l = 0;
+    for (uint64_t i = 0; i < m; ++i) {
+        const uint64_t pos = pointers[i];
+        while ((i + l) < m && (pos + l) < n && (i < 1 || pos != (pointers[i - 1] + 1)) && (uint8_t)p[i + l] == ix.text[pos + l]) ++l;
+        ptr_out[i] = pos; len_out[i] = l;
+        l = (l == 0 ? 0 : (l - 1));
+    }
+}
+
 void orc_free(void* p) { free(p); }
 
 // ksw2 restatement: one problem. out[11] = max,max_q,max_t,mqe,mqe_t,mte,mte_q,score,reach_end,n_cigar,zdropped

@@ -58,6 +58,9 @@ def lib():
         L.orc_align_batch.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint64] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int,
                                                                                                      ctypes.c_void_p, ctypes.c_void_p]
         L.orc_free.argtypes = [ctypes.c_void_p]
+        L.orc_report_mems_batch.restype = ctypes.c_void_p
+        L.orc_report_mems_batch.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint64] + [ctypes.c_void_p] * 4
+        L.orc_ms_lengths.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_extz.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int8,
                                ctypes.c_void_p, ctypes.c_int8, ctypes.c_int8, ctypes.c_int, ctypes.c_int,
                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -101,6 +104,13 @@ class OracleIndex:
         out = np.zeros(cap, dtype=np.uint32)
         n = self._L.orc_lift_cigar(self._h, cigar.ctypes.data, len(cigar), pos, out.ctypes.data, cap)
         return out[:n].copy()
+
+    def ms_lengths(self, pattern: bytes):
+        """legacy `moni ms`: (pointers, lengths) of a pattern"""
+        ptr = np.empty(len(pattern), dtype=np.uint64)
+        ln = np.empty(len(pattern), dtype=np.uint64)
+        self._L.orc_ms_lengths(self._h, pattern, len(pattern), ptr.ctypes.data, ln.ctypes.data)
+        return ptr, ln
 
     def ms_query(self, pattern: bytes) -> np.ndarray:
         out = np.empty(len(pattern), dtype=np.uint64)
@@ -191,3 +201,29 @@ def extz(query: np.ndarray, target: np.ndarray, flag: int, m: int = 5, mat: np.n
     res = {k: int(v) for k, v in zip(keys, out)}
     res["cigar"] = cig[: res["n_cigar"]].copy()
     return res
+
+
+def report_mems_batch(oidx: "OracleIndex", seqs, offsets, names, name_off, quals=None) -> bytes:
+    """aligner::align with report_mems (-m): the MEM records of the batch"""
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    names = np.ascontiguousarray(names, dtype=np.uint8)
+    name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
+    if quals is not None:
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+    out_len = ctypes.c_uint64()
+    p = lib().orc_report_mems_batch(oidx._h, seqs.ctypes.data, offsets.ctypes.data, len(offsets) - 1, names.ctypes.data, name_off.ctypes.data,
+                                    quals.ctypes.data if quals is not None else None, ctypes.byref(out_len))
+    try:
+        return ctypes.string_at(p, out_len.value)
+    finally:
+        lib().orc_free(p)
+
+
+def legacy_mems(pointers: np.ndarray, lengths: np.ndarray):
+    """src/mems.cpp:241-262: the (offset, length) pairs `moni mems` reports from ms pointers / lengths"""
+    out = []
+    for i in range(len(lengths)):
+        if i == 0 or lengths[i] >= lengths[i - 1]:
+            out.append((i, int(lengths[i])))
+    return out

@@ -41,7 +41,7 @@ def test_dry_run_parsing(exe, small_case, tmp_path):
 def test_unsupported_modes_exit_1(exe, tmp_path):
     fq = str(tmp_path / "x.fq")
     open(fq, "w").write("@a\nACGT\n+\nIIII\n")
-    for extra in (["-1", fq, "-2", fq], ["-p", fq, "-m"], ["-p", fq, "-q"]):
+    for extra in (["-1", fq, "-2", fq], ["-p", fq, "-q"], ["-p", fq, "-c"]):
         r = subprocess.run([exe, "x"] + extra, capture_output=True)
         assert r.returncode == 1 and b"not implemented" in r.stderr
     assert subprocess.run([exe], capture_output=True).returncode == 1
@@ -62,3 +62,47 @@ def test_cli_end_to_end(exe, medium_case, tmp_path):
     names, noff = orc.make_names(N)
     want, _ = orc.align_batch(o, reads.reshape(-1), offs, names, noff, np.full(N * L, ord("I"), dtype=np.uint8), with_header=True, threads=8)
     assert open(out, "rb").read() == want
+
+
+@pytest.mark.gpu
+def test_cli_report_mems_legacy_outputs_and_mouse_fixture_reads(exe, medium_case, tmp_path):
+    """-m (report-MEMs SAM), --ms / --mems (legacy `moni ms` / `moni mems` text files) against the oracle, with several batches in
+    flight; and the reference's own read file data/mouse/reads (names with /1, real quality strings) as a parser / format fixture."""
+    from oracle import orc
+    N, L = 2500, 150
+    reads = medium_case.synth.make_reads(medium_case.pg, N, L, seed=45)
+    fq = str(tmp_path / "reads.fastq")
+    medium_case.synth.write_fastq(fq, reads)
+    prefix = medium_case.path[:-4]
+    o = orc.OracleIndex(medium_case.path)
+    offs = np.arange(0, (N + 1) * L, L, dtype=np.uint64)
+    names, noff = orc.make_names(N)
+    quals = np.full(N * L, ord("I"), dtype=np.uint8)
+    out = str(tmp_path / "mems.sam")
+    subprocess.check_call([exe, prefix, "-p", fq, "-o", out, "-m", "-S", "1000", "-F", "0.5", "--gpu-batch", "700"])
+    hdr = orc.align_batch(o, reads[:0].reshape(-1), offs[:1], names[:0], noff[:1], None, with_header=True)[0]
+    assert open(out, "rb").read() == hdr + orc.report_mems_batch(o, reads.reshape(-1), offs, names, noff, quals)
+    base = str(tmp_path / "legacy")
+    subprocess.check_call([exe, prefix, "-p", fq, "-o", base, "--ms", "--gpu-batch", "900"])
+    subprocess.check_call([exe, prefix, "-p", fq, "-o", base, "--mems", "--gpu-batch", "900"])
+    wp, wl, wm = [], [], []
+    for i in range(N):
+        p, l = o.ms_lengths(reads[i].tobytes())
+        h = ">simulated.%d\n" % i
+        wp.append(h + "".join("%d " % x for x in p) + "\n")
+        wl.append(h + "".join("%d " % x for x in l) + "\n")
+        wm.append(h + "".join("(%d,%d) " % t for t in orc.legacy_mems(p, l)) + "\n")
+    assert open(base + ".pointers").read() == "".join(wp)
+    assert open(base + ".lengths").read() == "".join(wl)
+    assert open(base + ".mems").read() == "".join(wm)
+
+
+def test_reference_fixture_reads_parse(exe):
+    """data/mouse/reads/mouse.chr19.R1.fastq of the reference (5000 x 100 bp, names with /1): both readers give the same batch."""
+    src = "/root/reference/data/mouse/reads/mouse.chr19.R1.fastq"
+    if not os.path.exists(src):
+        pytest.skip("the reference checkout is not on this machine")
+    out = subprocess.check_output([exe, "x", "-p", src, "--dry-run"]).decode()
+    assert "reads=5000 bases=500000" in out
+    first = open(src).readline().split()[0][1:]
+    assert ("first=" + first) in out

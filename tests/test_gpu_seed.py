@@ -134,6 +134,7 @@ def test_long_runs_take_the_general_path():
     LF kernel's general path (rows / cr / recs with absolute positions) on the GPU against the oracle."""
     from moni_align_amd import capi
     from oracle import orc
+    from tests.parity import assert_seeds_equal
     from tests.test_host_sim import long_run_case, ragged
     fi, reads = long_run_case()
     sq, offs = ragged(reads)
@@ -147,6 +148,75 @@ def test_long_runs_take_the_general_path():
         ptr = ctx.ms_query_batch(sq, offs)
         for i in range(0, 400, 11):
             assert np.array_equal(ptr[int(offs[i]) * 2:int(offs[i]) * 2 + 150], o.ms_query(reads[i].tobytes()))
+    finally:
+        ctx.close()
+        idx.close()
+
+
+def test_legacy_ms_lengths_and_report_mems(medium_case):
+    """`moni ms` / `moni mems` (pointers + matching-statistics lengths of the forward strand) and the -m report-MEMs SAM mode of
+    `moni align` (aligner_ksw2.hpp:346-373) on the GPU against the oracle's restatements."""
+    from moni_align_amd import capi
+    from oracle import orc
+    reads = medium_case.synth.make_reads(medium_case.pg, 600, 150, seed=171, sub_rate=0.02, indel_rate=0.003)
+    reads[5, 30:33] = ord("N")
+    offs = np.arange(0, 601 * 150, 150, dtype=np.uint64)
+    o = orc.OracleIndex(medium_case.path)
+    idx = capi.Index(fi=medium_case.fi)
+    ctx = capi.Ctx(idx)
+    try:
+        ptr, ln = ctx.ms_lengths_batch(reads.reshape(-1), offs)
+        for i in range(0, 600, 13):
+            wp, wl = o.ms_lengths(reads[i].tobytes())
+            assert np.array_equal(ptr[150 * i:150 * (i + 1)], wp) and np.array_equal(ln[150 * i:150 * (i + 1)], wl)
+        names, noff = orc.make_names(600)
+        for quals in (None, np.full(reads.size, ord("F"), dtype=np.uint8)):
+            got = ctx.report_mems_batch(reads.reshape(-1), offs, names, noff, quals)
+            want = orc.report_mems_batch(o, reads.reshape(-1), offs, names, noff, quals)
+            assert got == want and got.count(b"\n") > 600
+    finally:
+        ctx.close()
+        idx.close()
+
+
+def test_positions_beyond_2_to_32():
+    """The 40-bit packing of the device image (image.hpp: rows, recs, fast rows with their high sample bytes; seed_core.h: `hi << 32`):
+    an r-index whose BWT is longer than 2^32 and whose SA samples exceed 2^32.  No such text can be built here (a 4 G suffix array),
+    but ms_pointers::_query (moni.hpp:568-624) is mechanical over the run-length BWT, the thresholds and the samples, so a real
+    index of a 2 Mbp text is stretched: every run 2048 times as long (F, run starts and thresholds scale with it, single-position
+    runs stay below the 12-bit limit of the fast rows, longer ones take the general path), samples scaled past 2^32.  The kernel's
+    pointers must equal the oracle's on the same arrays."""
+    import dataclasses
+    from moni_align_amd import capi, index_build, synth
+    from oracle import orc
+    pg = synth.make_pangenome(2_000_000, 0, seed=23)
+    fi = index_build.build_from_pangenome(pg, device="cuda:0", lifted=False)
+    M = np.uint64(2048)
+    n2 = int(fi.n) * int(M)
+    assert n2 > (1 << 32)
+    big = dataclasses.replace(
+        fi, n=n2, F=fi.F * M, starts=fi.starts * M, thr=fi.thr * M,
+        ssa=fi.ssa * M + np.uint64(7), esa=fi.esa * M + np.uint64(3),
+        text=np.full(n2 - 1, ord("A"), dtype=np.uint8),
+        seq_starts=np.array([0, n2 // 2, n2 - 10], dtype=np.uint64), names=["a", "b"])       # (a lift covers fewer than 2^32 columns)
+    assert int(big.ssa.max()) > (1 << 32) and int(np.diff(big.starts.astype(np.int64)).min()) == 2048
+    rng = np.random.default_rng(4)
+    reads = [pg.seqs[0][a:a + 120].copy() for a in rng.integers(0, 1_900_000, size=300)]
+    for r in reads[::3]:
+        r[int(rng.integers(0, 120))] = ord("ACGT"[int(rng.integers(0, 4))])
+    offs = np.arange(0, 301 * 120, 120, dtype=np.uint64)
+    sq = np.concatenate(reads)
+    idx = capi.Index(fi=big)
+    ctx = capi.Ctx(idx)
+    try:
+        o = orc.OracleIndex(fi=big)
+        ptr = ctx.ms_query_batch(sq, offs)
+        seen_high = False
+        for i in range(300):
+            want = o.ms_query(reads[i].tobytes())
+            assert np.array_equal(ptr[240 * i:240 * i + 120], want), i
+            seen_high = seen_high or bool((want >= (1 << 32)).any())
+        assert seen_high
     finally:
         ctx.close()
         idx.close()

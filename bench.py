@@ -216,7 +216,7 @@ def main():
             "vs_baseline": None, "dtype": "u64/int32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: mouse-chr19-scale index (%d bp base%s + %d haplotypes, %s, n=%d, r=%d), "
                                    "%s x %d bp reads resident in HBM -> MEM seeding + staged align kernels (chaining, lane-per-problem ksw2 DP, traceback, "
-                                   "lift-over, SAM lines) -> SAM text in host memory (%d host threads per GPU put the lines in read order, overlapped)"
+                                   "lift-over, SAM lines, lines gathered in read order) -> SAM text in pinned host memory, one transfer per sub-batch (%d host threads per GPU stand by for reads handed back)"
                                    % (3 if scaling == "strong" else 2, args.base_len, " with %g interspersed repeats" % args.repeats if args.repeats else "", args.haps,
                                       "FASTA-built: null lifts" if args.fasta_index else "ref+VCF -H12 style: haplotypes lift onto the reference contig", fi.n, fi.r,
                                       ("%d sharded over %d ranks" % (args.total_reads, world)) if scaling == "strong" else ("%d per GPU" % args.reads), L, threads),

@@ -1316,6 +1316,51 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 rec.txt_len = p; rec.txt_off = to;
             }
         }
-        if (lane == 0) A.recs[r_in] = rec;
+        if (lane == 0) {
+            A.recs[r_in] = rec;
+            if (A.dev_len) {
+                A.dev_len[r_in] = rec.txt_len; A.dev_off[r_in] = rec.txt_off;
+                if (rec.status == 2 || rec.txt_len == 0) atomicAdd(&A.dev_sum[0], 1ull);
+                else if (rec.status == 1) atomicAdd(&A.dev_sum[8 + 8 * (blockIdx.x % 16)], 1ull);      // sharded: one address takes only ~50 M atomics/s
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// gather_lines_kernel: the SAM lines of a sub-batch, which the kernels wrote to the text pool in completion order, copied into one
+// block in read order (pos = exclusive scan of the line lengths): the host receives the block with one transfer and does nothing else
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_lines_kernel(const uint64_t* __restrict__ pool, const uint64_t* __restrict__ len, const uint64_t* __restrict__ off,
+                                                           const uint64_t* __restrict__ pos, uint64_t n_reads, uint8_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * 256) >> 6;
+    for (uint64_t r = wave; r < n_reads; r += n_waves) {
+        const uint64_t l = len[r];
+        const uint8_t* __restrict__ src = reinterpret_cast<const uint8_t*>(pool + off[r]);
+        uint8_t* __restrict__ dst = out + pos[r];
+        // destination offsets are byte-granular: a head up to the first 8-byte boundary, aligned words, a tail
+        const uint64_t head = l < 8 ? l : ((8 - (reinterpret_cast<uintptr_t>(dst) & 7)) & 7);
+        if ((uint64_t)lane < head) dst[lane] = src[lane];
+        const uint64_t words = (l - head) >> 3;
+        for (uint64_t k = lane; k < words; k += 64) {
+            uint64_t w;
+            memcpy(&w, src + head + 8 * k, 8);
+            *reinterpret_cast<uint64_t*>(dst + head + 8 * k) = w;
+        }
+        const uint64_t done = head + 8 * words;
+        if (done + lane < l) dst[done + lane] = src[done + lane];
+    }
+}
+// the per-sub-batch summary the host reads: [0] bytes of the block, [1] records that need the host, [2] aligned reads
+__global__ void gather_summary_kernel(const uint64_t* __restrict__ len, const uint64_t* __restrict__ pos, uint64_t n_reads, const unsigned long long* __restrict__ dev_sum,
+                                      unsigned long long* __restrict__ out3) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out3[0] = n_reads ? pos[n_reads - 1] + len[n_reads - 1] : 0ull;
+        out3[1] = dev_sum[0];
+        unsigned long long al = dev_sum[1];
+        for (int s = 0; s < 16; ++s) al += dev_sum[8 + 8 * s];
+        out3[2] = al;
     }
 }

@@ -96,6 +96,8 @@ struct ak_args_t {
     moni_alt_t* alt_pool; uint64_t alt_cap;
     uint64_t* md_pool; uint64_t md_cap;          // in 8-byte words
     ak_fmt_t fmt;                                // SAM text in the kernel (txt_pool == nullptr: records only, the host formats)
+    uint64_t* dev_len; uint64_t* dev_off;    // per record slot, in device memory: length of the read's SAM line in bytes and where it is in the text pool
+    unsigned long long* dev_sum;             // (8-byte words); dev_sum[0] += records that need the host (no kernel text), dev_sum[1] += aligned reads
     unsigned long long* cursors;             // [0] cigar pool, [1] alt pool, [2] DP problems run, [3] their cells, [4] next read, [5..7] wave cycles: serial
                                              // phases (init+first drive, later drives), dp, [8] DP problems answered from the per-read memo, [9] their cells,
                                              // [14] MD pool (words)
@@ -339,6 +341,11 @@ __device__ __attribute__((noinline)) void ak_write_record(const ak_args_t& A, co
         }
     }
     A.recs[slot_in_launch] = rec;
+    if (A.dev_len) {
+        A.dev_len[slot_in_launch] = rec.txt_len; A.dev_off[slot_in_launch] = rec.txt_off;
+        if (rec.status == 2 || rec.txt_len == 0) atomicAdd(&A.dev_sum[0], 1ull);
+        else if (rec.status == 1) atomicAdd(&A.dev_sum[1], 1ull);
+    }
 }
 
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))

@@ -148,7 +148,11 @@ struct moni_ctx {
     DBuf<moni_alt_t> ak_alt;
     DBuf<int32_t> ak_minscore;
     unsigned long long* d_ak_cursors = nullptr;
-    char* out_buf = nullptr; size_t out_cap = 0;      // moni_align_run's text buffer, kept (and kept mapped) across calls
+    char* out_buf = nullptr; size_t out_cap = 0;      // moni_align_run's text buffer, kept across calls; pinned (hipHostMalloc): the in-order blocks of the
+                                                      // sub-batches land in it by DMA
+    DBuf<uint64_t> ak_block;                          // per sub-batch: its SAM lines in read order (gather_lines_kernel)
+    DBuf<uint64_t> ak_dev_len, ak_dev_off, ak_dev_pos; DBuf<unsigned long long> ak_dev_sum;
+    HBuf<unsigned long long> h_sum;                   // per sub-batch: bytes of the block, records that need the host, aligned reads
     float ak_kernel_ms = 0;
 };
 
@@ -353,7 +357,8 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     for (auto e : c->ak_done) (void)hipEventDestroy(e);
     c->ak_recs.release(); c->ak_cig.release(); c->ak_alt.release(); c->ak_minscore.release();
     if (c->d_ak_cursors) (void)hipFree(c->d_ak_cursors);
-    free(c->out_buf);
+    if (c->out_buf) (void)hipHostFree(c->out_buf);
+    c->ak_block.release(); c->ak_dev_len.release(); c->ak_dev_off.release(); c->ak_dev_pos.release(); c->ak_dev_sum.release(); c->h_sum.release();
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->d_counters) (void)hipFree(c->d_counters);
     for (int i = 0; i < EV_N; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -852,6 +857,15 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         // has been handed back
         char* abuf = ctx_out ? c->out_buf : nullptr; size_t acap = ctx_out ? c->out_cap : 0, alen = 0; uint64_t eager_upto = 0; bool eager_ok = true, eager_oom = false;
         auto drop_abuf = [&]() { if (!ctx_out) free(abuf); abuf = nullptr; };
+        auto grow_abuf = [&](size_t cap) -> bool {        // keeps the first alen bytes
+            if (!ctx_out) { char* nb = (char*)realloc(abuf, cap); if (!nb) return false; abuf = nb; acap = cap; return true; }
+            char* nb = nullptr;
+            if (hipHostMalloc((void**)&nb, cap, hipHostMallocDefault) != hipSuccess) return false;
+            if (abuf && alen) memcpy(nb, abuf, alen);
+            if (abuf) (void)hipHostFree(abuf);
+            abuf = nb; acap = cap; c->out_buf = nb; c->out_cap = cap;
+            return true;
+        };
         double prof[7] = {0, 0, 0, 0, 0, 0, 0};
         double hist[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cyc[7] = {0, 0, 0, 0, 0, 0, 0};
         uint64_t waves_used = 0;
@@ -923,6 +937,12 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         const uint64_t af_dirs_cap = 65536ull * sub_reads + (16ull << 20);
         const unsigned af_dp_grid = (unsigned)n_cu * 12;
         const unsigned af_fin_grid = (unsigned)std::min<uint64_t>((sub_reads + 63) / 64, (uint64_t)n_cu * 16);
+        // in-order text on the GPU: when the caller takes the context-owned buffer and the kernels spell the text, every sub-batch's lines are
+        // put in read order on the device and arrive with one transfer; the host threads are needed only for sub-batches with hand-backs
+        const bool inorder = use_fast && gpu_text && ctx_out && force_back == 0 && getenv("MONI_ALIGN_HOST_ORDER") == nullptr;
+        if (inorder && ((rc = c->ak_block.ensure(txt_per * n_sub + 8)) || (rc = c->ak_dev_len.ensure(NR + n_sub + 8)) || (rc = c->ak_dev_off.ensure(NR + n_sub + 8)) ||
+                        (rc = c->ak_dev_pos.ensure(NR + 2 * n_sub + 8)) || (rc = c->ak_dev_sum.ensure(160 * n_sub + 8)) || (rc = c->h_sum.ensure(4 * n_sub + 4)))) return rc;
+        if (inorder) { HIPCHK(hipMemsetAsync(c->ak_dev_sum.p, 0, (160 * n_sub + 8) * sizeof(unsigned long long), c->stream)); memset(c->h_sum.p, 0, (4 * n_sub + 4) * sizeof(unsigned long long)); }
         if (use_fast) for (int x = 0; x < (n_sub > 1 ? 2 : 1); ++x) {
             moni_ctx::AfSet& S = c->af[x];
             if ((rc = S.plans.ensure(sub_reads + 1)) || (rc = S.tasks.ensure(af_task_cap)) || (rc = S.res.ensure(af_task_cap)) || (rc = S.bin_q.ensure((size_t)AF_NBIN * af_task_cap)) ||
@@ -973,6 +993,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 A.fmt.min_len = (int32_t)prm->min_len; A.fmt.smatch = prm->smatch; A.fmt.smismatch = prm->smismatch;
                 A.fmt.txt_pool = c->ak_txt.p + k * txt_per; A.fmt.txt_cap = (use_fast && nr > 0) ? txt_per / (AF_TXT_SHARDS + 1) : txt_per;
             }
+            if (inorder) { A.dev_len = c->ak_dev_len.p + r0 + k; A.dev_off = c->ak_dev_off.p + r0 + k; A.dev_sum = c->ak_dev_sum.p + 160 * k; }
             hipStream_t sx = c->ak_stream[k & 1];
             if (use_fast && k >= 2) HIPCHK(hipStreamWaitEvent(sx, c->ak_done[k - 2], 0));      // the set's buffers are free once its previous sub-batch is through align_kernel too
             HIPCHK(hipEventRecord(c->ak_begin[k], sx));
@@ -1025,6 +1046,18 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 HIPCHK(hipStreamWaitEvent(sf, c->ak_fin[k], 0));
                 hipLaunchKernelGGL(align_kernel, dim3((unsigned)ak_waves), dim3(64), 0, sf, A);
                 HIPCHK(hipMemcpyAsync(c->af_ctr_host.p + AF_NCTR * k, S.ctr.p, AF_NCTR * sizeof(uint32_t), hipMemcpyDeviceToHost, sf));
+                if (inorder) {          // lines in read order: scan of the lengths, gather, summary for the host
+                    uint64_t* pos = c->ak_dev_pos.p + r0 + 2 * k;
+                    size_t tmp_bytes = 0;
+                    if (rocprim::exclusive_scan(nullptr, tmp_bytes, A.dev_len, pos, (uint64_t)0, nr, rocprim::plus<uint64_t>(), sf) != hipSuccess) return MONI_ENODEV;
+                    if ((rc = c->scan_tmp.ensure(tmp_bytes + 16))) return rc;          // (sized by the seeding stage's far larger scans: no reallocation here)
+                    if (rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, A.dev_len, pos, (uint64_t)0, nr, rocprim::plus<uint64_t>(), sf) != hipSuccess) return MONI_ENODEV;
+                    hipLaunchKernelGGL(gather_lines_kernel, dim3((unsigned)std::min<uint64_t>((nr + 3) / 4, (uint64_t)n_cu * 8)), dim3(256), 0, sf, (const uint64_t*)A.fmt.txt_pool,
+                                       (const uint64_t*)A.dev_len, (const uint64_t*)A.dev_off, (const uint64_t*)pos, nr, reinterpret_cast<uint8_t*>(c->ak_block.p + k * txt_per));
+                    hipLaunchKernelGGL(gather_summary_kernel, dim3(1), dim3(64), 0, sf, (const uint64_t*)A.dev_len, (const uint64_t*)pos, nr, (const unsigned long long*)A.dev_sum,
+                                       c->ak_dev_sum.p + 160 * k + 150);
+                    HIPCHK(hipMemcpyAsync(c->h_sum.p + 4 * k, c->ak_dev_sum.p + 160 * k + 150, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, sf));
+                }
                 HIPCHK(hipEventRecord(c->ak_done[k], sf));
                 done_recorded = true;
             } else if (nr > 0) {
@@ -1103,8 +1136,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 if (need + 1 > acap) {
                     const size_t sub_bytes = need - alen, rest = NR - (r0 + nr);
                     size_t cap = need + (size_t)((double)sub_bytes / (double)(nr ? nr : 1) * (double)rest * 1.06) + 65536;
-                    char* nb = (char*)realloc(abuf, cap);
-                    if (!nb) eager_oom = true; else { abuf = nb; acap = cap; if (ctx_out) { c->out_buf = nb; c->out_cap = cap; } }
+                    if (!grow_abuf(cap)) eager_oom = true;
                 }
                 if (!eager_oom) {
                     mh::parallel_for(pool, (size_t)T, [&](int, size_t lo, size_t hi) {
@@ -1123,6 +1155,29 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         for (int t = 0; t < T; ++t) c->pieces[t].len = 0;
         for (uint64_t k = 0; k < n_sub && !rc_host; ++k) {
             SubRes R;
+            if (inorder && sub_lo[k + 1] > sub_lo[k]) {
+                if (hipEventSynchronize(c->ak_done[k]) != hipSuccess) { rc_host = MONI_ENODEV; break; }
+                const unsigned long long* sm = c->h_sum.p + 4 * k;
+                if (sm[1] == 0 && eager_ok && !eager_oom && eager_upto == k && sm[0] <= txt_per * 8) {
+                    // every line of the sub-batch was spelled by the kernels: the block goes straight into the (pinned) output buffer
+                    { float ms = 0; if (hipEventElapsedTime(&ms, c->ak_begin[k], c->ak_done[k]) == hipSuccess) { c->dp_kernel_ms_accum += ms; c->ak_kernel_ms = ms; } }
+                    if (k + 1 == n_sub) { t_mark[1] = mh::now_s() - t_enter; st.t_dp += mh::now_s() - t_gpu0; }
+                    const double h0 = mh::now_s();
+                    const size_t need = alen + (size_t)sm[0];
+                    if (need + 1 > acap) {
+                        const uint64_t done_reads = sub_lo[k + 1], rest = NR - done_reads;
+                        const size_t cap = need + (size_t)((double)need / (double)(done_reads ? done_reads : 1) * (double)rest * 1.06) + 65536;
+                        if (!grow_abuf(cap)) { eager_oom = true; break; }
+                    }
+                    if (sm[0]) {
+                        if (hipMemcpyAsync(abuf + alen, c->ak_block.p + k * txt_per, (size_t)sm[0], hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess ||
+                            hipStreamSynchronize(c->copy_stream) != hipSuccess) { rc_host = MONI_ENODEV; break; }
+                    }
+                    alen = need; eager_upto = k + 1; aligned_t[0] += sm[2];
+                    host_busy += mh::now_s() - h0;
+                    continue;
+                }
+            }
             if ((rc_host = fetch(k, R))) break;
             if (k + 1 == n_sub) { t_mark[1] = mh::now_s() - t_enter; st.t_dp += mh::now_s() - t_gpu0; }
             host_stage(k, R);
@@ -1197,7 +1252,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         st.handed_back = back.size();
         if (eager_oom) { drop_abuf(); return MONI_ENOMEM; }
         if (back.empty() && eager_upto == n_sub && (abuf || NR == 0)) {
-            if (!abuf) { abuf = (char*)malloc(64); if (!abuf) return MONI_ENOMEM; if (ctx_out) { c->out_buf = abuf; c->out_cap = 64; } }
+            if (!abuf && !grow_abuf(64)) return MONI_ENOMEM;
             abuf[alen] = 0;
             *sam = abuf; *sam_len = alen;
             out_done = true;
@@ -1227,7 +1282,12 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
     if (!out_done) {
         char* dst;
         if (ctx_out) {
-            if (c->out_cap < out.size() + 1) { char* nb = (char*)realloc(c->out_buf, out.size() + 1); if (!nb) return MONI_ENOMEM; c->out_buf = nb; c->out_cap = out.size() + 1; }
+            if (c->out_cap < out.size() + 1) {
+                char* nb = nullptr;
+                if (hipHostMalloc((void**)&nb, out.size() + 1, hipHostMallocDefault) != hipSuccess) return MONI_ENOMEM;
+                if (c->out_buf) (void)hipHostFree(c->out_buf);
+                c->out_buf = nb; c->out_cap = out.size() + 1;
+            }
             dst = c->out_buf;
         } else if (!(dst = (char*)malloc(out.size() + 1))) return MONI_ENOMEM;
         memcpy(dst, out.data(), out.size());

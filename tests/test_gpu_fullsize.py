@@ -75,6 +75,12 @@ def check(pg, fi, n_reads, L, seed, threads=16, seeds_too=True):
         if got != want:
             raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
         assert st["aligned"] == wc["aligned"]
+        # moni_align_run: reads resident in HBM, lines put in read order by gather_lines_kernel, one transfer per sub-batch
+        ctx.upload(reads.reshape(-1), offs)
+        got_run, st_run = ctx.align_run(names, noff, quals, host_threads=threads)
+        if got_run != want:
+            raise AssertionError("moni_align_run SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got_run, want))
+        assert st_run["aligned"] == wc["aligned"]
         return got, st
     finally:
         ctx.close()

@@ -183,7 +183,7 @@ def test_positions_beyond_2_to_32():
     """The 40-bit packing of the device image (image.hpp: rows, recs, fast rows with their high sample bytes; seed_core.h: `hi << 32`):
     an r-index whose BWT is longer than 2^32 and whose SA samples exceed 2^32.  No such text can be built here (a 4 G suffix array),
     but ms_pointers::_query (moni.hpp:568-624) is mechanical over the run-length BWT, the thresholds and the samples, so a real
-    index of a 2 Mbp text is stretched: every run 2048 times as long (F, run starts and thresholds scale with it, single-position
+    index of a 2 Mbp text is stretched: every run 2560 times as long (F, run starts and thresholds scale with it, single-position
     runs stay below the 12-bit limit of the fast rows, longer ones take the general path), samples scaled past 2^32.  The kernel's
     pointers must equal the oracle's on the same arrays."""
     import dataclasses
@@ -191,7 +191,7 @@ def test_positions_beyond_2_to_32():
     from oracle import orc
     pg = synth.make_pangenome(2_000_000, 0, seed=23)
     fi = index_build.build_from_pangenome(pg, device="cuda:0", lifted=False)
-    M = np.uint64(2048)
+    M = np.uint64(2560)
     n2 = int(fi.n) * int(M)
     assert n2 > (1 << 32)
     big = dataclasses.replace(
@@ -199,7 +199,7 @@ def test_positions_beyond_2_to_32():
         ssa=fi.ssa * M + np.uint64(7), esa=fi.esa * M + np.uint64(3),
         text=np.full(n2 - 1, ord("A"), dtype=np.uint8),
         seq_starts=np.array([0, n2 // 2, n2 - 10], dtype=np.uint64), names=["a", "b"])       # (a lift covers fewer than 2^32 columns)
-    assert int(big.ssa.max()) > (1 << 32) and int(np.diff(big.starts.astype(np.int64)).min()) == 2048
+    assert int(big.ssa.max()) > (1 << 32) and int(np.diff(big.starts.astype(np.int64)).min()) == 2560
     rng = np.random.default_rng(4)
     reads = [pg.seqs[0][a:a + 120].copy() for a in rng.integers(0, 1_900_000, size=300)]
     for r in reads[::3]:

@@ -212,8 +212,24 @@ int moni_sam_header(const moni_index_t *idx, char **sam, uint64_t *sam_len);
 int moni_ldx_info(const char *path, uint64_t *n_seq, uint64_t *u, uint64_t *w, int *has_w);
 /* Load and write again (with_w: current layout).  Writing is sdsl-exact: the fixture round-trips byte for byte. */
 int moni_ldx_rewrite(const char *in_path, const char *out_path, int with_w);
+/* liftidx::serialize of a flat index's sequences and lifts (null lifts, liftidx.hpp:150-157, when idx carries none). */
+int moni_ldx_write(const moni_flat_index_t *idx, const char *path, int with_w);
 /* liftidx::lift (liftidx.hpp:89-95) of n text positions with the lifts of an .ldx file, on the GPU (lift_core.h tables). */
 int moni_ldx_lift_batch(const char *path, int device, const uint64_t *pos, uint64_t n, uint64_t *out);
+
+/* ---- the reference's on-disk r-index (<prefix>.thrbv.full.lcp.ms: moni_lcp::serialize / load, include/aligner/moni_lcp.hpp:178-225) ---- */
+/* Layout of the absent r-index / sdsl pieces restated from recall (UNPINNED: the reference tree holds no such file); the reader takes a
+ * file only if it parses to its last byte AND every redundancy in it agrees (moni_align_amd/csrc/ms_index_io.hpp).  Host-only calls. */
+int moni_ms_file_info(const char *path, uint64_t *n, uint64_t *r);
+/* Arrays for r runs (from moni_ms_file_info): F[256], heads[r], starts[r+1], ssa[r], esa[r], thr[r] (0 = none), slcp[r].  On
+ * MONI_EIO err (if given) says which part of the file disagreed. */
+int moni_ms_file_read(const char *path, uint64_t r, uint64_t *F, uint8_t *heads, uint64_t *starts, uint64_t *ssa, uint64_t *esa,
+                      uint64_t *thr, uint64_t *slcp, char *err, uint64_t err_cap);
+/* moni_lcp::serialize of a flat index (only n, r, F, heads, starts, ssa, esa, thr, slcp are read). */
+int moni_ms_file_write(const moni_flat_index_t *idx, const char *path);
+/* What aligner's constructor loads (seed_finder.hpp:66-124): <prefix>.thrbv.full.lcp.ms + <prefix>.ldx + the text.  The text is taken
+ * as plain bytes (n - 1 of them, what PlainSlp::expandSubstr would return; the .plain.slp grammar format is not read). */
+int moni_index_load_reference(const char *ms_path, const char *ldx_path, const char *text_path, int device, moni_index_t **out);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 /* HIP-event time (ms) of the kernels of the last *_run on this ctx's stream.

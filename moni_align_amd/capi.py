@@ -22,7 +22,8 @@ EXPORTS = [
     "moni_ms_query_batch", "moni_seed_run", "moni_seed_counts", "moni_seed_fetch", "moni_seed_batch", "moni_free",
     "moni_phi_lcp_batch", "moni_extz_batch", "moni_last_kernel_ms", "moni_last_counters",
     "moni_align_params_default", "moni_align_batch", "moni_align_run", "moni_sam_header",
-    "moni_ldx_info", "moni_ldx_rewrite", "moni_ldx_lift_batch", "moni_ms_lengths_batch", "moni_report_mems_batch",
+    "moni_ldx_info", "moni_ldx_rewrite", "moni_ldx_lift_batch", "moni_ldx_write",
+    "moni_ms_file_info", "moni_ms_file_read", "moni_ms_file_write", "moni_index_load_reference", "moni_ms_lengths_batch", "moni_report_mems_batch",
 ]
 
 
@@ -132,6 +133,11 @@ def lib():
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.moni_ldx_info.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.moni_ldx_rewrite.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        L.moni_ldx_write.argtypes = [C.POINTER(FlatIndexC), C.c_char_p, C.c_int]
+        L.moni_ms_file_info.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.moni_ms_file_read.argtypes = [C.c_char_p, C.c_uint64] + [C.c_void_p] * 7 + [C.c_char_p, C.c_uint64]
+        L.moni_ms_file_write.argtypes = [C.POINTER(FlatIndexC), C.c_char_p]
+        L.moni_index_load_reference.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         L.moni_ldx_lift_batch.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _lib = L
     return _lib
@@ -161,11 +167,15 @@ def flat_struct(fi) -> FlatIndexC:
 
 
 class Index:
-    def __init__(self, fi=None, path: Optional[str] = None, device: int = 0):
+    def __init__(self, fi=None, path: Optional[str] = None, device: int = 0, reference=None):
+        """fi: a FlatIndex; path: an .mfi file; reference: (<prefix>.thrbv.full.lcp.ms, <prefix>.ldx, text file) of the reference."""
         self._L = lib()
         self._h = C.c_void_p()
         self._keep = fi
-        if fi is not None:
+        if reference is not None:
+            ms, ldx, text = reference
+            _chk(self._L.moni_index_load_reference(ms.encode(), ldx.encode(), text.encode(), device, C.byref(self._h)), "moni_index_load_reference")
+        elif fi is not None:
             st = flat_struct(fi)
             _chk(self._L.moni_index_create(C.byref(st), device, C.byref(self._h)), "moni_index_create")
         else:
@@ -363,6 +373,35 @@ def ldx_info(path: str):
 
 def ldx_rewrite(src: str, dst: str, with_w: bool):
     _chk(lib().moni_ldx_rewrite(src.encode(), dst.encode(), int(with_w)), "moni_ldx_rewrite")
+
+
+def ldx_write(fi, path: str, with_w: bool = True):
+    st = flat_struct(fi)
+    _chk(lib().moni_ldx_write(C.byref(st), path.encode(), int(with_w)), "moni_ldx_write")
+
+
+def ms_file_info(path: str):
+    n, r = C.c_uint64(), C.c_uint64()
+    _chk(lib().moni_ms_file_info(path.encode(), C.byref(n), C.byref(r)), "moni_ms_file_info")
+    return n.value, r.value
+
+
+def ms_file_read(path: str):
+    """<prefix>.thrbv.full.lcp.ms -> dict of the flat arrays (n, r, F, heads, starts, ssa, esa, thr, slcp)."""
+    n, r = ms_file_info(path)
+    a = {"F": np.zeros(256, np.uint64), "heads": np.zeros(r, np.uint8), "starts": np.zeros(r + 1, np.uint64), "ssa": np.zeros(r, np.uint64),
+         "esa": np.zeros(r, np.uint64), "thr": np.zeros(r, np.uint64), "slcp": np.zeros(r, np.uint64)}
+    err = C.create_string_buffer(256)
+    rc = lib().moni_ms_file_read(path.encode(), r, *[a[k].ctypes.data for k in ("F", "heads", "starts", "ssa", "esa", "thr", "slcp")], err, 256)
+    if rc != 0:
+        raise RuntimeError("moni_ms_file_read failed with code %d: %s" % (rc, err.value.decode()))
+    a["n"], a["r"] = n, r
+    return a
+
+
+def ms_file_write(fi, path: str):
+    st = flat_struct(fi)
+    _chk(lib().moni_ms_file_write(C.byref(st), path.encode()), "moni_ms_file_write")
 
 
 def ldx_lift_batch(path: str, pos: np.ndarray, device: int = 0) -> np.ndarray:

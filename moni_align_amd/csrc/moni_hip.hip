@@ -19,6 +19,7 @@
 #include "image.hpp"
 #include "lift_build.hpp"
 #include "ref_index_io.hpp"
+#include "ms_index_io.hpp"
 #include "align_host.hpp"
 #include "layout.h"
 #include "seed_kernels.hip"
@@ -1359,6 +1360,60 @@ __global__ void lift_batch_kernel(const ac_params_t P, const uint64_t* __restric
     if (i < n) out[i] = ac_lift(P, pos[i]);
 }
 
+// ---- <prefix>.thrbv.full.lcp.ms (ms_index_io.hpp) --------------------------------------------------------------------------------------
+int moni_ms_file_info(const char* path, uint64_t* n, uint64_t* r) {
+    if (!path) return MONI_EINVAL;
+    uint64_t a = 0, b = 0;
+    int rc = msio::info_ms(path, a, b);
+    if (rc) return rc;
+    if (n) *n = a;
+    if (r) *r = b;
+    return MONI_OK;
+}
+
+int moni_ms_file_read(const char* path, uint64_t r, uint64_t* F, uint8_t* heads, uint64_t* starts, uint64_t* ssa, uint64_t* esa, uint64_t* thr, uint64_t* slcp,
+                      char* err, uint64_t err_cap) {
+    if (!path || !F || !heads || !starts || !ssa || !esa || !thr || !slcp) return MONI_EINVAL;
+    try {
+        msio::MsFile M; std::string e;
+        int rc = msio::load_ms(path, M, e);
+        if (rc) { if (err && err_cap) snprintf(err, (size_t)err_cap, "%s", e.c_str()); return rc; }
+        if (M.r != r) return MONI_EINVAL;
+        memcpy(F, M.F.data(), 256 * 8); memcpy(heads, M.heads.data(), r); memcpy(starts, M.starts.data(), (r + 1) * 8);
+        memcpy(ssa, M.ssa.data(), r * 8); memcpy(esa, M.esa.data(), r * 8); memcpy(thr, M.thr.data(), r * 8); memcpy(slcp, M.slcp.data(), r * 8);
+        return MONI_OK;
+    } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
+}
+
+int moni_ms_file_write(const moni_flat_index_t* f, const char* path) {
+    if (!f || !path || !f->F || !f->heads || !f->starts || !f->ssa || !f->esa || !f->thr || !f->slcp || f->r < 1 || f->n < 2) return MONI_EINVAL;
+    try { return msio::save_ms(path, *f, f->r); } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
+}
+
+int moni_index_load_reference(const char* ms_path, const char* ldx_path, const char* text_path, int device, moni_index_t** out) {
+    if (!ms_path || !ldx_path || !text_path || !out) return MONI_EINVAL;
+    try {
+        msio::MsFile M; std::string e;
+        int rc = msio::load_ms(ms_path, M, e);
+        if (rc) { fprintf(stderr, "moni_hip: %s: %s\n", ms_path, e.c_str()); return rc; }
+        refio::Ldx L;
+        if ((rc = refio::load_ldx(ldx_path, L))) { fprintf(stderr, "moni_hip: %s: not a liftidx file\n", ldx_path); return rc; }
+        std::vector<uint8_t> text;
+        if (!refio::read_file(text_path, text)) return MONI_EIO;
+        if (text.size() != M.n - 1) { fprintf(stderr, "moni_hip: %s holds %zu bytes, the BWT %llu\n", text_path, text.size(), (unsigned long long)M.n); return MONI_EINVAL; }
+        refio::LdxFlat lf; lf.from(L);
+        const uint64_t w = L.has_w ? L.w : 10;
+        if (lf.seq_starts.empty() || (lf.seq_starts.back() != text.size() && lf.seq_starts.back() + (w ? w - 1 : 0) != text.size())) {
+            fprintf(stderr, "moni_hip: %s does not describe this text\n", ldx_path); return MONI_EINVAL;
+        }
+        moni_flat_index_t f; memset(&f, 0, sizeof f);
+        f.n = M.n; f.r = M.r; f.F = M.F.data(); f.heads = M.heads.data(); f.starts = M.starts.data(); f.ssa = M.ssa.data(); f.esa = M.esa.data();
+        f.thr = M.thr.data(); f.slcp = M.slcp.data(); f.text = text.data();
+        lf.fill(f, w);
+        return moni_index_create(&f, device, out);
+    } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
+}
+
 int moni_ldx_rewrite(const char* in_path, const char* out_path, int with_w) {
     if (!in_path || !out_path) return MONI_EINVAL;
     refio::Ldx L;
@@ -1366,6 +1421,31 @@ int moni_ldx_rewrite(const char* in_path, const char* out_path, int with_w) {
     if (rc) return rc;
     if (with_w && !L.has_w) L.w = 10;          // the older layout has no field for it: the separator width of every build of the reference
     return refio::save_ldx(out_path, L, with_w != 0);
+}
+
+int moni_ldx_write(const moni_flat_index_t* f, const char* path, int with_w) {
+    if (!f || !path || !f->seq_starts || !f->seq_names || f->n_seq < 1) return MONI_EINVAL;
+    if (f->lift_second && (!f->lift_len || !f->lift_ins_off || !f->lift_del_off)) return MONI_EINVAL;
+    try {
+        refio::Ldx L;
+        L.u = f->seq_starts[f->n_seq] + 1; L.w = f->w; L.has_w = with_w != 0;
+        L.starts.size = L.u; L.starts.ones.assign(f->seq_starts, f->seq_starts + f->n_seq + 1);
+        const char* nm = f->seq_names;
+        for (uint64_t i = 0; i < f->n_seq; ++i) { L.names.emplace_back(nm); nm += L.names.back().size() + 1; }
+        L.lifts.resize(f->n_seq);
+        for (uint64_t i = 0; i < f->n_seq; ++i) {
+            refio::LiftSd& x = L.lifts[i];
+            const uint64_t span = f->seq_starts[i + 1] - f->seq_starts[i];
+            const uint64_t len = f->lift_second ? f->lift_len[i] : span - (span >= f->w ? f->w : 0);
+            x.second = f->lift_second ? f->lift_second[i] : f->seq_starts[i];
+            x.ins.size = x.del.size = x.snp.size = len;
+            if (f->lift_second) {
+                if (f->lift_ins) x.ins.ones.assign(f->lift_ins + f->lift_ins_off[i], f->lift_ins + f->lift_ins_off[i + 1]);
+                if (f->lift_del) x.del.ones.assign(f->lift_del + f->lift_del_off[i], f->lift_del + f->lift_del_off[i + 1]);
+            }
+        }
+        return refio::save_ldx(path, L, with_w != 0);
+    } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
 }
 
 int moni_ldx_info(const char* path, uint64_t* n_seq, uint64_t* u, uint64_t* w, int* has_w) {

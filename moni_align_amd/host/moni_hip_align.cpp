@@ -5,7 +5,8 @@
 //
 // Same getopt string, flag meanings, struct defaults and default output name as the reference, so the `moni align` wrapper
 // (pipeline/moni.in:494-546) can call it unchanged.  Index: <prefix>.mfi (the flat arrays moni_align_amd/index_build.py
-// writes; reading the reference's sdsl-serialised files is SURVEY §8(f) item 1).  Reads are streamed in large batches (the
+// writes) or, when that file is absent, the reference's own files <prefix>.thrbv.full.lcp.ms + <prefix>.ldx with the text as plain
+// bytes in <prefix>.txt (moni_index_load_reference; the .plain.slp grammar is not read).  Reads are streamed in large batches (the
 // reference's -b is a per-thread batch of 512; a GPU wants ~10^5): a reader thread parses ahead into a bounded queue (plain files
 // are mapped and split with memchr, a few GB/s; gzip files go through zlib), two worker threads per GPU each with its own context
 // keep two batches in flight per GPU (upload + seeding of one beside the align kernels of the other), a writer thread puts the
@@ -260,8 +261,12 @@ int main(int argc, char** argv) {
     const int per_gpu = legacy ? 1 : 2;                      // contexts (batches in flight) per GPU
     std::vector<moni_index_t*> idx(a.gpus, nullptr);
     std::vector<moni_ctx_t*> ctx((size_t)a.gpus * per_gpu, nullptr);
+    const bool have_mfi = access(idx_path.c_str(), R_OK) == 0;
+    const std::string ms_path = a.filename + ".thrbv.full.lcp.ms", ldx_path = a.filename + ".ldx", txt_path = a.filename + ".txt";
     for (int g = 0; g < a.gpus; ++g) {
-        if (moni_index_load(idx_path.c_str(), g, &idx[g])) die("cannot load " + idx_path + " on GPU " + std::to_string(g) + " (moni-hip has no CPU path)");
+        if (have_mfi) { if (moni_index_load(idx_path.c_str(), g, &idx[g])) die("cannot load " + idx_path + " on GPU " + std::to_string(g) + " (moni-hip has no CPU path)"); }
+        else if (moni_index_load_reference(ms_path.c_str(), ldx_path.c_str(), txt_path.c_str(), g, &idx[g]))
+            die("cannot load " + idx_path + " nor " + ms_path + " + " + ldx_path + " + " + txt_path + " on GPU " + std::to_string(g) + " (moni-hip has no CPU path)");
         for (int k = 0; k < per_gpu; ++k) if (moni_ctx_create(idx[g], &ctx[(size_t)g * per_gpu + k])) die("cannot create a context on GPU " + std::to_string(g));
     }
     FILE* out = nullptr; FILE* out2 = nullptr;

@@ -422,6 +422,19 @@ def from_raw_files(prefix: str, text_path: str, lidx_path: str, w: int = 10) -> 
                      slcp=slcp.astype(np.uint64), text=text, seq_starts=on, names=names)
 
 
+def from_reference_files(ms_path: str, lidx_path: str, text_path: str, w: int = 10) -> FlatIndex:
+    """<prefix>.thrbv.full.lcp.ms (moni_lcp::serialize; read by csrc/ms_index_io.hpp through the C ABI) + .lidx + plain text -> FlatIndex
+    with null lifts.  (moni_index_load_reference takes the .ldx, lifts included, straight to the device.)"""
+    from . import capi
+    a = capi.ms_file_read(ms_path)
+    text = np.fromfile(text_path, dtype=np.uint8)
+    if text.size != a["n"] - 1:
+        raise ValueError("text has %d bytes, the BWT %d" % (text.size, a["n"]))
+    names, on = read_lidx(lidx_path, w)
+    return FlatIndex(n=a["n"], r=a["r"], w=int(w), F=a["F"], heads=a["heads"], starts=a["starts"], ssa=a["ssa"], esa=a["esa"], thr=a["thr"],
+                     slcp=a["slcp"], text=text, seq_starts=on, names=names)
+
+
 def to_raw_files(fi: FlatIndex, prefix: str, text_path: str, lidx_path: str) -> None:
     """The inverse of from_raw_files (tests; also lets upstream's `moni build --no-parse`-style tooling consume our index)."""
     fi.heads.astype(np.uint8).tofile(prefix + ".bwt.heads")

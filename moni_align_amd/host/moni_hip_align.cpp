@@ -287,14 +287,25 @@ int main(int argc, char** argv) {
     bool reader_done = false;
     const size_t q_cap = (size_t)a.gpus * per_gpu + 2, window = 2 * (size_t)a.gpus * per_gpu + 2;
     size_t next_out = 0, n_batches = 0, processed = 0, aligned = 0;
+    double t_reader = 0, t_writer = 0, t_align = 0, t_wait_window = 0;      // busy seconds of the stages (t_align summed over the workers)
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     bool workers_done = false;
     std::map<size_t, Done> done;
     std::thread reader([&]() {
         size_t id = 0;
         while (true) {
+            const double r0 = now();
             Batch* b = new Batch();
             b->seq.reserve(a.gpu_batch * 160); b->qual.reserve(a.gpu_batch * 160); b->names.reserve(a.gpu_batch * 24);
-            while (b->n() < a.gpu_batch && next_record(*b)) {}
+            // the matching-statistics workspace of a batch is strided by its longest read (2 x reads x longest x 8 bytes): the legacy modes,
+            // which take long patterns, close a batch when that product passes 2^28 entries (4 GB)
+            size_t longest = 0;
+            while (b->n() < a.gpu_batch && next_record(*b)) {
+                if (!legacy) continue;
+                longest = std::max(longest, (size_t)(b->off[b->n()] - b->off[b->n() - 1]));
+                if (b->n() * longest > ((size_t)1 << 28)) break;
+            }
+            t_reader += now() - r0;
             if (b->n() == 0) { delete b; break; }
             std::unique_lock<std::mutex> lk(mu_q);
             cv_q_put.wait(lk, [&] { return queue.size() < q_cap; });
@@ -317,9 +328,11 @@ int main(int argc, char** argv) {
                 ++next_out;
                 cv_window.notify_all();
             }
+            const double w0 = now();
             if (d.la) fwrite(d.a, 1, d.la, out);
             if (d.a) moni_free(d.a);
             if (out2 && !d.b.empty()) fwrite(d.b.data(), 1, d.b.size(), out2);
+            t_writer += now() - w0;
         }
     });
     auto worker = [&](int w) {
@@ -337,6 +350,7 @@ int main(int argc, char** argv) {
             moni_read_batch_t rb{b.seq.data(), b.off.data(), b.n()};
             Done d;
             size_t n_al = 0;
+            const double a0 = now();
             if (legacy) {
                 std::vector<uint64_t> ptr(b.seq.size() + 1), len(b.seq.size() + 1);
                 if (moni_ms_lengths_batch(C, &rb, ptr.data(), len.data())) die("moni_ms_lengths_batch failed");
@@ -365,8 +379,10 @@ int main(int argc, char** argv) {
             }
             const size_t n_reads = b.n();
             delete it.b;
+            const double a1 = now();
             std::unique_lock<std::mutex> lk(mu_out);
-            cv_window.wait(lk, [&] { return it.id < next_out + window; });      // bounded: a slow writer holds the workers back instead of the heap growing
+            cv_window.wait(lk, [&] { return it.id < next_out + window; });
+            t_align += a1 - a0; t_wait_window += now() - a1;      // bounded: a slow writer holds the workers back instead of the heap growing
             done[it.id] = std::move(d);
             processed += n_reads; aligned += n_al;
             cv_out.notify_one();
@@ -385,6 +401,8 @@ int main(int argc, char** argv) {
     info("Number of aligned reads: " + std::to_string(aligned) + "/" + std::to_string(processed));
     info("Elapsed time (s): " + std::to_string(el));
     info("Reads per second: " + std::to_string(processed / (el > 0 ? el : 1)));
+    info("Stage busy seconds: reader (parse) " + std::to_string(t_reader) + ", library calls summed over " + std::to_string(ctx.size()) + " workers " + std::to_string(t_align) +
+         ", writer " + std::to_string(t_writer) + ", workers held back by the writer " + std::to_string(t_wait_window));
     for (size_t w = 0; w < ctx.size(); ++w) moni_ctx_destroy(ctx[w]);
     for (int g = 0; g < a.gpus; ++g) moni_index_destroy(idx[g]);
     return 0;

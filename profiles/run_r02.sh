@@ -1,0 +1,66 @@
+#!/bin/bash
+# Round-2 evidence for bench.py's numbers, one gpurun call from the repo root:  bash profiles/run_r02.sh <tag>
+#   1. index built once and cached (the profiled runs only load it)
+#   2. rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 5 --warmup 2 --no-cpu`  -> kernel_stats.csv
+#   3. --pmc FETCH_SIZE WRITE_SIZE (own pass, counters only) over the hot-path kernels       -> pmc_hbm.csv (per kernel, per launch)
+#   4. --pmc SQ issue counters (own pass)                                                   -> pmc_sq.csv
+# Summaries are printed and written to gpurun_out/prof_<tag>/summary.txt; copy that directory's small files into profiles/<tag>/.
+set -o pipefail
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+KERNELS="ms_lf|mem_kernel|occ_kernel|pack_kernel|chain_plan|dp_lane|select_kernel|traceback|finish_wave|finish_kernel|global_task|af_chunk|gather_lines|align_kernel"
+echo "[1/4] building + caching the index"
+MONI_BENCH_SAVE_INDEX=1 python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/bench_build.json 2> $OUT/bench_build.log || exit 1
+echo "[2/4] kernel trace"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu > $OUT/bench_trace.json 2> $OUT/bench_trace.log || exit 1
+cp "$(find $OUT/trace -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv
+echo "[3/4] HBM counters"
+rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --kernel-include-regex "$KERNELS" --output-format csv -d $OUT/pmc_hbm -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/bench_pmc_hbm.json 2> $OUT/bench_pmc_hbm.log || exit 1
+echo "[4/4] SQ counters"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY --kernel-include-regex "$KERNELS" --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/bench_pmc_sq.json 2> $OUT/bench_pmc_sq.log || exit 1
+cd $ROOT
+python3 - <<PY | tee $OUT/summary.txt
+import csv, glob, collections
+def short(n):
+    n = n.replace("void ", "")
+    return n[:n.index("(")] if "(" in n else n
+print("== rocprofv3 --kernel-trace --stats: python3 bench.py --steps 5 --warmup 2 --no-cpu (7 passes of 1 M reads; index build excluded: cached) ==")
+rows = list(csv.DictReader(open("$OUT/kernel_stats.csv")))
+rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+for r in rows[:28]:
+    print("%-72s calls %6s  total %9.2f ms  avg %9.3f ms  %5.1f%%" % (short(r["Name"])[:72], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e6, 100 * float(r["TotalDurationNs"]) / tot))
+def pmc(path):
+    f = glob.glob(path + "/**/*counter_collection.csv", recursive=True)[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter(); seen = set()
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])[:60]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if (k, r["Dispatch_Id"]) not in seen: seen.add((k, r["Dispatch_Id"])); calls[k] += 1
+    return agg, calls
+print()
+print("== --pmc FETCH_SIZE WRITE_SIZE (KB, as rocprofv3 reports them; x1024 = bytes; no x2 correction: these are 64-byte request streams), one pass of 1 M reads ==")
+agg, calls = pmc("$OUT/pmc_hbm")
+w = csv.writer(open("$OUT/pmc_hbm.csv", "w")); w.writerow(["kernel", "launches", "fetch_bytes_per_pass", "write_bytes_per_pass"])
+for k, v in sorted(agg.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", 0) + kv[1].get("WRITE_SIZE", 0))):
+    fb, wb = v.get("FETCH_SIZE", 0) * 1024, v.get("WRITE_SIZE", 0) * 1024
+    w.writerow([k, calls[k], "%.0f" % fb, "%.0f" % wb])
+    print("%-60s x%-3d fetch %8.3f GB  write %8.3f GB   (per launch: %7.3f / %7.3f GB)" % (k, calls[k], fb / 1e9, wb / 1e9, fb / 1e9 / calls[k], wb / 1e9 / calls[k]))
+tf = sum(v.get("FETCH_SIZE", 0) for v in agg.values()) * 1024; tw = sum(v.get("WRITE_SIZE", 0) for v in agg.values()) * 1024
+print("all hot-path kernels of the pass: fetch %.2f GB + write %.2f GB = %.2f GB" % (tf / 1e9, tw / 1e9, (tf + tw) / 1e9))
+print()
+print("== --pmc SQ counters per launch (profiled serially) ==")
+agg, calls = pmc("$OUT/pmc_sq")
+w = csv.writer(open("$OUT/pmc_sq.csv", "w")); names = sorted({c for v in agg.values() for c in v}); w.writerow(["kernel", "launches"] + names)
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
+    n = calls[k]
+    w.writerow([k, n] + ["%.0f" % v.get(c, 0) for c in names])
+    wc = v.get("SQ_WAVE_CYCLES", 0) or 1
+    print("%-60s x%-3d VALU insts %.3g  LDS insts %.3g  VALU-active/wave-cycles %.3f  WAIT_ANY/wave-cycles %.3f" % (k, n, v.get("SQ_INSTS_VALU", 0), v.get("SQ_INSTS_LDS", 0), v.get("SQ_ACTIVE_INST_VALU", 0) / wc, v.get("SQ_WAIT_INST_ANY", 0) / wc))
+PY
+find $OUT -name "*kernel_trace.csv" -size +20M -delete
+find $OUT -name "*counter_collection.csv" -size +20M -delete

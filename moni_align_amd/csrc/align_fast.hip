@@ -1138,6 +1138,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         const af_cand_t* C = aligned ? &PL.cand[PL.final_cand] : nullptr;
         const uint32_t strand = aligned ? C->strand : 0u;
         __syncthreads();
+        AF_STAMP(fw0);
         // ---- the read in alignment orientation ----
         for (uint32_t k = lane; k < m; k += 64) {
             uint8_t b = strand ? ak_compl(A.D.reads[off + m - 1 - k]) : A.D.reads[off + k];
@@ -1181,6 +1182,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             L.n_cig = n; L.n_lcig = nl < 0 ? 0u : (uint32_t)nl; L.ovf = ovf ? 1u : 0u;
         }
         __syncthreads();
+        AF_STAMP(fw1); AF_PROF(G, 16, fw0, fw1);
         if (aligned) { ovf = L.ovf != 0; lifted = ((uint64_t)(uint32_t)__shfl((int)(lifted >> 32), 0) << 32) | (uint32_t)__shfl((int)(lifted & 0xFFFFFFFFull), 0); }
         if (aligned && ovf) {
             if (lane == 0) { PL.status = AF_ST_FALLBACK; G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)r; atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CIGAR], 1u); }
@@ -1248,6 +1250,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             }
             p = (uint32_t)__shfl((int)p, 0);
             __syncthreads();
+            AF_STAMP(fw2); AF_PROF(G, 17, fw1, fw2);
             for (uint32_t k = lane; k < m; k += 64) if (p + k < AK_TXT_CAP) L.line[p + k] = L.seq[k];
             p += m;
             if (lane == 0 && p < AK_TXT_CAP) L.line[p] = '\t';
@@ -1261,6 +1264,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             if (mapped) nm = afw_md(G, L, L.lcig, n_lcig, lifted, true, pm);
             if (same) lift_nm = nm;
             __syncthreads();
+            AF_STAMP(fw3); AF_PROF(G, 18, fw2, fw3);
             const uint32_t md_len = pm - AK_TXT_CAP / 2;
             p = p_nm;
             if (lane == 0) {
@@ -1281,6 +1285,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 p += md_len;
             }
             __syncthreads();
+            AF_STAMP(fw4); AF_PROF(G, 19, fw3, fw4);
             if (lane == 0) {
                 afw_lit(L, p, "\tOA:Z:");
                 for (uint32_t k = F.sname_off[sid]; k < F.sname_off[sid + 1]; ++k) afw_c(L, p, F.snames[k]);
@@ -1298,8 +1303,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             }
             p = (uint32_t)__shfl((int)p, 0);
             if (too_long) p = AK_TXT_CAP + 1;
+            AF_STAMP(fw5); AF_PROF(G, 20, fw4, fw5);
         }
         __syncthreads();
+        AF_STAMP(fw6);
         // ---- out: the text pool (8-byte words, bump-allocated), coalesced; the record ----
         if (p > AK_TXT_CAP) rec.status = 2;           // does not fit the staging: the host pipeline redoes the read
         else {
@@ -1324,6 +1331,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 else if (rec.status == 1) atomicAdd(&A.dev_sum[8 + 8 * (blockIdx.x % 16)], 1ull);      // sharded: one address takes only ~50 M atomics/s
             }
         }
+        AF_STAMP(fw7); AF_PROF(G, 21, fw6, fw7); AF_PROF(G, 22, fw0, fw7);
     }
 }
 

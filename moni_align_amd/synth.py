@@ -79,12 +79,15 @@ class Pangenome:
 
 def make_pangenome(base_len: int, n_haps: int, seed: int = 19, var_seed: int = 12,
                    site_spacing: int = 1800, w: int = 10,
-                   contig: str = "chr19", repeat_frac: float = 0.0, rep_seed: int = 1919) -> Pangenome:
+                   contig: str = "chr19", repeat_frac: float = 0.0, rep_seed: int = 1919, base: np.ndarray = None) -> Pangenome:
     """repeat_frac > 0: interspersed repeats: segments of 300-3000 bp are copied to random places with 5 %
     divergence until that fraction of the base genome is repeat copies, so that MEMs have many occurrences and the phi walks,
     the per-genome cap and the chaining see more than one locus per haplotype."""
     rng = np.random.Generator(np.random.MT19937(seed))
     g0 = _ACGT[rng.integers(0, 4, size=base_len, dtype=np.uint8)]
+    if base is not None:                  # a given base genome (tests plant real reads in it)
+        g0 = np.ascontiguousarray(base, dtype=np.uint8).copy()
+        base_len = len(g0)
     if repeat_frac > 0:
         rr = np.random.Generator(np.random.MT19937(rep_seed))
         code0 = np.full(256, 0, dtype=np.uint8)

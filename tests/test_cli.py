@@ -106,3 +106,52 @@ def test_reference_fixture_reads_parse(exe):
     assert "reads=5000 bases=500000" in out
     first = open(src).readline().split()[0][1:]
     assert ("first=" + first) in out
+
+
+def read_fastq(path):
+    names, seqs, quals = [], [], []
+    with open(path, "rb") as f:
+        while True:
+            h = f.readline()
+            if not h:
+                break
+            names.append(h[1:].split()[0]); seqs.append(f.readline().rstrip(b"\n")); f.readline(); quals.append(f.readline().rstrip(b"\n"))
+    return names, seqs, quals
+
+
+@pytest.mark.gpu
+def test_cli_on_the_reference_mouse_reads_planted_in_a_pangenome(exe, tmp_path):
+    """The reference's own read file (data/mouse/reads/mouse.chr19.R1.fastq, copied as data to tests/golden/ref_data/mouse: 5000 x 100 bp
+    with real quality strings and /1 names).  No mouse reference sequence exists here, so the first 800 reads are planted (every other one
+    reverse-complemented, every fifth with two substitutions) 300 bp apart in a random base genome from which 4 haplotypes are derived:
+    the CLI's SAM file for all 5000 reads (planted ones align, the others mostly do not) equals the oracle's."""
+    from moni_align_amd import index_build, synth
+    from oracle import orc
+    src = os.path.join(ROOT, "tests", "golden", "ref_data", "mouse", "mouse.chr19.R1.fastq")
+    names, seqs, quals = read_fastq(src)
+    assert len(names) == 5000 and all(len(s) == 100 for s in seqs)
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    base = acgt[rng.integers(0, 4, size=800 * 300 + 500)].copy()
+    for k in range(800):
+        r = np.frombuffer(seqs[k], np.uint8).copy()
+        r[~np.isin(r, acgt)] = ord("A")               # an N of a read cannot be planted in an ACGT index
+        if k % 2:
+            r = synth.revcomp(r[None, :])[0]
+        if k % 5 == 0:
+            r[[20, 70]] = acgt[(np.searchsorted(acgt, r[[20, 70]]) + 1) & 3]
+        base[200 + 300 * k:300 + 300 * k] = r
+    pg = synth.make_pangenome(len(base), 4, site_spacing=900, base=base)
+    fi = index_build.build_from_pangenome(pg, device="cpu")
+    mfi = str(tmp_path / "mouse.mfi")
+    fi.save(mfi)
+    out = str(tmp_path / "mouse.sam")
+    subprocess.check_call([exe, mfi[:-4], "-p", src, "-o", out, "-S", "1000", "-F", "0.5", "-t", "4", "--gpu-batch", "1800"])
+    seq = np.frombuffer(b"".join(seqs), np.uint8)
+    offs = np.arange(0, 5001 * 100, 100, dtype=np.uint64)
+    nm = np.frombuffer(b"".join(names), np.uint8)
+    noff = np.zeros(5001, np.uint64); noff[1:] = np.cumsum([len(x) for x in names])
+    want, cnt = orc.align_batch(orc.OracleIndex(fi=fi), seq, offs, nm, noff, np.frombuffer(b"".join(quals), np.uint8), with_header=True, threads=8)
+    got = open(out, "rb").read()
+    assert got == want
+    assert cnt["aligned"] >= 790

@@ -201,6 +201,12 @@ int moni_align_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint
  * (a streaming caller writes it out and calls again; the pages stay mapped between batches). */
 int moni_align_run(moni_ctx_t *ctx, const uint8_t *names, const uint64_t *name_off, const uint8_t *quals,
                    const moni_align_params_t *prm, char **sam, uint64_t *sam_len, moni_align_stats_t *stats);
+/* moni_align_batch for a streaming caller: reads in host memory (uploaded by the call, no host copy kept), *sam in the context-owned
+ * pinned buffer of moni_align_run (valid until the next moni_align_run / moni_align_stream / moni_ctx_destroy on this context, NOT to
+ * be freed): the lines arrive in read order by one DMA per sub-batch, no host thread touches the text. */
+int moni_align_stream(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
+                      const uint8_t *quals, const moni_align_params_t *prm, char **sam, uint64_t *sam_len,
+                      moni_align_stats_t *stats);
 /* aligner::align with report_mems (-m; aligner_ksw2.hpp:346-373): one secondary record per MEM occurrence.  *sam is malloc'ed. */
 int moni_report_mems_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
                            const uint8_t *quals, const moni_align_params_t *prm, char **sam, uint64_t *sam_len);

@@ -21,7 +21,7 @@ EXPORTS = [
     "moni_index_device_bytes", "moni_ctx_create", "moni_ctx_destroy", "moni_reads_upload", "moni_ms_run",
     "moni_ms_query_batch", "moni_seed_run", "moni_seed_counts", "moni_seed_fetch", "moni_seed_batch", "moni_free",
     "moni_phi_lcp_batch", "moni_extz_batch", "moni_last_kernel_ms", "moni_last_counters",
-    "moni_align_params_default", "moni_align_batch", "moni_align_run", "moni_sam_header",
+    "moni_align_params_default", "moni_align_batch", "moni_align_run", "moni_align_stream", "moni_sam_header",
     "moni_ldx_info", "moni_ldx_rewrite", "moni_ldx_lift_batch", "moni_ldx_write",
     "moni_ms_file_info", "moni_ms_file_read", "moni_ms_file_write", "moni_index_load_reference", "moni_ms_lengths_batch", "moni_report_mems_batch",
 ]
@@ -123,6 +123,7 @@ def lib():
         L.moni_align_params_default.restype = None
         L.moni_align_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
+        L.moni_align_stream.argtypes = L.moni_align_batch.argtypes
         L.moni_align_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
         L.moni_sam_header.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
@@ -268,8 +269,9 @@ class Ctx:
         return res, pool[: used.value]
 
     def align_batch(self, seq: np.ndarray, offsets: np.ndarray, names: np.ndarray, name_off: np.ndarray, quals=None,
-                    host_threads: Optional[int] = None, **overrides):
-        """SAM text (bytes) of the batch + stats dict; the whole single-end path on the GPU + host stages."""
+                    host_threads: Optional[int] = None, stream: bool = False, **overrides):
+        """SAM text (bytes) of the batch + stats dict; the whole single-end path on the GPU + host stages.
+        stream=True: moni_align_stream (text in the context-owned pinned buffer, lines ordered on the GPU)."""
         b, keep = self._batch(seq, offsets)
         names = np.ascontiguousarray(names, dtype=np.uint8)
         name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
@@ -284,14 +286,16 @@ class Ctx:
         out = C.c_void_p()
         ln = C.c_uint64()
         st = AlignStatsC()
-        _chk(self._L.moni_align_batch(self._h, C.byref(b), names.ctypes.data, name_off.ctypes.data,
-                                      quals.ctypes.data if quals is not None else None, C.byref(prm), C.byref(out), C.byref(ln),
-                                      C.byref(st)), "moni_align_batch")
+        fn = self._L.moni_align_stream if stream else self._L.moni_align_batch
+        _chk(fn(self._h, C.byref(b), names.ctypes.data, name_off.ctypes.data,
+                quals.ctypes.data if quals is not None else None, C.byref(prm), C.byref(out), C.byref(ln),
+                C.byref(st)), "moni_align_stream" if stream else "moni_align_batch")
         self.n_reads = len(offsets) - 1
         try:
             sam = C.string_at(out, ln.value)
         finally:
-            self._L.moni_free(out)
+            if not stream:
+                self._L.moni_free(out)
         return sam, {k: getattr(st, k) for k, _ in AlignStatsC._fields_}
 
     def align_run(self, names: np.ndarray, name_off: np.ndarray, quals=None, host_threads: Optional[int] = None,

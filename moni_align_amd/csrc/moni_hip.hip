@@ -780,6 +780,29 @@ int moni_align_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* n
     } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
 }
 
+int moni_align_stream(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
+                      const moni_align_params_t* prm, char** sam, uint64_t* sam_len, moni_align_stats_t* stats) {
+    if (!c || !b || !prm || !sam || !sam_len || (b->n_reads && (!names || !name_off))) return MONI_EINVAL;
+    bool any_long = false;
+    for (uint64_t r = 0; r < b->n_reads && !any_long; ++r) any_long = b->offsets[r + 1] - b->offsets[r] >= MONI_LONG_READ;
+    if (!any_long) return align_core(c, b, false, true, names, name_off, quals, prm, sam, sam_len, stats);
+    // long reads in the batch (rare): the splicing path of moni_align_batch, its text moved into the context's buffer
+    char* tmp = nullptr; uint64_t len = 0;
+    int rc = moni_align_batch(c, b, names, name_off, quals, prm, &tmp, &len, stats);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->idx->device));
+    if (c->out_cap < len + 1) {
+        char* nb = nullptr;
+        if (hipHostMalloc((void**)&nb, len + 1, hipHostMallocDefault) != hipSuccess) { free(tmp); return MONI_ENOMEM; }
+        if (c->out_buf) (void)hipHostFree(c->out_buf);
+        c->out_buf = nb; c->out_cap = len + 1;
+    }
+    memcpy(c->out_buf, tmp, len); c->out_buf[len] = 0;
+    free(tmp);
+    *sam = c->out_buf; *sam_len = len;
+    return MONI_OK;
+}
+
 int moni_align_run(moni_ctx_t* c, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals, const moni_align_params_t* prm,
                    char** sam, uint64_t* sam_len, moni_align_stats_t* stats) {
     if (!c || !prm || !sam || !sam_len || (c->n_reads && (!names || !name_off))) return MONI_EINVAL;

@@ -7,10 +7,14 @@
 // (pipeline/moni.in:494-546) can call it unchanged.  Index: <prefix>.mfi (the flat arrays moni_align_amd/index_build.py
 // writes) or, when that file is absent, the reference's own files <prefix>.thrbv.full.lcp.ms + <prefix>.ldx with the text as plain
 // bytes in <prefix>.txt (moni_index_load_reference; the .plain.slp grammar is not read).  Reads are streamed in large batches (the
-// reference's -b is a per-thread batch of 512; a GPU wants ~10^5): a reader thread parses ahead into a bounded queue (plain files
-// are mapped and split with memchr, a few GB/s; gzip files go through zlib), two worker threads per GPU each with its own context
-// keep two batches in flight per GPU (upload + seeding of one beside the align kernels of the other), a writer thread puts the
-// finished blocks out in input order from a bounded window.  -m writes the report-MEMs records (aligner_ksw2.hpp:346-373);
+// reference's -b is a per-thread batch of 512; a GPU wants ~10^6).  Plain FASTQ / FASTA files (the streaming path, fast_align below):
+// the file is mapped and cut into record-aligned byte ranges of about --gpu-batch reads; three workers per GPU, each with its own
+// context, take ranges in order: parse (two passes over the range with a few helper threads: count, then fill the batch arrays in
+// place), moni_align_stream (upload, kernels, the lines in read order in the context's pinned buffer), then pwrite of the block at its
+// place in the output file, again in parallel slices.  A block's place is known as soon as the earlier ranges have reported their
+// lengths, so parsing, GPU work and file writes of different ranges overlap and nothing is copied twice.  gzip input, -m and the legacy
+// modes take the older path: a reader thread parses ahead into a bounded queue, two workers per GPU, a writer thread with a bounded
+// in-order window.  -m writes the report-MEMs records (aligner_ksw2.hpp:346-373);
 // --ms / --mems write the legacy `moni ms` / `moni mems` text outputs (src/matching_statistics.cpp:520-610, src/mems.cpp:520-600).
 // Not implemented here (exit 1 with a message): paired-end (-1/-2), -c, -q, -n, -Z.
 #include <fcntl.h>
@@ -20,6 +24,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+
+#include <atomic>
+#include <cerrno>
 
 #include <chrono>
 #include <condition_variable>
@@ -166,7 +173,8 @@ struct Args {
     bool report_mems = false, csv = false, no_lcp = false, shaped_slp = false, secondary = false;
     bool legacy_ms = false, legacy_mems = false;      // --ms / --mems
     int gpus = 1;
-    size_t gpu_batch = 262144;
+    size_t gpu_batch = 1048576;
+    int ctx_per_gpu = 3;               // streaming path: contexts (ranges in flight) per GPU
     bool dry_run = false;
 };
 
@@ -178,6 +186,7 @@ static void parse(int argc, char** argv, Args& a) {
         if (!strcmp(argv[i], "--gpus") && i + 1 < argc) { a.gpus = atoi(argv[++i]); continue; }
         if (!strcmp(argv[i], "--gpu-batch") && i + 1 < argc) { a.gpu_batch = strtoull(argv[++i], nullptr, 10); continue; }
         if (!strcmp(argv[i], "--dry-run")) { a.dry_run = true; continue; }
+        if (!strcmp(argv[i], "--ctx-per-gpu") && i + 1 < argc) { a.ctx_per_gpu = std::max(1, atoi(argv[++i])); continue; }
         if (!strcmp(argv[i], "--ms")) { a.legacy_ms = true; continue; }
         if (!strcmp(argv[i], "--mems")) { a.legacy_mems = true; continue; }
         av.push_back(argv[i]);
@@ -230,6 +239,112 @@ static void parse(int argc, char** argv, Args& a) {
     if (a.th > 1) a.P.host_threads = (uint32_t)a.th;
 }
 
+
+// ---- streaming path for plain files ---------------------------------------------------------------------------------------------------
+namespace fastpath {
+
+static inline const char* next_line(const char* s, const char* end) { const char* e = (const char*)memchr(s, '\n', (size_t)(end - s)); return e ? e + 1 : end; }
+
+// the first record that starts at or after s.  Four-line FASTQ: a line that starts with '@' whose second-next line starts with '+'
+// (a quality line may start with '@', but then the second-next line is a sequence); FASTA: a line that starts with '>'.
+static const char* align_record(const char* s, const char* base, const char* end, bool fq) {
+    if (s <= base) return base;
+    if (s >= end) return end;
+    s = next_line(s - 1, end);
+    while (s < end) {
+        if (fq) {
+            if (*s == '@') { const char* l3 = next_line(next_line(s, end), end); if (l3 < end && *l3 == '+') return s; }
+        } else if (*s == '>') return s;
+        s = next_line(s, end);
+    }
+    return end;
+}
+
+struct Count { size_t n = 0, seq = 0, name = 0; };
+struct Raw {          // uninitialised grow-only bytes (a vector would zero 300 MB per batch)
+    uint8_t* p = nullptr; size_t cap = 0;
+    void ensure(size_t n) { if (n > cap) { free(p); cap = n + n / 8 + 64; p = (uint8_t*)malloc(cap); if (!p) die("out of memory"); } }
+    ~Raw() { free(p); }
+};
+
+// one pass over the records of [a, b): FILL = false counts, FILL = true writes them at the given cursors
+template <bool FILL>
+static Count walk(const char* a, const char* b, bool fq, uint8_t* seq, uint8_t* qual, uint8_t* names, uint64_t* off, uint64_t* name_off,
+                  uint64_t seq_at, uint64_t name_at) {
+    Count c;
+    const char* s = a;
+    while (s < b) {
+        while (s < b && (*s == '\n' || *s == '\r')) ++s;
+        if (s >= b) break;
+        if (*s != (fq ? '@' : '>')) die("malformed record in the reads file");
+        const char* e1 = (const char*)memchr(s, '\n', (size_t)(b - s)); if (!e1) e1 = b;
+        const char* w = s + 1;
+        while (w < e1 && !isspace((unsigned char)*w)) ++w;
+        const size_t nl = (size_t)(w - (s + 1));
+        const char* q = e1 < b ? e1 + 1 : b;
+        const char* e2 = (const char*)memchr(q, '\n', (size_t)(b - q)); if (!e2) e2 = b;
+        size_t sl = (size_t)(e2 - q);
+        if (sl && q[sl - 1] == '\r') --sl;
+        const char* nx = e2 < b ? e2 + 1 : b;
+        const char* ql = nullptr;
+        if (fq) {
+            const char* e3 = (const char*)memchr(nx, '\n', (size_t)(b - nx)); if (!e3) e3 = b;
+            ql = e3 < b ? e3 + 1 : b;
+            const char* e4 = (const char*)memchr(ql, '\n', (size_t)(b - ql)); if (!e4) e4 = b;
+            size_t qn = (size_t)(e4 - ql);
+            if (qn && ql[qn - 1] == '\r') --qn;
+            if (qn != sl) die("truncated quality string");
+            nx = e4 < b ? e4 + 1 : b;
+        }
+        if (FILL) {
+            memcpy(names + name_at + c.name, s + 1, nl);
+            memcpy(seq + seq_at + c.seq, q, sl);
+            if (fq) memcpy(qual + seq_at + c.seq, ql, sl); else memset(qual + seq_at + c.seq, '*', sl);
+            off[c.n + 1] = seq_at + c.seq + sl; name_off[c.n + 1] = name_at + c.name + nl;
+        }
+        c.n++; c.seq += sl; c.name += nl;
+        s = nx;
+    }
+    return c;
+}
+
+struct ParsedBatch {
+    Raw seq, qual, names;
+    std::vector<uint64_t> off, name_off;
+    size_t n = 0;
+};
+
+static void parse_range(const char* a, const char* b, const char* base, const char* end, bool fq, int P, ParsedBatch& B) {
+    std::vector<const char*> cut(P + 1);
+    cut[0] = a; cut[P] = b;
+    for (int i = 1; i < P; ++i) { cut[i] = align_record(a + (size_t)(b - a) / P * i, base, end, fq); if (cut[i] > b) cut[i] = b; if (cut[i] < cut[i - 1]) cut[i] = cut[i - 1]; }
+    std::vector<Count> cnt(P);
+    auto run = [&](auto&& fn) {
+        std::vector<std::thread> th;
+        for (int i = 1; i < P; ++i) th.emplace_back(fn, i);
+        fn(0);
+        for (auto& t : th) t.join();
+    };
+    run([&](int i) { cnt[i] = walk<false>(cut[i], cut[i + 1], fq, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0); });
+    std::vector<size_t> n_at(P + 1, 0), s_at(P + 1, 0), m_at(P + 1, 0);
+    for (int i = 0; i < P; ++i) { n_at[i + 1] = n_at[i] + cnt[i].n; s_at[i + 1] = s_at[i] + cnt[i].seq; m_at[i + 1] = m_at[i] + cnt[i].name; }
+    B.n = n_at[P];
+    B.seq.ensure(s_at[P] + 16); B.qual.ensure(s_at[P] + 16); B.names.ensure(m_at[P] + 16);
+    if (B.off.size() < B.n + 1) { B.off.resize(B.n + 1 + B.n / 8); B.name_off.resize(B.n + 1 + B.n / 8); }
+    B.off[0] = 0; B.name_off[0] = 0;
+    run([&](int i) { walk<true>(cut[i], cut[i + 1], fq, B.seq.p, B.qual.p, B.names.p, B.off.data() + n_at[i], B.name_off.data() + n_at[i], s_at[i], m_at[i]); });
+}
+
+static void pwrite_all(int fd, const char* p, size_t n, uint64_t at) {
+    while (n) {
+        const ssize_t w = pwrite(fd, p, n, (off_t)at);
+        if (w < 0) { if (errno == EINTR) continue; die("write to the output file failed"); }
+        p += w; n -= (size_t)w; at += (uint64_t)w;
+    }
+}
+
+}  // namespace fastpath
+
 int main(int argc, char** argv) {
     Args a;
     parse(argc, argv, a);
@@ -258,7 +373,8 @@ int main(int argc, char** argv) {
         return 0;
     }
     const std::string idx_path = a.filename + ".mfi";
-    const int per_gpu = legacy ? 1 : 2;                      // contexts (batches in flight) per GPU
+    const bool fast = mapped && !legacy && !a.report_mems && getenv("MONI_CLI_QUEUE_PATH") == nullptr;
+    const int per_gpu = legacy ? 1 : (fast ? a.ctx_per_gpu : 2);                      // contexts (batches in flight) per GPU
     std::vector<moni_index_t*> idx(a.gpus, nullptr);
     std::vector<moni_ctx_t*> ctx((size_t)a.gpus * per_gpu, nullptr);
     const bool have_mfi = access(idx_path.c_str(), R_OK) == 0;
@@ -268,6 +384,86 @@ int main(int argc, char** argv) {
         else if (moni_index_load_reference(ms_path.c_str(), ldx_path.c_str(), txt_path.c_str(), g, &idx[g]))
             die("cannot load " + idx_path + " nor " + ms_path + " + " + ldx_path + " + " + txt_path + " on GPU " + std::to_string(g) + " (moni-hip has no CPU path)");
         for (int k = 0; k < per_gpu; ++k) if (moni_ctx_create(idx[g], &ctx[(size_t)g * per_gpu + k])) die("cannot create a context on GPU " + std::to_string(g));
+    }
+    if (fast) {
+        using namespace fastpath;
+        const auto t0 = std::chrono::steady_clock::now();
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const char* base = mrd.p; const char* end = mrd.p + mrd.n;
+        const bool fq = base[0] == '@';
+        // record-aligned ranges of about gpu_batch reads (the first record's size is the estimate)
+        const char* r1 = base; for (int k = 0; k < (fq ? 4 : 2); ++k) r1 = next_line(r1, end);
+        const size_t rec_bytes = std::max<size_t>((size_t)(r1 - base), 8), chunk_bytes = std::max<size_t>(rec_bytes * a.gpu_batch, 1 << 16);
+        std::vector<const char*> cuts(1, base);
+        while (cuts.back() < end) { const char* nx = (size_t)(end - cuts.back()) <= chunk_bytes + chunk_bytes / 4 ? end : align_record(cuts.back() + chunk_bytes, base, end, fq); if (nx <= cuts.back()) nx = end; cuts.push_back(nx); }
+        const size_t n_chunks = cuts.size() - 1;
+        const int fd = ::open(sam_filename.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) die("open() file " + sam_filename + " failed");
+        uint64_t hdr_len = 0;
+        { char* h; uint64_t hl; if (moni_sam_header(idx[0], &h, &hl)) die("header"); pwrite_all(fd, h, hl, 0); hdr_len = hl; moni_free(h); }
+        std::mutex mu; std::condition_variable cv;
+        std::vector<uint64_t> lens(n_chunks, ~0ull), starts(n_chunks, 0);
+        size_t upto = 0; uint64_t off_upto = hdr_len;
+        std::atomic<size_t> next_chunk{0};
+        std::atomic<size_t> processed{0}, aligned{0};
+        const int P = (int)std::max<size_t>(1, std::min<size_t>(8, a.th / std::max<size_t>(1, ctx.size() / (size_t)a.gpus)));      // helper threads of one worker
+        std::vector<double> t_parse(ctx.size(), 0), t_lib(ctx.size(), 0), t_wait(ctx.size(), 0), t_write(ctx.size(), 0);
+        const bool verbose_ranges = getenv("MONI_CLI_VERBOSE") != nullptr;
+        auto worker = [&](int w) {
+            ParsedBatch B;
+            while (true) {
+                const size_t id = next_chunk.fetch_add(1);
+                if (id >= n_chunks) return;
+                double x0 = now();
+                parse_range(cuts[id], cuts[id + 1], base, end, fq, P, B);
+                double x1 = now(); t_parse[w] += x1 - x0;
+                char* sam = nullptr; uint64_t len = 0;
+                moni_align_stats_t st; memset(&st, 0, sizeof st);
+                if (B.n) {
+                    moni_read_batch_t rb{B.seq.p, B.off.data(), (uint64_t)B.n};
+                    if (moni_align_stream(ctx[w], &rb, B.names.p, B.name_off.data(), fq ? B.qual.p : nullptr, &a.P, &sam, &len, &st)) die("moni_align_stream failed");
+                }
+                double x2 = now(); t_lib[w] += x2 - x1;
+                uint64_t at;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    lens[id] = len;
+                    while (upto < n_chunks && lens[upto] != ~0ull) { starts[upto] = off_upto; off_upto += lens[upto]; ++upto; }
+                    cv.notify_all();
+                    cv.wait(lk, [&] { return upto > id; });
+                    at = starts[id];
+                }
+                double x3 = now(); t_wait[w] += x3 - x2;
+                if (len) {
+                    std::vector<std::thread> th;
+                    const size_t sl = (len + P - 1) / P;
+                    for (int i = 1; i < P; ++i) { const size_t lo = std::min<size_t>(len, sl * i), hi = std::min<size_t>(len, sl * (i + 1)); if (hi > lo) th.emplace_back(pwrite_all, fd, sam + lo, hi - lo, at + lo); }
+                    pwrite_all(fd, sam, std::min<size_t>(len, sl), at);
+                    for (auto& t : th) t.join();
+                }
+                const double x4 = now();
+                t_write[w] += x4 - x3;
+                if (verbose_ranges) fprintf(stderr, "range %zu (worker %d, %zu reads): parse %.0f ms, library %.0f ms (seed %.0f, align kernels %.0f), wait %.0f ms, write %.0f ms, done at %.3f s\n", id, w, B.n,
+                                            (x1 - x0) * 1e3, (x2 - x1) * 1e3, st.t_seed * 1e3, st.t_dp_kernel * 1e3, (x3 - x2) * 1e3, (x4 - x3) * 1e3,
+                                            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+                processed += B.n; aligned += st.aligned;
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t w = 0; w < ctx.size(); ++w) th.emplace_back(worker, (int)w);
+        for (auto& t : th) t.join();
+        if (::close(fd) != 0) die("close() of the output file failed");
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        info("Number of aligned reads: " + std::to_string(aligned.load()) + "/" + std::to_string(processed.load()));
+        info("Elapsed time (s): " + std::to_string(el));
+        info("Reads per second: " + std::to_string(processed.load() / (el > 0 ? el : 1)));
+        double sp = 0, sl2 = 0, sw = 0, sr = 0;
+        for (size_t w = 0; w < ctx.size(); ++w) { sp += t_parse[w]; sl2 += t_lib[w]; sw += t_wait[w]; sr += t_write[w]; }
+        info("Stage seconds summed over " + std::to_string(ctx.size()) + " workers (" + std::to_string(n_chunks) + " ranges, " + std::to_string(P) + " helper threads each): parse " + std::to_string(sp) +
+             ", library calls " + std::to_string(sl2) + ", waiting for the block's place " + std::to_string(sw) + ", file writes " + std::to_string(sr));
+        for (size_t w = 0; w < ctx.size(); ++w) moni_ctx_destroy(ctx[w]);
+        for (int g = 0; g < a.gpus; ++g) moni_index_destroy(idx[g]);
+        return 0;
     }
     FILE* out = nullptr; FILE* out2 = nullptr;
     if (a.legacy_ms) { out = fopen((sam_filename + ".pointers").c_str(), "w"); out2 = fopen((sam_filename + ".lengths").c_str(), "w"); if (!out || !out2) die("open() file " + sam_filename + ".pointers/.lengths failed"); }

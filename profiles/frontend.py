@@ -51,7 +51,7 @@ print(" ".join(cmd), flush=True)
 t2 = time.time()
 r = subprocess.run(cmd, capture_output=True, text=True)
 wall = time.time() - t2
-print(r.stdout[-3000:], r.stderr[-2000:], flush=True)
+print(r.stdout[-3000:], r.stderr[-6000:], flush=True)
 print("CLI wall %.2fs (index load included) -> %.2f M reads/s end to end; SAM %.2f GB" % (wall, n_reads / wall / 1e6, os.path.getsize(out) / 1e9), flush=True)
 # identity of the head of the file with the library call the parity tests cover
 m = 50000

@@ -812,39 +812,70 @@ __device__ __forceinline__ void af_window(const af_cand_t& C, uint32_t m, int lc
 __global__ void __launch_bounds__(256) global_task_kernel(const af_args_t G) {
     const uint64_t r_in = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const ak_args_t& A = G.A;
-    if (r_in >= A.n_reads) return;
-    af_plan_t& PL = G.plans[r_in];
-    if (PL.status != AF_ST_CAND) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    // lanes stay converged (the counters are bumped once per wave, not once per lane: one address takes only ~50 M atomics/s)
+    bool active = r_in < A.n_reads;
+    af_plan_t* PLp = active ? &G.plans[r_in] : nullptr;
+    if (active && PLp->status != AF_ST_CAND) active = false;
     const uint64_t r = A.read_lo + r_in;
-    const uint64_t off = A.offs[r];
-    const uint32_t m = (uint32_t)(A.offs[r + 1] - off);
+    uint64_t off = 0; uint32_t m = 0, n_cand = 0;
+    if (active) { off = A.offs[r]; m = (uint32_t)(A.offs[r + 1] - off); n_cand = PLp->n_cand; }
     uint32_t why = AF_WHY_N;
-    for (uint32_t c = 0; c < PL.n_cand && why == AF_WHY_N; ++c) {
-        af_cand_t& C = PL.cand[c];
-        if (!C.overlap) continue;
-        uint32_t t = C.task0;
-        int lc_t = -1, rc_t = -1;
-        if (C.has_lc) { const af_res_t R = G.res[t++]; if (R.flags) why = AF_WHY_WILDCARD; lc_t = R.mqe_t; }
-        if (C.has_rc) { const af_res_t R = G.res[t++]; if (R.flags) why = AF_WHY_WILDCARD; rc_t = R.mqe_t; }
-        uint64_t ref_pos, ref_len;
-        af_window(C, m, lc_t, rc_t, ref_pos, ref_len);
-        if (why != AF_WHY_N) break;
-        C.gtask = ~0u;
-        if (!ac_valid(A.P, ref_pos, ref_len)) continue;                    // scored INT32_MIN whatever the DP says; never the final chain
-        if (ref_len == 0 || ref_len > (uint64_t)AF_GPASS * AF_GBLK) { why = AF_WHY_TASK_SIZE; break; }
-        const uint32_t tid = atomicAdd(&G.ctr[AFC_TASKS], 1u);
-        if (tid >= G.task_cap) { why = AF_WHY_CAPACITY; break; }
-        moni_dp_task_t T;
-        if (!C.strand) { T.q_off = off; T.reserved = DP_Q_READS | DP_T_TEXT; } else { T.q_off = off + m - 1; T.reserved = DP_Q_READS | DP_T_TEXT | DP_Q_REV | DP_Q_COMP; }
-        T.t_off = ref_pos; T.qlen = (int32_t)m; T.tlen = (int32_t)ref_len; T.flag = DP_EZ_RIGHT;
-        G.tasks[tid] = T;
+    uint32_t max_cand = n_cand;
+    for (int d = 32; d; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)max_cand, d); max_cand = o > max_cand ? o : max_cand; }
+    for (uint32_t c = 0; c < max_cand; ++c) {
+        bool need = false;
+        uint64_t ref_pos = 0, ref_len = 0;
+        af_cand_t* Cp = nullptr;
+        if (active && why == AF_WHY_N && c < n_cand) {
+            Cp = &PLp->cand[c];
+            if (Cp->overlap) {
+                uint32_t t = Cp->task0;
+                int lc_t = -1, rc_t = -1;
+                if (Cp->has_lc) { const af_res_t R = G.res[t++]; if (R.flags) why = AF_WHY_WILDCARD; lc_t = R.mqe_t; }
+                if (Cp->has_rc) { const af_res_t R = G.res[t++]; if (R.flags) why = AF_WHY_WILDCARD; rc_t = R.mqe_t; }
+                af_window(*Cp, m, lc_t, rc_t, ref_pos, ref_len);
+                if (why == AF_WHY_N) {
+                    Cp->gtask = ~0u;
+                    if (ac_valid(A.P, ref_pos, ref_len)) {                    // else: scored INT32_MIN whatever the DP says; never the final chain
+                        if (ref_len == 0 || ref_len > (uint64_t)AF_GPASS * AF_GBLK) why = AF_WHY_TASK_SIZE;
+                        else need = true;
+                    }
+                }
+            }
+        }
+        const unsigned long long nm = __ballot(need);
+        if (nm == 0) continue;
+        uint32_t base = 0;
+        if (lane == __ffsll((long long)nm) - 1) base = atomicAdd(&G.ctr[AFC_TASKS], (uint32_t)__popcll(nm));
+        base = (uint32_t)__shfl((int)base, __ffsll((long long)nm) - 1);
+        const uint32_t tid = base + (uint32_t)__popcll(nm & lt_mask);
+        if (need && tid >= G.task_cap) { why = AF_WHY_CAPACITY; need = false; }
         const uint32_t bin = AF_BIN_GLOBAL + ((m - 1) >> 4);
-        const uint32_t at = atomicAdd(&G.ctr[AFC_BINS + bin], 1u);
-        G.bin_q[(size_t)bin * G.bin_cap + at] = tid;
-        G.task_pos[tid] = at | (bin << 26);
-        C.gtask = tid;
+        uint32_t at = 0;
+        unsigned long long rest = __ballot(need);
+        while (rest) {                                     // one bump per distinct bin of the wave (reads of one length: one)
+            const int lead = __ffsll((long long)rest) - 1;
+            const uint32_t b = (uint32_t)__shfl((int)bin, lead);
+            const unsigned long long same = __ballot(need && bin == b);
+            uint32_t a0 = 0;
+            if (lane == lead) a0 = atomicAdd(&G.ctr[AFC_BINS + b], (uint32_t)__popcll(same));
+            a0 = (uint32_t)__shfl((int)a0, lead);
+            if (need && bin == b) at = a0 + (uint32_t)__popcll(same & lt_mask);
+            rest &= ~same;
+        }
+        if (need) {
+            moni_dp_task_t T;
+            if (!Cp->strand) { T.q_off = off; T.reserved = DP_Q_READS | DP_T_TEXT; } else { T.q_off = off + m - 1; T.reserved = DP_Q_READS | DP_T_TEXT | DP_Q_REV | DP_Q_COMP; }
+            T.t_off = ref_pos; T.qlen = (int32_t)m; T.tlen = (int32_t)ref_len; T.flag = DP_EZ_RIGHT;
+            G.tasks[tid] = T;
+            G.bin_q[(size_t)bin * G.bin_cap + at] = tid;
+            G.task_pos[tid] = at | (bin << 26);
+            Cp->gtask = tid;
+        }
     }
-    if (why != AF_WHY_N) { PL.status = AF_ST_FALLBACK; G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)r; atomicAdd(&G.ctr[AFC_WHY + why], 1u); }
+    if (active && why != AF_WHY_N) { PLp->status = AF_ST_FALLBACK; G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)r; atomicAdd(&G.ctr[AFC_WHY + why], 1u); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -1059,16 +1090,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // (sam.hpp:144-188, aligner_ksw2.hpp:3116-3175, mapq.hpp:146-184).  Needs the kernel-side text pool (ak_fmt_t::txt_pool); a line that
 // does not fit is marked for the host pipeline like everywhere else.
 // ------------------------------------------------------------------------------------------------------------------------------
+#define AFW_TXT_CAP 2560         // bytes of one line in LDS (longer: the host pipeline redoes the read); the upper half doubles as staging
+#define AFW_NAMES 1024           // sequence names kept in LDS when they fit (else they are read from HBM)
+#define AFW_NSEQ 126
+#define AFW_TB_WORDS (AF_TB_CIG + 1)
 struct af_finw_t {
-    uint8_t line[AK_TXT_CAP];
+    uint8_t line[AFW_TXT_CAP];
     uint8_t seq[AF_MAX_READ];            // the read in alignment orientation (ASCII, kpbseq.h:120-137 complement)
     uint8_t qc[AF_MAX_READ];             // its nt4 codes
     uint32_t cig[AF_FIN_CIG], lcig[AF_FIN_LCIG];
     uint32_t n_cig, n_lcig, pos, ovf;    // pos: write cursor in line[]
     uint64_t out_off;
+    uint8_t names[AFW_NAMES]; uint16_t name_off[AFW_NSEQ + 2];      // the index's sequence names (kernel lifetime)
+    af_cand_t cand;                                                  // the final chain's record and the alternatives, fetched by all lanes at once
+    uint64_t alt_pos[AF_MAX_CAND]; int32_t alt_score[AF_MAX_CAND];
+    uint32_t tb_idx[8], n_tb;
 };
 
-__device__ __forceinline__ void afw_c(af_finw_t& L, uint32_t& p, uint8_t ch) { if (p < AK_TXT_CAP) L.line[p] = ch; ++p; }
+__device__ __forceinline__ void afw_c(af_finw_t& L, uint32_t& p, uint8_t ch) { if (p < AFW_TXT_CAP) L.line[p] = ch; ++p; }
 __device__ __forceinline__ void afw_i(af_finw_t& L, uint32_t& p, int v) {
     char b[12]; int k = 0; unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
     do { b[k++] = (char)('0' + u % 10); u /= 10; } while (u);
@@ -1112,7 +1151,7 @@ __device__ __forceinline__ int afw_md(const af_args_t& G, af_finw_t& L, const ui
             if (with_text) {
                 if (lane == 0) { afw_i(L, p, l_MD); afw_c(L, p, '^'); }
                 p = (uint32_t)__shfl((int)p, 0);
-                for (uint32_t k = lane; k < len; k += 64) { const uint64_t a = t + k; const uint32_t tc = dp_nt4(a < D.n_text ? D.text[a] : 0u); if (p + k < AK_TXT_CAP) L.line[p + k] = (uint8_t)"ACGTN"[tc]; }
+                for (uint32_t k = lane; k < len; k += 64) { const uint64_t a = t + k; const uint32_t tc = dp_nt4(a < D.n_text ? D.text[a] : 0u); if (p + k < AFW_TXT_CAP) L.line[p + k] = (uint8_t)"ACGTN"[tc]; }
                 p += len;
             }
             l_MD = 0; t += len; NM += (int)len;
@@ -1122,11 +1161,25 @@ __device__ __forceinline__ int afw_md(const af_args_t& G, af_finw_t& L, const ui
     return NM;
 }
 
+__device__ __forceinline__ void afw_name(af_finw_t& L, const ak_fmt_t& F, bool names_lds, uint32_t& p, uint32_t sid) {
+    if (names_lds) { for (uint32_t k = L.name_off[sid]; k < L.name_off[sid + 1]; ++k) afw_c(L, p, L.names[k]); }
+    else { for (uint32_t k = F.sname_off[sid]; k < F.sname_off[sid + 1]; ++k) afw_c(L, p, F.snames[k]); }
+}
+
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) finish_wave_kernel(const af_args_t G) {
     __shared__ af_finw_t L;
     const int lane = threadIdx.x;
     const ak_args_t& A = G.A;
     const ak_fmt_t& F = A.fmt;
+    // the sequence names: in LDS for the kernel's lifetime when they fit
+    const uint32_t n_seq = (uint32_t)A.P.n_seq;
+    const bool names_lds = n_seq <= AFW_NSEQ && F.sname_off[n_seq] <= AFW_NAMES;
+    if (names_lds) {
+        for (uint32_t k = lane; k <= n_seq; k += 64) L.name_off[k] = (uint16_t)F.sname_off[k];
+        for (uint32_t k = lane; k < F.sname_off[n_seq]; k += 64) L.names[k] = F.snames[k];
+    }
+#define put_name(p, sid) afw_name(L, F, names_lds, (p), (sid))          /* lane 0 */
+    uint32_t* const tbs = reinterpret_cast<uint32_t*>(L.line + AFW_TXT_CAP / 2);       // staged traceback records: the line's upper half is free until the MD text
     for (uint64_t r_in = blockIdx.x; r_in < A.n_reads; r_in += gridDim.x) {
         af_plan_t& PL = G.plans[r_in];
         const uint32_t st = PL.status;
@@ -1135,10 +1188,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         const uint64_t off = A.offs[r];
         const uint32_t m = (uint32_t)(A.offs[r + 1] - off);
         const bool aligned = st == AF_ST_FINAL;
-        const af_cand_t* C = aligned ? &PL.cand[PL.final_cand] : nullptr;
-        const uint32_t strand = aligned ? C->strand : 0u;
         __syncthreads();
         AF_STAMP(fw0);
+        // the final chain's record, the alternatives and (below) its traceback records come with one round trip each instead of field by field
+        if (aligned) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&PL.cand[PL.final_cand]);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(&L.cand);
+            for (uint32_t w = lane; w < sizeof(af_cand_t) / 4; w += 64) dst[w] = src[w];
+            if (lane < AF_MAX_CAND) { L.alt_pos[lane] = PL.alt_pos[lane]; L.alt_score[lane] = PL.alt_score[lane]; }
+        }
+        __syncthreads();
+        const af_cand_t* C = aligned ? &L.cand : nullptr;
+        const uint32_t strand = aligned ? C->strand : 0u;
+        const uint32_t tb0 = aligned ? PL.tb0 : 0u;
+        if (aligned) {
+            const uint32_t n_tb = C->overlap ? 1u : (uint32_t)C->has_lc + C->has_rc + C->n_gap_tasks;      // as select_kernel counted them
+            for (uint32_t w = lane; w < n_tb * AFW_TB_WORDS; w += 64) {
+                const uint32_t k = w / AFW_TB_WORDS, x = w % AFW_TB_WORDS;
+                tbs[w] = reinterpret_cast<const uint32_t*>(&G.tb[tb0 + k])[x];
+            }
+        }
         // ---- the read in alignment orientation ----
         for (uint32_t k = lane; k < m; k += 64) {
             uint8_t b = strand ? ak_compl(A.D.reads[off + m - 1 - k]) : A.D.reads[off + k];
@@ -1151,34 +1220,38 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             uint32_t n = 0;
             auto push = [&](uint32_t op) { if (n < AF_FIN_CIG) L.cig[n++] = op; else ovf = true; };
             auto push_merge_first = [&](uint32_t op, bool first) { if (first && (op & 0xf) == 0 && n > 0) L.cig[n - 1] += op; else push(op); };
-            uint32_t tbx = PL.tb0;
+            uint32_t tbx = 0;
+#define TB(k) (*reinterpret_cast<const af_tb_t*>(tbs + (k) * AFW_TB_WORDS))
             if (C->overlap) {
-                const af_tb_t& T = G.tb[tbx];
+                const af_tb_t& T = TB(tbx);
                 if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push(T.ops[T.n_ops - 1 - k]);
             } else {
-                if (C->has_lc) { const af_tb_t& T = G.tb[tbx++]; if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push(T.ops[k]); }
+                if (C->has_lc) { const af_tb_t& T = TB(tbx++); if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push(T.ops[k]); }
                 const uint32_t rc_x = C->has_rc ? tbx++ : 0u;
                 for (uint32_t j = 0; j < C->n_an; ++j) {
                     const uint32_t mlen = C->an[j].len;
                     if (n > 0 && (L.cig[n - 1] & 0xf) == 0) L.cig[n - 1] += mlen << 4; else push(mlen << 4);
                     if (j + 1 < C->n_an) {
                         const af_anchor_t g = C->an[j];
-                        if (g.gap_kind == AF_GAP_TASK) { const af_tb_t& T = G.tb[tbx++]; if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push_merge_first(T.ops[T.n_ops - 1 - k], k == 0); }
+                        if (g.gap_kind == AF_GAP_TASK) { const af_tb_t& T = TB(tbx++); if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push_merge_first(T.ops[T.n_ops - 1 - k], k == 0); }
                         else if (g.gap_kind == AF_GAP_INS) push_merge_first(((uint32_t)(uint16_t)g.gap_val << 4) | 1u, true);
                         else if (g.gap_kind == AF_GAP_DEL0) push_merge_first(2u, true);
                         else if (g.gap_kind == AF_GAP_1X1) push_merge_first(1u << 4, true);
                     }
                 }
-                if (C->has_rc) { const af_tb_t& T = G.tb[rc_x]; if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push_merge_first(T.ops[T.n_ops - 1 - k], k == 0); }
+                if (C->has_rc) { const af_tb_t& T = TB(rc_x); if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push_merge_first(T.ops[T.n_ops - 1 - k], k == 0); }
             }
             // ---- the alignment lifted to the reference contig (aligner_ksw2.hpp:3133-3160) ----
-            const uint32_t sid = ac_seq_of(A.P, PL.ref_pos);
+            uint32_t hint;
+            const uint32_t sid = ac_seq_of(A.P, PL.ref_pos, &hint);
             const moni_lift_seq_t LS = A.P.lift_seqs[sid];
             const moni_lift_run_t* __restrict__ runs = A.P.lift_runs + LS.run_off;
             const uint64_t start = PL.ref_pos - LS.start;
-            const int nl = ovf ? -1 : lift_cigar(runs, LS.n_runs, start, L.cig, n, L.lcig, AF_FIN_LCIG);
+            const uint32_t rel = hint == 0xFFFFFFFFu ? hint : hint - LS.run_off;
+            uint64_t lp = 0;
+            const int nl = ovf ? -1 : lift_cigar(runs, LS.n_runs, start, L.cig, n, L.lcig, AF_FIN_LCIG, rel, &lp);
             if (nl < 0) ovf = true;
-            lifted = LS.second + lift_pos(runs, LS.n_runs, start);
+            lifted = LS.second + (ovf ? 0ull : lp);
             L.n_cig = n; L.n_lcig = nl < 0 ? 0u : (uint32_t)nl; L.ovf = ovf ? 1u : 0u;
         }
         __syncthreads();
@@ -1191,7 +1264,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         // ---- the line ----
         uint32_t p = 0;
         const uint64_t n0 = F.rname_off[r], n1 = F.rname_off[r + 1];
-        for (uint64_t k = lane; k < n1 - n0; k += 64) if (k < AK_TXT_CAP) L.line[k] = F.rnames[n0 + k];
+        for (uint64_t k = lane; k < n1 - n0; k += 64) if (k < AFW_TXT_CAP) L.line[k] = F.rnames[n0 + k];
         p = (uint32_t)(n1 - n0);
         moni_aln_rec_t rec;
         rec.status = aligned ? 1u : 0u; rec.strand = strand; rec.ref_pos = aligned ? PL.ref_pos : 0; rec.score = aligned ? C->score : 0; rec.score2 = aligned ? PL.score2 : 0;
@@ -1200,17 +1273,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             if (lane == 0) afw_lit(L, p, "\t4\t*\t0\t255\t*\t*\t0\t0\t");
             p = (uint32_t)__shfl((int)p, 0);
             __syncthreads();
-            for (uint32_t k = lane; k < m; k += 64) if (p + k < AK_TXT_CAP) L.line[p + k] = A.D.reads[off + k];
+            for (uint32_t k = lane; k < m; k += 64) if (p + k < AFW_TXT_CAP) L.line[p + k] = A.D.reads[off + k];
             p += m;
-            if (lane == 0 && p < AK_TXT_CAP) L.line[p] = '\t';
+            if (lane == 0 && p < AFW_TXT_CAP) L.line[p] = '\t';
             ++p;
-            if (F.quals) { for (uint32_t k = lane; k < m; k += 64) if (p + k < AK_TXT_CAP) L.line[p + k] = F.quals[off + k]; p += m; }
-            else { if (lane == 0 && p < AK_TXT_CAP) L.line[p] = '*'; ++p; }
-            if (lane == 0 && p < AK_TXT_CAP) L.line[p] = '\n';
+            if (F.quals) { for (uint32_t k = lane; k < m; k += 64) if (p + k < AFW_TXT_CAP) L.line[p + k] = F.quals[off + k]; p += m; }
+            else { if (lane == 0 && p < AFW_TXT_CAP) L.line[p] = '*'; ++p; }
+            if (lane == 0 && p < AFW_TXT_CAP) L.line[p] = '\n';
             ++p;
         } else {
             const uint32_t n_cig = L.n_cig, n_lcig = L.n_lcig;
             const int32_t score = C->score, score2 = PL.score2;
+            const uint32_t n_alt = PL.n_alt;
             uint64_t ref_len = 0;
             for (uint32_t k = 0; k < n_lcig; ++k) { const int op = L.lcig[k] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += L.lcig[k] >> 4; }
             const bool mapped = ref_len > 0;
@@ -1243,7 +1317,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             int lift_nm = same ? 0 : afw_md(G, L, L.cig, n_cig, PL.ref_pos, false, dummy);
             if (lane == 0) {
                 afw_c(L, p, '\t'); afw_i(L, p, strand ? 16 : 0); afw_c(L, p, '\t');
-                if (mapped) { for (uint32_t k = F.sname_off[lsid]; k < F.sname_off[lsid + 1]; ++k) afw_c(L, p, F.snames[k]); } else afw_c(L, p, '*');
+                if (mapped) put_name(p, lsid); else afw_c(L, p, '*');
                 afw_c(L, p, '\t'); afw_i(L, p, mapped ? pos1 : 0); afw_c(L, p, '\t'); afw_i(L, p, mapq); afw_c(L, p, '\t');
                 if (mapped) afw_cigar(L, p, L.lcig, n_lcig); else afw_c(L, p, '*');
                 afw_lit(L, p, "\t*\t0\t0\t");
@@ -1251,21 +1325,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             p = (uint32_t)__shfl((int)p, 0);
             __syncthreads();
             AF_STAMP(fw2); AF_PROF(G, 17, fw1, fw2);
-            for (uint32_t k = lane; k < m; k += 64) if (p + k < AK_TXT_CAP) L.line[p + k] = L.seq[k];
+            for (uint32_t k = lane; k < m; k += 64) if (p + k < AFW_TXT_CAP) L.line[p + k] = L.seq[k];
             p += m;
-            if (lane == 0 && p < AK_TXT_CAP) L.line[p] = '\t';
+            if (lane == 0 && p < AFW_TXT_CAP) L.line[p] = '\t';
             ++p;
-            if (F.quals) { for (uint32_t k = lane; k < m; k += 64) if (p + k < AK_TXT_CAP) L.line[p + k] = F.quals[strand ? off + m - 1 - k : off + k]; p += m; }
-            else { if (lane == 0 && p < AK_TXT_CAP) L.line[p] = '*'; ++p; }
+            if (F.quals) { for (uint32_t k = lane; k < m; k += 64) if (p + k < AFW_TXT_CAP) L.line[p + k] = F.quals[strand ? off + m - 1 - k : off + k]; p += m; }
+            else { if (lane == 0 && p < AFW_TXT_CAP) L.line[p] = '*'; ++p; }
             const uint32_t p_nm = p;           // "\tAS:i:<score>\tNM:i:" then NM, which needs the MD walk: MD goes to a scratch place first
             // MD text: behind everything else it could collide with; build it at the end of the buffer region then move
-            uint32_t pm = AK_TXT_CAP / 2;      // MD staging area: second half of the line buffer
+            uint32_t pm = AFW_TXT_CAP / 2;      // MD staging area: second half of the line buffer
             int nm = 0;
             if (mapped) nm = afw_md(G, L, L.lcig, n_lcig, lifted, true, pm);
             if (same) lift_nm = nm;
             __syncthreads();
             AF_STAMP(fw3); AF_PROF(G, 18, fw2, fw3);
-            const uint32_t md_len = pm - AK_TXT_CAP / 2;
+            const uint32_t md_len = pm - AFW_TXT_CAP / 2;
             p = p_nm;
             if (lane == 0) {
                 afw_lit(L, p, "\tAS:i:"); afw_i(L, p, score); afw_lit(L, p, "\tNM:i:"); afw_i(L, p, mapped ? nm : 0);
@@ -1274,11 +1348,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             }
             p = (uint32_t)__shfl((int)p, 0);
             __syncthreads();
-            bool too_long = pm > AK_TXT_CAP || p + md_len + 64 > AK_TXT_CAP / 2;      // the head of the line must not reach the MD staging area
+            bool too_long = pm > AFW_TXT_CAP || p + md_len + 64 > AFW_TXT_CAP / 2;      // the head of the line must not reach the MD staging area
             if (!too_long && mapped) {
-                uint8_t tmpb[(AK_TXT_CAP / 2 + 63) / 64];
+                uint8_t tmpb[(AFW_TXT_CAP / 2 + 63) / 64];
                 int cnt = 0;
-                for (uint32_t k = lane; k < md_len; k += 64) tmpb[cnt++] = L.line[AK_TXT_CAP / 2 + k];
+                for (uint32_t k = lane; k < md_len; k += 64) tmpb[cnt++] = L.line[AFW_TXT_CAP / 2 + k];
                 __syncthreads();
                 cnt = 0;
                 for (uint32_t k = lane; k < md_len; k += 64) L.line[p + k] = tmpb[cnt++];
@@ -1288,27 +1362,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             AF_STAMP(fw4); AF_PROF(G, 19, fw3, fw4);
             if (lane == 0) {
                 afw_lit(L, p, "\tOA:Z:");
-                for (uint32_t k = F.sname_off[sid]; k < F.sname_off[sid + 1]; ++k) afw_c(L, p, F.snames[k]);
+                put_name(p, sid);
                 afw_c(L, p, ','); afw_i(L, p, oa_pos); afw_lit(L, p, strand ? ",-," : ",+,");
                 afw_cigar(L, p, L.cig, n_cig);
                 afw_c(L, p, ','); afw_i(L, p, mapq); afw_c(L, p, ','); afw_i(L, p, lift_nm); afw_c(L, p, ';');
                 afw_lit(L, p, "\tAA:Z:");
-                for (uint32_t k = 0; k < PL.n_alt; ++k) {
-                    const uint64_t ap = PL.alt_pos[k];
+                for (uint32_t k = 0; k < n_alt; ++k) {
+                    const uint64_t ap = L.alt_pos[k];
                     const uint32_t s2 = ac_seq_of(A.P, ap);
-                    for (uint32_t x = F.sname_off[s2]; x < F.sname_off[s2 + 1]; ++x) afw_c(L, p, F.snames[x]);
-                    afw_c(L, p, ','); afw_i(L, p, (int)(ap - A.P.lift_seqs[s2].start + 1)); afw_c(L, p, ','); afw_i(L, p, PL.alt_score[k]); afw_c(L, p, ';');
+                    put_name(p, s2);
+                    afw_c(L, p, ','); afw_i(L, p, (int)(ap - A.P.lift_seqs[s2].start + 1)); afw_c(L, p, ','); afw_i(L, p, L.alt_score[k]); afw_c(L, p, ';');
                 }
                 afw_c(L, p, '\n');
             }
             p = (uint32_t)__shfl((int)p, 0);
-            if (too_long) p = AK_TXT_CAP + 1;
+            if (too_long) p = AFW_TXT_CAP + 1;
             AF_STAMP(fw5); AF_PROF(G, 20, fw4, fw5);
         }
         __syncthreads();
         AF_STAMP(fw6);
         // ---- out: the text pool (8-byte words, bump-allocated), coalesced; the record ----
-        if (p > AK_TXT_CAP) rec.status = 2;           // does not fit the staging: the host pipeline redoes the read
+        if (p > AFW_TXT_CAP) rec.status = 2;           // does not fit the staging: the host pipeline redoes the read
         else {
             const unsigned long long words = (unsigned long long)((p + 7) >> 3);
             const uint32_t shard = blockIdx.x % AF_TXT_SHARDS;

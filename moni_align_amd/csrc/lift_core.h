@@ -40,6 +40,18 @@ LIFT_HD uint32_t lift_find(const moni_lift_run_t* __restrict runs, uint32_t n_ru
     return lo;
 }
 
+// lift_find when a run at or before p's run is already known (the position directory gives one): a short walk forward
+LIFT_HD uint32_t lift_find_from(const moni_lift_run_t* __restrict runs, uint32_t n_runs, uint32_t hint, uint64_t p, uint64_t& x) {
+    if (hint >= n_runs || (uint64_t)runs[hint].hap > p) return lift_find(runs, n_runs, p, x);
+    uint32_t k = hint;
+    for (int step = 0; step < 32 && k + 1 < n_runs; ++step) { if ((uint64_t)runs[k + 1].hap > p) { x = (uint64_t)runs[k].col + (p - (uint64_t)runs[k].hap); return k; } ++k; }
+    if (k + 1 >= n_runs) { x = (uint64_t)runs[k].col + (p - (uint64_t)runs[k].hap); return k; }
+    uint32_t lo = k, hi = n_runs;               // far from the hint: finish with the binary search
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)runs[mid].hap <= p) lo = mid; else hi = mid; }
+    x = (uint64_t)runs[lo].col + (p - (uint64_t)runs[lo].hap);
+    return lo;
+}
+
 // lift::Lift::lift_pos: ins.rank0(del.select0(p + 1))
 LIFT_HD uint64_t lift_pos(const moni_lift_run_t* __restrict runs, uint32_t n_runs, uint64_t p) {
     uint64_t x;
@@ -52,9 +64,10 @@ LIFT_HD uint64_t lift_pos(const moni_lift_run_t* __restrict runs, uint32_t n_run
 // D / N vanish on an inserted column; equal neighbours merge, zero-length operations disappear), taken run by run.
 // Returns the number of operations written, or -1 when they do not fit cap.
 LIFT_HD int lift_cigar(const moni_lift_run_t* __restrict runs, uint32_t n_runs, uint64_t p, const uint32_t* __restrict cig, uint32_t n_cig,
-                       uint32_t* __restrict out, uint32_t cap) {
+                       uint32_t* __restrict out, uint32_t cap, uint32_t hint = 0xFFFFFFFFu, uint64_t* lifted_pos = nullptr) {
     uint64_t x;
-    uint32_t k = lift_find(runs, n_runs, p, x);
+    uint32_t k = lift_find_from(runs, n_runs, hint, p, x);
+    if (lifted_pos) *lifted_pos = (uint64_t)runs[k].ref + ((runs[k].flags & MONI_LIFT_INS) ? 0ull : x - (uint64_t)runs[k].col);      // lift_pos(p)
     int n = 0;
     uint32_t cur_op = 0xFu; uint64_t cur_len = 0;
     bool ovf = false;

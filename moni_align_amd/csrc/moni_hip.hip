@@ -154,6 +154,7 @@ struct moni_ctx {
     DBuf<uint64_t> ak_block;                          // per sub-batch: its SAM lines in read order (gather_lines_kernel)
     DBuf<uint64_t> ak_dev_len, ak_dev_off, ak_dev_pos; DBuf<unsigned long long> ak_dev_sum;
     HBuf<unsigned long long> h_sum;                   // per sub-batch: bytes of the block, records that need the host, aligned reads
+    DBuf<uint8_t> gather_tmp[2];                      // rocPRIM scan workspace of the gather, one per stream it runs on (the two streams' scans overlap)
     float ak_kernel_ms = 0;
 };
 
@@ -359,6 +360,7 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->ak_recs.release(); c->ak_cig.release(); c->ak_alt.release(); c->ak_minscore.release();
     if (c->d_ak_cursors) (void)hipFree(c->d_ak_cursors);
     if (c->out_buf) (void)hipHostFree(c->out_buf);
+    c->gather_tmp[0].release(); c->gather_tmp[1].release();
     c->ak_block.release(); c->ak_dev_len.release(); c->ak_dev_off.release(); c->ak_dev_pos.release(); c->ak_dev_sum.release(); c->h_sum.release();
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->d_counters) (void)hipFree(c->d_counters);
@@ -966,6 +968,11 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         const bool inorder = use_fast && gpu_text && ctx_out && force_back == 0 && getenv("MONI_ALIGN_HOST_ORDER") == nullptr;
         if (inorder && ((rc = c->ak_block.ensure(txt_per * n_sub + 8)) || (rc = c->ak_dev_len.ensure(NR + n_sub + 8)) || (rc = c->ak_dev_off.ensure(NR + n_sub + 8)) ||
                         (rc = c->ak_dev_pos.ensure(NR + 2 * n_sub + 8)) || (rc = c->ak_dev_sum.ensure(160 * n_sub + 8)) || (rc = c->h_sum.ensure(4 * n_sub + 4)))) return rc;
+        size_t gather_tmp_bytes = 0;
+        if (inorder) {
+            if (rocprim::exclusive_scan(nullptr, gather_tmp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, (size_t)sub_reads, rocprim::plus<uint64_t>(), c->stream) != hipSuccess) return MONI_ENODEV;
+            if ((rc = c->gather_tmp[0].ensure(gather_tmp_bytes + 16)) || (rc = c->gather_tmp[1].ensure(gather_tmp_bytes + 16))) return rc;
+        }
         if (inorder) { HIPCHK(hipMemsetAsync(c->ak_dev_sum.p, 0, (160 * n_sub + 8) * sizeof(unsigned long long), c->stream)); memset(c->h_sum.p, 0, (4 * n_sub + 4) * sizeof(unsigned long long)); }
         if (use_fast) for (int x = 0; x < (n_sub > 1 ? 2 : 1); ++x) {
             moni_ctx::AfSet& S = c->af[x];
@@ -1073,9 +1080,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 if (inorder) {          // lines in read order: scan of the lengths, gather, summary for the host
                     uint64_t* pos = c->ak_dev_pos.p + r0 + 2 * k;
                     size_t tmp_bytes = 0;
-                    if (rocprim::exclusive_scan(nullptr, tmp_bytes, A.dev_len, pos, (uint64_t)0, nr, rocprim::plus<uint64_t>(), sf) != hipSuccess) return MONI_ENODEV;
-                    if ((rc = c->scan_tmp.ensure(tmp_bytes + 16))) return rc;          // (sized by the seeding stage's far larger scans: no reallocation here)
-                    if (rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, A.dev_len, pos, (uint64_t)0, nr, rocprim::plus<uint64_t>(), sf) != hipSuccess) return MONI_ENODEV;
+                    if (rocprim::exclusive_scan(nullptr, tmp_bytes, A.dev_len, pos, (uint64_t)0, nr, rocprim::plus<uint64_t>(), sf) != hipSuccess || tmp_bytes > gather_tmp_bytes + 16) return MONI_ENODEV;
+                    if (rocprim::exclusive_scan(c->gather_tmp[k & 1].p, tmp_bytes, A.dev_len, pos, (uint64_t)0, nr, rocprim::plus<uint64_t>(), sf) != hipSuccess) return MONI_ENODEV;
                     hipLaunchKernelGGL(gather_lines_kernel, dim3((unsigned)std::min<uint64_t>((nr + 3) / 4, (uint64_t)n_cu * 8)), dim3(256), 0, sf, (const uint64_t*)A.fmt.txt_pool,
                                        (const uint64_t*)A.dev_len, (const uint64_t*)A.dev_off, (const uint64_t*)pos, nr, reinterpret_cast<uint8_t*>(c->ak_block.p + k * txt_per));
                     hipLaunchKernelGGL(gather_summary_kernel, dim3(1), dim3(64), 0, sf, (const uint64_t*)A.dev_len, (const uint64_t*)pos, nr, (const unsigned long long*)A.dev_sum,

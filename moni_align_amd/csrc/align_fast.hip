@@ -1076,7 +1076,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                     if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push_merge_first(T.ops[T.n_ops - 1 - k], k == 0);
                 }
             }
-            if (ovf) { PL.status = AF_ST_FALLBACK; G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)r; atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CIGAR], 1u); continue; }
+            if (ovf) {       // the host pipeline redoes the read (align_kernel runs beside this kernel, its list is closed)
+                atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CIGAR], 1u);
+                moni_aln_rec_t rec;
+                rec.status = 2u; rec.strand = C.strand; rec.ref_pos = 0; rec.score = 0; rec.score2 = 0;
+                rec.n_cigar = 0; rec.n_alt = 0; rec.cigar_off = 0; rec.alt_off = 0; rec.nm = 0; rec.md_len = 0; rec.md_off = 0; rec.txt_len = 0; rec.lift_nm = 0; rec.txt_off = 0;
+                A.recs[r_in] = rec;
+                if (A.dev_len) { A.dev_len[r_in] = 0; A.dev_off[r_in] = 0; atomicAdd(&A.dev_sum[0], 1ull); }
+                continue;
+            }
             V.strand = C.strand; V.ref_pos = PL.ref_pos; V.score = C.score; V.score2 = PL.score2; V.n_cigar = n; V.n_alt = PL.n_alt; V.aligned = 1;
         }
         ak_write_record(A, V, S.md_tmp, S.txt_tmp, S.lcig, AF_FIN_LCIG, r_in, r);      // a record that does not fit the pools is marked for the host pipeline, as in align_kernel
@@ -1257,8 +1265,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         __syncthreads();
         AF_STAMP(fw1); AF_PROF(G, 16, fw0, fw1);
         if (aligned) { ovf = L.ovf != 0; lifted = ((uint64_t)(uint32_t)__shfl((int)(lifted >> 32), 0) << 32) | (uint32_t)__shfl((int)(lifted & 0xFFFFFFFFull), 0); }
-        if (aligned && ovf) {
-            if (lane == 0) { PL.status = AF_ST_FALLBACK; G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)r; atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CIGAR], 1u); }
+        if (aligned && ovf) {        // more CIGAR operations than the staging holds: the host pipeline redoes the read (align_kernel runs beside this kernel, its list is closed)
+            if (lane == 0) {
+                atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CIGAR], 1u);
+                moni_aln_rec_t rec;
+                rec.status = 2u; rec.strand = strand; rec.ref_pos = 0; rec.score = 0; rec.score2 = 0;
+                rec.n_cigar = 0; rec.n_alt = 0; rec.cigar_off = 0; rec.alt_off = 0; rec.nm = 0; rec.md_len = 0; rec.md_off = 0; rec.txt_len = 0; rec.lift_nm = 0; rec.txt_off = 0;
+                A.recs[r_in] = rec;
+                if (A.dev_len) { A.dev_len[r_in] = 0; A.dev_off[r_in] = 0; atomicAdd(&A.dev_sum[0], 1ull); }
+            }
             continue;
         }
         // ---- the line ----

@@ -84,6 +84,7 @@ struct HBuf {                  // pinned host buffer, grow-only
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+#define AK_NSET 2          // launch streams of the align stage, each with its own buffer set: sub-batch k runs on set k % AK_NSET
 struct moni_ctx {
     moni_index* idx = nullptr;
     hipStream_t stream = nullptr;
@@ -108,6 +109,8 @@ struct moni_ctx {
     uint32_t* d_small = nullptr;            // [0] pool_next, [1] error_flag
     unsigned long long* d_counters = nullptr;   // 4
     uint64_t n_mems = 0, n_occs = 0;
+    float ms_accum[7] = {0, 0, 0, 0, 0, 0, 0}; unsigned long long ctr_accum[4] = {0, 0, 0, 0}; bool accum_valid = false;      // pipelined seeding: sums over the slices
+    double est_mems_per_read = 6, est_occs_per_read = 80;      // sizes the per-MEM buffers of a pipelined batch (updated by every batch)
     uint32_t tmp_cap = 16;
     uint32_t pool_rows = 4096;
     double dp_kernel_ms_accum = 0;
@@ -128,7 +131,7 @@ struct moni_ctx {
         DBuf<af_chunk_t> chunks; DBuf<uint8_t> dirs, fin; DBuf<af_tb_t> tb; DBuf<uint64_t> bnd; DBuf<unsigned long long> prof, txt_cur;
         void release() { bnd.release(); prof.release(); big_list.release(); txt_cur.release(); plans.release(); tasks.release(); res.release(); bin_q.release(); task_pos.release(); tb_task.release(); fb_list.release(); ctr.release();
                          chunks.release(); dirs.release(); fin.release(); tb.release(); }
-    } af[2];
+    } af[AK_NSET];
     HBuf<uint32_t> af_ctr_host;             // counters of the last batch's launches (64 words per sub-batch), pinned
     DBuf<ak_slot_t> ak_slots;
     DBuf<ak_wave_t> ak_waves;
@@ -137,7 +140,7 @@ struct moni_ctx {
     DBuf<uint8_t> ak_rnames, ak_quals; DBuf<uint64_t> ak_rname_off, ak_txt; DBuf<double> ak_mapq_tab;      // SAM text in the kernel
     HBuf<uint64_t> h_txt;                                 // pinned staging of one sub-batch's text
     uint64_t ak_waves_full = 0;
-    hipStream_t ak_stream[2] = {nullptr, nullptr}, copy_stream = nullptr, fb_stream[2] = {nullptr, nullptr};
+    hipStream_t ak_stream[AK_NSET] = {}, copy_stream = nullptr, fb_stream[AK_NSET] = {};
     std::vector<hipEvent_t> ak_fin;                // staged kernels of a sub-batch queued; the handed-over reads follow on fb_stream
     std::vector<hipEvent_t> af_ev;                 // per sub-batch: after the chaining kernels, after the DP kernels, after selection + traceback (HIP-event kernel times)
     std::vector<hipEvent_t> ak_begin, ak_done;
@@ -154,7 +157,7 @@ struct moni_ctx {
     DBuf<uint64_t> ak_block;                          // per sub-batch: its SAM lines in read order (gather_lines_kernel)
     DBuf<uint64_t> ak_dev_len, ak_dev_off, ak_dev_pos; DBuf<unsigned long long> ak_dev_sum;
     HBuf<unsigned long long> h_sum;                   // per sub-batch: bytes of the block, records that need the host, aligned reads
-    DBuf<uint8_t> gather_tmp[2];                      // rocPRIM scan workspace of the gather, one per stream it runs on (the two streams' scans overlap)
+    DBuf<uint8_t> gather_tmp[AK_NSET];                      // rocPRIM scan workspace of the gather, one per stream it runs on (the two streams' scans overlap)
     float ak_kernel_ms = 0;
 };
 
@@ -346,12 +349,13 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->seq.release(); c->offs.release(); c->ptr.release(); c->pat.release(); c->cnt_m.release(); c->cnt_s.release(); c->mem_slots.release(); c->tot.release();
     c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
     c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
-    c->af[0].release(); c->af[1].release(); c->af_ctr_host.release();
+    for (int x = 0; x < AK_NSET; ++x) c->af[x].release();
+    c->af_ctr_host.release();
     c->dp_q.release(); c->dp_t.release(); c->dp_dir.release(); c->dp_tasks.release(); c->dp_res.release(); c->dp_cig.release();
     c->dp_off.release(); c->dp_ws.release(); c->dp_big.release(); c->dp_dir_big.release(); c->ak_slots.release(); c->ak_waves.release(); c->ak_cursors.release(); c->ak_rnames.release(); c->ak_quals.release(); c->ak_rname_off.release(); c->ak_txt.release(); c->ak_mapq_tab.release(); c->h_txt.release(); c->h_recs.release(); c->h_cig.release(); c->h_alt.release(); c->h_md.release();
     for (auto& ob : c->pieces) ob.release();
-    if (c->ak_stream[1]) (void)hipStreamDestroy(c->ak_stream[1]);
-    for (int x = 0; x < 2; ++x) if (c->fb_stream[x]) (void)hipStreamDestroy(c->fb_stream[x]);
+    for (int x = 0; x < AK_NSET; ++x) if (c->ak_stream[x]) (void)hipStreamDestroy(c->ak_stream[x]);
+    for (int x = 0; x < AK_NSET; ++x) if (c->fb_stream[x]) (void)hipStreamDestroy(c->fb_stream[x]);
     for (auto e : c->ak_fin) (void)hipEventDestroy(e);
     for (auto e : c->af_ev) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -360,7 +364,7 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->ak_recs.release(); c->ak_cig.release(); c->ak_alt.release(); c->ak_minscore.release();
     if (c->d_ak_cursors) (void)hipFree(c->d_ak_cursors);
     if (c->out_buf) (void)hipHostFree(c->out_buf);
-    c->gather_tmp[0].release(); c->gather_tmp[1].release();
+    for (int x = 0; x < AK_NSET; ++x) c->gather_tmp[x].release();
     c->ak_block.release(); c->ak_dev_len.release(); c->ak_dev_off.release(); c->ak_dev_pos.release(); c->ak_dev_sum.release(); c->h_sum.release();
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->d_counters) (void)hipFree(c->d_counters);
@@ -399,21 +403,35 @@ static int reads_upload(moni_ctx* c, const moni_read_batch_t* b, bool keep_host_
     return MONI_OK;
 }
 
-static int ms_launch(moni_ctx* c) {
+// A slice = a range of the resident reads with its own region of every seeding buffer (the whole batch is the slice r0 = 0).  The
+// align stage seeds sub-batch k+1 while the align kernels of sub-batch k run: their seeds must stay where they are.
+struct SeedSlice {
+    uint64_t r0 = 0, nr = 0, idx = 0;        // reads [r0, r0 + nr), slice number
+    uint64_t mem_base = 0, occ_base = 0;     // first MEM / occurrence of the slice in c->mems / c->occs (pipelined: after the earlier slices')
+    uint64_t n_mems = 0, n_occs = 0;         // results
+    bool pipelined = false;                  // buffers were sized for the whole batch by the caller; growing them needs a drained GPU
+    uint64_t rmo() const { return r0 + idx; }                 // tot / read_mem_off: nr + 1 entries per slice
+    uint64_t mem_at() const { return mem_base + 2 * idx; }    // per-MEM arrays with n_mems + 1 (+1) entries per slice
+};
+
+static int ms_launch(moni_ctx* c, const SeedSlice& S) {
     moni_index* I = c->idx;
-    const uint64_t n_tasks = 2 * c->n_reads;
+    const uint64_t n_tasks = 2 * S.nr;
     const uint32_t n_words = (uint32_t)((c->max_len + 7) / 8);
-    int rc = c->ptr.ensure(n_tasks * c->max_len + 1);
-    if (rc) return rc;
-    if ((rc = c->pat.ensure(n_tasks * n_words + 1))) return rc;
+    int rc;
+    if (!S.pipelined) {
+        if ((rc = c->ptr.ensure(2 * c->n_reads * c->max_len + 1))) return rc;
+        if ((rc = c->pat.ensure(2 * c->n_reads * n_words + 1))) return rc;
+    }
+    uint64_t* pat = c->pat.p + 2 * S.r0 * n_words; uint64_t* ptr = c->ptr.p + 2 * S.r0 * c->max_len; const uint64_t* offs = c->offs.p + S.r0;
     const unsigned grid = (unsigned)((n_tasks + MS_BLOCK - 1) / MS_BLOCK);
     if (n_tasks)
-        hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, c->seq.p, c->offs.p, n_tasks, n_words, c->pat.p);
+        hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, c->seq.p, offs, n_tasks, n_words, pat);
     rec(c, EV_MS0);
     if (n_tasks) {
 #define MS_LAUNCH(NCH, MINW) do { const uint64_t nl = (n_tasks + (NCH) - 1) / (NCH); \
         hipLaunchKernelGGL((ms_lf_kernel<NCH, MINW>), dim3((unsigned)((nl + MS_BLOCK - 1) / MS_BLOCK)), dim3(MS_BLOCK), 0, c->stream, \
-                           I->K, I->d_tables, I->d_rows, I->d_frows, I->d_cr, I->d_recs, c->pat.p, c->offs.p, n_tasks, c->ptr.p, c->d_counters); } while (0)
+                           I->K, I->d_tables, I->d_rows, I->d_frows, I->d_cr, I->d_recs, pat, offs, n_tasks, ptr, c->d_counters); } while (0)
         switch (c->ms_variant) {
             case 1: MS_LAUNCH(1, 8); break;
             case 2: MS_LAUNCH(2, 8); break;
@@ -428,6 +446,7 @@ static int ms_launch(moni_ctx* c) {
     HIPCHK(hipGetLastError());
     return MONI_OK;
 }
+static int ms_launch(moni_ctx* c) { SeedSlice S; S.nr = c->n_reads; return ms_launch(c, S); }
 
 int moni_ms_run(moni_ctx_t* c) {
     if (!c) return MONI_EINVAL;
@@ -486,48 +505,66 @@ int moni_ms_lengths_batch(moni_ctx_t* c, const moni_read_batch_t* b, uint64_t* p
     return MONI_OK;
 }
 
-int moni_seed_run(moni_ctx_t* c, const moni_seed_params_t* prm) {
-    if (!c || !prm) return MONI_EINVAL;
+// Per-MEM buffers of a pipelined batch: grown only with the GPU drained (earlier slices' align kernels read them through pointers in
+// their arguments); nothing has to be kept, the slice that needs the room has not written there yet.
+static int grow_drained(moni_ctx* c, bool pipelined) {
+    if (pipelined) HIPCHK(hipDeviceSynchronize());
+    return MONI_OK;
+}
+
+static int seed_slice(moni_ctx* c, const moni_seed_params_t* prm, SeedSlice& S) {
     moni_index* I = c->idx;
-    HIPCHK(hipSetDevice(I->device));
-    const uint64_t nr = c->n_reads, n_tasks = 2 * nr;
+    const uint64_t nr = S.nr, n_tasks = 2 * nr;
     int rc;
-    if ((rc = c->cnt_m.ensure(n_tasks + 2)) || (rc = c->cnt_s.ensure(n_tasks + 2)) || (rc = c->tot.ensure(nr + 2)) ||
-        (rc = c->read_mem_off.ensure(nr + 2)) || (rc = c->mem_slots.ensure(n_tasks * MONI_MEM_SLOTS + 1)))
+    if (!S.pipelined && ((rc = c->cnt_m.ensure(n_tasks + 2)) || (rc = c->cnt_s.ensure(n_tasks + 2)) || (rc = c->tot.ensure(nr + 2)) ||
+                         (rc = c->read_mem_off.ensure(nr + 2)) || (rc = c->mem_slots.ensure(n_tasks * MONI_MEM_SLOTS + 1))))
         return rc;
+    uint32_t* cnt_m = c->cnt_m.p + 2 * S.r0; uint32_t* cnt_s = c->cnt_s.p + 2 * S.r0;
+    uint64_t* tot = c->tot.p + S.rmo(); uint64_t* rmo = c->read_mem_off.p + S.rmo();
+    moni_u64x2* slots = c->mem_slots.p + 2 * S.r0 * MONI_MEM_SLOTS;
+    const uint32_t n_words = (uint32_t)((c->max_len + 7) / 8);
+    const uint64_t* offs = c->offs.p + S.r0;
     HIPCHK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->d_small, 0, 16, c->stream));
     rec(c, EV_ALL0);
-    if ((rc = ms_launch(c))) return rc;
+    if ((rc = ms_launch(c, S))) return rc;                              // (allocates pat / ptr of a whole-batch slice)
+    const uint64_t* pat = c->pat.p + 2 * S.r0 * n_words; const uint64_t* ptr = c->ptr.p + 2 * S.r0 * c->max_len;
     const unsigned grid_t = (unsigned)((n_tasks + MS_BLOCK - 1) / MS_BLOCK);
     const uint32_t split_on = prm->report_mems ? 0u : 1u;
     rec(c, EV_MC0);
     if (n_tasks)
-        hipLaunchKernelGGL(mem_kernel<false>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, c->pat.p, c->offs.p,
-                           n_tasks, c->ptr.p, prm->min_len, split_on, c->cnt_m.p, c->cnt_s.p, (const uint64_t*)nullptr,
-                           (moni_mem_t*)nullptr, (uint32_t*)nullptr, c->mem_slots.p, c->d_counters);
+        hipLaunchKernelGGL(mem_kernel<false>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, pat, offs,
+                           n_tasks, ptr, prm->min_len, split_on, cnt_m, cnt_s, (const uint64_t*)nullptr,
+                           (moni_mem_t*)nullptr, (uint32_t*)nullptr, slots, c->d_counters);
     rec(c, EV_MC1);
-    hipLaunchKernelGGL(read_totals_kernel, dim3((unsigned)((nr + 1 + 255) / 256)), dim3(256), 0, c->stream, c->cnt_m.p, c->cnt_s.p, nr, c->tot.p);
-    if ((rc = exclusive_scan_u64(c, c->tot.p, c->read_mem_off.p, nr + 1))) return rc;
+    hipLaunchKernelGGL(read_totals_kernel, dim3((unsigned)((nr + 1 + 255) / 256)), dim3(256), 0, c->stream, cnt_m, cnt_s, nr, tot);
+    if ((rc = exclusive_scan_u64(c, tot, rmo, nr + 1))) return rc;
     uint64_t n_mems = 0;
-    HIPCHK(hipMemcpyAsync(&n_mems, c->read_mem_off.p + nr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&n_mems, rmo + nr, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->n_mems = n_mems;
+    S.n_mems = n_mems;
     c->tmp_cap = 16;
-    if ((rc = c->mems.ensure(n_mems + 1)) || (rc = c->aux.ensure(n_mems + 1)) || (rc = c->lowers.ensure(n_mems + 1)) ||
-        (rc = c->tmp.ensure(n_mems * c->tmp_cap + 1)) || (rc = c->occ_cnt.ensure(n_mems + 2)) || (rc = c->occ_off.ensure(n_mems + 2)) ||
-        (rc = c->pool.ensure((size_t)c->pool_rows * I->K.n_seq + 1)))
-        return rc;
+    {
+        const uint64_t need = S.mem_at() + n_mems + 2;
+        if (need > c->mems.cap || need > c->aux.cap || need > c->lowers.cap || need * c->tmp_cap > c->tmp.cap || need > c->occ_cnt.cap || need > c->occ_off.cap) {
+            if ((rc = grow_drained(c, S.pipelined))) return rc;
+            const uint64_t want = S.pipelined ? need + need / 2 : need;
+            if ((rc = c->mems.ensure(want)) || (rc = c->aux.ensure(want)) || (rc = c->lowers.ensure(want)) || (rc = c->tmp.ensure(want * c->tmp_cap + 1)) ||
+                (rc = c->occ_cnt.ensure(want + 1)) || (rc = c->occ_off.ensure(want + 1))) return rc;
+        }
+        if ((rc = c->pool.ensure((size_t)c->pool_rows * I->K.n_seq + 1))) return rc;
+    }
+    moni_mem_t* mems = c->mems.p + S.mem_at(); uint32_t* aux = c->aux.p + S.mem_at();
+    uint64_t* occ_cnt = c->occ_cnt.p + S.mem_at(); uint64_t* occ_off = c->occ_off.p + S.mem_at();
     rec(c, EV_ME0);
     if (n_tasks)
-        hipLaunchKernelGGL(mem_kernel<true>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, c->pat.p, c->offs.p,
-                           n_tasks, c->ptr.p, prm->min_len, split_on, c->cnt_m.p, c->cnt_s.p, c->read_mem_off.p, c->mems.p, c->aux.p,
-                           c->mem_slots.p, c->d_counters);
+        hipLaunchKernelGGL(mem_kernel<true>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, pat, offs,
+                           n_tasks, ptr, prm->min_len, split_on, cnt_m, cnt_s, (const uint64_t*)rmo, mems, aux, slots, c->d_counters);
     rec(c, EV_ME1);
     occ_args_t A;
     A.phi.recs = I->d_phi; A.phi.dir = I->d_phi_dir; A.phi_inv.recs = I->d_phi_inv; A.phi_inv.dir = I->d_phi_inv_dir;
-    A.seq_starts = I->d_seq_starts; A.name_id = I->d_name_id; A.mems = c->mems.p; A.aux = c->aux.p; A.read_mem_off = c->read_mem_off.p;
-    A.n_mems = n_mems; A.occs = nullptr; A.tmp = c->tmp.p; A.lowers = c->lowers.p; A.tmp_cap = c->tmp_cap;
+    A.seq_starts = I->d_seq_starts; A.name_id = I->d_name_id; A.mems = mems; A.aux = aux; A.read_mem_off = rmo;
+    A.n_mems = n_mems; A.occs = nullptr; A.tmp = c->tmp.p + S.mem_at() * c->tmp_cap; A.lowers = c->lowers.p + S.mem_at(); A.tmp_cap = c->tmp_cap;
     A.filter_seeds = prm->filter_seeds; A.n_seeds_thr = prm->n_seeds_thr; A.pool_rows = c->pool_rows; A.pool = c->pool.p;
     A.pool_next = c->d_small; A.error_flag = c->d_small + 1; A.counters = c->d_counters;
     const unsigned grid_m = (unsigned)((n_mems + MS_BLOCK - 1) / MS_BLOCK);
@@ -550,14 +587,18 @@ int moni_seed_run(moni_ctx_t* c, const moni_seed_params_t* prm) {
         c->pool_rows = small[0] + small[0] / 4 + 64;
         if ((rc = c->pool.ensure((size_t)c->pool_rows * I->K.n_seq + 1))) return rc;
     }
-    hipLaunchKernelGGL(occ_cnt_gather_kernel, dim3((unsigned)((n_mems + 1 + 255) / 256)), dim3(256), 0, c->stream, c->mems.p, n_mems, c->occ_cnt.p);
-    if ((rc = exclusive_scan_u64(c, c->occ_cnt.p, c->occ_off.p, n_mems + 1))) return rc;
-    if (n_mems) hipLaunchKernelGGL(occ_off_scatter_kernel, dim3(grid_m), dim3(256), 0, c->stream, c->mems.p, n_mems, c->occ_off.p);
-    HIPCHK(hipMemcpyAsync(&n_occs, c->occ_off.p + n_mems, 8, hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(occ_cnt_gather_kernel, dim3((unsigned)((n_mems + 1 + 255) / 256)), dim3(256), 0, c->stream, mems, n_mems, occ_cnt);
+    if ((rc = exclusive_scan_u64(c, occ_cnt, occ_off, n_mems + 1))) return rc;
+    if (n_mems) hipLaunchKernelGGL(occ_off_scatter_kernel, dim3(grid_m), dim3(256), 0, c->stream, mems, n_mems, occ_off);
+    HIPCHK(hipMemcpyAsync(&n_occs, occ_off + n_mems, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->n_occs = n_occs;
-    if ((rc = c->occs.ensure(n_occs + 1))) return rc;
-    A.occs = c->occs.p;
+    S.n_occs = n_occs;
+    if (S.occ_base + n_occs + 1 > c->occs.cap) {
+        if ((rc = grow_drained(c, S.pipelined))) return rc;
+        const uint64_t need = S.occ_base + n_occs + 1;
+        if ((rc = c->occs.ensure(S.pipelined ? need + need / 2 : need))) return rc;
+    }
+    A.occs = c->occs.p + S.occ_base;
     for (int attempt = 0;; ++attempt) {
         A.pool = c->pool.p; A.pool_rows = c->pool_rows;
         HIPCHK(hipMemsetAsync(c->d_small, 0, 16, c->stream));
@@ -573,6 +614,27 @@ int moni_seed_run(moni_ctx_t* c, const moni_seed_params_t* prm) {
         if ((rc = c->pool.ensure((size_t)c->pool_rows * I->K.n_seq + 1))) return rc;
     }
     HIPCHK(hipGetLastError());
+    if (S.pipelined) {      // kernel times and work counters of the slices add up to the batch's
+        for (int w = 0; w < 7; ++w) {
+            const int ea = w == 6 ? EV_ALL0 : 2 * w, eb = ea + 1;
+            float ms = 0;
+            if (c->ev_valid[ea] && c->ev_valid[eb] && hipEventElapsedTime(&ms, c->ev[ea], c->ev[eb]) == hipSuccess) c->ms_accum[w] += ms;
+        }
+        unsigned long long h[4];
+        HIPCHK(hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 4; ++i) c->ctr_accum[i] += h[i];
+    }
+    return MONI_OK;
+}
+
+int moni_seed_run(moni_ctx_t* c, const moni_seed_params_t* prm) {
+    if (!c || !prm) return MONI_EINVAL;
+    HIPCHK(hipSetDevice(c->idx->device));
+    SeedSlice S; S.nr = c->n_reads;
+    c->accum_valid = false;
+    int rc = seed_slice(c, prm, S);
+    if (rc) return rc;
+    c->n_mems = S.n_mems; c->n_occs = S.n_occs;
     return MONI_OK;
 }
 
@@ -628,6 +690,7 @@ int moni_phi_lcp_batch(moni_ctx_t* c, const uint64_t* pos, uint64_t n, int inver
 
 int moni_last_kernel_ms(moni_ctx_t* c, int which, float* ms) {
     if (!c || !ms || which < 0 || which > 6) return MONI_EINVAL;
+    if (c->accum_valid && which != 5) { *ms = c->ms_accum[which]; return MONI_OK; }
     const int a = which == 6 ? EV_ALL0 : 2 * which, b = a + 1;
     if (!c->ev_valid[a] || !c->ev_valid[b]) return MONI_EINVAL;
     HIPCHK(hipEventSynchronize(c->ev[b]));
@@ -638,6 +701,7 @@ int moni_last_kernel_ms(moni_ctx_t* c, int which, float* ms) {
 int moni_last_counters(moni_ctx_t* c, uint64_t out[4]) {
     if (!c || !out) return MONI_EINVAL;
     HIPCHK(hipSetDevice(c->idx->device));
+    if (c->accum_valid) { for (int i = 0; i < 4; ++i) out[i] = c->ctr_accum[i]; return MONI_OK; }
     unsigned long long h[4];
     HIPCHK(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; ++i) out[i] = h[i];
@@ -852,6 +916,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         // several reads per lane in flight: ~4000 waves x AK_NL lanes), a small last one (the host stage left over after it is short)
         uint64_t sub_min = 250000, sub_mid = 250000;      // ~one read per lane and launch (4096 waves x AK_NL = 64 lanes); equal pieces: measured, profiles/sweep_align_nl.sh
         if (const char* v = getenv("MONI_ALIGN_SUB")) { const long long x = atoll(v); if (x > 0) sub_min = sub_mid = (uint64_t)x; }
+        if (const char* v = getenv("MONI_ALIGN_SUB_MIN")) { const long long x = atoll(v); if (x > 0) sub_min = (uint64_t)x; }
         std::vector<uint64_t> sub_lo(1, 0);
         while (sub_lo.back() < NR) {
             const uint64_t done = sub_lo.back(), rest = NR - done;
@@ -916,13 +981,31 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             });
         }
         struct JoinGuard { std::thread& t; ~JoinGuard() { if (t.joinable()) t.join(); } } join_guard{uploader};
-        // seeding: the whole batch at once (the LF kernel wants millions of lanes in flight)
+        // The staged kernels (align_fast.hip) take the common case; align_kernel takes the reads they hand over (MONI_ALIGN_V1=1: every read)
+        static const bool use_fast = getenv("MONI_ALIGN_V1") == nullptr;
+        // seeding: with one sub-batch the whole batch at once; with several, slice by slice inside the launch loop below, so that the
+        // (HBM-bound) seeding of sub-batch k+1 runs beside the (latency-bound) align kernels of sub-batch k
+        // (opt-in, MONI_SEED_PIPELINE=1: measured, it does not pay inside one context — the two align streams already fill the GPU, the slices'
+        // seeding and the align kernels only slow each other down, 83.7 ms against 80.6 ms per 1 M reads; two contexts out of phase do gain)
+        const bool pipelined = use_fast && n_sub >= 2 && getenv("MONI_SEED_PIPELINE") != nullptr;
+        moni_seed_params_t sp;
+        sp.min_len = prm->min_len; sp.filter_seeds = prm->filter_seeds; sp.n_seeds_thr = prm->n_seeds_thr; sp.report_mems = 0;
         {
             const double t0 = mh::now_s();
             if (!resident && (rc = reads_upload(c, b, false))) return rc;
-            moni_seed_params_t sp;
-            sp.min_len = prm->min_len; sp.filter_seeds = prm->filter_seeds; sp.n_seeds_thr = prm->n_seeds_thr; sp.report_mems = 0;
-            if ((rc = moni_seed_run(c, &sp))) return rc;
+            if (!pipelined) { if ((rc = moni_seed_run(c, &sp))) return rc; }
+            else {
+                const uint32_t n_words = (uint32_t)((c->max_len + 7) / 8);
+                if (const char* v = getenv("MONI_SEED_EST")) { double a = 0, b2 = 0; if (sscanf(v, "%lf,%lf", &a, &b2) == 2 && a > 0 && b2 > 0) { c->est_mems_per_read = a; c->est_occs_per_read = b2; } }      // test hook: small estimates exercise the growth path
+                const uint64_t em = (uint64_t)((double)NR * c->est_mems_per_read * 1.2) + 4 * n_sub + 4096, eo = (uint64_t)((double)NR * c->est_occs_per_read * 1.2) + 4096;
+                if ((rc = c->ptr.ensure(2 * NR * c->max_len + 1)) || (rc = c->pat.ensure(2 * NR * n_words + 1)) || (rc = c->cnt_m.ensure(2 * NR + 2)) || (rc = c->cnt_s.ensure(2 * NR + 2)) ||
+                    (rc = c->tot.ensure(NR + n_sub + 2)) || (rc = c->read_mem_off.ensure(NR + n_sub + 2)) || (rc = c->mem_slots.ensure(2 * NR * MONI_MEM_SLOTS + 1)) ||
+                    (rc = c->mems.ensure(em)) || (rc = c->aux.ensure(em)) || (rc = c->lowers.ensure(em)) || (rc = c->tmp.ensure(em * 16 + 1)) || (rc = c->occ_cnt.ensure(em + 1)) ||
+                    (rc = c->occ_off.ensure(em + 1)) || (rc = c->occs.ensure(eo))) return rc;
+                for (int w = 0; w < 7; ++w) c->ms_accum[w] = 0;
+                for (int i = 0; i < 4; ++i) c->ctr_accum[i] = 0;
+                c->accum_valid = true; c->n_mems = c->n_occs = 0;
+            }
             st.t_seed += mh::now_s() - t0;
         }
         t_mark[0] = mh::now_s() - t_enter;
@@ -949,12 +1032,10 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 c->mapq_tab_ready = true;
             }
         }
-        // The staged kernels (align_fast.hip) take the common case; align_kernel takes the reads they hand over (MONI_ALIGN_V1=1: every read)
-        static const bool use_fast = getenv("MONI_ALIGN_V1") == nullptr;
         int n_cu = 256;
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, I->device) == hipSuccess) n_cu = pr.multiProcessorCount; }
         const uint64_t ak_waves = use_fast ? std::min<uint64_t>(waves_full, 1024) : waves_full;       // in-flight read slots of align_kernel (75 KB each)
-        if ((rc = c->ak_slots.ensure(2 * ak_waves * AK_NL)) || (rc = c->ak_waves.ensure(2 * ak_waves)) || (rc = c->h_recs.ensure(NR + 1)) ||
+        if ((rc = c->ak_slots.ensure(AK_NSET * ak_waves * AK_NL)) || (rc = c->ak_waves.ensure(AK_NSET * ak_waves)) || (rc = c->h_recs.ensure(NR + 1)) ||
             (rc = c->h_cig.ensure(cig_per * n_sub + 1)) || (rc = c->h_alt.ensure(alt_per * n_sub + 1)) || (rc = c->h_md.ensure(md_per * n_sub + 1)) || (rc = c->ak_minscore.ensure(msc.size())) ||
             (rc = c->ak_cursors.ensure(AK_CUR * n_sub + AK_CUR)))
             return rc;
@@ -971,10 +1052,10 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         size_t gather_tmp_bytes = 0;
         if (inorder) {
             if (rocprim::exclusive_scan(nullptr, gather_tmp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, (size_t)sub_reads, rocprim::plus<uint64_t>(), c->stream) != hipSuccess) return MONI_ENODEV;
-            if ((rc = c->gather_tmp[0].ensure(gather_tmp_bytes + 16)) || (rc = c->gather_tmp[1].ensure(gather_tmp_bytes + 16))) return rc;
+            if ((rc = c->gather_tmp[0].ensure(gather_tmp_bytes + 16)) || (rc = c->gather_tmp[1].ensure(gather_tmp_bytes + 16)) || (rc = c->gather_tmp[AK_NSET - 1].ensure(gather_tmp_bytes + 16))) return rc;
         }
         if (inorder) { HIPCHK(hipMemsetAsync(c->ak_dev_sum.p, 0, (160 * n_sub + 8) * sizeof(unsigned long long), c->stream)); memset(c->h_sum.p, 0, (4 * n_sub + 4) * sizeof(unsigned long long)); }
-        if (use_fast) for (int x = 0; x < (n_sub > 1 ? 2 : 1); ++x) {
+        if (use_fast) for (int x = 0; x < (int)std::min<uint64_t>(n_sub, AK_NSET); ++x) {
             moni_ctx::AfSet& S = c->af[x];
             if ((rc = S.plans.ensure(sub_reads + 1)) || (rc = S.tasks.ensure(af_task_cap)) || (rc = S.res.ensure(af_task_cap)) || (rc = S.bin_q.ensure((size_t)AF_NBIN * af_task_cap)) ||
                 (rc = S.task_pos.ensure(af_task_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.fb_list.ensure(sub_reads + 1)) || (rc = S.big_list.ensure(sub_reads + 1)) ||
@@ -983,12 +1064,12 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         }
         // the launches alternate between the context's stream and one more: HIP multiplexes streams onto a handful of hardware queues
         // (4 by default), and two streams that land on the same queue run their kernels one after the other
-        c->ak_stream[0] = c->stream;
-        if (!c->ak_stream[1]) HIPCHK(hipStreamCreateWithFlags(&c->ak_stream[1], hipStreamNonBlocking));
+        // (the context's own stream carries the seeding, which in the pipelined form runs beside the align launches)
+        for (int x = 0; x < AK_NSET; ++x) if (!c->ak_stream[x]) HIPCHK(hipStreamCreateWithFlags(&c->ak_stream[x], hipStreamNonBlocking));
         if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         while (c->ak_done.size() < n_sub) { hipEvent_t e0, e1, e2; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
                                             c->ak_begin.push_back(e0); c->ak_done.push_back(e1); c->ak_fin.push_back(e2); }
-        for (int x = 0; x < 2; ++x) if (use_fast && !c->fb_stream[x]) HIPCHK(hipStreamCreateWithFlags(&c->fb_stream[x], hipStreamNonBlocking));
+        for (int x = 0; x < AK_NSET; ++x) if (use_fast && !c->fb_stream[x]) HIPCHK(hipStreamCreateWithFlags(&c->fb_stream[x], hipStreamNonBlocking));
         while (c->af_ev.size() < 3 * n_sub) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->af_ev.push_back(e); }
         HIPCHK(hipMemsetAsync(c->ak_cursors.p, 0, (AK_CUR * n_sub + AK_CUR) * sizeof(unsigned long long), c->stream));
         HIPCHK(hipMemcpyAsync(c->ak_minscore.p, msc.data(), msc.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -996,107 +1077,6 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         t_launch[0] = mh::now_s() - t_enter;
         if ((rc = c->af_ctr_host.ensure(AF_NCTR * n_sub + AF_NCTR))) return rc;
         memset(c->af_ctr_host.p, 0, AF_NCTR * n_sub * sizeof(uint32_t));
-        for (uint64_t k = 0; k < n_sub; ++k) {
-            const uint64_t r0 = sub_lo[k], nr = sub_lo[k + 1] - sub_lo[k];
-            uint64_t n_waves = ak_waves;
-            if (!use_fast && n_waves * AK_NL > nr) n_waves = (nr + AK_NL - 1) / AK_NL;
-            waves_used = std::max(waves_used, n_waves);
-            ak_args_t A;
-            memset(&A, 0, sizeof A);
-            A.P.min_len = prm->min_len; A.P.ext_len = prm->ext_len; A.P.check_k = prm->check_k; A.P.region_dist = prm->region_dist;
-            A.P.filter_freq = prm->filter_freq; A.P.left_mem_check = prm->left_mem_check; A.P.freq_thr = prm->freq_thr;
-            A.P.smatch = prm->smatch; A.P.gapo = prm->gapo; A.P.gapo2 = prm->gapo2; A.P.gape = prm->gape; A.P.gape2 = prm->gape2;
-            A.P.max_dist_x = prm->max_dist_x; A.P.max_dist_y = prm->max_dist_y; A.P.max_iter = prm->max_iter; A.P.max_pred = prm->max_pred;
-            A.P.min_chain_score = prm->min_chain_score; A.P.min_chain_length = prm->min_chain_length;
-            A.P.n_text = I->K.n_text; A.P.n_seq = I->K.n_seq; A.P.seq_starts = I->d_seq_starts;
-            A.P.lift_seqs = I->d_lift_seqs; A.P.lift_runs = I->d_lift_runs; A.P.pdir = I->d_pdir;
-            A.D.sc_mch = prm->smatch; A.D.sc_mis = -prm->smismatch; A.D.sc_N = -prm->gape; A.D.wild = 4; A.D.qo = prm->gapo; A.D.e = prm->gape;
-            A.D.end_bonus = prm->end_bonus; A.D.reads = c->seq.p; A.D.text = I->d_text; A.D.n_text = I->K.n_text;
-            A.D.reads_limit = (c->total_len + 8) & ~7ull; A.D.text_limit = (I->K.n_text + 8) & ~7ull;       // both buffers carry 16 bytes of padding
-            A.mems = c->mems.p; A.occs = c->occs.p; A.read_mem_off = c->read_mem_off.p; A.offs = c->offs.p;
-            A.min_score_of_len = c->ak_minscore.p; A.max_len = (uint32_t)c->max_len + 1; A.read_lo = r0; A.n_reads = nr;
-            A.slots = c->ak_slots.p + (k & 1) * ak_waves * AK_NL; A.waves = c->ak_waves.p + (k & 1) * ak_waves;
-            A.recs = c->h_recs.p + r0; A.cig_pool = c->h_cig.p + k * cig_per; A.cig_cap = cig_per; A.alt_pool = c->h_alt.p + k * alt_per;
-            A.alt_cap = alt_per; A.md_pool = c->h_md.p + k * md_per; A.md_cap = md_per; A.cursors = c->ak_cursors.p + AK_CUR * k;
-            if (gpu_text) {
-                A.fmt.rnames = c->ak_rnames.p; A.fmt.rname_off = c->ak_rname_off.p; A.fmt.quals = quals ? c->ak_quals.p : nullptr;
-                A.fmt.snames = I->d_snames; A.fmt.sname_off = I->d_sname_off; A.fmt.mapq_tab = c->ak_mapq_tab.p; A.fmt.mapq_tab_n = 8192;
-                A.fmt.min_len = (int32_t)prm->min_len; A.fmt.smatch = prm->smatch; A.fmt.smismatch = prm->smismatch;
-                A.fmt.txt_pool = c->ak_txt.p + k * txt_per; A.fmt.txt_cap = (use_fast && nr > 0) ? txt_per / (AF_TXT_SHARDS + 1) : txt_per;
-            }
-            if (inorder) { A.dev_len = c->ak_dev_len.p + r0 + k; A.dev_off = c->ak_dev_off.p + r0 + k; A.dev_sum = c->ak_dev_sum.p + 160 * k; }
-            hipStream_t sx = c->ak_stream[k & 1];
-            if (use_fast && k >= 2) HIPCHK(hipStreamWaitEvent(sx, c->ak_done[k - 2], 0));      // the set's buffers are free once its previous sub-batch is through align_kernel too
-            HIPCHK(hipEventRecord(c->ak_begin[k], sx));
-            bool done_recorded = false;
-            if (use_fast && nr > 0) {
-                moni_ctx::AfSet& S = c->af[k & 1];
-                af_args_t G;
-                memset(&G, 0, sizeof G);
-                G.A = A;
-                G.plans = S.plans.p; G.tasks = S.tasks.p; G.task_cap = af_task_cap; G.res = S.res.p; G.bin_q = S.bin_q.p; G.bin_cap = af_task_cap; G.task_pos = S.task_pos.p;
-                G.chunks = S.chunks.p; G.chunk_cap = af_chunk_cap; G.dirs = S.dirs.p; G.dirs_cap = af_dirs_cap; G.tb_task = S.tb_task.p; G.tb = S.tb.p; G.tb_cap = af_tb_cap;
-                G.fb_list = S.fb_list.p; G.big_list = S.big_list.p; G.fin_scratch = S.fin.p; G.fin_stride = sizeof(af_fin_t); G.ctr = S.ctr.p;
-                G.bnd = S.bnd.p;
-                G.txt_cur = S.txt_cur.p; G.txt_shard_words = txt_per / (AF_TXT_SHARDS + 1);
-                HIPCHK(hipMemsetAsync(S.txt_cur.p, 0, AF_TXT_SHARDS * 8 * sizeof(unsigned long long), sx));
-#ifdef AF_PROFILE
-                if ((rc = S.prof.ensure(32))) return rc;
-                if (k < 2) HIPCHK(hipMemsetAsync(S.prof.p, 0, 32 * 8, sx));
-                G.prof = S.prof.p;
-                if (const char* v = getenv("MONI_AF_DBG")) G.dbg = (uint32_t)atoi(v);
-#endif
-                HIPCHK(hipMemsetAsync(S.ctr.p, 0, AF_NCTR * sizeof(uint32_t), sx));
-                {
-                    static const int k1occ = getenv("MONI_AF_K1OCC") ? atoi(getenv("MONI_AF_K1OCC")) : 6;
-                    const dim3 g1((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 4 * k1occ));
-                    if (k1occ == 4) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 4>), g1, dim3(64), 0, sx, G);
-                    else if (k1occ == 5) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 5>), g1, dim3(64), 0, sx, G);
-                    else if (k1occ == 8) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 8>), g1, dim3(64), 0, sx, G);
-                    else hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 6>), g1, dim3(64), 0, sx, G);
-                }
-                hipLaunchKernelGGL((chain_plan_kernel<af_wave_t, true>), dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 10)), dim3(64), 0, sx, G);
-                HIPCHK(hipEventRecord(c->af_ev[3 * k], sx));
-                hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_SMALL);
-                hipLaunchKernelGGL((dp_lane_kernel<AF_BLK, AF_QCAP, AF_LPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE);
-                hipLaunchKernelGGL((dp_lane_kernel<AF_TS, AF_TS, 1>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_SMALL);
-                hipLaunchKernelGGL(global_task_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
-                hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL, (uint32_t)AF_GRP_GLOBAL);
-                hipLaunchKernelGGL((dp_lane_kernel<AF_GBLK, AF_QCAP, AF_GPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL);
-                HIPCHK(hipEventRecord(c->af_ev[3 * k + 1], sx));
-                hipLaunchKernelGGL(select_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
-                hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)((af_tb_cap + 255) / 256)), dim3(256), 0, sx, G);
-                HIPCHK(hipEventRecord(c->af_ev[3 * k + 2], sx));
-                // the record and the SAM line of every read that stayed on the staged path: one wave per read when the kernel spells the text
-                if (gpu_text) hipLaunchKernelGGL(finish_wave_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 24)), dim3(64), 0, sx, G);
-                else hipLaunchKernelGGL(finish_kernel, dim3((unsigned)std::min<uint64_t>((nr + 63) / 64, af_fin_grid)), dim3(64), 0, sx, G);
-                // the reads the staged kernels handed over: few, but each a long serial job; they run beside the next sub-batch's kernels
-                A.read_list = S.fb_list.p; A.n_reads_dev = S.ctr.p + AFC_FALLBACK;
-                hipStream_t sf = c->fb_stream[k & 1];
-                HIPCHK(hipEventRecord(c->ak_fin[k], sx));
-                HIPCHK(hipStreamWaitEvent(sf, c->ak_fin[k], 0));
-                hipLaunchKernelGGL(align_kernel, dim3((unsigned)ak_waves), dim3(64), 0, sf, A);
-                HIPCHK(hipMemcpyAsync(c->af_ctr_host.p + AF_NCTR * k, S.ctr.p, AF_NCTR * sizeof(uint32_t), hipMemcpyDeviceToHost, sf));
-                if (inorder) {          // lines in read order: scan of the lengths, gather, summary for the host
-                    uint64_t* pos = c->ak_dev_pos.p + r0 + 2 * k;
-                    size_t tmp_bytes = 0;
-                    if (rocprim::exclusive_scan(nullptr, tmp_bytes, A.dev_len, pos, (uint64_t)0, nr, rocprim::plus<uint64_t>(), sf) != hipSuccess || tmp_bytes > gather_tmp_bytes + 16) return MONI_ENODEV;
-                    if (rocprim::exclusive_scan(c->gather_tmp[k & 1].p, tmp_bytes, A.dev_len, pos, (uint64_t)0, nr, rocprim::plus<uint64_t>(), sf) != hipSuccess) return MONI_ENODEV;
-                    hipLaunchKernelGGL(gather_lines_kernel, dim3((unsigned)std::min<uint64_t>((nr + 3) / 4, (uint64_t)n_cu * 8)), dim3(256), 0, sf, (const uint64_t*)A.fmt.txt_pool,
-                                       (const uint64_t*)A.dev_len, (const uint64_t*)A.dev_off, (const uint64_t*)pos, nr, reinterpret_cast<uint8_t*>(c->ak_block.p + k * txt_per));
-                    hipLaunchKernelGGL(gather_summary_kernel, dim3(1), dim3(64), 0, sf, (const uint64_t*)A.dev_len, (const uint64_t*)pos, nr, (const unsigned long long*)A.dev_sum,
-                                       c->ak_dev_sum.p + 160 * k + 150);
-                    HIPCHK(hipMemcpyAsync(c->h_sum.p + 4 * k, c->ak_dev_sum.p + 160 * k + 150, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, sf));
-                }
-                HIPCHK(hipEventRecord(c->ak_done[k], sf));
-                done_recorded = true;
-            } else if (nr > 0) {
-                hipLaunchKernelGGL(align_kernel, dim3((unsigned)n_waves), dim3(64), 0, sx, A);
-            }
-            if (!done_recorded) HIPCHK(hipEventRecord(c->ak_done[k], sx));
-            HIPCHK(hipGetLastError());
-        }
-        t_launch[1] = mh::now_s() - t_enter;
         // host side: follows the launches
         struct SubRes { moni_aln_rec_t* recs = nullptr; uint32_t* cig = nullptr; moni_alt_t* alt = nullptr; const uint64_t* md = nullptr; const uint64_t* txt = nullptr; uint64_t nr = 0; };
         int rc_host = MONI_OK;
@@ -1183,10 +1163,10 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         };
         if ((int)c->md_scratch.size() < T) c->md_scratch.resize(T);
         for (int t = 0; t < T; ++t) c->pieces[t].len = 0;
-        for (uint64_t k = 0; k < n_sub && !rc_host; ++k) {
+        auto handle = [&](uint64_t k) {            // what the calling thread does for a finished sub-batch
             SubRes R;
             if (inorder && sub_lo[k + 1] > sub_lo[k]) {
-                if (hipEventSynchronize(c->ak_done[k]) != hipSuccess) { rc_host = MONI_ENODEV; break; }
+                if (hipEventSynchronize(c->ak_done[k]) != hipSuccess) { rc_host = MONI_ENODEV; return; }
                 const unsigned long long* sm = c->h_sum.p + 4 * k;
                 if (sm[1] == 0 && eager_ok && !eager_oom && eager_upto == k && sm[0] <= txt_per * 8) {
                     // every line of the sub-batch was spelled by the kernels: the block goes straight into the (pinned) output buffer
@@ -1197,22 +1177,146 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                     if (need + 1 > acap) {
                         const uint64_t done_reads = sub_lo[k + 1], rest = NR - done_reads;
                         const size_t cap = need + (size_t)((double)need / (double)(done_reads ? done_reads : 1) * (double)rest * 1.06) + 65536;
-                        if (!grow_abuf(cap)) { eager_oom = true; break; }
+                        if (!grow_abuf(cap)) { eager_oom = true; return; }
                     }
                     if (sm[0]) {
                         if (hipMemcpyAsync(abuf + alen, c->ak_block.p + k * txt_per, (size_t)sm[0], hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess ||
-                            hipStreamSynchronize(c->copy_stream) != hipSuccess) { rc_host = MONI_ENODEV; break; }
+                            hipStreamSynchronize(c->copy_stream) != hipSuccess) { rc_host = MONI_ENODEV; return; }
                     }
                     alen = need; eager_upto = k + 1; aligned_t[0] += sm[2];
                     host_busy += mh::now_s() - h0;
-                    continue;
+                    return;
                 }
             }
-            if ((rc_host = fetch(k, R))) break;
+            if ((rc_host = fetch(k, R))) return;
             if (k + 1 == n_sub) { t_mark[1] = mh::now_s() - t_enter; st.t_dp += mh::now_s() - t_gpu0; }
             host_stage(k, R);
+        };
+        uint64_t retired = 0, launched = 0;
+        auto retire = [&](bool block) {            // finished sub-batches in order; block = false: only those already through
+            while (retired < launched && !rc_host && !eager_oom) {
+                if (!block && sub_lo[retired + 1] > sub_lo[retired] && hipEventQuery(c->ak_done[retired]) != hipSuccess) break;
+                handle(retired);
+                ++retired;
+            }
+        };
+        uint64_t mem_base = 0, occ_base = 0;
+        for (uint64_t k = 0; k < n_sub; ++k) {
+            const uint64_t r0 = sub_lo[k], nr = sub_lo[k + 1] - sub_lo[k];
+            SeedSlice SL; SL.r0 = r0; SL.nr = nr; SL.idx = k; SL.mem_base = mem_base; SL.occ_base = occ_base; SL.pipelined = true;
+            if (pipelined) {
+                const double s0 = mh::now_s();
+                if ((rc = seed_slice(c, &sp, SL))) { rc_host = rc; break; }
+                mem_base += SL.n_mems; occ_base += SL.n_occs;
+                st.t_seed += mh::now_s() - s0;
+            }
+            uint64_t n_waves = ak_waves;
+            if (!use_fast && n_waves * AK_NL > nr) n_waves = (nr + AK_NL - 1) / AK_NL;
+            waves_used = std::max(waves_used, n_waves);
+            ak_args_t A;
+            memset(&A, 0, sizeof A);
+            A.P.min_len = prm->min_len; A.P.ext_len = prm->ext_len; A.P.check_k = prm->check_k; A.P.region_dist = prm->region_dist;
+            A.P.filter_freq = prm->filter_freq; A.P.left_mem_check = prm->left_mem_check; A.P.freq_thr = prm->freq_thr;
+            A.P.smatch = prm->smatch; A.P.gapo = prm->gapo; A.P.gapo2 = prm->gapo2; A.P.gape = prm->gape; A.P.gape2 = prm->gape2;
+            A.P.max_dist_x = prm->max_dist_x; A.P.max_dist_y = prm->max_dist_y; A.P.max_iter = prm->max_iter; A.P.max_pred = prm->max_pred;
+            A.P.min_chain_score = prm->min_chain_score; A.P.min_chain_length = prm->min_chain_length;
+            A.P.n_text = I->K.n_text; A.P.n_seq = I->K.n_seq; A.P.seq_starts = I->d_seq_starts;
+            A.P.lift_seqs = I->d_lift_seqs; A.P.lift_runs = I->d_lift_runs; A.P.pdir = I->d_pdir;
+            A.D.sc_mch = prm->smatch; A.D.sc_mis = -prm->smismatch; A.D.sc_N = -prm->gape; A.D.wild = 4; A.D.qo = prm->gapo; A.D.e = prm->gape;
+            A.D.end_bonus = prm->end_bonus; A.D.reads = c->seq.p; A.D.text = I->d_text; A.D.n_text = I->K.n_text;
+            A.D.reads_limit = (c->total_len + 8) & ~7ull; A.D.text_limit = (I->K.n_text + 8) & ~7ull;       // both buffers carry 16 bytes of padding
+            A.mems = c->mems.p; A.occs = c->occs.p; A.read_mem_off = c->read_mem_off.p; A.offs = c->offs.p;
+            if (pipelined) { A.mems = c->mems.p + SL.mem_at(); A.occs = c->occs.p + SL.occ_base; A.read_mem_off = c->read_mem_off.p + k; }      // the slice's arrays, indexed by the batch's read numbers
+            A.min_score_of_len = c->ak_minscore.p; A.max_len = (uint32_t)c->max_len + 1; A.read_lo = r0; A.n_reads = nr;
+            A.slots = c->ak_slots.p + (k % AK_NSET) * ak_waves * AK_NL; A.waves = c->ak_waves.p + (k % AK_NSET) * ak_waves;
+            A.recs = c->h_recs.p + r0; A.cig_pool = c->h_cig.p + k * cig_per; A.cig_cap = cig_per; A.alt_pool = c->h_alt.p + k * alt_per;
+            A.alt_cap = alt_per; A.md_pool = c->h_md.p + k * md_per; A.md_cap = md_per; A.cursors = c->ak_cursors.p + AK_CUR * k;
+            if (gpu_text) {
+                A.fmt.rnames = c->ak_rnames.p; A.fmt.rname_off = c->ak_rname_off.p; A.fmt.quals = quals ? c->ak_quals.p : nullptr;
+                A.fmt.snames = I->d_snames; A.fmt.sname_off = I->d_sname_off; A.fmt.mapq_tab = c->ak_mapq_tab.p; A.fmt.mapq_tab_n = 8192;
+                A.fmt.min_len = (int32_t)prm->min_len; A.fmt.smatch = prm->smatch; A.fmt.smismatch = prm->smismatch;
+                A.fmt.txt_pool = c->ak_txt.p + k * txt_per; A.fmt.txt_cap = (use_fast && nr > 0) ? txt_per / (AF_TXT_SHARDS + 1) : txt_per;
+            }
+            if (inorder) { A.dev_len = c->ak_dev_len.p + r0 + k; A.dev_off = c->ak_dev_off.p + r0 + k; A.dev_sum = c->ak_dev_sum.p + 160 * k; }
+            hipStream_t sx = c->ak_stream[k % AK_NSET];
+            if (use_fast && k >= AK_NSET) HIPCHK(hipStreamWaitEvent(sx, c->ak_done[k - AK_NSET], 0));      // the set's buffers are free once its previous sub-batch is through align_kernel too
+            HIPCHK(hipEventRecord(c->ak_begin[k], sx));
+            bool done_recorded = false;
+            if (use_fast && nr > 0) {
+                moni_ctx::AfSet& S = c->af[k % AK_NSET];
+                af_args_t G;
+                memset(&G, 0, sizeof G);
+                G.A = A;
+                G.plans = S.plans.p; G.tasks = S.tasks.p; G.task_cap = af_task_cap; G.res = S.res.p; G.bin_q = S.bin_q.p; G.bin_cap = af_task_cap; G.task_pos = S.task_pos.p;
+                G.chunks = S.chunks.p; G.chunk_cap = af_chunk_cap; G.dirs = S.dirs.p; G.dirs_cap = af_dirs_cap; G.tb_task = S.tb_task.p; G.tb = S.tb.p; G.tb_cap = af_tb_cap;
+                G.fb_list = S.fb_list.p; G.big_list = S.big_list.p; G.fin_scratch = S.fin.p; G.fin_stride = sizeof(af_fin_t); G.ctr = S.ctr.p;
+                G.bnd = S.bnd.p;
+                G.txt_cur = S.txt_cur.p; G.txt_shard_words = txt_per / (AF_TXT_SHARDS + 1);
+                HIPCHK(hipMemsetAsync(S.txt_cur.p, 0, AF_TXT_SHARDS * 8 * sizeof(unsigned long long), sx));
+#ifdef AF_PROFILE
+                if ((rc = S.prof.ensure(32))) return rc;
+                if (k < AK_NSET) HIPCHK(hipMemsetAsync(S.prof.p, 0, 32 * 8, sx));
+                G.prof = S.prof.p;
+                if (const char* v = getenv("MONI_AF_DBG")) G.dbg = (uint32_t)atoi(v);
+#endif
+                HIPCHK(hipMemsetAsync(S.ctr.p, 0, AF_NCTR * sizeof(uint32_t), sx));
+                {
+                    static const int k1occ = getenv("MONI_AF_K1OCC") ? atoi(getenv("MONI_AF_K1OCC")) : 6;
+                    const dim3 g1((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 4 * k1occ));
+                    if (k1occ == 4) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 4>), g1, dim3(64), 0, sx, G);
+                    else if (k1occ == 5) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 5>), g1, dim3(64), 0, sx, G);
+                    else if (k1occ == 8) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 8>), g1, dim3(64), 0, sx, G);
+                    else hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 6>), g1, dim3(64), 0, sx, G);
+                }
+                hipLaunchKernelGGL((chain_plan_kernel<af_wave_t, true>), dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 10)), dim3(64), 0, sx, G);
+                HIPCHK(hipEventRecord(c->af_ev[3 * k], sx));
+                hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_SMALL);
+                hipLaunchKernelGGL((dp_lane_kernel<AF_BLK, AF_QCAP, AF_LPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE);
+                hipLaunchKernelGGL((dp_lane_kernel<AF_TS, AF_TS, 1>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_SMALL);
+                hipLaunchKernelGGL(global_task_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
+                hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL, (uint32_t)AF_GRP_GLOBAL);
+                hipLaunchKernelGGL((dp_lane_kernel<AF_GBLK, AF_QCAP, AF_GPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL);
+                HIPCHK(hipEventRecord(c->af_ev[3 * k + 1], sx));
+                hipLaunchKernelGGL(select_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
+                hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)((af_tb_cap + 255) / 256)), dim3(256), 0, sx, G);
+                HIPCHK(hipEventRecord(c->af_ev[3 * k + 2], sx));
+                // the reads the staged kernels handed over: few, but each a long serial job (milliseconds): align_kernel takes them on its own stream
+                // beside finish_wave_kernel, which hands nothing over any more (a line or CIGAR beyond its staging goes to the host pipeline)
+                A.read_list = S.fb_list.p; A.n_reads_dev = S.ctr.p + AFC_FALLBACK;
+                hipStream_t sf = c->fb_stream[k % AK_NSET];
+                HIPCHK(hipStreamWaitEvent(sf, c->af_ev[3 * k + 2], 0));
+                hipLaunchKernelGGL(align_kernel, dim3((unsigned)ak_waves), dim3(64), 0, sf, A);
+                // the record and the SAM line of every read that stayed on the staged path: one wave per read when the kernel spells the text
+                if (gpu_text) hipLaunchKernelGGL(finish_wave_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 24)), dim3(64), 0, sx, G);
+                else hipLaunchKernelGGL(finish_kernel, dim3((unsigned)std::min<uint64_t>((nr + 63) / 64, af_fin_grid)), dim3(64), 0, sx, G);
+                HIPCHK(hipEventRecord(c->ak_fin[k], sx));
+                HIPCHK(hipStreamWaitEvent(sf, c->ak_fin[k], 0));
+                HIPCHK(hipMemcpyAsync(c->af_ctr_host.p + AF_NCTR * k, S.ctr.p, AF_NCTR * sizeof(uint32_t), hipMemcpyDeviceToHost, sf));
+                if (inorder) {          // lines in read order: scan of the lengths, gather, summary for the host
+                    uint64_t* pos = c->ak_dev_pos.p + r0 + 2 * k;
+                    size_t tmp_bytes = 0;
+                    if (rocprim::exclusive_scan(nullptr, tmp_bytes, A.dev_len, pos, (uint64_t)0, nr, rocprim::plus<uint64_t>(), sf) != hipSuccess || tmp_bytes > gather_tmp_bytes + 16) return MONI_ENODEV;
+                    if (rocprim::exclusive_scan(c->gather_tmp[k % AK_NSET].p, tmp_bytes, A.dev_len, pos, (uint64_t)0, nr, rocprim::plus<uint64_t>(), sf) != hipSuccess) return MONI_ENODEV;
+                    hipLaunchKernelGGL(gather_lines_kernel, dim3((unsigned)std::min<uint64_t>((nr + 3) / 4, (uint64_t)n_cu * 8)), dim3(256), 0, sf, (const uint64_t*)A.fmt.txt_pool,
+                                       (const uint64_t*)A.dev_len, (const uint64_t*)A.dev_off, (const uint64_t*)pos, nr, reinterpret_cast<uint8_t*>(c->ak_block.p + k * txt_per));
+                    hipLaunchKernelGGL(gather_summary_kernel, dim3(1), dim3(64), 0, sf, (const uint64_t*)A.dev_len, (const uint64_t*)pos, nr, (const unsigned long long*)A.dev_sum,
+                                       c->ak_dev_sum.p + 160 * k + 150);
+                    HIPCHK(hipMemcpyAsync(c->h_sum.p + 4 * k, c->ak_dev_sum.p + 160 * k + 150, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, sf));
+                }
+                HIPCHK(hipEventRecord(c->ak_done[k], sf));
+                done_recorded = true;
+            } else if (nr > 0) {
+                hipLaunchKernelGGL(align_kernel, dim3((unsigned)n_waves), dim3(64), 0, sx, A);
+            }
+            if (!done_recorded) HIPCHK(hipEventRecord(c->ak_done[k], sx));
+            HIPCHK(hipGetLastError());
+            launched = k + 1;
+            if (pipelined) retire(false);
         }
-        if (rc_host) { for (int x = 0; x < 2; ++x) { (void)hipStreamSynchronize(c->ak_stream[x]); if (c->fb_stream[x]) (void)hipStreamSynchronize(c->fb_stream[x]); } drop_abuf(); return rc_host; }
+        t_launch[1] = mh::now_s() - t_enter;
+        if (rc_host == MONI_OK) retire(true);
+        if (pipelined) { c->n_mems = mem_base; c->n_occs = occ_base; if (NR) { c->est_mems_per_read = (double)mem_base / (double)NR; c->est_occs_per_read = (double)occ_base / (double)NR; } }
+        if (rc_host) { for (int x = 0; x < AK_NSET; ++x) { (void)hipStreamSynchronize(c->ak_stream[x]); if (c->fb_stream[x]) (void)hipStreamSynchronize(c->fb_stream[x]); } drop_abuf(); return rc_host; }
         t_mark[2] = mh::now_s() - t_enter;
         st.dp_rounds = n_sub;          // align_kernel launches
         if (n_sub) {        // statistics of all launches, once the GPU is idle
@@ -1244,7 +1348,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             }
         }
 #ifdef AF_PROFILE
-        if (use_fast && n_sub) { unsigned long long pf[32]; for (int x = 0; x < (n_sub > 1 ? 2 : 1); ++x) { HIPCHK(hipMemcpy(pf, c->af[x].prof.p, sizeof pf, hipMemcpyDeviceToHost));
+        if (use_fast && n_sub) { unsigned long long pf[32]; for (int x = 0; x < (int)std::min<uint64_t>(n_sub, AK_NSET); ++x) { HIPCHK(hipMemcpy(pf, c->af[x].prof.p, sizeof pf, hipMemcpyDeviceToHost));
             fprintf(stderr, "chain_plan_kernel wave cycles (set %d): load+filter+anchors %.3g, chain %.3g (sort %.3g, dp %.3g, ends+backtrack %.3g), lifts %.3g, plan %.3g, whole read %.3g\n", x,
                     (double)pf[0], (double)pf[1], (double)pf[5], (double)pf[6], (double)pf[7], (double)pf[2], (double)pf[3], (double)pf[4]);
             fprintf(stderr, "finish_wave_kernel wave cycles (set %d): stage read + stitch + lift %.3g, head fields + OA NM %.3g, SEQ/QUAL + MD %.3g, NM/MD move %.3g, OA/AA tags %.3g, out %.3g, whole read %.3g\n", x,

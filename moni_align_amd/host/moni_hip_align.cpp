@@ -346,6 +346,9 @@ static void pwrite_all(int fd, const char* p, size_t n, uint64_t at) {
 }  // namespace fastpath
 
 int main(int argc, char** argv) {
+    // HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); every context runs its launches on several
+    // streams, and streams that share a queue run one after the other
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     Args a;
     parse(argc, argv, a);
     if (!a.mate1.empty() || !a.mate2.empty()) die("paired-end alignment (-1/-2) is not implemented in moni-hip-align yet");

@@ -22,6 +22,25 @@ for sub in ("", "3000", "1000000"):
     print("sub", sub or "default", "identical:", sam == want, {k: st[k] for k in ("reads", "aligned", "handed_back", "kernel_fallback")}, flush=True)
     sam2, st = ctx.align_run(names, noff, q, host_threads=8)
     print("  again:", sam2 == want)
+os.environ["MONI_ALIGN_SUB"] = "3000"; os.environ["MONI_SEED_EST"] = "0.5,2"          # pipelined seeding with buffers that must grow mid-batch
+sam, st = ctx.align_run(names, noff, q, host_threads=8)
+print("growth path identical:", sam == want, flush=True)
+del os.environ["MONI_SEED_EST"]
+os.environ["MONI_SEED_WHOLE"] = "1"
+sam, st = ctx.align_run(names, noff, q, host_threads=8)
+print("whole-batch seeding identical:", sam == want, flush=True)
+del os.environ["MONI_SEED_WHOLE"]
+sam, st = ctx.align_batch(reads.reshape(-1), offs, names, noff, q, host_threads=8)
+print("align_batch (host order, pipelined) identical:", sam == want, flush=True)
+sam, st = ctx.align_batch(reads.reshape(-1), offs, names, noff, q, host_threads=8, stream=True)
+print("align_stream identical:", sam == want, len(sam), len(want), flush=True)
+if sam != want:
+    la, lb = sam.split(b"\n"), want.split(b"\n")
+    for k, (x, y) in enumerate(zip(la, lb)):
+        if x != y:
+            print("first difference at record", k, "\n got:", x[:300], "\nwant:", y[:300], flush=True)
+            break
+ctx.upload(reads.reshape(-1), offs)
 os.environ["MONI_ALIGN_HOST_ORDER"] = "1"
 sam, st = ctx.align_run(names, noff, q, host_threads=8)
 print("host order identical:", sam == want)

@@ -1,0 +1,6 @@
+#!/bin/bash
+# sub-batch schedule sweep: "mid:min" pairs (first and last sub-batch of min reads, the others mid)
+MONI_BENCH_SAVE_INDEX=1 python3 bench.py --steps 1 --warmup 0 --no-cpu > /dev/null 2> gpurun_out/sweep_build.log || exit 1
+for s in "$@"; do
+  MONI_ALIGN_SUB=${s%%:*} MONI_ALIGN_SUB_MIN=${s##*:} timeout -k 10 200 python3 bench.py --steps 5 --warmup 2 --no-cpu 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sub $s:', round(d['value']/1e6,2), 'M reads/s', round(d['ms_per_step'],1), 'ms', d['stages_s_per_step'])" || exit 1
+done

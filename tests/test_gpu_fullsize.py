@@ -81,6 +81,15 @@ def check(pg, fi, n_reads, L, seed, threads=16, seeds_too=True):
         if got_run != want:
             raise AssertionError("moni_align_run SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got_run, want))
         assert st_run["aligned"] == wc["aligned"]
+        # several sub-batches: seeding slice by slice beside the align kernels of the previous slice, per-MEM buffers that have to grow
+        # mid-batch (small estimates), the streaming entry point
+        os.environ["MONI_ALIGN_SUB"] = str(max(1000, n_reads // 7)); os.environ["MONI_SEED_EST"] = "0.5,2"
+        try:
+            got_p, st_p = ctx.align_batch(reads.reshape(-1), offs, names, noff, quals, host_threads=threads, stream=True)
+        finally:
+            del os.environ["MONI_ALIGN_SUB"], os.environ["MONI_SEED_EST"]
+        if got_p != want:
+            raise AssertionError("pipelined moni_align_stream SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got_p, want))
         return got, st
     finally:
         ctx.close()

@@ -596,10 +596,10 @@ __global__ void af_chunk_kernel(const af_args_t G, const uint32_t first_group, c
         for (uint32_t bin = b1; bin-- > b0;) {          // longest queries first: the persistent DP waves take chunks in this order, the short ones fill the tail
             const uint32_t cnt = G.ctr[AFC_BINS + bin];
             const uint32_t qhi = grp == AF_GRP_SMALL ? AF_TS : ((bin - b0) + 1) * 16, tb = grp == AF_GRP_SMALL ? AF_TS : grp == AF_GRP_GLOBAL ? AF_GBLK : AF_BLK, np = grp == AF_GRP_GLOBAL ? AF_GPASS : grp == AF_GRP_LARGE ? AF_LPASS : 1;
-            for (uint32_t s = 0; s < cnt; s += 64) {
+            for (uint32_t s = 0; s < cnt; s += 128) {          // 128 problems: two per lane of the DP wave
                 if (nc >= G.chunk_cap) break;
-                const uint64_t bytes = (uint64_t)np * qhi * tb * 64;
-                af_chunk_t c; c.bin = bin; c.start = s; c.n = cnt - s < 64 ? cnt - s : 64; c.qhi = qhi;
+                const uint64_t bytes = (uint64_t)np * qhi * tb * 64;          // half a byte per cell
+                af_chunk_t c; c.bin = bin; c.start = s; c.n = cnt - s < 128 ? cnt - s : 128; c.qhi = qhi;
                 if (doff + bytes > G.dirs_cap) { c.dir_off = ~0ull; G.ctr[AFC_DIRS_OVF] = 1; } else { c.dir_off = doff; doff += bytes; }
                 G.chunks[nc++] = c;
             }
@@ -635,12 +635,34 @@ __device__ __forceinline__ uint64_t af_group(af_bytes_t& S, int g) {
 // H(i, j-1) and F(i, j) of every row of the block in registers, E and the diagonal carried along the block.  NP > 1: targets longer
 // than TB are taken block by block; (H, E) of a block's last row go through a per-wave buffer to the next block.
 // ------------------------------------------------------------------------------------------------------------------------------
+// Two problems per lane, their cells side by side in the 16-bit halves of every register (v_pk_* arithmetic: one instruction serves both):
+// a chunk holds 128 problems, lane l takes the problems at l (low half) and 64 + l (high half) of the chunk.  Scores of reads up to
+// AF_MAX_READ bases fit 16 bits with room for the "minus infinity" of E / F (AF_NEG16).  Per cell and problem four sign bits are kept
+// instead of ksw2's direction byte (diagonal beats E, that maximum beats F, E does not continue, F does not continue: the negations of
+// the tests of the right-aligned-gap rule), four rows per 16-bit half: half a byte per cell, decoded by traceback_kernel.
+#define AF_NEG16 (-12000)
+typedef short af_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short af_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ af_s2 af_as_s2(uint32_t x) { return __builtin_bit_cast(af_s2, x); }
+__device__ __forceinline__ af_u2 af_as_u2(uint32_t x) { return __builtin_bit_cast(af_u2, x); }
+__device__ __forceinline__ uint32_t af_pk(af_s2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t af_pku(af_u2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t af_pk_add(uint32_t a, uint32_t b) { return af_pk(af_as_s2(a) + af_as_s2(b)); }
+__device__ __forceinline__ uint32_t af_pk_sub(uint32_t a, uint32_t b) { return af_pk(af_as_s2(a) - af_as_s2(b)); }
+__device__ __forceinline__ uint32_t af_pk_max(uint32_t a, uint32_t b) { return af_pk(__builtin_elementwise_max(af_as_s2(a), af_as_s2(b))); }
+__device__ __forceinline__ uint32_t af_pk_minu(uint32_t a, uint32_t b) { return af_pku(__builtin_elementwise_min(af_as_u2(a), af_as_u2(b))); }
+__device__ __forceinline__ uint32_t af_pk_neg(uint32_t a) { return af_pku(af_as_u2(a) >> (af_u2)15); }      // 1 in a half that holds a negative value
+__device__ __forceinline__ uint32_t af_pk2(int v) { return ((uint32_t)v & 0xFFFFu) * 0x10001u; }
+__device__ __forceinline__ int af_lo16(uint32_t x) { return (int)(int16_t)(x & 0xFFFFu); }
+__device__ __forceinline__ int af_hi16(uint32_t x) { return (int)(int16_t)(x >> 16); }
+
 template <int TB, int QC, int NP>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64 ? 1 : 3, TB > 64 ? 1 : 3))) dp_lane_kernel(const af_args_t G, const uint32_t grp) {
-    __shared__ uint8_t qs[QC][64];
+    __shared__ uint8_t qs[QC][64];          // query codes of the lane's two problems: low one in bits 0-1, high one in bits 4-5
     const int lane = threadIdx.x;
     const dp_launch_t& D = G.A.D;
-    const int32_t qo = D.qo, e = D.e, scM = D.sc_mch, scX = D.sc_mis;
+    const uint32_t qo2 = af_pk2(D.qo), e2 = af_pk2(D.e), scM2 = af_pk2(D.sc_mch), scX2 = af_pk2(D.sc_mis);
+    const int32_t qo = D.qo, e = D.e;
     constexpr int NW = (TB + 15) / 16;
     uint64_t* __restrict__ bnd = NP > 1 ? G.bnd + (size_t)blockIdx.x * QC * 64 + lane : nullptr;
     uint32_t chunk0 = 0;
@@ -652,43 +674,61 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
         c = (uint32_t)__shfl((int)c, 0);
         if (c >= n_chunks) break;
         const af_chunk_t ch = G.chunks[chunk0 + c];
-        const bool has = (uint32_t)lane < ch.n;
-        const bool nodir = ch.dir_off == ~0ull;           // the direction bytes did not fit: the chunk's problems are flagged, their reads take align_kernel
-        uint32_t tid = 0;
-        moni_dp_task_t task; task.qlen = 0; task.tlen = 0; task.q_off = 0; task.t_off = 0; task.reserved = 0; task.flag = 0;
-        if (has) { tid = G.bin_q[(size_t)ch.bin * G.bin_cap + ch.start + lane]; task = G.tasks[tid]; }
-        const int qlen = task.qlen, tlen = task.tlen, mode = task.reserved;
-        int maxq = qlen, maxt = tlen;
-        for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(maxq, o); maxq = w > maxq ? w : maxq; const int w2 = __shfl_xor(maxt, o); maxt = w2 > maxt ? w2 : maxt; }
-        bool wild = nodir;
-        {   // query codes -> LDS, eight bases per load
-            af_bytes_t QS = af_bytes(D.reads, task.q_off, D.reads_limit, (mode & DP_Q_REV) != 0);
-            for (int g = 0; 8 * g < maxq; ++g) {
-                const uint64_t v = 8 * g < qlen ? af_group(QS, g) : 0ull;
+        const bool nodir = ch.dir_off == ~0ull;           // the direction bits did not fit: the chunk's problems are flagged, their reads take align_kernel
+        bool has[2]; uint32_t tid[2] = {0, 0};
+        moni_dp_task_t task[2];
+        int maxq = 0, maxt = 0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    uint32_t cq = dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu);
-                    if ((mode & DP_Q_COMP) && cq < 4) cq = 3 - cq;
-                    if (8 * g + u < qlen) { wild |= cq > 3; qs[8 * g + u][lane] = (uint8_t)cq; }
+        for (int h = 0; h < 2; ++h) {
+            has[h] = (uint32_t)lane + 64u * h < ch.n;
+            task[h].qlen = 0; task[h].tlen = 0; task[h].q_off = 0; task[h].t_off = 0; task[h].reserved = 0; task[h].flag = 0;
+            if (has[h]) { tid[h] = G.bin_q[(size_t)ch.bin * G.bin_cap + ch.start + lane + 64 * h]; task[h] = G.tasks[tid[h]]; }
+            maxq = task[h].qlen > maxq ? task[h].qlen : maxq; maxt = task[h].tlen > maxt ? task[h].tlen : maxt;
+        }
+        for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(maxq, o); maxq = w > maxq ? w : maxq; const int w2 = __shfl_xor(maxt, o); maxt = w2 > maxt ? w2 : maxt; }
+        bool wild[2] = {nodir, nodir};
+        {   // query codes -> LDS, eight bases per load
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int qlen = task[h].qlen, mode = task[h].reserved;
+                af_bytes_t QS = af_bytes(D.reads, task[h].q_off, D.reads_limit, (mode & DP_Q_REV) != 0);
+                for (int g = 0; 8 * g < maxq; ++g) {
+                    const uint64_t v = 8 * g < qlen ? af_group(QS, g) : 0ull;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        uint32_t cq = dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu);
+                        if ((mode & DP_Q_COMP) && cq < 4) cq = 3 - cq;
+                        const bool in = 8 * g + u < qlen;
+                        wild[h] |= in && cq > 3;
+                        if (8 * g + u < maxq) { if (h == 0) qs[8 * g + u][lane] = (uint8_t)(in ? (cq & 3u) : 0u); else qs[8 * g + u][lane] |= (uint8_t)((in ? (cq & 3u) : 0u) << 4); }
+                    }
                 }
             }
         }
         if (NP > 1) {       // a wildcard anywhere in the target: known before the first block runs
-            af_bytes_t TS = af_bytes(D.text, task.t_off, D.text_limit, (mode & DP_T_REV) != 0);
-            for (int g = 0; 8 * g < maxt; ++g) {
-                const uint64_t v = 8 * g < tlen ? af_group(TS, g) : 0ull;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) wild |= 8 * g + u < tlen && dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu) > 3;
+            for (int h = 0; h < 2; ++h) {
+                const int tlen = task[h].tlen;
+                af_bytes_t TS = af_bytes(D.text, task[h].t_off, D.text_limit, (task[h].reserved & DP_T_REV) != 0);
+                for (int g = 0; 8 * g < maxt; ++g) {
+                    const uint64_t v = 8 * g < tlen ? af_group(TS, g) : 0ull;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) wild[h] |= 8 * g + u < tlen && dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu) > 3;
+                }
             }
         }
-        af_res_t R; R.mqe = AF_NEG_INF; R.mqe_t = -1; R.score = AF_NEG_INF; R.flags = 0;
+        af_res_t R[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { R[h].mqe = AF_NEG_INF; R[h].mqe_t = -1; R[h].score = AF_NEG_INF; R[h].flags = 0; }
         for (int pass = 0; pass < NP && pass * TB < maxt; ++pass) {
             const int i0 = pass * TB;
-            uint32_t tp[NW];      // target codes of the block -> registers (2 bits each); the byte loads are unconditional and independent
+            uint32_t tp[2][NW];      // target codes of the block -> registers (2 bits each)
 #pragma unroll
-            for (int w = 0; w < NW; ++w) tp[w] = 0;
-            {
-                af_bytes_t TS = af_bytes(D.text, (mode & DP_T_REV) ? task.t_off - (uint64_t)i0 : task.t_off + (uint64_t)i0, D.text_limit, (mode & DP_T_REV) != 0);
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) tp[h][w] = 0;
+                const int tlen = task[h].tlen, mode = task[h].reserved;
+                af_bytes_t TS = af_bytes(D.text, (mode & DP_T_REV) ? task[h].t_off - (uint64_t)i0 : task[h].t_off + (uint64_t)i0, D.text_limit, (mode & DP_T_REV) != 0);
 #pragma unroll
                 for (int g = 0; g < (TB + 7) / 8; ++g) {
                     const uint64_t v = i0 + 8 * g < tlen ? af_group(TS, g) : 0ull;
@@ -698,76 +738,86 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
                         if (i < TB) {
                             const uint32_t ct = dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu);
                             const bool in = i0 + i < tlen;
-                            wild |= in && ct > 3;
-                            tp[i >> 4] |= (in ? (ct & 3u) : 0u) << (2 * (i & 15));
+                            wild[h] |= in && ct > 3;
+                            tp[h][i >> 4] |= (in ? (ct & 3u) : 0u) << (2 * (i & 15));
                         }
                     }
                 }
             }
-            int32_t Hc[TB], Fc[TB];
+            uint32_t Hc[TB], Fc[TB];
 #pragma unroll
-            for (int i = 0; i < TB; ++i) { Hc[i] = -(qo + (i0 + i + 1) * e); Fc[i] = AF_NEG_INF; }
+            for (int i = 0; i < TB; ++i) { Hc[i] = af_pk2(-(qo + (i0 + i + 1) * e)); Fc[i] = af_pk2(AF_NEG16); }
             uint32_t* __restrict__ dir = reinterpret_cast<uint32_t*>(G.dirs + (nodir ? 0ull : ch.dir_off) + (size_t)pass * ch.qhi * TB * 64) + lane;
-            const bool run = has && !wild && i0 < tlen;
-            int32_t prev_hb = -(qo + i0 * e);                           // H(i0 - 1, -1)
+            uint32_t prev_hb = af_pk2(-(qo + i0 * e));                           // H(i0 - 1, -1)
 #ifdef AF_PROFILE
             if (G.dbg & 2) maxq = 0;
 #endif
+            const int qe0 = task[0].qlen - 1, qe1 = task[1].qlen - 1;
             for (int j = 0; j < maxq; ++j) {
-                if (run && j < qlen) {
-                    const int32_t qc = qs[j][lane];
-                    int32_t diag, h_up, e_run;
-                    if (NP > 1 && pass > 0) {
-                        const uint64_t be = bnd[(size_t)j * 64];
-                        h_up = (int32_t)(uint32_t)be; e_run = (int32_t)(uint32_t)(be >> 32);      // H(i0 - 1, j), E(i0 - 1, j)
-                        diag = prev_hb;                                                            // H(i0 - 1, j - 1)
-                        prev_hb = h_up;
-                    } else {
-                        diag = j == 0 ? 0 : -(qo + j * e);              // H(-1, j-1)
-                        h_up = -(qo + (j + 1) * e);                     // H(-1, j)
-                        e_run = AF_NEG_INF;
-                    }
-                    uint32_t pack = 0;
-                    uint32_t* __restrict__ drow = dir + (size_t)j * (TB / 4) * 64;
+                const uint32_t qb = qs[j][lane];
+                // the query code of both problems spread over the 2-bit fields of a word: XOR with the target codes, fold each field to
+                // one "bases differ" bit: per row a signed 1-bit extract then gives the mismatch mask of a problem
+                const uint32_t qr0 = (qb & 3u) * 0x55555555u, qr1 = ((qb >> 4) & 3u) * 0x55555555u;
+                uint32_t x0[NW], x1[NW];
 #pragma unroll
-                    for (int i = 0; i < TB; ++i) {
-                        const int32_t tc = (int32_t)((tp[i >> 4] >> (2 * (i & 15))) & 3u);
-                        const int32_t h_old = Hc[i];
-                        const int32_t Eo = h_up - qo;
-                        const int32_t E = (Eo > e_run ? Eo : e_run) - e;
-                        const int32_t Fo = h_old - qo;
-                        const int32_t F = (Fo > Fc[i] ? Fo : Fc[i]) - e;
-                        int32_t z = diag + (tc == qc ? scM : scX);
-                        uint32_t d = z > E ? 0u : 1u; z = z > E ? z : E;
-                        d = z > F ? d : 2u; z = z > F ? z : F;
-                        const int32_t zq = z - qo;
-                        d |= (E >= zq) ? 0x08u : 0u;
-                        d |= (F >= zq) ? 0x10u : 0u;
-                        Hc[i] = z; Fc[i] = F; diag = h_old; h_up = z; e_run = E;
-                        pack |= d << (8 * (i & 3));
-#ifdef AF_PROFILE
-                        if ((i & 3) == 3) { if (!(G.dbg & 1)) drow[(i >> 2) * 64] = pack; pack = 0; }
-#else
-                        if ((i & 3) == 3) { drow[(i >> 2) * 64] = pack; pack = 0; }
-#endif
-                    }
-                    if (NP > 1) bnd[(size_t)j * 64] = (uint64_t)(uint32_t)h_up | ((uint64_t)(uint32_t)e_run << 32);      // (H, E) of the block's last row
+                for (int w = 0; w < NW; ++w) { const uint32_t a0 = tp[0][w] ^ qr0, a1 = tp[1][w] ^ qr1; x0[w] = (a0 | (a0 >> 1)) & 0x55555555u; x1[w] = (a1 | (a1 >> 1)) & 0x55555555u; }
+                uint32_t diag, h_up, e_run;
+                if (NP > 1 && pass > 0) {
+                    const uint64_t be = bnd[(size_t)j * 64];
+                    h_up = (uint32_t)be; e_run = (uint32_t)(be >> 32);      // H(i0 - 1, j), E(i0 - 1, j)
+                    diag = prev_hb;                                            // H(i0 - 1, j - 1)
+                    prev_hb = h_up;
+                } else {
+                    diag = af_pk2(j == 0 ? 0 : -(qo + j * e));              // H(-1, j-1)
+                    h_up = af_pk2(-(qo + (j + 1) * e));                     // H(-1, j)
+                    e_run = af_pk2(AF_NEG16);
                 }
-            }
-            if (run) {
+                uint32_t pack = 0;
+                uint32_t* __restrict__ drow = dir + (size_t)j * (TB / 4) * 64;
 #pragma unroll
                 for (int i = 0; i < TB; ++i) {
-                    const int32_t h = Hc[i];
-                    if (i0 + i < tlen) { if (h > R.mqe) { R.mqe = h; R.mqe_t = i0 + i; } if (i0 + i == tlen - 1) R.score = h; }
+                    const uint32_t k0 = (uint32_t)__builtin_amdgcn_sbfe((int)x0[i >> 4], 2 * (i & 15), 1), k1 = (uint32_t)__builtin_amdgcn_sbfe((int)x1[i >> 4], 2 * (i & 15), 1);
+                    const uint32_t mk = __builtin_amdgcn_perm(k1, k0, 0x05040100u);       // all ones in a half whose bases differ
+                    const uint32_t sc = (mk & scX2) | (~mk & scM2);
+                    const uint32_t h_old = Hc[i];
+                    const uint32_t E = af_pk_sub(af_pk_max(af_pk_sub(h_up, qo2), e_run), e2);
+                    const uint32_t F = af_pk_sub(af_pk_max(af_pk_sub(h_old, qo2), Fc[i]), e2);
+                    const uint32_t zd = af_pk_add(diag, sc);
+                    const uint32_t z1 = af_pk_max(zd, E), z = af_pk_max(z1, F), zq = af_pk_sub(z, qo2);
+                    // sign bits: E < zd (the diagonal wins), F < z1 (it stays), E < zq, F < zq (no continuation)
+                    uint32_t nb = af_pk_neg(af_pk_sub(E, zd));
+                    nb |= af_pk_neg(af_pk_sub(F, z1)) << 1;
+                    nb |= af_pk_neg(af_pk_sub(E, zq)) << 2;
+                    nb |= af_pk_neg(af_pk_sub(F, zq)) << 3;
+                    Hc[i] = z; Fc[i] = F; diag = h_old; h_up = z; e_run = E;
+                    pack = (pack << 4) | nb;
+#ifdef AF_PROFILE
+                    if ((i & 3) == 3) { if (!(G.dbg & 1)) drow[(i >> 2) * 64] = pack; pack = 0; }
+#else
+                    if ((i & 3) == 3) { drow[(i >> 2) * 64] = pack; pack = 0; }
+#endif
+                }
+                if (NP > 1) bnd[(size_t)j * 64] = (uint64_t)h_up | ((uint64_t)e_run << 32);      // (H, E) of the block's last row
+                if (j == qe0 || j == qe1) {      // the last query column of one of the two problems: its mqe / score come from this column
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) if (j == (h ? qe1 : qe0) && has[h] && !wild[h]) {
+                        const int tlen = task[h].tlen;
+#pragma unroll
+                        for (int i = 0; i < TB; ++i) {
+                            const int hv = h ? af_hi16(Hc[i]) : af_lo16(Hc[i]);
+                            if (i0 + i < tlen) { if (hv > R[h].mqe) { R[h].mqe = hv; R[h].mqe_t = i0 + i; } if (i0 + i == tlen - 1) R[h].score = hv; }
+                        }
+                    }
                 }
             }
         }
-        if (has) {
-            if (wild) { R.mqe = AF_NEG_INF; R.mqe_t = -1; R.score = AF_NEG_INF; R.flags = 1; }
-            G.res[tid] = R;
+        unsigned long long cells = 0, rq = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) if (has[h]) {
+            if (wild[h]) { R[h].mqe = AF_NEG_INF; R[h].mqe_t = -1; R[h].score = AF_NEG_INF; R[h].flags = 1; }
+            else { cells += (unsigned long long)task[h].qlen * (unsigned long long)task[h].tlen; rq += ((unsigned long long)task[h].tlen << 32) | (unsigned long long)task[h].qlen; }
+            G.res[tid[h]] = R[h];
         }
-        unsigned long long cells = wild ? 0ull : (unsigned long long)qlen * (unsigned long long)tlen;
-        unsigned long long rq = wild ? 0ull : ((unsigned long long)tlen << 32) | (unsigned long long)qlen;      // both operand sizes in one reduction (< 2^32 each per wave)
         for (int o = 32; o > 0; o >>= 1) { cells += __shfl_xor(cells, o); rq += __shfl_xor(rq, o); }
         if (lane == 0) {
             atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_CELLS]), cells);
@@ -779,19 +829,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
 }
 
 // where the direction byte of cell (i, j) of a task is: its chunk, its lane there, the target block of i
-struct af_dirs_t { const uint8_t* base; uint32_t tb; uint64_t pass_stride; };
+struct af_dirs_t { const uint8_t* base; uint32_t tb, half; uint64_t pass_stride; };      // half: which 16-bit half of the words holds the task
 __device__ __forceinline__ af_dirs_t af_dir_of(const af_args_t& G, uint32_t bin, uint32_t pos_in_bin) {
     const uint32_t grp = bin < AF_BIN_SMALL ? AF_GRP_LARGE : bin == AF_BIN_SMALL ? AF_GRP_SMALL : AF_GRP_GLOBAL;
     const uint32_t b1 = grp == AF_GRP_LARGE ? 16u : grp == AF_GRP_SMALL ? 17u : 33u;
     uint32_t ci = 0;
     for (uint32_t g = 0; g < grp; ++g) ci += G.ctr[AFC_NCHUNKS + g];
-    for (uint32_t b2 = bin + 1; b2 < b1; ++b2) ci += (G.ctr[AFC_BINS + b2] + 63) >> 6;        // chunks are laid out from the group's last bin down
-    ci += pos_in_bin >> 6;
+    for (uint32_t b2 = bin + 1; b2 < b1; ++b2) ci += (G.ctr[AFC_BINS + b2] + 127) >> 7;        // chunks are laid out from the group's last bin down
+    ci += pos_in_bin >> 7;
     const af_chunk_t ch = G.chunks[ci];
     af_dirs_t X;
     X.tb = grp == AF_GRP_SMALL ? AF_TS : grp == AF_GRP_GLOBAL ? AF_GBLK : AF_BLK;
     X.pass_stride = (uint64_t)ch.qhi * X.tb * 64;
     X.base = G.dirs + ch.dir_off + (size_t)(pos_in_bin & 63) * 4;
+    X.half = (pos_in_bin >> 6) & 1u;
     return X;
 }
 
@@ -1014,7 +1065,9 @@ __global__ void __launch_bounds__(256) traceback_kernel(const af_args_t G) {
     int state = 0;
     while (i >= 0 && j >= 0) {
         const uint32_t ps = (uint32_t)i / tb, ii = (uint32_t)i - ps * tb;
-        const uint32_t tmp = X.base[ps * X.pass_stride + ((size_t)j * (tb / 4) + (size_t)(ii >> 2)) * 256 + (ii & 3)];
+        const uint32_t word = *reinterpret_cast<const uint32_t*>(X.base + ps * X.pass_stride + ((size_t)j * (tb / 4) + (size_t)(ii >> 2)) * 256);
+        const uint32_t nb = (word >> (16 * X.half + 4 * (3 - (ii & 3)))) & 0xFu;      // sign bits of dp_lane_kernel: diagonal beats E, that beats F, E ends, F ends
+        const uint32_t tmp = ((nb & 2u) ? ((nb & 1u) ? 0u : 1u) : 2u) | ((nb & 4u) ? 0u : 0x08u) | ((nb & 8u) ? 0u : 0x10u);      // ksw2's direction byte
         if (state == 0) state = tmp & 7;
         else if (!(tmp >> (state + 2) & 1)) state = 0;
         if (state == 0) state = tmp & 7;

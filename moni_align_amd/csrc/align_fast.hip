@@ -657,7 +657,10 @@ __device__ __forceinline__ int af_lo16(uint32_t x) { return (int)(int16_t)(x & 0
 __device__ __forceinline__ int af_hi16(uint32_t x) { return (int)(int16_t)(x >> 16); }
 
 template <int TB, int QC, int NP>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64 ? 1 : 3, TB > 64 ? 1 : 3))) dp_lane_kernel(const af_args_t G, const uint32_t grp) {
+#ifndef AF_DP_OCC
+#define AF_DP_OCC 2          // 52 rows x two problems + the cell temporaries fit 256 registers without scratch; at 3 waves the block spills
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64 ? 1 : AF_DP_OCC, TB > 64 ? 1 : AF_DP_OCC))) dp_lane_kernel(const af_args_t G, const uint32_t grp) {
     __shared__ uint8_t qs[QC][64];          // query codes of the lane's two problems: low one in bits 0-1, high one in bits 4-5
     const int lane = threadIdx.x;
     const dp_launch_t& D = G.A.D;

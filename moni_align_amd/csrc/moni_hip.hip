@@ -1261,7 +1261,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
 #endif
                 HIPCHK(hipMemsetAsync(S.ctr.p, 0, AF_NCTR * sizeof(uint32_t), sx));
                 {
-                    static const int k1occ = getenv("MONI_AF_K1OCC") ? atoi(getenv("MONI_AF_K1OCC")) : 6;
+                    static const int k1occ = getenv("MONI_AF_K1OCC") ? atoi(getenv("MONI_AF_K1OCC")) : 8;      // 8 waves/SIMD: 32 reads in flight per CU (4.9 KB of LDS each); measured 5, 6, 8
                     const dim3 g1((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 4 * k1occ));
                     if (k1occ == 4) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 4>), g1, dim3(64), 0, sx, G);
                     else if (k1occ == 5) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 5>), g1, dim3(64), 0, sx, G);

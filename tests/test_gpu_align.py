@@ -105,6 +105,35 @@ def test_sam_identical_250bp_noisy_ragged(medium_case, env):
     both(env, reads)
 
 
+def test_degenerate_reads(medium_case, env):
+    """Empty and one-base reads, reads shorter than min_len, homopolymers, a read across the separator between two sequences, the very
+    first and last bases of the text, IUPAC codes, exact duplicates: whatever the reference's loops make of them, both sides must agree.
+    Also through moni_align_stream (lines ordered on the GPU)."""
+    from oracle import orc
+    text = np.frombuffer(bytes(medium_case.fi.text), dtype=np.uint8)
+    ss = medium_case.fi.seq_starts
+    base = list(medium_case.synth.make_reads(medium_case.pg, 200, 150, seed=77))
+    edge = [np.zeros(0, np.uint8), np.frombuffer(b"A", np.uint8), np.frombuffer(b"ACGTACGTACGTACGTACGTACGT", np.uint8),       # 0, 1, 24 bases
+            np.frombuffer(b"A" * 150, np.uint8), np.frombuffer(b"T" * 26, np.uint8), np.frombuffer(b"ACGTRYKMSWBDHVN" * 8, np.uint8),
+            text[int(ss[1]) - 80:int(ss[1]) + 70].copy(),                        # across a separator
+            text[:150].copy(), text[len(text) - 150:].copy(), text[len(text) - 40:].copy(),
+            medium_case.synth.revcomp(text[None, 300:450])[0].copy(), base[3].copy(), base[3].copy()]
+    rng = np.random.default_rng(5)
+    reads = list(base)
+    for e in edge:
+        reads.insert(int(rng.integers(0, len(reads))), e)
+    both(env, reads)
+    both(env, reads, quals=False)
+    o, ctx = env
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64); offs[1:] = np.cumsum([len(r) for r in reads])
+    seq = np.concatenate(reads)
+    names, noff = orc.make_names(len(reads))
+    q = np.full(len(seq), ord("#"), dtype=np.uint8)
+    want, _ = orc.align_batch(o, seq, offs, names, noff, q, threads=8)
+    got, _ = ctx.align_batch(seq, offs, names, noff, q, host_threads=8, stream=True)
+    assert got == want
+
+
 def test_long_reads_go_through_the_hand_back_path(medium_case, env):
     """Reads whose flanks exceed the align kernel's DP capacities (query > 512) are handed back to the host pipeline by the
     kernel itself; the output must still be the oracle's."""

@@ -104,6 +104,22 @@ MONI_HD void settle_run(const moni_row_t* __restrict__ rows, uint64_t r, uint64_
 // (step s reads pattern[m-1-s]; the reverse-complement strand is complemented here: aligner_ksw2.hpp:169-176,
 // kpbseq.h:150-168).  One coalesced 8-byte load per lane every 8 steps replaces a byte load per step.
 // ------------------------------------------------------------------------------------------------
+// bytes a .. a+7 of a buffer that is 8-byte aligned and padded by 16 bytes: two aligned word loads instead of eight byte loads
+// (64 lanes on 64 different reads make every byte load a separate request)
+MONI_HD uint64_t load8_unaligned(const uint8_t* __restrict__ p, uint64_t a) {
+    const uint64_t w = a & ~7ull;
+    const uint32_t sh = (uint32_t)(a & 7u) * 8u;
+    const uint64_t lo = *reinterpret_cast<const uint64_t*>(p + w);
+    if (!sh) return lo;
+    const uint64_t hi = *reinterpret_cast<const uint64_t*>(p + w + 8);
+    return (lo >> sh) | (hi << (64u - sh));
+}
+MONI_HD uint64_t bswap64_(uint64_t v) {
+    v = ((v & 0x00FF00FF00FF00FFull) << 8) | ((v >> 8) & 0x00FF00FF00FF00FFull);
+    v = ((v & 0x0000FFFF0000FFFFull) << 16) | ((v >> 16) & 0x0000FFFF0000FFFFull);
+    return (v << 32) | (v >> 32);
+}
+
 MONI_HD void pack_task(const lds_tables_t& L, const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t n_tasks,
                        uint64_t task, uint32_t n_words, uint64_t* __restrict__ pat) {
     const uint64_t read = task >> 1;
@@ -112,11 +128,16 @@ MONI_HD void pack_task(const lds_tables_t& L, const uint8_t* __restrict__ seq, c
     const uint32_t m = (uint32_t)(offs[read + 1] - off);
     for (uint32_t w = 0; w < n_words; ++w) {
         uint64_t word = 0;
-        for (uint32_t j = 0; j < 8; ++j) {
-            const uint32_t s = 8 * w + j;
-            if (s < m) {
-                const uint8_t raw = strand ? L.compl_tab[seq[off + s]] : seq[off + (m - 1 - s)];
-                word |= (uint64_t)raw << (8 * j);
+        const uint32_t s0 = 8 * w;
+        if (s0 < m) {
+            const uint32_t nv = m - s0 < 8 ? m - s0 : 8;          // bytes of this word inside the pattern
+            if (strand) {                                          // the read's bytes s0 .. s0 + 7, complemented
+                const uint64_t v = load8_unaligned(seq, off + s0);
+                for (uint32_t j = 0; j < nv; ++j) word |= (uint64_t)L.compl_tab[(uint32_t)(v >> (8 * j)) & 0xFFu] << (8 * j);
+            } else if (nv == 8) {                                  // the read's bytes m-1-s0 down to m-8-s0
+                word = bswap64_(load8_unaligned(seq, off + m - 8 - s0));
+            } else {
+                for (uint32_t j = 0; j < nv; ++j) word |= (uint64_t)seq[off + (m - 1 - s0 - j)] << (8 * j);
             }
         }
         pat[(uint64_t)w * n_tasks + task] = word;

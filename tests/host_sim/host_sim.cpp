@@ -68,6 +68,10 @@ int sim_seed_run(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_r
     unsigned long long cnt[4] = {0, 0, 0, 0};
     const uint32_t n_words = (uint32_t)((mx + 7) / 8);
     std::vector<uint64_t> pat(n_tasks * n_words + 1);
+    // pack_task reads aligned 8-byte words: the device buffer is aligned and padded by 16 bytes, so is this copy
+    std::vector<uint64_t> seq_pad((offs[n_reads] + 16 + 7) / 8 + 1, 0);
+    memcpy(seq_pad.data(), seq, offs[n_reads]);
+    seq = reinterpret_cast<const uint8_t*>(seq_pad.data());
     for (uint64_t t = 0; t < n_tasks; ++t) pack_task(S->L, seq, offs, n_tasks, t, n_words, pat.data());
     for (uint64_t t = 0; t < n_tasks; t += 2)
         ms_task<2>(K, S->L, S->img.rows.data(), S->img.frows.data(), S->img.cr.data(), S->img.recs.data(), pat.data(), offs, n_tasks, t, S->ptr.data(), cnt[0], cnt[1]);

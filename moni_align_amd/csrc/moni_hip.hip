@@ -1041,7 +1041,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             return rc;
         const uint32_t af_task_cap = (uint32_t)std::min<uint64_t>(12 * sub_reads + 4096, (1ull << 26) - 1), af_tb_cap = (uint32_t)std::min<uint64_t>(4 * sub_reads + 1024, 0x7FFFFFFFull);
         const uint32_t af_chunk_cap = af_task_cap / 64 + 2 * AF_NBIN;
-        const uint64_t af_dirs_cap = 65536ull * sub_reads + (16ull << 20);
+        const uint64_t af_dirs_cap = 32768ull * sub_reads + (16ull << 20);      // direction bits: half a byte per DP cell, ~10 KB per 150 bp read on the bench; a chunk that does not fit sends its reads to align_kernel
         const unsigned af_dp_grid = (unsigned)n_cu * 12;
         const unsigned af_fin_grid = (unsigned)std::min<uint64_t>((sub_reads + 63) / 64, (uint64_t)n_cu * 16);
         // in-order text on the GPU: when the caller takes the context-owned buffer and the kernels spell the text, every sub-batch's lines are

@@ -4,8 +4,10 @@
 #pragma once
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/moni_hip.h"
@@ -32,12 +34,35 @@ struct HostImage {
         return x;
     }
 
+    // the per-run loops below are independent across runs: a few host threads share them (the image of a 46 M-run index is 10 GB)
+    template <class Fn>
+    static void par_for(uint64_t n, Fn fn) {
+        unsigned T = std::thread::hardware_concurrency();
+        if (const char* v = getenv("MONI_IMAGE_THREADS")) T = (unsigned)atoi(v);
+        if (T > 16) T = 16;
+        if (T < 2 || n < (1u << 16)) { fn((uint64_t)0, n); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; ++t) th.emplace_back(fn, n * t / T, n * (t + 1) / T);
+        fn((uint64_t)0, n / T);
+        for (auto& x : th) x.join();
+    }
+
     int build(const moni_flat_index_t& f) {
         const uint64_t n = f.n, r = f.r;
         if (n >= (1ull << 40) || r >= (1ull << 32) - 2 || r == 0) { err = "index too large for the 40/32-bit layout"; return MONI_ERANGE; }
         memset(&K, 0, sizeof(K));
         memset(&T, 0, sizeof(T));
         K.n = n; K.r = r; K.n_text = n - 1; K.n_seq = (uint32_t)f.n_seq;
+        {   // phi / phi_inv (two sorts of r keys) are independent of everything else: two threads build them beside the rows
+            uint32_t sh = 0;
+            while ((n >> sh) > 2 * r + 1024 && sh < 30) ++sh;   // about <= 2 keys per directory slot on average
+            K.phi_shift = sh;
+        }
+        int rc_phi[2] = {MONI_OK, MONI_OK}; std::string err_phi[2];
+        std::thread phi_thread[2];
+        phi_thread[0] = std::thread([&]() { rc_phi[0] = build_phi(f, f.ssa, false, phi, phi_dir, err_phi[0]); });
+        phi_thread[1] = std::thread([&]() { rc_phi[1] = build_phi(f, f.esa, true, phi_inv, phi_inv_dir, err_phi[1]); });
+        struct Join { std::thread* t; ~Join() { for (int i = 0; i < 2; ++i) if (t[i].joinable()) t[i].join(); } } join_phi{phi_thread};
         K.last_run_sample = (f.esa[r - 1] + 1) % n;
         K.first_run_sample = (f.ssa[0] + 1) % n;
         // alphabet
@@ -131,11 +156,13 @@ struct HostImage {
             std::sort(by_runs.begin(), by_runs.end(), std::greater<std::pair<uint64_t, uint32_t>>());
             for (uint32_t s = 0; s < 4 && s < by_runs.size(); ++s) K.hot_slot[by_runs[s].second] = (uint8_t)s;
         }
-        for (uint64_t k = 0; k <= r; ++k) {
-            rows[k] = k < r ? pack_row(f.starts[k], (uint32_t)code_of[f.heads[k]], lfbase[k], dest[k], f.starts[k + 1] - f.starts[k])
-                            : pack_row(n, MONI_HEAD_NONE, 0, r, MONI_ROW_LEN_SAT);
-            for (uint32_t c = 0; c < sigma; ++c) if (K.hot_slot[c] != 0xFF) rows[k].hot_cr[K.hot_slot[c]] = cr[k * sigma + c];
-        }
+        par_for(r + 1, [&](uint64_t k0, uint64_t k1) {
+            for (uint64_t k = k0; k < k1; ++k) {
+                rows[k] = k < r ? pack_row(f.starts[k], (uint32_t)code_of[f.heads[k]], lfbase[k], dest[k], f.starts[k + 1] - f.starts[k])
+                                : pack_row(n, MONI_HEAD_NONE, 0, r, MONI_ROW_LEN_SAT);
+                for (uint32_t c = 0; c < sigma; ++c) if (K.hot_slot[c] != 0xFF) rows[k].hot_cr[K.hot_slot[c]] = cr[k * sigma + c];
+            }
+        });
         rows[r + 1] = pack_row(MONI_POS_MASK, MONI_HEAD_NONE, 0, r, MONI_ROW_LEN_SAT);
         // fast rows
         {
@@ -144,7 +171,8 @@ struct HostImage {
             int hot_code[4] = {-1, -1, -1, -1};
             for (uint32_t c = 0; c < sigma; ++c) if (K.hot_slot[c] != 0xFF) hot_code[K.hot_slot[c]] = (int)c;
             const bool four = hot_code[0] >= 0 && hot_code[1] >= 0 && hot_code[2] >= 0 && hot_code[3] >= 0;
-            for (uint64_t k = 0; four && k < r; ++k) {
+            if (four) par_for(r, [&](uint64_t k0, uint64_t k1) {
+            for (uint64_t k = k0; k < k1; ++k) {
                 const uint32_t h = (uint32_t)code_of[f.heads[k]];
                 const uint64_t len = f.starts[k + 1] - f.starts[k];
                 const uint64_t doff = lfbase[k] - f.starts[dest[k]];
@@ -177,6 +205,7 @@ struct HostImage {
                 w[7] = (esa[0] >> 32) | ((esa[1] >> 32) << 8) | ((esa[2] >> 32) << 16);
                 memcpy(frows[k].w, w, sizeof w);
             }
+            });
         }
         // absent bytes: LF(pos, b) = F[b]   (moni.hpp:583-588)
         for (int b = 0; b < 256; ++b) {
@@ -185,20 +214,14 @@ struct HostImage {
             if (f.F[b] >= n) k = r;
             T.abs_run[b] = (uint32_t)k;
         }
-        // phi
-        uint32_t sh = 0;
-        while ((n >> sh) > 2 * r + 1024 && sh < 30) ++sh;   // about <= 2 keys per directory slot on average
-        K.phi_shift = sh;
-        int rc;
-        if ((rc = build_phi(f, f.ssa, false, phi, phi_dir))) return rc;
-        if ((rc = build_phi(f, f.esa, true, phi_inv, phi_inv_dir))) return rc;
         seq_starts.assign(f.seq_starts, f.seq_starts + f.n_seq + 1);
+        for (int i = 0; i < 2; ++i) { phi_thread[i].join(); if (rc_phi[i]) { err = err_phi[i]; return rc_phi[i]; } }
         return MONI_OK;
     }
 
     // moni.hpp:186-251 (build_phi) + the lookups of moni_lcp.hpp:230-272 folded into one record per key
     int build_phi(const moni_flat_index_t& f, const uint64_t* smp, bool inverse, std::vector<moni_phi_t>& out,
-                  std::vector<uint32_t>& dir) {
+                  std::vector<uint32_t>& dir, std::string& err) {
         const uint64_t n = f.n, r = f.r;
         std::vector<std::pair<uint64_t, uint64_t>> s(r);
         for (uint64_t i = 0; i < r; ++i) s[i] = std::make_pair(smp[i], i);

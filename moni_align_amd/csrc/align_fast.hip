@@ -1149,44 +1149,72 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // finish_wave_kernel: the same work as finish_kernel, one wavefront per read, the SAM line assembled in LDS and written out with
-// coalesced stores.  The lanes stage the strand-oriented read, compare it with the reference window 64 columns at a time (MD / NM,
-// write_MD_core, sam.hpp:249-287), copy name / SEQ / QUAL; lane 0 stitches the CIGAR, lifts it, and spells the numeric fields and tags
-// (sam.hpp:144-188, aligner_ksw2.hpp:3116-3175, mapq.hpp:146-184).  Needs the kernel-side text pool (ak_fmt_t::txt_pool); a line that
-// does not fit is marked for the host pipeline like everywhere else.
+// coalesced stores.  The lanes stage the chain record, the traceback records and the strand-oriented read; lane 0 stitches the CIGAR
+// and lifts it (aligner_ksw2.hpp:3049-3108, 3133-3175); MD / NM (write_MD_core, sam.hpp:249-287) come from 64-column ballots, every
+// mismatching lane writing its own MD item.  The line itself (sam.hpp:144-188) is not spelled character by character: lane 0 lists
+// its SEGMENTS (a literal, a decimal number, a sequence name, SEQ, QUAL, reference bases ...: ~60 per line, a few instructions each)
+// and then all lanes render the bytes of the line side by side, each finding its segment by binary search.  MAPQ (mapq.hpp:146-184) in
+// IEEE double operations in the reference's order.  A line, CIGAR or MD beyond the LDS staging goes to the host pipeline.
 // ------------------------------------------------------------------------------------------------------------------------------
-#define AFW_TXT_CAP 2560         // bytes of one line in LDS (longer: the host pipeline redoes the read); the upper half doubles as staging
+#define AFS_LINE 1280            // bytes of one line in LDS
+#define AFS_MAXSEG 96            // segments of one line (a CIGAR and the MD string are one segment each)
+#define AFS_MAXMD 256            // MD items: one per mismatch or deletion (with the count of matches before it) + the closing count
+#define AFS_CIG 64               // operations of the stitched CIGAR ...
+#define AFS_LCIG 128             // ... and of the lifted one
 #define AFW_NAMES 1024           // sequence names kept in LDS when they fit (else they are read from HBM)
 #define AFW_NSEQ 126
 #define AFW_TB_WORDS (AF_TB_CIG + 1)
+static __device__ const char afs_lit[] = "\t" "\t*\t0\t0\t" "\tAS:i:" "\tNM:i:" "\tZS:i:" "\tMD:Z:" "\tOA:Z:" ",+," ",-," "," ";" "\tAA:Z:" "\n" "\t4\t*\t0\t255\t*\t*\t0\t0\t" "*" "^" "MIDNSHP=X" "ACGTN";
+static_assert(sizeof(afs_lit) == 89, "literal table");
+enum { LT_TAB = 0, LT_MATE = 1, LT_AS = 8, LT_NM = 14, LT_ZS = 20, LT_MD = 26, LT_OA = 32, LT_PLUS = 38, LT_MINUS = 41, LT_COMMA = 44, LT_SEMI = 45, LT_AA = 46, LT_NL = 52,
+       LT_UNAL = 53, LT_STAR = 72, LT_CARET = 73, LT_OPS = 74, LT_BASES = 83 };
+enum { SK_LIT = 0, SK_NUM, SK_NEG, SK_NAME, SK_RNAME, SK_SEQ, SK_QUAL, SK_CIG, SK_MD };
 struct af_finw_t {
-    uint8_t line[AFW_TXT_CAP];
+    uint8_t line[AFS_LINE];
     uint8_t seq[AF_MAX_READ];            // the read in alignment orientation (ASCII, kpbseq.h:120-137 complement)
-    uint8_t qc[AF_MAX_READ];             // its nt4 codes
-    uint32_t cig[AF_FIN_CIG], lcig[AF_FIN_LCIG];
-    uint32_t n_cig, n_lcig, pos, ovf;    // pos: write cursor in line[]
-    uint64_t out_off;
+    uint32_t cig[AFS_CIG], lcig[AFS_LCIG];
+    uint32_t n_cig, n_lcig, ovf, n_seg, total, seq_at, qual_at;      // seq_at / qual_at: where SEQ and QUAL start in the line (QUAL absent: ~0)
     uint8_t names[AFW_NAMES]; uint16_t name_off[AFW_NSEQ + 2];      // the index's sequence names (kernel lifetime)
     af_cand_t cand;                                                  // the final chain's record and the alternatives, fetched by all lanes at once
-    uint64_t alt_pos[AF_MAX_CAND]; int32_t alt_score[AF_MAX_CAND];
-    uint32_t tb_idx[8], n_tb;
+    uint64_t alt_pos[AF_MAX_CAND]; int32_t alt_score[AF_MAX_CAND]; uint32_t alt_sid[AF_MAX_CAND], alt_p1[AF_MAX_CAND];
+    uint32_t md_item[AFS_MAXMD];         // type (2 bits: 0 closing count, 1 mismatch, 2 deletion) | matches before it << 2 | mismatch: reference base << 12;
+                                         // deletion: length << 12 | offset of its first base in the reference window << 21
+    uint16_t md_off[AFS_MAXMD + 1];      // where an item's text starts in the MD string
+    uint16_t cig_off[AFS_CIG + 1], lcig_off[AFS_LCIG + 1];      // the same for the operations of the two CIGAR strings
+    uint16_t seg_off[AFS_MAXSEG + 1]; uint8_t seg_kind[AFS_MAXSEG]; uint32_t seg_val[AFS_MAXSEG];
 };
 
-__device__ __forceinline__ void afw_c(af_finw_t& L, uint32_t& p, uint8_t ch) { if (p < AFW_TXT_CAP) L.line[p] = ch; ++p; }
-__device__ __forceinline__ void afw_i(af_finw_t& L, uint32_t& p, int v) {
-    char b[12]; int k = 0; unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
-    do { b[k++] = (char)('0' + u % 10); u /= 10; } while (u);
-    if (v < 0) afw_c(L, p, '-');
-    while (k) afw_c(L, p, (uint8_t)b[--k]);
+__device__ __forceinline__ uint32_t afs_ndig(uint32_t u) {
+    return 1u + (u >= 10u) + (u >= 100u) + (u >= 1000u) + (u >= 10000u) + (u >= 100000u) + (u >= 1000000u) + (u >= 10000000u) + (u >= 100000000u) + (u >= 1000000000u);
 }
-__device__ __forceinline__ void afw_lit(af_finw_t& L, uint32_t& p, const char* q) { while (*q) afw_c(L, p, (uint8_t)*q++); }
-__device__ __forceinline__ void afw_cigar(af_finw_t& L, uint32_t& p, const uint32_t* cg, uint32_t n) { for (uint32_t k = 0; k < n; ++k) { afw_i(L, p, (int)(cg[k] >> 4)); afw_c(L, p, (uint8_t)"MID"[cg[k] & 0xf]); } }
+// lane 0: one more segment of the line
+__device__ __forceinline__ void afs_push(af_finw_t& L, uint32_t& n, uint32_t& p, uint32_t kind, uint32_t val, uint32_t len) {
+    if (len == 0) return;
+    if (n < AFS_MAXSEG) { L.seg_off[n] = (uint16_t)(p < 0xFFFFu ? p : 0xFFFFu); L.seg_kind[n] = (uint8_t)kind; L.seg_val[n] = val; }
+    ++n; p += len;
+}
+__device__ __forceinline__ void afs_lits(af_finw_t& L, uint32_t& n, uint32_t& p, uint32_t at, uint32_t len) { afs_push(L, n, p, SK_LIT, at, len); }
+__device__ __forceinline__ void afs_num(af_finw_t& L, uint32_t& n, uint32_t& p, int v) {
+    if (v < 0) { const uint32_t u = 0u - (uint32_t)v; afs_push(L, n, p, SK_NEG, u, afs_ndig(u) + 1); }
+    else afs_push(L, n, p, SK_NUM, (uint32_t)v, afs_ndig((uint32_t)v));
+}
+// a CIGAR string as one segment: the offsets of its operations' texts (number + letter) for the renderer
+__device__ __forceinline__ void afs_cigar(af_finw_t& L, uint32_t& n, uint32_t& p, const uint32_t* cg, uint32_t nc, uint16_t* offs, uint32_t which) {
+    uint32_t q = 0;
+    for (uint32_t k = 0; k < nc; ++k) { offs[k] = (uint16_t)q; q += afs_ndig(cg[k] >> 4) + 1u; }
+    offs[nc] = (uint16_t)q;
+    afs_push(L, n, p, SK_CIG, which | (nc << 1), q);
+}
 
-// MD / NM of one CIGAR over the window that starts at text position t0 (write_MD_core); with_text: the MD string goes to line[] at the
-// cursor.  All lanes call it (uniform control flow); lane 0 writes.  Returns NM (uniform).
-__device__ __forceinline__ int afw_md(const af_args_t& G, af_finw_t& L, const uint32_t* cg, uint32_t n_cig, uint64_t t0, bool with_text, uint32_t& p) {
+// MD / NM of one CIGAR over the window that starts at text position t0 (write_MD_core).  All lanes call it (uniform control flow).
+// items: the MD string as a list in L.md_item (a mismatching lane writes its own item: the matches before it and its base); n_items
+// counts them (AFS_MAXMD + 1: something did not fit, the caller sends the read to the host pipeline).  Returns NM (uniform).
+__device__ __forceinline__ int afs_md(const af_args_t& G, af_finw_t& L, const uint32_t* cg, uint32_t n_cig, uint64_t t0, bool items, uint32_t& n_items) {
     const int lane = threadIdx.x;
     const dp_launch_t& D = G.A.D;
-    int NM = 0, l_MD = 0;
+    const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    int NM = 0; uint32_t l_MD = 0, ni = 0;
+    bool bad = false;
     uint64_t t = t0; uint32_t q = 0;
     for (uint32_t i = 0; i < n_cig; ++i) {
         const uint32_t op = cg[i] & 0xf, len = cg[i] >> 4;
@@ -1194,40 +1222,36 @@ __device__ __forceinline__ int afw_md(const af_args_t& G, af_finw_t& L, const ui
             for (uint32_t k0 = 0; k0 < len; k0 += 64) {
                 const uint32_t k = k0 + lane;
                 uint32_t tc = 0; bool mis = false;
-                if (k < len) { const uint64_t a = t + k; tc = dp_nt4(a < D.n_text ? D.text[a] : 0u); mis = (uint32_t)L.qc[q + k] != tc; }
-                unsigned long long bal = __ballot(mis);
+                if (k < len) { const uint64_t a = t + k; tc = dp_nt4(a < D.n_text ? D.text[a] : 0u); mis = dp_nt4(L.seq[q + k]) != tc; }
+                const unsigned long long bal = __ballot(mis);
                 const uint32_t span = len - k0 < 64 ? len - k0 : 64;
-                uint32_t done = 0;                       // columns of this chunk already counted
-                while (bal) {
-                    const int b = __ffsll((long long)bal) - 1;
-                    l_MD += b - (int)done;
-                    const uint32_t tcb = (uint32_t)__shfl((int)tc, b);
-                    if (with_text && lane == 0) { afw_i(L, p, l_MD); afw_c(L, p, (uint8_t)"ACGTN"[tcb]); }
-                    if (with_text) p = (uint32_t)__shfl((int)p, 0);
-                    l_MD = 0; ++NM; done = (uint32_t)b + 1;
-                    bal &= bal - 1;
-                }
-                l_MD += (int)(span - done);
+                if (bal) {
+                    const uint32_t cnt = (uint32_t)__popcll(bal);
+                    if (items && mis) {
+                        const unsigned long long prev = bal & lt_mask;
+                        const uint32_t run = prev ? (uint32_t)lane - (63u - (uint32_t)__clzll((long long)prev)) - 1u : (uint32_t)lane + l_MD;
+                        const uint32_t at = ni + (uint32_t)__popcll(prev);
+                        if (at < AFS_MAXMD) L.md_item[at] = 1u | ((run & 0x3FFu) << 2) | (tc << 12);
+                    }
+                    if (l_MD + 63u > 0x3FFu) bad = true;                  // a count of matches beyond the item's 10 bits
+                    ni += cnt; NM += (int)cnt;
+                    l_MD = span - 1u - (63u - (uint32_t)__clzll((long long)bal));
+                } else l_MD += span;
             }
             q += len; t += len;
         } else if (op == 1) { q += len; NM += (int)len; }
         else if (op == 2) {
-            if (with_text) {
-                if (lane == 0) { afw_i(L, p, l_MD); afw_c(L, p, '^'); }
-                p = (uint32_t)__shfl((int)p, 0);
-                for (uint32_t k = lane; k < len; k += 64) { const uint64_t a = t + k; const uint32_t tc = dp_nt4(a < D.n_text ? D.text[a] : 0u); if (p + k < AFW_TXT_CAP) L.line[p + k] = (uint8_t)"ACGTN"[tc]; }
-                p += len;
+            if (items) {
+                if (lane == 0 && ni < AFS_MAXMD) L.md_item[ni] = 2u | ((l_MD & 0x3FFu) << 2) | ((len & 0x1FFu) << 12) | ((uint32_t)(t - t0) << 21);
+                if (l_MD > 0x3FFu || len > 0x1FFu || (t - t0) > 0x7FFu) bad = true;
             }
+            ++ni;
             l_MD = 0; t += len; NM += (int)len;
         } else if (op == 3) t += len;
     }
-    if (with_text && l_MD > 0) { if (lane == 0) afw_i(L, p, l_MD); p = (uint32_t)__shfl((int)p, 0); }
+    if (items && l_MD > 0) { if (lane == 0 && ni < AFS_MAXMD) L.md_item[ni] = (l_MD & 0x3FFu) << 2; if (l_MD > 0x3FFu) bad = true; ++ni; }
+    n_items = (bad || ni > AFS_MAXMD) ? AFS_MAXMD + 1 : ni;
     return NM;
-}
-
-__device__ __forceinline__ void afw_name(af_finw_t& L, const ak_fmt_t& F, bool names_lds, uint32_t& p, uint32_t sid) {
-    if (names_lds) { for (uint32_t k = L.name_off[sid]; k < L.name_off[sid + 1]; ++k) afw_c(L, p, L.names[k]); }
-    else { for (uint32_t k = F.sname_off[sid]; k < F.sname_off[sid + 1]; ++k) afw_c(L, p, F.snames[k]); }
 }
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) finish_wave_kernel(const af_args_t G) {
@@ -1242,8 +1266,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         for (uint32_t k = lane; k <= n_seq; k += 64) L.name_off[k] = (uint16_t)F.sname_off[k];
         for (uint32_t k = lane; k < F.sname_off[n_seq]; k += 64) L.names[k] = F.snames[k];
     }
-#define put_name(p, sid) afw_name(L, F, names_lds, (p), (sid))          /* lane 0 */
-    uint32_t* const tbs = reinterpret_cast<uint32_t*>(L.line + AFW_TXT_CAP / 2);       // staged traceback records: the line's upper half is free until the MD text
+    uint32_t* const tbs = reinterpret_cast<uint32_t*>(L.line);       // staged traceback records: the line buffer is free until the line is rendered
+#define TB(k) (*reinterpret_cast<const af_tb_t*>(tbs + (k) * AFW_TB_WORDS))
+#define NAME_LEN(sid) (names_lds ? (uint32_t)(L.name_off[(sid) + 1] - L.name_off[sid]) : F.sname_off[(sid) + 1] - F.sname_off[sid])
     for (uint64_t r_in = blockIdx.x; r_in < A.n_reads; r_in += gridDim.x) {
         af_plan_t& PL = G.plans[r_in];
         const uint32_t st = PL.status;
@@ -1264,47 +1289,52 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         __syncthreads();
         const af_cand_t* C = aligned ? &L.cand : nullptr;
         const uint32_t strand = aligned ? C->strand : 0u;
-        const uint32_t tb0 = aligned ? PL.tb0 : 0u;
+        const uint32_t n_alt = aligned ? PL.n_alt : 0u;
         if (aligned) {
+            const uint32_t tb0 = PL.tb0;
             const uint32_t n_tb = C->overlap ? 1u : (uint32_t)C->has_lc + C->has_rc + C->n_gap_tasks;      // as select_kernel counted them
             for (uint32_t w = lane; w < n_tb * AFW_TB_WORDS; w += 64) {
                 const uint32_t k = w / AFW_TB_WORDS, x = w % AFW_TB_WORDS;
                 tbs[w] = reinterpret_cast<const uint32_t*>(&G.tb[tb0 + k])[x];
             }
+            if ((uint32_t)lane < n_alt) {       // the alternatives' sequences and 1-based positions: one lane each
+                const uint64_t ap = L.alt_pos[lane];
+                const uint32_t s2 = ac_seq_of(A.P, ap);
+                L.alt_sid[lane] = s2; L.alt_p1[lane] = (uint32_t)(ap - A.P.lift_seqs[s2].start + 1);
+            }
         }
         // ---- the read in alignment orientation ----
-        for (uint32_t k = lane; k < m; k += 64) {
-            uint8_t b = strand ? ak_compl(A.D.reads[off + m - 1 - k]) : A.D.reads[off + k];
-            L.seq[k] = b; L.qc[k] = (uint8_t)dp_nt4(b);
-        }
+        for (uint32_t k = lane; k < m && k < AF_MAX_READ; k += 64) L.seq[k] = strand ? ak_compl(A.D.reads[off + m - 1 - k]) : A.D.reads[off + k];
+        __syncthreads();
         bool ovf = false;
         uint64_t lifted = 0;
         if (aligned && lane == 0) {
             // ---- CIGAR stitching (aligner_ksw2.hpp:3049-3108) ----
             uint32_t n = 0;
-            auto push = [&](uint32_t op) { if (n < AF_FIN_CIG) L.cig[n++] = op; else ovf = true; };
-            auto push_merge_first = [&](uint32_t op, bool first) { if (first && (op & 0xf) == 0 && n > 0) L.cig[n - 1] += op; else push(op); };
+#define PUSH(op) do { if (n < AFS_CIG) L.cig[n++] = (op); else ovf = true; } while (0)
+#define PUSH_MERGE_FIRST(op, first) do { const uint32_t o_ = (op); if ((first) && (o_ & 0xf) == 0 && n > 0) L.cig[n - 1] += o_; else PUSH(o_); } while (0)
             uint32_t tbx = 0;
-#define TB(k) (*reinterpret_cast<const af_tb_t*>(tbs + (k) * AFW_TB_WORDS))
             if (C->overlap) {
                 const af_tb_t& T = TB(tbx);
-                if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push(T.ops[T.n_ops - 1 - k]);
+                if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) PUSH(T.ops[T.n_ops - 1 - k]);
             } else {
-                if (C->has_lc) { const af_tb_t& T = TB(tbx++); if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push(T.ops[k]); }
+                if (C->has_lc) { const af_tb_t& T = TB(tbx++); if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) PUSH(T.ops[k]); }
                 const uint32_t rc_x = C->has_rc ? tbx++ : 0u;
                 for (uint32_t j = 0; j < C->n_an; ++j) {
                     const uint32_t mlen = C->an[j].len;
-                    if (n > 0 && (L.cig[n - 1] & 0xf) == 0) L.cig[n - 1] += mlen << 4; else push(mlen << 4);
+                    if (n > 0 && (L.cig[n - 1] & 0xf) == 0) L.cig[n - 1] += mlen << 4; else PUSH(mlen << 4);
                     if (j + 1 < C->n_an) {
                         const af_anchor_t g = C->an[j];
-                        if (g.gap_kind == AF_GAP_TASK) { const af_tb_t& T = TB(tbx++); if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push_merge_first(T.ops[T.n_ops - 1 - k], k == 0); }
-                        else if (g.gap_kind == AF_GAP_INS) push_merge_first(((uint32_t)(uint16_t)g.gap_val << 4) | 1u, true);
-                        else if (g.gap_kind == AF_GAP_DEL0) push_merge_first(2u, true);
-                        else if (g.gap_kind == AF_GAP_1X1) push_merge_first(1u << 4, true);
+                        if (g.gap_kind == AF_GAP_TASK) { const af_tb_t& T = TB(tbx++); if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) PUSH_MERGE_FIRST(T.ops[T.n_ops - 1 - k], k == 0); }
+                        else if (g.gap_kind == AF_GAP_INS) PUSH_MERGE_FIRST(((uint32_t)(uint16_t)g.gap_val << 4) | 1u, true);
+                        else if (g.gap_kind == AF_GAP_DEL0) PUSH_MERGE_FIRST(2u, true);
+                        else if (g.gap_kind == AF_GAP_1X1) PUSH_MERGE_FIRST(1u << 4, true);
                     }
                 }
-                if (C->has_rc) { const af_tb_t& T = TB(rc_x); if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push_merge_first(T.ops[T.n_ops - 1 - k], k == 0); }
+                if (C->has_rc) { const af_tb_t& T = TB(rc_x); if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) PUSH_MERGE_FIRST(T.ops[T.n_ops - 1 - k], k == 0); }
             }
+#undef PUSH
+#undef PUSH_MERGE_FIRST
             // ---- the alignment lifted to the reference contig (aligner_ksw2.hpp:3133-3160) ----
             uint32_t hint;
             const uint32_t sid = ac_seq_of(A.P, PL.ref_pos, &hint);
@@ -1313,7 +1343,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             const uint64_t start = PL.ref_pos - LS.start;
             const uint32_t rel = hint == 0xFFFFFFFFu ? hint : hint - LS.run_off;
             uint64_t lp = 0;
-            const int nl = ovf ? -1 : lift_cigar(runs, LS.n_runs, start, L.cig, n, L.lcig, AF_FIN_LCIG, rel, &lp);
+            const int nl = ovf ? -1 : lift_cigar(runs, LS.n_runs, start, L.cig, n, L.lcig, AFS_LCIG, rel, &lp);
             if (nl < 0) ovf = true;
             lifted = LS.second + (ovf ? 0ull : lp);
             L.n_cig = n; L.n_lcig = nl < 0 ? 0u : (uint32_t)nl; L.ovf = ovf ? 1u : 0u;
@@ -1321,139 +1351,154 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         __syncthreads();
         AF_STAMP(fw1); AF_PROF(G, 16, fw0, fw1);
         if (aligned) { ovf = L.ovf != 0; lifted = ((uint64_t)(uint32_t)__shfl((int)(lifted >> 32), 0) << 32) | (uint32_t)__shfl((int)(lifted & 0xFFFFFFFFull), 0); }
-        if (aligned && ovf) {        // more CIGAR operations than the staging holds: the host pipeline redoes the read (align_kernel runs beside this kernel, its list is closed)
-            if (lane == 0) {
-                atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CIGAR], 1u);
-                moni_aln_rec_t rec;
-                rec.status = 2u; rec.strand = strand; rec.ref_pos = 0; rec.score = 0; rec.score2 = 0;
-                rec.n_cigar = 0; rec.n_alt = 0; rec.cigar_off = 0; rec.alt_off = 0; rec.nm = 0; rec.md_len = 0; rec.md_off = 0; rec.txt_len = 0; rec.lift_nm = 0; rec.txt_off = 0;
-                A.recs[r_in] = rec;
-                if (A.dev_len) { A.dev_len[r_in] = 0; A.dev_off[r_in] = 0; atomicAdd(&A.dev_sum[0], 1ull); }
-            }
-            continue;
-        }
-        // ---- the line ----
-        uint32_t p = 0;
-        const uint64_t n0 = F.rname_off[r], n1 = F.rname_off[r + 1];
-        for (uint64_t k = lane; k < n1 - n0; k += 64) if (k < AFW_TXT_CAP) L.line[k] = F.rnames[n0 + k];
-        p = (uint32_t)(n1 - n0);
         moni_aln_rec_t rec;
         rec.status = aligned ? 1u : 0u; rec.strand = strand; rec.ref_pos = aligned ? PL.ref_pos : 0; rec.score = aligned ? C->score : 0; rec.score2 = aligned ? PL.score2 : 0;
         rec.n_cigar = 0; rec.n_alt = 0; rec.cigar_off = 0; rec.alt_off = 0; rec.nm = 0; rec.md_len = 0; rec.md_off = 0; rec.txt_len = 0; rec.lift_nm = 0; rec.txt_off = 0;
-        if (!aligned) {
-            if (lane == 0) afw_lit(L, p, "\t4\t*\t0\t255\t*\t*\t0\t0\t");
-            p = (uint32_t)__shfl((int)p, 0);
-            __syncthreads();
-            for (uint32_t k = lane; k < m; k += 64) if (p + k < AFW_TXT_CAP) L.line[p + k] = A.D.reads[off + k];
-            p += m;
-            if (lane == 0 && p < AFW_TXT_CAP) L.line[p] = '\t';
-            ++p;
-            if (F.quals) { for (uint32_t k = lane; k < m; k += 64) if (p + k < AFW_TXT_CAP) L.line[p + k] = F.quals[off + k]; p += m; }
-            else { if (lane == 0 && p < AFW_TXT_CAP) L.line[p] = '*'; ++p; }
-            if (lane == 0 && p < AFW_TXT_CAP) L.line[p] = '\n';
-            ++p;
-        } else {
-            const uint32_t n_cig = L.n_cig, n_lcig = L.n_lcig;
-            const int32_t score = C->score, score2 = PL.score2;
-            const uint32_t n_alt = PL.n_alt;
-            uint64_t ref_len = 0;
-            for (uint32_t k = 0; k < n_lcig; ++k) { const int op = L.lcig[k] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += L.lcig[k] >> 4; }
-            const bool mapped = ref_len > 0;
-            const uint32_t sid = ac_seq_of(A.P, PL.ref_pos), lsid = ac_seq_of(A.P, lifted);
-            const int oa_pos = (int)(PL.ref_pos - A.P.lift_seqs[sid].start + 1);
-            const int pos1 = (int)(lifted - A.P.lift_seqs[lsid].start + 1);
-            // compute_mapq_se_bwa (mapq.hpp:146-184), the operations in the host's order, none contracted
-            int mapq = 0;
-            {
-                const int32_t rl = mapped ? (int32_t)ref_len : 0;
-                const int32_t l = rl > (int32_t)m ? rl : (int32_t)m;
-                const int32_t sub = score2 ? score2 : F.min_len * F.smatch;
-                if (sub < score) {
-                    const double identity = __dsub_rn(1., __ddiv_rn(__ddiv_rn((double)(l * F.smatch - score), (double)(F.smatch + F.smismatch)), (double)l));
-                    if (score != 0) {
-                        double tmp = (double)l < 50.0 ? 1. : ((uint32_t)l < F.mapq_tab_n ? F.mapq_tab[l] : F.mapq_tab[F.mapq_tab_n - 1]);
-                        tmp = __dmul_rn(tmp, __dmul_rn(identity, identity));
-                        const double v = __dadd_rn(__dmul_rn(__dmul_rn(__ddiv_rn(__dmul_rn(6.02, (double)(score - sub)), (double)F.smatch), tmp), tmp), .499);
-                        mapq = (int)v;
+        bool to_host = (aligned && ovf) || m > AF_MAX_READ;       // more CIGAR operations than the staging holds (align_kernel runs beside this kernel, its list is closed)
+        if (aligned && ovf && lane == 0) atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CIGAR], 1u);
+        uint32_t p = 0;
+        const uint64_t n0 = F.rname_off[r], n1 = F.rname_off[r + 1];
+        if (!to_host) {
+            // ---- what the line needs besides the CIGARs: NM / MD of the lifted alignment, NM of the one on the pangenome text, MAPQ ----
+            int nm = 0, lift_nm = 0, mapq = 0, oa_pos = 0, pos1 = 0;
+            uint32_t n_md = 0, sid = 0, lsid = 0;
+            bool mapped = false;
+            const uint32_t n_cig = aligned ? L.n_cig : 0u, n_lcig = aligned ? L.n_lcig : 0u;
+            const int32_t score = aligned ? C->score : 0, score2 = aligned ? PL.score2 : 0;
+            if (aligned) {
+                uint64_t ref_len = 0;
+                for (uint32_t k = 0; k < n_lcig; ++k) { const int op = L.lcig[k] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += L.lcig[k] >> 4; }
+                mapped = ref_len > 0;
+                sid = ac_seq_of(A.P, PL.ref_pos); lsid = ac_seq_of(A.P, lifted);
+                oa_pos = (int)(PL.ref_pos - A.P.lift_seqs[sid].start + 1);
+                pos1 = (int)(lifted - A.P.lift_seqs[lsid].start + 1);
+                // compute_mapq_se_bwa (mapq.hpp:146-184), the operations in the host's order, none contracted
+                {
+                    const int32_t rl = mapped ? (int32_t)ref_len : 0;
+                    const int32_t l = rl > (int32_t)m ? rl : (int32_t)m;
+                    const int32_t sub = score2 ? score2 : F.min_len * F.smatch;
+                    if (sub < score) {
+                        const double identity = __dsub_rn(1., __ddiv_rn(__ddiv_rn((double)(l * F.smatch - score), (double)(F.smatch + F.smismatch)), (double)l));
+                        if (score != 0) {
+                            double tmp = (double)l < 50.0 ? 1. : ((uint32_t)l < F.mapq_tab_n ? F.mapq_tab[l] : F.mapq_tab[F.mapq_tab_n - 1]);
+                            tmp = __dmul_rn(tmp, __dmul_rn(identity, identity));
+                            const double v = __dadd_rn(__dmul_rn(__dmul_rn(__ddiv_rn(__dmul_rn(6.02, (double)(score - sub)), (double)F.smatch), tmp), tmp), .499);
+                            mapq = (int)v;
+                        }
+                        if (mapq > 60) mapq = 60;
+                        if (mapq < 0) mapq = 0;
+                        mapq = (int)__dadd_rn(__dmul_rn((double)mapq, 1.), .499);
                     }
-                    if (mapq > 60) mapq = 60;
-                    if (mapq < 0) mapq = 0;
-                    mapq = (int)__dadd_rn(__dmul_rn((double)mapq, 1.), .499);
                 }
+                bool same = n_lcig == n_cig && lifted == PL.ref_pos;
+                for (uint32_t k = 0; same && k < n_cig; ++k) same = L.lcig[k] == L.cig[k];
+                uint32_t dummy = 0;
+                if (mapped) nm = afs_md(G, L, L.lcig, n_lcig, lifted, true, n_md);
+                lift_nm = same ? nm : afs_md(G, L, L.cig, n_cig, PL.ref_pos, false, dummy);
+                if (n_md > AFS_MAXMD) { to_host = true; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CIGAR], 1u); }
             }
-            // NM of the alignment on the pangenome text (OA tag) and, further down, MD / NM of the lifted one
-            uint32_t dummy = 0;
-            bool same = n_lcig == n_cig && lifted == PL.ref_pos;
-            for (uint32_t k = 0; same && k < n_cig; ++k) same = L.lcig[k] == L.cig[k];
-            int lift_nm = same ? 0 : afw_md(G, L, L.cig, n_cig, PL.ref_pos, false, dummy);
-            if (lane == 0) {
-                afw_c(L, p, '\t'); afw_i(L, p, strand ? 16 : 0); afw_c(L, p, '\t');
-                if (mapped) put_name(p, lsid); else afw_c(L, p, '*');
-                afw_c(L, p, '\t'); afw_i(L, p, mapped ? pos1 : 0); afw_c(L, p, '\t'); afw_i(L, p, mapq); afw_c(L, p, '\t');
-                if (mapped) afw_cigar(L, p, L.lcig, n_lcig); else afw_c(L, p, '*');
-                afw_lit(L, p, "\t*\t0\t0\t");
-            }
-            p = (uint32_t)__shfl((int)p, 0);
             __syncthreads();
             AF_STAMP(fw2); AF_PROF(G, 17, fw1, fw2);
-            for (uint32_t k = lane; k < m; k += 64) if (p + k < AFW_TXT_CAP) L.line[p + k] = L.seq[k];
-            p += m;
-            if (lane == 0 && p < AFW_TXT_CAP) L.line[p] = '\t';
-            ++p;
-            if (F.quals) { for (uint32_t k = lane; k < m; k += 64) if (p + k < AFW_TXT_CAP) L.line[p + k] = F.quals[strand ? off + m - 1 - k : off + k]; p += m; }
-            else { if (lane == 0 && p < AFW_TXT_CAP) L.line[p] = '*'; ++p; }
-            const uint32_t p_nm = p;           // "\tAS:i:<score>\tNM:i:" then NM, which needs the MD walk: MD goes to a scratch place first
-            // MD text: behind everything else it could collide with; build it at the end of the buffer region then move
-            uint32_t pm = AFW_TXT_CAP / 2;      // MD staging area: second half of the line buffer
-            int nm = 0;
-            if (mapped) nm = afw_md(G, L, L.lcig, n_lcig, lifted, true, pm);
-            if (same) lift_nm = nm;
+            // ---- the segments of the line (sam.hpp:144-188), lane 0 ----
+            if (lane == 0 && !to_host) {
+                uint32_t n = 0, q = 0;
+                afs_push(L, n, q, SK_RNAME, 0, (uint32_t)(n1 - n0));
+                if (!aligned) {
+                    afs_lits(L, n, q, LT_UNAL, 19);
+                    L.seq_at = q; afs_push(L, n, q, SK_SEQ, 0, m); afs_lits(L, n, q, LT_TAB, 1);
+                    L.qual_at = F.quals ? q : ~0u;
+                    if (F.quals) afs_push(L, n, q, SK_QUAL, 0, m); else afs_lits(L, n, q, LT_STAR, 1);
+                    afs_lits(L, n, q, LT_NL, 1);
+                } else {
+                    afs_lits(L, n, q, LT_TAB, 1); afs_num(L, n, q, strand ? 16 : 0); afs_lits(L, n, q, LT_TAB, 1);
+                    if (mapped) afs_push(L, n, q, SK_NAME, lsid, NAME_LEN(lsid)); else afs_lits(L, n, q, LT_STAR, 1);
+                    afs_lits(L, n, q, LT_TAB, 1); afs_num(L, n, q, mapped ? pos1 : 0); afs_lits(L, n, q, LT_TAB, 1); afs_num(L, n, q, mapq); afs_lits(L, n, q, LT_TAB, 1);
+                    if (mapped) afs_cigar(L, n, q, L.lcig, n_lcig, L.lcig_off, 0u); else afs_lits(L, n, q, LT_STAR, 1);
+                    afs_lits(L, n, q, LT_MATE, 7);
+                    L.seq_at = q; afs_push(L, n, q, SK_SEQ, 0, m); afs_lits(L, n, q, LT_TAB, 1);
+                    L.qual_at = F.quals ? q : ~0u;
+                    if (F.quals) afs_push(L, n, q, SK_QUAL, 0, m); else afs_lits(L, n, q, LT_STAR, 1);
+                    afs_lits(L, n, q, LT_AS, 6); afs_num(L, n, q, score); afs_lits(L, n, q, LT_NM, 6); afs_num(L, n, q, mapped ? nm : 0);
+                    if (score2 != 0) { afs_lits(L, n, q, LT_ZS, 6); afs_num(L, n, q, score2); }
+                    afs_lits(L, n, q, LT_MD, 6);
+                    {   // the MD string as one segment: where every item's text starts
+                        uint32_t w = 0;
+                        for (uint32_t k = 0; k < n_md; ++k) {
+                            const uint32_t it = L.md_item[k], ty = it & 3u;
+                            L.md_off[k] = (uint16_t)w;
+                            w += afs_ndig((it >> 2) & 0x3FFu) + (ty == 1 ? 1u : ty == 2 ? 1u + ((it >> 12) & 0x1FFu) : 0u);
+                        }
+                        L.md_off[n_md] = (uint16_t)w;
+                        afs_push(L, n, q, SK_MD, n_md, w);
+                    }
+                    afs_lits(L, n, q, LT_OA, 6); afs_push(L, n, q, SK_NAME, sid, NAME_LEN(sid));
+                    afs_lits(L, n, q, LT_COMMA, 1); afs_num(L, n, q, oa_pos); afs_lits(L, n, q, strand ? LT_MINUS : LT_PLUS, 3);
+                    afs_cigar(L, n, q, L.cig, n_cig, L.cig_off, 1u);
+                    afs_lits(L, n, q, LT_COMMA, 1); afs_num(L, n, q, mapq); afs_lits(L, n, q, LT_COMMA, 1); afs_num(L, n, q, lift_nm); afs_lits(L, n, q, LT_SEMI, 1);
+                    afs_lits(L, n, q, LT_AA, 6);
+                    for (uint32_t k = 0; k < n_alt; ++k) {
+                        const uint32_t s2 = L.alt_sid[k];
+                        afs_push(L, n, q, SK_NAME, s2, NAME_LEN(s2));
+                        afs_lits(L, n, q, LT_COMMA, 1); afs_num(L, n, q, (int)L.alt_p1[k]); afs_lits(L, n, q, LT_COMMA, 1); afs_num(L, n, q, L.alt_score[k]); afs_lits(L, n, q, LT_SEMI, 1);
+                    }
+                    afs_lits(L, n, q, LT_NL, 1);
+                }
+                if (n <= AFS_MAXSEG) L.seg_off[n] = (uint16_t)(q < 0xFFFFu ? q : 0xFFFFu);
+                L.n_seg = n; L.total = q;
+            }
             __syncthreads();
             AF_STAMP(fw3); AF_PROF(G, 18, fw2, fw3);
-            const uint32_t md_len = pm - AFW_TXT_CAP / 2;
-            p = p_nm;
-            if (lane == 0) {
-                afw_lit(L, p, "\tAS:i:"); afw_i(L, p, score); afw_lit(L, p, "\tNM:i:"); afw_i(L, p, mapped ? nm : 0);
-                if (score2 != 0) { afw_lit(L, p, "\tZS:i:"); afw_i(L, p, score2); }
-                afw_lit(L, p, "\tMD:Z:");
-            }
-            p = (uint32_t)__shfl((int)p, 0);
-            __syncthreads();
-            bool too_long = pm > AFW_TXT_CAP || p + md_len + 64 > AFW_TXT_CAP / 2;      // the head of the line must not reach the MD staging area
-            if (!too_long && mapped) {
-                uint8_t tmpb[(AFW_TXT_CAP / 2 + 63) / 64];
-                int cnt = 0;
-                for (uint32_t k = lane; k < md_len; k += 64) tmpb[cnt++] = L.line[AFW_TXT_CAP / 2 + k];
-                __syncthreads();
-                cnt = 0;
-                for (uint32_t k = lane; k < md_len; k += 64) L.line[p + k] = tmpb[cnt++];
-                p += md_len;
-            }
-            __syncthreads();
-            AF_STAMP(fw4); AF_PROF(G, 19, fw3, fw4);
-            if (lane == 0) {
-                afw_lit(L, p, "\tOA:Z:");
-                put_name(p, sid);
-                afw_c(L, p, ','); afw_i(L, p, oa_pos); afw_lit(L, p, strand ? ",-," : ",+,");
-                afw_cigar(L, p, L.cig, n_cig);
-                afw_c(L, p, ','); afw_i(L, p, mapq); afw_c(L, p, ','); afw_i(L, p, lift_nm); afw_c(L, p, ';');
-                afw_lit(L, p, "\tAA:Z:");
-                for (uint32_t k = 0; k < n_alt; ++k) {
-                    const uint64_t ap = L.alt_pos[k];
-                    const uint32_t s2 = ac_seq_of(A.P, ap);
-                    put_name(p, s2);
-                    afw_c(L, p, ','); afw_i(L, p, (int)(ap - A.P.lift_seqs[s2].start + 1)); afw_c(L, p, ','); afw_i(L, p, L.alt_score[k]); afw_c(L, p, ';');
+            const uint32_t n_seg = to_host ? 0u : L.n_seg;
+            p = to_host ? 0u : L.total;
+            if (!to_host && (n_seg > AFS_MAXSEG || p > AFS_LINE)) { to_host = true; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CAPACITY], 1u); }
+            if (!to_host) {
+                // ---- SEQ and QUAL are plain copies; every lane renders its share of the other bytes of the line ----
+                const uint32_t s_at = L.seq_at, q_at = L.qual_at, holes = m + (q_at != ~0u ? m : 0u);
+                if (s_at + m <= AFS_LINE) for (uint32_t k = lane; k < m; k += 64) L.line[s_at + k] = L.seq[k];
+                if (q_at != ~0u && q_at + m <= AFS_LINE) for (uint32_t k = lane; k < m; k += 64) L.line[q_at + k] = F.quals[strand ? off + m - 1 - k : off + k];
+                for (uint32_t i = lane; i + holes < p; i += 64) {
+                    uint32_t b = i;
+                    if (b >= s_at) b += m;
+                    if (q_at != ~0u && b >= q_at) b += m;
+                    uint32_t lo = 0, hi = n_seg;                       // last segment that starts at or before b
+                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)L.seg_off[mid] <= b) lo = mid; else hi = mid; }
+                    const uint32_t d = b - L.seg_off[lo], kind = L.seg_kind[lo], val = L.seg_val[lo];
+                    uint8_t ch;
+                    if (kind == SK_LIT) ch = (uint8_t)afs_lit[val + d];
+                    else if (kind == SK_NUM || kind == SK_NEG) {
+                        const uint32_t len = (uint32_t)L.seg_off[lo + 1] - L.seg_off[lo];
+                        if (kind == SK_NEG && d == 0) ch = '-';
+                        else { uint32_t u = val; for (uint32_t t = d + 1; t < len; ++t) u /= 10u; ch = (uint8_t)('0' + u % 10u); }
+                    }
+                    else if (kind == SK_SEQ) ch = L.seq[d];
+                    else if (kind == SK_QUAL) ch = F.quals[strand ? off + m - 1 - d : off + d];
+                    else if (kind == SK_NAME) ch = names_lds ? L.names[L.name_off[val] + d] : F.snames[F.sname_off[val] + d];
+                    else if (kind == SK_RNAME) ch = F.rnames[n0 + d];
+                    else if (kind == SK_CIG) {          // operation k of a CIGAR: its length, then its letter
+                        const uint16_t* offs = (val & 1u) ? L.cig_off : L.lcig_off; const uint32_t* cg = (val & 1u) ? L.cig : L.lcig;
+                        uint32_t a = 0, z = val >> 1;
+                        while (z - a > 1) { const uint32_t mid = (a + z) >> 1; if ((uint32_t)offs[mid] <= d) a = mid; else z = mid; }
+                        const uint32_t e = d - offs[a], nd = (uint32_t)offs[a + 1] - offs[a] - 1u;
+                        if (e == nd) ch = (uint8_t)afs_lit[LT_OPS + (cg[a] & 0xfu)];
+                        else { uint32_t u = cg[a] >> 4; for (uint32_t t = e + 1; t < nd; ++t) u /= 10u; ch = (uint8_t)('0' + u % 10u); }
+                    } else {                            // SK_MD: item k of the MD string: the count of matches, then the base or ^ and the deleted bases
+                        uint32_t a = 0, z = val;
+                        while (z - a > 1) { const uint32_t mid = (a + z) >> 1; if ((uint32_t)L.md_off[mid] <= d) a = mid; else z = mid; }
+                        const uint32_t it = L.md_item[a], ty = it & 3u, run = (it >> 2) & 0x3FFu, e = d - L.md_off[a], nd = afs_ndig(run);
+                        if (e < nd) { uint32_t u = run; for (uint32_t t = e + 1; t < nd; ++t) u /= 10u; ch = (uint8_t)('0' + u % 10u); }
+                        else if (ty == 1) { const uint32_t bc = (it >> 12) & 7u; ch = (uint8_t)afs_lit[LT_BASES + (bc > 4 ? 4 : bc)]; }
+                        else if (e == nd) ch = '^';
+                        else { const uint64_t ta = lifted + (it >> 21) + (e - nd - 1u); ch = (uint8_t)afs_lit[LT_BASES + dp_nt4(ta < A.D.n_text ? A.D.text[ta] : 0u)]; }
+                    }
+                    L.line[b] = ch;
                 }
-                afw_c(L, p, '\n');
             }
-            p = (uint32_t)__shfl((int)p, 0);
-            if (too_long) p = AFW_TXT_CAP + 1;
-            AF_STAMP(fw5); AF_PROF(G, 20, fw4, fw5);
+            AF_STAMP(fw4); AF_PROF(G, 19, fw3, fw4);
         }
         __syncthreads();
         AF_STAMP(fw6);
         // ---- out: the text pool (8-byte words, bump-allocated), coalesced; the record ----
-        if (p > AFW_TXT_CAP) rec.status = 2;           // does not fit the staging: the host pipeline redoes the read
+        if (to_host) rec.status = 2;           // does not fit the staging: the host pipeline redoes the read
         else {
             const unsigned long long words = (unsigned long long)((p + 7) >> 3);
             const uint32_t shard = blockIdx.x % AF_TXT_SHARDS;
@@ -1478,6 +1523,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         }
         AF_STAMP(fw7); AF_PROF(G, 21, fw6, fw7); AF_PROF(G, 22, fw0, fw7);
     }
+#undef TB
+#undef NAME_LEN
 }
 
 

@@ -1351,8 +1351,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         if (use_fast && n_sub) { unsigned long long pf[32]; for (int x = 0; x < (int)std::min<uint64_t>(n_sub, AK_NSET); ++x) { HIPCHK(hipMemcpy(pf, c->af[x].prof.p, sizeof pf, hipMemcpyDeviceToHost));
             fprintf(stderr, "chain_plan_kernel wave cycles (set %d): load+filter+anchors %.3g, chain %.3g (sort %.3g, dp %.3g, ends+backtrack %.3g), lifts %.3g, plan %.3g, whole read %.3g\n", x,
                     (double)pf[0], (double)pf[1], (double)pf[5], (double)pf[6], (double)pf[7], (double)pf[2], (double)pf[3], (double)pf[4]);
-            fprintf(stderr, "finish_wave_kernel wave cycles (set %d): stage read + stitch + lift %.3g, head fields + OA NM %.3g, SEQ/QUAL + MD %.3g, NM/MD move %.3g, OA/AA tags %.3g, out %.3g, whole read %.3g\n", x,
-                    (double)pf[16], (double)pf[17], (double)pf[18], (double)pf[19], (double)pf[20], (double)pf[21], (double)pf[22]); } }
+            fprintf(stderr, "finish_wave_kernel wave cycles (set %d): stage + stitch + lift %.3g, MD / NM / MAPQ %.3g, segment list %.3g, render %.3g, out %.3g, whole read %.3g\n", x,
+                    (double)pf[16], (double)pf[17], (double)pf[18], (double)pf[19], (double)pf[21], (double)pf[22]); } }
 #endif
         double ak_sum_ms = c->dp_kernel_ms_accum;
         if (n_sub) { float ms = 0; if (hipEventElapsedTime(&ms, c->ak_begin[0], c->ak_done[n_sub - 1]) == hipSuccess) c->dp_kernel_ms_accum = ms; }      // launches overlap: report the span

@@ -1209,7 +1209,8 @@ __device__ __forceinline__ void afs_cigar(af_finw_t& L, uint32_t& n, uint32_t& p
 // MD / NM of one CIGAR over the window that starts at text position t0 (write_MD_core).  All lanes call it (uniform control flow).
 // items: the MD string as a list in L.md_item (a mismatching lane writes its own item: the matches before it and its base); n_items
 // counts them (AFS_MAXMD + 1: something did not fit, the caller sends the read to the host pipeline).  Returns NM (uniform).
-__device__ __forceinline__ int afs_md(const af_args_t& G, af_finw_t& L, const uint32_t* cg, uint32_t n_cig, uint64_t t0, bool items, uint32_t& n_items) {
+__device__ __forceinline__ int afs_md(const af_args_t& G, af_finw_t& L, const uint32_t* cg, uint32_t n_cig, uint64_t t0, bool items, uint32_t& n_items,
+                                      const uint8_t* win) {          // win: the window's nt4 codes in LDS (or nullptr: read the text)
     const int lane = threadIdx.x;
     const dp_launch_t& D = G.A.D;
     const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -1222,7 +1223,7 @@ __device__ __forceinline__ int afs_md(const af_args_t& G, af_finw_t& L, const ui
             for (uint32_t k0 = 0; k0 < len; k0 += 64) {
                 const uint32_t k = k0 + lane;
                 uint32_t tc = 0; bool mis = false;
-                if (k < len) { const uint64_t a = t + k; tc = dp_nt4(a < D.n_text ? D.text[a] : 0u); mis = dp_nt4(L.seq[q + k]) != tc; }
+                if (k < len) { const uint64_t a = t + k; tc = win ? (uint32_t)win[a - t0] : dp_nt4(a < D.n_text ? D.text[a] : 0u); mis = dp_nt4(L.seq[q + k]) != tc; }
                 const unsigned long long bal = __ballot(mis);
                 const uint32_t span = len - k0 < 64 ? len - k0 : 64;
                 if (bal) {
@@ -1279,6 +1280,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         const bool aligned = st == AF_ST_FINAL;
         __syncthreads();
         AF_STAMP(fw0);
+        // where the alignment starts in the lift tables: these dependent loads (directory, sequence record, first run) are started before the
+        // staging below instead of inside lane 0's serial section
+        const uint64_t aln_pos = aligned ? PL.ref_pos : 0ull;
+        uint32_t hint0 = 0xFFFFFFFFu;
+        const uint32_t sid0 = aligned ? ac_seq_of(A.P, aln_pos, &hint0) : 0u;
+        moni_lift_seq_t LS0; LS0.second = 0; LS0.run_off = 0; LS0.n_runs = 0; LS0.start = 0; LS0.end = 0;
+        if (aligned) LS0 = A.P.lift_seqs[sid0];
         // the final chain's record, the alternatives and (below) its traceback records come with one round trip each instead of field by field
         if (aligned) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(&PL.cand[PL.final_cand]);
@@ -1336,12 +1344,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
 #undef PUSH
 #undef PUSH_MERGE_FIRST
             // ---- the alignment lifted to the reference contig (aligner_ksw2.hpp:3133-3160) ----
-            uint32_t hint;
-            const uint32_t sid = ac_seq_of(A.P, PL.ref_pos, &hint);
-            const moni_lift_seq_t LS = A.P.lift_seqs[sid];
+            const moni_lift_seq_t LS = LS0;
             const moni_lift_run_t* __restrict__ runs = A.P.lift_runs + LS.run_off;
-            const uint64_t start = PL.ref_pos - LS.start;
-            const uint32_t rel = hint == 0xFFFFFFFFu ? hint : hint - LS.run_off;
+            const uint64_t start = aln_pos - LS.start;
+            const uint32_t rel = hint0 == 0xFFFFFFFFu ? hint0 : hint0 - LS.run_off;
             uint64_t lp = 0;
             const int nl = ovf ? -1 : lift_cigar(runs, LS.n_runs, start, L.cig, n, L.lcig, AFS_LCIG, rel, &lp);
             if (nl < 0) ovf = true;
@@ -1369,8 +1375,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 uint64_t ref_len = 0;
                 for (uint32_t k = 0; k < n_lcig; ++k) { const int op = L.lcig[k] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += L.lcig[k] >> 4; }
                 mapped = ref_len > 0;
-                sid = ac_seq_of(A.P, PL.ref_pos); lsid = ac_seq_of(A.P, lifted);
-                oa_pos = (int)(PL.ref_pos - A.P.lift_seqs[sid].start + 1);
+                sid = sid0; lsid = ac_seq_of(A.P, lifted);
+                oa_pos = (int)(aln_pos - LS0.start + 1);
                 pos1 = (int)(lifted - A.P.lift_seqs[lsid].start + 1);
                 // compute_mapq_se_bwa (mapq.hpp:146-184), the operations in the host's order, none contracted
                 {
@@ -1393,8 +1399,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 bool same = n_lcig == n_cig && lifted == PL.ref_pos;
                 for (uint32_t k = 0; same && k < n_cig; ++k) same = L.lcig[k] == L.cig[k];
                 uint32_t dummy = 0;
-                if (mapped) nm = afs_md(G, L, L.lcig, n_lcig, lifted, true, n_md);
-                lift_nm = same ? nm : afs_md(G, L, L.cig, n_cig, PL.ref_pos, false, dummy);
+                // the two reference windows (lifted, and on the pangenome text) go to LDS with one round trip: the MD walks read them there
+                uint64_t ref_len_u = 0;
+                for (uint32_t k = 0; k < n_cig; ++k) { const int op = L.cig[k] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len_u += L.cig[k] >> 4; }
+                const bool win = ref_len <= AFS_LINE / 2 && ref_len_u <= AFS_LINE / 2;
+                if (win) {
+                    if (mapped) for (uint32_t k = lane; k < (uint32_t)ref_len; k += 64) { const uint64_t a = lifted + k; L.line[k] = (uint8_t)dp_nt4(a < A.D.n_text ? A.D.text[a] : 0u); }
+                    if (!same) for (uint32_t k = lane; k < (uint32_t)ref_len_u; k += 64) { const uint64_t a = aln_pos + k; L.line[AFS_LINE / 2 + k] = (uint8_t)dp_nt4(a < A.D.n_text ? A.D.text[a] : 0u); }
+                    __syncthreads();
+                }
+                if (mapped) nm = afs_md(G, L, L.lcig, n_lcig, lifted, true, n_md, win ? L.line : nullptr);
+                lift_nm = same ? nm : afs_md(G, L, L.cig, n_cig, aln_pos, false, dummy, win ? L.line + AFS_LINE / 2 : nullptr);
                 if (n_md > AFS_MAXMD) { to_host = true; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CIGAR], 1u); }
             }
             __syncthreads();

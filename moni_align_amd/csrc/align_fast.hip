@@ -91,7 +91,9 @@ struct af_tb_t { uint32_t n_ops; uint32_t ops[AF_TB_CIG]; };      // raw backtra
 struct af_args_t {
     ak_args_t A;                             // reads / text / seeds / record pools: as align_kernel
     af_plan_t* plans;                        // per read of the launch
-    moni_dp_task_t* tasks; uint32_t task_cap;
+    moni_dp_task_t* tasks; uint32_t task_cap;    // slots: AF_MAX_TASKS_READ per read of the launch (chain_plan_kernel writes a read's tasks to its own slots: no shared
+                                             // counter - one address takes only ~70 M atomics/s, one per read was the kernel's bound), then the global problems
+    uint8_t* ntasks;                         // per read: how many of its slots are in use
     af_res_t* res;
     uint32_t* bin_q; uint32_t bin_cap;       // AF_NBIN queues of task indices
     uint32_t* task_pos;                      // where a task sits: position in its bin's queue | bin << 26
@@ -117,7 +119,7 @@ struct af_args_t {
 #endif
 enum { AFC_TASKS = 0, AFC_FALLBACK = 1, AFC_TRACED = 2, AFC_READ_CUR = 3, AFC_DIRS_OVF = 4, AFC_CELLS = 6 /* 64 bit */, AFC_DIROFF = 8 /* 64 bit */,
        AFC_NCHUNKS = 10 /* + group */, AFC_CURSOR = 13 /* + group */, AFC_BINS = 16 /* + bin */, AFC_BIG = 49, AFC_BIG_CUR = 50, AFC_WHY = 52 /* + reason */, AFC_RBYTES = 64 /* 64 bit: text bytes of the DP targets, the R of SURVEY.md 8(d) */,
-       AFC_QBYTES = 66 /* 64 bit: read bytes of the DP queries */, AF_NCTR = 96 };
+       AFC_QBYTES = 66 /* 64 bit: read bytes of the DP queries */, AFC_NT = 68 /* DP problems queued by bin_tasks_kernel */, AF_NCTR = 96 };
 enum { AF_GRP_LARGE = 0, AF_GRP_SMALL = 1, AF_GRP_GLOBAL = 2 };
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -179,6 +181,105 @@ __device__ __forceinline__ void af_small_sort(T* a, uint32_t n, Less less, int l
     __syncthreads();
 }
 
+// std::sort of the anchors by reference end, by the whole wave, element for element what libstdc++'s introsort leaves (sort_emul.h
+// is the serial form; ties between anchors are common - a MEM's right half ends where the MEM ends - and their order reaches the SAM):
+//   * the introsort loop keeps its order of partitions (explicit stack), but a partition is done by all lanes at once: the unguarded
+//     Hoare partition swaps the k-th element from the left that is not below the pivot with the k-th from the right that is not above
+//     it for as long as the former lies left of the latter - ranks that ballots give without walking;
+//   * std::__final_insertion_sort (guarded for the first 16, unguarded after) is a stable sort: every lane places its elements by
+//     stable rank;
+//   * the depth-limit fallback (heap sort of a range) stays serial: it needs 2 * log2(n) unlucky partitions in a row.
+// NC: elements per lane (n <= 64 * NC).  ipos / jpos: scratch of n entries each.
+template <int NC>
+__device__ __forceinline__ void af_wave_sort_anchors(uint64_t* a, uint32_t n, lsort::frame* st, uint16_t* ipos, uint16_t* jpos, int lane) {
+    auto less = [](const uint64_t& x, const uint64_t& y) { return AF_X(x) < AF_X(y); };
+    const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    if (n > 16) {
+        int lg = 0;
+        for (uint32_t v = n; v > 1; v >>= 1) ++lg;
+        int sp = 0;
+        if (lane == 0) st[0] = lsort::frame{0, (int)n, lg * 2};
+        sp = 1;
+        __syncthreads();
+        while (sp > 0) {
+            const lsort::frame f = st[--sp];
+            __syncthreads();
+            long first = f.first, last = f.last, depth = f.depth;
+            while (last - first > 16) {
+                if (depth == 0) { if (lane == 0) lsort::heap_sort(a, first, last, less); __syncthreads(); break; }
+                --depth;
+                const long mid = first + (last - first) / 2;
+                if (lane == 0) lsort::move_median_to_first(a, first, first + 1, mid, last - 1, less);
+                __syncthreads();
+                // ---- unguarded_partition(a, first + 1, last, first) ----
+                const uint64_t pk = AF_X(a[first]);
+                const uint32_t lo = (uint32_t)first + 1, hi = (uint32_t)last;
+                uint64_t v[NC]; bool fa[NC], fb[NC]; uint32_t ra[NC], rb[NC];
+                uint32_t nA = 0, nB = 0;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {          // ranks from the left among the elements not below the pivot
+                    const uint32_t i = lo + (uint32_t)lane + 64u * c;
+                    fa[c] = fb[c] = false; v[c] = 0;
+                    if (i < hi) { v[c] = a[i]; const uint64_t k = AF_X(v[c]); fa[c] = !(k < pk); fb[c] = !(pk < k); }
+                    const unsigned long long ba = __ballot(fa[c]);
+                    ra[c] = nA + (uint32_t)__popcll(ba & lt_mask);
+                    nA += (uint32_t)__popcll(ba);
+                }
+#pragma unroll
+                for (int c = NC - 1; c >= 0; --c) {     // ranks from the right among the elements not above it
+                    const unsigned long long bb = __ballot(fb[c]);
+                    const unsigned long long gt_mask = lane == 63 ? 0ull : (~0ull << (lane + 1));
+                    rb[c] = nB + (uint32_t)__popcll(bb & gt_mask);
+                    nB += (uint32_t)__popcll(bb);
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const uint32_t i = lo + (uint32_t)lane + 64u * c;
+                    if (fa[c]) ipos[ra[c]] = (uint16_t)i;
+                    if (fb[c]) jpos[rb[c]] = (uint16_t)i;
+                }
+                __syncthreads();
+                uint32_t K = 0;                           // swaps: the pairs whose left element lies left of the right one (a prefix of the ranks)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const uint32_t i = lo + (uint32_t)lane + 64u * c;
+                    const bool sw = fa[c] && ra[c] < nB && i < (uint32_t)jpos[ra[c]];
+                    K += (uint32_t)__popcll(__ballot(sw));
+                }
+                const uint32_t iK = K < nA ? (uint32_t)ipos[K] : 0xFFFFFFFFu, jK1 = K > 0 ? (uint32_t)jpos[K - 1] : 0xFFFFFFFFu;
+                const long cut = (long)(iK < jK1 ? iK : jK1);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    if (fa[c] && ra[c] < K) a[jpos[ra[c]]] = v[c];
+                    if (fb[c] && rb[c] < K) a[ipos[rb[c]]] = v[c];
+                }
+                __syncthreads();
+                // the reference recurses into [cut, last) first and then loops on [first, cut): disjoint ranges, either order gives the same array
+                if (lane == 0) st[sp] = lsort::frame{(int)cut, (int)last, (int)depth};
+                ++sp;
+                last = cut;
+                __syncthreads();
+            }
+        }
+    }
+    // ---- std::__final_insertion_sort == a stable sort of what the loop left ----
+    uint64_t v[NC]; uint32_t rk[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const uint32_t i = (uint32_t)lane + 64u * c;
+        rk[c] = 0; v[c] = 0;
+        if (i < n) {
+            v[c] = a[i];
+            const uint64_t kx = AF_X(v[c]);
+            for (uint32_t k = 0; k < n; ++k) { const uint64_t kk = AF_X(a[k]); rk[c] += (kk < kx || (kk == kx && k < i)) ? 1u : 0u; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) if ((uint32_t)lane + 64u * c < n) a[rk[c]] = v[c];
+    __syncthreads();
+}
+
 // The whole wave: anchors -> chains (chain.hpp:221-438) over the wave's LDS arrays.  The sorts are the libstdc++ emulation where
 // ties exist (one lane; short arrays by stable rank); the chaining DP and the backtracking run one lane per RUN of anchors: a run
 // is a maximal stretch of the sorted anchors whose consecutive reference ends are at most max_dist_x apart, pairs from different
@@ -190,8 +291,17 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
     const int lane = threadIdx.x;
     // ---- std::sort of the anchors by reference end (chain.hpp:246) ----
     AF_STAMP(s0);
-    if (na <= 16) af_small_sort(L.anch, na, [](const uint64_t& a, const uint64_t& b) { return AF_X(a) < AF_X(b); }, lane);
-    else { if (lane == 0) lsort::sort(L.anch, (long)na, [](const uint64_t& a, const uint64_t& b) { return AF_X(a) < AF_X(b); }, L.stack); __syncthreads(); }
+#if defined(AF_PROFILE) || defined(AF_CUTS)
+    if (G.dbg & 32) { /* timing experiment: the anchors stay unsorted */ } else
+#endif
+    if (G.dbg & 64) {          // MONI_AF_DBG=64 (any build): the serial form, for cross-checking the wave's
+        if (na <= 16) af_small_sort(L.anch, na, [](const uint64_t& a, const uint64_t& b) { return AF_X(a) < AF_X(b); }, lane);
+        else { if (lane == 0) lsort::sort(L.anch, (long)na, [](const uint64_t& a, const uint64_t& b) { return AF_X(a) < AF_X(b); }, L.stack); __syncthreads(); }
+    } else {
+        af_wave_sort_anchors<(WT::MA + 63) / 64>(L.anch, na, L.stack, L.run_start, reinterpret_cast<uint16_t*>(L.p), lane);
+        for (uint32_t i = lane; i < na; i += 64) L.p[i] = 0;        // (scratch of the sort)
+        __syncthreads();
+    }
     AF_STAMP(s1); AF_PROF(G, 5, s0, s1);
     // ---- runs ----
     uint32_t n_runs = 0;
@@ -204,6 +314,9 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
     }
     if (lane == 0) L.run_start[n_runs] = (uint16_t)na;
     __syncthreads();
+#if defined(AF_PROFILE) || defined(AF_CUTS)
+    if (G.dbg & 128) return AF_ST_UNALIGNED;          // timing experiment: stop after the sort
+#endif
     // ---- chaining DP (chain.hpp:278-362), one lane per run ----
     for (uint32_t k = lane; k < n_runs; k += 64) {
         const uint32_t fb = L.run_start[k], fe = L.run_start[k + 1];
@@ -247,6 +360,9 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
     }
     __syncthreads();
     AF_STAMP(s2); AF_PROF(G, 6, s1, s2);
+#if defined(AF_PROFILE) || defined(AF_CUTS)
+    if (G.dbg & 256) return AF_ST_UNALIGNED;          // ... after the chaining DP
+#endif
     // ---- chain ends and starts (chain.hpp:115-164) ----
     for (uint32_t i = lane; i < na; i += 64) L.t[i] = 0;
     __syncthreads();
@@ -281,6 +397,9 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
         for (int q = 0; q < (WT::MC + 63) / 64; ++q) if ((uint32_t)lane + 64u * q < ns) L.starts[rk[q]] = v[q];
         __syncthreads();
     }
+#if defined(AF_PROFILE) || defined(AF_CUTS)
+    if (G.dbg & 512) return AF_ST_UNALIGNED;          // ... after the chain starts
+#endif
     // ---- backtracking (chain.hpp:166-200), one lane per run, every lane over the sorted starts of its run in order ----
     for (uint32_t i = lane; i < na; i += 64) L.t[i] = 0;
     __syncthreads();
@@ -518,11 +637,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         }
         __syncthreads();
         AF_STAMP(c1); AF_PROF(G, 0, c0, c1);
+#if defined(AF_PROFILE) || defined(AF_CUTS)
+        if (G.dbg & 4) na = 0;                                   // timing experiments (results are wrong): stop after the anchors ...
+#endif
         if (!fallback && !too_big && na > 0) {
             status = af_chain(G, L, na, avg);
             status = (uint32_t)__shfl((int)status, 0);
             __syncthreads();
             AF_STAMP(c2); AF_PROF(G, 1, c1, c2);
+#if defined(AF_PROFILE) || defined(AF_CUTS)
+            if ((G.dbg & 8) && status == AF_ST_CAND) status = AF_ST_UNALIGNED;      // ... after the chains ...
+#endif
             if (status == 0xFFu) too_big = true;
             else if (status == AF_ST_CAND) {
                 // check_left_MEM's coordinate of every chain: index(lift(leftmost anchor)).second + 1 (aligner_ksw2.hpp:565-576)
@@ -534,6 +659,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
                 }
                 __syncthreads();
                 AF_STAMP(c3); AF_PROF(G, 2, c2, c3);
+#if defined(AF_PROFILE) || defined(AF_CUTS)
+                if (G.dbg & 16) { if (lane == 0) L.status_sh = AF_ST_UNALIGNED; } else      // ... after the lifts
+#endif
                 if (lane == 0) L.status_sh = af_plan_cands(G, L, off, m);
                 __syncthreads();
                 AF_STAMP(c4); AF_PROF(G, 3, c3, c4);
@@ -549,21 +677,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         // ---- the read's tasks go to the batch's list and the bins of their tile / query length; the plan goes to HBM ----
         af_plan_t& PL = L.plan;
         const uint32_t nt = status == AF_ST_CAND ? L.n_tasks : 0u;
-        uint32_t t0 = 0;
-        if (lane == 0 && nt) t0 = atomicAdd(&G.ctr[AFC_TASKS], nt);
-        t0 = (uint32_t)__shfl((int)t0, 0);
-        if (nt && t0 + nt > G.task_cap) { status = AF_ST_FALLBACK; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CAPACITY], 1u); }
+        const uint32_t t0 = r_in * AF_MAX_TASKS_READ;                 // the read's own slots (bin_tasks_kernel queues them)
         if (status == AF_ST_CAND) {
-            if ((uint32_t)lane < nt) {
-                const moni_dp_task_t t = L.tasks[lane];
-                G.tasks[t0 + lane] = t;
-                const uint32_t bin = af_bin_of(t.qlen, t.tlen);
-                const uint32_t at = atomicAdd(&G.ctr[AFC_BINS + bin], 1u);
-                G.bin_q[(size_t)bin * G.bin_cap + at] = t0 + lane;        // bin_cap == task_cap: cannot overflow
-                G.task_pos[t0 + lane] = at | (bin << 26);
-            }
+            if ((uint32_t)lane < nt) G.tasks[t0 + lane] = L.tasks[lane];
             if ((uint32_t)lane < PL.n_cand) PL.cand[lane].task0 += t0;
         }
+        if (lane == 0) G.ntasks[r_in] = (uint8_t)nt;
         if (lane == 0) {
             if (status != AF_ST_CAND) { PL.n_cand = 0; PL.n_chains = 0; }
             PL.status = (uint8_t)status; PL.final_cand = 0; PL.n_alt = 0; PL.pad = 0; PL.score2 = 0; PL.ref_pos = PL.ref_len = 0; PL.tb0 = 0; PL.pad2 = 0;
@@ -582,6 +701,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     }
 }
 
+// bin_tasks_kernel: the reads' DP problems go to the queues of their tile / query-length bins.  A block takes 8 reads (their 8 x 32 task
+// slots, one thread each), counts per bin in LDS and bumps every bin's global counter once: a few thousand atomics per address and
+// launch where one per task was the bound of chain_plan_kernel.
+__global__ void __launch_bounds__(256) bin_tasks_kernel(const af_args_t G) {
+    __shared__ uint32_t cnt[AF_NBIN], base[AF_NBIN], ovf[8];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n_reads = G.A.n_reads;
+    if (blockIdx.x == 0 && tid == 0) G.ctr[AFC_TASKS] = (uint32_t)n_reads * AF_MAX_TASKS_READ;      // the global problems (global_task_kernel) come after the slots
+    if (tid < AF_NBIN) cnt[tid] = 0;
+    if (tid < 8) ovf[tid] = 0;
+    __syncthreads();
+    const uint64_t r_in = (uint64_t)blockIdx.x * 8 + (tid >> 5);
+    const uint32_t k = tid & 31u;
+    const bool valid = r_in < n_reads && k < (uint32_t)G.ntasks[r_in];
+    const uint32_t id = (uint32_t)r_in * AF_MAX_TASKS_READ + k;
+    uint32_t bin = 0, local = 0;
+    if (valid) { const moni_dp_task_t t = G.tasks[id]; bin = af_bin_of(t.qlen, t.tlen); local = atomicAdd(&cnt[bin], 1u); }
+    __syncthreads();
+    if (tid < AF_NBIN && cnt[tid]) base[tid] = atomicAdd(&G.ctr[AFC_BINS + tid], cnt[tid]);
+    if (tid == 0) { uint32_t n = 0; for (uint32_t b = 0; b < AF_NBIN; ++b) n += cnt[b]; if (n) atomicAdd(&G.ctr[AFC_NT], n); }
+    __syncthreads();
+    if (valid) {
+        const uint32_t at = base[bin] + local;
+        if (at < G.bin_cap) { G.bin_q[(size_t)bin * G.bin_cap + at] = id; G.task_pos[id] = at | (bin << 26); }
+        else ovf[tid >> 5] = 1;                      // the queue is full: the read goes to align_kernel
+    }
+    __syncthreads();
+    if (tid < 8 && ovf[tid]) {
+        const uint64_t rr = (uint64_t)blockIdx.x * 8 + tid;
+        G.plans[rr].status = AF_ST_FALLBACK;
+        G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)(G.A.read_lo + rr);
+        atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CAPACITY], 1u);
+    }
+}
+
 // 64-task chunks of a group of bins with the offsets of their direction bytes (one thread; a few thousand chunks).  Runs once for
 // the extension / gap problems (groups large and small) and once more, after global_task_kernel, for the global problems.
 __global__ void af_chunk_kernel(const af_args_t G, const uint32_t first_group, const uint32_t last_group) {
@@ -594,7 +748,7 @@ __global__ void af_chunk_kernel(const af_args_t G, const uint32_t first_group, c
         const uint32_t b0 = grp == AF_GRP_LARGE ? 0u : grp == AF_GRP_SMALL ? AF_BIN_SMALL : AF_BIN_GLOBAL, b1 = grp == AF_GRP_LARGE ? 16u : grp == AF_GRP_SMALL ? 17u : 33u;
         const uint32_t nc0 = nc;
         for (uint32_t bin = b1; bin-- > b0;) {          // longest queries first: the persistent DP waves take chunks in this order, the short ones fill the tail
-            const uint32_t cnt = G.ctr[AFC_BINS + bin];
+            const uint32_t cnt = G.ctr[AFC_BINS + bin] < G.bin_cap ? G.ctr[AFC_BINS + bin] : G.bin_cap;      // (a bin beyond its queue: bin_tasks_kernel sent the reads to align_kernel)
             const uint32_t qhi = grp == AF_GRP_SMALL ? AF_TS : ((bin - b0) + 1) * 16, tb = grp == AF_GRP_SMALL ? AF_TS : grp == AF_GRP_GLOBAL ? AF_GBLK : AF_BLK, np = grp == AF_GRP_GLOBAL ? AF_GPASS : grp == AF_GRP_LARGE ? AF_LPASS : 1;
             for (uint32_t s = 0; s < cnt; s += 128) {          // 128 problems: two per lane of the DP wave
                 if (nc >= G.chunk_cap) break;

@@ -127,9 +127,9 @@ struct moni_ctx {
     DBuf<dp_big_t> dp_big;
     DBuf<uint8_t> dp_dir_big;
     struct AfSet {          // device buffers of the staged align kernels (align_fast.hip), one set per launch stream
-        DBuf<af_plan_t> plans; DBuf<moni_dp_task_t> tasks; DBuf<af_res_t> res; DBuf<uint32_t> bin_q, task_pos, tb_task, fb_list, big_list, ctr;
+        DBuf<af_plan_t> plans; DBuf<moni_dp_task_t> tasks; DBuf<af_res_t> res; DBuf<uint32_t> bin_q, task_pos, tb_task, fb_list, big_list, ctr; DBuf<uint8_t> ntasks;
         DBuf<af_chunk_t> chunks; DBuf<uint8_t> dirs, fin; DBuf<af_tb_t> tb; DBuf<uint64_t> bnd; DBuf<unsigned long long> prof, txt_cur;
-        void release() { bnd.release(); prof.release(); big_list.release(); txt_cur.release(); plans.release(); tasks.release(); res.release(); bin_q.release(); task_pos.release(); tb_task.release(); fb_list.release(); ctr.release();
+        void release() { ntasks.release(); bnd.release(); prof.release(); big_list.release(); txt_cur.release(); plans.release(); tasks.release(); res.release(); bin_q.release(); task_pos.release(); tb_task.release(); fb_list.release(); ctr.release();
                          chunks.release(); dirs.release(); fin.release(); tb.release(); }
     } af[AK_NSET];
     HBuf<uint32_t> af_ctr_host;             // counters of the last batch's launches (64 words per sub-batch), pinned
@@ -1039,6 +1039,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             (rc = c->h_cig.ensure(cig_per * n_sub + 1)) || (rc = c->h_alt.ensure(alt_per * n_sub + 1)) || (rc = c->h_md.ensure(md_per * n_sub + 1)) || (rc = c->ak_minscore.ensure(msc.size())) ||
             (rc = c->ak_cursors.ensure(AK_CUR * n_sub + AK_CUR)))
             return rc;
+        // task slots: AF_MAX_TASKS_READ per read (each read's problems at its own place) + the global problems; bin queues: as many entries as problems are expected
+        const uint32_t af_slot_cap = (uint32_t)std::min<uint64_t>((uint64_t)AF_MAX_TASKS_READ * sub_reads + 4 * sub_reads + 4096, 0xFFFFFFF0ull);
         const uint32_t af_task_cap = (uint32_t)std::min<uint64_t>(12 * sub_reads + 4096, (1ull << 26) - 1), af_tb_cap = (uint32_t)std::min<uint64_t>(4 * sub_reads + 1024, 0x7FFFFFFFull);
         const uint32_t af_chunk_cap = af_task_cap / 64 + 2 * AF_NBIN;
         const uint64_t af_dirs_cap = 32768ull * sub_reads + (16ull << 20);      // direction bits: half a byte per DP cell, ~10 KB per 150 bp read on the bench; a chunk that does not fit sends its reads to align_kernel
@@ -1057,8 +1059,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         if (inorder) { HIPCHK(hipMemsetAsync(c->ak_dev_sum.p, 0, (160 * n_sub + 8) * sizeof(unsigned long long), c->stream)); memset(c->h_sum.p, 0, (4 * n_sub + 4) * sizeof(unsigned long long)); }
         if (use_fast) for (int x = 0; x < (int)std::min<uint64_t>(n_sub, AK_NSET); ++x) {
             moni_ctx::AfSet& S = c->af[x];
-            if ((rc = S.plans.ensure(sub_reads + 1)) || (rc = S.tasks.ensure(af_task_cap)) || (rc = S.res.ensure(af_task_cap)) || (rc = S.bin_q.ensure((size_t)AF_NBIN * af_task_cap)) ||
-                (rc = S.task_pos.ensure(af_task_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.fb_list.ensure(sub_reads + 1)) || (rc = S.big_list.ensure(sub_reads + 1)) ||
+            if ((rc = S.plans.ensure(sub_reads + 1)) || (rc = S.tasks.ensure(af_slot_cap)) || (rc = S.res.ensure(af_slot_cap)) || (rc = S.ntasks.ensure(sub_reads + 8)) || (rc = S.bin_q.ensure((size_t)AF_NBIN * af_task_cap)) ||
+                (rc = S.task_pos.ensure(af_slot_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.fb_list.ensure(sub_reads + 1)) || (rc = S.big_list.ensure(sub_reads + 1)) ||
                 (rc = S.ctr.ensure(AF_NCTR)) || (rc = S.txt_cur.ensure(AF_TXT_SHARDS * 8)) || (rc = S.bnd.ensure((size_t)af_dp_grid * AF_QCAP * 64)) || (rc = S.chunks.ensure(af_chunk_cap)) || (rc = S.dirs.ensure(af_dirs_cap)) || (rc = S.fin.ensure((size_t)af_fin_grid * 64 * sizeof(af_fin_t))))
                 return rc;
         }
@@ -1247,7 +1249,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 af_args_t G;
                 memset(&G, 0, sizeof G);
                 G.A = A;
-                G.plans = S.plans.p; G.tasks = S.tasks.p; G.task_cap = af_task_cap; G.res = S.res.p; G.bin_q = S.bin_q.p; G.bin_cap = af_task_cap; G.task_pos = S.task_pos.p;
+                G.plans = S.plans.p; G.tasks = S.tasks.p; G.task_cap = af_slot_cap; G.ntasks = S.ntasks.p; G.res = S.res.p; G.bin_q = S.bin_q.p; G.bin_cap = af_task_cap; G.task_pos = S.task_pos.p;
                 G.chunks = S.chunks.p; G.chunk_cap = af_chunk_cap; G.dirs = S.dirs.p; G.dirs_cap = af_dirs_cap; G.tb_task = S.tb_task.p; G.tb = S.tb.p; G.tb_cap = af_tb_cap;
                 G.fb_list = S.fb_list.p; G.big_list = S.big_list.p; G.fin_scratch = S.fin.p; G.fin_stride = sizeof(af_fin_t); G.ctr = S.ctr.p;
                 G.bnd = S.bnd.p;
@@ -1259,6 +1261,10 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 G.prof = S.prof.p;
                 if (const char* v = getenv("MONI_AF_DBG")) G.dbg = (uint32_t)atoi(v);
 #endif
+#ifdef AF_CUTS
+                if (const char* v = getenv("MONI_AF_DBG")) G.dbg = (uint32_t)atoi(v);
+#endif
+                if (const char* v = getenv("MONI_AF_DBG")) G.dbg |= (uint32_t)atoi(v) & 64u;          // 64: the serial anchor sort (cross-check), any build
                 HIPCHK(hipMemsetAsync(S.ctr.p, 0, AF_NCTR * sizeof(uint32_t), sx));
                 {
                     static const int k1occ = getenv("MONI_AF_K1OCC") ? atoi(getenv("MONI_AF_K1OCC")) : 8;      // 8 waves/SIMD: 32 reads in flight per CU (4.9 KB of LDS each); measured 5, 6, 8
@@ -1269,6 +1275,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                     else hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 6>), g1, dim3(64), 0, sx, G);
                 }
                 hipLaunchKernelGGL((chain_plan_kernel<af_wave_t, true>), dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 10)), dim3(64), 0, sx, G);
+                hipLaunchKernelGGL(bin_tasks_kernel, dim3((unsigned)((nr + 7) / 8)), dim3(256), 0, sx, G);
                 HIPCHK(hipEventRecord(c->af_ev[3 * k], sx));
                 hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_SMALL);
                 hipLaunchKernelGGL((dp_lane_kernel<AF_BLK, AF_QCAP, AF_LPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE);
@@ -1335,9 +1342,9 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 if (use_fast) {         // the staged kernels' own counters
                     const uint32_t* fc = c->af_ctr_host.p + AF_NCTR * k;
                     unsigned long long cells, rb; memcpy(&cells, fc + AFC_CELLS, 8); memcpy(&rb, fc + AFC_RBYTES, 8);
-                    st.dp_tasks += fc[AFC_TASKS]; st.dp_cells += cells; st.kernel_fallback += fc[AFC_FALLBACK]; st.dp_ref_bytes += rb;
+                    st.dp_tasks += fc[AFC_NT] + (fc[AFC_TASKS] >= (uint32_t)(sub_lo[k + 1] - sub_lo[k]) * AF_MAX_TASKS_READ ? fc[AFC_TASKS] - (uint32_t)(sub_lo[k + 1] - sub_lo[k]) * AF_MAX_TASKS_READ : 0u); st.dp_cells += cells; st.kernel_fallback += fc[AFC_FALLBACK]; st.dp_ref_bytes += rb;
                     if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "  staged kernels, sub-batch %llu: %u DP tasks, %llu cells, %u traced, %u large + %u small + %u global chunks, %u reads to align_kernel%s\n",
-                                                           (unsigned long long)k, fc[AFC_TASKS], cells, fc[AFC_TRACED], fc[AFC_NCHUNKS], fc[AFC_NCHUNKS + 1], fc[AFC_NCHUNKS + 2], fc[AFC_FALLBACK], fc[AFC_DIRS_OVF] ? " (direction bytes overflowed)" : "");
+                                                           (unsigned long long)k, fc[AFC_NT], cells, fc[AFC_TRACED], fc[AFC_NCHUNKS], fc[AFC_NCHUNKS + 1], fc[AFC_NCHUNKS + 2], fc[AFC_FALLBACK], fc[AFC_DIRS_OVF] ? " (direction bytes overflowed)" : "");
                     if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "    handed over because: long read %u, anchors/seeds %u, chains %u, chains to score %u, chain length %u, DP size %u, overlapping anchors %u, wildcard %u, "
                                                            "loop depends on a score %u, extension short of the query end %u, capacity %u, CIGAR %u\n",
                                                            fc[AFC_WHY + 0], fc[AFC_WHY + 1], fc[AFC_WHY + 2], fc[AFC_WHY + 3], fc[AFC_WHY + 4], fc[AFC_WHY + 5], fc[AFC_WHY + 6], fc[AFC_WHY + 7], fc[AFC_WHY + 8], fc[AFC_WHY + 9], fc[AFC_WHY + 10], fc[AFC_WHY + 11]);

@@ -190,9 +190,10 @@ __device__ __forceinline__ void af_small_sort(T* a, uint32_t n, Less less, int l
 //     stable rank;
 //   * the depth-limit fallback (heap sort of a range) stays serial: it needs 2 * log2(n) unlucky partitions in a row.
 // NC: elements per lane (n <= 64 * NC).  ipos / jpos: scratch of n entries each.
-template <int NC>
-__device__ __forceinline__ void af_wave_sort_anchors(uint64_t* a, uint32_t n, lsort::frame* st, uint16_t* ipos, uint16_t* jpos, int lane) {
-    auto less = [](const uint64_t& x, const uint64_t& y) { return AF_X(x) < AF_X(y); };
+// key(x): the integer the elements are ordered by (ascending).
+template <int NC, class T, class Key>
+__device__ __forceinline__ void af_wave_sort(T* a, uint32_t n, lsort::frame* st, uint16_t* ipos, uint16_t* jpos, int lane, Key key) {
+    auto less = [&](const T& x, const T& y) { return key(x) < key(y); };
     const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     if (n > 16) {
         int lg = 0;
@@ -212,15 +213,15 @@ __device__ __forceinline__ void af_wave_sort_anchors(uint64_t* a, uint32_t n, ls
                 if (lane == 0) lsort::move_median_to_first(a, first, first + 1, mid, last - 1, less);
                 __syncthreads();
                 // ---- unguarded_partition(a, first + 1, last, first) ----
-                const uint64_t pk = AF_X(a[first]);
+                const auto pk = key(a[first]);
                 const uint32_t lo = (uint32_t)first + 1, hi = (uint32_t)last;
-                uint64_t v[NC]; bool fa[NC], fb[NC]; uint32_t ra[NC], rb[NC];
+                T v[NC]; bool fa[NC], fb[NC]; uint32_t ra[NC], rb[NC];
                 uint32_t nA = 0, nB = 0;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {          // ranks from the left among the elements not below the pivot
                     const uint32_t i = lo + (uint32_t)lane + 64u * c;
-                    fa[c] = fb[c] = false; v[c] = 0;
-                    if (i < hi) { v[c] = a[i]; const uint64_t k = AF_X(v[c]); fa[c] = !(k < pk); fb[c] = !(pk < k); }
+                    fa[c] = fb[c] = false;
+                    if (i < hi) { v[c] = a[i]; const auto k = key(v[c]); fa[c] = !(k < pk); fb[c] = !(pk < k); }
                     const unsigned long long ba = __ballot(fa[c]);
                     ra[c] = nA + (uint32_t)__popcll(ba & lt_mask);
                     nA += (uint32_t)__popcll(ba);
@@ -263,15 +264,15 @@ __device__ __forceinline__ void af_wave_sort_anchors(uint64_t* a, uint32_t n, ls
         }
     }
     // ---- std::__final_insertion_sort == a stable sort of what the loop left ----
-    uint64_t v[NC]; uint32_t rk[NC];
+    T v[NC]; uint32_t rk[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const uint32_t i = (uint32_t)lane + 64u * c;
-        rk[c] = 0; v[c] = 0;
+        rk[c] = 0;
         if (i < n) {
             v[c] = a[i];
-            const uint64_t kx = AF_X(v[c]);
-            for (uint32_t k = 0; k < n; ++k) { const uint64_t kk = AF_X(a[k]); rk[c] += (kk < kx || (kk == kx && k < i)) ? 1u : 0u; }
+            const auto kx = key(v[c]);
+            for (uint32_t k = 0; k < n; ++k) { const auto kk = key(a[k]); rk[c] += (kk < kx || (kk == kx && k < i)) ? 1u : 0u; }
         }
     }
     __syncthreads();
@@ -298,7 +299,7 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
         if (na <= 16) af_small_sort(L.anch, na, [](const uint64_t& a, const uint64_t& b) { return AF_X(a) < AF_X(b); }, lane);
         else { if (lane == 0) lsort::sort(L.anch, (long)na, [](const uint64_t& a, const uint64_t& b) { return AF_X(a) < AF_X(b); }, L.stack); __syncthreads(); }
     } else {
-        af_wave_sort_anchors<(WT::MA + 63) / 64>(L.anch, na, L.stack, L.run_start, reinterpret_cast<uint16_t*>(L.p), lane);
+        af_wave_sort<(WT::MA + 63) / 64>(L.anch, na, L.stack, L.run_start, reinterpret_cast<uint16_t*>(L.p), lane, [](const uint64_t& x) { return AF_X(x); });
         for (uint32_t i = lane; i < na; i += 64) L.p[i] = 0;        // (scratch of the sort)
         __syncthreads();
     }
@@ -421,6 +422,9 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
         }
     }
     __syncthreads();
+#if defined(AF_PROFILE) || defined(AF_CUTS)
+    if (G.dbg & 1024) return AF_ST_UNALIGNED;         // ... after the backtracking
+#endif
     uint32_t n_chains = 0;
     for (uint32_t s0 = 0; s0 < ns; s0 += 64) {
         const uint32_t sx = s0 + lane;
@@ -435,8 +439,11 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
     }
     __syncthreads();
     // std::sort of the chains by score (chain.hpp:402): ties
-    if (n_chains <= 16) af_small_sort(L.chains, n_chains, [](const af_chain_t& x, const af_chain_t& y) { return x.score > y.score; }, lane);
-    else { if (lane == 0) lsort::sort(L.chains, (long)n_chains, [](const af_chain_t& x, const af_chain_t& y) { return x.score > y.score; }, L.stack); __syncthreads(); }
+    if (G.dbg & 64) {
+        if (n_chains <= 16) af_small_sort(L.chains, n_chains, [](const af_chain_t& x, const af_chain_t& y) { return x.score > y.score; }, lane);
+        else { if (lane == 0) lsort::sort(L.chains, (long)n_chains, [](const af_chain_t& x, const af_chain_t& y) { return x.score > y.score; }, L.stack); __syncthreads(); }
+    } else          // by the whole wave (run_start and p are free again: scratch)
+        af_wave_sort<(WT::MC + 63) / 64>(L.chains, n_chains, L.stack, L.run_start, reinterpret_cast<uint16_t*>(L.p), lane, [](const af_chain_t& x) { return -(int64_t)x.score; });
     if (lane == 0) L.n_chains_sh = n_chains;
     __syncthreads();
     AF_STAMP(s3); AF_PROF(G, 7, s2, s3);

@@ -76,7 +76,7 @@ struct af_cand_t {               // one chain the selection loop scores (in loop
 struct af_plan_t {
     uint8_t status, n_cand; uint16_t n_chains;
     int32_t min_score;
-    uint8_t final_cand, n_alt; uint16_t pad;
+    uint8_t final_cand, n_alt; uint16_t pad;      // pad: strand of the final chain | its traced problems << 8 (select_kernel)
     int32_t score2;
     uint64_t ref_pos, ref_len;   // window of the final chain
     uint32_t tb0, pad2;          // first traced problem of the final chain: [left ext][right ext][gap fills]
@@ -1194,6 +1194,7 @@ __global__ void __launch_bounds__(256) select_kernel(const af_args_t G) {
         }
         af_window(C, m, lc_t, rc_t, PL.ref_pos, PL.ref_len);
         const uint32_t n_tb = C.overlap ? 1u : (uint32_t)C.has_lc + C.has_rc + C.n_gap_tasks;
+        PL.pad = (uint16_t)(C.strand | (n_tb << 8));          // finish_wave_kernel starts its fetches from the plan's header alone
         if (!fallback && n_tb) {
             const uint32_t tb0 = atomicAdd(&G.ctr[AFC_TRACED], n_tb);
             if (tb0 + n_tb > G.tb_cap) { fallback = true; why = AF_WHY_CAPACITY; }
@@ -1416,6 +1417,11 @@ __device__ __forceinline__ int afs_md(const af_args_t& G, af_finw_t& L, const ui
     return NM;
 }
 
+#if defined(AF_CUTS)
+#define AFW_CUT(bit) if (G.dbg & (bit)) { if (lane == 0) { moni_aln_rec_t rc_; memset(&rc_, 0, sizeof rc_); A.recs[r_in] = rc_; if (A.dev_len) { A.dev_len[r_in] = 0; A.dev_off[r_in] = 0; } } continue; }
+#else
+#define AFW_CUT(bit)
+#endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) finish_wave_kernel(const af_args_t G) {
     __shared__ af_finw_t L;
     const int lane = threadIdx.x;
@@ -1431,10 +1437,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
     uint32_t* const tbs = reinterpret_cast<uint32_t*>(L.line);       // staged traceback records: the line buffer is free until the line is rendered
 #define TB(k) (*reinterpret_cast<const af_tb_t*>(tbs + (k) * AFW_TB_WORDS))
 #define NAME_LEN(sid) (names_lds ? (uint32_t)(L.name_off[(sid) + 1] - L.name_off[sid]) : F.sname_off[(sid) + 1] - F.sname_off[sid])
-    for (uint64_t r_in = blockIdx.x; r_in < A.n_reads; r_in += gridDim.x) {
+    // the plan's 40-byte header (status, final chain, strand, traced problems, window) says where everything else is: it is read with
+    // one round trip, the next read's while this one is worked on
+    uint64_t h0 = 0, h1 = 0, h2 = 0, h4 = 0, g0 = 0, g1 = 0, g2 = 0, g4 = 0;
+    if (blockIdx.x < A.n_reads) { const uint64_t* H = reinterpret_cast<const uint64_t*>(&G.plans[blockIdx.x]); h0 = H[0]; h1 = H[1]; h2 = H[2]; h4 = H[4]; }
+    for (uint64_t r_in = blockIdx.x; r_in < A.n_reads; r_in += gridDim.x, h0 = g0, h1 = g1, h2 = g2, h4 = g4) {
+        if (r_in + gridDim.x < A.n_reads) { const uint64_t* H = reinterpret_cast<const uint64_t*>(&G.plans[r_in + gridDim.x]); g0 = H[0]; g1 = H[1]; g2 = H[2]; g4 = H[4]; }
         af_plan_t& PL = G.plans[r_in];
-        const uint32_t st = PL.status;
+        const uint32_t st = (uint32_t)(h0 & 0xFFu);
         if (st == AF_ST_FALLBACK) continue;
+        const uint32_t h_final = (uint32_t)(h1 & 0xFFu), h_nalt = (uint32_t)((h1 >> 8) & 0xFFu), h_strand = (uint32_t)((h1 >> 16) & 0xFFu), h_ntb = (uint32_t)((h1 >> 24) & 0xFFu);
+        const int32_t h_score2 = (int32_t)(uint32_t)(h1 >> 32);
+        const uint32_t h_tb0 = (uint32_t)h4;
         const uint64_t r = A.read_lo + r_in;
         const uint64_t off = A.offs[r];
         const uint32_t m = (uint32_t)(A.offs[r + 1] - off);
@@ -1443,31 +1457,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         AF_STAMP(fw0);
         // where the alignment starts in the lift tables: these dependent loads (directory, sequence record, first run) are started before the
         // staging below instead of inside lane 0's serial section
-        const uint64_t aln_pos = aligned ? PL.ref_pos : 0ull;
+        const uint64_t aln_pos = aligned ? h2 : 0ull;
         uint32_t hint0 = 0xFFFFFFFFu;
         const uint32_t sid0 = aligned ? ac_seq_of(A.P, aln_pos, &hint0) : 0u;
         moni_lift_seq_t LS0; LS0.second = 0; LS0.run_off = 0; LS0.n_runs = 0; LS0.start = 0; LS0.end = 0;
         if (aligned) LS0 = A.P.lift_seqs[sid0];
         // the final chain's record, the alternatives and (below) its traceback records come with one round trip each instead of field by field
         if (aligned) {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(&PL.cand[PL.final_cand]);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&PL.cand[h_final]);
             uint32_t* dst = reinterpret_cast<uint32_t*>(&L.cand);
             for (uint32_t w = lane; w < sizeof(af_cand_t) / 4; w += 64) dst[w] = src[w];
-            if (lane < AF_MAX_CAND) { L.alt_pos[lane] = PL.alt_pos[lane]; L.alt_score[lane] = PL.alt_score[lane]; }
+            if (lane < AF_MAX_CAND) L.alt_score[lane] = PL.alt_score[lane];
         }
-        __syncthreads();
         const af_cand_t* C = aligned ? &L.cand : nullptr;
-        const uint32_t strand = aligned ? C->strand : 0u;
-        const uint32_t n_alt = aligned ? PL.n_alt : 0u;
+        const uint32_t strand = aligned ? h_strand : 0u;
+        const uint32_t n_alt = aligned ? h_nalt : 0u;
         if (aligned) {
-            const uint32_t tb0 = PL.tb0;
-            const uint32_t n_tb = C->overlap ? 1u : (uint32_t)C->has_lc + C->has_rc + C->n_gap_tasks;      // as select_kernel counted them
-            for (uint32_t w = lane; w < n_tb * AFW_TB_WORDS; w += 64) {
+            for (uint32_t w = lane; w < h_ntb * AFW_TB_WORDS; w += 64) {
                 const uint32_t k = w / AFW_TB_WORDS, x = w % AFW_TB_WORDS;
-                tbs[w] = reinterpret_cast<const uint32_t*>(&G.tb[tb0 + k])[x];
+                tbs[w] = reinterpret_cast<const uint32_t*>(&G.tb[h_tb0 + k])[x];
             }
             if ((uint32_t)lane < n_alt) {       // the alternatives' sequences and 1-based positions: one lane each
-                const uint64_t ap = L.alt_pos[lane];
+                const uint64_t ap = PL.alt_pos[lane];
                 const uint32_t s2 = ac_seq_of(A.P, ap);
                 L.alt_sid[lane] = s2; L.alt_p1[lane] = (uint32_t)(ap - A.P.lift_seqs[s2].start + 1);
             }
@@ -1517,9 +1528,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         }
         __syncthreads();
         AF_STAMP(fw1); AF_PROF(G, 16, fw0, fw1);
+        AFW_CUT(2048)          // timing experiment: stop after staging, stitching, lifting
         if (aligned) { ovf = L.ovf != 0; lifted = ((uint64_t)(uint32_t)__shfl((int)(lifted >> 32), 0) << 32) | (uint32_t)__shfl((int)(lifted & 0xFFFFFFFFull), 0); }
         moni_aln_rec_t rec;
-        rec.status = aligned ? 1u : 0u; rec.strand = strand; rec.ref_pos = aligned ? PL.ref_pos : 0; rec.score = aligned ? C->score : 0; rec.score2 = aligned ? PL.score2 : 0;
+        rec.status = aligned ? 1u : 0u; rec.strand = strand; rec.ref_pos = aligned ? aln_pos : 0; rec.score = aligned ? C->score : 0; rec.score2 = aligned ? h_score2 : 0;
         rec.n_cigar = 0; rec.n_alt = 0; rec.cigar_off = 0; rec.alt_off = 0; rec.nm = 0; rec.md_len = 0; rec.md_off = 0; rec.txt_len = 0; rec.lift_nm = 0; rec.txt_off = 0;
         bool to_host = (aligned && ovf) || m > AF_MAX_READ;       // more CIGAR operations than the staging holds (align_kernel runs beside this kernel, its list is closed)
         if (aligned && ovf && lane == 0) atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CIGAR], 1u);
@@ -1531,7 +1543,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             uint32_t n_md = 0, sid = 0, lsid = 0;
             bool mapped = false;
             const uint32_t n_cig = aligned ? L.n_cig : 0u, n_lcig = aligned ? L.n_lcig : 0u;
-            const int32_t score = aligned ? C->score : 0, score2 = aligned ? PL.score2 : 0;
+            const int32_t score = aligned ? C->score : 0, score2 = aligned ? h_score2 : 0;
             if (aligned) {
                 uint64_t ref_len = 0;
                 for (uint32_t k = 0; k < n_lcig; ++k) { const int op = L.lcig[k] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += L.lcig[k] >> 4; }
@@ -1557,7 +1569,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
                         mapq = (int)__dadd_rn(__dmul_rn((double)mapq, 1.), .499);
                     }
                 }
-                bool same = n_lcig == n_cig && lifted == PL.ref_pos;
+                bool same = n_lcig == n_cig && lifted == aln_pos;
                 for (uint32_t k = 0; same && k < n_cig; ++k) same = L.lcig[k] == L.cig[k];
                 uint32_t dummy = 0;
                 // the two reference windows (lifted, and on the pangenome text) go to LDS with one round trip: the MD walks read them there
@@ -1575,6 +1587,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             }
             __syncthreads();
             AF_STAMP(fw2); AF_PROF(G, 17, fw1, fw2);
+            AFW_CUT(4096)      // ... after MD / NM / MAPQ
             // ---- the segments of the line (sam.hpp:144-188), lane 0 ----
             if (lane == 0 && !to_host) {
                 uint32_t n = 0, q = 0;
@@ -1624,6 +1637,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             }
             __syncthreads();
             AF_STAMP(fw3); AF_PROF(G, 18, fw2, fw3);
+            AFW_CUT(8192)      // ... after the segment list
             const uint32_t n_seg = to_host ? 0u : L.n_seg;
             p = to_host ? 0u : L.total;
             if (!to_host && (n_seg > AFS_MAXSEG || p > AFS_LINE)) { to_host = true; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CAPACITY], 1u); }

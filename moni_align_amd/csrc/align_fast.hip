@@ -743,31 +743,53 @@ __global__ void __launch_bounds__(256) bin_tasks_kernel(const af_args_t G) {
     }
 }
 
-// 64-task chunks of a group of bins with the offsets of their direction bytes (one thread; a few thousand chunks).  Runs once for
-// the extension / gap problems (groups large and small) and once more, after global_task_kernel, for the global problems.
-__global__ void af_chunk_kernel(const af_args_t G, const uint32_t first_group, const uint32_t last_group) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// 128-task chunks of a group of bins with the offsets of their direction bits (one wavefront: a lane per bin for the sizes, a prefix
+// sum, then the lanes write the few thousand chunk records side by side).  Runs once for the extension / gap problems (groups large
+// and small) and once more, after global_task_kernel, for the global problems.  Longest queries first: the persistent DP waves take
+// chunks in this order, the short ones fill the tail.
+__global__ void __launch_bounds__(64) af_chunk_kernel(const af_args_t G, const uint32_t first_group, const uint32_t last_group) {
+    __shared__ uint32_t s_cnt[32], s_cbase[33], s_qhi[32], s_bin[32];
+    __shared__ uint64_t s_dbase[32], s_bytes[32];
+    const int lane = threadIdx.x;
+    if (blockIdx.x != 0) return;
     uint32_t nc = 0;
     for (uint32_t g = 0; g < first_group; ++g) nc += G.ctr[AFC_NCHUNKS + g];
     uint64_t doff;
     memcpy(&doff, &G.ctr[AFC_DIROFF], 8);
     for (uint32_t grp = first_group; grp <= last_group; ++grp) {
         const uint32_t b0 = grp == AF_GRP_LARGE ? 0u : grp == AF_GRP_SMALL ? AF_BIN_SMALL : AF_BIN_GLOBAL, b1 = grp == AF_GRP_LARGE ? 16u : grp == AF_GRP_SMALL ? 17u : 33u;
-        const uint32_t nc0 = nc;
-        for (uint32_t bin = b1; bin-- > b0;) {          // longest queries first: the persistent DP waves take chunks in this order, the short ones fill the tail
-            const uint32_t cnt = G.ctr[AFC_BINS + bin] < G.bin_cap ? G.ctr[AFC_BINS + bin] : G.bin_cap;      // (a bin beyond its queue: bin_tasks_kernel sent the reads to align_kernel)
-            const uint32_t qhi = grp == AF_GRP_SMALL ? AF_TS : ((bin - b0) + 1) * 16, tb = grp == AF_GRP_SMALL ? AF_TS : grp == AF_GRP_GLOBAL ? AF_GBLK : AF_BLK, np = grp == AF_GRP_GLOBAL ? AF_GPASS : grp == AF_GRP_LARGE ? AF_LPASS : 1;
-            for (uint32_t s = 0; s < cnt; s += 128) {          // 128 problems: two per lane of the DP wave
-                if (nc >= G.chunk_cap) break;
-                const uint64_t bytes = (uint64_t)np * qhi * tb * 64;          // half a byte per cell
-                af_chunk_t c; c.bin = bin; c.start = s; c.n = cnt - s < 128 ? cnt - s : 128; c.qhi = qhi;
-                if (doff + bytes > G.dirs_cap) { c.dir_off = ~0ull; G.ctr[AFC_DIRS_OVF] = 1; } else { c.dir_off = doff; doff += bytes; }
-                G.chunks[nc++] = c;
-            }
+        const uint32_t nb = b1 - b0;                     // <= 16
+        const uint32_t tb = grp == AF_GRP_SMALL ? AF_TS : grp == AF_GRP_GLOBAL ? AF_GBLK : AF_BLK, np = grp == AF_GRP_GLOBAL ? AF_GPASS : grp == AF_GRP_LARGE ? AF_LPASS : 1;
+        uint32_t cnt = 0, nch = 0, qhi = 0, bin = 0; uint64_t bytes = 0;
+        if ((uint32_t)lane < nb) {
+            bin = b1 - 1 - (uint32_t)lane;
+            cnt = G.ctr[AFC_BINS + bin] < G.bin_cap ? G.ctr[AFC_BINS + bin] : G.bin_cap;      // (a bin beyond its queue: bin_tasks_kernel sent the reads to align_kernel)
+            nch = (cnt + 127) >> 7;
+            qhi = grp == AF_GRP_SMALL ? AF_TS : ((bin - b0) + 1) * 16;
+            bytes = (uint64_t)np * qhi * tb * 64;          // of one chunk: half a byte per cell
         }
-        G.ctr[AFC_NCHUNKS + grp] = nc - nc0;
+        uint32_t cb = nch; uint64_t db = (uint64_t)nch * bytes;          // inclusive prefix sums over the lanes
+        for (int o = 1; o < 32; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)cb, o); const uint64_t y = __shfl_up(db, o); if (lane >= o) { cb += x; db += y; } }
+        if ((uint32_t)lane < nb) { s_cnt[lane] = cnt; s_qhi[lane] = qhi; s_bin[lane] = bin; s_bytes[lane] = bytes; s_cbase[lane] = cb - nch; s_dbase[lane] = db - (uint64_t)nch * bytes; }
+        uint32_t total = (uint32_t)__shfl((int)cb, (int)nb - 1);
+        const uint64_t total_bytes = __shfl(db, (int)nb - 1);
+        if (lane == 0) s_cbase[nb] = total;
+        __syncthreads();
+        if (nc + total > G.chunk_cap) total = G.chunk_cap > nc ? G.chunk_cap - nc : 0;      // (cannot happen: the cap counts a chunk per 64 queue entries)
+        for (uint32_t c = lane; c < total; c += 64) {
+            uint32_t l = 0;
+            while (l + 1 < nb && s_cbase[l + 1] <= c) ++l;
+            const uint32_t j = c - s_cbase[l];
+            af_chunk_t ch; ch.bin = s_bin[l]; ch.start = j * 128u; ch.n = s_cnt[l] - j * 128u < 128u ? s_cnt[l] - j * 128u : 128u; ch.qhi = s_qhi[l];
+            const uint64_t at = doff + s_dbase[l] + (uint64_t)j * s_bytes[l];
+            if (at + s_bytes[l] > G.dirs_cap) { ch.dir_off = ~0ull; G.ctr[AFC_DIRS_OVF] = 1; } else ch.dir_off = at;
+            G.chunks[nc + c] = ch;
+        }
+        if (lane == 0) G.ctr[AFC_NCHUNKS + grp] = total;
+        nc += total; doff += total_bytes;
+        __syncthreads();
     }
-    memcpy(&G.ctr[AFC_DIROFF], &doff, 8);
+    if (lane == 0) memcpy(&G.ctr[AFC_DIROFF], &doff, 8);
 }
 
 // A lane's operand bytes come as aligned 8-byte words (one request per eight bases instead of one per base: with 64 lanes on 64
@@ -999,7 +1021,7 @@ __device__ __forceinline__ af_dirs_t af_dir_of(const af_args_t& G, uint32_t bin,
     const uint32_t b1 = grp == AF_GRP_LARGE ? 16u : grp == AF_GRP_SMALL ? 17u : 33u;
     uint32_t ci = 0;
     for (uint32_t g = 0; g < grp; ++g) ci += G.ctr[AFC_NCHUNKS + g];
-    for (uint32_t b2 = bin + 1; b2 < b1; ++b2) ci += (G.ctr[AFC_BINS + b2] + 127) >> 7;        // chunks are laid out from the group's last bin down
+    for (uint32_t b2 = bin + 1; b2 < b1; ++b2) ci += ((G.ctr[AFC_BINS + b2] < G.bin_cap ? G.ctr[AFC_BINS + b2] : G.bin_cap) + 127) >> 7;        // chunks are laid out from the group's last bin down
     ci += pos_in_bin >> 7;
     const af_chunk_t ch = G.chunks[ci];
     af_dirs_t X;
@@ -1486,6 +1508,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         // ---- the read in alignment orientation ----
         for (uint32_t k = lane; k < m && k < AF_MAX_READ; k += 64) L.seq[k] = strand ? ak_compl(A.D.reads[off + m - 1 - k]) : A.D.reads[off + k];
         __syncthreads();
+        AFW_CUT(16384)         // timing experiment: stop after the staging
         bool ovf = false;
         uint64_t lifted = 0;
         if (aligned && lane == 0) {
@@ -1515,6 +1538,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             }
 #undef PUSH
 #undef PUSH_MERGE_FIRST
+#if defined(AF_CUTS)
+            if (G.dbg & 32768) { L.n_cig = n; L.n_lcig = 0; L.ovf = 1; } else {      // timing experiment: no lift
+#endif
             // ---- the alignment lifted to the reference contig (aligner_ksw2.hpp:3133-3160) ----
             const moni_lift_seq_t LS = LS0;
             const moni_lift_run_t* __restrict__ runs = A.P.lift_runs + LS.run_off;
@@ -1525,6 +1551,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             if (nl < 0) ovf = true;
             lifted = LS.second + (ovf ? 0ull : lp);
             L.n_cig = n; L.n_lcig = nl < 0 ? 0u : (uint32_t)nl; L.ovf = ovf ? 1u : 0u;
+#if defined(AF_CUTS)
+            }
+#endif
         }
         __syncthreads();
         AF_STAMP(fw1); AF_PROF(G, 16, fw0, fw1);

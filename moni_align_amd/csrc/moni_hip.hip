@@ -1049,7 +1049,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         // in-order text on the GPU: when the caller takes the context-owned buffer and the kernels spell the text, every sub-batch's lines are
         // put in read order on the device and arrive with one transfer; the host threads are needed only for sub-batches with hand-backs
         const bool inorder = use_fast && gpu_text && ctx_out && force_back == 0 && getenv("MONI_ALIGN_HOST_ORDER") == nullptr;
-        if (inorder && ((rc = c->ak_block.ensure(txt_per * n_sub + 8)) || (rc = c->ak_dev_len.ensure(NR + n_sub + 8)) || (rc = c->ak_dev_off.ensure(NR + n_sub + 8)) ||
+        if (inorder && ((rc = c->ak_recs.ensure(NR + 1)) || (rc = c->ak_block.ensure(txt_per * n_sub + 8)) || (rc = c->ak_dev_len.ensure(NR + n_sub + 8)) || (rc = c->ak_dev_off.ensure(NR + n_sub + 8)) ||
                         (rc = c->ak_dev_pos.ensure(NR + 2 * n_sub + 8)) || (rc = c->ak_dev_sum.ensure(160 * n_sub + 8)) || (rc = c->h_sum.ensure(4 * n_sub + 4)))) return rc;
         size_t gather_tmp_bytes = 0;
         if (inorder) {
@@ -1087,6 +1087,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             const double f0 = mh::now_s();
             HIPCHK(hipEventSynchronize(c->ak_done[k]));
             const double f1 = mh::now_s();
+            if (inorder && nr) { HIPCHK(hipMemcpyAsync(c->h_recs.p + r0, c->ak_recs.p + r0, nr * sizeof(moni_aln_rec_t), hipMemcpyDeviceToHost, c->copy_stream)); HIPCHK(hipStreamSynchronize(c->copy_stream)); }
             R.recs = c->h_recs.p + r0; R.cig = c->h_cig.p + k * cig_per; R.alt = c->h_alt.p + k * alt_per; R.md = c->h_md.p + k * md_per; R.nr = nr;
             if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "  sub-batch %llu: waited for the launch from %.1f to %.1f ms\n", (unsigned long long)k, (f0 - t_enter) * 1e3, (f1 - t_enter) * 1e3);
             if (force_back) for (uint64_t r = 0; r < nr; ++r) if ((r0 + r) % force_back == 0) R.recs[r].status = 2;
@@ -1231,7 +1232,9 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             if (pipelined) { A.mems = c->mems.p + SL.mem_at(); A.occs = c->occs.p + SL.occ_base; A.read_mem_off = c->read_mem_off.p + k; }      // the slice's arrays, indexed by the batch's read numbers
             A.min_score_of_len = c->ak_minscore.p; A.max_len = (uint32_t)c->max_len + 1; A.read_lo = r0; A.n_reads = nr;
             A.slots = c->ak_slots.p + (k % AK_NSET) * ak_waves * AK_NL; A.waves = c->ak_waves.p + (k % AK_NSET) * ak_waves;
-            A.recs = c->h_recs.p + r0; A.cig_pool = c->h_cig.p + k * cig_per; A.cig_cap = cig_per; A.alt_pool = c->h_alt.p + k * alt_per;
+            // records: pinned host memory when host threads read them behind every launch; with the lines ordered on the GPU they are read only
+            // when a sub-batch has hand-backs, and stay in HBM until then (80 bytes per read over PCIe were what finish_wave_kernel waited for)
+            A.recs = (inorder ? c->ak_recs.p : c->h_recs.p) + r0; A.cig_pool = c->h_cig.p + k * cig_per; A.cig_cap = cig_per; A.alt_pool = c->h_alt.p + k * alt_per;
             A.alt_cap = alt_per; A.md_pool = c->h_md.p + k * md_per; A.md_cap = md_per; A.cursors = c->ak_cursors.p + AK_CUR * k;
             if (gpu_text) {
                 A.fmt.rnames = c->ak_rnames.p; A.fmt.rname_off = c->ak_rname_off.p; A.fmt.quals = quals ? c->ak_quals.p : nullptr;
@@ -1294,7 +1297,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 HIPCHK(hipStreamWaitEvent(sf, c->af_ev[3 * k + 2], 0));
                 hipLaunchKernelGGL(align_kernel, dim3((unsigned)ak_waves), dim3(64), 0, sf, A);
                 // the record and the SAM line of every read that stayed on the staged path: one wave per read when the kernel spells the text
-                if (gpu_text) hipLaunchKernelGGL(finish_wave_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 24)), dim3(64), 0, sx, G);
+                static const int fin_mult = getenv("MONI_AF_FINGRID") ? atoi(getenv("MONI_AF_FINGRID")) : 96;          // blocks per CU: 4x what is resident (24 by LDS), so that the strided share of a block is short and the tail even (measured 24 .. 768)
+                if (gpu_text) hipLaunchKernelGGL(finish_wave_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * fin_mult)), dim3(64), 0, sx, G);
                 else hipLaunchKernelGGL(finish_kernel, dim3((unsigned)std::min<uint64_t>((nr + 63) / 64, af_fin_grid)), dim3(64), 0, sx, G);
                 HIPCHK(hipEventRecord(c->ak_fin[k], sx));
                 HIPCHK(hipStreamWaitEvent(sf, c->ak_fin[k], 0));

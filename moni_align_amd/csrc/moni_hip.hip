@@ -110,6 +110,7 @@ struct moni_ctx {
     unsigned long long* d_counters = nullptr;   // 4
     uint64_t n_mems = 0, n_occs = 0;
     float ms_accum[7] = {0, 0, 0, 0, 0, 0, 0}; unsigned long long ctr_accum[4] = {0, 0, 0, 0}; bool accum_valid = false;      // pipelined seeding: sums over the slices
+    uint32_t dirs_scale = 1;                                   // direction-bit budget multiplier (doubles after a batch that overflowed it)
     double est_mems_per_read = 6, est_occs_per_read = 80;      // sizes the per-MEM buffers of a pipelined batch (updated by every batch)
     uint32_t tmp_cap = 16;
     uint32_t pool_rows = 4096;
@@ -1043,7 +1044,13 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         const uint32_t af_slot_cap = (uint32_t)std::min<uint64_t>((uint64_t)AF_MAX_TASKS_READ * sub_reads + 4 * sub_reads + 4096, 0xFFFFFFF0ull);
         const uint32_t af_task_cap = (uint32_t)std::min<uint64_t>(12 * sub_reads + 4096, (1ull << 26) - 1), af_tb_cap = (uint32_t)std::min<uint64_t>(4 * sub_reads + 1024, 0x7FFFFFFFull);
         const uint32_t af_chunk_cap = af_task_cap / 64 + 2 * AF_NBIN;
-        const uint64_t af_dirs_cap = 32768ull * sub_reads + (16ull << 20);      // direction bits: half a byte per DP cell, ~10 KB per 150 bp read on the bench; a chunk that does not fit sends its reads to align_kernel
+        // direction bits: half a byte per DP cell.  ~10 KB per 150 bp read on the bench; DP cells grow with the square of the read length (250 bp:
+        // ~90 KB with the global realignments); a chunk that does not fit sends its reads to align_kernel, and a batch in which that happened
+        // doubles the budget of the next ones
+        uint64_t dirs_per_read = 32768;
+        { const double f = (double)c->max_len / 150.0; if (f > 1.0) dirs_per_read = (uint64_t)(32768.0 * f * f); }
+        dirs_per_read = std::min<uint64_t>(dirs_per_read * c->dirs_scale, 1ull << 20);
+        const uint64_t af_dirs_cap = dirs_per_read * sub_reads + (16ull << 20);
         const unsigned af_dp_grid = (unsigned)n_cu * 12;
         const unsigned af_fin_grid = (unsigned)std::min<uint64_t>((sub_reads + 63) / 64, (uint64_t)n_cu * 16);
         // in-order text on the GPU: when the caller takes the context-owned buffer and the kernels spell the text, every sub-batch's lines are
@@ -1330,6 +1337,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         if (rc_host) { for (int x = 0; x < AK_NSET; ++x) { (void)hipStreamSynchronize(c->ak_stream[x]); if (c->fb_stream[x]) (void)hipStreamSynchronize(c->fb_stream[x]); } drop_abuf(); return rc_host; }
         t_mark[2] = mh::now_s() - t_enter;
         st.dp_rounds = n_sub;          // align_kernel launches
+        bool any_dirs_ovf_batch = false;
         if (n_sub) {        // statistics of all launches, once the GPU is idle
             std::vector<unsigned long long> cur(AK_CUR * n_sub);
             HIPCHK(hipMemcpy(cur.data(), c->ak_cursors.p, cur.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1346,6 +1354,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 if (use_fast) {         // the staged kernels' own counters
                     const uint32_t* fc = c->af_ctr_host.p + AF_NCTR * k;
                     unsigned long long cells, rb; memcpy(&cells, fc + AFC_CELLS, 8); memcpy(&rb, fc + AFC_RBYTES, 8);
+                    any_dirs_ovf_batch = any_dirs_ovf_batch || fc[AFC_DIRS_OVF] != 0;
                     st.dp_tasks += fc[AFC_NT] + (fc[AFC_TASKS] >= (uint32_t)(sub_lo[k + 1] - sub_lo[k]) * AF_MAX_TASKS_READ ? fc[AFC_TASKS] - (uint32_t)(sub_lo[k + 1] - sub_lo[k]) * AF_MAX_TASKS_READ : 0u); st.dp_cells += cells; st.kernel_fallback += fc[AFC_FALLBACK]; st.dp_ref_bytes += rb;
                     if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "  staged kernels, sub-batch %llu: %u DP tasks, %llu cells, %u traced, %u large + %u small + %u global chunks, %u reads to align_kernel%s\n",
                                                            (unsigned long long)k, fc[AFC_NT], cells, fc[AFC_TRACED], fc[AFC_NCHUNKS], fc[AFC_NCHUNKS + 1], fc[AFC_NCHUNKS + 2], fc[AFC_FALLBACK], fc[AFC_DIRS_OVF] ? " (direction bytes overflowed)" : "");
@@ -1358,6 +1367,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 for (int x = 0; x < 7; ++x) cyc[x] += (double)q[24 + x];
             }
         }
+        if (any_dirs_ovf_batch && c->dirs_scale < 16) c->dirs_scale *= 2;
 #ifdef AF_PROFILE
         if (use_fast && n_sub) { unsigned long long pf[32]; for (int x = 0; x < (int)std::min<uint64_t>(n_sub, AK_NSET); ++x) { HIPCHK(hipMemcpy(pf, c->af[x].prof.p, sizeof pf, hipMemcpyDeviceToHost));
             fprintf(stderr, "chain_plan_kernel wave cycles (set %d): load+filter+anchors %.3g, chain %.3g (sort %.3g, dp %.3g, ends+backtrack %.3g), lifts %.3g, plan %.3g, whole read %.3g\n", x,

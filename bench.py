@@ -223,8 +223,9 @@ def main():
                        "reads_per_gpu": n_mine, "read_len": L, "parallelism": "reads sharded x%d, index replicated" % world},
             "roofline": {"bound": "hbm", "kernel": "ms_lf_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_static_from": "profiles/traffic_ms_lf.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this kernel: 29.06 GB per launch "
-                                                "for 47.18 GB algorithmic, i.e. 0.45 of the HBM peak as counted traffic; not measured in this run)",
+                         "traffic_static_from": "profiles/r02y/pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of this workload, profiles/run_r02.sh: "
+                                                "26.66 GB fetched + 2.40 GB written = 29.06 GB per launch of 1 M reads for 47.18 GB algorithmic, i.e. 0.44 of the HBM peak as "
+                                                "counted traffic; counters cannot be read inside this run, so `traffic` stays null)",
                          "algorithmic_bytes_per_launch": ms_bytes, "avg_launch_ms": kern[0], "per_read_bytes": ms_bytes / max(1, n_mine),
                          "layout_model": {"bytes_per_launch": layout_bytes, "GB/s": layout_bytes / ms_s / 1e9 if ms_s > 0 else None,
                                           "frac": layout_bytes / ms_s / 1e9 / HBM_PEAK_GBS if ms_s > 0 else None,

@@ -536,7 +536,7 @@ struct aligner {
     // aligner_ksw2.hpp:2018-2098
     score_t chain_score(const std::vector<size_t>& chain, const std::vector<std::pair<size_t, size_t>>& anchors,
                         const std::vector<mem_t>& mems, const int32_t min_score, const read_t* read, const bool score_only = true,
-                        const int32_t score2 = 0, const uint8_t strand = 0, sam_t* sam = nullptr) {
+                        const int32_t score2 = 0, const uint8_t strand = 0, sam_t* sam = nullptr, const int32_t sub_n = 0, const double frac_rep = 0) {
         std::vector<std::pair<size_t, size_t>> chain_anchors(chain.size());
         for (size_t i = 0; i < chain_anchors.size(); ++i) chain_anchors[i] = anchors[chain[i]];
         size_t lcs_len = mems[chain_anchors[0].first].idx;
@@ -553,7 +553,7 @@ struct aligner {
             sam->flag = (strand ? 16 : 0);
             sam->zs = score2;
             sam->mapq = compute_mapq_se_bwa(sam->as, sam->zs, sam->rlen, read->seq.size(), cfg.min_len, cfg.smatch, cfg.smismatch,
-                                            mapq_coeff_len, mapq_coeff_fac, 0, 0, 0);
+                                            mapq_coeff_len, mapq_coeff_fac, sub_n, 0, frac_rep);
         }
         return score;
     }

@@ -1,0 +1,394 @@
+// oracle/ - CPU restatement of the reference algorithm; test infrastructure only (tests/, __graft_entry__.smoke(), bench.py's
+// cpu_baseline leg).  NOT linked into the product.
+//
+// align_pe.hpp: the PAIRED-END path of aligner<seed_finder_t> (include/aligner/aligner_ksw2.hpp) restated on top of align.hpp, as
+// groundwork for SURVEY.md 8(f)-2 (the product has no paired-end path yet).  Followed, in order:
+//   aligner_ksw2.hpp:598-700    orphan_paired_score_t / paired_score_t (operator> used by std::sort)
+//   aligner_ksw2.hpp:702-812    paired_alignment_t (min scores, remove_slash_mate, RNEXT)
+//   aligner_ksw2.hpp:816-885    learn_fragment_model (Welford, merged across batches)
+//   aligner_ksw2.hpp:888-918    align(kpbseq_t*) - with orphan recovery DISABLED (-u): orphan_recovery / fill_orphan need klib's
+//                               ksw_align (absent submodule) and are not restated; a pair that fails jointly is written as it stands
+//   aligner_ksw2.hpp:1000-1326  align(paired_alignment_t&, finalize): seeding of the four (mate, strand) patterns with r_offset,
+//                               direction filter, frequency filter, chaining, get_best_scores, final paired_chain_score
+//   aligner_ksw2.hpp:1329-1431  get_best_scores;  :1471-1534 check_paired_left_MEM;  :2115-2290 paired_chain_score
+//   mapq.hpp:186-223            compute_mapq_pe_bwa;  common/sam.hpp:126-142 remove_slash_mate
+//   align_reads_dispatcher.hpp:356-389  st_align's paired loop: learn on the first batches, then align them, then the rest
+// PARITY UNPINNED: nothing in the reference tree fixes paired-end output; -m (report_mems) for pairs and secondary_chains (-Z) are
+// not restated.  compute_frac_rep returns 0.0 in the reference (aligner_ksw2.hpp:1979-1981) and does here.
+#pragma once
+#include <mutex>
+
+#include "align.hpp"
+
+namespace oracle {
+
+#define ORC_RAW_MAPQ(diff, a) ((int)(6.02 * (diff) / (a) + .499))      // mapq.hpp:144
+
+// mapq.hpp:186-223
+inline size_t compute_mapq_pe_bwa(const int32_t score, const int32_t score2, const int32_t score_un, const int32_t match_score, const int32_t sub_n,
+                                  const double frac_rep_m1, const double frac_rep_m2, const int32_t score_m1, const int32_t score_m2,
+                                  const int32_t score2_m1, const int32_t score2_m2, size_t& mapq_m1, size_t& mapq_m2) {
+    int32_t mapq = 0;
+    int32_t sub = std::max(score2, score_un);
+    mapq = ORC_RAW_MAPQ(score - sub, match_score);
+    if (sub_n > 0) mapq -= (int)(4.343 * log(sub_n + 1) + .499);
+    if (mapq < 0) mapq = 0;
+    if (mapq > 60) mapq = 60;
+    mapq = (int)(mapq * (1. - .5 * (frac_rep_m1 + frac_rep_m2)) + .499);
+    if (score > score_un) {
+        // the reference mixes size_t and int32_t in these conditionals: the usual arithmetic conversions make every comparison unsigned
+        mapq_m1 = mapq_m1 > (size_t)mapq ? mapq_m1 : (size_t)mapq < mapq_m1 + 40 ? (size_t)mapq : mapq_m1 + 40;
+        mapq_m2 = mapq_m2 > (size_t)mapq ? mapq_m2 : (size_t)mapq < mapq_m2 + 40 ? (size_t)mapq : mapq_m2 + 40;
+        mapq_m1 = mapq_m1 < (size_t)ORC_RAW_MAPQ(score_m1 - score2_m1, match_score) ? mapq_m1 : (size_t)ORC_RAW_MAPQ(score_m1 - score2_m1, match_score);
+        mapq_m2 = mapq_m2 < (size_t)ORC_RAW_MAPQ(score_m2 - score2_m2, match_score) ? mapq_m2 : (size_t)ORC_RAW_MAPQ(score_m2 - score2_m2, match_score);
+    }
+    return mapq;
+}
+
+struct pe_config_t {               // aligner_ksw2.hpp:94-128 defaults
+    bool filter_dir = true;
+    double dir_thr = 50.0;
+    size_t ins_learning_n = 1000, ins_learning_score_gap_threshold = 0;
+};
+
+struct aligner_pe : aligner {
+    pe_config_t pe;
+    const int8_t max_penalty;      // aligner_ksw2.hpp:241: max(smatch + smismatch, gapo + gape)
+    // insert-size model (aligner_ksw2.hpp:3252-3262)
+    double ins_mean = 0.0, ins_std_dev = 0.0, ins_variance = 0.0, ins_sample_variance = 0.0, ins_m2 = 0.0;
+    size_t ins_count = 0;
+    bool ins_learning_complete = false;
+
+    aligner_pe(const FlatIndex& ix_, const align_config_t& c, const pe_config_t& p = pe_config_t())
+        : aligner(ix_, c), pe(p), max_penalty((int8_t)std::max(c.smatch + c.smismatch, c.gapo + c.gape)) {}
+
+    struct paired_score_t {        // aligner_ksw2.hpp:625-660
+        int32_t tot = 0;
+        int64_t dist = 0;
+        score_t m1, m2;
+        size_t chain_i = 0;
+        bool paired = false;
+    };
+    static bool ps_greater(const paired_score_t& lhs, const paired_score_t& rhs) {      // operator> (:649-654)
+        return (lhs.tot > rhs.tot) or (lhs.tot == rhs.tot and lhs.m1.lft > rhs.m1.lft) or
+               (lhs.tot == rhs.tot and lhs.m1.lft == rhs.m1.lft and lhs.m2.lft > rhs.m2.lft);
+    }
+
+    struct paired_alignment_t {    // aligner_ksw2.hpp:662-812
+        bool aligned = false, chained = false, best_score = false, second_best_score = false;
+        read_t mate1, mate2, mate1_rev, mate2_rev;          // copies: remove_slash_mate edits the names
+        sam_t sam_m1, sam_m2;
+        int32_t min_score_m1 = 0, min_score_m2 = 0, min_score = 0;
+        paired_score_t score;
+        int32_t score2 = 0, score2_m1 = 0, score2_m2 = 0;
+        float frac_rep_m1 = 0.0, frac_rep_m2 = 0.0;
+        int sub_n = 0;
+        float mean = 0.0, std_dev = 0.0;
+        size_t n_seeds_dir1 = 0, n_seeds_dir2 = 0, n_mems_dir1 = 0, n_mems_dir2 = 0;
+        double avg_seed_length_dir1 = 0.0, avg_seed_length_dir2 = 0.0, avg_w_seed_length_dir1 = 0.0, avg_w_seed_length_dir2 = 0.0;
+        double armonic_avg_seed_length_dir1 = 0.0, armonic_avg_seed_length_dir2 = 0.0;
+        std::vector<mem_t> mems;
+        std::vector<std::pair<size_t, size_t>> anchors;
+        std::vector<chain_t> chains;
+        std::vector<paired_score_t> best_scores;
+    };
+
+    static void remove_slash_mate(read_t& r) {             // common/sam.hpp:132-141
+        const size_t len = r.name.size();
+        if (len >= 2 and r.name[len - 2] == '/' and (r.name[len - 1] == '1' or r.name[len - 1] == '2')) r.name.resize(len - 2);
+    }
+    static read_t rc_copy(const read_t& r) {               // rc_copy_kseq_t, kpbseq.h:150-168
+        static unsigned char ctab[256]; static bool init = false;
+        if (!init) { for (int i = 0; i < 256; ++i) ctab[i] = (unsigned char)i; ctab['A'] = 'T'; ctab['C'] = 'G'; ctab['G'] = 'C'; ctab['T'] = 'A';
+                     ctab['a'] = 'T'; ctab['c'] = 'G'; ctab['g'] = 'C'; ctab['t'] = 'A'; init = true; }
+        read_t o; o.name = r.name; o.has_qual = r.has_qual;
+        const size_t l = r.seq.size();
+        o.seq.resize(l);
+        for (size_t i = 0; i < l; ++i) o.seq[i] = (char)ctab[(unsigned char)r.seq[l - i - 1]];
+        o.qual.assign(r.qual.rbegin(), r.qual.rend());
+        return o;
+    }
+    // paired_alignment_t::init (aligner_ksw2.hpp:748-779)
+    void init(paired_alignment_t& al, const read_t& m1, const read_t& m2, double mean_ = 0.0, double std_dev_ = 0.0) {
+        al.mate1 = m1; al.mate2 = m2;
+        al.min_score_m1 = 20 + 8 * log(al.mate1.seq.size());
+        al.min_score_m2 = 20 + 8 * log(al.mate2.seq.size());
+        al.min_score = al.min_score_m1 + al.min_score_m2;
+        al.mean = mean_; al.std_dev = std_dev_;
+        remove_slash_mate(al.mate1); remove_slash_mate(al.mate2);
+        al.mate1_rev = rc_copy(al.mate1); al.mate2_rev = rc_copy(al.mate2);
+        al.sam_m1.read = &al.mate1; al.sam_m2.read = &al.mate2;
+        if (al.mate1.name == al.mate2.name) { al.sam_m1.rnext = "="; al.sam_m2.rnext = "="; }
+        else { al.sam_m1.rnext = al.mate2.name; al.sam_m2.rnext = al.mate1.name; }
+    }
+
+    // aligner_ksw2.hpp:1471-1534.  A chain without anchors of one of the mates reads that mate's coordinate uninitialised in the
+    // reference; such a chain scores 0 in paired_chain_score whatever happens here, so the value (0) never reaches the output.
+    bool check_paired_left_MEM(std::vector<std::pair<size_t, size_t>>& m1_vec, std::vector<std::pair<size_t, size_t>>& m2_vec, paired_alignment_t& al, size_t i) {
+        auto& chain = al.chains[i];
+        chain.reverse();
+        size_t m1_ref = 0, m2_ref = 0;
+        for (size_t j = 0; j < chain.anchors.size(); ++j) {
+            const size_t a = chain.anchors[j];
+            if ((al.mems[al.anchors[a].first].mate & MATE_2) == 0) { m1_ref = ix.index(ix.lift(al.mems[al.anchors[a].first].occs[al.anchors[a].second])).second + 1; break; }
+        }
+        for (size_t j = 0; j < chain.anchors.size(); ++j) {
+            const size_t a = chain.anchors[j];
+            if ((al.mems[al.anchors[a].first].mate & MATE_2) != 0) { m2_ref = ix.index(ix.lift(al.mems[al.anchors[a].first].occs[al.anchors[a].second])).second + 1; break; }
+        }
+        bool discovered = false;
+        for (size_t j = 0; j < m1_vec.size(); ++j)
+            if ((ORC_DIST(m1_vec[j].first, m1_ref) < cfg.region_dist) and (ORC_DIST(m2_vec[j].first, m2_ref) < cfg.region_dist))
+                if (m1_vec[j].second == (size_t)al.chains[i].score) discovered = true;
+        chain.reset();
+        if (discovered) return true;
+        m1_vec.push_back(std::make_pair(m1_ref, (size_t)al.chains[i].score));
+        m2_vec.push_back(std::make_pair(m2_ref, (size_t)al.chains[i].score));
+        return false;
+    }
+
+    // the pairing term of aligner_ksw2.hpp:2176-2181 / 2193-2198
+    int32_t pair_total(const paired_score_t& s, const paired_alignment_t& al) const {
+        double ns = 0.0;
+        if (al.std_dev > 0.0) ns = (s.dist - al.mean) / al.std_dev;
+        int32_t tot = (int)(s.m1.score + s.m2.score + .721 * log(2. * erfc(fabs(ns) * M_SQRT1_2)) * cfg.smatch + .499);
+        if (tot < 0) tot = 0;
+        return tot;
+    }
+
+    // aligner_ksw2.hpp:2115-2290
+    paired_score_t paired_chain_score(paired_alignment_t& al, const size_t chain_i, const bool score_only = true) {
+        auto& chain = al.chains[chain_i];
+        chain.reverse();                                   // lazily, and left reversed (as in the reference)
+        const read_t* mate1; const read_t* mate2;
+        uint8_t strand = 0;
+        if ((chain.mate == 0) || ((chain.mate & MATE_RC) and (chain.mate & MATE_2))) { mate1 = &al.mate1; mate2 = &al.mate2_rev; }
+        else { mate1 = &al.mate1_rev; mate2 = &al.mate2; strand = 1; }
+        paired_score_t score;
+        score.chain_i = chain_i;
+        if (!chain.paired) return score;
+        std::vector<size_t> c1, c2;
+        for (size_t i = 0; i < chain.anchors.size(); ++i) {
+            const size_t a = chain.anchors[i];
+            if ((al.mems[al.anchors[a].first].mate & MATE_2) == 0) c1.push_back(a); else c2.push_back(a);
+        }
+        score.paired = chain.paired;
+        sam_t& sam_m1 = al.sam_m1; sam_t& sam_m2 = al.sam_m2;
+        if (score_only) {
+            score.m1 = chain_score(c1, al.anchors, al.mems, al.min_score_m1, mate1);
+            score.m2 = chain_score(c2, al.anchors, al.mems, al.min_score_m2, mate2);
+        } else {
+            score.m1 = chain_score(c1, al.anchors, al.mems, al.min_score_m1, mate1, false, al.score2_m1, strand, &sam_m1, al.sub_n, al.frac_rep_m1);
+            score.m2 = chain_score(c2, al.anchors, al.mems, al.min_score_m2, mate2, false, al.score2_m2, strand, &sam_m2, al.sub_n, al.frac_rep_m2);
+        }
+        score.dist = (int64_t)ORC_DIST(score.m2.pos, (score.m1.pos + mate1->seq.size()));
+        score.tot = pair_total(score, al);
+        score.m1.lft = ix.lift(score.m1.pos);
+        score.m2.lft = ix.lift(score.m2.pos);
+        if (score_only) return score;
+        sam_m1.read = mate1; sam_m2.read = mate2;
+        if (score.m1.score >= al.min_score_m1 && !score.m1.unmapped_lft && score.m2.score >= al.min_score_m2 && !score.m2.unmapped_lft) {
+            sam_m1.pnext = sam_m2.pos; sam_m2.pnext = sam_m1.pos;
+            ll tlen;
+            if (sam_m2.pos > sam_m1.pos) { tlen = (sam_m2.pos + mate2->seq.size()) - sam_m1.pos; sam_m1.tlen = tlen; sam_m2.tlen = -tlen; }
+            else { tlen = (sam_m1.pos + mate1->seq.size()) - sam_m2.pos; sam_m1.tlen = -tlen; sam_m2.tlen = tlen; }
+            const int32_t score_un = 0;
+            compute_mapq_pe_bwa(score.tot, al.score2, score_un, cfg.smatch, al.sub_n, al.frac_rep_m1, al.frac_rep_m2, score.m1.score, score.m2.score,
+                                al.score2_m1, al.score2_m2, sam_m1.mapq, sam_m2.mapq);
+            sam_m1.as = score.tot; sam_m2.as = score.tot;
+            sam_m1.zs = al.score2; sam_m2.zs = al.score2;
+            sam_m1.flag = sam_m2.flag = 1 | 2;                                  // SAM_PAIRED | SAM_MAPPED_PAIRED
+            if (strand) { sam_m1.flag |= 16 | 64; sam_m2.flag |= 32 | 128; }    // REVERSED | FIRST ; MATE_REVERSED | SECOND
+            else { sam_m1.flag |= 32 | 64; sam_m2.flag |= 16 | 128; }
+        } else if (score.m1.score >= al.min_score_m1 && !score.m1.unmapped_lft) {
+            sam_m1.zs = al.score2_m1;
+            sam_m1.flag = 1 | 8 | 64;                                           // PAIRED | MATE_UNMAPPED | FIRST
+            sam_m2.flag = 1 | 4 | 128;                                          // PAIRED | UNMAPPED | SECOND
+            if (strand) sam_m1.flag |= 16;
+            sam_m2.rname = sam_m1.rname; sam_m2.pos = sam_m1.pos; sam_m2.mapq = sam_m1.mapq; sam_m2.cigar = "*";
+            sam_m2.pnext = sam_m1.pnext = sam_m1.pos;
+            sam_m2.tlen = sam_m1.tlen = 0;
+        } else if (score.m2.score >= al.min_score_m2 && !score.m2.unmapped_lft) {
+            sam_m1.zs = al.score2_m2;                                           // sic (aligner_ksw2.hpp:2258)
+            sam_m1.flag = 1 | 4 | 64;
+            sam_m2.flag = 1 | 8 | 128;
+            if (not strand) sam_m2.flag |= 16;
+            sam_m1.rname = sam_m2.rname; sam_m1.pos = sam_m2.pos; sam_m1.mapq = sam_m2.mapq; sam_m1.cigar = "*";
+            sam_m1.pnext = sam_m2.pnext = sam_m2.pos;
+            sam_m1.tlen = sam_m2.tlen = 0;
+        } else {
+            sam_m1.flag = sam_m2.flag = 1 | 4 | 8;
+        }
+        return score;
+    }
+
+    // aligner_ksw2.hpp:1329-1431
+    void get_best_scores(paired_alignment_t& al, size_t k) {
+        std::set<size_t> different_scores;
+        size_t i = 0;
+        std::vector<std::pair<size_t, size_t>> m1_left, m2_left;
+        int32_t m1_max = 0, m2_max = 0;
+        std::vector<std::string> m1_h, m2_h; std::vector<size_t> m1_p, m1_s, m2_p, m2_s;
+        while (i < al.chains.size() and different_scores.size() < k) {
+            different_scores.insert(al.chains[i].score);
+            if (cfg.left_mem_check) {
+                if (check_paired_left_MEM(m1_left, m2_left, al, i)) { ++i; continue; }
+            }
+            if (different_scores.size() < k) {
+                paired_score_t score = paired_chain_score(al, i);
+                m1_max = check_max_score(m1_max, score.m1, m1_h, m1_p, m1_s);
+                m2_max = check_max_score(m2_max, score.m2, m2_h, m2_p, m2_s);
+                if (score.tot >= al.min_score) {
+                    bool replaced = false;
+                    for (size_t j = 0; j < al.best_scores.size(); ++j) {
+                        paired_score_t zero; zero.chain_i = i;
+                        if ((ORC_DIST(al.best_scores[j].m1.lft, score.m1.lft) < cfg.region_dist) and (ORC_DIST(al.best_scores[j].m2.lft, score.m2.lft) < cfg.region_dist)) {
+                            if (score.tot > al.best_scores[j].tot) {
+                                if (replaced) al.best_scores[j] = zero;
+                                else { al.best_scores[j] = score; replaced = true; }
+                            } else if (score.tot <= al.best_scores[j].tot) { j = al.best_scores.size(); replaced = true; }
+                        }
+                    }
+                    if (not replaced) al.best_scores.push_back(score);
+                }
+                ++i;
+            }
+        }
+        al.sam_m1.alt_haplotypes = m1_h; al.sam_m1.alt_pos = m1_p; al.sam_m1.alt_scores = m1_s;
+        al.sam_m2.alt_haplotypes = m2_h; al.sam_m2.alt_pos = m2_p; al.sam_m2.alt_scores = m2_s;
+        paired_score_t zero; zero.chain_i = al.chains.size();
+        while (al.best_scores.size() < 2) al.best_scores.push_back(zero);
+        std::sort(al.best_scores.begin(), al.best_scores.end(), ps_greater);
+        size_t j = 1;
+        al.sub_n = 0;
+        while (j < al.best_scores.size() and al.best_scores[j++].tot >= (al.best_scores[0].tot - max_penalty)) ++al.sub_n;
+        al.best_score = true;
+        al.score2 = al.best_scores[1].tot; al.score2_m1 = al.best_scores[1].m1.score; al.score2_m2 = al.best_scores[1].m2.score;
+        al.second_best_score = (al.score2 >= al.min_score);
+    }
+
+    // aligner_ksw2.hpp:1000-1326 (report_mems and secondary_chains not restated)
+    bool align(paired_alignment_t& al, bool finalize = true) {
+        const size_t l1 = al.mate1.seq.size(), l2 = al.mate2.seq.size();
+        if (pe.filter_dir) {
+            mem_finder.find_mems(al.mate1.seq.data(), l1, al.mems, 0, MATE_1 | MATE_F);
+            mem_finder.find_mems(al.mate2_rev.seq.data(), l2, al.mems, l1, MATE_2 | MATE_RC);
+            al.n_mems_dir1 = al.mems.size(); al.n_seeds_dir1 = 0;
+            mem_finder.find_mems(al.mate2.seq.data(), l2, al.mems, 0, MATE_2 | MATE_F);
+            mem_finder.find_mems(al.mate1_rev.seq.data(), l1, al.mems, l2, MATE_1 | MATE_RC);
+            al.n_mems_dir2 = al.mems.size() - al.n_mems_dir1; al.n_seeds_dir2 = 0;
+            mem_finder.populate_seeds(al.mems, cfg.report_mems);
+            // NB: populate_seeds appends the halves of long MEMs behind all four calls' MEMs; the direction statistics below run over
+            // the first n_mems_dir1 entries and "the rest", halves included, exactly as the reference's index arithmetic does
+            for (size_t i = 0; i < al.n_mems_dir1; ++i) {
+                al.n_seeds_dir1 += al.mems[i].occs.size();
+                al.avg_seed_length_dir1 += al.mems[i].len;
+                al.avg_w_seed_length_dir1 += al.mems[i].len * al.mems[i].occs.size();
+                al.armonic_avg_seed_length_dir1 += (double)l1 / (double)al.mems[i].len;
+            }
+            if (al.n_mems_dir1 > 0) { al.avg_seed_length_dir1 /= al.n_mems_dir1; al.avg_w_seed_length_dir1 /= al.n_seeds_dir1; al.armonic_avg_seed_length_dir1 = (double)al.n_mems_dir1 / al.armonic_avg_seed_length_dir1; }
+            for (size_t i = al.n_mems_dir1; i < al.mems.size(); ++i) {
+                al.n_seeds_dir2 += al.mems[i].occs.size();
+                al.avg_seed_length_dir2 += al.mems[i].len;
+                al.avg_w_seed_length_dir2 += al.mems[i].len * al.mems[i].occs.size();
+                al.armonic_avg_seed_length_dir2 += (double)l2 / (double)al.mems[i].len;
+            }
+            if (al.n_mems_dir2 > 0) { al.avg_seed_length_dir2 /= al.n_mems_dir2; al.avg_w_seed_length_dir2 /= al.n_seeds_dir2; al.armonic_avg_seed_length_dir2 = (double)al.n_mems_dir2 / al.armonic_avg_seed_length_dir2; }
+            if ((al.avg_seed_length_dir1 > al.avg_seed_length_dir2) and ((al.avg_seed_length_dir1 - al.avg_seed_length_dir2) > pe.dir_thr))
+                al.mems.erase(al.mems.begin() + al.n_mems_dir1, al.mems.end());
+            if ((al.avg_seed_length_dir2 > al.avg_seed_length_dir1) and ((al.avg_seed_length_dir2 - al.avg_seed_length_dir1) > pe.dir_thr))
+                al.mems.erase(al.mems.begin(), al.mems.begin() + al.n_mems_dir1);
+            if (cfg.filter_freq) seed_freq_filter(al.mems, cfg.freq_thr);
+        } else {
+            mem_finder.find_mems(al.mate1.seq.data(), l1, al.mems, 0, MATE_1 | MATE_F);
+            mem_finder.find_mems(al.mate1_rev.seq.data(), l1, al.mems, l2, MATE_1 | MATE_RC);
+            mem_finder.find_mems(al.mate2.seq.data(), l2, al.mems, 0, MATE_2 | MATE_F);
+            mem_finder.find_mems(al.mate2_rev.seq.data(), l2, al.mems, l1, MATE_2 | MATE_RC);
+            mem_finder.populate_seeds(al.mems, cfg.report_mems);
+            if (cfg.filter_freq) seed_freq_filter(al.mems, cfg.freq_thr);
+        }
+        al.frac_rep_m1 = 0.0; al.frac_rep_m2 = 0.0;                  // compute_frac_rep (aligner_ksw2.hpp:1973-1981) returns 0.0
+        al.chained = find_chains(al.mems, al.anchors, al.chains, cfg.chain);
+        if (not al.chained) return false;
+        get_best_scores(al, cfg.check_k);
+        auto& best = al.best_scores;
+        if (best[0].tot < al.min_score) {
+            al.sam_m1.alt_haplotypes.clear(); al.sam_m1.alt_pos.clear(); al.sam_m1.alt_scores.clear();
+            al.sam_m2.alt_haplotypes.clear(); al.sam_m2.alt_pos.clear(); al.sam_m2.alt_scores.clear();
+            return false;
+        }
+        if (finalize) {
+            al.score = paired_chain_score(al, best[0].chain_i, false);
+            al.aligned = (al.score.tot >= al.min_score);
+        } else al.aligned = (best[0].tot >= al.min_score);
+        return al.aligned;
+    }
+
+    // aligner_ksw2.hpp:816-885 (one thread: no mutex needed)
+    bool learn_fragment_model(const std::vector<read_t>& m1, const std::vector<read_t>& m2) {
+        size_t count = 0; double mean = 0.0, m2acc = 0.0;
+        for (size_t i = 0; i < m1.size(); ++i) {
+            paired_alignment_t al;
+            init(al, m1[i], m2[i]);
+            if (align(al, false) and ((not al.second_best_score) or ((size_t)(al.best_scores[0].tot - al.best_scores[1].tot) > pe.ins_learning_score_gap_threshold))) {
+                const double value = (double)(al.best_scores[0].dist);
+                const double delta = value - mean;
+                mean += delta / (++count);
+                m2acc += delta * (value - mean);
+            }
+        }
+        const double variance = m2acc / count;
+        const double std_dev = sqrt(variance);
+        if (not ins_learning_complete) {
+            if (ins_count > 0) {
+                const size_t t_count = ins_count + count;
+                const double delta = ins_mean - mean;
+                ins_m2 += m2acc + (delta * delta * ins_count * count) / t_count;
+                ins_mean = (ins_count * ins_mean + count * mean) / t_count;
+                ins_count = t_count;
+            } else { ins_mean = mean; ins_std_dev = std_dev; ins_m2 = m2acc; ins_count = count; }
+            ins_learning_complete = ins_learning_complete or (ins_count >= pe.ins_learning_n);
+            if (ins_learning_complete) { ins_variance = ins_m2 / ins_count; ins_sample_variance = ins_m2 / (ins_count - 1); ins_std_dev = sqrt(ins_variance); }
+        }
+        return ins_learning_complete;
+    }
+
+    // aligner_ksw2.hpp:888-918 with find_orphan == false: both records of every pair, in order
+    size_t align_batch(const std::vector<read_t>& m1, const std::vector<read_t>& m2, std::string& out) {
+        size_t aligned = 0;
+        for (size_t i = 0; i < m1.size(); ++i) {
+            paired_alignment_t al;
+            init(al, m1[i], m2[i]);
+            al.mean = ins_mean; al.std_dev = ins_std_dev;
+            align(al, true);
+            write_sam(out, al.sam_m1);
+            write_sam(out, al.sam_m2);
+            if (al.aligned) ++aligned;
+        }
+        return aligned;
+    }
+
+    // st_align's paired loop (align_reads_dispatcher.hpp:356-389): batches of b_size pairs; learn until the model is complete (or the input
+    // ends), align the batches read so far, then the rest
+    size_t align_all(const std::vector<read_t>& m1, const std::vector<read_t>& m2, size_t b_size, std::string& out) {
+        size_t at = 0;
+        std::vector<read_t> l1, l2;
+        while (at < m1.size()) {
+            const size_t e = std::min(m1.size(), at + b_size);
+            std::vector<read_t> b1(m1.begin() + at, m1.begin() + e), b2(m2.begin() + at, m2.begin() + e);
+            at = e;
+            l1.insert(l1.end(), b1.begin(), b1.end()); l2.insert(l2.end(), b2.begin(), b2.end());
+            if (learn_fragment_model(b1, b2)) break;
+        }
+        size_t aligned = align_batch(l1, l2, out);
+        while (at < m1.size()) {
+            const size_t e = std::min(m1.size(), at + b_size);
+            std::vector<read_t> b1(m1.begin() + at, m1.begin() + e), b2(m2.begin() + at, m2.begin() + e);
+            at = e;
+            aligned += align_batch(b1, b2, out);
+        }
+        return aligned;
+    }
+};
+
+}  // namespace oracle

@@ -5,6 +5,7 @@
 #include "seed.hpp"
 #include "ksw2.hpp"
 #include "align.hpp"
+#include "align_pe.hpp"
 
 #include <atomic>
 #include <chrono>
@@ -196,6 +197,32 @@ char* orc_align_batch(void* h, const uint8_t* seqs, const uint64_t* offsets, uin
     if (with_header) { aligner A(ix, cfg); all = A.sam_header(); }
     for (auto& p : parts) all += p;
     if (counters) for (int i = 0; i < 8; ++i) { counters[i] = 0; for (int t = 0; t < threads; ++t) counters[i] += cnt[t][i]; }
+    char* buf = (char*)malloc(all.size() + 1);
+    memcpy(buf, all.data(), all.size());
+    buf[all.size()] = 0;
+    *out_len = all.size();
+    return buf;
+}
+// Paired-end path (align_pe.hpp; orphan recovery off, i.e. the reference with -u), one thread, st_align's batch order: mate k of pair i is
+// read i of batch k.  out[0] = aligned pairs, out[1..4] = the learnt insert-size model (count, mean, std dev, complete).
+char* orc_align_pe(void* h, const uint8_t* seqs1, const uint64_t* off1, const uint8_t* seqs2, const uint64_t* off2, uint64_t n_pairs,
+                   const uint8_t* names1, const uint64_t* noff1, const uint8_t* names2, const uint64_t* noff2, const uint8_t* quals1,
+                   const uint8_t* quals2, uint64_t b_size, uint64_t* out_len, double* out) {
+    const FlatIndex& ix = *(FlatIndex*)h;
+    align_config_t cfg;
+    aligner_pe A(ix, cfg);
+    std::vector<read_t> m1(n_pairs), m2(n_pairs);
+    for (uint64_t i = 0; i < n_pairs; ++i) {
+        m1[i].name.assign((const char*)names1 + noff1[i], (const char*)names1 + noff1[i + 1]);
+        m2[i].name.assign((const char*)names2 + noff2[i], (const char*)names2 + noff2[i + 1]);
+        m1[i].seq.assign((const char*)seqs1 + off1[i], (const char*)seqs1 + off1[i + 1]);
+        m2[i].seq.assign((const char*)seqs2 + off2[i], (const char*)seqs2 + off2[i + 1]);
+        if (quals1) { m1[i].qual.assign((const char*)quals1 + off1[i], (const char*)quals1 + off1[i + 1]); m1[i].has_qual = true; }
+        if (quals2) { m2[i].qual.assign((const char*)quals2 + off2[i], (const char*)quals2 + off2[i + 1]); m2[i].has_qual = true; }
+    }
+    std::string all;
+    const size_t aligned = A.align_all(m1, m2, b_size ? b_size : 512, all);
+    if (out) { out[0] = (double)aligned; out[1] = (double)A.ins_count; out[2] = A.ins_mean; out[3] = A.ins_std_dev; out[4] = A.ins_learning_complete ? 1.0 : 0.0; }
     char* buf = (char*)malloc(all.size() + 1);
     memcpy(buf, all.data(), all.size());
     buf[all.size()] = 0;

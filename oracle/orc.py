@@ -54,6 +54,8 @@ def lib():
         L.orc_seed_n_occs.argtypes = [ctypes.c_void_p]
         L.orc_seed_get.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.orc_seed_free.argtypes = [ctypes.c_void_p]
+        L.orc_align_pe.restype = ctypes.c_void_p
+        L.orc_align_pe.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_uint64] + [ctypes.c_void_p] * 6 + [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]
         L.orc_align_batch.restype = ctypes.c_void_p
         L.orc_align_batch.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint64] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int,
                                                                                                      ctypes.c_void_p, ctypes.c_void_p]
@@ -182,6 +184,27 @@ def align_batch(oidx: "OracleIndex", seqs: np.ndarray, offsets: np.ndarray, name
         lib().orc_free(p)
     keys = ["lf_steps", "jumps", "phi_steps", "text_cmp", "dp_cells", "dp_calls", "ref_bytes", "aligned"]
     return sam, {k: int(v) for k, v in zip(keys, cnt)}
+
+
+def align_pe(oidx: "OracleIndex", seqs1, offs1, seqs2, offs2, names1, noff1, names2, noff2, quals1=None, quals2=None, b_size: int = 512):
+    """SAM text (bytes) of the reference's paired-end path without orphan recovery (oracle/align_pe.hpp), one thread, st_align's
+    batch order, plus {"aligned", "ins_count", "ins_mean", "ins_std_dev", "ins_complete"}."""
+    c = lambda a, t: np.ascontiguousarray(a, dtype=t)
+    seqs1, seqs2, names1, names2 = c(seqs1, np.uint8), c(seqs2, np.uint8), c(names1, np.uint8), c(names2, np.uint8)
+    offs1, offs2, noff1, noff2 = c(offs1, np.uint64), c(offs2, np.uint64), c(noff1, np.uint64), c(noff2, np.uint64)
+    if quals1 is not None:
+        quals1, quals2 = c(quals1, np.uint8), c(quals2, np.uint8)
+    n = len(offs1) - 1
+    out_len = ctypes.c_uint64()
+    st = np.zeros(5, dtype=np.float64)
+    p = lib().orc_align_pe(oidx._h, seqs1.ctypes.data, offs1.ctypes.data, seqs2.ctypes.data, offs2.ctypes.data, n, names1.ctypes.data, noff1.ctypes.data,
+                           names2.ctypes.data, noff2.ctypes.data, quals1.ctypes.data if quals1 is not None else None,
+                           quals2.ctypes.data if quals2 is not None else None, b_size, ctypes.byref(out_len), st.ctypes.data)
+    try:
+        sam = ctypes.string_at(p, out_len.value)
+    finally:
+        lib().orc_free(p)
+    return sam, {"aligned": int(st[0]), "ins_count": int(st[1]), "ins_mean": float(st[2]), "ins_std_dev": float(st[3]), "ins_complete": bool(st[4])}
 
 
 DEFAULT_MAT = np.array([2, -4, -4, -4, 0, -4, 2, -4, -4, 0, -4, -4, 2, -4, 0, -4, -4, -4, 2, 0, 0, 0, 0, 0, 0],

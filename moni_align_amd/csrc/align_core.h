@@ -38,13 +38,13 @@
 #define AC_MAX_LEFT 256
 #define AC_MAX_ALT 64
 #define AC_MAX_FILL 16          // anchors of one chain that fill_chain handles
-#define AC_MAX_TASKS (AC_MAX_FILL + 2)
+#define AC_MAX_TASKS (2 * (AC_MAX_FILL + 2))      // one round of a pair: both mates' fills (pe_core.h)
 #define AC_MAX_CIGAR 512
 
 struct ac_mem_t { uint64_t pos; const uint64_t* occs; uint32_t len, idx, rpos, mate, nocc; };
 struct ac_anchor_t { uint64_t x; uint32_t mem, occ; };                 // x = reference end of the anchor (the sort key)
 struct ac_node_t { uint64_t x; uint16_t rpos, len; uint8_t mate, pad0; uint16_t pad1; int32_t f, p, t, msc; };      // 32 bytes
-struct ac_chain_t { long long score; uint32_t mate, off, cnt; };      // anchors (right to left) at pool[off .. off+cnt)
+struct ac_chain_t { long long score; uint32_t mate, off, cnt, paired; };      // anchors (right to left) at pool[off .. off+cnt); paired: chain.hpp:186
 struct ac_start_t { long long f; uint64_t j; };
 struct ac_best_t { int32_t score; uint64_t lft; uint64_t idx; };
 struct ac_left_t { uint64_t ref; uint64_t score; };
@@ -164,10 +164,14 @@ AC_HD uint64_t ac_occ(const ac_ws_t& W, uint32_t mem, uint32_t occ) { return W.m
 
 // ---- seeds -> filtered mems -> anchors -> chains (aligner_ksw2.hpp:342,382; chain.hpp:221-438) ----
 // returns false if the read is not chained (or overflowed: W.overflow)
-AC_HD_BIG bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, uint64_t a, uint64_t b, const uint64_t* occs) {
+AC_HD void ac_reset(ac_ws_t& W) {
     W.stage = AC_DONE; W.aligned = 0; W.overflow = 0; W.n_cigar = 0; W.n_tasks = 0;
     W.i = 0; W.n_diff = W.n_best = W.n_left = W.n_alt = 0; W.max_score = 0; W.score2 = 0; W.final_chain = 0;
     W.n_mems = W.n_anch = W.n_chains = W.pool_used = 0;
+}
+AC_HD_BIG bool ac_chain(ac_ws_t& W, const ac_params_t& P);
+AC_HD_BIG bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, uint64_t a, uint64_t b, const uint64_t* occs) {
+    ac_reset(W);
     unsigned long long pc0 = AC_CLOCK();
     size_t total = 0;
     for (uint64_t k = a; k < b; ++k) total += gm[k].occ_cnt;
@@ -178,6 +182,12 @@ AC_HD_BIG bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, u
         ac_mem_t& M = W.mems[W.n_mems++];
         M.pos = g.pos; M.len = g.len; M.idx = g.idx; M.rpos = g.rpos; M.mate = g.mate; M.occs = occs + g.occ_off; M.nocc = g.occ_cnt;
     }
+    W.prof[0] += AC_CLOCK() - pc0;
+    return ac_chain(W, P);
+}
+// find_chains (chain.hpp:221-438) over W.mems[0 .. n_mems): anchors, chaining DP, chain starts, backtrack, chains by score
+AC_HD_BIG bool ac_chain(ac_ws_t& W, const ac_params_t& P) {
+    unsigned long long pc0 = AC_CLOCK();
     size_t tot_mem_length = 0, na = 0;
     for (uint32_t i = 0; i < W.n_mems; ++i) { na += W.mems[i].nocc; tot_mem_length += (size_t)W.mems[i].len * W.mems[i].nocc; }
     if (na == 0) return false;
@@ -252,8 +262,9 @@ AC_HD_BIG bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, u
         ac_chain_t c;
         c.mate = W.node[j].mate;
         c.score = W.starts[i].f;
-        c.off = W.pool_used; c.cnt = 0;
+        c.off = W.pool_used; c.cnt = 0; c.paired = 0;
         do {
+            c.paired |= (c.mate != (uint32_t)W.node[j].mate) ? 1u : 0u;
             if (W.pool_used >= AC_MAX_POOL) { W.overflow = 1; return false; }
             W.pool[W.pool_used++] = (uint32_t)j; c.cnt++;
             W.node[j].t = 1; j = W.node[j].p;
@@ -277,28 +288,21 @@ AC_HD void ac_task(ac_ws_t& W, uint64_t q_off, int qlen, int qmode, uint64_t t_o
     id = (int32_t)W.n_tasks++;
 }
 // query segment R[a .. a+len) of the strand-oriented read, optionally reversed
-AC_HD void ac_qseg(const ac_ws_t& W, uint32_t strand, uint64_t a, uint64_t len, bool reversed, uint64_t& q_off, int& qmode) {
-    const uint64_t m = W.m;
-    if (!strand) { q_off = reversed ? W.off + a + len - 1 : W.off + a; qmode = reversed ? DP_Q_REV : 0; }
-    else { q_off = reversed ? W.off + (m - (a + len)) : W.off + (m - 1 - a); qmode = DP_Q_COMP | (reversed ? 0 : DP_Q_REV); }
-    if (len == 0) q_off = W.off;
+AC_HD void ac_qseg(uint64_t off, uint64_t m, uint32_t strand, uint64_t a, uint64_t len, bool reversed, uint64_t& q_off, int& qmode) {
+    if (!strand) { q_off = reversed ? off + a + len - 1 : off + a; qmode = reversed ? DP_Q_REV : 0; }
+    else { q_off = reversed ? off + (m - (a + len)) : off + (m - 1 - a); qmode = DP_Q_COMP | (reversed ? 0 : DP_Q_REV); }
+    if (len == 0) q_off = off;
 }
 
 // returns false if the chain does not fit (overflow)
-AC_HD_BIG bool ac_fill_begin(ac_ws_t& W, const ac_params_t& P, const ac_chain_t& ch, bool score_only) {
-    ac_fill_t& F = W.fill;
-    W.n_tasks = 0;
-    if (ch.cnt > AC_MAX_FILL) { W.overflow = 1; return false; }
-    F.score_only = score_only; F.n_an = ch.cnt; F.overlap = 0;
+// F.an_mem / F.an_occ [0 .. F.n_an): the anchors left to right; the read is reads[off .. off + m_); tasks are appended to W.tasks
+AC_HD_BIG bool ac_fill_begin_g(ac_ws_t& W, const ac_params_t& P, ac_fill_t& F, uint64_t off, uint32_t m_, bool score_only) {
+    F.score_only = score_only; F.overlap = 0;
     F.t_lc = F.t_rc = F.t_glob = -1; F.lc_mqe_t = F.rc_mqe_t = -1; F.score = 0; F.score_pos = 0;
-    for (uint32_t k = 0; k < ch.cnt; ++k) {                  // stored right to left (chain.hpp:166-200); fill_chain wants left to right
-        const ac_anchor_t& A = W.anch[W.pool[ch.off + ch.cnt - 1 - k]];
-        F.an_mem[k] = A.mem; F.an_occ[k] = A.occ;
-    }
     const ac_mem_t& first = W.mems[F.an_mem[0]];
     const ac_mem_t& last = W.mems[F.an_mem[F.n_an - 1]];
     F.strand = (first.mate & 2) ? 1 : 0;
-    const uint64_t m = W.m, ext_len = P.ext_len, n = P.n_text;
+    const uint64_t m = m_, ext_len = P.ext_len, n = P.n_text;
     F.lcs_len = first.idx;
     F.rcs_occ = (uint64_t)last.idx + last.len;
     F.rcs_len = m - F.rcs_occ;
@@ -308,14 +312,14 @@ AC_HD_BIG bool ac_fill_begin(ac_ws_t& W, const ac_params_t& P, const ac_chain_t&
         const uint64_t lc_occ = mem_pos > ext_len ? mem_pos - ext_len : 0;
         const uint64_t lc_len = mem_pos > ext_len ? ext_len : ext_len - mem_pos;     // sic (aligner_ksw2.hpp:2796)
         uint64_t q_off; int qmode;
-        ac_qseg(W, F.strand, 0, F.lcs_len, true, q_off, qmode);
+        ac_qseg(off, m, F.strand, 0, F.lcs_len, true, q_off, qmode);
         ac_task(W, q_off, (int)F.lcs_len, qmode, lc_len ? lc_occ + lc_len - 1 : 0, (int)lc_len, DP_T_REV, ext_flag, F.t_lc);
     }
     if (F.rcs_len > 0) {
         const uint64_t rc_occ = ac_occ(W, F.an_mem[F.n_an - 1], F.an_occ[F.n_an - 1]) + last.len;
         const uint64_t rc_len = rc_occ < n - ext_len ? ext_len : n - rc_occ;
         uint64_t q_off; int qmode;
-        ac_qseg(W, F.strand, F.rcs_occ, F.rcs_len, false, q_off, qmode);
+        ac_qseg(off, m, F.strand, F.rcs_occ, F.rcs_len, false, q_off, qmode);
         ac_task(W, q_off, (int)F.rcs_len, qmode, rc_occ, (int)rc_len, 0, ext_flag, F.t_rc);
     }
     uint64_t last_ref = mem_pos + first.len, last_seq = (uint64_t)first.idx + first.len;
@@ -351,7 +355,7 @@ AC_HD_BIG bool ac_fill_begin(ac_ws_t& W, const ac_params_t& P, const ac_chain_t&
                 const uint64_t ccs_pos = (uint64_t)mp.idx + mp.len;
                 const uint64_t ccs_len = seq_occ - ccs_pos;
                 uint64_t q_off; int qmode;
-                ac_qseg(W, F.strand, ccs_pos, ccs_len, false, q_off, qmode);
+                ac_qseg(off, m, F.strand, ccs_pos, ccs_len, false, q_off, qmode);
                 ac_task(W, q_off, (int)ccs_len, qmode, cc_occ, (int)cc_len, 0, DP_EZ_RIGHT, F.t_gap[k - 1]);
             }
             last_ref = ref_occ + mk.len; last_seq = seq_occ + mk.len;
@@ -359,10 +363,20 @@ AC_HD_BIG bool ac_fill_begin(ac_ws_t& W, const ac_params_t& P, const ac_chain_t&
     }
     return true;
 }
-
-// ---- fill_chain, part 2 (aligner_ksw2.hpp:2852-2886, 2975-2996); returns true if a dependent global problem was queued ----
-AC_HD_BIG bool ac_fill_after_ext(ac_ws_t& W, const ac_params_t& P, const moni_dp_result_t* res) {
+AC_HD_BIG bool ac_fill_begin(ac_ws_t& W, const ac_params_t& P, const ac_chain_t& ch, bool score_only) {
     ac_fill_t& F = W.fill;
+    W.n_tasks = 0;
+    if (ch.cnt > AC_MAX_FILL) { W.overflow = 1; return false; }
+    F.n_an = ch.cnt;
+    for (uint32_t k = 0; k < ch.cnt; ++k) {                  // stored right to left (chain.hpp:166-200); fill_chain wants left to right
+        const ac_anchor_t& A = W.anch[W.pool[ch.off + ch.cnt - 1 - k]];
+        F.an_mem[k] = A.mem; F.an_occ[k] = A.occ;
+    }
+    return ac_fill_begin_g(W, P, F, W.off, W.m, score_only);
+}
+
+// ---- fill_chain, part 2 (aligner_ksw2.hpp:2852-2886, 2975-2996); returns true if a dependent global problem was queued (appended to W.tasks) ----
+AC_HD_BIG bool ac_fill_after_ext_g(ac_ws_t& W, const ac_params_t& P, ac_fill_t& F, uint64_t off, uint32_t m_, const moni_dp_result_t* res) {
     const ac_mem_t& last = W.mems[F.an_mem[F.n_an - 1]];
     int score_lc = 0, score_rc = 0;
     if (F.t_lc >= 0) { score_lc = res[F.t_lc].mqe; F.lc_mqe_t = res[F.t_lc].mqe_t; }
@@ -375,7 +389,6 @@ AC_HD_BIG bool ac_fill_after_ext(ac_ws_t& W, const ac_params_t& P, const moni_dp
     F.ref_pos = lq > mem_pos ? 0 : mem_pos - lq;
     F.ref_len = lq + mem_len + rq;
     F.score_pos = F.ref_pos;
-    W.n_tasks = 0;
     if (!F.overlap) {
         uint32_t sc = (uint32_t)F.score;
         for (uint32_t k = 1; k < F.n_an; ++k) {
@@ -388,19 +401,22 @@ AC_HD_BIG bool ac_fill_after_ext(ac_ws_t& W, const ac_params_t& P, const moni_dp
     }
     // overlapping MEMs: one global alignment of the whole read against the window (aligner_ksw2.hpp:2984-2996, 3009-3015)
     uint64_t q_off; int qmode;
-    if (!F.strand) { q_off = W.off; qmode = 0; } else { q_off = W.off + W.m - 1; qmode = DP_Q_REV | DP_Q_COMP; }
-    ac_task(W, q_off, (int)W.m, qmode, F.ref_pos, (int)F.ref_len, 0, F.score_only ? DP_EZ_SCORE_ONLY : DP_EZ_RIGHT, F.t_glob);
+    if (!F.strand) { q_off = off; qmode = 0; } else { q_off = off + m_ - 1; qmode = DP_Q_REV | DP_Q_COMP; }
+    ac_task(W, q_off, (int)m_, qmode, F.ref_pos, (int)F.ref_len, 0, F.score_only ? DP_EZ_SCORE_ONLY : DP_EZ_RIGHT, F.t_glob);
     return true;
+}
+AC_HD_BIG bool ac_fill_after_ext(ac_ws_t& W, const ac_params_t& P, const moni_dp_result_t* res) {
+    W.n_tasks = 0;                                 // (after the results were read: ac_fill_after_ext_g reads res, not W.tasks)
+    return ac_fill_after_ext_g(W, P, W.fill, W.off, W.m, res);
 }
 
 // ---- fill_chain, part 3 (final pass): the stitched CIGAR (aligner_ksw2.hpp:3000-3108) ----
-AC_HD_BIG bool ac_fill_final(ac_ws_t& W, const ac_params_t& P, const moni_dp_result_t* res, const uint32_t* cig) {
-    ac_fill_t& F = W.fill;
-    W.n_cigar = 0;
+AC_HD_BIG bool ac_fill_final_g(ac_ws_t& W, const ac_params_t& P, ac_fill_t& F, const moni_dp_result_t* res, const uint32_t* cig, uint32_t* out, uint32_t& n_out) {
+    n_out = 0;
     if (!ac_valid(P, F.ref_pos, F.ref_len)) return true;
-    auto push = [&](uint32_t op) -> bool { if (W.n_cigar >= AC_MAX_CIGAR) { W.overflow = 1; return false; } W.cigar[W.n_cigar++] = op; return true; };
+    auto push = [&](uint32_t op) -> bool { if (n_out >= AC_MAX_CIGAR) { W.overflow = 1; return false; } out[n_out++] = op; return true; };
     auto push_merge_first = [&](const uint32_t* c, uint32_t n) -> bool {
-        if (n > 0) { if ((c[0] & 0xf) == 0 && W.n_cigar > 0) W.cigar[W.n_cigar - 1] += c[0]; else if (!push(c[0])) return false; }
+        if (n > 0) { if ((c[0] & 0xf) == 0 && n_out > 0) out[n_out - 1] += c[0]; else if (!push(c[0])) return false; }
         for (uint32_t k = 1; k < n; ++k) if (!push(c[k])) return false;
         return true;
     };
@@ -413,7 +429,7 @@ AC_HD_BIG bool ac_fill_final(ac_ws_t& W, const ac_params_t& P, const moni_dp_res
     if (F.t_lc >= 0) { const moni_dp_result_t& r = res[F.t_lc]; for (uint32_t k = 0; k < r.n_cigar; ++k) if (!push(cig[r.cigar_off + r.n_cigar - 1 - k])) return false; }
     for (uint32_t j = 0; j < F.n_an; ++j) {
         const uint32_t mlen = W.mems[F.an_mem[j]].len;
-        if (W.n_cigar > 0 && (W.cigar[W.n_cigar - 1] & 0xf) == 0) W.cigar[W.n_cigar - 1] += mlen << 4;
+        if (n_out > 0 && (out[n_out - 1] & 0xf) == 0) out[n_out - 1] += mlen << 4;
         else if (!push(mlen << 4)) return false;
         if (j + 1 < F.n_an) {
             if (F.t_gap[j] >= 0) { const moni_dp_result_t& r = res[F.t_gap[j]]; if (!push_merge_first(cig + r.cigar_off, r.n_cigar)) return false; }
@@ -422,6 +438,9 @@ AC_HD_BIG bool ac_fill_final(ac_ws_t& W, const ac_params_t& P, const moni_dp_res
     }
     if (F.t_rc >= 0) { const moni_dp_result_t& r = res[F.t_rc]; if (!push_merge_first(cig + r.cigar_off, r.n_cigar)) return false; }
     return true;
+}
+AC_HD_BIG bool ac_fill_final(ac_ws_t& W, const ac_params_t& P, const moni_dp_result_t* res, const uint32_t* cig) {
+    return ac_fill_final_g(W, P, W.fill, res, cig, W.cigar, W.n_cigar);
 }
 
 // aligner_ksw2.hpp:553-597

@@ -203,7 +203,7 @@ static bool chain_mems(const std::vector<Mem>& mems, std::vector<std::pair<uint3
 
 // ---- MAPQ: mapq.hpp:146-184 ------------------------------------------------------------------------------------------------
 static size_t mapq_se_bwa(int32_t score, int32_t score2, int32_t rlen, int32_t qlen, int32_t min_seed_length, int32_t match_score,
-                          int32_t mismatch_score, double coeff_len, int32_t coeff_fac) {
+                          int32_t mismatch_score, double coeff_len, int32_t coeff_fac, int32_t sub_n = 0) {
     int32_t mapq = 0;
     const int32_t l = std::max(rlen, qlen);
     const int32_t sub = score2 ? score2 : min_seed_length * match_score;
@@ -215,6 +215,7 @@ static size_t mapq_se_bwa(int32_t score, int32_t score2, int32_t rlen, int32_t q
         tmp *= identity * identity;
         mapq = (int)(6.02 * (score - sub) / match_score * tmp * tmp + .499);
     }
+    if (sub_n > 0) mapq -= (int)(4.343 * log(sub_n + 1) + .499);
     if (mapq > 60) mapq = 60;
     if (mapq < 0) mapq = 0;
     mapq = (int)(mapq * 1. + .499);
@@ -274,6 +275,9 @@ struct Sam {                       // sam_t (sam.hpp:47-112), the fields the SE 
     size_t lift_pos = 0, lift_nm = 0;
     std::string lift_md;
     bool unmapped_lft = false;
+    std::string rnext = "*";       // paired-end only (pe_host.hpp)
+    size_t pnext = 0;
+    long long tlen = 0;
 };
 
 struct Score { int32_t score = 0; uint64_t pos = 0, lft = 0; bool unmapped_lft = false; };

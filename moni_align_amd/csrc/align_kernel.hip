@@ -405,8 +405,10 @@ align_kernel(const ak_args_t A) {
             // later) and its memo (lane e holds entry e: key, target offset, the three result words)
             const uint32_t* __restrict__ tsrc = reinterpret_cast<const uint32_t*>(Q->ws.tasks);
             constexpr uint32_t TW = AC_MAX_TASKS * (uint32_t)(sizeof(moni_dp_task_t) / 4);
-            const uint32_t tw0 = tsrc[lane], tw1 = tsrc[lane + 64], tw2 = (uint32_t)lane + 128 < TW ? tsrc[lane + 128] : 0u;
-            static_assert(TW > 128 && TW <= 192, "task staging assumes three words per lane");
+            constexpr uint32_t TWL = (TW + 63) / 64;                 // words per lane
+            uint32_t tw[TWL];
+#pragma unroll
+            for (uint32_t x = 0; x < TWL; ++x) tw[x] = (uint32_t)lane + 64 * x < TW ? tsrc[lane + 64 * x] : 0u;
             const uint32_t nt = Q->ws.n_tasks;
             const uint64_t read_off = Q->ws.off;
             uint32_t memo_n = Q->memo_n;
@@ -414,7 +416,8 @@ align_kernel(const ak_args_t A) {
             uint64_t mt = lane < AK_MEMO ? Q->memo_toff[lane] : 0ull;
             dp_brief_t mv = Q->memo_val[lane < AK_MEMO ? lane : 0];
             __syncthreads();
-            ((uint32_t*)s_tasks)[lane] = tw0; ((uint32_t*)s_tasks)[lane + 64] = tw1; if ((uint32_t)lane + 128 < TW) ((uint32_t*)s_tasks)[lane + 128] = tw2;
+#pragma unroll
+            for (uint32_t x = 0; x < TWL; ++x) if ((uint32_t)lane + 64 * x < TW) ((uint32_t*)s_tasks)[lane + 64 * x] = tw[x];
             if ((uint32_t)lane >= memo_n) mk = ~0ull;
             __syncthreads();
             bool too_big = false;

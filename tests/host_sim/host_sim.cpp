@@ -13,6 +13,8 @@
 #include "../../moni_align_amd/csrc/seed_core.h"
 #include "../../moni_align_amd/csrc/align_host.hpp"
 #include "../../moni_align_amd/csrc/align_core.h"
+#include "../../moni_align_amd/csrc/pe_core.h"
+#include "../../moni_align_amd/csrc/pe_host.hpp"
 #include "../../oracle/ksw2.hpp"      // CPU stand-in for extz_kernel in this harness (tests may use the oracle)
 
 struct Sim {
@@ -24,6 +26,7 @@ struct Sim {
     std::vector<uint64_t> ptr;
     std::vector<moni_mem_t> mems;
     std::vector<uint64_t> occs, read_mem_off;
+    std::vector<uint32_t> aux;      // per MEM slot: plain / has halves / is a half (seed_core.h)
     uint64_t counters[4];
     uint64_t max_len = 0, n_reads = 0;
     mh::HostIndex hix;
@@ -112,6 +115,7 @@ int sim_seed_run(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_r
     if (small[1]) return MONI_ENOMEM;
     S->occs.resize(acc);
     S->mems.resize(n_mems);
+    S->aux = aux;
     for (int i = 0; i < 4; ++i) S->counters[i] = cnt[i];
     return MONI_OK;
 }
@@ -288,6 +292,86 @@ char* sim_align_core_batch(void* s, const uint8_t* seq, const uint64_t* offs, ui
     memcpy(buf, out.data(), out.size() + 1);
     *out_len = out.size();
     if (stats5) { stats5[0] = n_reads; stats5[1] = n_aligned; stats5[2] = n_tasks; stats5[3] = n_over; stats5[4] = n_rounds; }
+    return buf;
+}
+// ---- the paired-end per-pair logic (pe_core.h) replayed on the host + the host finishing (pe_host.hpp).  Reads 2p / 2p + 1 are the mates
+// of pair p.  finalize == 0: the learn pass (learn[4*p .. 4*p+4) = aligned, best tot, second tot, dist; min_score in learn_min[p]) ----
+char* sim_align_pe_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_pairs, const uint8_t* names, const uint64_t* name_off,
+                         const uint8_t* quals, int finalize, double mean, double std_dev, long long* learn, uint64_t* out_len, uint64_t* stats5) {
+    Sim* S = (Sim*)s;
+    SimBackend be;
+    const uint64_t n_reads = 2 * n_pairs;
+    be.S = S; be.seq = seq; be.offs = offs; be.n_reads = n_reads;
+    moni_align_params_t P;
+    memset(&P, 0, sizeof P);
+    P.min_len = 25; P.ext_len = 100; P.check_k = 5; P.region_dist = 10; P.filter_seeds = 1; P.n_seeds_thr = 1000; P.filter_freq = 1;
+    P.left_mem_check = 1; P.freq_thr = 0.5; P.smatch = 2; P.smismatch = 4; P.gapo = 4; P.gapo2 = 13; P.gape = 2; P.gape2 = 1;
+    P.end_bonus = 400; P.w = -1; P.zdrop = -1; P.max_dist_x = 500; P.max_dist_y = 100; P.max_iter = 10; P.max_pred = 5;
+    P.min_chain_score = 40; P.min_chain_length = 1; P.host_threads = 1;
+    moni_seed_params_t sp{P.min_len, P.filter_seeds, P.n_seeds_thr, 0};
+    std::vector<moni_mem_t> gm; std::vector<uint64_t> go, rmo;
+    if (be.seed(sp, gm, go, rmo)) return nullptr;
+    const std::vector<uint32_t>& aux = S->aux;
+    pe_params_t PP;
+    ac_params_t& AP = PP.P;
+    AP.min_len = P.min_len; AP.ext_len = P.ext_len; AP.check_k = P.check_k; AP.region_dist = P.region_dist; AP.filter_freq = P.filter_freq;
+    AP.left_mem_check = P.left_mem_check; AP.freq_thr = P.freq_thr; AP.smatch = P.smatch; AP.gapo = P.gapo; AP.gapo2 = P.gapo2; AP.gape = P.gape;
+    AP.gape2 = P.gape2; AP.max_dist_x = P.max_dist_x; AP.max_dist_y = P.max_dist_y; AP.max_iter = P.max_iter; AP.max_pred = P.max_pred;
+    AP.min_chain_score = P.min_chain_score; AP.min_chain_length = P.min_chain_length; AP.n_text = S->hix.n_text; AP.n_seq = (uint32_t)S->hix.names.size();
+    AP.seq_starts = S->hix.seq_starts.data();
+    AP.lift_seqs = S->hix.lift_seqs.data(); AP.lift_runs = S->hix.lift_runs.data(); AP.pdir = S->pdir.data();
+    PP.smismatch = P.smismatch; PP.max_penalty = std::max(P.smatch + P.smismatch, P.gapo + P.gape); PP.filter_dir = 1; PP.finalize = finalize ? 1 : 0;
+    PP.dir_thr = 50.0; PP.mean = (float)mean; PP.std_dev = (float)std_dev;
+    moni_dp_params_t dp;
+    memset(&dp, 0, sizeof dp);
+    dp.m = 5;
+    for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) dp.mat[i * 5 + j] = i == j ? P.smatch : (int8_t)-P.smismatch; }
+    dp.q = P.gapo; dp.e = P.gape; dp.w = -1; dp.zdrop = -1; dp.end_bonus = P.end_bonus;
+    mh::Aligner A(S->hix, P, seq, offs);
+    std::string out;
+    uint64_t n_aligned = 0, n_over = 0, n_tasks = 0, n_rounds = 0;
+    pe_ws_t* W = new pe_ws_t();
+    for (uint64_t p = 0; p < n_pairs; ++p) {
+        for (int k = 0; k < 2; ++k) {
+            W->off[k] = offs[2 * p + k] - offs[0]; W->m[k] = (uint32_t)(offs[2 * p + k + 1] - offs[2 * p + k]);
+            W->min_score_m[k] = (int32_t)(20 + 8 * log((double)W->m[k]));
+        }
+        W->min_score = W->min_score_m[0] + W->min_score_m[1];
+        std::vector<moni_dp_result_t> res;
+        std::vector<uint32_t> cig;
+        if (pe_init(*W, PP, gm.data(), rmo.data(), aux.data(), go.data(), p)) {
+            pe_drive(*W, PP, nullptr, nullptr);
+            while (!W->W.overflow && W->W.stage != AC_DONE) {
+                std::vector<moni_dp_task_t> tasks(W->W.tasks, W->W.tasks + W->W.n_tasks);
+                n_tasks += tasks.size(); ++n_rounds;
+                if (be.dp(dp, tasks, res, cig)) return nullptr;
+                pe_drive(*W, PP, res.data(), cig.data());
+            }
+        }
+        if (W->W.overflow) { ++n_over; }
+        if (!finalize) {
+            learn[4 * p] = (!W->W.overflow && W->W.aligned) ? 1 : 0; learn[4 * p + 1] = W->final.tot; learn[4 * p + 2] = W->score2; learn[4 * p + 3] = W->final.dist;
+            continue;
+        }
+        mh::PePairOut R;
+        R.finalized = !W->W.overflow && W->W.aligned;
+        R.strand = W->strand; R.tot = W->final.tot; R.score2 = W->score2; R.sub_n = W->sub_n;
+        for (int k = 0; k < 2; ++k) {
+            R.score2_m[k] = W->score2_m[k]; R.min_score_m[k] = W->min_score_m[k];
+            mh::PeMateOut& M = R.mate[k];
+            M.m = W->m[k]; M.off = W->off[k]; M.score = k ? W->final.m2.score : W->final.m1.score; M.filled = R.finalized && W->filled[k];
+            M.ref_pos = W->ref_pos[k]; M.as = W->as[k]; M.cig = W->cigar[k]; M.n_cig = W->n_cigar[k];
+            M.alt_pos = W->alt_pos[k]; M.alt_score = W->alt_score[k]; M.n_alt = W->n_alt[k];
+        }
+        if (R.finalized) ++n_aligned;
+        mh::pe_emit(A, P, R, std::string((const char*)names + name_off[2 * p], (const char*)names + name_off[2 * p + 1]),
+                    std::string((const char*)names + name_off[2 * p + 1], (const char*)names + name_off[2 * p + 2]), seq, quals, out);
+    }
+    delete W;
+    char* buf = (char*)malloc(out.size() + 1);
+    memcpy(buf, out.data(), out.size() + 1);
+    *out_len = out.size();
+    if (stats5) { stats5[0] = n_pairs; stats5[1] = n_aligned; stats5[2] = n_tasks; stats5[3] = n_over; stats5[4] = n_rounds; }
     return buf;
 }
 void sim_free(void* p) { free(p); }

@@ -210,6 +210,33 @@ int moni_align_stream(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uin
 /* aligner::align with report_mems (-m; aligner_ksw2.hpp:346-373): one secondary record per MEM occurrence.  *sam is malloc'ed. */
 int moni_report_mems_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
                            const uint8_t *quals, const moni_align_params_t *prm, char **sam, uint64_t *sam_len);
+/* ---- the paired-end path: aligner::align(kpbseq_t*) (aligner_ksw2.hpp:888-918, 1000-1326) without orphan recovery ---------------- */
+/* The batch holds the pairs interleaved: reads 2p and 2p+1 are mate 1 and mate 2 of pair p (kpbseq_t's two kbseq_t,
+ * include/common/kpbseq.h:300-326).  Orphan recovery (aligner_ksw2.hpp:920-998; klib's ksw_align, an absent submodule) is not built:
+ * the records are those of the reference with find_orphan == false. */
+typedef struct {
+    uint32_t filter_dir, reserved;                        /* 1: aligner::config_t::filter_dir (aligner_ksw2.hpp:113) */
+    double dir_thr;                                       /* 50.0 */
+    uint64_t ins_learning_n;                              /* 1000 */
+    uint64_t ins_learning_score_gap_threshold;            /* 0 */
+} moni_pe_params_t;
+/* The insert-size model (aligner_ksw2.hpp:3252-3262): zero-initialise, feed batches to moni_pe_learn_batch until complete != 0 (or
+ * the input ends), then align - the order of st_align's paired loop (align_reads_dispatcher.hpp:356-389). */
+typedef struct {
+    double mean, std_dev, variance, sample_variance, m2;
+    uint64_t count;
+    uint32_t complete, reserved;
+} moni_pe_model_t;
+void moni_pe_params_default(moni_pe_params_t *p);
+/* aligner::learn_fragment_model (aligner_ksw2.hpp:816-885) over one batch: updates *model.  MONI_ERANGE: a pair exceeded the
+ * kernel's capacities (there is no host pipeline for pairs). */
+int moni_pe_learn_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const moni_align_params_t *prm,
+                        const moni_pe_params_t *pe, moni_pe_model_t *model);
+/* The two SAM records of every pair, in input order, no header.  names / name_off / quals as in moni_align_batch (2N reads).
+ * *sam is malloc'ed (moni_free). */
+int moni_pe_align_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
+                        const uint8_t *quals, const moni_align_params_t *prm, const moni_pe_params_t *pe,
+                        const moni_pe_model_t *model, char **sam, uint64_t *sam_len, moni_align_stats_t *stats);
 /* aligner::to_sam (aligner_ksw2.hpp:3213-3219): "@HD", one "@SQ" per sequence, "@PG". */
 int moni_sam_header(const moni_index_t *idx, char **sam, uint64_t *sam_len);
 

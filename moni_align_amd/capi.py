@@ -24,6 +24,7 @@ EXPORTS = [
     "moni_align_params_default", "moni_align_batch", "moni_align_run", "moni_align_stream", "moni_sam_header",
     "moni_ldx_info", "moni_ldx_rewrite", "moni_ldx_lift_batch", "moni_ldx_write",
     "moni_ms_file_info", "moni_ms_file_read", "moni_ms_file_write", "moni_index_load_reference", "moni_ms_lengths_batch", "moni_report_mems_batch",
+    "moni_pe_params_default", "moni_pe_learn_batch", "moni_pe_align_batch",
 ]
 
 
@@ -62,6 +63,16 @@ class AlignStatsC(C.Structure):
                 ("t_dp_kernel", C.c_double), ("handed_back", C.c_uint64), ("dp_reused", C.c_uint64), ("dp_cells_reused", C.c_uint64),
                 ("kernel_fallback", C.c_uint64), ("dp_ref_bytes", C.c_uint64),
                 ("t_k_chain", C.c_double), ("t_k_dp", C.c_double), ("t_k_select", C.c_double), ("t_k_finish", C.c_double)]
+
+
+class PeParamsC(C.Structure):
+    _fields_ = [("filter_dir", C.c_uint32), ("reserved", C.c_uint32), ("dir_thr", C.c_double), ("ins_learning_n", C.c_uint64),
+                ("ins_learning_score_gap_threshold", C.c_uint64)]
+
+
+class PeModelC(C.Structure):
+    _fields_ = [("mean", C.c_double), ("std_dev", C.c_double), ("variance", C.c_double), ("sample_variance", C.c_double), ("m2", C.c_double),
+                ("count", C.c_uint64), ("complete", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class DpParamsC(C.Structure):
@@ -124,6 +135,11 @@ def lib():
         L.moni_align_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
         L.moni_align_stream.argtypes = L.moni_align_batch.argtypes
+        L.moni_pe_params_default.argtypes = [C.POINTER(PeParamsC)]
+        L.moni_pe_params_default.restype = None
+        L.moni_pe_learn_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.POINTER(AlignParamsC), C.POINTER(PeParamsC), C.POINTER(PeModelC)]
+        L.moni_pe_align_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
+                                          C.POINTER(PeParamsC), C.POINTER(PeModelC), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
         L.moni_align_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
         L.moni_sam_header.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
@@ -296,6 +312,45 @@ class Ctx:
         finally:
             if not stream:
                 self._L.moni_free(out)
+        return sam, {k: getattr(st, k) for k, _ in AlignStatsC._fields_}
+
+    def _pe_params(self, host_threads, overrides):
+        prm = AlignParamsC()
+        self._L.moni_align_params_default(C.byref(prm))
+        if host_threads is not None:
+            prm.host_threads = host_threads
+        pe = PeParamsC()
+        self._L.moni_pe_params_default(C.byref(pe))
+        for k, v in overrides.items():
+            setattr(pe if hasattr(pe, k) and not hasattr(prm, k) else prm, k, v)
+        return prm, pe
+
+    def pe_learn(self, seq: np.ndarray, offsets: np.ndarray, model: Optional["PeModelC"] = None, **overrides):
+        """learn_fragment_model over one batch of interleaved pairs (reads 2p, 2p+1); returns the updated model."""
+        b, keep = self._batch(seq, offsets)
+        prm, pe = self._pe_params(None, overrides)
+        model = model if model is not None else PeModelC()
+        _chk(self._L.moni_pe_learn_batch(self._h, C.byref(b), C.byref(prm), C.byref(pe), C.byref(model)), "moni_pe_learn_batch")
+        return model
+
+    def pe_align(self, seq: np.ndarray, offsets: np.ndarray, names: np.ndarray, name_off: np.ndarray, quals, model: "PeModelC",
+                 host_threads: Optional[int] = None, **overrides):
+        """SAM text (bytes) of the interleaved pairs + stats dict (moni_pe_align_batch)."""
+        b, keep = self._batch(seq, offsets)
+        names = np.ascontiguousarray(names, dtype=np.uint8)
+        name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
+        if quals is not None:
+            quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        prm, pe = self._pe_params(host_threads, overrides)
+        out = C.c_void_p()
+        ln = C.c_uint64()
+        st = AlignStatsC()
+        _chk(self._L.moni_pe_align_batch(self._h, C.byref(b), names.ctypes.data, name_off.ctypes.data, quals.ctypes.data if quals is not None else None,
+                                         C.byref(prm), C.byref(pe), C.byref(model), C.byref(out), C.byref(ln), C.byref(st)), "moni_pe_align_batch")
+        try:
+            sam = C.string_at(out, ln.value)
+        finally:
+            self._L.moni_free(out)
         return sam, {k: getattr(st, k) for k, _ in AlignStatsC._fields_}
 
     def align_run(self, names: np.ndarray, name_off: np.ndarray, quals=None, host_threads: Optional[int] = None,

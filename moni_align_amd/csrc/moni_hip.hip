@@ -25,6 +25,8 @@
 #include "seed_kernels.hip"
 #include "extz_kernels.hip"
 #include "align_kernel.hip"
+#include "pe_kernel.hip"
+#include "pe_host.hpp"
 #include "align_fast.hip"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "moni_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return MONI_ENODEV; } } while (0)
@@ -152,6 +154,8 @@ struct moni_ctx {
     DBuf<uint32_t> ak_cig;
     DBuf<moni_alt_t> ak_alt;
     DBuf<int32_t> ak_minscore;
+    struct PeBufs { DBuf<pe_slot_t> slots; DBuf<ak_wave_t> waves; DBuf<pe_rec_t> recs; DBuf<uint32_t> cig; DBuf<moni_alt_t> alt; DBuf<unsigned long long> cur; DBuf<int32_t> minscore;
+                    void release() { slots.release(); waves.release(); recs.release(); cig.release(); alt.release(); cur.release(); minscore.release(); } } pe;      // paired-end path (pe_api.inc)
     unsigned long long* d_ak_cursors = nullptr;
     char* out_buf = nullptr; size_t out_cap = 0;      // moni_align_run's text buffer, kept across calls; pinned (hipHostMalloc): the in-order blocks of the
                                                       // sub-batches land in it by DMA
@@ -362,7 +366,7 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto e : c->ak_begin) (void)hipEventDestroy(e);
     for (auto e : c->ak_done) (void)hipEventDestroy(e);
-    c->ak_recs.release(); c->ak_cig.release(); c->ak_alt.release(); c->ak_minscore.release();
+    c->ak_recs.release(); c->ak_cig.release(); c->ak_alt.release(); c->ak_minscore.release(); c->pe.release();
     if (c->d_ak_cursors) (void)hipFree(c->d_ak_cursors);
     if (c->out_buf) (void)hipHostFree(c->out_buf);
     for (int x = 0; x < AK_NSET; ++x) c->gather_tmp[x].release();
@@ -1653,5 +1657,7 @@ int moni_sam_header(const moni_index_t* I, char** sam, uint64_t* sam_len) {
     *sam_len = h.size();
     return MONI_OK;
 }
+
+#include "pe_api.inc"
 
 }  // extern "C"

@@ -1,0 +1,152 @@
+// pe_align_kernel: the paired-end path after seeding, persistent waves, AK_NL pairs in flight per wavefront - the same shape as
+// align_kernel (every lane runs one pair's state machine, pe_core.h, out of its own slot in HBM; whenever pairs need DP results the
+// whole wave solves their problems one after the other, extz_wave_lds_lite).  Reads 2p and 2p + 1 of the resident batch are the mates
+// of pair p; the seeds are read where the seeding kernels left them (the four (mate, strand) lists of aligner_ksw2.hpp:1012-1040 are
+// put in the reference's order by pe_init).  Output per pair: a fixed record plus the two CIGARs and the alternative hits of each mate
+// in bump-allocated pools; lift-over, MD/NM, MAPQ and the SAM text of a pair are host work (pe_host.hpp).
+// finalize == 0 is the learn pass of learn_fragment_model: the record carries best_scores[0] / [1] only.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pe_core.h"
+
+struct pe_slot_t {
+    pe_ws_t ws;
+    moni_dp_result_t res[AC_MAX_TASKS];
+    uint32_t cig[AK_CIG_CAP];
+};
+
+struct pe_rec_t {                            // one per pair
+    uint32_t status;                         // 0 not aligned, 1 aligned (finalize: the final paired_chain_score ran), 2 overflow
+    uint32_t strand;
+    int32_t tot, score2, score2_m[2], sub_n, pad;
+    long long dist;
+    int32_t mate_score[2];
+    uint32_t filled[2];
+    uint64_t ref_pos[2];
+    int32_t as[2];
+    uint32_t n_cigar[2], n_alt[2];
+    uint64_t cigar_off[2], alt_off[2];       // into the pools
+};
+
+struct pe_args_t {
+    pe_params_t PP;
+    dp_launch_t D;
+    const moni_mem_t* mems;
+    const uint64_t* occs;
+    const uint64_t* read_mem_off;
+    const uint32_t* aux;
+    const uint64_t* offs;
+    const int32_t* min_score_of_len;
+    uint32_t max_len;
+    uint64_t n_pairs;
+    pe_slot_t* slots;                        // gridDim.x * AK_NL
+    ak_wave_t* waves;                        // gridDim.x
+    pe_rec_t* recs;
+    uint32_t* cig_pool; uint64_t cig_cap;
+    moni_alt_t* alt_pool; uint64_t alt_cap;
+    unsigned long long* cursors;             // [0] cigar pool, [1] alt pool, [2] DP problems run, [3] their cells, [4] next pair
+};
+
+__device__ __attribute__((noinline)) void pe_write_record(const pe_args_t& A, const pe_ws_t& S, uint64_t pair) {
+    pe_rec_t R;
+    R.status = S.W.overflow ? 2u : (S.W.aligned ? 1u : 0u);
+    R.strand = S.strand; R.tot = S.final.tot; R.score2 = S.score2; R.sub_n = S.sub_n; R.pad = 0; R.dist = S.final.dist;
+    R.mate_score[0] = S.final.m1.score; R.mate_score[1] = S.final.m2.score;
+    for (int k = 0; k < 2; ++k) {
+        R.score2_m[k] = S.score2_m[k];
+        R.filled[k] = 0; R.ref_pos[k] = 0; R.as[k] = 0; R.n_cigar[k] = 0; R.n_alt[k] = 0; R.cigar_off[k] = 0; R.alt_off[k] = 0;
+    }
+    if (R.status == 1 && A.PP.finalize) {
+        for (int k = 0; k < 2 && R.status == 1; ++k) {
+            if (!S.filled[k]) continue;
+            const unsigned long long co = atomicAdd(&A.cursors[0], (unsigned long long)S.n_cigar[k]);
+            const unsigned long long ao = atomicAdd(&A.cursors[1], (unsigned long long)S.n_alt[k]);
+            if (co + S.n_cigar[k] > A.cig_cap || ao + S.n_alt[k] > A.alt_cap) { R.status = 2; break; }
+            R.filled[k] = 1; R.ref_pos[k] = S.ref_pos[k]; R.as[k] = S.as[k];
+            R.n_cigar[k] = S.n_cigar[k]; R.cigar_off[k] = co; R.n_alt[k] = S.n_alt[k]; R.alt_off[k] = ao;
+            for (uint32_t i = 0; i < S.n_cigar[k]; ++i) A.cig_pool[co + i] = S.cigar[k][i];
+            for (uint32_t i = 0; i < S.n_alt[k]; ++i) { moni_alt_t x; x.pos = S.alt_pos[k][i]; x.score = S.alt_score[k][i]; x.pad = 0; A.alt_pool[ao + i] = x; }
+        }
+    }
+    A.recs[pair] = R;
+}
+
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+pe_align_kernel(const pe_args_t A) {
+    __shared__ dp_lds_t L;
+    __shared__ moni_dp_task_t s_tasks[AC_MAX_TASKS];
+    __shared__ unsigned long long s_cnt[2];
+    const int lane = threadIdx.x;
+    if (lane < 2) s_cnt[lane] = 0;
+    __syncthreads();
+    pe_slot_t* __restrict__ S = A.slots + (size_t)blockIdx.x * AK_NL + (lane < AK_NL ? lane : 0);
+    pe_ws_t& W = S->ws;
+    uint8_t* __restrict__ dirs = A.waves[blockIdx.x].dirs;
+    int state = lane < AK_NL ? 0 : 2;             // 0: wants a pair, 1: waits for DP results, 2: no more pairs, 3: finished, record not yet written
+    uint64_t pair = 0;
+    while (true) {
+        // ---- phase 1 (lane-private): take a pair; seeds -> chains -> first DP request ----
+        const bool start = __popcll(__ballot(state == 0 || state == 3)) >= AK_START_MIN || __ballot(state == 1) == 0ull;
+        if (state == 3 && start) { pe_write_record(A, W, pair); state = 0; }
+        if (state == 0 && start) {
+            pair = atomicAdd(&A.cursors[4], 1ull);
+            if (pair >= A.n_pairs) state = 2;
+            else {
+                bool chained = false;
+                for (int k = 0; k < 2; ++k) {
+                    const uint64_t r = 2 * pair + k;
+                    W.off[k] = A.offs[r]; W.m[k] = (uint32_t)(A.offs[r + 1] - A.offs[r]);
+                    W.min_score_m[k] = A.min_score_of_len[W.m[k] <= A.max_len ? W.m[k] : A.max_len];
+                }
+                W.min_score = W.min_score_m[0] + W.min_score_m[1];
+                if (W.m[0] >= 4096 || W.m[1] >= 4096 || W.m[0] == 0 || W.m[1] == 0) {          // beyond the kernel's DP / the 16-bit read coordinates of the chaining nodes
+                    ac_reset(W.W); W.W.overflow = (W.m[0] >= 4096 || W.m[1] >= 4096) ? 1u : 0u;
+                    W.final.tot = 0; W.final.dist = 0; W.final.m1.score = W.final.m2.score = 0; W.score2 = W.score2_m[0] = W.score2_m[1] = 0; W.sub_n = 0; W.strand = 0;
+                    W.filled[0] = W.filled[1] = 0; W.n_alt[0] = W.n_alt[1] = 0;
+                } else chained = pe_init(W, A.PP, A.mems, A.read_mem_off, A.aux, A.occs, pair);
+                if (chained) pe_drive(W, A.PP, nullptr, nullptr);
+                if (chained && !W.W.overflow && W.W.stage != AC_DONE) state = 1;
+                else pe_write_record(A, W, pair);
+            }
+        }
+        const unsigned long long waiting = __ballot(state == 1);
+        if (waiting == 0ull) { if (__ballot(state == 0 || state == 3) == 0ull) break; continue; }
+        __threadfence();
+        // ---- phase 2 (whole wave): the DP problems of every waiting pair, one pair after the other ----
+        for (unsigned long long todo = waiting; todo; todo &= todo - 1) {
+            const int src = __ffsll((long long)todo) - 1;
+            pe_slot_t* __restrict__ Q = A.slots + (size_t)blockIdx.x * AK_NL + src;
+            const uint32_t* __restrict__ tsrc = reinterpret_cast<const uint32_t*>(Q->ws.W.tasks);
+            constexpr uint32_t TW = AC_MAX_TASKS * (uint32_t)(sizeof(moni_dp_task_t) / 4);
+            const uint32_t nt = Q->ws.W.n_tasks;
+            __syncthreads();
+            for (uint32_t x = (uint32_t)lane; x < TW; x += 64) ((uint32_t*)s_tasks)[x] = tsrc[x];
+            __syncthreads();
+            bool too_big = false;
+            uint32_t cig_used = 0;
+            for (uint32_t t = 0; t < nt; ++t) {
+                const moni_dp_task_t task = s_tasks[t];
+                const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
+                const uint32_t cig_need = with_cigar && task.qlen > 0 && task.tlen > 0 ? (uint32_t)(task.qlen + task.tlen + 2) : 0u;
+                if (task.qlen > DP_LDS_Q || task.tlen > DP_LDS_T || cig_used + cig_need > AK_CIG_CAP ||
+                    (with_cigar && (uint64_t)(task.qlen + task.tlen - 1) * (uint64_t)task.tlen > AK_DIRS_CAP)) { too_big = true; break; }
+                const uint32_t cig_at = cig_used;
+                cig_used += cig_need;
+                (void)extz_wave_lds_lite(A.D, task, L, dirs, Q->cig + cig_at, &Q->res[t], cig_at);
+                if (lane == 0) { s_cnt[0]++; s_cnt[1] += (unsigned long long)(task.qlen > 0 ? task.qlen : 0) * (unsigned long long)(task.tlen > 0 ? task.tlen : 0); }
+                __syncthreads();
+            }
+            if (lane == 0 && too_big) Q->ws.W.overflow = 1;
+        }
+        __threadfence();
+        __syncthreads();
+        // ---- phase 3 (lane-private): results -> next DP request, or the finished record ----
+        if (state == 1) {
+            if (!W.W.overflow) pe_drive(W, A.PP, S->res, S->cig);
+            if (W.W.overflow || W.W.stage == AC_DONE) state = 3;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) { atomicAdd(&A.cursors[2], s_cnt[0]); atomicAdd(&A.cursors[3], s_cnt[1]); }
+}

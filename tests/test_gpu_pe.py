@@ -1,0 +1,91 @@
+"""Paired-end on the GPU (moni_pe_learn_batch / moni_pe_align_batch: seeding kernels + pe_align_kernel + the host finishing) against the
+oracle's restatement of the reference's paired path without orphan recovery (oracle/align_pe.hpp): the learnt fragment model must be
+bit-identical and the SAM text byte-identical, batch order as in st_align (learn on the first batches, align them, then the rest)."""
+import numpy as np
+import pytest
+
+from moni_align_amd import capi, index_build, synth
+from oracle import orc
+from tests.test_host_sim_pe import first_diff, hard_pairs, interleave, oracle_pe
+from tests.test_oracle_pe import make_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def case():
+    pg = synth.make_pangenome(80000, 3, site_spacing=800)
+    fi = index_build.build_from_pangenome(pg, device="cpu")
+    return pg, fi, orc.OracleIndex(fi=fi)
+
+
+def gpu_align_all(ctx, seq, offs, names, noff, q, b_size):
+    """st_align's paired loop (align_reads_dispatcher.hpp:356-389) over the C ABI"""
+    n = (len(offs) - 1) // 2
+    model = capi.PeModelC()
+    at, out, learnt = 0, [], []
+    def cut(lo, hi):
+        sl = slice(2 * lo, 2 * hi + 1)
+        return (seq[int(offs[2 * lo]):int(offs[2 * hi])], offs[sl] - offs[2 * lo], names[int(noff[2 * lo]):int(noff[2 * hi])], noff[sl] - noff[2 * lo],
+                q[int(offs[2 * lo]):int(offs[2 * hi])])
+    while at < n:
+        hi = min(n, at + b_size)
+        s, o, _, _, _ = cut(at, hi)
+        learnt.append((at, hi))
+        at = hi
+        ctx.pe_learn(s, o, model)
+        if model.complete:
+            break
+    aligned = 0
+    rest = [(lo, min(n, lo + b_size)) for lo in range(at, n, b_size)]
+    for lo, hi in learnt + rest:
+        sam, st = ctx.pe_align(*cut(lo, hi), model, host_threads=4)
+        out.append(sam); aligned += st["aligned"]
+    return b"".join(out), model, aligned
+
+
+def on_gpu(fi, seq, offs, names, noff, q, b_size):
+    idx = capi.Index(fi=fi)
+    ctx = capi.Ctx(idx)
+    try:
+        return gpu_align_all(ctx, seq, offs, names, noff, q, b_size)
+    finally:
+        ctx.close()
+        idx.close()
+
+
+def test_pe_matches_oracle(case):
+    pg, fi, o = case
+    m1, m2, _ = make_pairs(pg, 1300)
+    want, st = oracle_pe(o, m1, m2, b_size=512)
+    seq, offs, names, noff, q = interleave(m1, m2)
+    got, model, aligned = on_gpu(fi, seq, offs, names, noff, q, 512)
+    assert model.complete and model.count == st["ins_count"] and model.mean == st["ins_mean"] and model.std_dev == st["ins_std_dev"]
+    if got != want:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
+    assert aligned == st["aligned"] and aligned > 1200
+
+
+def test_pe_hard_cases(case):
+    pg, fi, o = case
+    m1, m2 = hard_pairs(pg)
+    want, st = oracle_pe(o, m1, m2, slash=False, b_size=4096)
+    seq, offs, names, noff, q = interleave(m1, m2, slash=False)
+    got, model, aligned = on_gpu(fi, seq, offs, names, noff, q, 4096)
+    assert not model.complete and model.count == st["ins_count"] and model.mean == st["ins_mean"] and model.std_dev == st["ins_std_dev"]
+    if got != want:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
+
+
+def test_pe_250bp_lifted_index(case):
+    """longer mates, more indels, a second index shape (5 haplotypes)"""
+    pg = synth.make_pangenome(60000, 5, site_spacing=400)
+    fi = index_build.build_from_pangenome(pg, device="cpu")
+    o = orc.OracleIndex(fi=fi)
+    m1, m2, _ = make_pairs(pg, 700, L=250, mean=700.0, sd=60.0, seed=77)
+    want, st = oracle_pe(o, m1, m2, b_size=512)
+    seq, offs, names, noff, q = interleave(m1, m2)
+    got, model, aligned = on_gpu(fi, seq, offs, names, noff, q, 512)
+    assert model.count == st["ins_count"] and model.mean == st["ins_mean"] and model.std_dev == st["ins_std_dev"]
+    if got != want:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))

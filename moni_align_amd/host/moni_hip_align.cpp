@@ -16,7 +16,7 @@
 // modes take the older path: a reader thread parses ahead into a bounded queue, two workers per GPU, a writer thread with a bounded
 // in-order window.  -m writes the report-MEMs records (aligner_ksw2.hpp:346-373);
 // --ms / --mems write the legacy `moni ms` / `moni mems` text outputs (src/matching_statistics.cpp:520-610, src/mems.cpp:520-600).
-// Not implemented here (exit 1 with a message): paired-end (-1/-2), -c, -q, -n, -Z.
+// Paired-end (-1/-2) runs without orphan recovery and therefore asks for -u.  Not implemented here (exit 1 with a message): -c, -q, -n, -Z.
 #include <fcntl.h>
 #include <getopt.h>
 #include <libgen.h>
@@ -176,10 +176,13 @@ struct Args {
     size_t gpu_batch = 1048576;
     int ctx_per_gpu = 3;               // streaming path: contexts (ranges in flight) per GPU
     bool dry_run = false;
+    moni_pe_params_t PE;               // -d, -D (paired-end)
+    bool find_orphan = true;           // -u switches orphan recovery off; moni-hip-align has none: paired input needs -u
 };
 
 static void parse(int argc, char** argv, Args& a) {
     moni_align_params_default(&a.P);
+    moni_pe_params_default(&a.PE);
     a.P.n_seeds_thr = 5000; a.P.freq_thr = 0.30;          // struct defaults of align_full_ksw2.cpp:70,73 (the wrapper always passes -S/-F)
     std::vector<char*> av;
     for (int i = 0; i < argc; ++i) {
@@ -209,11 +212,11 @@ static void parse(int argc, char** argv, Args& a) {
             case 'L': a.P.ext_len = (uint32_t)std::stoi(optarg); break;
             case 'A': a.P.smatch = (int8_t)std::stoi(optarg); break;
             case 'B': a.P.smismatch = (int8_t)std::stoi(optarg); break;
-            case 'd': break;                                   // filter_dir: paired-end only
+            case 'd': a.PE.filter_dir = 0; break;              // filter_dir off (align_full_ksw2.cpp:189-191)
             case 's': a.P.filter_seeds = 0; break;
             case 'f': a.P.filter_freq = 0; break;
             case 'n': a.no_lcp = true; break;
-            case 'D': (void)std::stoi(optarg); break;          // dir_thr: paired-end only (parsed with stoi, align_full_ksw2.cpp:195-198)
+            case 'D': a.PE.dir_thr = std::stoi(optarg); break;  // dir_thr (parsed with stoi, align_full_ksw2.cpp:195-198)
             case 'S': a.P.n_seeds_thr = (uint32_t)std::stoi(optarg); break;
             case 'F': a.P.freq_thr = std::stod(optarg); break;
             case 'O': a.P.gapo = a.P.gapo2 = (int8_t)strtol(optarg, &s, 10); if (*s == ',') a.P.gapo2 = (int8_t)strtol(s + 1, &s, 10); break;
@@ -227,7 +230,7 @@ static void parse(int argc, char** argv, Args& a) {
             case 'j': a.P.min_chain_score = std::stoi(optarg); break;
             case 'Z': a.secondary = true; break;
             case 'a': a.P.left_mem_check = 0; break;
-            case 'u': break;                                   // find_orphan: paired-end only
+            case 'u': a.find_orphan = false; break;
             case 'm': a.report_mems = true; break;
             case 'c': a.csv = true; break;
             case 'h': die(usage);
@@ -345,20 +348,120 @@ static void pwrite_all(int fd, const char* p, size_t n, uint64_t at) {
 
 }  // namespace fastpath
 
+// ---- paired-end (-1 / -2): st_align's paired loop (align_reads_dispatcher.hpp:356-389) over the C ABI ----------------------------------
+// Learn the insert-size model on batches of -b pairs until it is complete (or the input ends), align those batches, then the rest (in
+// larger batches: with the model fixed and no orphan recovery every pair is independent).  Orphan recovery is not built: -u is required.
+struct AnyReader {
+    MappedReader m; Reader* z = nullptr; bool mapped = false;
+    explicit AnyReader(const std::string& path) { mapped = m.open(path); if (!mapped) z = new Reader(path); }
+    ~AnyReader() { delete z; }
+    bool next(Batch& b) { return mapped ? m.next(b) : z->next(b); }
+};
+static size_t read_pairs(AnyReader& r1, AnyReader& r2, size_t n_pairs, Batch& b) {
+    size_t n = 0;
+    while (n < n_pairs) {
+        const bool g1 = r1.next(b);
+        if (!g1) { Batch t; if (r2.next(t)) die("the mate files have different numbers of records"); break; }
+        if (!r2.next(b)) die("the mate files have different numbers of records");
+        ++n;
+    }
+    return n;
+}
+static int run_paired(Args& a, const std::string& sam_filename) {
+    if (a.find_orphan) die("orphan recovery is not implemented in moni-hip-align: pass -u (the records are then those of `moni align -u`)");
+    info("Output file: " + sam_filename);
+    AnyReader r1(a.mate1), r2(a.mate2);
+    const std::string idx_path = a.filename + ".mfi";
+    const bool have_mfi = access(idx_path.c_str(), R_OK) == 0;
+    const std::string ms_path = a.filename + ".thrbv.full.lcp.ms", ldx_path = a.filename + ".ldx", txt_path = a.filename + ".txt";
+    std::vector<moni_index_t*> idx(a.gpus, nullptr);
+    std::vector<moni_ctx_t*> ctx(a.gpus, nullptr);
+    for (int g = 0; g < a.gpus; ++g) {
+        if (have_mfi) { if (moni_index_load(idx_path.c_str(), g, &idx[g])) die("cannot load " + idx_path + " on GPU " + std::to_string(g) + " (moni-hip has no CPU path)"); }
+        else if (moni_index_load_reference(ms_path.c_str(), ldx_path.c_str(), txt_path.c_str(), g, &idx[g]))
+            die("cannot load " + idx_path + " nor " + ms_path + " + " + ldx_path + " + " + txt_path + " on GPU " + std::to_string(g) + " (moni-hip has no CPU path)");
+        if (moni_ctx_create(idx[g], &ctx[g])) die("cannot create a context on GPU " + std::to_string(g));
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    FILE* out = fopen(sam_filename.c_str(), "w");
+    if (!out) die("open() file " + sam_filename + " failed");
+    { char* h; uint64_t hl; if (moni_sam_header(idx[0], &h, &hl)) die("header"); fwrite(h, 1, hl, out); moni_free(h); }
+    moni_pe_model_t model;
+    memset(&model, 0, sizeof model);
+    size_t processed = 0, aligned = 0;
+    auto align_one = [&](int g, Batch& b, char** sam, uint64_t* len, uint64_t* n_al) {
+        moni_read_batch_t rb{b.seq.data(), b.off.data(), b.n()};
+        moni_align_stats_t st;
+        const int rc = moni_pe_align_batch(ctx[g], &rb, b.names.data(), b.name_off.data(), b.has_qual ? b.qual.data() : nullptr, &a.P, &a.PE, &model, sam, len, &st);
+        if (rc) die("moni_pe_align_batch failed (" + std::to_string(rc) + (rc == MONI_ERANGE ? ": a pair exceeds the paired kernel's capacities)" : ")"));
+        *n_al = st.aligned;
+    };
+    std::vector<Batch*> learnt;
+    while (!model.complete) {
+        Batch* b = new Batch();
+        if (!read_pairs(r1, r2, a.b, *b)) { delete b; break; }
+        moni_read_batch_t rb{b->seq.data(), b->off.data(), b->n()};
+        const int rc = moni_pe_learn_batch(ctx[0], &rb, &a.P, &a.PE, &model);
+        if (rc) die("moni_pe_learn_batch failed (" + std::to_string(rc) + ")");
+        learnt.push_back(b);
+    }
+    info("Insert size model: count " + std::to_string(model.count) + ", mean " + std::to_string(model.mean) + ", std dev " + std::to_string(model.std_dev) +
+         (model.complete ? "" : " (input ended before " + std::to_string(a.PE.ins_learning_n) + " pairs)"));
+    {   // the learning batches as one batch
+        Batch all;
+        for (Batch* b : learnt) {
+            const uint64_t s0 = all.seq.size(), n0 = all.names.size();
+            all.seq.insert(all.seq.end(), b->seq.begin(), b->seq.end()); all.qual.insert(all.qual.end(), b->qual.begin(), b->qual.end());
+            all.names.insert(all.names.end(), b->names.begin(), b->names.end());
+            for (size_t i = 1; i < b->off.size(); ++i) { all.off.push_back(s0 + b->off[i]); all.name_off.push_back(n0 + b->name_off[i]); }
+            all.has_qual = all.has_qual && b->has_qual;
+            delete b;
+        }
+        if (all.n()) {
+            char* sam = nullptr; uint64_t len = 0, n_al = 0;
+            align_one(0, all, &sam, &len, &n_al);
+            fwrite(sam, 1, len, out); moni_free(sam);
+            processed += all.n() / 2; aligned += n_al;
+        }
+    }
+    const size_t pairs_per_batch = std::max<size_t>(a.gpu_batch / 8, 1024);      // the paired kernel keeps one pair per lane: moderate batches
+    bool more = true;
+    while (more) {
+        std::vector<Batch*> bs;
+        for (int g = 0; g < a.gpus; ++g) { Batch* b = new Batch(); if (!read_pairs(r1, r2, pairs_per_batch, *b)) { delete b; more = false; break; } bs.push_back(b); }
+        std::vector<char*> sams(bs.size(), nullptr); std::vector<uint64_t> lens(bs.size(), 0), nal(bs.size(), 0);
+        std::vector<std::thread> th;
+        for (size_t g = 1; g < bs.size(); ++g) th.emplace_back([&, g] { align_one((int)g, *bs[g], &sams[g], &lens[g], &nal[g]); });
+        if (!bs.empty()) align_one(0, *bs[0], &sams[0], &lens[0], &nal[0]);
+        for (auto& t : th) t.join();
+        for (size_t g = 0; g < bs.size(); ++g) { fwrite(sams[g], 1, lens[g], out); moni_free(sams[g]); processed += bs[g]->n() / 2; aligned += nal[g]; delete bs[g]; }
+    }
+    fclose(out);
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    info("Number of aligned pairs: " + std::to_string(aligned) + "/" + std::to_string(processed));
+    info("Elapsed time (s): " + std::to_string(el));
+    info("Pairs per second: " + std::to_string(processed / (el > 0 ? el : 1)));
+    for (int g = 0; g < a.gpus; ++g) { moni_ctx_destroy(ctx[g]); moni_index_destroy(idx[g]); }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     // HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); every context runs its launches on several
     // streams, and streams that share a queue run one after the other
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
     Args a;
     parse(argc, argv, a);
-    if (!a.mate1.empty() || !a.mate2.empty()) die("paired-end alignment (-1/-2) is not implemented in moni-hip-align yet");
     if (a.csv || a.no_lcp || a.shaped_slp || a.secondary) die("options -c, -n, -q, -Z are not implemented in moni-hip-align yet");
-    if (a.patterns.empty()) die("no reads given (-p)");
+    const bool paired = !a.mate1.empty() || !a.mate2.empty();
+    if (paired && (a.mate1.empty() || a.mate2.empty())) die("paired-end alignment needs both -1 and -2");
+    if (paired && (a.report_mems || a.legacy_ms || a.legacy_mems)) die("-m / --ms / --mems take single-end input (-p)");
+    if (!paired && a.patterns.empty()) die("no reads given (-p)");
     std::string fn = a.filename;
     std::vector<char> tmp(fn.begin(), fn.end()); tmp.push_back(0);
     const std::string base_name = basename(tmp.data());
-    std::string sam_filename = a.patterns + "_" + base_name + "_" + std::to_string(a.P.min_len) + ".sam";   // align_full_ksw2.cpp:347-349
+    std::string sam_filename = (paired ? a.mate1 : a.patterns) + "_" + base_name + "_" + std::to_string(a.P.min_len) + ".sam";   // align_full_ksw2.cpp:347-353
     if (!a.output.empty()) sam_filename = a.output;
+    if (paired) return run_paired(a, sam_filename);
     const bool legacy = a.legacy_ms || a.legacy_mems;
     if (legacy && a.output.empty()) sam_filename = a.patterns + "_" + base_name;       // mems.cpp / matching_statistics.cpp: <patterns>_<index> + .mems / .pointers / .lengths
     info("Output file: " + sam_filename);

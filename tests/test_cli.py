@@ -155,3 +155,35 @@ def test_cli_on_the_reference_mouse_reads_planted_in_a_pangenome(exe, tmp_path):
     got = open(out, "rb").read()
     assert got == want
     assert cnt["aligned"] >= 790
+
+
+@pytest.mark.gpu
+def test_cli_paired_end(exe, medium_case, tmp_path):
+    """-1 / -2 -u: st_align's paired loop (learn on batches of -b pairs, align them, then the rest) through the binary, against the
+    oracle's paired path (oracle/align_pe.hpp); one mate file gzip-compressed (the kseq-style reader), the other plain (mmap)."""
+    from oracle import orc
+    from tests.test_host_sim_pe import oracle_pe
+    from tests.test_oracle_pe import make_pairs
+    m1, m2, _ = make_pairs(medium_case.pg, 1500, L=100)
+    f1, f2 = str(tmp_path / "m_1.fastq"), str(tmp_path / "m_2.fastq.gz")
+    with open(f1, "wb") as f:
+        for i, r in enumerate(m1):
+            f.write(b"@p%d/1 first mate\n%s\n+\n%s\n" % (i, r.tobytes(), b"I" * len(r)))
+    with gzip.open(f2, "wb") as f:
+        for i, r in enumerate(m2):
+            f.write(b"@p%d/2\n%s\n+\n%s\n" % (i, r.tobytes(), b"I" * len(r)))
+    prefix = medium_case.path[:-4]
+    out = str(tmp_path / "pe.sam")
+    log = subprocess.check_output([exe, prefix, "-1", f1, "-2", f2, "-u", "-o", out, "-S", "1000", "-F", "0.5", "-t", "4", "-b", "512", "--gpu-batch", "2048"]).decode()
+    o = orc.OracleIndex(medium_case.path)
+    want, st = oracle_pe(o, m1, m2, b_size=512)
+    hdr, _ = orc.align_batch(o, np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, np.uint8), np.zeros(1, np.uint64), None, with_header=True)
+    got = open(out, "rb").read()
+    assert got[:len(hdr)] == hdr
+    if got[len(hdr):] != want:
+        from tests.test_host_sim_pe import first_diff
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got[len(hdr):], want))
+    assert ("Number of aligned pairs: %d/1500" % st["aligned"]) in log
+    # without -u the binary refuses (no orphan recovery)
+    r = subprocess.run([exe, prefix, "-1", f1, "-2", f2], capture_output=True)
+    assert r.returncode == 1 and b"orphan recovery is not implemented" in r.stderr

@@ -1,8 +1,8 @@
 // oracle/ - CPU restatement of the reference algorithm; test infrastructure only (tests/, __graft_entry__.smoke(), bench.py's
 // cpu_baseline leg).  NOT linked into the product.
 //
-// align_pe.hpp: the PAIRED-END path of aligner<seed_finder_t> (include/aligner/aligner_ksw2.hpp) restated on top of align.hpp, as
-// groundwork for SURVEY.md 8(f)-2 (the product has no paired-end path yet).  Followed, in order:
+// align_pe.hpp: the PAIRED-END path of aligner<seed_finder_t> (include/aligner/aligner_ksw2.hpp) restated on top of align.hpp: the checker of
+// the product's paired path (moni_pe_learn_batch / moni_pe_align_batch).  Followed, in order:
 //   aligner_ksw2.hpp:598-700    orphan_paired_score_t / paired_score_t (operator> used by std::sort)
 //   aligner_ksw2.hpp:702-812    paired_alignment_t (min scores, remove_slash_mate, RNEXT)
 //   aligner_ksw2.hpp:816-885    learn_fragment_model (Welford, merged across batches)

@@ -1,5 +1,5 @@
-"""The paired-end restatement of the oracle (oracle/align_pe.hpp: groundwork for SURVEY.md 8(f)-2; the product has no paired-end path,
-and nothing in the reference tree pins paired-end output).  What can be checked without a reference binary: on simulated FR pairs
+"""The paired-end restatement of the oracle (oracle/align_pe.hpp: the checker of the product's paired path, tests/test_gpu_pe.py;
+nothing in the reference tree pins paired-end output).  What can be checked without a reference binary: on simulated FR pairs
 with a known insert-size distribution the learnt model is the simulated one, proper pairs carry the SAM invariants (complementary flags,
 mirrored TLEN, PNEXT = the mate's POS, RNEXT '='), each mate's alignment is what the single-end path gives for a uniquely placed read,
 and the batch order of st_align (learn first, then align the learning batches, then the rest) keeps the records in input order."""

@@ -78,8 +78,13 @@ struct HostIndex {                 // host copies of what the host stages read (
         const moni_lift_seq_t& L = lift_seqs[rk - 1];
         uint64_t units = 0;
         for (uint32_t k = 0; k < n_cig; ++k) units += cig[k] >> 4;
-        out.resize(2 * (size_t)n_cig + 2 * (size_t)L.n_runs + 4);
-        const int n = lift_cigar(lift_runs.data() + L.run_off, L.n_runs, pos - select1(rk), cig, n_cig, out.data(), (uint32_t)out.size());
+        // an alignment crosses few runs: try a small buffer first (the full bound is two entries per run of the sequence: tens of KB to clear)
+        out.resize(2 * (size_t)n_cig + 64);
+        int n = lift_cigar(lift_runs.data() + L.run_off, L.n_runs, pos - select1(rk), cig, n_cig, out.data(), (uint32_t)out.size());
+        if (n < 0) {
+            out.resize(2 * (size_t)n_cig + 2 * (size_t)L.n_runs + 4);
+            n = lift_cigar(lift_runs.data() + L.run_off, L.n_runs, pos - select1(rk), cig, n_cig, out.data(), (uint32_t)out.size());
+        }
         out.resize(n < 0 ? 0 : (size_t)n);
         (void)units;
     }

@@ -39,8 +39,10 @@ struct pe_args_t {
     const uint64_t* offs;
     const int32_t* min_score_of_len;
     uint32_t max_len;
-    uint64_t n_pairs;
-    pe_slot_t* slots;                        // gridDim.x * AK_NL
+    uint64_t pair_lo, n_pairs;               // this launch takes pairs [pair_lo, pair_lo + n_pairs) of the resident batch; records go to recs[pair - pair_lo]
+    uint32_t nl, pad;                        // pairs in flight per wavefront (lanes 0 .. nl-1 run state machines): the wave solves its pairs' DP problems one after
+                                             // the other, so fewer pairs per wave = shorter serial DP phases, more waves
+    pe_slot_t* slots;                        // gridDim.x * nl
     ak_wave_t* waves;                        // gridDim.x
     pe_rec_t* recs;
     uint32_t* cig_pool; uint64_t cig_cap;
@@ -69,7 +71,7 @@ __device__ __attribute__((noinline)) void pe_write_record(const pe_args_t& A, co
             for (uint32_t i = 0; i < S.n_alt[k]; ++i) { moni_alt_t x; x.pos = S.alt_pos[k][i]; x.score = S.alt_score[k][i]; x.pad = 0; A.alt_pool[ao + i] = x; }
         }
     }
-    A.recs[pair] = R;
+    A.recs[pair - A.pair_lo] = R;
 }
 
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
@@ -80,18 +82,19 @@ pe_align_kernel(const pe_args_t A) {
     const int lane = threadIdx.x;
     if (lane < 2) s_cnt[lane] = 0;
     __syncthreads();
-    pe_slot_t* __restrict__ S = A.slots + (size_t)blockIdx.x * AK_NL + (lane < AK_NL ? lane : 0);
+    const int NL = (int)A.nl;
+    pe_slot_t* __restrict__ S = A.slots + (size_t)blockIdx.x * NL + (lane < NL ? lane : 0);
     pe_ws_t& W = S->ws;
     uint8_t* __restrict__ dirs = A.waves[blockIdx.x].dirs;
-    int state = lane < AK_NL ? 0 : 2;             // 0: wants a pair, 1: waits for DP results, 2: no more pairs, 3: finished, record not yet written
+    int state = lane < NL ? 0 : 2;             // 0: wants a pair, 1: waits for DP results, 2: no more pairs, 3: finished, record not yet written
     uint64_t pair = 0;
     while (true) {
         // ---- phase 1 (lane-private): take a pair; seeds -> chains -> first DP request ----
-        const bool start = __popcll(__ballot(state == 0 || state == 3)) >= AK_START_MIN || __ballot(state == 1) == 0ull;
+        const bool start = __popcll(__ballot(state == 0 || state == 3)) >= (NL + 1) / 2 || __ballot(state == 1) == 0ull;
         if (state == 3 && start) { pe_write_record(A, W, pair); state = 0; }
         if (state == 0 && start) {
-            pair = atomicAdd(&A.cursors[4], 1ull);
-            if (pair >= A.n_pairs) state = 2;
+            pair = A.pair_lo + atomicAdd(&A.cursors[4], 1ull);
+            if (pair >= A.pair_lo + A.n_pairs) state = 2;
             else {
                 bool chained = false;
                 for (int k = 0; k < 2; ++k) {
@@ -116,7 +119,7 @@ pe_align_kernel(const pe_args_t A) {
         // ---- phase 2 (whole wave): the DP problems of every waiting pair, one pair after the other ----
         for (unsigned long long todo = waiting; todo; todo &= todo - 1) {
             const int src = __ffsll((long long)todo) - 1;
-            pe_slot_t* __restrict__ Q = A.slots + (size_t)blockIdx.x * AK_NL + src;
+            pe_slot_t* __restrict__ Q = A.slots + (size_t)blockIdx.x * NL + src;
             const uint32_t* __restrict__ tsrc = reinterpret_cast<const uint32_t*>(Q->ws.W.tasks);
             constexpr uint32_t TW = AC_MAX_TASKS * (uint32_t)(sizeof(moni_dp_task_t) / 4);
             const uint32_t nt = Q->ws.W.n_tasks;

@@ -331,6 +331,7 @@ char* sim_align_pe_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint
     std::string out;
     uint64_t n_aligned = 0, n_over = 0, n_tasks = 0, n_rounds = 0;
     pe_ws_t* W = new pe_ws_t();
+    double t_emit = 0, t_fast = 0; std::string fast; uint64_t n_fast_diff = 0;
     for (uint64_t p = 0; p < n_pairs; ++p) {
         for (int k = 0; k < 2; ++k) {
             W->off[k] = offs[2 * p + k] - offs[0]; W->m[k] = (uint32_t)(offs[2 * p + k + 1] - offs[2 * p + k]);
@@ -364,10 +365,26 @@ char* sim_align_pe_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint
             M.alt_pos = W->alt_pos[k]; M.alt_score = W->alt_score[k]; M.n_alt = W->n_alt[k];
         }
         if (R.finalized) ++n_aligned;
+        const size_t line_at = out.size();
+        const double e0 = mh::now_s();
         mh::pe_emit(A, P, R, std::string((const char*)names + name_off[2 * p], (const char*)names + name_off[2 * p + 1]),
                     std::string((const char*)names + name_off[2 * p + 1], (const char*)names + name_off[2 * p + 2]), seq, quals, out);
+        t_emit += mh::now_s() - e0;
+        {   // the one-pass emitter the product runs must spell the same two lines
+            const double f0 = mh::now_s();
+            fast.clear();
+            mh::pe_emit_fast(A, P, R, (const char*)names + name_off[2 * p], (size_t)(name_off[2 * p + 1] - name_off[2 * p]), (const char*)names + name_off[2 * p + 1],
+                             (size_t)(name_off[2 * p + 2] - name_off[2 * p + 1]), seq, quals, fast);
+            t_fast += mh::now_s() - f0;
+            if (fast.size() != out.size() - line_at || memcmp(fast.data(), out.data() + line_at, fast.size()) != 0) {
+                if (!n_fast_diff) fprintf(stderr, "host_sim pe: fast emitter differs at pair %llu:\n%s%s", (unsigned long long)p, fast.c_str(), out.c_str() + line_at);
+                ++n_fast_diff;
+            }
+        }
     }
     delete W;
+    if (getenv("MH_TIMES")) fprintf(stderr, "host_sim pe: %.3f us per pair in pe_emit, %.3f in pe_emit_fast (%llu pairs)\n", t_emit / (double)(n_pairs ? n_pairs : 1) * 1e6, t_fast / (double)(n_pairs ? n_pairs : 1) * 1e6, (unsigned long long)n_pairs);
+    if (n_fast_diff) return nullptr;
     char* buf = (char*)malloc(out.size() + 1);
     memcpy(buf, out.data(), out.size() + 1);
     *out_len = out.size();

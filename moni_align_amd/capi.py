@@ -97,11 +97,14 @@ _lib = None
 
 def build_lib(force: bool = False) -> str:
     """hipcc cross-compiles for gfx950 without a GPU."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".hpp", ".inc"))]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".hpp", ".inc", ".cpp"))]
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "moni_hip.h"))
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        # pe_big.cpp: host-only translation unit (the paired state machine with large capacities, its own namespace)
+        big_o = os.path.join(CSRC, "pe_big.o")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-c", os.path.join(CSRC, "pe_big.cpp"), "-o", big_o])
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               "-o", LIB_PATH, os.path.join(CSRC, "moni_hip.hip")])
+                               "-o", LIB_PATH, os.path.join(CSRC, "moni_hip.hip"), "-Wl," + big_o])      # (as a linker input: hipcc would read a bare .o as HIP source)
     return LIB_PATH
 
 

@@ -30,6 +30,7 @@
 #define DP_T_REV 0x10
 #endif
 
+#ifndef AC_MAX_MEMS                // (pe_big.cpp compiles this header a second time, in its own namespace, with large capacities)
 #define AC_MAX_MEMS 96
 #define AC_MAX_ANCH 512
 #define AC_MAX_CHAINS 256
@@ -38,8 +39,9 @@
 #define AC_MAX_LEFT 256
 #define AC_MAX_ALT 64
 #define AC_MAX_FILL 16          // anchors of one chain that fill_chain handles
-#define AC_MAX_TASKS (2 * (AC_MAX_FILL + 2))      // one round of a pair: both mates' fills (pe_core.h)
 #define AC_MAX_CIGAR 512
+#endif
+#define AC_MAX_TASKS (2 * (AC_MAX_FILL + 2))      // one round of a pair: both mates' fills (pe_core.h)
 
 struct ac_mem_t { uint64_t pos; const uint64_t* occs; uint32_t len, idx, rpos, mate, nocc; };
 struct ac_anchor_t { uint64_t x; uint32_t mem, occ; };                 // x = reference end of the anchor (the sort key)

@@ -27,6 +27,7 @@
 #include "align_kernel.hip"
 #include "pe_kernel.hip"
 #include "pe_host.hpp"
+#include "pe_big.h"
 #include "align_fast.hip"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "moni_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return MONI_ENODEV; } } while (0)

@@ -10,7 +10,9 @@
 
 #include "align_core.h"
 
+#ifndef PE_MAX_BEST
 #define PE_MAX_BEST 64
+#endif
 
 struct pe_params_t {
     ac_params_t P;

@@ -89,3 +89,44 @@ def test_pe_250bp_lifted_index(case):
     assert model.count == st["ins_count"] and model.mean == st["ins_mean"] and model.std_dev == st["ins_std_dev"]
     if got != want:
         raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
+
+
+def test_pe_host_pipeline_forced(case, monkeypatch):
+    """every third pair is treated as beyond pe_align_kernel's capacities (MONI_PE_FORCE_BIG): it goes through the host pipeline for pairs
+    (pe_big.cpp: the same state machine with large capacities, DP batches on the GPU) and must come out the same"""
+    pg, fi, o = case
+    m1, m2 = hard_pairs(pg, n=400, seed=31)
+    want, st = oracle_pe(o, m1, m2, slash=False, b_size=4096)
+    seq, offs, names, noff, q = interleave(m1, m2, slash=False)
+    monkeypatch.setenv("MONI_PE_FORCE_BIG", "3")
+    got, model, aligned = on_gpu(fi, seq, offs, names, noff, q, 4096)
+    assert model.count == st["ins_count"] and model.mean == st["ins_mean"] and model.std_dev == st["ins_std_dev"]
+    if got != want:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
+
+
+def test_pe_exact_repeats_overflow_the_kernel():
+    """a 600-base segment copied 60 times: every MEM inside it has hundreds of occurrences, the pairs exceed the kernel's 512 anchors and
+    are taken by the host pipeline for pairs (stats: handed_back)"""
+    rng = np.random.default_rng(11)
+    base = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=60000)].copy()
+    seg = base[1000:1600].copy()
+    for k in range(60):
+        base[2000 + k * 900:2600 + k * 900] = seg
+    pg = synth.make_pangenome(60000, 4, site_spacing=2500, base=base)
+    fi = index_build.build_from_pangenome(pg, device="cpu")
+    o = orc.OracleIndex(fi=fi)
+    m1, m2, _ = make_pairs(pg, 300, L=100, mean=350, sd=30, seed=5)
+    want, st = oracle_pe(o, m1, m2, b_size=1024)
+    seq, offs, names, noff, q = interleave(m1, m2)
+    idx = capi.Index(fi=fi)
+    ctx = capi.Ctx(idx)
+    try:
+        model = ctx.pe_learn(seq, offs)
+        got, gst = ctx.pe_align(seq, offs, names, noff, q, model, host_threads=4)
+    finally:
+        ctx.close(); idx.close()
+    assert model.count == st["ins_count"] and model.mean == st["ins_mean"] and model.std_dev == st["ins_std_dev"]
+    assert gst["handed_back"] > 50
+    if got != want:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))

@@ -229,7 +229,7 @@ typedef struct {
 } moni_pe_model_t;
 void moni_pe_params_default(moni_pe_params_t *p);
 /* aligner::learn_fragment_model (aligner_ksw2.hpp:816-885) over one batch: updates *model.  MONI_ERANGE: a pair exceeded the
- * kernel's capacities (there is no host pipeline for pairs). */
+ * kernel's capacities and those of the host pipeline for pairs behind it (32 k anchors, mates of 32 k bases). */
 int moni_pe_learn_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const moni_align_params_t *prm,
                         const moni_pe_params_t *pe, moni_pe_model_t *model);
 /* The two SAM records of every pair, in input order, no header.  names / name_off / quals as in moni_align_batch (2N reads).

@@ -393,7 +393,7 @@ static int run_paired(Args& a, const std::string& sam_filename) {
         moni_read_batch_t rb{b.seq.data(), b.off.data(), b.n()};
         moni_align_stats_t st;
         const int rc = moni_pe_align_batch(ctx[g], &rb, b.names.data(), b.name_off.data(), b.has_qual ? b.qual.data() : nullptr, &a.P, &a.PE, &model, sam, len, &st);
-        if (rc) die("moni_pe_align_batch failed (" + std::to_string(rc) + (rc == MONI_ERANGE ? ": a pair exceeds the paired kernel's capacities)" : ")"));
+        if (rc) die("moni_pe_align_batch failed (" + std::to_string(rc) + (rc == MONI_ERANGE ? ": a pair exceeds the paired path's capacities)" : ")"));
         *n_al = st.aligned;
     };
     std::vector<Batch*> learnt;

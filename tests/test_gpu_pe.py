@@ -130,3 +130,20 @@ def test_pe_exact_repeats_overflow_the_kernel():
     assert gst["handed_back"] > 50
     if got != want:
         raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
+
+
+def test_pe_chunking_and_wave_shape_are_invisible(case, monkeypatch):
+    """many small chunks (the double-buffered records / pools are reused every second chunk, the host finishing of one chunk runs beside
+    the next chunk's kernel) and another number of pairs per wave must give the same bytes as one chunk - and the oracle's"""
+    pg, fi, o = case
+    m1, m2, _ = make_pairs(pg, 6000, seed=41)
+    want, st = oracle_pe(o, m1, m2, b_size=512)
+    seq, offs, names, noff, q = interleave(m1, m2)
+    a, model_a, _ = on_gpu(fi, seq, offs, names, noff, q, 512)
+    monkeypatch.setenv("MONI_PE_CHUNK", "700")
+    monkeypatch.setenv("MONI_PE_NL", "5")
+    b, model_b, _ = on_gpu(fi, seq, offs, names, noff, q, 512)
+    assert model_a.mean == st["ins_mean"] and model_b.mean == st["ins_mean"] and model_b.std_dev == st["ins_std_dev"]
+    assert a == b
+    if a != want:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(a, want))

@@ -6,8 +6,11 @@
 //   aligner_ksw2.hpp:598-700    orphan_paired_score_t / paired_score_t (operator> used by std::sort)
 //   aligner_ksw2.hpp:702-812    paired_alignment_t (min scores, remove_slash_mate, RNEXT)
 //   aligner_ksw2.hpp:816-885    learn_fragment_model (Welford, merged across batches)
-//   aligner_ksw2.hpp:888-918    align(kpbseq_t*) - with orphan recovery DISABLED (-u): orphan_recovery / fill_orphan need klib's
-//                               ksw_align (absent submodule) and are not restated; a pair that fails jointly is written as it stands
+//   aligner_ksw2.hpp:888-918    align(kpbseq_t*): with find_orphan == false (-u) a pair that fails jointly is written as it stands (the
+//                               product's paired path is checked against this mode); with find_orphan == true:
+//   aligner_ksw2.hpp:1536-1640  orphan_recovery;  :2329-2560 paired_chain_orphan_score;  :2566-2720 fill_orphan, on klib's ksw_align
+//                               (thirdparty/klib, an absent submodule: ksw.c's ksw_i16 + the KSW_XSTART second pass restated below from
+//                               the published source as plain DP with its tie rules) - groundwork: the product has no orphan recovery
 //   aligner_ksw2.hpp:1000-1326  align(paired_alignment_t&, finalize): seeding of the four (mate, strand) patterns with r_offset,
 //                               direction filter, frequency filter, chaining, get_best_scores, final paired_chain_score
 //   aligner_ksw2.hpp:1329-1431  get_best_scores;  :1471-1534 check_paired_left_MEM;  :2115-2290 paired_chain_score
@@ -49,6 +52,7 @@ struct pe_config_t {               // aligner_ksw2.hpp:94-128 defaults
     bool filter_dir = true;
     double dir_thr = 50.0;
     size_t ins_learning_n = 1000, ins_learning_score_gap_threshold = 0;
+    bool find_orphan = false;          // aligner_ksw2.hpp:128 (true in the reference; -u clears it).  The product is checked against false
 };
 
 struct aligner_pe : aligner {
@@ -58,6 +62,7 @@ struct aligner_pe : aligner {
     double ins_mean = 0.0, ins_std_dev = 0.0, ins_variance = 0.0, ins_sample_variance = 0.0, ins_m2 = 0.0;
     size_t ins_count = 0;
     bool ins_learning_complete = false;
+    size_t orphan_pairs = 0, orphan_recovered = 0;      // statistics_t::orphan_reads / orphan_recovered_reads
 
     aligner_pe(const FlatIndex& ix_, const align_config_t& c, const pe_config_t& p = pe_config_t())
         : aligner(ix_, c), pe(p), max_penalty((int8_t)std::max(c.smatch + c.smismatch, c.gapo + c.gape)) {}
@@ -156,6 +161,44 @@ struct aligner_pe : aligner {
         return tot;
     }
 
+    // the tail of paired_chain_score / paired_chain_orphan_score (aligner_ksw2.hpp:2200-2288, 2470-2556): PNEXT / TLEN / flags / paired MAPQ,
+    // or one mate placed by the other
+    void pair_tail(paired_alignment_t& al, const int32_t tot, const score_t& m1, const score_t& m2, const uint8_t strand, const read_t* mate1, const read_t* mate2) {
+        sam_t& sam_m1 = al.sam_m1; sam_t& sam_m2 = al.sam_m2;
+        if (m1.score >= al.min_score_m1 && !m1.unmapped_lft && m2.score >= al.min_score_m2 && !m2.unmapped_lft) {
+            sam_m1.pnext = sam_m2.pos; sam_m2.pnext = sam_m1.pos;
+            ll tlen;
+            if (sam_m2.pos > sam_m1.pos) { tlen = (sam_m2.pos + mate2->seq.size()) - sam_m1.pos; sam_m1.tlen = tlen; sam_m2.tlen = -tlen; }
+            else { tlen = (sam_m1.pos + mate1->seq.size()) - sam_m2.pos; sam_m1.tlen = -tlen; sam_m2.tlen = tlen; }
+            const int32_t score_un = 0;
+            compute_mapq_pe_bwa(tot, al.score2, score_un, cfg.smatch, al.sub_n, al.frac_rep_m1, al.frac_rep_m2, m1.score, m2.score,
+                                al.score2_m1, al.score2_m2, sam_m1.mapq, sam_m2.mapq);
+            sam_m1.as = tot; sam_m2.as = tot;
+            sam_m1.zs = al.score2; sam_m2.zs = al.score2;
+            sam_m1.flag = sam_m2.flag = 1 | 2;                                  // SAM_PAIRED | SAM_MAPPED_PAIRED
+            if (strand) { sam_m1.flag |= 16 | 64; sam_m2.flag |= 32 | 128; }    // REVERSED | FIRST ; MATE_REVERSED | SECOND
+            else { sam_m1.flag |= 32 | 64; sam_m2.flag |= 16 | 128; }
+        } else if (m1.score >= al.min_score_m1 && !m1.unmapped_lft) {
+            sam_m1.zs = al.score2_m1;
+            sam_m1.flag = 1 | 8 | 64;                                           // PAIRED | MATE_UNMAPPED | FIRST
+            sam_m2.flag = 1 | 4 | 128;                                          // PAIRED | UNMAPPED | SECOND
+            if (strand) sam_m1.flag |= 16;
+            sam_m2.rname = sam_m1.rname; sam_m2.pos = sam_m1.pos; sam_m2.mapq = sam_m1.mapq; sam_m2.cigar = "*";
+            sam_m2.pnext = sam_m1.pnext = sam_m1.pos;
+            sam_m2.tlen = sam_m1.tlen = 0;
+        } else if (m2.score >= al.min_score_m2 && !m2.unmapped_lft) {
+            sam_m1.zs = al.score2_m2;                                           // sic (aligner_ksw2.hpp:2258)
+            sam_m1.flag = 1 | 4 | 64;
+            sam_m2.flag = 1 | 8 | 128;
+            if (not strand) sam_m2.flag |= 16;
+            sam_m1.rname = sam_m2.rname; sam_m1.pos = sam_m2.pos; sam_m1.mapq = sam_m2.mapq; sam_m1.cigar = "*";
+            sam_m1.pnext = sam_m2.pnext = sam_m2.pos;
+            sam_m1.tlen = sam_m2.tlen = 0;
+        } else {
+            sam_m1.flag = sam_m2.flag = 1 | 4 | 8;
+        }
+    }
+
     // aligner_ksw2.hpp:2115-2290
     paired_score_t paired_chain_score(paired_alignment_t& al, const size_t chain_i, const bool score_only = true) {
         auto& chain = al.chains[chain_i];
@@ -187,38 +230,7 @@ struct aligner_pe : aligner {
         score.m2.lft = ix.lift(score.m2.pos);
         if (score_only) return score;
         sam_m1.read = mate1; sam_m2.read = mate2;
-        if (score.m1.score >= al.min_score_m1 && !score.m1.unmapped_lft && score.m2.score >= al.min_score_m2 && !score.m2.unmapped_lft) {
-            sam_m1.pnext = sam_m2.pos; sam_m2.pnext = sam_m1.pos;
-            ll tlen;
-            if (sam_m2.pos > sam_m1.pos) { tlen = (sam_m2.pos + mate2->seq.size()) - sam_m1.pos; sam_m1.tlen = tlen; sam_m2.tlen = -tlen; }
-            else { tlen = (sam_m1.pos + mate1->seq.size()) - sam_m2.pos; sam_m1.tlen = -tlen; sam_m2.tlen = tlen; }
-            const int32_t score_un = 0;
-            compute_mapq_pe_bwa(score.tot, al.score2, score_un, cfg.smatch, al.sub_n, al.frac_rep_m1, al.frac_rep_m2, score.m1.score, score.m2.score,
-                                al.score2_m1, al.score2_m2, sam_m1.mapq, sam_m2.mapq);
-            sam_m1.as = score.tot; sam_m2.as = score.tot;
-            sam_m1.zs = al.score2; sam_m2.zs = al.score2;
-            sam_m1.flag = sam_m2.flag = 1 | 2;                                  // SAM_PAIRED | SAM_MAPPED_PAIRED
-            if (strand) { sam_m1.flag |= 16 | 64; sam_m2.flag |= 32 | 128; }    // REVERSED | FIRST ; MATE_REVERSED | SECOND
-            else { sam_m1.flag |= 32 | 64; sam_m2.flag |= 16 | 128; }
-        } else if (score.m1.score >= al.min_score_m1 && !score.m1.unmapped_lft) {
-            sam_m1.zs = al.score2_m1;
-            sam_m1.flag = 1 | 8 | 64;                                           // PAIRED | MATE_UNMAPPED | FIRST
-            sam_m2.flag = 1 | 4 | 128;                                          // PAIRED | UNMAPPED | SECOND
-            if (strand) sam_m1.flag |= 16;
-            sam_m2.rname = sam_m1.rname; sam_m2.pos = sam_m1.pos; sam_m2.mapq = sam_m1.mapq; sam_m2.cigar = "*";
-            sam_m2.pnext = sam_m1.pnext = sam_m1.pos;
-            sam_m2.tlen = sam_m1.tlen = 0;
-        } else if (score.m2.score >= al.min_score_m2 && !score.m2.unmapped_lft) {
-            sam_m1.zs = al.score2_m2;                                           // sic (aligner_ksw2.hpp:2258)
-            sam_m1.flag = 1 | 4 | 64;
-            sam_m2.flag = 1 | 8 | 128;
-            if (not strand) sam_m2.flag |= 16;
-            sam_m1.rname = sam_m2.rname; sam_m1.pos = sam_m2.pos; sam_m1.mapq = sam_m2.mapq; sam_m1.cigar = "*";
-            sam_m1.pnext = sam_m2.pnext = sam_m2.pos;
-            sam_m1.tlen = sam_m2.tlen = 0;
-        } else {
-            sam_m1.flag = sam_m2.flag = 1 | 4 | 8;
-        }
+        pair_tail(al, score.tot, score.m1, score.m2, strand, mate1, mate2);
         return score;
     }
 
@@ -324,6 +336,219 @@ struct aligner_pe : aligner {
         return al.aligned;
     }
 
+    // ---- klib ksw.c (attractivechaos/klib; the submodule is empty): kswr_t of ksw_align(.., xtra = KSW_XSTART) through ksw_i16 -------------
+    // Local alignment, rows = target.  H = max(0, diag + s, E, F); E / F lose gape per step and restart from H - (gapo + gape), never below 0
+    // (unsigned saturating subtraction).  te: the first row whose maximum exceeds every earlier row's; qe: the smallest query index holding
+    // that row's maximum.  The second pass aligns the reversed prefixes and stops at the first row that reaches the score: tb / qb.
+    struct kswr_t { int score = 0, te = -1, qe = -1, score2 = -1, te2 = -1, tb = -1, qb = -1; };
+    static kswr_t ksw_pass(int qlen, const uint8_t* q, int tlen, const uint8_t* t, int m_, const int8_t* mat_, int gapo_, int gape_, int endsc) {
+        kswr_t r;
+        std::vector<int> H0(qlen + 1, 0), H1(qlen + 1, 0), E(qlen + 1, 0), Hmax(qlen + 1, 0);
+        const int gapoe = gapo_ + gape_;
+        int gmax = 0, te = -1;
+        for (int i = 0; i < tlen; ++i) {
+            int f = 0, imax = 0;
+            const int8_t* row = mat_ + (int)t[i] * m_;
+            for (int j = 0; j < qlen; ++j) {
+                int h = (j ? H0[j - 1] : 0) + row[q[j]];
+                h = std::max(h, E[j]); h = std::max(h, f);
+                H1[j] = h;
+                imax = std::max(imax, h);
+                const int hh = std::max(h - gapoe, 0);
+                E[j] = std::max(std::max(E[j] - gape_, 0), hh);
+                f = std::max(std::max(f - gape_, 0), hh);
+            }
+            if (imax > gmax) { gmax = imax; te = i; Hmax = H1; if (gmax >= endsc) break; }
+            std::swap(H0, H1);
+        }
+        r.score = gmax; r.te = te;
+        int mx = -1;
+        for (int j = 0; j < qlen; ++j) if (Hmax[j] > mx) { mx = Hmax[j]; r.qe = j; }
+        return r;
+    }
+    static kswr_t ksw_align(int qlen, uint8_t* query, int tlen, uint8_t* target, int m_, const int8_t* mat_, int gapo_, int gape_) {
+        kswr_t r = ksw_pass(qlen, query, tlen, target, m_, mat_, gapo_, gape_, 0x10000);
+        std::reverse(query, query + (r.qe + 1)); std::reverse(target, target + (r.te + 1));
+        const kswr_t rr = ksw_pass(r.qe + 1, query, tlen, target, m_, mat_, gapo_, gape_, r.score);
+        std::reverse(query, query + (r.qe + 1)); std::reverse(target, target + (r.te + 1));
+        if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
+        return r;
+    }
+
+    struct orphan_paired_score_t {     // aligner_ksw2.hpp:599-622
+        int32_t tot = 0;
+        int64_t dist = 0;
+        score_t m1, m2;
+        size_t chain_i = 0;
+        std::pair<size_t, size_t> pos = std::make_pair(0, 0);
+    };
+    static bool ops_greater(const orphan_paired_score_t& lhs, const orphan_paired_score_t& rhs) {
+        return (lhs.tot > rhs.tot) or (lhs.tot == rhs.tot and lhs.m1.lft > rhs.m1.lft) or
+               (lhs.tot == rhs.tot and lhs.m1.lft == rhs.m1.lft and lhs.m2.lft > rhs.m2.lft);
+    }
+
+    // aligner_ksw2.hpp:2566-2720
+    score_t fill_orphan(ll& start, ll& end, const read_t* paired_mate, const bool score_only = true, sam_t* sam = nullptr) {
+        score_t score;
+        const size_t ref_occ = start;
+        ll ref_len = end - start + 1;
+        std::vector<uint8_t> refv(ref_len + 1);
+        uint8_t* ref = refv.data();
+        expand_nt4(ref_occ, ref_len, ref);
+        const size_t seq_len = paired_mate->seq.size();
+        std::vector<uint8_t> seqv(seq_len + 1);
+        uint8_t* seq = seqv.data();
+        for (size_t i = 0; i < seq_len; ++i) seq[i] = seq_nt4_table[(unsigned char)paired_mate->seq[i]];
+        if (score_only) {
+            const kswr_t r = ksw_align((int)seq_len, seq, (int)ref_len, ref, 5, mat, cfg.gapo, cfg.gape);
+            end = start + r.te;
+            start += r.tb;
+            const size_t ref_len_ = r.te - r.tb + 1;
+            ksw_extz_t ez;
+            memset(&ez, 0, sizeof(ksw_extz_t));
+            ksw_reset_extz(&ez);
+            if (r.tb >= 0) extz(seq_len, seq, ref_len_, ref + r.tb, KSW_EZ_SCORE_ONLY, &ez);      // (tb == -1 reads before the buffer in the reference)
+            score.score = ez.score;
+            score.pos = start;
+            if (not ix.valid(start, end - start + 1)) score.score = std::numeric_limits<int32_t>::min();
+            return score;
+        }
+        ksw_extz_t ez;
+        memset(&ez, 0, sizeof(ksw_extz_t));
+        ksw_reset_extz(&ez);
+        extz(seq_len, seq, ref_len, ref, KSW_EZ_RIGHT, &ez);
+        sam->lift_cigar = "";
+        for (int i = 0; i < ez.n_cigar; ++i) sam->lift_cigar += std::to_string(ez.cigar[i] >> 4) + "MID"[ez.cigar[i] & 0xf];
+        sam->lift_nm = write_MD_core(ref, seq, ez.cigar, ez.n_cigar, sam->lift_md);
+        const auto refi = ix.index(ref_occ);
+        sam->as = ez.score;
+        sam->lift_pos = refi.second + 1;
+        sam->lift_rname = ix.names[refi.first];
+        sam->lift_rlen = ref_len;
+        const std::vector<uint32_t> lft_cigar = ix.lift_cigar(ez.cigar, ez.n_cigar, ref_occ);
+        const auto lift = ix.lift(ref_occ);
+        const auto lft_ref = ix.index(lift);
+        sam->pos = lft_ref.second + 1;
+        sam->rname = ix.names[lft_ref.first];
+        sam->cigar = "";
+        for (size_t i = 0; i < lft_cigar.size(); ++i) sam->cigar += std::to_string(lft_cigar[i] >> 4) + "MID"[lft_cigar[i] & 0xf];
+        size_t l_len = 0;
+        for (size_t i = 0; i < lft_cigar.size(); ++i) { int op = lft_cigar[i] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) l_len += lft_cigar[i] >> 4; }
+        if (l_len > 0) {
+            std::vector<uint8_t> l_ref(l_len + 1);
+            expand_nt4(lift, l_len, l_ref.data());
+            sam->nm = write_MD_core(l_ref.data(), seq, lft_cigar.data(), lft_cigar.size(), sam->md);
+            sam->rlen = l_len;
+            score.score = ez.score;
+            score.pos = start;
+        } else {
+            sam->pos = 0; sam->rname = "*"; sam->cigar = "*"; sam->rlen = 0;
+            sam->unmapped_lft = true;
+            score.unmapped_lft = true;
+        }
+        free(ez.cigar);
+        return score;
+    }
+
+    // aligner_ksw2.hpp:2329-2560
+    orphan_paired_score_t paired_chain_orphan_score(paired_alignment_t& al, const size_t chain_i, const double mean, const double std_dev,
+                                                    const bool score_only = true, ll start = 0, ll end = 0) {
+        auto& chain = al.chains[chain_i];
+        chain.reverse();
+        const read_t* mate1; const read_t* mate2;
+        uint8_t strand = 0;
+        if ((chain.mate == 0) || ((chain.mate & MATE_RC) and (chain.mate & MATE_2))) { mate1 = &al.mate1; mate2 = &al.mate2_rev; }
+        else { mate1 = &al.mate1_rev; mate2 = &al.mate2; strand = 1; }
+        orphan_paired_score_t score;
+        score.chain_i = chain_i;
+        std::vector<size_t> c1, c2;
+        size_t lm_pos = (size_t)-1, rm_pos = 0;
+        for (size_t i = 0; i < chain.anchors.size(); ++i) {
+            const size_t a = chain.anchors[i];
+            const mem_t& mem = al.mems[al.anchors[a].first];
+            rm_pos = std::max(rm_pos, mem.occs[al.anchors[a].second] + mem.len);
+            lm_pos = std::min(lm_pos, mem.occs[al.anchors[a].second]);
+            if ((mem.mate & MATE_2) == 0) c1.push_back(a); else c2.push_back(a);
+        }
+        sam_t& sam_m1 = al.sam_m1; sam_t& sam_m2 = al.sam_m2;
+        const ll lim = (ll)(n - ix.w);
+        if (score_only) {
+            if (c1.size() > 0) {
+                score.m1 = chain_score(c1, al.anchors, al.mems, al.min_score_m1, mate1);
+                start = rm_pos + (ll)std::floor(mean - 4 * std_dev);
+                end = rm_pos + (ll)std::ceil(mean + 4 * std_dev);
+                start = std::max(start, (ll)0); start = std::min(start, lim); end = std::min(end, lim);
+                if (start < end) score.m2 = fill_orphan(start, end, mate2);
+                score.pos = std::make_pair((size_t)start, (size_t)end);
+            } else {
+                score.m2 = chain_score(c2, al.anchors, al.mems, al.min_score_m2, mate2);
+                start = lm_pos + (ll)std::floor(-mean - 4 * std_dev);
+                end = lm_pos + (ll)std::ceil(-mean + 4 * std_dev);
+                start = std::max(start, (ll)0); start = std::min(start, lim); end = std::min(end, lim);
+                if (start < end) score.m1 = fill_orphan(start, end, mate1);
+                score.pos = std::make_pair((size_t)start, (size_t)end);
+            }
+        } else {
+            if (c1.size() > 0) {
+                score.m1 = chain_score(c1, al.anchors, al.mems, al.min_score_m1, mate1, false, al.score2_m1, strand, &sam_m1, al.sub_n, al.frac_rep_m1);
+                if (start < end) score.m2 = fill_orphan(start, end, mate2, false, &sam_m2);
+                sam_m2.mapq = compute_mapq_se_bwa(sam_m2.as, al.score2_m2, sam_m2.rlen, mate2->seq.size(), cfg.min_len, cfg.smatch, cfg.smismatch,
+                                                  mapq_coeff_len, mapq_coeff_fac, al.sub_n, 0, al.frac_rep_m2);
+            } else {
+                if (start < end) score.m1 = fill_orphan(start, end, mate1, false, &sam_m1);
+                score.m2 = chain_score(c2, al.anchors, al.mems, al.min_score_m2, mate2, false, al.score2_m2, strand, &sam_m2, al.sub_n, al.frac_rep_m2);
+                sam_m1.mapq = compute_mapq_se_bwa(sam_m1.as, al.score2_m1, sam_m1.rlen, mate1->seq.size(), cfg.min_len, cfg.smatch, cfg.smismatch,
+                                                  mapq_coeff_len, mapq_coeff_fac, al.sub_n, 0, al.frac_rep_m1);
+            }
+        }
+        score.dist = (int64_t)ORC_DIST(score.m2.pos, (score.m1.pos + mate1->seq.size()));
+        {
+            paired_score_t tmp; tmp.dist = score.dist; tmp.m1 = score.m1; tmp.m2 = score.m2;
+            score.tot = pair_total(tmp, al);
+        }
+        score.m1.lft = ix.lift(score.m1.pos);
+        score.m2.lft = ix.lift(score.m2.pos);
+        if (score_only) return score;
+        sam_m1.read = mate1; sam_m2.read = mate2;
+        pair_tail(al, score.tot, score.m1, score.m2, strand, mate1, mate2);
+        return score;
+    }
+
+    // aligner_ksw2.hpp:1536-1640
+    bool orphan_recovery(paired_alignment_t& al, const double mean, const double std_dev) {
+        std::vector<orphan_paired_score_t> best_scores;
+        for (size_t i = 0; i < al.chains.size(); ++i) {
+            orphan_paired_score_t score = paired_chain_orphan_score(al, i, mean, std_dev);
+            if (score.tot >= al.min_score) {
+                bool replaced = false;
+                for (size_t j = 0; j < best_scores.size(); ++j) {
+                    orphan_paired_score_t zero; zero.chain_i = i;
+                    if ((ORC_DIST(best_scores[j].m1.lft, score.m1.lft) < cfg.region_dist) and (ORC_DIST(best_scores[j].m2.lft, score.m2.lft) < cfg.region_dist)) {
+                        if (score.tot > best_scores[j].tot) {
+                            if (replaced) best_scores[j] = zero;
+                            else { best_scores[j] = score; replaced = true; }
+                        } else if (score.tot <= best_scores[j].tot) { j = best_scores.size(); replaced = true; }
+                    }
+                }
+                if (not replaced) best_scores.push_back(score);
+            }
+        }
+        orphan_paired_score_t zero; zero.chain_i = al.chains.size();
+        while (best_scores.size() < 2) best_scores.push_back(zero);
+        std::sort(best_scores.begin(), best_scores.end(), ops_greater);
+        if (best_scores[0].tot < al.min_score) return false;
+        size_t j = 1;
+        al.sub_n = 0;
+        while (j < best_scores.size() and best_scores[j++].tot >= (best_scores[0].tot - max_penalty)) ++al.sub_n;
+        al.best_score = true;
+        al.score2 = best_scores[1].tot; al.score2_m1 = best_scores[1].m1.score; al.score2_m2 = best_scores[1].m2.score;
+        al.second_best_score = (al.score2 >= al.min_score);
+        const orphan_paired_score_t fin = paired_chain_orphan_score(al, best_scores[0].chain_i, mean, std_dev, false, (ll)best_scores[0].pos.first, (ll)best_scores[0].pos.second);
+        al.score.tot = fin.tot; al.score.dist = fin.dist; al.score.m1 = fin.m1; al.score.m2 = fin.m2; al.score.chain_i = fin.chain_i;
+        al.aligned = (al.score.tot >= al.min_score);
+        return al.aligned;
+    }
+
     // aligner_ksw2.hpp:816-885 (one thread: no mutex needed)
     bool learn_fragment_model(const std::vector<read_t>& m1, const std::vector<read_t>& m2) {
         size_t count = 0; double mean = 0.0, m2acc = 0.0;
@@ -353,14 +578,18 @@ struct aligner_pe : aligner {
         return ins_learning_complete;
     }
 
-    // aligner_ksw2.hpp:888-918 with find_orphan == false: both records of every pair, in order
+    // aligner_ksw2.hpp:888-918: both records of every pair, in order
     size_t align_batch(const std::vector<read_t>& m1, const std::vector<read_t>& m2, std::string& out) {
         size_t aligned = 0;
         for (size_t i = 0; i < m1.size(); ++i) {
             paired_alignment_t al;
             init(al, m1[i], m2[i]);
             al.mean = ins_mean; al.std_dev = ins_std_dev;
-            align(al, true);
+            if (not align(al, true) and al.chained) {              // aligner_ksw2.hpp:900-906
+                ++orphan_pairs;
+                if (pe.find_orphan) orphan_recovery(al, ins_mean, ins_std_dev);
+                if (al.aligned) ++orphan_recovered;
+            }
             write_sam(out, al.sam_m1);
             write_sam(out, al.sam_m2);
             if (al.aligned) ++aligned;

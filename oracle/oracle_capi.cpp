@@ -203,14 +203,16 @@ char* orc_align_batch(void* h, const uint8_t* seqs, const uint64_t* offsets, uin
     *out_len = all.size();
     return buf;
 }
-// Paired-end path (align_pe.hpp; orphan recovery off, i.e. the reference with -u), one thread, st_align's batch order: mate k of pair i is
+// Paired-end path (align_pe.hpp; find_orphan == 0: the reference with -u), one thread, st_align's batch order: mate k of pair i is
 // read i of batch k.  out[0] = aligned pairs, out[1..4] = the learnt insert-size model (count, mean, std dev, complete).
 char* orc_align_pe(void* h, const uint8_t* seqs1, const uint64_t* off1, const uint8_t* seqs2, const uint64_t* off2, uint64_t n_pairs,
                    const uint8_t* names1, const uint64_t* noff1, const uint8_t* names2, const uint64_t* noff2, const uint8_t* quals1,
-                   const uint8_t* quals2, uint64_t b_size, uint64_t* out_len, double* out) {
+                   const uint8_t* quals2, uint64_t b_size, int find_orphan, uint64_t* out_len, double* out) {
     const FlatIndex& ix = *(FlatIndex*)h;
     align_config_t cfg;
-    aligner_pe A(ix, cfg);
+    pe_config_t pcfg;
+    pcfg.find_orphan = find_orphan != 0;
+    aligner_pe A(ix, cfg, pcfg);
     std::vector<read_t> m1(n_pairs), m2(n_pairs);
     for (uint64_t i = 0; i < n_pairs; ++i) {
         m1[i].name.assign((const char*)names1 + noff1[i], (const char*)names1 + noff1[i + 1]);
@@ -222,12 +224,18 @@ char* orc_align_pe(void* h, const uint8_t* seqs1, const uint64_t* off1, const ui
     }
     std::string all;
     const size_t aligned = A.align_all(m1, m2, b_size ? b_size : 512, all);
-    if (out) { out[0] = (double)aligned; out[1] = (double)A.ins_count; out[2] = A.ins_mean; out[3] = A.ins_std_dev; out[4] = A.ins_learning_complete ? 1.0 : 0.0; }
+    if (out) { out[0] = (double)aligned; out[1] = (double)A.ins_count; out[2] = A.ins_mean; out[3] = A.ins_std_dev; out[4] = A.ins_learning_complete ? 1.0 : 0.0; out[5] = (double)A.orphan_pairs; out[6] = (double)A.orphan_recovered; }
     char* buf = (char*)malloc(all.size() + 1);
     memcpy(buf, all.data(), all.size());
     buf[all.size()] = 0;
     *out_len = all.size();
     return buf;
+}
+// klib's ksw_align (KSW_XSTART) as restated in align_pe.hpp: out = score, te, qe, tb, qb
+void orc_ksw_align(const uint8_t* q, int qlen, const uint8_t* t, int tlen, const int8_t* mat, int gapo, int gape, int* out) {
+    std::vector<uint8_t> qq(q, q + qlen), tt(t, t + tlen);
+    const aligner_pe::kswr_t r = aligner_pe::ksw_align(qlen, qq.data(), tlen, tt.data(), 5, mat, gapo, gape);
+    out[0] = r.score; out[1] = r.te; out[2] = r.qe; out[3] = r.tb; out[4] = r.qb;
 }
 // aligner::align with report_mems (-m): SAM text of the MEM records of a ragged batch
 char* orc_report_mems_batch(void* h, const uint8_t* seqs, const uint64_t* offsets, uint64_t n_reads, const uint8_t* names,

@@ -54,8 +54,10 @@ def lib():
         L.orc_seed_n_occs.argtypes = [ctypes.c_void_p]
         L.orc_seed_get.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.orc_seed_free.argtypes = [ctypes.c_void_p]
+        L.orc_ksw_align.restype = None
+        L.orc_ksw_align.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.orc_align_pe.restype = ctypes.c_void_p
-        L.orc_align_pe.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_uint64] + [ctypes.c_void_p] * 6 + [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]
+        L.orc_align_pe.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4 + [ctypes.c_uint64] + [ctypes.c_void_p] * 6 + [ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]
         L.orc_align_batch.restype = ctypes.c_void_p
         L.orc_align_batch.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint64] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int,
                                                                                                      ctypes.c_void_p, ctypes.c_void_p]
@@ -186,7 +188,8 @@ def align_batch(oidx: "OracleIndex", seqs: np.ndarray, offsets: np.ndarray, name
     return sam, {k: int(v) for k, v in zip(keys, cnt)}
 
 
-def align_pe(oidx: "OracleIndex", seqs1, offs1, seqs2, offs2, names1, noff1, names2, noff2, quals1=None, quals2=None, b_size: int = 512):
+def align_pe(oidx: "OracleIndex", seqs1, offs1, seqs2, offs2, names1, noff1, names2, noff2, quals1=None, quals2=None, b_size: int = 512,
+             find_orphan: bool = False):
     """SAM text (bytes) of the reference's paired-end path without orphan recovery (oracle/align_pe.hpp), one thread, st_align's
     batch order, plus {"aligned", "ins_count", "ins_mean", "ins_std_dev", "ins_complete"}."""
     c = lambda a, t: np.ascontiguousarray(a, dtype=t)
@@ -196,15 +199,16 @@ def align_pe(oidx: "OracleIndex", seqs1, offs1, seqs2, offs2, names1, noff1, nam
         quals1, quals2 = c(quals1, np.uint8), c(quals2, np.uint8)
     n = len(offs1) - 1
     out_len = ctypes.c_uint64()
-    st = np.zeros(5, dtype=np.float64)
+    st = np.zeros(7, dtype=np.float64)
     p = lib().orc_align_pe(oidx._h, seqs1.ctypes.data, offs1.ctypes.data, seqs2.ctypes.data, offs2.ctypes.data, n, names1.ctypes.data, noff1.ctypes.data,
                            names2.ctypes.data, noff2.ctypes.data, quals1.ctypes.data if quals1 is not None else None,
-                           quals2.ctypes.data if quals2 is not None else None, b_size, ctypes.byref(out_len), st.ctypes.data)
+                           quals2.ctypes.data if quals2 is not None else None, b_size, int(find_orphan), ctypes.byref(out_len), st.ctypes.data)
     try:
         sam = ctypes.string_at(p, out_len.value)
     finally:
         lib().orc_free(p)
-    return sam, {"aligned": int(st[0]), "ins_count": int(st[1]), "ins_mean": float(st[2]), "ins_std_dev": float(st[3]), "ins_complete": bool(st[4])}
+    return sam, {"aligned": int(st[0]), "ins_count": int(st[1]), "ins_mean": float(st[2]), "ins_std_dev": float(st[3]), "ins_complete": bool(st[4]),
+                 "orphan_pairs": int(st[5]), "orphan_recovered": int(st[6])}
 
 
 DEFAULT_MAT = np.array([2, -4, -4, -4, 0, -4, 2, -4, -4, 0, -4, -4, 2, -4, 0, -4, -4, -4, 2, 0, 0, 0, 0, 0, 0],
@@ -224,6 +228,16 @@ def extz(query: np.ndarray, target: np.ndarray, flag: int, m: int = 5, mat: np.n
     res = {k: int(v) for k, v in zip(keys, out)}
     res["cigar"] = cig[: res["n_cigar"]].copy()
     return res
+
+
+def ksw_align(query: np.ndarray, target: np.ndarray, mat: np.ndarray = None, gapo: int = 4, gape: int = 2):
+    """klib's ksw_align(.., KSW_XSTART) as restated in align_pe.hpp (nt4 codes): dict score / te / qe / tb / qb."""
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    target = np.ascontiguousarray(target, dtype=np.uint8)
+    mat = DEFAULT_MAT if mat is None else np.ascontiguousarray(mat, dtype=np.int8)
+    out = np.zeros(5, dtype=np.int32)
+    lib().orc_ksw_align(query.ctypes.data, len(query), target.ctypes.data, len(target), mat.ctypes.data, gapo, gape, out.ctypes.data)
+    return dict(zip(["score", "te", "qe", "tb", "qb"], (int(x) for x in out)))
 
 
 def report_mems_batch(oidx: "OracleIndex", seqs, offsets, names, name_off, quals=None) -> bytes:

@@ -105,3 +105,83 @@ def test_batch_order_and_small_inputs(case):
     assert [r[0] for r in recs[1::2]] == [b"q%d" % i for i in range(130)]
     # different names: RNEXT is the mate's name (aligner_ksw2.hpp:733-742)
     assert all(r[6] in (b"q%d" % i, b"=") for i, r in enumerate(recs[0::2]))
+
+
+def _naive_local(q, t, mat, gapo, gape):
+    """Gotoh local alignment with full matrices: best score and, for every cell, H (independent of the rolling-row restatement)"""
+    n, m = len(t), len(q)
+    H = np.zeros((n + 1, m + 1), np.int64); E = np.zeros((n + 1, m + 1), np.int64); F = np.zeros((n + 1, m + 1), np.int64)
+    for i in range(1, n + 1):
+        for j in range(1, m + 1):
+            E[i, j] = max(E[i - 1, j] - gape, H[i - 1, j] - gapo - gape, 0)
+            F[i, j] = max(F[i, j - 1] - gape, H[i, j - 1] - gapo - gape, 0)
+            H[i, j] = max(0, H[i - 1, j - 1] + int(mat[int(t[i - 1]) * 5 + int(q[j - 1])]), E[i, j], F[i, j])
+    return H
+
+
+def test_ksw_align_restatement_against_full_matrices():
+    """klib's ksw_align as restated for fill_orphan: the score is the full-matrix optimum, (te, qe) is the first row reaching it and the
+    leftmost query position in that row, and the reported start (tb, qb) bounds a segment whose best local score is the same"""
+    rng = np.random.default_rng(3)
+    mat = orc.DEFAULT_MAT
+    for trial in range(40):
+        m, n = int(rng.integers(20, 60)), int(rng.integers(40, 160))
+        t = rng.integers(0, 4, size=n).astype(np.uint8)
+        at = int(rng.integers(0, n - 15))
+        q = t[at:at + m].copy()[:m]
+        k = rng.random(len(q)) < 0.12
+        q[k] = (q[k] + 1) & 3
+        if trial % 5 == 0 and len(q) > 12:
+            q = np.concatenate([q[:6], q[9:]])          # a deletion in the query
+        if trial % 7 == 0:
+            t[int(rng.integers(0, n))] = 4              # an N in the target scores 0
+        r = orc.ksw_align(q, t)
+        H = _naive_local(q, t, mat, 4, 2)
+        assert r["score"] == int(H.max())
+        rows = np.where(H.max(axis=1) == H.max())[0]
+        assert r["te"] == int(rows[0]) - 1
+        assert r["qe"] == int(np.where(H[rows[0]] == H.max())[0][0]) - 1
+        assert 0 <= r["tb"] <= r["te"] and 0 <= r["qb"] <= r["qe"]
+        sub = _naive_local(q[r["qb"]:r["qe"] + 1], t[r["tb"]:r["te"] + 1], mat, 4, 2)
+        assert int(sub.max()) == r["score"] and int(sub[-1, -1]) == r["score"]      # the segment ends at its last cell with the whole score
+
+
+def test_orphan_recovery_places_the_seedless_mate(case):
+    """a mate with a substitution every 19 bases has no 25-base MEM: the pair fails jointly; with find_orphan the mate is found by local
+    alignment inside the window the fragment model predicts, and the pair comes out proper at the simulated position"""
+    pg, fi, o = case
+    m1, m2, truth = make_pairs(pg, 1200)
+    broken = list(range(7, 1200, 10))
+    for i in broken:
+        x = m2[i].copy()
+        for p in range(9, len(x), 19):
+            x[p] = ord("A") if x[p] != ord("A") else ord("C")
+        m2[i] = x
+    n, L = len(m1), 100
+    offs = np.arange(0, (n + 1) * L, L, dtype=np.uint64)
+    nm1 = [b"p%d/1" % i for i in range(n)]; nm2 = [b"p%d/2" % i for i in range(n)]
+    no1 = np.zeros(n + 1, np.uint64); no1[1:] = np.cumsum([len(x) for x in nm1])
+    no2 = np.zeros(n + 1, np.uint64); no2[1:] = np.cumsum([len(x) for x in nm2])
+    q = np.full(n * L, ord("I"), np.uint8)
+    args = (o, np.concatenate(m1), offs, np.concatenate(m2), offs, np.frombuffer(b"".join(nm1), np.uint8), no1, np.frombuffer(b"".join(nm2), np.uint8), no2, q, q)
+    off_sam, off_st = orc.align_pe(*args, b_size=512, find_orphan=False)
+    on_sam, on_st = orc.align_pe(*args, b_size=512, find_orphan=True)
+    ro = [l.split(b"\t") for l in off_sam.split(b"\n") if l]
+    rn = [l.split(b"\t") for l in on_sam.split(b"\n") if l]
+    assert on_st["ins_mean"] == off_st["ins_mean"] and on_st["orphan_pairs"] == off_st["orphan_pairs"] >= len(broken) - 5
+    # the search window lies to the right of the anchored mate when that is mate 1 and to the left when it is mate 2 (aligner_ksw2.hpp:2398-2420),
+    # whatever the strand: a fragment whose mate 1 is the reverse-strand end has its mate 2 on the other side and is not recovered - half of these
+    assert off_st["orphan_recovered"] == 0 and on_st["orphan_recovered"] >= len(broken) // 3
+    rec = 0
+    for i in range(n):
+        if i not in set(broken):
+            if int(ro[2 * i][1]) != 4:                                               # pairs that align jointly are untouched
+                assert ro[2 * i] == rn[2 * i] and ro[2 * i + 1] == rn[2 * i + 1]
+            continue
+        a, b = rn[2 * i], rn[2 * i + 1]
+        if int(a[1]) & 2:
+            rec += 1
+            assert int(b[1]) & 2 and int(a[7]) == int(b[3]) and int(b[7]) == int(a[3]) and int(a[8]) == -int(b[8])
+            assert abs(abs(int(a[8])) - truth[i]) <= 60
+            assert b"M" in b[5] and int(dict(x.split(b":", 2)[::2] for x in b[11:] if x.startswith(b"NM"))[b"NM"]) >= 4
+    assert rec >= len(broken) // 3

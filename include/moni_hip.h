@@ -212,10 +212,10 @@ int moni_report_mems_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, cons
                            const uint8_t *quals, const moni_align_params_t *prm, char **sam, uint64_t *sam_len);
 /* ---- the paired-end path: aligner::align(kpbseq_t*) (aligner_ksw2.hpp:888-918, 1000-1326) without orphan recovery ---------------- */
 /* The batch holds the pairs interleaved: reads 2p and 2p+1 are mate 1 and mate 2 of pair p (kpbseq_t's two kbseq_t,
- * include/common/kpbseq.h:300-326).  Orphan recovery (aligner_ksw2.hpp:920-998; klib's ksw_align, an absent submodule) is not built:
- * the records are those of the reference with find_orphan == false. */
+ * include/common/kpbseq.h:300-326).  find_orphan: orphan recovery (aligner_ksw2.hpp:1536-1640, 2329-2720) for the pairs that chain but fail
+ * jointly; its local alignment is klib's ksw_align (an absent submodule) restated as plain DP with its tie rules. */
 typedef struct {
-    uint32_t filter_dir, reserved;                        /* 1: aligner::config_t::filter_dir (aligner_ksw2.hpp:113) */
+    uint32_t filter_dir, find_orphan;                     /* 1, 1: aligner::config_t::filter_dir, find_orphan (aligner_ksw2.hpp:113,128) */
     double dir_thr;                                       /* 50.0 */
     uint64_t ins_learning_n;                              /* 1000 */
     uint64_t ins_learning_score_gap_threshold;            /* 0 */

@@ -20,10 +20,17 @@ struct pe_params_t {
     uint32_t filter_dir, finalize;       // finalize == 0: learn_fragment_model's align(al, false)
     double dir_thr;
     float mean, std_dev;                 // paired_alignment_t::mean / std_dev are floats (aligner_ksw2.hpp:684-685)
+    uint32_t find_orphan, w;             // w: the separator run between sequences (seqidx::get_w); orphan recovery for the pairs that chain but fail jointly (aligner_ksw2.hpp:900-906)
+    double ins_mean, ins_std_dev;        // the model as doubles: the search window of paired_chain_orphan_score (aligner_ksw2.hpp:2398-2420)
 };
 
+#ifndef DP_EZ_LOCAL
+#define DP_EZ_LOCAL 0x100                // a DP request that is klib's ksw_align(KSW_XSTART): result in score / max_t (te) / max_q (qe) / mte (tb) / mte_q (qb)
+#endif
+enum { PE_O_LOOP = 10, PE_O_WAIT_A, PE_O_WAIT_B, PE_O_FINAL_A, PE_O_FINAL_B };
+
 struct pe_mscore_t { int32_t score; uint32_t pad; uint64_t pos, lft; };                 // score_t
-struct pe_pscore_t { int32_t tot; uint32_t paired; long long dist; pe_mscore_t m1, m2; uint64_t chain_i; };      // paired_score_t
+struct pe_pscore_t { int32_t tot; uint32_t paired; long long dist; pe_mscore_t m1, m2; uint64_t chain_i; long long w0, w1; };      // paired_score_t; w0 / w1: orphan_paired_score_t::pos
 struct pe_left_t { uint64_t r1, r2, score; };
 
 struct pe_ws_t {
@@ -43,6 +50,10 @@ struct pe_ws_t {
     int32_t score2, score2_m[2], sub_n;
     pe_pscore_t final;                   // al.score
     uint32_t strand, filled[2];
+    uint32_t orphan[2];                  // the mate was placed by orphan recovery (fill_orphan): no ZS of its own, no alternative hits
+    uint32_t o_anch, o_have;             // orphan recovery: the mate that has the chain's anchors; a window was searched
+    long long o_start, o_end;            // the window (narrowed once the local alignment is known)
+    int32_t o_t_local, o_t_ext, o_t_glob;      // DP requests of the orphan mate
     uint64_t ref_pos[2]; int32_t as[2];
     uint32_t n_cigar[2];
     uint32_t cigar[2][AC_MAX_CIGAR];
@@ -80,6 +91,7 @@ AC_HD_BIG bool pe_init(pe_ws_t& S, const pe_params_t& PP, const moni_mem_t* gm, 
     ac_reset(W);
     S.n_best = S.n_left = 0; S.n_alt[0] = S.n_alt[1] = 0; S.max_m[0] = S.max_m[1] = 0;
     S.score2 = S.score2_m[0] = S.score2_m[1] = 0; S.sub_n = 0; S.strand = 0; S.filled[0] = S.filled[1] = 0; S.n_cigar[0] = S.n_cigar[1] = 0;
+    S.orphan[0] = S.orphan[1] = 0; S.o_anch = 0; S.o_have = 0; S.o_start = S.o_end = 0; S.o_t_local = S.o_t_ext = S.o_t_glob = -1; S.final.w0 = S.final.w1 = 0;
     S.final.tot = 0; S.final.paired = 0; S.final.dist = 0; S.final.chain_i = 0;
     S.final.m1.score = S.final.m2.score = 0; S.final.m1.pos = S.final.m2.pos = S.final.m1.lft = S.final.m2.lft = 0;
     const uint64_t r1 = 2 * pair, r2 = 2 * pair + 1;
@@ -174,16 +186,21 @@ AC_HD void pe_check_max(pe_ws_t& S, int k, int32_t score, uint64_t pos) {
 }
 
 // a scored chain comes back into get_best_scores (aligner_ksw2.hpp:1368-1400)
+AC_HD_BIG void pe_absorb_best(pe_ws_t& S, const pe_params_t& PP, const pe_pscore_t& sc);
 AC_HD_BIG void pe_absorb(pe_ws_t& S, const pe_params_t& PP, const pe_pscore_t& sc) {
-    const ac_params_t& P = PP.P;
     pe_check_max(S, 0, sc.m1.score, sc.m1.pos);
     pe_check_max(S, 1, sc.m2.score, sc.m2.pos);
     if (S.W.overflow) return;
+    pe_absorb_best(S, PP, sc);
+}
+// the best_scores update shared by get_best_scores and orphan_recovery (aligner_ksw2.hpp:1376-1400, 1572-1596)
+AC_HD_BIG void pe_absorb_best(pe_ws_t& S, const pe_params_t& PP, const pe_pscore_t& sc) {
+    const ac_params_t& P = PP.P;
     if (sc.tot >= S.min_score) {
         bool replaced = false;
         pe_pscore_t zero;
         zero.tot = 0; zero.paired = 0; zero.dist = 0; zero.chain_i = S.W.i;
-        zero.m1.score = zero.m2.score = 0; zero.m1.pad = zero.m2.pad = 0; zero.m1.pos = zero.m2.pos = zero.m1.lft = zero.m2.lft = 0;
+        zero.m1.score = zero.m2.score = 0; zero.m1.pad = zero.m2.pad = 0; zero.m1.pos = zero.m2.pos = zero.m1.lft = zero.m2.lft = 0; zero.w0 = zero.w1 = 0;
         for (uint32_t j = 0; j < S.n_best; ++j) {
             if (pe_dist(S.best[j].m1.lft, sc.m1.lft) < P.region_dist && pe_dist(S.best[j].m2.lft, sc.m2.lft) < P.region_dist) {
                 if (sc.tot > S.best[j].tot) {
@@ -227,6 +244,94 @@ AC_HD_BIG bool pe_fills_begin(pe_ws_t& S, const pe_params_t& PP, bool score_only
     return true;
 }
 
+// ---- orphan recovery (aligner_ksw2.hpp:1536-1640 orphan_recovery, :2329-2560 paired_chain_orphan_score, :2566-2720 fill_orphan) ----
+// the whole mate k in the orientation the pair's strand gives it (mate1 / mate2_rev, or mate1_rev / mate2), as a DP query
+AC_HD void pe_whole_mate(const pe_ws_t& S, int k, uint64_t& q_off, int& qmode) {
+    const bool rev = k == 0 ? S.strand != 0 : S.strand == 0;
+    if (!rev) { q_off = S.off[k]; qmode = 0; } else { q_off = S.off[k] + S.m[k] - 1; qmode = DP_Q_REV | DP_Q_COMP; }
+}
+// chain ci: the anchored mate's score-only fill and the local search of the other mate in the window the model predicts
+AC_HD_BIG bool pe_orphan_begin(pe_ws_t& S, const pe_params_t& PP, uint64_t ci) {
+    ac_ws_t& W = S.W;
+    const ac_params_t& P = PP.P;
+    if (!pe_split_chain(S, ci)) return false;
+    const ac_chain_t& ch = W.chains[ci];
+    uint64_t lm = ~0ull, rm = 0;
+    for (uint32_t k = 0; k < ch.cnt; ++k) {
+        const ac_anchor_t& A = W.anch[W.pool[ch.off + k]];
+        const uint64_t o = ac_occ(W, A.mem, A.occ);
+        if (o + W.mems[A.mem].len > rm) rm = o + W.mems[A.mem].len;
+        if (o < lm) lm = o;
+    }
+    S.o_anch = S.fill[0].n_an > 0 ? 0u : 1u;
+    S.fill_on[S.o_anch] = 1; S.fill_on[1 - S.o_anch] = 0;
+    if (!pe_fills_begin(S, PP, true)) return false;
+    const long long lim = (long long)(P.n_text - PP.w);
+    long long start, end;
+    if (S.o_anch == 0) { start = (long long)(rm + (uint64_t)(long long)floor(PP.ins_mean - 4 * PP.ins_std_dev)); end = (long long)(rm + (uint64_t)(long long)ceil(PP.ins_mean + 4 * PP.ins_std_dev)); }
+    else { start = (long long)(lm + (uint64_t)(long long)floor(-PP.ins_mean - 4 * PP.ins_std_dev)); end = (long long)(lm + (uint64_t)(long long)ceil(-PP.ins_mean + 4 * PP.ins_std_dev)); }
+    if (start < 0) start = 0;
+    if (start > lim) start = lim;
+    if (end > lim) end = lim;
+    S.o_start = start; S.o_end = end; S.o_have = start < end ? 1u : 0u;
+    S.o_t_local = S.o_t_ext = S.o_t_glob = -1;
+    if (S.o_have) {
+        if (W.n_tasks >= AC_MAX_TASKS) { W.overflow = 1; return false; }
+        uint64_t q_off; int qmode;
+        const int k = 1 - (int)S.o_anch;
+        pe_whole_mate(S, k, q_off, qmode);
+        moni_dp_task_t& t = W.tasks[W.n_tasks];
+        t.q_off = q_off; t.t_off = (uint64_t)start; t.qlen = (int)S.m[k]; t.tlen = (int)(end - start + 1); t.flag = DP_EZ_LOCAL; t.reserved = DP_Q_READS | DP_T_TEXT | qmode;
+        S.o_t_local = (int32_t)W.n_tasks++;
+    }
+    return true;
+}
+// the orphan loop: every chain in turn, then the best of them (returns true if DP requests were queued)
+AC_HD_BIG bool pe_orphan_advance(pe_ws_t& S, const pe_params_t& PP) {
+    ac_ws_t& W = S.W;
+    while (W.stage == PE_O_LOOP && !W.overflow) {
+        if (W.i < W.n_chains) {
+            if (!pe_orphan_begin(S, PP, W.i)) return false;
+            W.stage = PE_O_WAIT_A;
+            return true;
+        }
+        while (S.n_best < 2) {
+            pe_pscore_t& z = S.best[S.n_best++];
+            z.tot = 0; z.paired = 0; z.dist = 0; z.chain_i = W.n_chains;
+            z.m1.score = z.m2.score = 0; z.m1.pad = z.m2.pad = 0; z.m1.pos = z.m2.pos = z.m1.lft = z.m2.lft = 0; z.w0 = z.w1 = 0;
+        }
+        lsort::sort(S.best, (long)S.n_best, [](const pe_pscore_t& x, const pe_pscore_t& y) {            // orphan_paired_score_t::operator>
+            return x.tot > y.tot || (x.tot == y.tot && x.m1.lft > y.m1.lft) || (x.tot == y.tot && x.m1.lft == y.m1.lft && x.m2.lft > y.m2.lft);
+        }, W.sort_stack);
+        if (S.best[0].tot < S.min_score) { W.stage = AC_DONE; return false; }
+        S.sub_n = 0;
+        { uint32_t j = 1; while (j < S.n_best && S.best[j++].tot >= S.best[0].tot - PP.max_penalty) ++S.sub_n; }
+        S.score2 = S.best[1].tot; S.score2_m[0] = S.best[1].m1.score; S.score2_m[1] = S.best[1].m2.score;
+        S.final = S.best[0];
+        // the final paired_chain_orphan_score: the anchored mate's chain_score with its CIGAR, the other mate aligned globally over the window
+        if (S.best[0].chain_i >= W.n_chains) { W.stage = AC_DONE; return false; }
+        if (!pe_split_chain(S, S.best[0].chain_i)) return false;
+        S.o_anch = S.fill[0].n_an > 0 ? 0u : 1u;
+        const int32_t a_score = S.o_anch == 0 ? S.best[0].m1.score : S.best[0].m2.score;
+        S.fill_on[S.o_anch] = a_score >= S.min_score_m[S.o_anch]; S.fill_on[1 - S.o_anch] = 0;
+        if (!pe_fills_begin(S, PP, false)) return false;
+        S.o_start = S.best[0].w0; S.o_end = S.best[0].w1; S.o_have = S.o_start < S.o_end ? 1u : 0u;
+        S.o_t_local = S.o_t_ext = S.o_t_glob = -1;
+        if (S.o_have) {
+            if (W.n_tasks >= AC_MAX_TASKS) { W.overflow = 1; return false; }
+            uint64_t q_off; int qmode;
+            const int k = 1 - (int)S.o_anch;
+            pe_whole_mate(S, k, q_off, qmode);
+            moni_dp_task_t& t = W.tasks[W.n_tasks];
+            t.q_off = q_off; t.t_off = (uint64_t)S.o_start; t.qlen = (int)S.m[k]; t.tlen = (int)(S.o_end - S.o_start + 1); t.flag = DP_EZ_RIGHT; t.reserved = DP_Q_READS | DP_T_TEXT | qmode;
+            S.o_t_glob = (int32_t)W.n_tasks++;
+        }
+        W.stage = PE_O_FINAL_A;
+        return true;
+    }
+    return false;
+}
+
 // Runs get_best_scores until the pair needs DP results or is done.  Returns true if fills were started.
 AC_HD_BIG bool pe_advance(pe_ws_t& S, const pe_params_t& PP) {
     ac_ws_t& W = S.W;
@@ -240,7 +345,7 @@ AC_HD_BIG bool pe_advance(pe_ws_t& S, const pe_params_t& PP) {
                 if (!W.chains[W.i].paired) {              // paired_chain_score returns the empty score (aligner_ksw2.hpp:2145)
                     pe_pscore_t z;
                     z.tot = 0; z.paired = 0; z.dist = 0; z.chain_i = W.i;
-                    z.m1.score = z.m2.score = 0; z.m1.pad = z.m2.pad = 0; z.m1.pos = z.m2.pos = z.m1.lft = z.m2.lft = 0;
+                    z.m1.score = z.m2.score = 0; z.m1.pad = z.m2.pad = 0; z.m1.pos = z.m2.pos = z.m1.lft = z.m2.lft = 0; z.w0 = z.w1 = 0;
                     pe_absorb(S, PP, z);
                     ++W.i;
                     continue;
@@ -257,7 +362,7 @@ AC_HD_BIG bool pe_advance(pe_ws_t& S, const pe_params_t& PP) {
         while (S.n_best < 2) {
             pe_pscore_t& z = S.best[S.n_best++];
             z.tot = 0; z.paired = 0; z.dist = 0; z.chain_i = W.n_chains;
-            z.m1.score = z.m2.score = 0; z.m1.pad = z.m2.pad = 0; z.m1.pos = z.m2.pos = z.m1.lft = z.m2.lft = 0;
+            z.m1.score = z.m2.score = 0; z.m1.pad = z.m2.pad = 0; z.m1.pos = z.m2.pos = z.m1.lft = z.m2.lft = 0; z.w0 = z.w1 = 0;
         }
         lsort::sort(S.best, (long)S.n_best, [](const pe_pscore_t& x, const pe_pscore_t& y) {            // paired_score_t::operator>
             return x.tot > y.tot || (x.tot == y.tot && x.m1.lft > y.m1.lft) || (x.tot == y.tot && x.m1.lft == y.m1.lft && x.m2.lft > y.m2.lft);
@@ -266,7 +371,12 @@ AC_HD_BIG bool pe_advance(pe_ws_t& S, const pe_params_t& PP) {
         { uint32_t j = 1; while (j < S.n_best && S.best[j++].tot >= S.best[0].tot - PP.max_penalty) ++S.sub_n; }
         S.score2 = S.best[1].tot; S.score2_m[0] = S.best[1].m1.score; S.score2_m[1] = S.best[1].m2.score;
         S.final = S.best[0];
-        if (S.best[0].tot < S.min_score) { S.n_alt[0] = S.n_alt[1] = 0; W.stage = AC_DONE; return false; }
+        if (S.best[0].tot < S.min_score) {
+            S.n_alt[0] = S.n_alt[1] = 0;
+            if (PP.finalize && PP.find_orphan && W.n_chains > 0) { S.n_best = 0; W.i = 0; W.stage = PE_O_LOOP; return pe_orphan_advance(S, PP); }      // aligner_ksw2.hpp:900-906
+            W.stage = AC_DONE;
+            return false;
+        }
         if (!PP.finalize) { W.aligned = 1; W.stage = AC_DONE; return false; }                        // learn pass: best_scores[0] is the answer
         if (S.best[0].chain_i >= W.n_chains || !W.chains[S.best[0].chain_i].paired) { W.stage = AC_DONE; return false; }      // (cannot happen: tot >= min_score)
         if (!pe_split_chain(S, S.best[0].chain_i)) return false;
@@ -301,7 +411,7 @@ AC_HD_BIG void pe_drive(pe_ws_t& S, const pe_params_t& PP, const moni_dp_result_
                     for (int k = 0; k < 2; ++k) if (S.fill[k].t_glob >= 0) S.fill[k].score = res[S.fill[k].t_glob].score;
                 }
                 pe_pscore_t sc;
-                sc.chain_i = W.i; sc.paired = 1;
+                sc.chain_i = W.i; sc.paired = 1; sc.w0 = sc.w1 = 0;
                 for (int k = 0; k < 2; ++k) {
                     ac_fill_t& F = S.fill[k];
                     if (!ac_valid(P, F.ref_pos, F.ref_len)) F.score = INT32_MIN;
@@ -330,6 +440,94 @@ AC_HD_BIG void pe_drive(pe_ws_t& S, const pe_params_t& PP, const moni_dp_result_
                     S.fill_on[k] = 0;
                 }
                 if (more) { W.stage = AC_FINAL_WAIT_B; return; }
+                W.aligned = 1; W.stage = AC_DONE; W.n_tasks = 0;
+                return;
+            }
+            case PE_O_LOOP:
+                W.n_tasks = 0;
+                if (!pe_orphan_advance(S, PP)) return;
+                if (W.n_tasks > 0) return;
+                break;
+            case PE_O_WAIT_A:
+            case PE_O_WAIT_B: {
+                const int a = (int)S.o_anch, o = 1 - a;
+                const bool second = W.stage == PE_O_WAIT_B;
+                ac_fill_t& FA = S.fill[a];
+                if (!second) {
+                    int te = -1, tb = -1;
+                    if (S.o_t_local >= 0) { te = res[S.o_t_local].max_t; tb = res[S.o_t_local].mte; }
+                    W.n_tasks = 0;
+                    bool more = ac_fill_after_ext_g(W, P, FA, S.off[a], S.m[a], res);
+                    S.o_t_ext = -1;
+                    if (S.o_have) {                                   // fill_orphan: end = start + r.te; start += r.tb; then the extension score over the narrowed window
+                        S.o_end = S.o_start + te; S.o_start += tb;
+                        if (tb >= 0 && te >= tb) {
+                            if (W.n_tasks >= AC_MAX_TASKS) { W.overflow = 1; return; }
+                            uint64_t q_off; int qmode;
+                            pe_whole_mate(S, o, q_off, qmode);
+                            moni_dp_task_t& t = W.tasks[W.n_tasks];
+                            t.q_off = q_off; t.t_off = (uint64_t)S.o_start; t.qlen = (int)S.m[o]; t.tlen = te - tb + 1; t.flag = DP_EZ_SCORE_ONLY; t.reserved = DP_Q_READS | DP_T_TEXT | qmode;
+                            S.o_t_ext = (int32_t)W.n_tasks++;
+                            more = true;
+                        }
+                    }
+                    if (more) { W.stage = PE_O_WAIT_B; return; }
+                } else if (FA.t_glob >= 0) FA.score = res[FA.t_glob].score;
+                pe_pscore_t sc;
+                sc.chain_i = W.i; sc.paired = 1; sc.w0 = S.o_start; sc.w1 = S.o_end;
+                pe_mscore_t ms[2];
+                if (!ac_valid(P, FA.ref_pos, FA.ref_len)) FA.score = INT32_MIN;
+                ms[a].score = FA.score; ms[a].pad = 0; ms[a].pos = FA.score_pos;
+                ms[o].score = 0; ms[o].pad = 0; ms[o].pos = 0;
+                if (S.o_have) {
+                    ms[o].score = (second && S.o_t_ext >= 0) ? res[S.o_t_ext].score : -0x40000000;      // KSW_NEG_INF: no extension ran
+                    ms[o].pos = (uint64_t)S.o_start;
+                    if (!ac_valid(P, (uint64_t)S.o_start, (uint64_t)(S.o_end - S.o_start + 1))) ms[o].score = INT32_MIN;
+                }
+                ms[0].lft = ac_lift(P, ms[0].pos); ms[1].lft = ac_lift(P, ms[1].pos);
+                sc.m1 = ms[0]; sc.m2 = ms[1];
+                sc.dist = (long long)pe_dist(sc.m2.pos, sc.m1.pos + (uint64_t)S.m[0]);
+                sc.tot = pe_pair_total(PP, sc.m1.score, sc.m2.score, sc.dist);
+                pe_absorb_best(S, PP, sc);
+                ++W.i;
+                W.stage = PE_O_LOOP;
+                break;
+            }
+            case PE_O_FINAL_A:
+            case PE_O_FINAL_B: {
+                const int a = (int)S.o_anch, o = 1 - a;
+                const bool first = W.stage == PE_O_FINAL_A;
+                ac_fill_t& FA = S.fill[a];
+                if (first) {
+                    if (S.o_t_glob >= 0) {                            // fill_orphan(.., false, sam): the whole mate against the window, with its CIGAR
+                        const moni_dp_result_t& r = res[S.o_t_glob];
+                        if (r.n_cigar > AC_MAX_CIGAR) { W.overflow = 1; return; }
+                        for (uint32_t k = 0; k < r.n_cigar; ++k) S.cigar[o][k] = cig[r.cigar_off + k];
+                        S.n_cigar[o] = r.n_cigar; S.filled[o] = 1; S.orphan[o] = 1; S.ref_pos[o] = (uint64_t)S.o_start; S.as[o] = r.score;
+                    }
+                    W.n_tasks = 0;
+                    if (S.fill_on[a] && ac_fill_after_ext_g(W, P, FA, S.off[a], S.m[a], res)) { W.stage = PE_O_FINAL_B; return; }
+                }
+                if (S.fill_on[a]) {
+                    if (!ac_fill_final_g(W, P, FA, res, cig, S.cigar[a], S.n_cigar[a])) return;
+                    S.filled[a] = 1; S.ref_pos[a] = FA.ref_pos; S.as[a] = FA.score;
+                }
+                pe_mscore_t ms[2];
+                ms[a] = a == 0 ? S.final.m1 : S.final.m2;            // chain_score's score-only values
+                ms[o].score = 0; ms[o].pad = 0; ms[o].pos = 0;
+                if (S.filled[o]) {                                   // score / pos only when the lifted alignment spans reference bases (aligner_ksw2.hpp:2690-2705)
+                    const uint32_t sid = ac_seq_of(P, S.ref_pos[o]);
+                    const moni_lift_seq_t Lq = P.lift_seqs[sid];
+                    const int nl = lift_cigar(P.lift_runs + Lq.run_off, Lq.n_runs, S.ref_pos[o] - Lq.start, S.cigar[o], S.n_cigar[o], W.cigar, AC_MAX_CIGAR);
+                    if (nl < 0) { W.overflow = 1; return; }
+                    uint64_t l_len = 0;
+                    for (int k = 0; k < nl; ++k) { const int op = W.cigar[k] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) l_len += W.cigar[k] >> 4; }
+                    if (l_len > 0) { ms[o].score = S.as[o]; ms[o].pos = S.ref_pos[o]; }
+                }
+                ms[0].lft = ac_lift(P, ms[0].pos); ms[1].lft = ac_lift(P, ms[1].pos);
+                S.final.m1 = ms[0]; S.final.m2 = ms[1];
+                S.final.dist = (long long)pe_dist(ms[1].pos, ms[0].pos + (uint64_t)S.m[0]);
+                S.final.tot = pe_pair_total(PP, ms[0].score, ms[1].score, S.final.dist);
                 W.aligned = 1; W.stage = AC_DONE; W.n_tasks = 0;
                 return;
             }

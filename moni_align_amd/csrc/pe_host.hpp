@@ -12,7 +12,8 @@ namespace mh {
 struct PeMateOut {
     uint32_t m = 0; uint64_t off = 0;            // the mate in the batch
     int32_t score = 0;                            // score.m1 / score.m2 of the best pair (score-only pass)
-    bool filled = false;                          // chain_score ran fill_chain with a CIGAR (score >= min_score of the mate)
+    bool filled = false;                          // chain_score ran fill_chain with a CIGAR (score >= min_score of the mate), or fill_orphan placed the mate
+    bool orphan = false;                          // placed by fill_orphan: its record has no ZS of its own (aligner_ksw2.hpp:2440-2452)
     uint64_t ref_pos = 0; int32_t as = 0;
     const uint32_t* cig = nullptr; uint32_t n_cig = 0;
     const uint64_t* alt_pos = nullptr; const int32_t* alt_score = nullptr; uint32_t n_alt = 0;
@@ -83,8 +84,9 @@ static inline void pe_emit(const Aligner& A, const moni_align_params_t& P, const
             if (!M.filled) continue;
             A.finish_record(M.m, M.off, rev[k] ? 1u : 0u, M.ref_pos, M.as, R.score2_m[k], M.cig, M.n_cig, M.alt_pos, M.alt_score, M.n_alt, s[k]);
             s[k].flag = strand ? 16 : 0;                     // chain_score: the pair's strand (aligner_ksw2.hpp:2069)
-            s[k].mapq = mapq_se_bwa((int32_t)s[k].as, (int32_t)s[k].zs, (int32_t)s[k].rlen, (int32_t)M.m, (int32_t)P.min_len, P.smatch, P.smismatch, 50.0,
+            s[k].mapq = mapq_se_bwa((int32_t)s[k].as, R.score2_m[k], (int32_t)s[k].rlen, (int32_t)M.m, (int32_t)P.min_len, P.smatch, P.smismatch, 50.0,
                                     (int32_t)log(50.0f), R.sub_n);
+            if (M.orphan) { s[k].zs = 0; s[k].flag = 4; }  // fill_orphan sets neither
             ok[k] = !s[k].unmapped_lft;
         }
         const size_t l1 = R.mate[0].m, l2 = R.mate[1].m;
@@ -217,9 +219,9 @@ static inline void pe_emit_fast(const Aligner& A, const moni_align_params_t& P, 
                 const auto lfti = ix.index(lifted);
                 F.pos = lfti.second + 1; F.rname = (int)lfti.first; F.cigar_star = false; F.rlen = ref_len;
             } else { F.pos = 0; F.rname = -1; F.cigar_star = true; F.rlen = 0; F.unmapped_lft = true; F.nm = 0; F.md_len = 0; }
-            F.flag = strand ? 16 : 0;
-            F.zs = (size_t)(int64_t)R.score2_m[k];
-            F.mapq = mapq_se_bwa((int32_t)F.as, (int32_t)F.zs, (int32_t)F.rlen, (int32_t)m, (int32_t)P.min_len, P.smatch, P.smismatch, 50.0, (int32_t)log(50.0f), R.sub_n);
+            F.flag = M.orphan ? 4 : (strand ? 16 : 0);
+            F.zs = M.orphan ? 0 : (size_t)(int64_t)R.score2_m[k];
+            F.mapq = mapq_se_bwa((int32_t)F.as, R.score2_m[k], (int32_t)F.rlen, (int32_t)m, (int32_t)P.min_len, P.smatch, P.smismatch, 50.0, (int32_t)log(50.0f), R.sub_n);
             ok[k] = !F.unmapped_lft;
         }
         const size_t l1 = R.mate[0].m, l2 = R.mate[1].m;

@@ -10,16 +10,84 @@
 
 #include "pe_core.h"
 
+// klib's ksw_align(KSW_XSTART) for the orphan search (pe_core.h queues it as a DP_EZ_LOCAL request): ksw_i16's local alignment, rows =
+// target, with its tie rules (the first row that reaches the maximum, the leftmost query position in it), then the same over the reversed
+// prefixes up to the first row that reaches the score (tb / qb).  One lane per request, rolling rows in the lane's workspace in HBM: the
+// requests are rare (pairs that chain but fail jointly) and each lane's pair waits for nothing else.
+#define PE_SW_QMAX 4096
+struct pe_sw_ws_t { int32_t H0[PE_SW_QMAX], H1[PE_SW_QMAX], E[PE_SW_QMAX], HM[PE_SW_QMAX]; uint8_t qc[PE_SW_QMAX]; };
+
+// one pass; reverse: query[j] = q(q_last - j), target[i] = i <= t_last ? T(t_last - i) : T(i) (klib reverses the two prefixes in place)
+__device__ __attribute__((noinline)) void pe_sw_pass(const dp_launch_t& D, pe_sw_ws_t& ws, const moni_dp_task_t& task, int qlen, int tlen, bool reverse, int q_last, int t_last,
+                                                     int endsc, int& score, int& te_out, int& qe_out) {
+    const int mode = task.reserved;
+    for (int j = 0; j < qlen; ++j) {
+        const int k = reverse ? q_last - j : j;
+        uint32_t c = dp_nt4(D.reads[(mode & DP_Q_REV) ? task.q_off - (uint64_t)k : task.q_off + (uint64_t)k]);
+        if ((mode & DP_Q_COMP) && c < 4) c = 3 - c;
+        ws.qc[j] = (uint8_t)c; ws.H0[j] = 0; ws.H1[j] = 0; ws.E[j] = 0; ws.HM[j] = 0;
+    }
+    const int gape = D.e, gapoe = D.qo + D.e;
+    int32_t* H0 = ws.H0; int32_t* H1 = ws.H1;
+    int gmax = 0, te = -1;
+    for (int i = 0; i < tlen; ++i) {
+        const int ti = (reverse && i <= t_last) ? t_last - i : i;
+        const uint64_t ta = task.t_off + (uint64_t)ti;
+        const uint32_t tc = dp_nt4(ta < D.n_text ? D.text[ta] : 0u);
+        int f = 0, imax = 0, diag = 0;
+        for (int j = 0; j < qlen; ++j) {
+            const uint32_t qc = ws.qc[j];
+            const int sc = (tc >= 4 || qc >= 4) ? 0 : (tc == qc ? D.sc_mch : D.sc_mis);
+            int h = diag + sc;
+            diag = H0[j];
+            const int e = ws.E[j];
+            h = h > e ? h : e; h = h > f ? h : f;
+            H1[j] = h;
+            imax = imax > h ? imax : h;
+            int hh = h - gapoe; hh = hh > 0 ? hh : 0;
+            int e2 = e - gape; e2 = e2 > 0 ? e2 : 0;
+            ws.E[j] = e2 > hh ? e2 : hh;
+            f -= gape; f = f > 0 ? f : 0; f = f > hh ? f : hh;
+        }
+        if (imax > gmax) { gmax = imax; te = i; for (int j = 0; j < qlen; ++j) ws.HM[j] = H1[j]; if (gmax >= endsc) break; }
+        int32_t* tmp = H0; H0 = H1; H1 = tmp;
+    }
+    score = gmax; te_out = te;
+    int mx = -1, qe = -1;
+    for (int j = 0; j < qlen; ++j) if (ws.HM[j] > mx) { mx = ws.HM[j]; qe = j; }
+    qe_out = qe;
+}
+__device__ __attribute__((noinline)) void pe_sw_local(const dp_launch_t& D, pe_sw_ws_t& ws, const moni_dp_task_t& task, moni_dp_result_t* out) {
+    moni_dp_result_t r;
+    r.max = 0; r.max_q = r.max_t = -1; r.mqe = 0; r.mqe_t = -1; r.mte = -1; r.mte_q = -1; r.score = 0; r.reach_end = 0; r.zdropped = 0; r.n_cigar = 0; r.cigar_off = 0;
+    if (task.qlen > 0 && task.qlen <= PE_SW_QMAX && task.tlen > 0) {
+        int score, te, qe;
+        pe_sw_pass(D, ws, task, task.qlen, task.tlen, false, 0, 0, 0x10000, score, te, qe);
+        int s2, te2, qe2;
+        pe_sw_pass(D, ws, task, qe + 1, task.tlen, true, qe, te, score, s2, te2, qe2);
+        r.score = score; r.max_t = te; r.max_q = qe;
+        if (score == s2) { r.mte = te - te2; r.mte_q = qe - qe2; }
+    }
+    *out = r;
+}
+// the same for the host pipeline for pairs (pe_big.h): one lane per request
+extern "C" __global__ void __launch_bounds__(64) pe_sw_kernel(const dp_launch_t D, const moni_dp_task_t* tasks, uint32_t n, pe_sw_ws_t* ws, moni_dp_result_t* res) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) pe_sw_local(D, ws[i], tasks[i], res + i);
+}
+
 struct pe_slot_t {
     pe_ws_t ws;
     moni_dp_result_t res[AC_MAX_TASKS];
     uint32_t cig[AK_CIG_CAP];
+    pe_sw_ws_t sw;
 };
 
 struct pe_rec_t {                            // one per pair
     uint32_t status;                         // 0 not aligned, 1 aligned (finalize: the final paired_chain_score ran), 2 overflow
     uint32_t strand;
     int32_t tot, score2, score2_m[2], sub_n, pad;
+    uint32_t orphan[2];                      // the mate was placed by orphan recovery
     long long dist;
     int32_t mate_score[2];
     uint32_t filled[2];
@@ -57,7 +125,7 @@ __device__ __attribute__((noinline)) void pe_write_record(const pe_args_t& A, co
     R.mate_score[0] = S.final.m1.score; R.mate_score[1] = S.final.m2.score;
     for (int k = 0; k < 2; ++k) {
         R.score2_m[k] = S.score2_m[k];
-        R.filled[k] = 0; R.ref_pos[k] = 0; R.as[k] = 0; R.n_cigar[k] = 0; R.n_alt[k] = 0; R.cigar_off[k] = 0; R.alt_off[k] = 0;
+        R.orphan[k] = 0; R.filled[k] = 0; R.ref_pos[k] = 0; R.as[k] = 0; R.n_cigar[k] = 0; R.n_alt[k] = 0; R.cigar_off[k] = 0; R.alt_off[k] = 0;
     }
     if (R.status == 1 && A.PP.finalize) {
         for (int k = 0; k < 2 && R.status == 1; ++k) {
@@ -65,7 +133,7 @@ __device__ __attribute__((noinline)) void pe_write_record(const pe_args_t& A, co
             const unsigned long long co = atomicAdd(&A.cursors[0], (unsigned long long)S.n_cigar[k]);
             const unsigned long long ao = atomicAdd(&A.cursors[1], (unsigned long long)S.n_alt[k]);
             if (co + S.n_cigar[k] > A.cig_cap || ao + S.n_alt[k] > A.alt_cap) { R.status = 2; break; }
-            R.filled[k] = 1; R.ref_pos[k] = S.ref_pos[k]; R.as[k] = S.as[k];
+            R.filled[k] = 1; R.orphan[k] = S.orphan[k]; R.ref_pos[k] = S.ref_pos[k]; R.as[k] = S.as[k];
             R.n_cigar[k] = S.n_cigar[k]; R.cigar_off[k] = co; R.n_alt[k] = S.n_alt[k]; R.alt_off[k] = ao;
             for (uint32_t i = 0; i < S.n_cigar[k]; ++i) A.cig_pool[co + i] = S.cigar[k][i];
             for (uint32_t i = 0; i < S.n_alt[k]; ++i) { moni_alt_t x; x.pos = S.alt_pos[k][i]; x.score = S.alt_score[k][i]; x.pad = 0; A.alt_pool[ao + i] = x; }
@@ -115,6 +183,8 @@ pe_align_kernel(const pe_args_t A) {
         }
         const unsigned long long waiting = __ballot(state == 1);
         if (waiting == 0ull) { if (__ballot(state == 0 || state == 3) == 0ull) break; continue; }
+        // the local-alignment requests of orphan recovery: each waiting lane solves its own (at most one per round)
+        if (state == 1) for (uint32_t t = 0; t < W.W.n_tasks; ++t) if (W.W.tasks[t].flag & DP_EZ_LOCAL) pe_sw_local(A.D, S->sw, W.W.tasks[t], &S->res[t]);
         __threadfence();
         // ---- phase 2 (whole wave): the DP problems of every waiting pair, one pair after the other ----
         for (unsigned long long todo = waiting; todo; todo &= todo - 1) {
@@ -130,6 +200,7 @@ pe_align_kernel(const pe_args_t A) {
             uint32_t cig_used = 0;
             for (uint32_t t = 0; t < nt; ++t) {
                 const moni_dp_task_t task = s_tasks[t];
+                if (task.flag & DP_EZ_LOCAL) continue;              // solved by the pair's own lane above
                 const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
                 const uint32_t cig_need = with_cigar && task.qlen > 0 && task.tlen > 0 ? (uint32_t)(task.qlen + task.tlen + 2) : 0u;
                 if (task.qlen > DP_LDS_Q || task.tlen > DP_LDS_T || cig_used + cig_need > AK_CIG_CAP ||

@@ -16,7 +16,7 @@
 // modes take the older path: a reader thread parses ahead into a bounded queue, two workers per GPU, a writer thread with a bounded
 // in-order window.  -m writes the report-MEMs records (aligner_ksw2.hpp:346-373);
 // --ms / --mems write the legacy `moni ms` / `moni mems` text outputs (src/matching_statistics.cpp:520-610, src/mems.cpp:520-600).
-// Paired-end (-1/-2) runs without orphan recovery and therefore asks for -u.  Not implemented here (exit 1 with a message): -c, -q, -n, -Z.
+// Not implemented here (exit 1 with a message): -c, -q, -n, -Z.
 #include <fcntl.h>
 #include <getopt.h>
 #include <libgen.h>
@@ -177,7 +177,7 @@ struct Args {
     int ctx_per_gpu = 3;               // streaming path: contexts (ranges in flight) per GPU
     bool dry_run = false;
     moni_pe_params_t PE;               // -d, -D (paired-end)
-    bool find_orphan = true;           // -u switches orphan recovery off; moni-hip-align has none: paired input needs -u
+    bool find_orphan = true;           // -u switches orphan recovery off
 };
 
 static void parse(int argc, char** argv, Args& a) {
@@ -350,7 +350,7 @@ static void pwrite_all(int fd, const char* p, size_t n, uint64_t at) {
 
 // ---- paired-end (-1 / -2): st_align's paired loop (align_reads_dispatcher.hpp:356-389) over the C ABI ----------------------------------
 // Learn the insert-size model on batches of -b pairs until it is complete (or the input ends), align those batches, then the rest (in
-// larger batches: with the model fixed and no orphan recovery every pair is independent).  Orphan recovery is not built: -u is required.
+// larger batches: with the model fixed every pair is independent).  -u switches orphan recovery off.
 struct AnyReader {
     MappedReader m; Reader* z = nullptr; bool mapped = false;
     explicit AnyReader(const std::string& path) { mapped = m.open(path); if (!mapped) z = new Reader(path); }
@@ -368,7 +368,7 @@ static size_t read_pairs(AnyReader& r1, AnyReader& r2, size_t n_pairs, Batch& b)
     return n;
 }
 static int run_paired(Args& a, const std::string& sam_filename) {
-    if (a.find_orphan) die("orphan recovery is not implemented in moni-hip-align: pass -u (the records are then those of `moni align -u`)");
+    a.PE.find_orphan = a.find_orphan ? 1 : 0;            // -u switches orphan recovery off (align_full_ksw2.cpp:248-250)
     info("Output file: " + sam_filename);
     AnyReader r1(a.mate1), r2(a.mate2);
     const std::string idx_path = a.filename + ".mfi";

@@ -56,7 +56,7 @@ def main():
         n = min(args.check, args.pairs)
         o = orc.OracleIndex(fi=fi)
         t0 = time.time()
-        want, ost = oracle_pe(o, m1[:n], m2[:n], b_size=512)
+        want, ost = oracle_pe(o, m1[:n], m2[:n], b_size=512, find_orphan=True)
         res["oracle_pairs_per_s_1thread"] = n / (time.time() - t0)
         # the oracle learnt on the same first batches when n >= the pairs the model needed
         got = b"\n".join(sam.split(b"\n")[:2 * n]) + b"\n"

@@ -16,6 +16,7 @@
 #include "../../moni_align_amd/csrc/pe_core.h"
 #include "../../moni_align_amd/csrc/pe_host.hpp"
 #include "../../oracle/ksw2.hpp"      // CPU stand-in for extz_kernel in this harness (tests may use the oracle)
+#include "../../oracle/align_pe.hpp"  // ... and for the local-alignment requests of orphan recovery (klib ksw_align as restated there)
 
 struct Sim {
     HostImage img;
@@ -171,6 +172,13 @@ struct SimBackend : mh::Backend {
                 const uint64_t a = (t.reserved & DP_T_REV) ? t.t_off - k : t.t_off + k;
                 tg[k] = mh::nt4_of(a < S->hix.n_text ? S->text[a] : 0);
             }
+            if (t.flag & DP_EZ_LOCAL) {
+                const oracle::aligner_pe::kswr_t k = oracle::aligner_pe::ksw_align(t.qlen, q.data(), t.tlen, tg.data(), p.m, p.mat, p.q, p.e);
+                moni_dp_result_t& r = res[i];
+                memset(&r, 0, sizeof r);
+                r.score = k.score; r.max_t = k.te; r.max_q = k.qe; r.mte = k.tb; r.mte_q = k.qb; r.cigar_off = (uint32_t)cig.size();
+                continue;
+            }
             oracle::ksw_extz_t ez;
             memset(&ez, 0, sizeof ez);
             oracle::ksw_extz2_restated(t.qlen, q.data(), t.tlen, tg.data(), p.m, p.mat, p.q, p.e, p.w, p.zdrop, p.end_bonus, t.flag, &ez);
@@ -297,7 +305,7 @@ char* sim_align_core_batch(void* s, const uint8_t* seq, const uint64_t* offs, ui
 // ---- the paired-end per-pair logic (pe_core.h) replayed on the host + the host finishing (pe_host.hpp).  Reads 2p / 2p + 1 are the mates
 // of pair p.  finalize == 0: the learn pass (learn[4*p .. 4*p+4) = aligned, best tot, second tot, dist; min_score in learn_min[p]) ----
 char* sim_align_pe_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_pairs, const uint8_t* names, const uint64_t* name_off,
-                         const uint8_t* quals, int finalize, double mean, double std_dev, long long* learn, uint64_t* out_len, uint64_t* stats5) {
+                         const uint8_t* quals, int finalize, double mean, double std_dev, int find_orphan, long long* learn, uint64_t* out_len, uint64_t* stats5) {
     Sim* S = (Sim*)s;
     SimBackend be;
     const uint64_t n_reads = 2 * n_pairs;
@@ -322,6 +330,7 @@ char* sim_align_pe_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint
     AP.lift_seqs = S->hix.lift_seqs.data(); AP.lift_runs = S->hix.lift_runs.data(); AP.pdir = S->pdir.data();
     PP.smismatch = P.smismatch; PP.max_penalty = std::max(P.smatch + P.smismatch, P.gapo + P.gape); PP.filter_dir = 1; PP.finalize = finalize ? 1 : 0;
     PP.dir_thr = 50.0; PP.mean = (float)mean; PP.std_dev = (float)std_dev;
+    PP.find_orphan = find_orphan ? 1 : 0; PP.w = (uint32_t)S->hix.w; PP.ins_mean = mean; PP.ins_std_dev = std_dev;
     moni_dp_params_t dp;
     memset(&dp, 0, sizeof dp);
     dp.m = 5;
@@ -362,9 +371,9 @@ char* sim_align_pe_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint
             mh::PeMateOut& M = R.mate[k];
             M.m = W->m[k]; M.off = W->off[k]; M.score = k ? W->final.m2.score : W->final.m1.score; M.filled = R.finalized && W->filled[k];
             M.ref_pos = W->ref_pos[k]; M.as = W->as[k]; M.cig = W->cigar[k]; M.n_cig = W->n_cigar[k];
-            M.alt_pos = W->alt_pos[k]; M.alt_score = W->alt_score[k]; M.n_alt = W->n_alt[k];
+            M.alt_pos = W->alt_pos[k]; M.alt_score = W->alt_score[k]; M.n_alt = W->n_alt[k]; M.orphan = W->orphan[k] != 0;
         }
-        if (R.finalized) ++n_aligned;
+        if (R.finalized && R.tot >= W->min_score) ++n_aligned;
         const size_t line_at = out.size();
         const double e0 = mh::now_s();
         mh::pe_emit(A, P, R, std::string((const char*)names + name_off[2 * p], (const char*)names + name_off[2 * p + 1]),

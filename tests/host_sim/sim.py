@@ -17,7 +17,7 @@ def lib():
     if _lib is None:
         so = os.path.join(HERE, "libhost_sim.so")
         srcs = [os.path.join(HERE, "host_sim.cpp"), os.path.join(ROOT, "oracle", "ksw2.hpp")] + \
-               [os.path.join(capi.CSRC, f) for f in ("seed_core.h", "image.hpp", "layout.h", "align_host.hpp", "align_core.h", "pe_core.h", "pe_host.hpp", "sort_emul.h", "lift_core.h", "lift_build.hpp")]
+               [os.path.join(capi.CSRC, f) for f in ("seed_core.h", "image.hpp", "layout.h", "align_host.hpp", "align_core.h", "pe_core.h", "pe_host.hpp", "../../oracle/align_pe.hpp", "sort_emul.h", "lift_core.h", "lift_build.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(HERE, "host_sim.cpp")])
         L = C.CDLL(so)
@@ -40,7 +40,7 @@ def lib():
                                            C.POINTER(C.c_uint64), C.c_void_p]
         L.sim_align_pe_batch.restype = C.c_void_p
         L.sim_align_pe_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
-                                         C.c_double, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+                                         C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
         L.sim_free.argtypes = [C.c_void_p]
         L.liftsim_create.restype = C.c_void_p
         L.liftsim_create.argtypes = [C.POINTER(capi.FlatIndexC)]
@@ -122,7 +122,7 @@ class Sim:
         finally:
             lib().sim_free(p)
 
-    def align_pe_batch(self, seq, offsets, names, name_off, quals=None, finalize=True, mean=0.0, std_dev=0.0):
+    def align_pe_batch(self, seq, offsets, names, name_off, quals=None, finalize=True, mean=0.0, std_dev=0.0, find_orphan=False):
         """Paired-end: reads 2p / 2p+1 are the mates of pair p; pe_core.h replayed on the host + pe_host.hpp.  finalize=False is the
         learn pass: returns (learn[n_pairs, 4] = aligned, best tot, second tot, dist; stats)."""
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
@@ -136,7 +136,7 @@ class Sim:
         st = np.zeros(5, dtype=np.uint64)
         learn = np.zeros((n_pairs, 4), dtype=np.int64)
         p = lib().sim_align_pe_batch(self.h, seq.ctypes.data, offsets.ctypes.data, n_pairs, names.ctypes.data, name_off.ctypes.data,
-                                     quals.ctypes.data if quals is not None else None, int(finalize), float(mean), float(std_dev),
+                                     quals.ctypes.data if quals is not None else None, int(finalize), float(mean), float(std_dev), int(find_orphan),
                                      learn.ctypes.data, C.byref(ln), st.ctypes.data)
         if not p:
             raise RuntimeError("sim_align_pe_batch failed")

@@ -41,7 +41,7 @@ def test_dry_run_parsing(exe, small_case, tmp_path):
 def test_unsupported_modes_exit_1(exe, tmp_path):
     fq = str(tmp_path / "x.fq")
     open(fq, "w").write("@a\nACGT\n+\nIIII\n")
-    for extra in (["-1", fq, "-2", fq], ["-p", fq, "-q"], ["-p", fq, "-c"]):
+    for extra in (["-p", fq, "-q"], ["-p", fq, "-c"], ["-1", fq, "-2", fq, "-Z"]):
         r = subprocess.run([exe, "x"] + extra, capture_output=True)
         assert r.returncode == 1 and b"not implemented" in r.stderr
     assert subprocess.run([exe], capture_output=True).returncode == 1
@@ -184,6 +184,8 @@ def test_cli_paired_end(exe, medium_case, tmp_path):
         from tests.test_host_sim_pe import first_diff
         raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got[len(hdr):], want))
     assert ("Number of aligned pairs: %d/1500" % st["aligned"]) in log
-    # without -u the binary refuses (no orphan recovery)
-    r = subprocess.run([exe, prefix, "-1", f1, "-2", f2], capture_output=True)
-    assert r.returncode == 1 and b"orphan recovery is not implemented" in r.stderr
+    # without -u: orphan recovery on (the reference's default)
+    out2 = str(tmp_path / "pe_orphan.sam")
+    subprocess.check_call([exe, prefix, "-1", f1, "-2", f2, "-o", out2, "-S", "1000", "-F", "0.5", "-t", "4", "-b", "512", "--gpu-batch", "2048"])
+    want2, _ = oracle_pe(o, m1, m2, b_size=512, find_orphan=True)
+    assert open(out2, "rb").read()[len(hdr):] == want2

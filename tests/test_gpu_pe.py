@@ -19,7 +19,7 @@ def case():
     return pg, fi, orc.OracleIndex(fi=fi)
 
 
-def gpu_align_all(ctx, seq, offs, names, noff, q, b_size):
+def gpu_align_all(ctx, seq, offs, names, noff, q, b_size, find_orphan=False):
     """st_align's paired loop (align_reads_dispatcher.hpp:356-389) over the C ABI"""
     n = (len(offs) - 1) // 2
     model = capi.PeModelC()
@@ -39,16 +39,16 @@ def gpu_align_all(ctx, seq, offs, names, noff, q, b_size):
     aligned = 0
     rest = [(lo, min(n, lo + b_size)) for lo in range(at, n, b_size)]
     for lo, hi in learnt + rest:
-        sam, st = ctx.pe_align(*cut(lo, hi), model, host_threads=4)
+        sam, st = ctx.pe_align(*cut(lo, hi), model, host_threads=4, find_orphan=int(find_orphan))
         out.append(sam); aligned += st["aligned"]
     return b"".join(out), model, aligned
 
 
-def on_gpu(fi, seq, offs, names, noff, q, b_size):
+def on_gpu(fi, seq, offs, names, noff, q, b_size, find_orphan=False):
     idx = capi.Index(fi=fi)
     ctx = capi.Ctx(idx)
     try:
-        return gpu_align_all(ctx, seq, offs, names, noff, q, b_size)
+        return gpu_align_all(ctx, seq, offs, names, noff, q, b_size, find_orphan)
     finally:
         ctx.close()
         idx.close()
@@ -123,7 +123,7 @@ def test_pe_exact_repeats_overflow_the_kernel():
     ctx = capi.Ctx(idx)
     try:
         model = ctx.pe_learn(seq, offs)
-        got, gst = ctx.pe_align(seq, offs, names, noff, q, model, host_threads=4)
+        got, gst = ctx.pe_align(seq, offs, names, noff, q, model, host_threads=4, find_orphan=0)
     finally:
         ctx.close(); idx.close()
     assert model.count == st["ins_count"] and model.mean == st["ins_mean"] and model.std_dev == st["ins_std_dev"]
@@ -147,3 +147,23 @@ def test_pe_chunking_and_wave_shape_are_invisible(case, monkeypatch):
     assert a == b
     if a != want:
         raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(a, want))
+
+
+def test_pe_orphan_recovery(case, monkeypatch):
+    """pairs that chain but fail jointly (one mate without a 25-base MEM): with find_orphan the mate is searched by local alignment (klib's
+    ksw_align, here pe_sw_local: one lane per request) in the window the model predicts - in the kernel, and in the host pipeline for pairs when
+    every third pair is forced through it; SAM identical to the oracle's orphan_recovery"""
+    from tests.test_host_sim_pe import seedless_pairs
+    pg, fi, o = case
+    m1, m2 = seedless_pairs(pg)
+    want, st = oracle_pe(o, m1, m2, b_size=4096, find_orphan=True)
+    assert st["orphan_recovered"] > 20
+    seq, offs, names, noff, q = interleave(m1, m2)
+    got, model, aligned = on_gpu(fi, seq, offs, names, noff, q, 4096, find_orphan=True)
+    assert model.mean == st["ins_mean"] and model.std_dev == st["ins_std_dev"]
+    if got != want:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
+    assert aligned == st["aligned"]
+    monkeypatch.setenv("MONI_PE_FORCE_BIG", "3")
+    got2, _, _ = on_gpu(fi, seq, offs, names, noff, q, 4096, find_orphan=True)
+    assert got2 == want

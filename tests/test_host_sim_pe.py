@@ -25,7 +25,7 @@ def interleave(m1, m2, slash=True, names=None):
     return seq, offs, np.frombuffer(b"".join(nm), np.uint8), noff, np.full(len(seq), ord("I"), np.uint8)
 
 
-def oracle_pe(o, m1, m2, slash=True, b_size=512):
+def oracle_pe(o, m1, m2, slash=True, b_size=512, find_orphan=False):
     n = len(m1)
     o1 = np.zeros(n + 1, np.uint64); o1[1:] = np.cumsum([len(x) for x in m1])
     o2 = np.zeros(n + 1, np.uint64); o2[1:] = np.cumsum([len(x) for x in m2])
@@ -35,7 +35,7 @@ def oracle_pe(o, m1, m2, slash=True, b_size=512):
     no2 = np.zeros(n + 1, np.uint64); no2[1:] = np.cumsum([len(x) for x in nm2])
     q1 = np.full(int(o1[-1]), ord("I"), np.uint8); q2 = np.full(int(o2[-1]), ord("I"), np.uint8)
     return orc.align_pe(o, np.concatenate(m1), o1, np.concatenate(m2), o2, np.frombuffer(b"".join(nm1), np.uint8), no1,
-                        np.frombuffer(b"".join(nm2), np.uint8), no2, q1, q2, b_size=b_size)
+                        np.frombuffer(b"".join(nm2), np.uint8), no2, q1, q2, b_size=b_size, find_orphan=find_orphan)
 
 
 def first_diff(a: bytes, b: bytes):
@@ -143,3 +143,44 @@ def test_pe_replay_hard_cases(case):
         raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
     flags = [int(l.split(b"\t")[1]) for l in want.split(b"\n") if l]
     assert any(f & 8 and not f & 4 for f in flags) and any(f & 4 and f & 1 for f in flags) and any(f == 4 for f in flags) and any(f & 2 for f in flags)
+
+
+def seedless_pairs(pg, n=600, seed=5):
+    """every 6th pair: mate 2 (or mate 1) gets a substitution every 19 bases - no 25-base MEM, the pair fails jointly and is a case for orphan
+    recovery; a few pairs have one mate of noise (orphan search finds nothing good enough)"""
+    rng = np.random.default_rng(seed)
+    m1, m2, _ = make_pairs(pg, n, seed=seed)
+    for i in range(5, n, 6):
+        tgt = m2 if (i // 6) % 2 == 0 else m1
+        x = tgt[i].copy()
+        for p in range(9, len(x), 19):
+            x[p] = ord("A") if x[p] != ord("A") else ord("C")
+        tgt[i] = x
+    for i in range(2, n, 37):
+        m2[i] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=len(m2[i]))].copy()
+    return m1, m2
+
+
+def oracle_pe_orphan(o, m1, m2, b_size=512):
+    n = len(m1)
+    o1 = np.zeros(n + 1, np.uint64); o1[1:] = np.cumsum([len(x) for x in m1])
+    o2 = np.zeros(n + 1, np.uint64); o2[1:] = np.cumsum([len(x) for x in m2])
+    nm1 = [b"p%d/1" % i for i in range(n)]; nm2 = [b"p%d/2" % i for i in range(n)]
+    no1 = np.zeros(n + 1, np.uint64); no1[1:] = np.cumsum([len(x) for x in nm1])
+    no2 = np.zeros(n + 1, np.uint64); no2[1:] = np.cumsum([len(x) for x in nm2])
+    q1 = np.full(int(o1[-1]), ord("I"), np.uint8); q2 = np.full(int(o2[-1]), ord("I"), np.uint8)
+    return orc.align_pe(o, np.concatenate(m1), o1, np.concatenate(m2), o2, np.frombuffer(b"".join(nm1), np.uint8), no1,
+                        np.frombuffer(b"".join(nm2), np.uint8), no2, q1, q2, b_size=b_size, find_orphan=True)
+
+
+def test_pe_replay_orphan_recovery(case):
+    pg, fi, o = case
+    m1, m2 = seedless_pairs(pg)
+    want, st = oracle_pe_orphan(o, m1, m2, b_size=4096)
+    assert st["orphan_recovered"] > 20 and st["orphan_pairs"] > st["orphan_recovered"]
+    seq, offs, names, noff, q = interleave(m1, m2)
+    got, stats = hs.Sim(fi).align_pe_batch(seq, offs, names, noff, q, finalize=True, mean=st["ins_mean"], std_dev=st["ins_std_dev"], find_orphan=True)
+    assert int(stats[3]) == 0
+    if got != want:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
+    assert int(stats[1]) == st["aligned"]

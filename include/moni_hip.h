@@ -210,7 +210,7 @@ int moni_align_stream(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uin
 /* aligner::align with report_mems (-m; aligner_ksw2.hpp:346-373): one secondary record per MEM occurrence.  *sam is malloc'ed. */
 int moni_report_mems_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
                            const uint8_t *quals, const moni_align_params_t *prm, char **sam, uint64_t *sam_len);
-/* ---- the paired-end path: aligner::align(kpbseq_t*) (aligner_ksw2.hpp:888-918, 1000-1326) without orphan recovery ---------------- */
+/* ---- the paired-end path: aligner::align(kpbseq_t*) (aligner_ksw2.hpp:888-918, 1000-1326, 1536-1640) -------------------------------- */
 /* The batch holds the pairs interleaved: reads 2p and 2p+1 are mate 1 and mate 2 of pair p (kpbseq_t's two kbseq_t,
  * include/common/kpbseq.h:300-326).  find_orphan: orphan recovery (aligner_ksw2.hpp:1536-1640, 2329-2720) for the pairs that chain but fail
  * jointly; its local alignment is klib's ksw_align (an absent submodule) restated as plain DP with its tie rules. */

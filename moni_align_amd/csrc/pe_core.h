@@ -1,6 +1,6 @@
 // Per-pair logic of the PAIRED-END path, STL-free, on top of align_core.h: compiled for the device (pe_align_kernel: every lane
 // runs this code for its own pair, the whole wave runs the DP problems the pairs ask for) and for the host (tests/host_sim replays it).
-// Orphan recovery is not built (the reference's ksw_align / klib is absent): this is `-u`-less behaviour with find_orphan == false.
+// Orphan recovery (find_orphan) runs in the same state machine; its local alignment (klib's ksw_align) is a DP_EZ_LOCAL request.
 //   aligner_ksw2.hpp:1000-1326  align(paired_alignment_t&, finalize): the four (mate, strand) seed lists, direction filter,
 //                               frequency filter, find_chains, get_best_scores, the final paired_chain_score
 //   aligner_ksw2.hpp:1329-1431  get_best_scores;  :1471-1534 check_paired_left_MEM;  :2115-2290 paired_chain_score

@@ -10,7 +10,7 @@
 //                               product's paired path is checked against this mode); with find_orphan == true:
 //   aligner_ksw2.hpp:1536-1640  orphan_recovery;  :2329-2560 paired_chain_orphan_score;  :2566-2720 fill_orphan, on klib's ksw_align
 //                               (thirdparty/klib, an absent submodule: ksw.c's ksw_i16 + the KSW_XSTART second pass restated below from
-//                               the published source as plain DP with its tie rules) - groundwork: the product has no orphan recovery
+//                               the published source as plain DP with its tie rules)
 //   aligner_ksw2.hpp:1000-1326  align(paired_alignment_t&, finalize): seeding of the four (mate, strand) patterns with r_offset,
 //                               direction filter, frequency filter, chaining, get_best_scores, final paired_chain_score
 //   aligner_ksw2.hpp:1329-1431  get_best_scores;  :1471-1534 check_paired_left_MEM;  :2115-2290 paired_chain_score
@@ -52,7 +52,7 @@ struct pe_config_t {               // aligner_ksw2.hpp:94-128 defaults
     bool filter_dir = true;
     double dir_thr = 50.0;
     size_t ins_learning_n = 1000, ins_learning_score_gap_threshold = 0;
-    bool find_orphan = false;          // aligner_ksw2.hpp:128 (true in the reference; -u clears it).  The product is checked against false
+    bool find_orphan = false;          // aligner_ksw2.hpp:128 (true in the reference; -u clears it).  The product is checked in both modes
 };
 
 struct aligner_pe : aligner {

@@ -70,6 +70,80 @@ __device__ __attribute__((noinline)) void pe_sw_local(const dp_launch_t& D, pe_s
     }
     *out = r;
 }
+// The same pass by the whole wave (the kernel's default): 64 target rows at a time, lane l on row i0 + l, the cells of an anti-diagonal in one
+// step (lane l on column s - l); a lane takes H / E of the row above from lane l - 1 by one shuffle per step (lane 0: from the previous tile's
+// bottom row in LDS), keeps F and the diagonal to itself, and tracks its row's maximum and the leftmost column that reaches it; after a tile
+// the rows are visited in order for klib's rule (the first row that exceeds every earlier one; stop at endsc).  ~(qlen + 63) * tlen / 64 steps
+// instead of qlen * tlen cells by one lane.  qlen <= DP_LDS_Q; the dataflow was checked lane by lane against the oracle before it was written here.
+__device__ __attribute__((noinline)) void pe_sw_pass_wave(const dp_launch_t& D, dp_lds_t& L, const moni_dp_task_t& task, int qlen, int tlen, bool reverse, int q_last, int t_last,
+                                                          int endsc, int& score, int& te_out, int& qe_out) {
+    const int lane = threadIdx.x & 63;
+    const int mode = task.reserved;
+    int32_t* const Hb = L.H[0]; int32_t* const Eb = L.E; uint8_t* const qc = L.qs;
+    __syncthreads();
+    for (int j = lane; j < qlen; j += 64) {
+        const int k = reverse ? q_last - j : j;
+        uint32_t c = dp_nt4(D.reads[(mode & DP_Q_REV) ? task.q_off - (uint64_t)k : task.q_off + (uint64_t)k]);
+        if ((mode & DP_Q_COMP) && c < 4) c = 3 - c;
+        qc[j] = (uint8_t)c; Hb[j] = 0; Eb[j] = 0;
+    }
+    __syncthreads();
+    const int gape = D.e, gapoe = D.qo + D.e;
+    int gmax = 0, te = -1, qe = -1;
+    bool stop = false;
+    for (int i0 = 0; i0 < tlen && !stop; i0 += 64) {
+        const int i = i0 + lane;
+        const bool row_ok = i < tlen;
+        uint32_t tc = 4;
+        if (row_ok) {
+            const int ti = (reverse && i <= t_last) ? t_last - i : i;
+            const uint64_t ta = task.t_off + (uint64_t)ti;
+            tc = dp_nt4(ta < D.n_text ? D.text[ta] : 0u);
+        }
+        int pubH = 0, pubE = 0, upH_prev = 0, f = 0, rmax = 0, rarg = -1;
+        const int n_steps = qlen + 63;
+        for (int s = 0; s < n_steps; ++s) {
+            const int inH = __shfl_up(pubH, 1), inE = __shfl_up(pubE, 1);
+            const int j = s - lane;
+            const bool col_ok = j >= 0 && j < qlen;
+            int upH, upE, diag;
+            if (lane == 0) { upH = col_ok ? Hb[j] : 0; upE = col_ok ? Eb[j] : 0; diag = (j >= 1 && j < qlen) ? Hb[j - 1] : 0; }
+            else { upH = inH; upE = inE; diag = j >= 1 ? upH_prev : 0; upH_prev = upH; }
+            if (row_ok && col_ok) {
+                if (j == 0) f = 0;
+                const uint32_t q = qc[j];
+                const int sc = (tc >= 4 || q >= 4) ? 0 : (tc == q ? D.sc_mch : D.sc_mis);
+                int h = diag + sc;
+                h = h > upE ? h : upE; h = h > f ? h : f;
+                int hh = h - gapoe; hh = hh > 0 ? hh : 0;
+                int e2 = upE - gape; e2 = e2 > 0 ? e2 : 0; e2 = e2 > hh ? e2 : hh;
+                f -= gape; f = f > 0 ? f : 0; f = f > hh ? f : hh;
+                pubH = h; pubE = e2;
+                if (h > rmax) { rmax = h; rarg = j; }
+                if (lane == 63) { Hb[j] = h; Eb[j] = e2; }
+            }
+        }
+        __syncthreads();
+        for (int l = 0; l < 64; ++l) {
+            const int r = __shfl(rmax, l), a = __shfl(rarg, l);
+            if (i0 + l < tlen && !stop && r > gmax) { gmax = r; te = i0 + l; qe = a; if (gmax >= endsc) stop = true; }
+        }
+    }
+    if (qe < 0 && qlen > 0) qe = 0;
+    score = gmax; te_out = te; qe_out = qe;
+}
+__device__ __attribute__((noinline)) void pe_sw_local_wave(const dp_launch_t& D, dp_lds_t& L, const moni_dp_task_t& task, moni_dp_result_t* out) {
+    moni_dp_result_t r;
+    r.max = 0; r.max_q = r.max_t = -1; r.mqe = 0; r.mqe_t = -1; r.mte = -1; r.mte_q = -1; r.score = 0; r.reach_end = 0; r.zdropped = 0; r.n_cigar = 0; r.cigar_off = 0;
+    if (task.qlen > 0 && task.tlen > 0) {
+        int score, te, qe, s2, te2, qe2;
+        pe_sw_pass_wave(D, L, task, task.qlen, task.tlen, false, 0, 0, 0x10000, score, te, qe);
+        pe_sw_pass_wave(D, L, task, qe + 1, task.tlen, true, qe, te, score, s2, te2, qe2);
+        r.score = score; r.max_t = te; r.max_q = qe;
+        if (score == s2) { r.mte = te - te2; r.mte_q = qe - qe2; }
+    }
+    if ((threadIdx.x & 63) == 0) *out = r;
+}
 // the same for the host pipeline for pairs (pe_big.h): one lane per request
 extern "C" __global__ void __launch_bounds__(64) pe_sw_kernel(const dp_launch_t D, const moni_dp_task_t* tasks, uint32_t n, pe_sw_ws_t* ws, moni_dp_result_t* res) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
@@ -108,7 +182,7 @@ struct pe_args_t {
     const int32_t* min_score_of_len;
     uint32_t max_len;
     uint64_t pair_lo, n_pairs;               // this launch takes pairs [pair_lo, pair_lo + n_pairs) of the resident batch; records go to recs[pair - pair_lo]
-    uint32_t nl, pad;                        // pairs in flight per wavefront (lanes 0 .. nl-1 run state machines): the wave solves its pairs' DP problems one after
+    uint32_t nl, sw_wave;                    // sw_wave: the orphan search by the whole wave (pe_sw_local_wave) instead of the pair's own lane; nl: pairs in flight per wavefront (lanes 0 .. nl-1 run state machines): the wave solves its pairs' DP problems one after
                                              // the other, so fewer pairs per wave = shorter serial DP phases, more waves
     pe_slot_t* slots;                        // gridDim.x * nl
     ak_wave_t* waves;                        // gridDim.x
@@ -184,7 +258,7 @@ pe_align_kernel(const pe_args_t A) {
         const unsigned long long waiting = __ballot(state == 1);
         if (waiting == 0ull) { if (__ballot(state == 0 || state == 3) == 0ull) break; continue; }
         // the local-alignment requests of orphan recovery: each waiting lane solves its own (at most one per round)
-        if (state == 1) for (uint32_t t = 0; t < W.W.n_tasks; ++t) if (W.W.tasks[t].flag & DP_EZ_LOCAL) pe_sw_local(A.D, S->sw, W.W.tasks[t], &S->res[t]);
+        if (!A.sw_wave && state == 1) for (uint32_t t = 0; t < W.W.n_tasks; ++t) if (W.W.tasks[t].flag & DP_EZ_LOCAL) pe_sw_local(A.D, S->sw, W.W.tasks[t], &S->res[t]);
         __threadfence();
         // ---- phase 2 (whole wave): the DP problems of every waiting pair, one pair after the other ----
         for (unsigned long long todo = waiting; todo; todo &= todo - 1) {
@@ -200,7 +274,14 @@ pe_align_kernel(const pe_args_t A) {
             uint32_t cig_used = 0;
             for (uint32_t t = 0; t < nt; ++t) {
                 const moni_dp_task_t task = s_tasks[t];
-                if (task.flag & DP_EZ_LOCAL) continue;              // solved by the pair's own lane above
+                if (task.flag & DP_EZ_LOCAL) {                      // orphan search: by the wave, or already solved by the pair's own lane above
+                    if (A.sw_wave) {
+                        if (task.qlen > DP_LDS_Q) { too_big = true; break; }
+                        pe_sw_local_wave(A.D, L, task, &Q->res[t]);
+                        __syncthreads();
+                    }
+                    continue;
+                }
                 const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
                 const uint32_t cig_need = with_cigar && task.qlen > 0 && task.tlen > 0 ? (uint32_t)(task.qlen + task.tlen + 2) : 0u;
                 if (task.qlen > DP_LDS_Q || task.tlen > DP_LDS_T || cig_used + cig_need > AK_CIG_CAP ||

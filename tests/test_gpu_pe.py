@@ -164,6 +164,10 @@ def test_pe_orphan_recovery(case, monkeypatch):
     if got != want:
         raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
     assert aligned == st["aligned"]
+    monkeypatch.setenv("MONI_PE_SW_WAVE", "0")           # the one-lane form of the local alignment
+    got1, _, _ = on_gpu(fi, seq, offs, names, noff, q, 4096, find_orphan=True)
+    assert got1 == want
+    monkeypatch.delenv("MONI_PE_SW_WAVE")
     monkeypatch.setenv("MONI_PE_FORCE_BIG", "3")
     got2, _, _ = on_gpu(fi, seq, offs, names, noff, q, 4096, find_orphan=True)
     assert got2 == want

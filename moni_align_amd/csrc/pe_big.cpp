@@ -80,9 +80,9 @@ int pe_big_run(const void* pe_params, size_t pe_params_size, const moni_mem_t* m
             R.mate_score[0] = W.final.m1.score; R.mate_score[1] = W.final.m2.score;
             for (int k = 0; k < 2; ++k) {
                 R.score2_m[k] = W.score2_m[k];
-                R.filled[k] = 0; R.cig[k].clear(); R.alt_pos[k].clear(); R.alt_score[k].clear();
+                R.filled[k] = 0; R.orphan[k] = 0; R.cig[k].clear(); R.alt_pos[k].clear(); R.alt_score[k].clear();
                 if (R.status == 1 && PP.finalize && W.filled[k]) {
-                    R.filled[k] = 1; R.ref_pos[k] = W.ref_pos[k]; R.as[k] = W.as[k];
+                    R.filled[k] = 1; R.orphan[k] = W.orphan[k]; R.ref_pos[k] = W.ref_pos[k]; R.as[k] = W.as[k];
                     R.cig[k].assign(W.cigar[k], W.cigar[k] + W.n_cigar[k]);
                     R.alt_pos[k].assign(W.alt_pos[k], W.alt_pos[k] + W.n_alt[k]);
                     R.alt_score[k].assign(W.alt_score[k], W.alt_score[k] + W.n_alt[k]);

@@ -14,7 +14,7 @@ struct PeBigPair {
     int32_t tot = 0, score2 = 0, score2_m[2] = {0, 0}, sub_n = 0;
     long long dist = 0;
     int32_t mate_score[2] = {0, 0};
-    uint32_t filled[2] = {0, 0};
+    uint32_t filled[2] = {0, 0}, orphan[2] = {0, 0};
     uint64_t ref_pos[2] = {0, 0};
     int32_t as[2] = {0, 0};
     std::vector<uint32_t> cig[2];

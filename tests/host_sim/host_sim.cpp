@@ -15,6 +15,7 @@
 #include "../../moni_align_amd/csrc/align_core.h"
 #include "../../moni_align_amd/csrc/pe_core.h"
 #include "../../moni_align_amd/csrc/pe_host.hpp"
+#include "../../moni_align_amd/csrc/pe_big.h"
 #include "../../oracle/ksw2.hpp"      // CPU stand-in for extz_kernel in this harness (tests may use the oracle)
 #include "../../oracle/align_pe.hpp"  // ... and for the local-alignment requests of orphan recovery (klib ksw_align as restated there)
 
@@ -394,6 +395,75 @@ char* sim_align_pe_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint
     delete W;
     if (getenv("MH_TIMES")) fprintf(stderr, "host_sim pe: %.3f us per pair in pe_emit, %.3f in pe_emit_fast (%llu pairs)\n", t_emit / (double)(n_pairs ? n_pairs : 1) * 1e6, t_fast / (double)(n_pairs ? n_pairs : 1) * 1e6, (unsigned long long)n_pairs);
     if (n_fast_diff) return nullptr;
+    char* buf = (char*)malloc(out.size() + 1);
+    memcpy(buf, out.data(), out.size() + 1);
+    *out_len = out.size();
+    if (stats5) { stats5[0] = n_pairs; stats5[1] = n_aligned; stats5[2] = n_tasks; stats5[3] = n_over; stats5[4] = n_rounds; }
+    return buf;
+}
+// ---- the host pipeline for pairs (pe_big.cpp: pe_core.h with large capacities) with the CPU stand-ins for its DP batches: every pair of
+// the batch goes through it ----
+char* sim_align_pe_big_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_pairs, const uint8_t* names, const uint64_t* name_off,
+                             const uint8_t* quals, double mean, double std_dev, int find_orphan, uint64_t* out_len, uint64_t* stats5) {
+    Sim* S = (Sim*)s;
+    SimBackend be;
+    const uint64_t n_reads = 2 * n_pairs;
+    be.S = S; be.seq = seq; be.offs = offs; be.n_reads = n_reads;
+    moni_align_params_t P;
+    memset(&P, 0, sizeof P);
+    P.min_len = 25; P.ext_len = 100; P.check_k = 5; P.region_dist = 10; P.filter_seeds = 1; P.n_seeds_thr = 1000; P.filter_freq = 1;
+    P.left_mem_check = 1; P.freq_thr = 0.5; P.smatch = 2; P.smismatch = 4; P.gapo = 4; P.gapo2 = 13; P.gape = 2; P.gape2 = 1;
+    P.end_bonus = 400; P.w = -1; P.zdrop = -1; P.max_dist_x = 500; P.max_dist_y = 100; P.max_iter = 10; P.max_pred = 5;
+    P.min_chain_score = 40; P.min_chain_length = 1; P.host_threads = 1;
+    moni_seed_params_t sp{P.min_len, P.filter_seeds, P.n_seeds_thr, 0};
+    std::vector<moni_mem_t> gm; std::vector<uint64_t> go, rmo;
+    if (be.seed(sp, gm, go, rmo)) return nullptr;
+    pe_params_t PP;
+    memset(&PP, 0, sizeof PP);
+    ac_params_t& AP = PP.P;
+    AP.min_len = P.min_len; AP.ext_len = P.ext_len; AP.check_k = P.check_k; AP.region_dist = P.region_dist; AP.filter_freq = P.filter_freq;
+    AP.left_mem_check = P.left_mem_check; AP.freq_thr = P.freq_thr; AP.smatch = P.smatch; AP.gapo = P.gapo; AP.gapo2 = P.gapo2; AP.gape = P.gape;
+    AP.gape2 = P.gape2; AP.max_dist_x = P.max_dist_x; AP.max_dist_y = P.max_dist_y; AP.max_iter = P.max_iter; AP.max_pred = P.max_pred;
+    AP.min_chain_score = P.min_chain_score; AP.min_chain_length = P.min_chain_length; AP.n_text = S->hix.n_text; AP.n_seq = (uint32_t)S->hix.names.size();
+    AP.seq_starts = S->hix.seq_starts.data();
+    AP.lift_seqs = S->hix.lift_seqs.data(); AP.lift_runs = S->hix.lift_runs.data(); AP.pdir = nullptr;          // as moni_pe_align_batch hands it over
+    PP.smismatch = P.smismatch; PP.max_penalty = std::max(P.smatch + P.smismatch, P.gapo + P.gape); PP.filter_dir = 1; PP.finalize = 1;
+    PP.dir_thr = 50.0; PP.mean = (float)mean; PP.std_dev = (float)std_dev;
+    PP.find_orphan = find_orphan ? 1 : 0; PP.w = (uint32_t)S->hix.w; PP.ins_mean = mean; PP.ins_std_dev = std_dev;
+    moni_dp_params_t dp;
+    memset(&dp, 0, sizeof dp);
+    dp.m = 5;
+    for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) dp.mat[i * 5 + j] = i == j ? P.smatch : (int8_t)-P.smismatch; }
+    dp.q = P.gapo; dp.e = P.gape; dp.w = -1; dp.zdrop = -1; dp.end_bonus = P.end_bonus;
+    std::vector<uint64_t> rel(n_reads + 1);
+    for (uint64_t r = 0; r <= n_reads; ++r) rel[r] = offs[r] - offs[0];
+    std::vector<PeBigPair> pairs(n_pairs);
+    for (uint64_t p = 0; p < n_pairs; ++p) pairs[p].pair = p;
+    uint64_t n_tasks = 0, n_rounds = 0;
+    const int rc = pe_big_run(&PP, sizeof PP, gm.data(), rmo.data(), S->aux.data(), go.data(), rel.data(), pairs,
+                              [&](const std::vector<moni_dp_task_t>& t, std::vector<moni_dp_result_t>& r, std::vector<uint32_t>& cg) -> int { n_tasks += t.size(); ++n_rounds; return be.dp(dp, t, r, cg); });
+    if (rc) return nullptr;
+    mh::Aligner A(S->hix, P, seq, offs);
+    std::string out;
+    uint64_t n_aligned = 0, n_over = 0;
+    for (uint64_t p = 0; p < n_pairs; ++p) {
+        const PeBigPair& B = pairs[p];
+        if (B.status == 2) ++n_over;
+        mh::PePairOut R;
+        R.finalized = B.status == 1; R.strand = B.strand; R.tot = B.tot; R.score2 = B.score2; R.sub_n = B.sub_n;
+        int32_t ms = 0;
+        for (int k = 0; k < 2; ++k) {
+            R.score2_m[k] = B.score2_m[k];
+            mh::PeMateOut& M = R.mate[k];
+            M.m = (uint32_t)(rel[2 * p + k + 1] - rel[2 * p + k]); M.off = rel[2 * p + k]; M.score = B.mate_score[k]; M.filled = R.finalized && B.filled[k];
+            M.ref_pos = B.ref_pos[k]; M.as = B.as[k]; M.cig = B.cig[k].data(); M.n_cig = (uint32_t)B.cig[k].size();
+            M.alt_pos = B.alt_pos[k].data(); M.alt_score = B.alt_score[k].data(); M.n_alt = (uint32_t)B.alt_pos[k].size(); M.orphan = B.orphan[k] != 0;
+            ms += (int32_t)(20 + 8 * log((double)M.m));
+        }
+        if (R.finalized && R.tot >= ms) ++n_aligned;
+        mh::pe_emit_fast(A, P, R, (const char*)names + name_off[2 * p], (size_t)(name_off[2 * p + 1] - name_off[2 * p]), (const char*)names + name_off[2 * p + 1],
+                         (size_t)(name_off[2 * p + 2] - name_off[2 * p + 1]), seq, quals, out);
+    }
     char* buf = (char*)malloc(out.size() + 1);
     memcpy(buf, out.data(), out.size() + 1);
     *out_len = out.size();

@@ -17,9 +17,10 @@ def lib():
     if _lib is None:
         so = os.path.join(HERE, "libhost_sim.so")
         srcs = [os.path.join(HERE, "host_sim.cpp"), os.path.join(ROOT, "oracle", "ksw2.hpp")] + \
-               [os.path.join(capi.CSRC, f) for f in ("seed_core.h", "image.hpp", "layout.h", "align_host.hpp", "align_core.h", "pe_core.h", "pe_host.hpp", "../../oracle/align_pe.hpp", "sort_emul.h", "lift_core.h", "lift_build.hpp")]
+               [os.path.join(capi.CSRC, f) for f in ("seed_core.h", "image.hpp", "layout.h", "align_host.hpp", "align_core.h", "pe_core.h", "pe_host.hpp", "pe_big.h", "pe_big.cpp", "../../oracle/align_pe.hpp", "sort_emul.h", "lift_core.h", "lift_build.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(HERE, "host_sim.cpp")])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(HERE, "host_sim.cpp"),
+                                   os.path.join(capi.CSRC, "pe_big.cpp")])
         L = C.CDLL(so)
         L.sim_create.restype = C.c_void_p
         L.sim_create.argtypes = [C.POINTER(capi.FlatIndexC)]
@@ -41,6 +42,9 @@ def lib():
         L.sim_align_pe_batch.restype = C.c_void_p
         L.sim_align_pe_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
                                          C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+        L.sim_align_pe_big_batch.restype = C.c_void_p
+        L.sim_align_pe_big_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
+                                             C.POINTER(C.c_uint64), C.c_void_p]
         L.sim_free.argtypes = [C.c_void_p]
         L.liftsim_create.restype = C.c_void_p
         L.liftsim_create.argtypes = [C.POINTER(capi.FlatIndexC)]
@@ -142,6 +146,25 @@ class Sim:
             raise RuntimeError("sim_align_pe_batch failed")
         try:
             return (C.string_at(p, ln.value) if finalize else learn), st
+        finally:
+            lib().sim_free(p)
+
+    def align_pe_big_batch(self, seq, offsets, names, name_off, quals=None, mean=0.0, std_dev=0.0, find_orphan=False):
+        """Every pair through the host pipeline for pairs (pe_big.cpp) with the CPU stand-ins for its DP batches."""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        names = np.ascontiguousarray(names, dtype=np.uint8)
+        name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
+        if quals is not None:
+            quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        ln = C.c_uint64()
+        st = np.zeros(5, dtype=np.uint64)
+        p = lib().sim_align_pe_big_batch(self.h, seq.ctypes.data, offsets.ctypes.data, (len(offsets) - 1) // 2, names.ctypes.data, name_off.ctypes.data,
+                                         quals.ctypes.data if quals is not None else None, float(mean), float(std_dev), int(find_orphan), C.byref(ln), st.ctypes.data)
+        if not p:
+            raise RuntimeError("sim_align_pe_big_batch failed")
+        try:
+            return C.string_at(p, ln.value), st
         finally:
             lib().sim_free(p)
 

@@ -184,3 +184,25 @@ def test_pe_replay_orphan_recovery(case):
     if got != want:
         raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
     assert int(stats[1]) == st["aligned"]
+
+
+def test_pe_host_pipeline_replay(case):
+    """pe_big.cpp (the host pipeline for pairs: pe_core.h compiled with large capacities in its own namespace) on the CPU, every pair through
+    it: hard cases, and orphan recovery - its records must give the oracle's text too"""
+    pg, fi, o = case
+    S = hs.Sim(fi)
+    m1, m2 = hard_pairs(pg, n=300, seed=29)
+    want, st = oracle_pe(o, m1, m2, slash=False, b_size=4096)
+    seq, offs, names, noff, q = interleave(m1, m2, slash=False)
+    got, stats = S.align_pe_big_batch(seq, offs, names, noff, q, mean=st["ins_mean"], std_dev=st["ins_std_dev"])
+    assert int(stats[3]) == 0
+    if got != want:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
+    m1, m2 = seedless_pairs(pg, n=300, seed=8)
+    want, st = oracle_pe_orphan(o, m1, m2, b_size=4096)
+    assert st["orphan_recovered"] > 10
+    seq, offs, names, noff, q = interleave(m1, m2)
+    got, stats = S.align_pe_big_batch(seq, offs, names, noff, q, mean=st["ins_mean"], std_dev=st["ins_std_dev"], find_orphan=True)
+    if got != want:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
+    assert int(stats[1]) == st["aligned"]

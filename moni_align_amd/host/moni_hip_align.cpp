@@ -371,6 +371,14 @@ static int run_paired(Args& a, const std::string& sam_filename) {
     a.PE.find_orphan = a.find_orphan ? 1 : 0;            // -u switches orphan recovery off (align_full_ksw2.cpp:248-250)
     info("Output file: " + sam_filename);
     AnyReader r1(a.mate1), r2(a.mate2);
+    if (a.dry_run) {
+        Batch b;
+        const size_t n = read_pairs(r1, r2, (size_t)-1, b);
+        printf("dry-run: pairs=%zu bases=%zu min_len=%u filter_dir=%u dir_thr=%.1f find_orphan=%u b=%zu threads=%zu gpus=%d out=%s first=%.*s second=%.*s\n", n, b.seq.size(),
+               a.P.min_len, a.PE.filter_dir, a.PE.dir_thr, a.PE.find_orphan, a.b, a.th, a.gpus, sam_filename.c_str(), n ? (int)b.name_off[1] : 0,
+               n ? (const char*)b.names.data() : "", n ? (int)(b.name_off[2] - b.name_off[1]) : 0, n ? (const char*)b.names.data() + b.name_off[1] : "");
+        return 0;
+    }
     const std::string idx_path = a.filename + ".mfi";
     const bool have_mfi = access(idx_path.c_str(), R_OK) == 0;
     const std::string ms_path = a.filename + ".thrbv.full.lcp.ms", ldx_path = a.filename + ".ldx", txt_path = a.filename + ".txt";

@@ -189,3 +189,25 @@ def test_cli_paired_end(exe, medium_case, tmp_path):
     subprocess.check_call([exe, prefix, "-1", f1, "-2", f2, "-o", out2, "-S", "1000", "-F", "0.5", "-t", "4", "-b", "512", "--gpu-batch", "2048"])
     want2, _ = oracle_pe(o, m1, m2, b_size=512, find_orphan=True)
     assert open(out2, "rb").read()[len(hdr):] == want2
+
+
+def test_dry_run_paired(exe, tmp_path):
+    """-1 / -2 argument handling and the two readers (plain + gzip) without a GPU"""
+    f1, f2 = str(tmp_path / "a_1.fq"), str(tmp_path / "a_2.fq.gz")
+    with open(f1, "w") as f:
+        f.write("".join("@x%d/1 c\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(7)))
+    with gzip.open(f2, "wt") as f:
+        f.write("".join("@x%d/2\nTTGCA\n+\nIIIII\n" % i for i in range(7)))
+    out = subprocess.check_output([exe, "idx/pref", "-1", f1, "-2", f2, "-u", "-d", "-D", "40", "-b", "256", "-l", "30", "--dry-run"]).decode()
+    assert "pairs=7 bases=105" in out and "filter_dir=0 dir_thr=40.0 find_orphan=0 b=256" in out and "first=x0/1 second=x0/2" in out
+    assert ("out=%s_pref_30.sam" % f1) in out
+    out = subprocess.check_output([exe, "idx/pref", "-1", f1, "-2", f2, "--dry-run"]).decode()
+    assert "filter_dir=1 dir_thr=50.0 find_orphan=1 b=512" in out
+    # different numbers of records
+    with open(f1, "a") as f:
+        f.write("@extra/1\nACGT\n+\nIIII\n")
+    r = subprocess.run([exe, "idx/pref", "-1", f1, "-2", f2, "--dry-run"], capture_output=True)
+    assert r.returncode == 1 and b"different numbers of records" in r.stderr
+    # only one mate file
+    r = subprocess.run([exe, "idx/pref", "-1", f1, "--dry-run"], capture_output=True)
+    assert r.returncode == 1 and b"needs both -1 and -2" in r.stderr

@@ -1,36 +1,45 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the HIP hot path on the BASELINE.json workload.
 
-One "step" = one pass of the whole single-end hot path over one resident batch of synthetic 150 bp reads on the
-mouse-chr19-scale index built `-r ref -v vcf -H12` style (12 haplotypes that lift onto the reference contig: BASELINE.json
-configs[2]): MEM seeding (MS pointers by LF / threshold jumps -> MEMs -> phi / phi^-1 occurrence enumeration, both strands), then
-the staged align kernels (chaining, chain selection, lane-per-problem ksw2 DP, traceback, lift-over, MD/NM, MAPQ, the SAM line of
-every read) and the host stage that puts the lines in read order.  The reads are in HBM when the timed region starts; the step
-ends with the batch's SAM text in host memory.
+One "step" = one pass of the whole single-end hot path over this rank's reads, resident in HBM, on the mouse-chr19-scale index
+built `-r ref -v vcf -H12` style (12 haplotypes that lift onto the reference contig): MEM seeding (MS pointers by LF / threshold
+jumps -> MEMs -> phi / phi^-1 occurrence enumeration, both strands), then the staged align kernels (chaining, chain selection,
+lane-per-problem ksw2 DP, traceback, lift-over, MD/NM, MAPQ, the SAM line of every read, lines put in read order).  The step ends
+with the SAM text in pinned host memory.
 
-N > 1: one process per GPU (torch.distributed / RCCL), index replicated, no data-path collective inside the step.
-  default       every rank aligns its own --reads reads                                   ("weak":   per-GPU batch fixed)
-  --total-reads one read set of that size, sharded by contiguous ranges over the ranks   ("strong": BASELINE.json configs[3])
-  --gather-sam  after the timed steps, the per-rank SAM blocks go to rank 0 over RCCL (sizes by all-gather, blocks by
-                send/recv) and the time of that gather is reported beside the step time
+  N = 1 (default)   BASELINE.json configs[2]: 1 M x 150 bp reads, one resident batch                          ("weak")
+  N > 1 (default)   BASELINE.json configs[3]: ONE read set of 10 M reads, sharded by contiguous ranges over the ranks; a rank
+                    goes through its shard in resident chunks of <= --reads reads (moni_reads_swap)           ("strong")
+                    and, after the timed steps, the per-rank SAM blocks go to rank 0 over RCCL (sizes by all-gather, blocks by
+                    send/recv): the `gather` block of the line; --no-gather-sam skips it
+  --total-reads T   the sharded mode with T reads at any N (N = 1: the same set on one GPU, the base of the scaling curve)
+
+`python bench.py --gpus N` starts the N rank processes itself when it is not already running under a launcher (no RANK in the
+environment): fresh children, one GPU each, RCCL; the parent never touches the GPU.  Under `python -m torch.distributed.run` the
+ranks come from the launcher.  --dry-run rehearses the launch, the sharding and the gather on CPU (gloo) without any GPU.
 
 Prints ONE JSON line (rank 0).  Everything in it is measured in this run: `roofline` prices ms_lf_kernel (the path's HBM-bound
 kernel) with HIP events recorded inside the library on the kernel's own stream; `whole_path` prices the step against SURVEY.md
 §8(d)'s bytes(read) = 128 S + 64 J + 128 P + C + R with all five counted by the kernels; `align` carries the HIP-event times of
-the align kernels by group and the DP rate; `cpu_baseline` is the CPU oracle's whole path on a bounded sample (rank 0, N == 1).
+the align kernels by group and the DP rate; `from_host` is the same batch from host memory to SAM text in host memory
+(moni_align_stream: upload included); `cpu_baseline` is the CPU oracle's whole path on a bounded sample (rank 0, N == 1).
 HBM traffic from rocprofv3 PMC passes cannot be collected from inside this process; the last committed pass is named under
 `roofline.traffic_static_from` and never mixed into the measured fields.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 # HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); the align stage runs its launches on
 # two streams next to a copy stream and two hand-over streams, and with RCCL's own streams in the process (N > 1) some would share
 # a queue and serialise.  Read by the HIP runtime when it starts, so it is set before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
 
 import numpy as np
 
@@ -38,7 +47,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9      # 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md: a wave64 VALU op issues over 2 cycles)
+CONFIGS3_READS = 10_000_000
 
 
 def log(*a):
@@ -57,31 +66,116 @@ def host_cpus() -> int:
     return max(1, min(n, 128))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--base-len", type=int, default=61420004)   # GRCm39 chr19
     ap.add_argument("--haps", type=int, default=12)
-    ap.add_argument("--reads", type=int, default=1000000, help="reads per GPU (weak scaling)")
-    ap.add_argument("--total-reads", type=int, default=0, help="one read set of this size sharded over the ranks (strong scaling)")
+    ap.add_argument("--reads", type=int, default=1000000, help="reads of one resident batch (N = 1: the batch; sharded mode: the largest chunk)")
+    ap.add_argument("--total-reads", type=int, default=-1,
+                    help="one read set of this size sharded over the ranks (strong scaling); default: %d when N > 1, off when N = 1; 0 = off (every rank its own --reads reads: weak)" % CONFIGS3_READS)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--repeats", type=float, default=0.0, help="fraction of the base genome made of interspersed repeat copies (SURVEY.md 8(d): 0.05)")
     ap.add_argument("--fasta-index", action="store_true", help="the same text as a FASTA-built index (null lifts)")
-    ap.add_argument("--gather-sam", action="store_true", help="N > 1: gather the per-rank SAM blocks on rank 0 over RCCL after the timed steps")
+    ap.add_argument("--gather-sam", dest="gather_sam", action="store_true", default=None, help="gather the per-rank SAM blocks on rank 0 over RCCL after the timed steps (default at N > 1)")
+    ap.add_argument("--no-gather-sam", dest="gather_sam", action="store_false")
+    ap.add_argument("--verify-gather", action="store_true", help="rank 0 also aligns the whole read set by itself and compares the gathered text with it byte for byte (rehearsals: use a small --total-reads)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-from-host", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: launch, rendezvous (gloo), sharding and the SAM gather with placeholder records")
     ap.add_argument("--cache", default="/tmp/moni_bench_cache")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+# ---- launcher: `python bench.py --gpus N` outside torch.distributed.run -------------------------------------------------
+def launch_ranks(args) -> int:
+    """Start args.gpus rank processes (fresh interpreters; this parent has not initialised HIP and never does), one GPU each, and
+    wait for them.  Rank 0 inherits stdout (the JSON line); the other ranks' stdout goes to stderr."""
+    n = args.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "MONI_BENCH_SELF_LAUNCHED": "1"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    log("launcher: started %d ranks (pids %s), rendezvous 127.0.0.1:%d" % (n, [p.pid for p in procs], port))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                log("launcher: rank %d exited with code %d; stopping the others" % (r, code))
+                for o in alive:
+                    procs[o].terminate()          # exactly the children started above
+        time.sleep(0.2)
+    return rc
+
+
+# ---- dry run: the multi-rank plumbing without a GPU -----------------------------------------------------------------------
+def placeholder_block(lo: int, hi: int) -> bytes:
+    """unaligned SAM records (flag 4) of reads [lo, hi): stands in for a rank's SAM block in the dry run"""
+    return b"".join(b"simulated.%d\t4\t*\t0\t255\t*\t*\t0\t0\tACGT\tIIII\n" % i for i in range(lo, hi))
+
+
+def dry_run(args) -> int:
+    import torch      # noqa: F401
+    from moni_align_amd import dist as mdist
+    rank, local_rank, world = mdist.env_world()
+    dist = mdist.init("gloo", rank, world) if world > 1 else None
+    total = args.total_reads if args.total_reads > 0 else (CONFIGS3_READS if world > 1 else args.reads)
+    total = min(total, 200000)                       # placeholder text only
+    lo, hi = mdist.shard_range(total, rank, world)
+    chunks = chunk_bounds(hi - lo, args.reads)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    blk = placeholder_block(lo, hi)
+    elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dist)
+    sizes = mdist.gather_counts([hi - lo, len(blk), len(chunks) - 1], dist)
+    tg = time.perf_counter()
+    got, gsz = mdist.gather_sam(blk, dist)
+    tg = mdist.max_over_ranks(time.perf_counter() - tg, dist)
+    if rank == 0:
+        same = bytes(got.numpy().tobytes()) == placeholder_block(0, total)
+        print(json.dumps({"metric": "dry run (no GPU): launch, rendezvous, sharding, gather", "dry_run": True, "value": 0.0, "unit": "reads/s",
+                          "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": elapsed * 1e3, "higher_is_better": True,
+                          "scaling": "strong" if world > 1 or args.total_reads > 0 else "weak", "vs_baseline": None, "data": "placeholder records",
+                          "config": {"workload": "placeholder", "total_reads": total, "reads_per_rank": [x[0] for x in sizes], "chunks_per_rank": [x[2] for x in sizes]},
+                          "gather": {"seconds": tg, "bytes": int(sum(gsz)), "per_rank_bytes": gsz, "identical_to_unsharded": bool(same)},
+                          "launched_by": "bench.py" if os.environ.get("MONI_BENCH_SELF_LAUNCHED") else "external launcher"}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def chunk_bounds(n: int, chunk_max: int):
+    """even split of n reads into the fewest chunks of at most chunk_max reads: k+1 boundaries"""
+    k = max(1, -(-n // max(1, chunk_max)))
+    return [n * i // k for i in range(k + 1)]
+
+
+# ---- one rank ---------------------------------------------------------------------------------------------------------------
+def run_rank(args) -> int:
     import torch
     from moni_align_amd import dist as mdist
     rank, local_rank, world = mdist.env_world()
     if world != args.gpus:
         log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback (--dry-run rehearses the multi-rank plumbing without one)")
     # rehearsal overrides (several ranks on one GPU with gloo); the driver's multi-GPU run uses the defaults: RCCL, one GPU per rank
     backend = os.environ.get("MONI_BENCH_BACKEND", "nccl")
     if "MONI_BENCH_DEVICE" in os.environ:
@@ -93,6 +187,10 @@ def main():
         dist = mdist.init(backend, rank, world, local_rank)
 
     from moni_align_amd import capi, index_build, synth
+
+    total = args.total_reads if args.total_reads >= 0 else (CONFIGS3_READS if world > 1 else 0)
+    sharded = total > 0
+    gather_on = (world > 1) if args.gather_sam is None else (args.gather_sam and world > 1)
 
     # ---- inputs (seeded, synthetic: SURVEY.md §8(d)) -------------------------------------------------
     t0 = time.time()
@@ -123,71 +221,133 @@ def main():
     log("rank %d: device image %.2f GB in %.1fs" % (rank, idx.device_bytes / 1e9, time.time() - t0))
     ctx = capi.Ctx(idx)
     L = args.read_len
-    if args.total_reads > 0:          # strong scaling: one read set, this rank's contiguous range of it
-        all_reads = synth.make_reads(pg, args.total_reads, L, seed=150)
-        lo, hi = mdist.shard_range(args.total_reads, rank, world)
-        reads = np.ascontiguousarray(all_reads[lo:hi])
-        all_names, all_noff = synth.make_names(args.total_reads)
-        names = all_names[int(all_noff[lo]):int(all_noff[hi])]
-        noff = (all_noff[lo:hi + 1] - all_noff[lo]).astype(np.uint64)
-        del all_reads
+    if sharded:            # strong scaling: one read set, this rank's contiguous range of it, in resident chunks
+        lo, hi = mdist.shard_range(total, rank, world)
+        reads = synth.make_reads_range(pg, lo, hi, L, seed=1500)
+        names, noff = synth.make_names_range(lo, hi)
         scaling = "strong"
     else:
+        lo, hi = 0, args.reads
         reads = synth.make_reads(pg, args.reads, L, seed=150 + rank)
         names, noff = synth.make_names(args.reads)
         scaling = "weak"
     n_mine = reads.shape[0]
+    cb = chunk_bounds(n_mine, args.reads)
+    n_chunks = len(cb) - 1
+    quals = np.full(n_mine * L, ord("I"), dtype=np.uint8)
+    chunk = []          # per chunk: (names, name offsets, quals) views + the read count
+    for k in range(n_chunks):
+        a, b = cb[k], cb[k + 1]
+        offs_k = np.arange(0, (b - a + 1) * L, L, dtype=np.uint64)
+        ctx.upload(reads[a:b].reshape(-1), offs_k)
+        if n_chunks > 1:
+            ctx.swap(k)                                   # parked in HBM; swapped in for its turn
+        chunk.append((names[int(noff[a]):int(noff[b])], (noff[a:b + 1] - noff[a]).astype(np.uint64), quals[a * L:b * L], b - a))
     offs = np.arange(0, (n_mine + 1) * L, L, dtype=np.uint64)
-    ctx.upload(reads.reshape(-1), offs)
     del pg
+    log("rank %d: reads [%d, %d) resident in %d chunk(s)" % (rank, lo, hi, n_chunks))
 
     def sync_all():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup + timed steps: the whole single-end path over the resident batch ------------------------------
-    quals = np.full(n_mine * L, ord("I"), dtype=np.uint8)
     threads = max(1, host_cpus() // max(1, world))          # host stage threads of this rank
+
+    def one_pass(want_text=False, acc=None):
+        """the whole path over every resident chunk of this rank; returns (SAM bytes or total length, stats of the last chunk)"""
+        outs, st_last, tot_len = [], None, 0
+        for k in range(n_chunks):
+            nm, no, ql, _ = chunk[k]
+            if n_chunks > 1:
+                ctx.swap(k)
+            sam, st = ctx.align_run(nm, no, ql, host_threads=threads, want_text=want_text)
+            if acc is not None:
+                acc(st)
+            if n_chunks > 1:
+                ctx.swap(k)
+            if want_text:
+                outs.append(sam)
+            else:
+                tot_len += sam
+            st_last = st
+        return (b"".join(outs) if want_text else tot_len), st_last
+
+    # ---- warmup + timed steps ------------------------------------------------------------------------------------------------
     for _ in range(args.warmup):
-        ctx.align_run(names, noff, quals, host_threads=threads, want_text=False)
+        one_pass()
     sync_all()
     kern = np.zeros(7)
     stage = {"seed": 0.0, "align_kernels_span": 0.0, "align_stage": 0.0, "host_stage_busy": 0.0}
     grp = {"chain_plan": 0.0, "dp_lane": 0.0, "select_traceback": 0.0, "finish": 0.0}
-    stf = None
+    tot = {"aligned": 0, "dp_tasks": 0, "dp_cells": 0, "kernel_fallback": 0, "handed_back": 0, "dp_ref_bytes": 0}
+    cnt = np.zeros(4, dtype=np.uint64)
+    n_calls = [0]
+
+    def acc(st):
+        kern[:] += [ctx.kernel_ms(w) if w != 5 else 0.0 for w in range(7)]
+        stage["seed"] += st["t_seed"]; stage["align_kernels_span"] += st["t_dp_kernel"]; stage["align_stage"] += st["t_dp"]
+        stage["host_stage_busy"] += st["t_host"]
+        grp["chain_plan"] += st["t_k_chain"]; grp["dp_lane"] += st["t_k_dp"]; grp["select_traceback"] += st["t_k_select"]; grp["finish"] += st["t_k_finish"]
+        for k2 in tot:
+            tot[k2] += st[k2]
+        cnt[:] += ctx.counters()
+        n_calls[0] += 1
+
+    sam_len = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sam_len, stf = ctx.align_run(names, noff, quals, host_threads=threads, want_text=False)
-        kern += [ctx.kernel_ms(w) if w != 5 else 0.0 for w in range(7)]
-        stage["seed"] += stf["t_seed"]; stage["align_kernels_span"] += stf["t_dp_kernel"]; stage["align_stage"] += stf["t_dp"]
-        stage["host_stage_busy"] += stf["t_host"]
-        grp["chain_plan"] += stf["t_k_chain"]; grp["dp_lane"] += stf["t_k_dp"]; grp["select_traceback"] += stf["t_k_select"]; grp["finish"] += stf["t_k_finish"]
+        sam_len, _ = one_pass(acc=acc)
     sync_all()
     elapsed = time.perf_counter() - t0
     elapsed = mdist.max_over_ranks(elapsed, dist, coll_dev)
-    kern /= max(1, args.steps)
+    steps = max(1, args.steps)
+    kern_launch = kern / max(1, n_calls[0])          # per launch (= per chunk)
     for d in (stage, grp):
         for k in d:
-            d[k] /= max(1, args.steps)
-    cnt = ctx.counters()
-    sizes = mdist.gather_counts([stf["aligned"], sam_len, n_mine], dist, coll_dev)     # per-rank record counts
+            d[k] /= steps                             # per step (all chunks of the rank)
+    for k in tot:
+        tot[k] //= steps
+    cnt = cnt // np.uint64(steps)
+    sizes = mdist.gather_counts([tot["aligned"], sam_len, n_mine], dist, coll_dev)     # per-rank record counts
 
-    # the final SAM gather of the north star: per-rank blocks to rank 0 over RCCL, timed on its own
+    # ---- the final SAM gather of the north star: per-rank blocks to rank 0 over RCCL, timed on its own ----------------------
     gather = None
-    if args.gather_sam and dist is not None:
-        sam_bytes, _ = ctx.align_run(names, noff, quals, host_threads=threads)
+    if gather_on:
+        sam_bytes, _ = one_pass(want_text=True)
         blk = torch.frombuffer(bytearray(sam_bytes), dtype=torch.uint8).to(coll_dev)
+        del sam_bytes
         sync_all()
         tg = time.perf_counter()
         got, gsz = mdist.gather_sam(blk, dist, coll_dev)
         sync_all()
         tg = mdist.max_over_ranks(time.perf_counter() - tg, dist, coll_dev)
-        gather = {"seconds": tg, "bytes": int(sum(gsz)), "GB/s": sum(gsz) / tg / 1e9 if tg > 0 else None,
-                  "note": "SAM blocks device to device into rank 0 (all-gather of sizes + send/recv), outside the timed steps"}
+        gather = {"seconds": tg, "bytes": int(sum(gsz)), "GB/s": sum(gsz) / tg / 1e9 if tg > 0 else None, "per_rank_bytes": gsz, "backend": backend,
+                  "note": "SAM blocks device to device into rank 0, in rank (= input) order (all-gather of sizes + send/recv), after the timed steps"}
+        if rank == 0:
+            n_lines = int((got == 10).sum().item())
+            gather["records"] = n_lines
+            gather["records_match_reads"] = bool(n_lines == sum(x[2] for x in sizes))
+            if args.verify_gather and sharded:
+                # the whole set on this rank alone, chunk by chunk in a second context: the unsharded text
+                pg2 = synth.make_pangenome(args.base_len, args.haps, seed=19, var_seed=12, repeat_frac=args.repeats)
+                ctx2 = capi.Ctx(idx)
+                whole = []
+                wb = chunk_bounds(total, args.reads)
+                for k in range(len(wb) - 1):
+                    rk = synth.make_reads_range(pg2, wb[k], wb[k + 1], L, seed=1500)
+                    nk, nok = synth.make_names_range(wb[k], wb[k + 1])
+                    ok = np.arange(0, (rk.shape[0] + 1) * L, L, dtype=np.uint64)
+                    s, _ = ctx2.align_batch(rk.reshape(-1), ok, nk, nok, np.full(rk.size, ord("I"), np.uint8), host_threads=threads, stream=True)
+                    whole.append(s)
+                ctx2.close()
+                del pg2
+                gather["identical_to_unsharded"] = bool(bytes(got.cpu().numpy().tobytes()) == b"".join(whole))
         del got, blk
 
-    # seeding stage alone (BASELINE.json configs[1]), same resident batch
+    # ---- seeding stage alone (BASELINE.json configs[1]) on the first resident chunk ------------------------------------------
+    if n_chunks > 1:
+        ctx.swap(0)
     ts = time.perf_counter()
     n_seed_rep = 3
     for _ in range(n_seed_rep):
@@ -196,19 +356,52 @@ def main():
     seed_s = (time.perf_counter() - ts) / n_seed_rep
     res = ctx.seed_fetch()
     n_mems, n_occs = len(res["mems"]), len(res["occs"])
+    n_first = chunk[0][3]
 
-    out = None
+    # ---- the same batch from host memory: upload + whole path + text in host memory (moni_align_stream) ----------------------
+    from_host = None
+    if rank == 0 and world == 1 and not args.no_from_host:
+        nm, no, ql, nb = chunk[0]
+        rd = reads[:nb].reshape(-1)
+        ob = offs[:nb + 1]
+        ctx.align_batch(rd, ob, nm, no, ql, host_threads=threads, stream=True)
+        reps = max(3, min(10, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ctx.align_batch(rd, ob, nm, no, ql, host_threads=threads, stream=True)
+        one_s = (time.perf_counter() - t1) / reps
+        # a streaming caller keeps two contexts per GPU going (moni-hip-align runs three): one uploads / seeds while the other aligns
+        ctx_b = capi.Ctx(idx)
+        ctx_b.align_batch(rd, ob, nm, no, ql, host_threads=threads, stream=True)
+
+        def worker(cx, n):
+            for _ in range(n):
+                cx.align_batch(rd, ob, nm, no, ql, host_threads=max(1, threads // 2), stream=True)
+        th = [threading.Thread(target=worker, args=(cx, reps)) for cx in (ctx, ctx_b)]
+        t1 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        two_s = (time.perf_counter() - t1) / (2 * reps)
+        ctx_b.close()
+        from_host = {"value": nb / one_s, "unit": "reads/s", "ms_per_batch": one_s * 1e3, "batch_reads": nb,
+                     "two_contexts": {"value": nb / two_s, "unit": "reads/s", "ms_per_batch": two_s * 1e3,
+                                      "note": "two contexts on the GPU, one caller thread each (the arrangement of moni-hip-align's workers): uploads and seeding of one overlap the align kernels of the other"},
+                     "note": "moni_align_stream: reads, names, qualities in pageable host memory -> SAM text in the context's pinned buffer; upload inside the timed call (align_full_ksw2.cpp:333,399-402 wraps file -> file; FASTQ parsing and file writes are the front end's, profiles/frontend.py)"}
+
     if rank == 0:
-        S, J, P, C = (int(x) for x in cnt)
-        R = int(stf["dp_ref_bytes"])
+        S, J, P, C = (int(x) for x in cnt)          # per step, this rank
+        R = int(tot["dp_ref_bytes"])
         n_all = sum(x[2] for x in sizes)
-        step_s = elapsed / args.steps
-        ms_bytes = 128 * S + 64 * J                 # algorithmic bytes of the LF stage
-        ms_s = kern[0] / 1e3
+        step_s = elapsed / steps
+        S1, J1 = S / n_chunks, J / n_chunks          # per launch (= per chunk)
+        ms_bytes = 128 * S1 + 64 * J1                # algorithmic bytes of the LF stage
+        ms_s = kern_launch[0] / 1e3
         achieved = ms_bytes / ms_s / 1e9 if ms_s > 0 else 0.0
-        layout_bytes = 73 * S      # what the move-structure layout itself needs per LF step: one 64-byte fast row, one 8-byte pointer store, 1/8 of a packed pattern word
+        layout_bytes = 73 * S1      # what the move-structure layout itself needs per LF step: one 64-byte fast row, one 8-byte pointer store, 1/8 of a packed pattern word
         path_bytes = 128 * S + 64 * J + 128 * P + C + R
-        value = n_all * args.steps / elapsed
+        value = n_all * steps / elapsed
         out = {
             "metric": "aligned reads/s (whole node), %d bp SE, mouse-chr19-scale x%d-haplotype index" % (L, args.haps),
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -217,74 +410,77 @@ def main():
             "config": {"workload": "BASELINE.json configs[%d]: mouse-chr19-scale index (%d bp base%s + %d haplotypes, %s, n=%d, r=%d), "
                                    "%s x %d bp reads resident in HBM -> MEM seeding + staged align kernels (chaining, lane-per-problem ksw2 DP, traceback, "
                                    "lift-over, SAM lines, lines gathered in read order) -> SAM text in pinned host memory, one transfer per sub-batch (%d host threads per GPU stand by for reads handed back)"
-                                   % (3 if scaling == "strong" else 2, args.base_len, " with %g interspersed repeats" % args.repeats if args.repeats else "", args.haps,
+                                   % (3 if sharded else 2, args.base_len, " with %g interspersed repeats" % args.repeats if args.repeats else "", args.haps,
                                       "FASTA-built: null lifts" if args.fasta_index else "ref+VCF -H12 style: haplotypes lift onto the reference contig", fi.n, fi.r,
-                                      ("%d sharded over %d ranks" % (args.total_reads, world)) if scaling == "strong" else ("%d per GPU" % args.reads), L, threads),
-                       "reads_per_gpu": n_mine, "read_len": L, "parallelism": "reads sharded x%d, index replicated" % world},
+                                      ("one set of %d sharded over %d rank(s) by contiguous ranges, %d resident chunk(s) of <= %d per rank" % (total, world, n_chunks, args.reads)) if sharded else ("%d per GPU" % args.reads), L, threads),
+                       "reads_per_gpu": n_mine, "total_reads": n_all, "chunks_per_rank": n_chunks, "read_len": L, "parallelism": "reads sharded x%d, index replicated" % world,
+                       "launched_by": "bench.py" if os.environ.get("MONI_BENCH_SELF_LAUNCHED") else ("torch.distributed.run / external launcher" if world > 1 else "single process")},
             "roofline": {"bound": "hbm", "kernel": "ms_lf_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "traffic_static_from": "profiles/r02y/pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of this workload, profiles/run_r02.sh: "
                                                 "26.66 GB fetched + 2.40 GB written = 29.06 GB per launch of 1 M reads for 47.18 GB algorithmic, i.e. 0.44 of the HBM peak as "
                                                 "counted traffic; counters cannot be read inside this run, so `traffic` stays null)",
-                         "algorithmic_bytes_per_launch": ms_bytes, "avg_launch_ms": kern[0], "per_read_bytes": ms_bytes / max(1, n_mine),
+                         "algorithmic_bytes_per_launch": ms_bytes, "avg_launch_ms": kern_launch[0], "per_read_bytes": ms_bytes / max(1, n_first),
                          "layout_model": {"bytes_per_launch": layout_bytes, "GB/s": layout_bytes / ms_s / 1e9 if ms_s > 0 else None,
                                           "frac": layout_bytes / ms_s / 1e9 / HBM_PEAK_GBS if ms_s > 0 else None,
                                           "note": "bytes the move-structure layout needs (one 64-byte fast row per LF step, threshold jumps included): the survey's model credits two requests per step"},
-                         "note": "the path's HBM-bound kernel (LF / threshold-jump stage of seeding), one launch per step inside the timed region, HIP events on its own stream"},
+                         "note": "the path's HBM-bound kernel (LF / threshold-jump stage of seeding), one launch per resident chunk inside the timed region, HIP events on its own stream"},
             "whole_path": {"bytes_per_read": path_bytes / max(1, n_mine), "formula": "128 S + 64 J + 128 P + C + R (SURVEY.md 8(d)), all counted by the kernels in this run",
                            "S_lf_steps": S, "J_threshold_jumps": J, "P_phi_steps": P, "C_text_bytes": C, "R_dp_target_bytes": R,
                            "GB/s": path_bytes / step_s / 1e9, "frac_of_hbm_peak": path_bytes / step_s / 1e9 / HBM_PEAK_GBS,
-                           "note": "rank 0's batch over rank 0's step time: the step as a whole is bound by dependent-access latency in the chaining and record kernels, not by HBM"},
+                           "note": "rank 0's reads over rank 0's step time: the step as a whole is bound by dependent-access latency in the chaining and record kernels, not by HBM"},
             "align": {"kernels_ms_per_step_summed": {k: v * 1e3 for k, v in grp.items()}, "span_ms_per_step": stage["align_kernels_span"] * 1e3,
                       "note": "HIP-event times of the staged align kernels by group, summed over the sub-batches (two launch streams overlap, so the sum exceeds the span)",
-                      "dp_problems": stf["dp_tasks"], "dp_cells": stf["dp_cells"],
-                      "dp_gcups_in_kernel": stf["dp_cells"] / grp["dp_lane"] / 1e9 if grp["dp_lane"] > 0 else None,
-                      "reads_taken_by_general_kernel": stf["kernel_fallback"], "reads_handed_to_host_pipeline": stf["handed_back"]},
+                      "dp_problems": tot["dp_tasks"], "dp_cells": tot["dp_cells"],
+                      "dp_gcups_in_kernel": tot["dp_cells"] / grp["dp_lane"] / 1e9 if grp["dp_lane"] > 0 else None,
+                      "reads_taken_by_general_kernel": tot["kernel_fallback"], "reads_handed_to_host_pipeline": tot["handed_back"]},
             "stages_s_per_step": stage,
-            "aligned_per_step": stf["aligned"], "sam_bytes_per_step": sam_len,
+            "aligned_per_step": tot["aligned"], "sam_bytes_per_step": sam_len,
             "aligned_all_ranks": sum(x[0] for x in sizes),
-            "kernels_ms": {"ms_lf": kern[0], "mem_count": kern[1], "mem_emit": kern[2], "occ_count": kern[3], "occ_fill": kern[4],
-                           "seeding_whole": kern[6]},
-            "seeding": {"workload": "BASELINE.json configs[1]: MEM seeding stage alone on the same resident batch",
-                        "value": n_all / seed_s, "unit": "reads/s", "ms_per_pass": seed_s * 1e3,
-                        "work_per_pass": {"lf_steps": S, "threshold_jumps": J, "phi_steps": P, "text_bytes": C, "mems": n_mems, "occs": n_occs}},
+            "kernels_ms": {"ms_lf": kern_launch[0], "mem_count": kern_launch[1], "mem_emit": kern_launch[2], "occ_count": kern_launch[3], "occ_fill": kern_launch[4],
+                           "seeding_whole": kern_launch[6], "note": "per launch (one launch per resident chunk)"},
+            "seeding": {"workload": "BASELINE.json configs[1]: MEM seeding stage alone on rank 0's first resident chunk (%d reads)" % n_first,
+                        "value": n_first / seed_s, "unit": "reads/s", "ms_per_pass": seed_s * 1e3,
+                        "work_per_pass": {"lf_steps": int(S1), "threshold_jumps": int(J1), "phi_steps": P // n_chunks, "text_bytes": C // n_chunks, "mems": n_mems, "occs": n_occs}},
         }
         if gather:
             out["gather"] = gather
+            out["value_with_gather"] = n_all / (step_s + gather["seconds"])
+        if from_host:
+            out["from_host"] = from_host
         out["host"] = {"cpus_usable": host_cpus(), "cpu_count": os.cpu_count(), "host_threads_per_gpu": threads}
         if world == 1 and not args.no_cpu:
             from oracle import orc as _orc          # the CPU baseline / at-scale checker: the only use of oracle/ in this file
             oidx = _orc.OracleIndex(fi=fi)
             cpu_threads = host_cpus()
+            nm, no, ql, nb = chunk[0]
+            rd, ob = reads[:nb], offs[:nb + 1]
             # full path on the CPU (oracle/align.hpp), bounded sample; the same sample is an at-scale SAM identity check
-            probe = 2000
+            probe = min(2000, nb)
             t1 = time.perf_counter()
-            _orc.align_batch(oidx, reads[:probe].reshape(-1), offs[:probe + 1], names[:int(noff[probe])], noff[:probe + 1], quals[:probe * L],
-                             threads=cpu_threads)
+            _orc.align_batch(oidx, rd[:probe].reshape(-1), ob[:probe + 1], nm[:int(no[probe])], no[:probe + 1], ql[:probe * L], threads=cpu_threads)
             rate = probe / (time.perf_counter() - t1)
-            n_cpu = int(max(probe, min(n_mine, rate * args.cpu_seconds)))
+            n_cpu = int(max(probe, min(nb, rate * args.cpu_seconds)))
             t1 = time.perf_counter()
-            wsam, wc = _orc.align_batch(oidx, reads[:n_cpu].reshape(-1), offs[:n_cpu + 1], names[:int(noff[n_cpu])], noff[:n_cpu + 1],
-                                        quals[:n_cpu * L], threads=cpu_threads)
+            wsam, wc = _orc.align_batch(oidx, rd[:n_cpu].reshape(-1), ob[:n_cpu + 1], nm[:int(no[n_cpu])], no[:n_cpu + 1], ql[:n_cpu * L], threads=cpu_threads)
             dtc = time.perf_counter() - t1
-            gsam, _ = ctx.align_batch(reads[:n_cpu].reshape(-1), offs[:n_cpu + 1], names[:int(noff[n_cpu])], noff[:n_cpu + 1], quals[:n_cpu * L],
-                                      host_threads=threads)
+            gsam, _ = ctx.align_batch(rd[:n_cpu].reshape(-1), ob[:n_cpu + 1], nm[:int(no[n_cpu])], no[:n_cpu + 1], ql[:n_cpu * L], host_threads=threads)
             out["cpu_baseline"] = {"value": n_cpu / dtc, "unit": "reads/s", "cores": cpu_threads, "kind": "port",
                                    "sample": "first %d reads of the same batch, whole SE path, oracle/align.hpp with %d threads" % (n_cpu, cpu_threads),
                                    "sam_identical_on_sample": bool(gsam == wsam)}
             # BASELINE.json configs[0]: the CPU path on one thread (the plumbing / SAM-diff baseline), small sample
             n1 = min(2000, n_cpu)
             t1 = time.perf_counter()
-            w1, _ = _orc.align_batch(oidx, reads[:n1].reshape(-1), offs[:n1 + 1], names[:int(noff[n1])], noff[:n1 + 1], quals[:n1 * L], threads=1)
+            w1, _ = _orc.align_batch(oidx, rd[:n1].reshape(-1), ob[:n1 + 1], nm[:int(no[n1])], no[:n1 + 1], ql[:n1 * L], threads=1)
             out["cpu_baseline"]["single_thread"] = {"value": n1 / (time.perf_counter() - t1), "unit": "reads/s", "cores": 1,
                                                     "sample": "first %d reads" % n1, "same_text_as_all_threads": bool(w1 == wsam[:len(w1)])}
             # seeding stage alone on the CPU, same bounded way
             t1 = time.perf_counter()
-            oidx.seed_batch(reads[:probe].reshape(-1), offs[:probe + 1], 25, True, 1000, threads=cpu_threads)
+            oidx.seed_batch(rd[:probe].reshape(-1), ob[:probe + 1], 25, True, 1000, threads=cpu_threads)
             rate = probe / (time.perf_counter() - t1)
-            n_cs = int(max(probe, min(n_mine, rate * args.cpu_seconds * 0.5)))
+            n_cs = int(max(probe, min(nb, rate * args.cpu_seconds * 0.5)))
             t1 = time.perf_counter()
-            want = oidx.seed_batch(reads[:n_cs].reshape(-1), offs[:n_cs + 1], 25, True, 1000, threads=cpu_threads)
+            want = oidx.seed_batch(rd[:n_cs].reshape(-1), ob[:n_cs + 1], 25, True, 1000, threads=cpu_threads)
             dt = time.perf_counter() - t1
             k = int(want["read_mem_off"][-1])
             same = (np.array_equal(res["read_mem_off"][:n_cs + 1], want["read_mem_off"]) and
@@ -300,6 +496,14 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))            # the parent: starts the ranks, never initialises HIP
+    sys.exit(dry_run(args) if args.dry_run else run_rank(args))
 
 
 if __name__ == "__main__":

@@ -131,6 +131,10 @@ void moni_ctx_destroy(moni_ctx_t *ctx);
 /* Copy a read batch to HBM (replaces rc_copy_kseq_t + kseq storage; the reverse-complement strand is
  * derived on the device with the table of include/common/kpbseq.h:120-137). */
 int moni_reads_upload(moni_ctx_t *ctx, const moni_read_batch_t *batch);
+/* Exchange the resident batch with the one parked in `slot` (0..255; an unused slot holds an empty batch): a caller that cycles
+ * through several batches (one rank's shard of a read set, align_reads_dispatcher.hpp:300-345 reads them one after the other) uploads
+ * each once, parks it, and swaps it in before moni_align_run.  Pointer exchange only; no copy, no kernel. */
+int moni_reads_swap(moni_ctx_t *ctx, uint32_t slot);
 
 /* ---- matching statistics: ms_t::query (include/ms/moni.hpp:292-295, 568-624) -------------- */
 /* Device-only run over the resident batch, both strands (aligner_ksw2.hpp:333-334). */

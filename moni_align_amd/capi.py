@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("MONI_HIP_LIB") or os.path.join(CSRC, "libmoni_hip.so"
 
 EXPORTS = [
     "moni_version", "moni_index_create", "moni_index_load", "moni_index_destroy", "moni_index_n", "moni_index_r",
-    "moni_index_device_bytes", "moni_ctx_create", "moni_ctx_destroy", "moni_reads_upload", "moni_ms_run",
+    "moni_index_device_bytes", "moni_ctx_create", "moni_ctx_destroy", "moni_reads_upload", "moni_reads_swap", "moni_ms_run",
     "moni_ms_query_batch", "moni_seed_run", "moni_seed_counts", "moni_seed_fetch", "moni_seed_batch", "moni_free",
     "moni_phi_lcp_batch", "moni_extz_batch", "moni_last_kernel_ms", "moni_last_counters",
     "moni_align_params_default", "moni_align_batch", "moni_align_run", "moni_align_stream", "moni_sam_header",
@@ -125,6 +125,7 @@ def lib():
         L.moni_index_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         L.moni_ctx_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.moni_reads_upload.argtypes = [C.c_void_p, C.POINTER(ReadBatchC)]
+        L.moni_reads_swap.argtypes = [C.c_void_p, C.c_uint32]
         L.moni_ms_run.argtypes = [C.c_void_p]
         L.moni_ms_query_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p]
         L.moni_seed_run.argtypes = [C.c_void_p, C.POINTER(SeedParamsC)]
@@ -217,6 +218,7 @@ class Ctx:
         self._h = C.c_void_p()
         _chk(self._L.moni_ctx_create(index._h, C.byref(self._h)), "moni_ctx_create")
         self.n_reads = 0
+        self._parked = {}
 
     def close(self):
         if self._h:
@@ -234,6 +236,11 @@ class Ctx:
         b, keep = self._batch(seq, offsets)
         _chk(self._L.moni_reads_upload(self._h, C.byref(b)), "moni_reads_upload")
         self.n_reads = len(offsets) - 1
+
+    def swap(self, slot: int):
+        """exchange the resident batch with the one parked in `slot` (moni_reads_swap)"""
+        _chk(self._L.moni_reads_swap(self._h, slot), "moni_reads_swap")
+        self.n_reads, self._parked[slot] = self._parked.get(slot, 0), self.n_reads
 
     def ms_run(self):
         _chk(self._L.moni_ms_run(self._h), "moni_ms_run")

@@ -99,6 +99,8 @@ struct moni_ctx {
     uint64_t n_reads = 0, total_len = 0, max_len = 0;
     std::vector<uint8_t> h_seq;              // host copy of the resident batch (SAM SEQ, MD/NM)
     std::vector<uint64_t> h_offs;
+    struct Stash { DBuf<uint8_t> seq; DBuf<uint64_t> offs; uint64_t n_reads = 0, total_len = 0, max_len = 0; std::vector<uint8_t> h_seq; std::vector<uint64_t> h_offs; };
+    std::vector<Stash> stash;                // moni_reads_swap: further batches kept in HBM beside the resident one
     // workspaces
     DBuf<uint64_t> ptr, pat;
     DBuf<uint32_t> cnt_m, cnt_s;
@@ -352,6 +354,7 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->idx->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& x : c->stash) { x.seq.release(); x.offs.release(); }
     c->seq.release(); c->offs.release(); c->ptr.release(); c->pat.release(); c->cnt_m.release(); c->cnt_s.release(); c->mem_slots.release(); c->tot.release();
     c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
     c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
@@ -405,6 +408,18 @@ static int reads_upload(moni_ctx* c, const moni_read_batch_t* b, bool keep_host_
     c->n_reads = nr; c->total_len = total; c->max_len = mx;
     if (keep_host_copy) { c->h_seq.assign(b->seq + b->offsets[0], b->seq + b->offsets[0] + total); c->h_offs = rel; }
     else { c->h_seq.clear(); c->h_offs.clear(); }
+    c->n_mems = c->n_occs = 0;
+    return MONI_OK;
+}
+
+int moni_reads_swap(moni_ctx_t* c, uint32_t slot) {
+    if (!c || slot >= 256) return MONI_EINVAL;
+    HIPCHK(hipSetDevice(c->idx->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    try { if (c->stash.size() <= slot) c->stash.resize(slot + 1); } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
+    moni_ctx::Stash& x = c->stash[slot];
+    std::swap(c->seq, x.seq); std::swap(c->offs, x.offs); std::swap(c->n_reads, x.n_reads); std::swap(c->total_len, x.total_len); std::swap(c->max_len, x.max_len);
+    c->h_seq.swap(x.h_seq); c->h_offs.swap(x.h_offs);
     c->n_mems = c->n_occs = 0;
     return MONI_OK;
 }

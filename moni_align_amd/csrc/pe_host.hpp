@@ -21,9 +21,11 @@ struct PeMateOut {
 struct PePairOut {
     bool finalized = false;                       // the final paired_chain_score ran
     uint32_t strand = 0;
-    int32_t tot = 0, score2 = 0, score2_m[2] = {0, 0}, sub_n = 0, min_score_m[2] = {0, 0};
+    int32_t tot = 0, score2 = 0, score2_m[2] = {0, 0}, sub_n = 0;
     PeMateOut mate[2];
 };
+
+static inline int32_t pe_min_score(uint32_t m) { return m ? (int32_t)(20 + 8 * log((double)m)) : INT32_MIN; }      // al.min_score_m1 / _m2 (aligner_ksw2.hpp:1000-1010)
 
 #define MH_RAW_MAPQ(diff, a) ((int)(6.02 * (diff) / (a) + .499))      // mapq.hpp:144
 
@@ -87,7 +89,9 @@ static inline void pe_emit(const Aligner& A, const moni_align_params_t& P, const
             s[k].mapq = mapq_se_bwa((int32_t)s[k].as, R.score2_m[k], (int32_t)s[k].rlen, (int32_t)M.m, (int32_t)P.min_len, P.smatch, P.smismatch, 50.0,
                                     (int32_t)log(50.0f), R.sub_n);
             if (M.orphan) { s[k].zs = 0; s[k].flag = 4; }  // fill_orphan sets neither
-            ok[k] = !s[k].unmapped_lft;
+            // score.m{1,2}.score >= al.min_score_m{1,2} (aligner_ksw2.hpp:2471,2519): chain_score fills a mate only above its minimum, but
+            // fill_orphan places the recovered mate whatever its global score is - below 20 + 8 ln(len) it is reported unmapped
+            ok[k] = !s[k].unmapped_lft && (!M.orphan || M.as >= pe_min_score(M.m));
         }
         const size_t l1 = R.mate[0].m, l2 = R.mate[1].m;
         if (ok[0] && ok[1]) {
@@ -222,7 +226,7 @@ static inline void pe_emit_fast(const Aligner& A, const moni_align_params_t& P, 
             F.flag = M.orphan ? 4 : (strand ? 16 : 0);
             F.zs = M.orphan ? 0 : (size_t)(int64_t)R.score2_m[k];
             F.mapq = mapq_se_bwa((int32_t)F.as, R.score2_m[k], (int32_t)F.rlen, (int32_t)m, (int32_t)P.min_len, P.smatch, P.smismatch, 50.0, (int32_t)log(50.0f), R.sub_n);
-            ok[k] = !F.unmapped_lft;
+            ok[k] = !F.unmapped_lft && (!M.orphan || M.as >= pe_min_score(M.m));      // as in pe_emit
         }
         const size_t l1 = R.mate[0].m, l2 = R.mate[1].m;
         if (ok[0] && ok[1]) {

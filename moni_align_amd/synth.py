@@ -203,6 +203,27 @@ def make_reads(pg: Pangenome, n_reads: int, read_len: int = 150, seed: int = 150
     return np.ascontiguousarray(out)
 
 
+READ_BLOCK = 250000
+
+
+def make_reads_range(pg: Pangenome, lo: int, hi: int, read_len: int = 150, seed: int = 1500, **kw) -> np.ndarray:
+    """Reads [lo, hi) of an unbounded seeded read set made of blocks of READ_BLOCK reads (block b = make_reads(seed + b)): any
+    contiguous range can be generated on its own, so that a rank makes only its shard of a sharded read set."""
+    parts = []
+    for b in range(lo // READ_BLOCK, (max(hi, lo + 1) - 1) // READ_BLOCK + 1):
+        blk = make_reads(pg, READ_BLOCK, read_len, seed=seed + b, **kw)
+        parts.append(blk[max(lo, b * READ_BLOCK) - b * READ_BLOCK: min(hi, (b + 1) * READ_BLOCK) - b * READ_BLOCK])
+    return np.ascontiguousarray(np.concatenate(parts)) if parts else np.zeros((0, read_len), np.uint8)
+
+
+def make_names_range(lo: int, hi: int, prefix: str = "simulated"):
+    """names of reads [lo, hi) of the set (`simulated.<i>`), ragged bytes + offsets"""
+    names = [("%s.%d" % (prefix, i)).encode() for i in range(lo, hi)]
+    off = np.zeros(hi - lo + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in names])
+    return np.frombuffer(b"".join(names), dtype=np.uint8).copy(), off
+
+
 def write_fastq(path: str, reads: np.ndarray, prefix: str = "simulated") -> None:
     with open(path, "wb") as f:
         q = b"I" * reads.shape[1]

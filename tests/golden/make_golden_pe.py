@@ -30,7 +30,9 @@ def inputs():
             a, b = b, a
         if i % 8 == 3:                           # no 25-base MEM in mate 2 (or mate 1): a case for orphan recovery
             x = (b if (i // 8) % 2 == 0 else a)
-            for q in range(9, 100, 19):
+            # a substitution every 19 bases: the recovered mate scores far above its minimum 20 + 8 ln(100) = 56; every 5: just above (80);
+            # every 4: below (50) - recovery finds the place but the mate stays unmapped (aligner_ksw2.hpp:2471,2519)
+            for q in range(9 if (i // 8) % 3 == 0 else 2, 100, (19, 4, 5)[(i // 8) % 3]):
                 x[q] = ord("A") if x[q] != ord("A") else ord("C")
         if i % 16 == 5:
             b = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=100)].copy()

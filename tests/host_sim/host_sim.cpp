@@ -368,7 +368,7 @@ char* sim_align_pe_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint
         R.finalized = !W->W.overflow && W->W.aligned;
         R.strand = W->strand; R.tot = W->final.tot; R.score2 = W->score2; R.sub_n = W->sub_n;
         for (int k = 0; k < 2; ++k) {
-            R.score2_m[k] = W->score2_m[k]; R.min_score_m[k] = W->min_score_m[k];
+            R.score2_m[k] = W->score2_m[k];
             mh::PeMateOut& M = R.mate[k];
             M.m = W->m[k]; M.off = W->off[k]; M.score = k ? W->final.m2.score : W->final.m1.score; M.filled = R.finalized && W->filled[k];
             M.ref_pos = W->ref_pos[k]; M.as = W->as[k]; M.cig = W->cigar[k]; M.n_cig = W->n_cigar[k];

@@ -284,7 +284,11 @@ def run_rank(args) -> int:
     cnt = np.zeros(4, dtype=np.uint64)
     n_calls = [0]
 
+    why = {}
+
     def acc(st):
+        for k2, v in st["handover_why"].items():
+            why[k2] = why.get(k2, 0) + v
         kern[:] += [ctx.kernel_ms(w) if w != 5 else 0.0 for w in range(7)]
         stage["seed"] += st["t_seed"]; stage["align_kernels_span"] += st["t_dp_kernel"]; stage["align_stage"] += st["t_dp"]
         stage["host_stage_busy"] += st["t_host"]
@@ -364,19 +368,19 @@ def run_rank(args) -> int:
         nm, no, ql, nb = chunk[0]
         rd = reads[:nb].reshape(-1)
         ob = offs[:nb + 1]
-        ctx.align_batch(rd, ob, nm, no, ql, host_threads=threads, stream=True)
+        ctx.align_batch(rd, ob, nm, no, ql, host_threads=threads, stream=True, want_text=False)
         reps = max(3, min(10, args.steps))
         t1 = time.perf_counter()
         for _ in range(reps):
-            ctx.align_batch(rd, ob, nm, no, ql, host_threads=threads, stream=True)
+            ctx.align_batch(rd, ob, nm, no, ql, host_threads=threads, stream=True, want_text=False)
         one_s = (time.perf_counter() - t1) / reps
         # a streaming caller keeps two contexts per GPU going (moni-hip-align runs three): one uploads / seeds while the other aligns
         ctx_b = capi.Ctx(idx)
-        ctx_b.align_batch(rd, ob, nm, no, ql, host_threads=threads, stream=True)
+        ctx_b.align_batch(rd, ob, nm, no, ql, host_threads=threads, stream=True, want_text=False)
 
         def worker(cx, n):
             for _ in range(n):
-                cx.align_batch(rd, ob, nm, no, ql, host_threads=max(1, threads // 2), stream=True)
+                cx.align_batch(rd, ob, nm, no, ql, host_threads=max(1, threads // 2), stream=True, want_text=False)
         th = [threading.Thread(target=worker, args=(cx, reps)) for cx in (ctx, ctx_b)]
         t1 = time.perf_counter()
         for t in th:
@@ -433,7 +437,8 @@ def run_rank(args) -> int:
                       "note": "HIP-event times of the staged align kernels by group, summed over the sub-batches (two launch streams overlap, so the sum exceeds the span)",
                       "dp_problems": tot["dp_tasks"], "dp_cells": tot["dp_cells"],
                       "dp_gcups_in_kernel": tot["dp_cells"] / grp["dp_lane"] / 1e9 if grp["dp_lane"] > 0 else None,
-                      "reads_taken_by_general_kernel": tot["kernel_fallback"], "reads_handed_to_host_pipeline": tot["handed_back"]},
+                      "reads_taken_by_general_kernel": tot["kernel_fallback"], "reads_handed_to_host_pipeline": tot["handed_back"],
+                      "handed_over_because": {k: v // steps for k, v in why.items()}},
             "stages_s_per_step": stage,
             "aligned_per_step": tot["aligned"], "sam_bytes_per_step": sam_len,
             "aligned_all_ranks": sum(x[0] for x in sizes),

@@ -191,6 +191,11 @@ typedef struct {
     uint64_t dp_ref_bytes;                                /* text bytes of the DP targets (the R of SURVEY.md 8(d)) */
     double t_k_chain, t_k_dp, t_k_select, t_k_finish;     /* HIP-event seconds of the staged kernels by group, summed over the sub-batches (launches of two
                                                              streams overlap: the sum exceeds the span t_dp_kernel) */
+    uint64_t handover_why[12];                            /* why reads left the staged kernels (their sum can exceed kernel_fallback + handed_back: a read is counted once per
+                                                             reason met): 0 read of 512 bases or more, 1 seeds / anchors beyond the largest LDS instance, 2 chains, 3 chains to
+                                                             score, 4 anchors of the chains to score, 5 a DP problem beyond the register tile, 6 (unused), 7 wildcard base or
+                                                             direction-bit budget, 8 selection loop depends on a score, 9 extension short of the query end, 10 a queue or pool
+                                                             full, 11 CIGAR / MD / line beyond the staging (host pipeline) */
 } moni_align_stats_t;
 
 void moni_align_params_default(moni_align_params_t *p);

@@ -62,7 +62,8 @@ class AlignStatsC(C.Structure):
                 ("t_seed", C.c_double), ("t_chain", C.c_double), ("t_dp", C.c_double), ("t_host", C.c_double),
                 ("t_dp_kernel", C.c_double), ("handed_back", C.c_uint64), ("dp_reused", C.c_uint64), ("dp_cells_reused", C.c_uint64),
                 ("kernel_fallback", C.c_uint64), ("dp_ref_bytes", C.c_uint64),
-                ("t_k_chain", C.c_double), ("t_k_dp", C.c_double), ("t_k_select", C.c_double), ("t_k_finish", C.c_double)]
+                ("t_k_chain", C.c_double), ("t_k_dp", C.c_double), ("t_k_select", C.c_double), ("t_k_finish", C.c_double),
+                ("handover_why", C.c_uint64 * 12)]
 
 
 class PeParamsC(C.Structure):
@@ -162,6 +163,16 @@ def lib():
         L.moni_ldx_lift_batch.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _lib = L
     return _lib
+
+
+HANDOVER_WHY = ("long_read", "anchors", "chains", "chains_to_score", "chain_anchors", "dp_size", "unused", "wildcard_or_dirs", "loop_depends_on_score",
+                "extension_short_of_end", "capacity", "cigar_md_line")
+
+
+def _stats_dict(st) -> dict:
+    d = {k: getattr(st, k) for k, _ in AlignStatsC._fields_ if k != "handover_why"}
+    d["handover_why"] = {HANDOVER_WHY[i]: int(st.handover_why[i]) for i in range(12) if st.handover_why[i]}
+    return d
 
 
 def _chk(rc: int, what: str):
@@ -295,9 +306,10 @@ class Ctx:
         return res, pool[: used.value]
 
     def align_batch(self, seq: np.ndarray, offsets: np.ndarray, names: np.ndarray, name_off: np.ndarray, quals=None,
-                    host_threads: Optional[int] = None, stream: bool = False, **overrides):
+                    host_threads: Optional[int] = None, stream: bool = False, want_text: bool = True, **overrides):
         """SAM text (bytes) of the batch + stats dict; the whole single-end path on the GPU + host stages.
-        stream=True: moni_align_stream (text in the context-owned pinned buffer, lines ordered on the GPU)."""
+        stream=True: moni_align_stream (text in the context-owned pinned buffer, lines ordered on the GPU); want_text=False
+        (with stream) returns the text's length instead of copying it into a Python bytes object."""
         b, keep = self._batch(seq, offsets)
         names = np.ascontiguousarray(names, dtype=np.uint8)
         name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
@@ -318,11 +330,11 @@ class Ctx:
                 C.byref(st)), "moni_align_stream" if stream else "moni_align_batch")
         self.n_reads = len(offsets) - 1
         try:
-            sam = C.string_at(out, ln.value)
+            sam = C.string_at(out, ln.value) if (want_text or not stream) else int(ln.value)
         finally:
             if not stream:
                 self._L.moni_free(out)
-        return sam, {k: getattr(st, k) for k, _ in AlignStatsC._fields_}
+        return sam, _stats_dict(st)
 
     def _pe_params(self, host_threads, overrides):
         prm = AlignParamsC()
@@ -361,7 +373,7 @@ class Ctx:
             sam = C.string_at(out, ln.value)
         finally:
             self._L.moni_free(out)
-        return sam, {k: getattr(st, k) for k, _ in AlignStatsC._fields_}
+        return sam, _stats_dict(st)
 
     def align_run(self, names: np.ndarray, name_off: np.ndarray, quals=None, host_threads: Optional[int] = None,
                   want_text: bool = True, **overrides):
@@ -383,7 +395,7 @@ class Ctx:
         _chk(self._L.moni_align_run(self._h, names.ctypes.data, name_off.ctypes.data, quals.ctypes.data if quals is not None else None,
                                     C.byref(prm), C.byref(out), C.byref(ln), C.byref(st)), "moni_align_run")
         sam = C.string_at(out, ln.value) if want_text else int(ln.value)      # the buffer belongs to the context
-        return sam, {k: getattr(st, k) for k, _ in AlignStatsC._fields_}
+        return sam, _stats_dict(st)
 
     def ms_lengths_batch(self, seq: np.ndarray, offsets: np.ndarray):
         """legacy `moni ms`: (pointers, lengths) of the forward strand of every read"""

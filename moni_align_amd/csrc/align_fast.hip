@@ -100,7 +100,8 @@ struct af_args_t {
     af_chunk_t* chunks; uint32_t chunk_cap;  // 64-task chunks of the two tiles: large first
     uint8_t* dirs; uint64_t dirs_cap;
     uint32_t* tb_task; af_tb_t* tb; uint32_t tb_cap;      // problems to trace
-    uint32_t* fb_list;                       // reads handed to align_kernel
+    uint32_t* fb_list; uint32_t* fb_n;       // reads handed to align_kernel and their number: per sub-batch, not per buffer set (align_kernel reads them on its own stream
+                                             // while the set's next sub-batch is already running)
     uint32_t* big_list;                      // reads (indices in the launch) that need the large instance of chain_plan_kernel
     unsigned long long* txt_cur;             // AF_TXT_SHARDS cursors (one per 64 bytes) of the text pool's shard regions: a device-scope atomic on ONE address
     uint64_t txt_shard_words;                // sustains only ~50 M/s; region s + 1 of the pool (txt_shard_words each) belongs to shard s, region 0 to cursors[15]
@@ -694,7 +695,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
             if (status != AF_ST_CAND) { PL.n_cand = 0; PL.n_chains = 0; }
             PL.status = (uint8_t)status; PL.final_cand = 0; PL.n_alt = 0; PL.pad = 0; PL.score2 = 0; PL.ref_pos = PL.ref_len = 0; PL.tb0 = 0; PL.pad2 = 0;
             PL.min_score = A.min_score_of_len[m <= A.max_len ? m : A.max_len];
-            if (status == AF_ST_FALLBACK) G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)r;
+            if (status == AF_ST_FALLBACK) G.fb_list[atomicAdd(G.fb_n, 1u)] = (uint32_t)r;
         }
         __syncthreads();
         {   // plan: only the part in use
@@ -738,7 +739,7 @@ __global__ void __launch_bounds__(256) bin_tasks_kernel(const af_args_t G) {
     if (tid < 8 && ovf[tid]) {
         const uint64_t rr = (uint64_t)blockIdx.x * 8 + tid;
         G.plans[rr].status = AF_ST_FALLBACK;
-        G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)(G.A.read_lo + rr);
+        G.fb_list[atomicAdd(G.fb_n, 1u)] = (uint32_t)(G.A.read_lo + rr);
         atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CAPACITY], 1u);
     }
 }
@@ -1112,7 +1113,7 @@ __global__ void __launch_bounds__(256) global_task_kernel(const af_args_t G) {
             Cp->gtask = tid;
         }
     }
-    if (active && why != AF_WHY_N) { PLp->status = AF_ST_FALLBACK; G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)r; atomicAdd(&G.ctr[AFC_WHY + why], 1u); }
+    if (active && why != AF_WHY_N) { PLp->status = AF_ST_FALLBACK; G.fb_list[atomicAdd(G.fb_n, 1u)] = (uint32_t)r; atomicAdd(&G.ctr[AFC_WHY + why], 1u); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -1223,7 +1224,7 @@ __global__ void __launch_bounds__(256) select_kernel(const af_args_t G) {
             else { PL.tb0 = tb0; if (C.overlap) G.tb_task[tb0] = C.gtask; else for (uint32_t k = 0; k < n_tb; ++k) G.tb_task[tb0 + k] = t + k; }
         }
     }
-    if (fallback) { PL.status = AF_ST_FALLBACK; G.fb_list[atomicAdd(&G.ctr[AFC_FALLBACK], 1u)] = (uint32_t)r; atomicAdd(&G.ctr[AFC_WHY + why], 1u); return; }
+    if (fallback) { PL.status = AF_ST_FALLBACK; G.fb_list[atomicAdd(G.fb_n, 1u)] = (uint32_t)r; atomicAdd(&G.ctr[AFC_WHY + why], 1u); return; }
     PL.status = (uint8_t)status; PL.final_cand = (uint8_t)final_c; PL.score2 = score2; PL.n_alt = (uint8_t)n_alt;
 }
 

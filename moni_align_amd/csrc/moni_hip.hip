@@ -133,12 +133,13 @@ struct moni_ctx {
     DBuf<dp_big_t> dp_big;
     DBuf<uint8_t> dp_dir_big;
     struct AfSet {          // device buffers of the staged align kernels (align_fast.hip), one set per launch stream
-        DBuf<af_plan_t> plans; DBuf<moni_dp_task_t> tasks; DBuf<af_res_t> res; DBuf<uint32_t> bin_q, task_pos, tb_task, fb_list, big_list, ctr; DBuf<uint8_t> ntasks;
+        DBuf<af_plan_t> plans; DBuf<moni_dp_task_t> tasks; DBuf<af_res_t> res; DBuf<uint32_t> bin_q, task_pos, tb_task, big_list, ctr; DBuf<uint8_t> ntasks;
         DBuf<af_chunk_t> chunks; DBuf<uint8_t> dirs, fin; DBuf<af_tb_t> tb; DBuf<uint64_t> bnd; DBuf<unsigned long long> prof, txt_cur;
-        void release() { ntasks.release(); bnd.release(); prof.release(); big_list.release(); txt_cur.release(); plans.release(); tasks.release(); res.release(); bin_q.release(); task_pos.release(); tb_task.release(); fb_list.release(); ctr.release();
+        void release() { ntasks.release(); bnd.release(); prof.release(); big_list.release(); txt_cur.release(); plans.release(); tasks.release(); res.release(); bin_q.release(); task_pos.release(); tb_task.release(); ctr.release();
                          chunks.release(); dirs.release(); fin.release(); tb.release(); }
     } af[AK_NSET];
     HBuf<uint32_t> af_ctr_host;             // counters of the last batch's launches (64 words per sub-batch), pinned
+    DBuf<uint32_t> fb_all;                  // per sub-batch: the number of reads handed to align_kernel (16 words apart), then their lists
     DBuf<ak_slot_t> ak_slots;
     DBuf<ak_wave_t> ak_waves;
     DBuf<unsigned long long> ak_cursors;
@@ -359,7 +360,7 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
     c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
     for (int x = 0; x < AK_NSET; ++x) c->af[x].release();
-    c->af_ctr_host.release();
+    c->af_ctr_host.release(); c->fb_all.release();
     c->dp_q.release(); c->dp_t.release(); c->dp_dir.release(); c->dp_tasks.release(); c->dp_res.release(); c->dp_cig.release();
     c->dp_off.release(); c->dp_ws.release(); c->dp_big.release(); c->dp_dir_big.release(); c->ak_slots.release(); c->ak_waves.release(); c->ak_cursors.release(); c->ak_rnames.release(); c->ak_quals.release(); c->ak_rname_off.release(); c->ak_txt.release(); c->ak_mapq_tab.release(); c->h_txt.release(); c->h_recs.release(); c->h_cig.release(); c->h_alt.release(); c->h_md.release();
     for (auto& ob : c->pieces) ob.release();
@@ -917,6 +918,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
     c->dp_kernel_ms_accum = 0;
     std::string out;
     mh::AlignStats st;
+    uint64_t why_out[12] = {};
     const uint8_t* q = quals ? quals + b->offsets[0] : nullptr;
     static const bool host_only = getenv("MONI_ALIGN_HOST") != nullptr;
     bool out_done = false;
@@ -979,6 +981,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             return true;
         };
         double prof[7] = {0, 0, 0, 0, 0, 0, 0};
+        uint64_t why_sum[AF_WHY_N] = {};
         double hist[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cyc[7] = {0, 0, 0, 0, 0, 0, 0};
         uint64_t waves_used = 0;
 
@@ -1087,7 +1090,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         if (use_fast) for (int x = 0; x < (int)std::min<uint64_t>(n_sub, AK_NSET); ++x) {
             moni_ctx::AfSet& S = c->af[x];
             if ((rc = S.plans.ensure(sub_reads + 1)) || (rc = S.tasks.ensure(af_slot_cap)) || (rc = S.res.ensure(af_slot_cap)) || (rc = S.ntasks.ensure(sub_reads + 8)) || (rc = S.bin_q.ensure((size_t)AF_NBIN * af_task_cap)) ||
-                (rc = S.task_pos.ensure(af_slot_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.fb_list.ensure(sub_reads + 1)) || (rc = S.big_list.ensure(sub_reads + 1)) ||
+                (rc = S.task_pos.ensure(af_slot_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.big_list.ensure(sub_reads + 1)) ||
                 (rc = S.ctr.ensure(AF_NCTR)) || (rc = S.txt_cur.ensure(AF_TXT_SHARDS * 8)) || (rc = S.bnd.ensure((size_t)af_dp_grid * AF_QCAP * 64)) || (rc = S.chunks.ensure(af_chunk_cap)) || (rc = S.dirs.ensure(af_dirs_cap)) || (rc = S.fin.ensure((size_t)af_fin_grid * 64 * sizeof(af_fin_t))))
                 return rc;
         }
@@ -1100,6 +1103,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                                             c->ak_begin.push_back(e0); c->ak_done.push_back(e1); c->ak_fin.push_back(e2); }
         for (int x = 0; x < AK_NSET; ++x) if (use_fast && !c->fb_stream[x]) HIPCHK(hipStreamCreateWithFlags(&c->fb_stream[x], hipStreamNonBlocking));
         while (c->af_ev.size() < 3 * n_sub) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->af_ev.push_back(e); }
+        if (use_fast) { if ((rc = c->fb_all.ensure(16 * n_sub + n_sub * (sub_reads + 1) + 16))) return rc; HIPCHK(hipMemsetAsync(c->fb_all.p, 0, 16 * n_sub * sizeof(uint32_t), c->stream)); }
         HIPCHK(hipMemsetAsync(c->ak_cursors.p, 0, (AK_CUR * n_sub + AK_CUR) * sizeof(unsigned long long), c->stream));
         HIPCHK(hipMemcpyAsync(c->ak_minscore.p, msc.data(), msc.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -1271,7 +1275,9 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             }
             if (inorder) { A.dev_len = c->ak_dev_len.p + r0 + k; A.dev_off = c->ak_dev_off.p + r0 + k; A.dev_sum = c->ak_dev_sum.p + 160 * k; }
             hipStream_t sx = c->ak_stream[k % AK_NSET];
-            if (use_fast && k >= AK_NSET) HIPCHK(hipStreamWaitEvent(sx, c->ak_done[k - AK_NSET], 0));      // the set's buffers are free once its previous sub-batch is through align_kernel too
+            // (the set's buffers are free once its previous sub-batch is through finish_wave_kernel - stream order; align_kernel and the gather of that
+            // sub-batch read only per-sub-batch buffers and may still be running on the hand-over stream: a slow hand-over read delays its own
+            // sub-batch's block, not the launches behind it)
             HIPCHK(hipEventRecord(c->ak_begin[k], sx));
             bool done_recorded = false;
             if (use_fast && nr > 0) {
@@ -1281,7 +1287,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 G.A = A;
                 G.plans = S.plans.p; G.tasks = S.tasks.p; G.task_cap = af_slot_cap; G.ntasks = S.ntasks.p; G.res = S.res.p; G.bin_q = S.bin_q.p; G.bin_cap = af_task_cap; G.task_pos = S.task_pos.p;
                 G.chunks = S.chunks.p; G.chunk_cap = af_chunk_cap; G.dirs = S.dirs.p; G.dirs_cap = af_dirs_cap; G.tb_task = S.tb_task.p; G.tb = S.tb.p; G.tb_cap = af_tb_cap;
-                G.fb_list = S.fb_list.p; G.big_list = S.big_list.p; G.fin_scratch = S.fin.p; G.fin_stride = sizeof(af_fin_t); G.ctr = S.ctr.p;
+                G.fb_n = c->fb_all.p + 16 * k; G.fb_list = c->fb_all.p + 16 * n_sub + k * (sub_reads + 1); G.big_list = S.big_list.p; G.fin_scratch = S.fin.p; G.fin_stride = sizeof(af_fin_t); G.ctr = S.ctr.p;
                 G.bnd = S.bnd.p;
                 G.txt_cur = S.txt_cur.p; G.txt_shard_words = txt_per / (AF_TXT_SHARDS + 1);
                 HIPCHK(hipMemsetAsync(S.txt_cur.p, 0, AF_TXT_SHARDS * 8 * sizeof(unsigned long long), sx));
@@ -1319,7 +1325,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 HIPCHK(hipEventRecord(c->af_ev[3 * k + 2], sx));
                 // the reads the staged kernels handed over: few, but each a long serial job (milliseconds): align_kernel takes them on its own stream
                 // beside finish_wave_kernel, which hands nothing over any more (a line or CIGAR beyond its staging goes to the host pipeline)
-                A.read_list = S.fb_list.p; A.n_reads_dev = S.ctr.p + AFC_FALLBACK;
+                A.read_list = G.fb_list; A.n_reads_dev = G.fb_n;
                 hipStream_t sf = c->fb_stream[k % AK_NSET];
                 HIPCHK(hipStreamWaitEvent(sf, c->af_ev[3 * k + 2], 0));
                 hipLaunchKernelGGL(align_kernel, dim3((unsigned)ak_waves), dim3(64), 0, sf, A);
@@ -1327,9 +1333,9 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 static const int fin_mult = getenv("MONI_AF_FINGRID") ? atoi(getenv("MONI_AF_FINGRID")) : 96;          // blocks per CU: 4x what is resident (24 by LDS), so that the strided share of a block is short and the tail even (measured 24 .. 768)
                 if (gpu_text) hipLaunchKernelGGL(finish_wave_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * fin_mult)), dim3(64), 0, sx, G);
                 else hipLaunchKernelGGL(finish_kernel, dim3((unsigned)std::min<uint64_t>((nr + 63) / 64, af_fin_grid)), dim3(64), 0, sx, G);
+                HIPCHK(hipMemcpyAsync(c->af_ctr_host.p + AF_NCTR * k, S.ctr.p, AF_NCTR * sizeof(uint32_t), hipMemcpyDeviceToHost, sx));      // (before the set's next sub-batch clears them)
                 HIPCHK(hipEventRecord(c->ak_fin[k], sx));
                 HIPCHK(hipStreamWaitEvent(sf, c->ak_fin[k], 0));
-                HIPCHK(hipMemcpyAsync(c->af_ctr_host.p + AF_NCTR * k, S.ctr.p, AF_NCTR * sizeof(uint32_t), hipMemcpyDeviceToHost, sf));
                 if (inorder) {          // lines in read order: scan of the lengths, gather, summary for the host
                     uint64_t* pos = c->ak_dev_pos.p + r0 + 2 * k;
                     size_t tmp_bytes = 0;
@@ -1361,6 +1367,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         if (n_sub) {        // statistics of all launches, once the GPU is idle
             std::vector<unsigned long long> cur(AK_CUR * n_sub);
             HIPCHK(hipMemcpy(cur.data(), c->ak_cursors.p, cur.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            std::vector<uint32_t> fbn(16 * n_sub, 0);
+            if (use_fast) HIPCHK(hipMemcpy(fbn.data(), c->fb_all.p, fbn.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
             for (uint64_t k = 0; k < n_sub; ++k) {
                 const unsigned long long* q = cur.data() + AK_CUR * k;
                 st.dp_tasks += q[2]; st.dp_cells += q[3]; st.dp_reused += q[8]; st.dp_cells_reused += q[9];
@@ -1375,9 +1383,10 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                     const uint32_t* fc = c->af_ctr_host.p + AF_NCTR * k;
                     unsigned long long cells, rb; memcpy(&cells, fc + AFC_CELLS, 8); memcpy(&rb, fc + AFC_RBYTES, 8);
                     any_dirs_ovf_batch = any_dirs_ovf_batch || fc[AFC_DIRS_OVF] != 0;
-                    st.dp_tasks += fc[AFC_NT] + (fc[AFC_TASKS] >= (uint32_t)(sub_lo[k + 1] - sub_lo[k]) * AF_MAX_TASKS_READ ? fc[AFC_TASKS] - (uint32_t)(sub_lo[k + 1] - sub_lo[k]) * AF_MAX_TASKS_READ : 0u); st.dp_cells += cells; st.kernel_fallback += fc[AFC_FALLBACK]; st.dp_ref_bytes += rb;
+                    st.dp_tasks += fc[AFC_NT] + (fc[AFC_TASKS] >= (uint32_t)(sub_lo[k + 1] - sub_lo[k]) * AF_MAX_TASKS_READ ? fc[AFC_TASKS] - (uint32_t)(sub_lo[k + 1] - sub_lo[k]) * AF_MAX_TASKS_READ : 0u); st.dp_cells += cells; st.kernel_fallback += fbn[16 * k]; st.dp_ref_bytes += rb;
+                    for (int x = 0; x < AF_WHY_N; ++x) why_sum[x] += fc[AFC_WHY + x];
                     if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "  staged kernels, sub-batch %llu: %u DP tasks, %llu cells, %u traced, %u large + %u small + %u global chunks, %u reads to align_kernel%s\n",
-                                                           (unsigned long long)k, fc[AFC_NT], cells, fc[AFC_TRACED], fc[AFC_NCHUNKS], fc[AFC_NCHUNKS + 1], fc[AFC_NCHUNKS + 2], fc[AFC_FALLBACK], fc[AFC_DIRS_OVF] ? " (direction bytes overflowed)" : "");
+                                                           (unsigned long long)k, fc[AFC_NT], cells, fc[AFC_TRACED], fc[AFC_NCHUNKS], fc[AFC_NCHUNKS + 1], fc[AFC_NCHUNKS + 2], fbn[16 * k], fc[AFC_DIRS_OVF] ? " (direction bytes overflowed)" : "");
                     if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "    handed over because: long read %u, anchors/seeds %u, chains %u, chains to score %u, chain length %u, DP size %u, overlapping anchors %u, wildcard %u, "
                                                            "loop depends on a score %u, extension short of the query end %u, capacity %u, CIGAR %u\n",
                                                            fc[AFC_WHY + 0], fc[AFC_WHY + 1], fc[AFC_WHY + 2], fc[AFC_WHY + 3], fc[AFC_WHY + 4], fc[AFC_WHY + 5], fc[AFC_WHY + 6], fc[AFC_WHY + 7], fc[AFC_WHY + 8], fc[AFC_WHY + 9], fc[AFC_WHY + 10], fc[AFC_WHY + 11]);
@@ -1388,6 +1397,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             }
         }
         if (any_dirs_ovf_batch && c->dirs_scale < 16) c->dirs_scale *= 2;
+        static_assert(AF_WHY_N == 12, "moni_align_stats_t::handover_why");
+        for (int x = 0; x < AF_WHY_N; ++x) why_out[x] = why_sum[x];
 #ifdef AF_PROFILE
         if (use_fast && n_sub) { unsigned long long pf[32]; for (int x = 0; x < (int)std::min<uint64_t>(n_sub, AK_NSET); ++x) { HIPCHK(hipMemcpy(pf, c->af[x].prof.p, sizeof pf, hipMemcpyDeviceToHost));
             fprintf(stderr, "chain_plan_kernel wave cycles (set %d): load+filter+anchors %.3g, chain %.3g (sort %.3g, dp %.3g, ends+backtrack %.3g), lifts %.3g, plan %.3g, whole read %.3g\n", x,
@@ -1478,6 +1489,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         stats->handed_back = st.handed_back; stats->dp_reused = st.dp_reused; stats->dp_cells_reused = st.dp_cells_reused;
         stats->kernel_fallback = st.kernel_fallback; stats->dp_ref_bytes = st.dp_ref_bytes;
         stats->t_k_chain = st.t_k_chain; stats->t_k_dp = st.t_k_dp; stats->t_k_select = st.t_k_select; stats->t_k_finish = st.t_k_finish;
+        for (int x = 0; x < 12; ++x) stats->handover_why[x] = why_out[x];
     }
     return MONI_OK;
 }

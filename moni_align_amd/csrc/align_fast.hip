@@ -31,8 +31,11 @@
 #define AF_MAX_MEMS 64
 #define AF_MAX_ANCH 256
 #define AF_MAX_CHAINS 128
-#define AF_MAX_CAND 8
-#define AF_MAX_AN 6
+#define AF_MAX_CAND 16            // chains the selection loop scores for one read (the small LDS instance holds 8)
+#define AF_PLAN_AN 96             // anchors of all those chains together (a chain's anchors are a slice of the plan's anchor pool: one long chain
+                                  // or many short ones; the round-2 form gave every chain 6 slots, and 250 bp reads left the staged path for a 7th anchor)
+#define AF_FIN_AN 16              // anchors / traced problems of the final chain that finish_wave_kernel stages in LDS (beyond: read from HBM)
+#define AF_FIN_TB 12
 #define AF_MAX_READ 512          // longest read of the staged path
 #define AF_QCAP 256              // longest query of a DP task
 #define AF_TB 104                // longest target of an extension / gap problem
@@ -63,26 +66,42 @@ __device__ __forceinline__ int32_t af_ins_score(const ac_params_t& P, uint64_t l
     const uint64_t c1 = (uint64_t)(int64_t)P.gapo + l * (uint64_t)(int64_t)P.gape, c2 = (uint64_t)(int64_t)P.gapo2 + l * (uint64_t)(int64_t)P.gape2;
     return (int32_t)(0 - (c1 < c2 ? c1 : c2));
 }
-struct af_cand_t {               // one chain the selection loop scores (in loop order)
+struct af_cand_t {               // one chain the selection loop scores (in loop order), 32 bytes
     int32_t chain_score;
     uint16_t chain_idx;
     uint8_t n_an, strand;
     uint32_t task0;              // its DP tasks: [left ext][right ext][gap fills in anchor order]
     uint8_t has_lc, has_rc, n_gap_tasks, overlap;      // overlap: anchors overlap, the chain is scored by one global problem (gtask) over the window the extensions give
     int32_t score;               // filled by select_kernel
-    uint32_t gtask; uint32_t pad;
-    af_anchor_t an[AF_MAX_AN];
+    uint32_t gtask;
+    uint16_t an0, pad;           // its anchors, left to right: an[an0 .. an0 + n_an) of the plan
+    uint32_t pad2;
 };
+static_assert(sizeof(af_cand_t) == 32, "af_cand_t");
+// the plan's 40-byte header: status, final chain, strand, traced problems, window - all finish_wave_kernel needs to start its fetches
+#define AF_PLAN_HEADER \
+    uint8_t status, n_cand; uint16_t n_chains; \
+    int32_t min_score; \
+    uint8_t final_cand, n_alt; uint16_t pad;      /* pad: strand of the final chain | its traced problems << 8 (select_kernel) */ \
+    int32_t score2; \
+    uint64_t ref_pos, ref_len;   /* window of the final chain */ \
+    uint32_t tb0, pad2;          /* first traced problem of the final chain: [left ext][right ext][gap fills]; pad2: an0 | n_an << 16 of the final chain */
 struct af_plan_t {
-    uint8_t status, n_cand; uint16_t n_chains;
-    int32_t min_score;
-    uint8_t final_cand, n_alt; uint16_t pad;      // pad: strand of the final chain | its traced problems << 8 (select_kernel)
-    int32_t score2;
-    uint64_t ref_pos, ref_len;   // window of the final chain
-    uint32_t tb0, pad2;          // first traced problem of the final chain: [left ext][right ext][gap fills]
-    uint64_t alt_pos[AF_MAX_CAND];
-    int32_t alt_score[AF_MAX_CAND];
+    AF_PLAN_HEADER
     af_cand_t cand[AF_MAX_CAND];
+    af_anchor_t an[AF_PLAN_AN];
+    uint64_t alt_pos[AF_MAX_CAND];      // (select_kernel)
+    int32_t alt_score[AF_MAX_CAND];
+};
+static_assert(offsetof(af_plan_t, cand) == 40, "af_plan_t header");
+// the plan while chain_plan_kernel builds it in LDS: NC chains to score, NA anchors, NT DP problems
+template <int NC, int NA, int NT>
+struct af_plan_lds_t {
+    AF_PLAN_HEADER
+    af_cand_t cand[NC];
+    af_anchor_t an[NA];
+    moni_dp_task_t tasks[NT];
+    uint32_t n_an;               // anchors in use
 };
 struct af_res_t { int32_t mqe, mqe_t, score, flags; };      // flags: 1 = a wildcard base in an operand (not computed)
 struct af_chunk_t { uint32_t bin, start, n, qhi; uint64_t dir_off; };
@@ -102,7 +121,7 @@ struct af_args_t {
     uint32_t* tb_task; af_tb_t* tb; uint32_t tb_cap;      // problems to trace
     uint32_t* fb_list; uint32_t* fb_n;       // reads handed to align_kernel and their number: per sub-batch, not per buffer set (align_kernel reads them on its own stream
                                              // while the set's next sub-batch is already running)
-    uint32_t* big_list;                      // reads (indices in the launch) that need the large instance of chain_plan_kernel
+    uint32_t* big_list; uint32_t* huge_list; // reads (indices in the launch) that need the large / the largest instance of chain_plan_kernel
     unsigned long long* txt_cur;             // AF_TXT_SHARDS cursors (one per 64 bytes) of the text pool's shard regions: a device-scope atomic on ONE address
     uint64_t txt_shard_words;                // sustains only ~50 M/s; region s + 1 of the pool (txt_shard_words each) belongs to shard s, region 0 to cursors[15]
     uint8_t* fin_scratch; uint64_t fin_stride;            // per finish lane: stitched CIGAR, lifted CIGAR, MD and text staging
@@ -120,7 +139,7 @@ struct af_args_t {
 #endif
 enum { AFC_TASKS = 0, AFC_FALLBACK = 1, AFC_TRACED = 2, AFC_READ_CUR = 3, AFC_DIRS_OVF = 4, AFC_CELLS = 6 /* 64 bit */, AFC_DIROFF = 8 /* 64 bit */,
        AFC_NCHUNKS = 10 /* + group */, AFC_CURSOR = 13 /* + group */, AFC_BINS = 16 /* + bin */, AFC_BIG = 49, AFC_BIG_CUR = 50, AFC_WHY = 52 /* + reason */, AFC_RBYTES = 64 /* 64 bit: text bytes of the DP targets, the R of SURVEY.md 8(d) */,
-       AFC_QBYTES = 66 /* 64 bit: read bytes of the DP queries */, AFC_NT = 68 /* DP problems queued by bin_tasks_kernel */, AF_NCTR = 96 };
+       AFC_QBYTES = 66 /* 64 bit: read bytes of the DP queries */, AFC_NT = 68 /* DP problems queued by bin_tasks_kernel */, AFC_HUGE = 70, AFC_HUGE_CUR = 71, AF_NCTR = 96 };
 enum { AF_GRP_LARGE = 0, AF_GRP_SMALL = 1, AF_GRP_GLOBAL = 2 };
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -130,19 +149,19 @@ struct af_mem_t { uint64_t occ_off; uint32_t nocc; uint16_t len, idx, rpos; uint
 struct af_chain_t { int32_t score; uint16_t off, cnt; uint32_t mate; };
 struct af_start_t { int32_t f, j; };
 struct af_left_t { uint64_t ref; int64_t score; };
-#define AF_MAX_TASKS_READ 32       // DP tasks of one read (beyond: align_kernel)
+#define AF_MAX_TASKS_READ 64       // DP task slots of one read in HBM (beyond: align_kernel)
 // LDS of one read.  MA / MC / MM: capacities for anchors, chains, seeds.  Two instances are launched: a small one that most reads
 // fit (more reads in flight per CU: the kernel is bound by the latency of its serial parts), and a large one for the reads that
 // overflow it.  Arrays that are dead by the time the plan is written share their space with it.
-template <int MA_, int MC_, int MM_>
+template <int MA_, int MC_, int MM_, int NC_, int NA_, int NT_>
 struct af_wave_tt {
-    static constexpr int MA = MA_, MC = MC_, MM = MM_;
+    static constexpr int MA = MA_, MC = MC_, MM = MM_, NC = NC_, NA = NA_, NT = NT_;
     af_mem_t mem[MM_];
     uint64_t anch[MA_];                  // x (reference end, 40 bits) | mem << 40
     af_chain_t chains[MC_];
     uint16_t pool[MA_ + MC_];
     uint64_t left_ref[MC_];              // check_left_MEM's lifted coordinate of every chain (lanes in parallel: each lift is a chain of dependent loads)
-    uint8_t left_idx[MC_];               // the chains check_left_MEM has recorded
+    uint16_t left_idx[MC_];              // the chains check_left_MEM has recorded
     int64_t diff[8];
     uint32_t n_chains_sh, status_sh, n_tasks;
     union {
@@ -154,14 +173,13 @@ struct af_wave_tt {
             uint16_t run_start[MA_ + 1];
             uint16_t s_off[MC_], s_cnt[MC_];       // per sorted start: where its chain's anchors are in the pool, how many (0: chain dropped)
         };
-        struct {                         // the plan and its tasks
-            af_plan_t plan;
-            moni_dp_task_t tasks[AF_MAX_TASKS_READ];
-        };
+        af_plan_lds_t<NC_, NA_, NT_> plan;      // the plan and its tasks
     };
 };
-typedef af_wave_tt<AF_MAX_ANCH, AF_MAX_CHAINS, AF_MAX_MEMS> af_wave_t;
-typedef af_wave_tt<96, 48, 24> af_wave_small_t;
+static_assert(AF_MAX_TASKS_READ <= 255, "ntasks is a byte");
+typedef af_wave_tt<96, 48, 24, 8, 32, 32> af_wave_small_t;                                                   // most reads: 8 waves per SIMD
+typedef af_wave_tt<AF_MAX_ANCH, AF_MAX_CHAINS, AF_MAX_MEMS, AF_MAX_CAND, AF_PLAN_AN, AF_MAX_TASKS_READ> af_wave_t;   // reads that overflow it
+typedef af_wave_tt<2048, 1024, 256, AF_MAX_CAND, AF_PLAN_AN, AF_MAX_TASKS_READ> af_wave_huge_t;             // repeat-rich reads (hundreds of occurrences per seed): one wave per CU
 
 // why a read left the staged path (counted in ctr[AFC_WHY + reason])
 enum { AF_WHY_LONG = 0, AF_WHY_ANCHORS, AF_WHY_CHAINS, AF_WHY_CANDS, AF_WHY_CHAIN_LEN, AF_WHY_TASK_SIZE, AF_WHY_OVERLAP, AF_WHY_WILDCARD, AF_WHY_LOOP, AF_WHY_REACH_END,
@@ -458,10 +476,11 @@ __device__ __forceinline__ void af_qseg(uint64_t off, uint32_t m, uint32_t stran
 }
 template <class WT>
 __device__ __forceinline__ bool af_add_task(WT& L, uint64_t q_off, uint64_t qlen, int qmode, uint64_t t_off, uint64_t tlen, int tmode, int flag) {
-    if (qlen == 0 || tlen == 0 || qlen > AF_QCAP || tlen > AF_TB || L.n_tasks >= AF_MAX_TASKS_READ) return false;
+    if (qlen == 0 || tlen == 0 || qlen > AF_QCAP || tlen > AF_TB) return false;
+    if (L.n_tasks >= (uint32_t)WT::NT) { L.n_tasks = 0xFFFFu; return false; }      // (does not fit this instance)
     moni_dp_task_t t;
     t.q_off = q_off; t.t_off = t_off; t.qlen = (int32_t)qlen; t.tlen = (int32_t)tlen; t.flag = flag; t.reserved = DP_Q_READS | DP_T_TEXT | qmode | tmode;
-    L.tasks[L.n_tasks++] = t;
+    L.plan.tasks[L.n_tasks++] = t;
     return true;
 }
 
@@ -471,9 +490,13 @@ template <class WT>
 __device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, WT& L, uint64_t off, uint32_t m) {
     const ac_params_t& P = G.A.P;
     const uint32_t n_chains = L.n_chains_sh;
-    af_plan_t& PL = L.plan;
-    PL.n_chains = (uint16_t)n_chains; PL.n_cand = 0;
+    auto& PL = L.plan;
+    PL.n_chains = (uint16_t)n_chains; PL.n_cand = 0; PL.n_an = 0;
     L.n_tasks = 0;
+    // a capacity of THIS instance (chains to score, their anchors, their problems): 0xFF = the next larger instance takes the read;
+    // the largest instance hands it to align_kernel
+#define AF_CAP(why) do { if ((uint32_t)WT::NC < AF_MAX_CAND || (uint32_t)WT::NA < AF_PLAN_AN || (uint32_t)WT::NT < AF_MAX_TASKS_READ) return 0xFFu; return AF_FALLBACK(G, why); } while (0)
+#define AF_TASK_FAIL() do { if (L.n_tasks == 0xFFFFu) AF_CAP(AF_WHY_CAPACITY); return AF_FALLBACK(G, AF_WHY_TASK_SIZE); } while (0)
     const uint64_t n_text = P.n_text, ext_len = P.ext_len;
     int64_t* diff = L.diff; uint32_t n_diff = 0, n_left = 0;
     for (uint32_t ci = 0; ci < n_chains && n_diff < P.check_k; ++ci) {
@@ -488,22 +511,25 @@ __device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, WT& L, uin
                 if (d < P.region_dist && L.chains[L.left_idx[k]].score == ch.score) seen = true;
             }
             if (seen) continue;
-            L.left_idx[n_left++] = (uint8_t)ci;                                         // n_left <= n_chains <= 255
+            L.left_idx[n_left++] = (uint16_t)ci;
         }
         if (n_diff >= P.check_k) continue;                       // not scored; the loop condition ends the loop
         // ---- fill_chain, part 1 (aligner_ksw2.hpp:2782-2979): the problems of this chain ----
-        if (PL.n_cand >= AF_MAX_CAND) return AF_FALLBACK(G, AF_WHY_CANDS);
-        if (ch.cnt > AF_MAX_AN) return AF_FALLBACK(G, AF_WHY_CHAIN_LEN);
+        if (PL.n_cand >= (uint32_t)WT::NC) AF_CAP(AF_WHY_CANDS);
+        if (ch.cnt > 255u || PL.n_an + ch.cnt > (uint32_t)WT::NA) AF_CAP(AF_WHY_CHAIN_LEN);
         af_cand_t& C = PL.cand[PL.n_cand];
-        C.chain_score = ch.score; C.chain_idx = (uint16_t)ci; C.n_an = (uint8_t)ch.cnt; C.task0 = L.n_tasks; C.has_lc = C.has_rc = C.n_gap_tasks = 0; C.overlap = 0; C.score = 0; C.gtask = 0; C.pad = 0;
+        af_anchor_t* const AN = PL.an + PL.n_an;
+        C.chain_score = ch.score; C.chain_idx = (uint16_t)ci; C.n_an = (uint8_t)ch.cnt; C.task0 = L.n_tasks; C.has_lc = C.has_rc = C.n_gap_tasks = 0; C.overlap = 0; C.score = 0; C.gtask = 0;
+        C.an0 = (uint16_t)PL.n_an; C.pad = 0; C.pad2 = 0;
+        PL.n_an += ch.cnt;
         for (uint32_t k = 0; k < ch.cnt; ++k) {                  // stored right to left (chain.hpp:166-200); fill_chain wants left to right
             const uint64_t aw = L.anch[L.pool[ch.off + ch.cnt - 1 - k]];
             const af_mem_t mk = L.mem[aw >> 40];
-            af_anchor_t& A = C.an[k];
+            af_anchor_t& A = AN[k];
             A.occ = AF_X(aw) - mk.len + 1; A.len = mk.len; A.idx = mk.idx; A.gap_val = 0; A.gap_kind = AF_GAP_NONE; A.pad = 0;
             if (k == 0) C.strand = (mk.mate & 2) ? 1 : 0;
         }
-        const af_anchor_t first = C.an[0], last = C.an[ch.cnt - 1];
+        const af_anchor_t first = AN[0], last = AN[ch.cnt - 1];
         const uint32_t strand = C.strand;
 #define qseg(a, len, reversed, q_off, qmode) af_qseg(off, m, strand, (a), (len), (reversed), (q_off), (qmode))
 #define add(q_off, qlen, qmode, t_off, tlen, tmode, flag) af_add_task(L, (q_off), (qlen), (qmode), (t_off), (tlen), (tmode), (flag))
@@ -514,7 +540,7 @@ __device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, WT& L, uin
             const uint64_t lc_len = mem_pos > ext_len ? ext_len : ext_len - mem_pos;     // sic (aligner_ksw2.hpp:2796)
             uint64_t q_off; int qmode;
             qseg(0, lcs_len, true, q_off, qmode);
-            if (!add(q_off, lcs_len, qmode, lc_len ? lc_occ + lc_len - 1 : 0, lc_len, DP_T_REV, DP_EZ_EXTZ_ONLY | DP_EZ_RIGHT)) return AF_FALLBACK(G, AF_WHY_TASK_SIZE);
+            if (!add(q_off, lcs_len, qmode, lc_len ? lc_occ + lc_len - 1 : 0, lc_len, DP_T_REV, DP_EZ_EXTZ_ONLY | DP_EZ_RIGHT)) AF_TASK_FAIL();
             C.has_lc = 1;
         }
         if (rcs_len > 0) {
@@ -522,20 +548,20 @@ __device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, WT& L, uin
             const uint64_t rc_len = rc_occ < n_text - ext_len ? ext_len : n_text - rc_occ;
             uint64_t q_off; int qmode;
             qseg(rcs_occ, rcs_len, false, q_off, qmode);
-            if (!add(q_off, rcs_len, qmode, rc_occ, rc_len, 0, DP_EZ_EXTZ_ONLY | DP_EZ_RIGHT)) return AF_FALLBACK(G, AF_WHY_TASK_SIZE);
+            if (!add(q_off, rcs_len, qmode, rc_occ, rc_len, 0, DP_EZ_EXTZ_ONLY | DP_EZ_RIGHT)) AF_TASK_FAIL();
             C.has_rc = 1;
         }
         uint64_t last_ref = mem_pos + first.len, last_seq = (uint64_t)first.idx + first.len;
         for (uint32_t k = 1; k < ch.cnt; ++k) {                  // overlapping anchors: the global realignment of the whole read (aligner_ksw2.hpp:2888-2900, 2984-2996)
-            const af_anchor_t ak = C.an[k];
+            const af_anchor_t ak = AN[k];
             if (last_ref > ak.occ || last_seq > ak.idx) C.overlap = 1;
             last_ref = ak.occ + ak.len; last_seq = (uint64_t)ak.idx + ak.len;
         }
         if (C.overlap && m > AF_QCAP) return AF_FALLBACK(G, AF_WHY_TASK_SIZE);
         last_ref = mem_pos + first.len; last_seq = (uint64_t)first.idx + first.len;
         for (uint32_t k = 1; k < ch.cnt && !C.overlap; ++k) {
-            const af_anchor_t ak = C.an[k], ap = C.an[k - 1];
-            af_anchor_t& GP = C.an[k - 1];
+            const af_anchor_t ak = AN[k], ap = AN[k - 1];
+            af_anchor_t& GP = AN[k - 1];
             const uint64_t ref_occ = ak.occ, seq_occ = ak.idx;
             if (last_ref == ref_occ) {
                 if (last_seq < seq_occ) {                                              // pure insertion
@@ -560,7 +586,7 @@ __device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, WT& L, uin
                     }
                 }
                 if (!closed) {
-                    if (!add(q_off, ccs_len, qmode, cc_occ, cc_len, 0, DP_EZ_RIGHT)) return AF_FALLBACK(G, AF_WHY_TASK_SIZE);
+                    if (!add(q_off, ccs_len, qmode, cc_occ, cc_len, 0, DP_EZ_RIGHT)) AF_TASK_FAIL();
                     GP.gap_kind = AF_GAP_TASK; C.n_gap_tasks++;
                 }
             }
@@ -570,28 +596,32 @@ __device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, WT& L, uin
     }
 #undef qseg
 #undef add
+#undef AF_CAP
+#undef AF_TASK_FAIL
     return AF_ST_CAND;
 }
 
-// WT: the LDS instance (capacities).  BIG = false: every read of the launch, reads that overflow the small instance go to big_list;
-// BIG = true: the reads of big_list, reads that overflow go to align_kernel.
-template <class WT, bool BIG, int OCC = (BIG ? 3 : 6)>
+// WT: the LDS instance (capacities).  LEVEL 0: every read of the launch, reads that overflow the small instance go to big_list;
+// LEVEL 1: the reads of big_list, reads that overflow go to huge_list; LEVEL 2: the reads of huge_list, reads that overflow go to align_kernel.
+template <class WT, int LEVEL, int OCC = (LEVEL == 0 ? 6 : LEVEL == 1 ? 3 : 1)>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) chain_plan_kernel(const af_args_t G) {
     __shared__ WT L;                          // one wavefront per workgroup: __syncthreads() orders the wave's own LDS traffic
     const int lane = threadIdx.x;
     const ak_args_t& A = G.A;
-    const uint32_t n_work = BIG ? G.ctr[AFC_BIG] : (uint32_t)A.n_reads;
+    constexpr bool BIG = LEVEL > 0;
+    const uint32_t n_work = LEVEL == 0 ? (uint32_t)A.n_reads : G.ctr[LEVEL == 1 ? AFC_BIG : AFC_HUGE];
     constexpr uint32_t GRAB = BIG ? 1u : 8u;          // reads taken per visit to the shared cursor
+    const uint32_t* const work_list = LEVEL == 1 ? G.big_list : G.huge_list;
     uint32_t w_next = 0, w_end = 0;
     while (true) {
         if (w_next >= w_end) {
-            if (lane == 0) w_next = atomicAdd(&G.ctr[BIG ? AFC_BIG_CUR : AFC_READ_CUR], GRAB);
+            if (lane == 0) w_next = atomicAdd(&G.ctr[LEVEL == 0 ? AFC_READ_CUR : LEVEL == 1 ? AFC_BIG_CUR : AFC_HUGE_CUR], GRAB);
             w_next = (uint32_t)__shfl((int)w_next, 0);
             w_end = w_next + GRAB;
         }
         const uint32_t w_in = w_next++;
         if (w_in >= n_work) break;
-        const uint32_t r_in = BIG ? G.big_list[w_in] : w_in;
+        const uint32_t r_in = BIG ? work_list[w_in] : w_in;
         AF_STAMP(c0);
         const uint64_t r = A.read_lo + r_in;
         const uint64_t off = A.offs[r];
@@ -674,20 +704,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
                 __syncthreads();
                 AF_STAMP(c4); AF_PROF(G, 3, c3, c4);
                 status = L.status_sh;
+                if (status == 0xFFu) too_big = true;              // the plan does not fit this instance
             }
         }
         __syncthreads();
         if (too_big) {
-            if (!BIG) { if (lane == 0) G.big_list[atomicAdd(&G.ctr[AFC_BIG], 1u)] = r_in; continue; }      // the large instance takes it
+            if (LEVEL == 0) { if (lane == 0) G.big_list[atomicAdd(&G.ctr[AFC_BIG], 1u)] = r_in; continue; }      // the next larger instance takes it
+            if (LEVEL == 1) { if (lane == 0) G.huge_list[atomicAdd(&G.ctr[AFC_HUGE], 1u)] = r_in; continue; }
             fallback = true;
         }
         if (fallback) { status = AF_ST_FALLBACK; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + (m >= AF_MAX_READ ? AF_WHY_LONG : AF_WHY_ANCHORS)], 1u); }
         // ---- the read's tasks go to the batch's list and the bins of their tile / query length; the plan goes to HBM ----
-        af_plan_t& PL = L.plan;
+        auto& PL = L.plan;
         const uint32_t nt = status == AF_ST_CAND ? L.n_tasks : 0u;
         const uint32_t t0 = r_in * AF_MAX_TASKS_READ;                 // the read's own slots (bin_tasks_kernel queues them)
         if (status == AF_ST_CAND) {
-            if ((uint32_t)lane < nt) G.tasks[t0 + lane] = L.tasks[lane];
+            if ((uint32_t)lane < nt) G.tasks[t0 + lane] = PL.tasks[lane];
             if ((uint32_t)lane < PL.n_cand) PL.cand[lane].task0 += t0;
         }
         if (lane == 0) G.ntasks[r_in] = (uint8_t)nt;
@@ -698,30 +730,35 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
             if (status == AF_ST_FALLBACK) G.fb_list[atomicAdd(G.fb_n, 1u)] = (uint32_t)r;
         }
         __syncthreads();
-        {   // plan: only the part in use
+        {   // plan: only the parts in use (header + chains to score; their anchors)
             const uint32_t words = (uint32_t)((offsetof(af_plan_t, cand) + (status == AF_ST_CAND ? PL.n_cand : 0u) * sizeof(af_cand_t)) / 4);
             const uint32_t* src = reinterpret_cast<const uint32_t*>(&PL);
             uint32_t* dst = reinterpret_cast<uint32_t*>(G.plans + r_in);
             for (uint32_t w = lane; w < words; w += 64) dst[w] = src[w];
+            const uint32_t awords = status == AF_ST_CAND ? PL.n_an * (uint32_t)(sizeof(af_anchor_t) / 4) : 0u;
+            const uint32_t* asrc = reinterpret_cast<const uint32_t*>(PL.an);
+            uint32_t* adst = reinterpret_cast<uint32_t*>(G.plans[r_in].an);
+            for (uint32_t w = lane; w < awords; w += 64) adst[w] = asrc[w];
         }
         __syncthreads();
         AF_STAMP(c5); AF_PROF(G, 4, c0, c5);
     }
 }
 
-// bin_tasks_kernel: the reads' DP problems go to the queues of their tile / query-length bins.  A block takes 8 reads (their 8 x 32 task
+// bin_tasks_kernel: the reads' DP problems go to the queues of their tile / query-length bins.  A block takes 4 reads (their 4 x 64 task
 // slots, one thread each), counts per bin in LDS and bumps every bin's global counter once: a few thousand atomics per address and
 // launch where one per task was the bound of chain_plan_kernel.
 __global__ void __launch_bounds__(256) bin_tasks_kernel(const af_args_t G) {
     __shared__ uint32_t cnt[AF_NBIN], base[AF_NBIN], ovf[8];
+    static_assert(AF_MAX_TASKS_READ == 64, "bin_tasks_kernel: 4 reads x 64 slots per block");
     const uint32_t tid = threadIdx.x;
     const uint64_t n_reads = G.A.n_reads;
     if (blockIdx.x == 0 && tid == 0) G.ctr[AFC_TASKS] = (uint32_t)n_reads * AF_MAX_TASKS_READ;      // the global problems (global_task_kernel) come after the slots
     if (tid < AF_NBIN) cnt[tid] = 0;
     if (tid < 8) ovf[tid] = 0;
     __syncthreads();
-    const uint64_t r_in = (uint64_t)blockIdx.x * 8 + (tid >> 5);
-    const uint32_t k = tid & 31u;
+    const uint64_t r_in = (uint64_t)blockIdx.x * 4 + (tid >> 6);
+    const uint32_t k = tid & 63u;
     const bool valid = r_in < n_reads && k < (uint32_t)G.ntasks[r_in];
     const uint32_t id = (uint32_t)r_in * AF_MAX_TASKS_READ + k;
     uint32_t bin = 0, local = 0;
@@ -733,11 +770,11 @@ __global__ void __launch_bounds__(256) bin_tasks_kernel(const af_args_t G) {
     if (valid) {
         const uint32_t at = base[bin] + local;
         if (at < G.bin_cap) { G.bin_q[(size_t)bin * G.bin_cap + at] = id; G.task_pos[id] = at | (bin << 26); }
-        else ovf[tid >> 5] = 1;                      // the queue is full: the read goes to align_kernel
+        else ovf[tid >> 6] = 1;                      // the queue is full: the read goes to align_kernel
     }
     __syncthreads();
-    if (tid < 8 && ovf[tid]) {
-        const uint64_t rr = (uint64_t)blockIdx.x * 8 + tid;
+    if (tid < 4 && ovf[tid]) {
+        const uint64_t rr = (uint64_t)blockIdx.x * 4 + tid;
         G.plans[rr].status = AF_ST_FALLBACK;
         G.fb_list[atomicAdd(G.fb_n, 1u)] = (uint32_t)(G.A.read_lo + rr);
         atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CAPACITY], 1u);
@@ -1034,8 +1071,8 @@ __device__ __forceinline__ af_dirs_t af_dir_of(const af_args_t& G, uint32_t bin,
 }
 
 // the window of a chain from its extensions (aligner_ksw2.hpp:2852-2886)
-__device__ __forceinline__ void af_window(const af_cand_t& C, uint32_t m, int lc_t, int rc_t, uint64_t& ref_pos, uint64_t& ref_len) {
-    const af_anchor_t first = C.an[0], last = C.an[C.n_an - 1];
+__device__ __forceinline__ void af_window(const af_cand_t& C, const af_anchor_t* an, uint32_t m, int lc_t, int rc_t, uint64_t& ref_pos, uint64_t& ref_len) {      // an: the chain's anchors
+    const af_anchor_t first = an[0], last = an[C.n_an - 1];
     const uint64_t mem_pos = first.occ, mem_len = last.occ + last.len - mem_pos;
     const uint64_t lq = (uint64_t)(int64_t)(first.idx > 0 ? lc_t + 1 : 0);
     const uint64_t rcs_len = m - ((uint64_t)last.idx + last.len);
@@ -1073,7 +1110,7 @@ __global__ void __launch_bounds__(256) global_task_kernel(const af_args_t G) {
                 int lc_t = -1, rc_t = -1;
                 if (Cp->has_lc) { const af_res_t R = G.res[t++]; if (R.flags) why = AF_WHY_WILDCARD; lc_t = R.mqe_t; }
                 if (Cp->has_rc) { const af_res_t R = G.res[t++]; if (R.flags) why = AF_WHY_WILDCARD; rc_t = R.mqe_t; }
-                af_window(*Cp, m, lc_t, rc_t, ref_pos, ref_len);
+                af_window(*Cp, PLp->an + Cp->an0, m, lc_t, rc_t, ref_pos, ref_len);
                 if (why == AF_WHY_N) {
                     Cp->gtask = ~0u;
                     if (ac_valid(A.P, ref_pos, ref_len)) {                    // else: scored INT32_MIN whatever the DP says; never the final chain
@@ -1141,8 +1178,9 @@ __global__ void __launch_bounds__(256) select_kernel(const af_args_t G) {
         if (C.has_lc) { const af_res_t R = G.res[t++]; fallback |= R.flags != 0; score_lc = R.mqe; lc_t = R.mqe_t; }
         if (C.has_rc) { const af_res_t R = G.res[t++]; fallback |= R.flags != 0; score_rc = R.mqe; rc_t = R.mqe_t; }
         const uint32_t n_an = C.n_an;
+        const af_anchor_t* const AN = PL.an + C.an0;
         uint64_t ref_pos, ref_len;
-        af_window(C, m, lc_t, rc_t, ref_pos, ref_len);
+        af_window(C, AN, m, lc_t, rc_t, ref_pos, ref_len);
         int32_t score;
         if (C.overlap) {
             score = INT32_MIN;                                              // gtask == ~0u: the window is not inside one sequence
@@ -1150,13 +1188,13 @@ __global__ void __launch_bounds__(256) select_kernel(const af_args_t G) {
         } else {
             uint32_t sc = (uint32_t)score_lc + (uint32_t)score_rc;
             for (uint32_t k = 1; k < n_an; ++k) {
-                const af_anchor_t ap = C.an[k - 1];
+                const af_anchor_t ap = AN[k - 1];
                 int32_t gs = ap.gap_val;                                        // AF_GAP_NONE: 0
                 if (ap.gap_kind == AF_GAP_INS) gs = af_ins_score(P, (uint64_t)(uint16_t)ap.gap_val);
                 else if (ap.gap_kind == AF_GAP_TASK) { const af_res_t R = G.res[t++]; fallback |= R.flags != 0; gs = R.score; }
                 sc += (uint32_t)((uint64_t)ap.len * (uint64_t)(int64_t)P.smatch + (uint64_t)(int64_t)gs);
             }
-            sc += (uint32_t)((uint64_t)C.an[n_an - 1].len * (uint64_t)(int64_t)P.smatch);
+            sc += (uint32_t)((uint64_t)AN[n_an - 1].len * (uint64_t)(int64_t)P.smatch);
             score = (int32_t)sc;
             if (!ac_valid(P, ref_pos, ref_len)) score = INT32_MIN;
         }
@@ -1215,9 +1253,10 @@ __global__ void __launch_bounds__(256) select_kernel(const af_args_t G) {
             if (!C.overlap && !(R.mqe + A.D.end_bonus > bound) && !fallback) { fallback = true; why = AF_WHY_REACH_END; }
             if (k == 0 && C.has_lc) lc_t = R.mqe_t; else rc_t = R.mqe_t;
         }
-        af_window(C, m, lc_t, rc_t, PL.ref_pos, PL.ref_len);
+        af_window(C, PL.an + C.an0, m, lc_t, rc_t, PL.ref_pos, PL.ref_len);
         const uint32_t n_tb = C.overlap ? 1u : (uint32_t)C.has_lc + C.has_rc + C.n_gap_tasks;
         PL.pad = (uint16_t)(C.strand | (n_tb << 8));          // finish_wave_kernel starts its fetches from the plan's header alone
+        PL.pad2 = (uint32_t)C.an0 | ((uint32_t)C.n_an << 16);
         if (!fallback && n_tb) {
             const uint32_t tb0 = atomicAdd(&G.ctr[AFC_TRACED], n_tb);
             if (tb0 + n_tb > G.tb_cap) { fallback = true; why = AF_WHY_CAPACITY; }
@@ -1299,11 +1338,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                     if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push(T.ops[k]);
                 }
                 const uint32_t rc_x = C.has_rc ? tbx++ : 0u;
+                const af_anchor_t* const AN = PL.an + C.an0;
                 for (uint32_t j = 0; j < C.n_an; ++j) {
-                    const uint32_t mlen = C.an[j].len;
+                    const uint32_t mlen = AN[j].len;
                     if (n > 0 && (S.cig[n - 1] & 0xf) == 0) S.cig[n - 1] += mlen << 4; else push(mlen << 4);
                     if (j + 1 < C.n_an) {
-                        const af_anchor_t g = C.an[j];
+                        const af_anchor_t g = AN[j];
                         if (g.gap_kind == AF_GAP_TASK) {
                             const af_tb_t& T = G.tb[tbx++];
                             if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) push_merge_first(T.ops[T.n_ops - 1 - k], k == 0);
@@ -1360,7 +1400,7 @@ struct af_finw_t {
     uint32_t cig[AFS_CIG], lcig[AFS_LCIG];
     uint32_t n_cig, n_lcig, ovf, n_seg, total, seq_at, qual_at;      // seq_at / qual_at: where SEQ and QUAL start in the line (QUAL absent: ~0)
     uint8_t names[AFW_NAMES]; uint16_t name_off[AFW_NSEQ + 2];      // the index's sequence names (kernel lifetime)
-    af_cand_t cand;                                                  // the final chain's record and the alternatives, fetched by all lanes at once
+    af_cand_t cand; af_anchor_t an[AF_FIN_AN];                       // the final chain's record, its first anchors and the alternatives, fetched by all lanes at once
     uint64_t alt_pos[AF_MAX_CAND]; int32_t alt_score[AF_MAX_CAND]; uint32_t alt_sid[AF_MAX_CAND], alt_p1[AF_MAX_CAND];
     uint32_t md_item[AFS_MAXMD];         // type (2 bits: 0 closing count, 1 mismatch, 2 deletion) | matches before it << 2 | mismatch: reference base << 12;
                                          // deletion: length << 12 | offset of its first base in the reference window << 21
@@ -1458,7 +1498,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         for (uint32_t k = lane; k < F.sname_off[n_seq]; k += 64) L.names[k] = F.snames[k];
     }
     uint32_t* const tbs = reinterpret_cast<uint32_t*>(L.line);       // staged traceback records: the line buffer is free until the line is rendered
-#define TB(k) (*reinterpret_cast<const af_tb_t*>(tbs + (k) * AFW_TB_WORDS))
+#define TB(k) ((k) < AF_FIN_TB ? *reinterpret_cast<const af_tb_t*>(tbs + (k) * AFW_TB_WORDS) : G.tb[h_tb0 + (k)])      // the first records are staged in LDS
+#define ANCH(j) ((j) < AF_FIN_AN ? L.an[j] : PL.an[h_an0 + (j)])
 #define NAME_LEN(sid) (names_lds ? (uint32_t)(L.name_off[(sid) + 1] - L.name_off[sid]) : F.sname_off[(sid) + 1] - F.sname_off[sid])
     // the plan's 40-byte header (status, final chain, strand, traced problems, window) says where everything else is: it is read with
     // one round trip, the next read's while this one is worked on
@@ -1471,7 +1512,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         if (st == AF_ST_FALLBACK) continue;
         const uint32_t h_final = (uint32_t)(h1 & 0xFFu), h_nalt = (uint32_t)((h1 >> 8) & 0xFFu), h_strand = (uint32_t)((h1 >> 16) & 0xFFu), h_ntb = (uint32_t)((h1 >> 24) & 0xFFu);
         const int32_t h_score2 = (int32_t)(uint32_t)(h1 >> 32);
-        const uint32_t h_tb0 = (uint32_t)h4;
+        const uint32_t h_tb0 = (uint32_t)h4, h_an0 = (uint32_t)(h4 >> 32) & 0xFFFFu, h_nan = (uint32_t)(h4 >> 48) & 0xFFu;
         const uint64_t r = A.read_lo + r_in;
         const uint64_t off = A.offs[r];
         const uint32_t m = (uint32_t)(A.offs[r + 1] - off);
@@ -1490,13 +1531,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
             const uint32_t* src = reinterpret_cast<const uint32_t*>(&PL.cand[h_final]);
             uint32_t* dst = reinterpret_cast<uint32_t*>(&L.cand);
             for (uint32_t w = lane; w < sizeof(af_cand_t) / 4; w += 64) dst[w] = src[w];
+            const uint32_t* asrc = reinterpret_cast<const uint32_t*>(PL.an + h_an0);
+            uint32_t* adst = reinterpret_cast<uint32_t*>(L.an);
+            for (uint32_t w = lane; w < (h_nan < AF_FIN_AN ? h_nan : AF_FIN_AN) * (uint32_t)(sizeof(af_anchor_t) / 4); w += 64) adst[w] = asrc[w];
             if (lane < AF_MAX_CAND) L.alt_score[lane] = PL.alt_score[lane];
         }
         const af_cand_t* C = aligned ? &L.cand : nullptr;
         const uint32_t strand = aligned ? h_strand : 0u;
         const uint32_t n_alt = aligned ? h_nalt : 0u;
         if (aligned) {
-            for (uint32_t w = lane; w < h_ntb * AFW_TB_WORDS; w += 64) {
+            for (uint32_t w = lane; w < (h_ntb < AF_FIN_TB ? h_ntb : AF_FIN_TB) * AFW_TB_WORDS; w += 64) {
                 const uint32_t k = w / AFW_TB_WORDS, x = w % AFW_TB_WORDS;
                 tbs[w] = reinterpret_cast<const uint32_t*>(&G.tb[h_tb0 + k])[x];
             }
@@ -1525,10 +1569,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 if (C->has_lc) { const af_tb_t& T = TB(tbx++); if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) PUSH(T.ops[k]); }
                 const uint32_t rc_x = C->has_rc ? tbx++ : 0u;
                 for (uint32_t j = 0; j < C->n_an; ++j) {
-                    const uint32_t mlen = C->an[j].len;
+                    const af_anchor_t g = ANCH(j);
+                    const uint32_t mlen = g.len;
                     if (n > 0 && (L.cig[n - 1] & 0xf) == 0) L.cig[n - 1] += mlen << 4; else PUSH(mlen << 4);
                     if (j + 1 < C->n_an) {
-                        const af_anchor_t g = C->an[j];
                         if (g.gap_kind == AF_GAP_TASK) { const af_tb_t& T = TB(tbx++); if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) PUSH_MERGE_FIRST(T.ops[T.n_ops - 1 - k], k == 0); }
                         else if (g.gap_kind == AF_GAP_INS) PUSH_MERGE_FIRST(((uint32_t)(uint16_t)g.gap_val << 4) | 1u, true);
                         else if (g.gap_kind == AF_GAP_DEL0) PUSH_MERGE_FIRST(2u, true);
@@ -1744,6 +1788,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         AF_STAMP(fw7); AF_PROF(G, 21, fw6, fw7); AF_PROF(G, 22, fw0, fw7);
     }
 #undef TB
+#undef ANCH
 #undef NAME_LEN
 }
 

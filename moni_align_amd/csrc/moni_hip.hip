@@ -97,9 +97,10 @@ struct moni_ctx {
     DBuf<uint8_t> seq;
     DBuf<uint64_t> offs;
     uint64_t n_reads = 0, total_len = 0, max_len = 0;
+    DBuf<moni_u64x2> blk; std::vector<moni_u64x2> h_blk;      // workspace layout of the resident batch (seed_core.h: ws_ptr_base / ws_pat_base), n_blocks + 1 entries
     std::vector<uint8_t> h_seq;              // host copy of the resident batch (SAM SEQ, MD/NM)
     std::vector<uint64_t> h_offs;
-    struct Stash { DBuf<uint8_t> seq; DBuf<uint64_t> offs; uint64_t n_reads = 0, total_len = 0, max_len = 0; std::vector<uint8_t> h_seq; std::vector<uint64_t> h_offs; };
+    struct Stash { DBuf<uint8_t> seq; DBuf<uint64_t> offs; DBuf<moni_u64x2> blk; std::vector<moni_u64x2> h_blk; uint64_t n_reads = 0, total_len = 0, max_len = 0; std::vector<uint8_t> h_seq; std::vector<uint64_t> h_offs; };
     std::vector<Stash> stash;                // moni_reads_swap: further batches kept in HBM beside the resident one
     // workspaces
     DBuf<uint64_t> ptr, pat;
@@ -114,9 +115,7 @@ struct moni_ctx {
     uint32_t* d_small = nullptr;            // [0] pool_next, [1] error_flag
     unsigned long long* d_counters = nullptr;   // 4
     uint64_t n_mems = 0, n_occs = 0;
-    float ms_accum[7] = {0, 0, 0, 0, 0, 0, 0}; unsigned long long ctr_accum[4] = {0, 0, 0, 0}; bool accum_valid = false;      // pipelined seeding: sums over the slices
     uint32_t dirs_scale = 1;                                   // direction-bit budget multiplier (doubles after a batch that overflowed it)
-    double est_mems_per_read = 6, est_occs_per_read = 80;      // sizes the per-MEM buffers of a pipelined batch (updated by every batch)
     uint32_t tmp_cap = 16;
     uint32_t pool_rows = 4096;
     double dp_kernel_ms_accum = 0;
@@ -355,8 +354,8 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->idx->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto& x : c->stash) { x.seq.release(); x.offs.release(); }
-    c->seq.release(); c->offs.release(); c->ptr.release(); c->pat.release(); c->cnt_m.release(); c->cnt_s.release(); c->mem_slots.release(); c->tot.release();
+    for (auto& x : c->stash) { x.seq.release(); x.offs.release(); x.blk.release(); }
+    c->blk.release(); c->seq.release(); c->offs.release(); c->ptr.release(); c->pat.release(); c->cnt_m.release(); c->cnt_s.release(); c->mem_slots.release(); c->tot.release();
     c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
     c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
     for (int x = 0; x < AK_NSET; ++x) c->af[x].release();
@@ -400,13 +399,28 @@ static int reads_upload(moni_ctx* c, const moni_read_batch_t* b, bool keep_host_
     if (mx >= (1ull << 31)) return MONI_EINVAL;
     const uint64_t total = nr ? b->offsets[nr] - b->offsets[0] : 0;
     int rc;
-    if ((rc = c->seq.ensure(total + 16)) || (rc = c->offs.ensure(nr + 1))) return rc;
+    // workspace layout (seed_core.h): per block of 32 reads (64 tasks) as many steps as its longest read has
+    const uint64_t n_blk = (nr + 31) / 32;
+    std::vector<moni_u64x2> blk(n_blk + 1);
+    {
+        uint64_t pw = 0, qw = 0;
+        for (uint64_t k = 0; k < n_blk; ++k) {
+            uint64_t lb = 0;
+            for (uint64_t i = 32 * k; i < nr && i < 32 * k + 32; ++i) lb = std::max<uint64_t>(lb, b->offsets[i + 1] - b->offsets[i]);
+            blk[k].x = qw; blk[k].y = pw;
+            qw += 64 * lb; pw += 64 * ((lb + 7) / 8);
+        }
+        blk[n_blk].x = qw; blk[n_blk].y = pw;
+    }
+    if ((rc = c->seq.ensure(total + 16)) || (rc = c->offs.ensure(nr + 1)) || (rc = c->blk.ensure(n_blk + 1))) return rc;
+    HIPCHK(hipMemcpyAsync(c->blk.p, blk.data(), (n_blk + 1) * sizeof(moni_u64x2), hipMemcpyHostToDevice, c->stream));
     std::vector<uint64_t> rel(nr + 1);
     for (uint64_t i = 0; i <= nr; ++i) rel[i] = b->offsets[i] - b->offsets[0];
     if (total) HIPCHK(hipMemcpyAsync(c->seq.p, b->seq + b->offsets[0], total, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->offs.p, rel.data(), (nr + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->n_reads = nr; c->total_len = total; c->max_len = mx;
+    c->h_blk.swap(blk);
     if (keep_host_copy) { c->h_seq.assign(b->seq + b->offsets[0], b->seq + b->offsets[0] + total); c->h_offs = rel; }
     else { c->h_seq.clear(); c->h_offs.clear(); }
     c->n_mems = c->n_occs = 0;
@@ -419,41 +433,26 @@ int moni_reads_swap(moni_ctx_t* c, uint32_t slot) {
     HIPCHK(hipStreamSynchronize(c->stream));
     try { if (c->stash.size() <= slot) c->stash.resize(slot + 1); } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
     moni_ctx::Stash& x = c->stash[slot];
-    std::swap(c->seq, x.seq); std::swap(c->offs, x.offs); std::swap(c->n_reads, x.n_reads); std::swap(c->total_len, x.total_len); std::swap(c->max_len, x.max_len);
+    std::swap(c->seq, x.seq); std::swap(c->offs, x.offs); std::swap(c->blk, x.blk); c->h_blk.swap(x.h_blk); std::swap(c->n_reads, x.n_reads); std::swap(c->total_len, x.total_len); std::swap(c->max_len, x.max_len);
     c->h_seq.swap(x.h_seq); c->h_offs.swap(x.h_offs);
     c->n_mems = c->n_occs = 0;
     return MONI_OK;
 }
 
-// A slice = a range of the resident reads with its own region of every seeding buffer (the whole batch is the slice r0 = 0).  The
-// align stage seeds sub-batch k+1 while the align kernels of sub-batch k run: their seeds must stay where they are.
-struct SeedSlice {
-    uint64_t r0 = 0, nr = 0, idx = 0;        // reads [r0, r0 + nr), slice number
-    uint64_t mem_base = 0, occ_base = 0;     // first MEM / occurrence of the slice in c->mems / c->occs (pipelined: after the earlier slices')
-    uint64_t n_mems = 0, n_occs = 0;         // results
-    bool pipelined = false;                  // buffers were sized for the whole batch by the caller; growing them needs a drained GPU
-    uint64_t rmo() const { return r0 + idx; }                 // tot / read_mem_off: nr + 1 entries per slice
-    uint64_t mem_at() const { return mem_base + 2 * idx; }    // per-MEM arrays with n_mems + 1 (+1) entries per slice
-};
-
-static int ms_launch(moni_ctx* c, const SeedSlice& S) {
+static int ms_launch(moni_ctx* c) {
     moni_index* I = c->idx;
-    const uint64_t n_tasks = 2 * S.nr;
-    const uint32_t n_words = (uint32_t)((c->max_len + 7) / 8);
+    const uint64_t n_tasks = 2 * c->n_reads;
     int rc;
-    if (!S.pipelined) {
-        if ((rc = c->ptr.ensure(2 * c->n_reads * c->max_len + 1))) return rc;
-        if ((rc = c->pat.ensure(2 * c->n_reads * n_words + 1))) return rc;
-    }
-    uint64_t* pat = c->pat.p + 2 * S.r0 * n_words; uint64_t* ptr = c->ptr.p + 2 * S.r0 * c->max_len; const uint64_t* offs = c->offs.p + S.r0;
+    if (c->h_blk.empty()) return MONI_EINVAL;
+    if ((rc = c->ptr.ensure(c->h_blk.back().x + 1)) || (rc = c->pat.ensure(c->h_blk.back().y + 1))) return rc;
     const unsigned grid = (unsigned)((n_tasks + MS_BLOCK - 1) / MS_BLOCK);
     if (n_tasks)
-        hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, c->seq.p, offs, n_tasks, n_words, pat);
+        hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, c->seq.p, c->offs.p, c->blk.p, n_tasks, c->pat.p);
     rec(c, EV_MS0);
     if (n_tasks) {
 #define MS_LAUNCH(NCH, MINW) do { const uint64_t nl = (n_tasks + (NCH) - 1) / (NCH); \
         hipLaunchKernelGGL((ms_lf_kernel<NCH, MINW>), dim3((unsigned)((nl + MS_BLOCK - 1) / MS_BLOCK)), dim3(MS_BLOCK), 0, c->stream, \
-                           I->K, I->d_tables, I->d_rows, I->d_frows, I->d_cr, I->d_recs, pat, offs, n_tasks, ptr, c->d_counters); } while (0)
+                           I->K, I->d_tables, I->d_rows, I->d_frows, I->d_cr, I->d_recs, c->pat.p, c->offs.p, c->blk.p, n_tasks, c->ptr.p, c->d_counters); } while (0)
         switch (c->ms_variant) {
             case 1: MS_LAUNCH(1, 8); break;
             case 2: MS_LAUNCH(2, 8); break;
@@ -468,7 +467,6 @@ static int ms_launch(moni_ctx* c, const SeedSlice& S) {
     HIPCHK(hipGetLastError());
     return MONI_OK;
 }
-static int ms_launch(moni_ctx* c) { SeedSlice S; S.nr = c->n_reads; return ms_launch(c, S); }
 
 int moni_ms_run(moni_ctx_t* c) {
     if (!c) return MONI_EINVAL;
@@ -482,21 +480,25 @@ int moni_ms_run(moni_ctx_t* c) {
     return MONI_OK;
 }
 
+// pointer of step s of a task, in the host copy of the pointer workspace (seed_core.h: ws_ptr_base)
+static inline uint64_t ws_ptr_host(const moni_ctx* c, const std::vector<uint64_t>& h, uint64_t task, uint64_t s) { return h[c->h_blk[task >> 6].x + (task & 63u) + s * 64u]; }
+
 int moni_ms_query_batch(moni_ctx_t* c, const moni_read_batch_t* b, uint64_t* pointers) {
     if (!pointers) return MONI_EINVAL;
     int rc = moni_reads_upload(c, b);
     if (rc) return rc;
     if ((rc = moni_ms_run(c))) return rc;
-    const uint64_t n_tasks = 2 * c->n_reads;
-    std::vector<uint64_t> h(n_tasks * c->max_len);
-    if (!h.empty()) HIPCHK(hipMemcpy(h.data(), c->ptr.p, h.size() * 8, hipMemcpyDeviceToHost));
-    const uint64_t base = b->offsets[0];
-    for (uint64_t rd = 0; rd < c->n_reads; ++rd) {
-        const uint64_t off = b->offsets[rd] - base, m = b->offsets[rd + 1] - b->offsets[rd];
-        for (uint64_t s = 0; s < 2; ++s)
-            for (uint64_t k = 0; k < m; ++k)
-                pointers[2 * off + s * m + k] = h[(m - 1 - k) * n_tasks + (2 * rd + s)];
-    }
+    try {
+        std::vector<uint64_t> h(c->h_blk.back().x);
+        if (!h.empty()) HIPCHK(hipMemcpy(h.data(), c->ptr.p, h.size() * 8, hipMemcpyDeviceToHost));
+        const uint64_t base = b->offsets[0];
+        for (uint64_t rd = 0; rd < c->n_reads; ++rd) {
+            const uint64_t off = b->offsets[rd] - base, m = b->offsets[rd + 1] - b->offsets[rd];
+            for (uint64_t s = 0; s < 2; ++s)
+                for (uint64_t k = 0; k < m; ++k)
+                    pointers[2 * off + s * m + k] = ws_ptr_host(c, h, 2 * rd + s, m - 1 - k);
+        }
+    } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
     return MONI_OK;
 }
 
@@ -507,55 +509,50 @@ int moni_ms_lengths_batch(moni_ctx_t* c, const moni_read_batch_t* b, uint64_t* p
     if (rc) return rc;
     if ((rc = moni_ms_run(c))) return rc;
     moni_index* I = c->idx;
-    const uint64_t nr = c->n_reads, n_tasks = 2 * nr;
+    const uint64_t nr = c->n_reads;
     if (!nr) return MONI_OK;
     DBuf<uint32_t> lens;
     if ((rc = lens.ensure(c->total_len + 1))) return rc;
-    hipLaunchKernelGGL(ms_len_kernel, dim3((unsigned)((nr + MS_BLOCK - 1) / MS_BLOCK)), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, c->pat.p, c->offs.p, nr,
+    hipLaunchKernelGGL(ms_len_kernel, dim3((unsigned)((nr + MS_BLOCK - 1) / MS_BLOCK)), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, c->pat.p, c->offs.p, c->blk.p, nr,
                        c->ptr.p, lens.p);
-    std::vector<uint64_t> h(n_tasks * c->max_len);
-    std::vector<uint32_t> hl(c->total_len + 1);
-    bool ok = hipStreamSynchronize(c->stream) == hipSuccess && (h.empty() || hipMemcpy(h.data(), c->ptr.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) &&
-              hipMemcpy(hl.data(), lens.p, c->total_len * 4, hipMemcpyDeviceToHost) == hipSuccess;
-    lens.release();
-    if (!ok) return MONI_ENODEV;
-    const uint64_t base = b->offsets[0];
-    for (uint64_t rd = 0; rd < nr; ++rd) {
-        const uint64_t off = b->offsets[rd] - base, m = b->offsets[rd + 1] - b->offsets[rd];
-        for (uint64_t k = 0; k < m; ++k) { pointers[off + k] = h[(m - 1 - k) * n_tasks + 2 * rd]; lengths[off + k] = hl[off + k]; }
-    }
+    try {
+        std::vector<uint64_t> h(c->h_blk.back().x);
+        std::vector<uint32_t> hl(c->total_len + 1);
+        bool ok = hipStreamSynchronize(c->stream) == hipSuccess && (h.empty() || hipMemcpy(h.data(), c->ptr.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) &&
+                  hipMemcpy(hl.data(), lens.p, c->total_len * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        lens.release();
+        if (!ok) return MONI_ENODEV;
+        const uint64_t base = b->offsets[0];
+        for (uint64_t rd = 0; rd < nr; ++rd) {
+            const uint64_t off = b->offsets[rd] - base, m = b->offsets[rd + 1] - b->offsets[rd];
+            for (uint64_t k = 0; k < m; ++k) { pointers[off + k] = ws_ptr_host(c, h, 2 * rd, m - 1 - k); lengths[off + k] = hl[off + k]; }
+        }
+    } catch (const std::bad_alloc&) { lens.release(); return MONI_ENOMEM; }
     return MONI_OK;
 }
 
-// Per-MEM buffers of a pipelined batch: grown only with the GPU drained (earlier slices' align kernels read them through pointers in
-// their arguments); nothing has to be kept, the slice that needs the room has not written there yet.
-static int grow_drained(moni_ctx* c, bool pipelined) {
-    if (pipelined) HIPCHK(hipDeviceSynchronize());
-    return MONI_OK;
-}
-
-static int seed_slice(moni_ctx* c, const moni_seed_params_t* prm, SeedSlice& S) {
+// The seeding stage over the resident batch: MS pointers, MEMs (count, scan, emit), occurrences (count, scan, fill).
+static int seed_all(moni_ctx* c, const moni_seed_params_t* prm) {
     moni_index* I = c->idx;
-    const uint64_t nr = S.nr, n_tasks = 2 * nr;
+    const uint64_t nr = c->n_reads, n_tasks = 2 * nr;
     int rc;
-    if (!S.pipelined && ((rc = c->cnt_m.ensure(n_tasks + 2)) || (rc = c->cnt_s.ensure(n_tasks + 2)) || (rc = c->tot.ensure(nr + 2)) ||
-                         (rc = c->read_mem_off.ensure(nr + 2)) || (rc = c->mem_slots.ensure(n_tasks * MONI_MEM_SLOTS + 1))))
+    if ((rc = c->cnt_m.ensure(n_tasks + 2)) || (rc = c->cnt_s.ensure(n_tasks + 2)) || (rc = c->tot.ensure(nr + 2)) ||
+        (rc = c->read_mem_off.ensure(nr + 2)) || (rc = c->mem_slots.ensure(n_tasks * MONI_MEM_SLOTS + 1)))
         return rc;
-    uint32_t* cnt_m = c->cnt_m.p + 2 * S.r0; uint32_t* cnt_s = c->cnt_s.p + 2 * S.r0;
-    uint64_t* tot = c->tot.p + S.rmo(); uint64_t* rmo = c->read_mem_off.p + S.rmo();
-    moni_u64x2* slots = c->mem_slots.p + 2 * S.r0 * MONI_MEM_SLOTS;
-    const uint32_t n_words = (uint32_t)((c->max_len + 7) / 8);
-    const uint64_t* offs = c->offs.p + S.r0;
+    uint32_t* cnt_m = c->cnt_m.p; uint32_t* cnt_s = c->cnt_s.p;
+    uint64_t* tot = c->tot.p; uint64_t* rmo = c->read_mem_off.p;
+    moni_u64x2* slots = c->mem_slots.p;
+    const uint64_t* offs = c->offs.p;
     HIPCHK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->d_small, 0, 16, c->stream));
     rec(c, EV_ALL0);
-    if ((rc = ms_launch(c, S))) return rc;                              // (allocates pat / ptr of a whole-batch slice)
-    const uint64_t* pat = c->pat.p + 2 * S.r0 * n_words; const uint64_t* ptr = c->ptr.p + 2 * S.r0 * c->max_len;
+    if ((rc = ms_launch(c))) return rc;                              // (allocates pat / ptr)
+    const uint64_t* pat = c->pat.p; const uint64_t* ptr = c->ptr.p;
     const unsigned grid_t = (unsigned)((n_tasks + MS_BLOCK - 1) / MS_BLOCK);
     const uint32_t split_on = prm->report_mems ? 0u : 1u;
     rec(c, EV_MC0);
     if (n_tasks)
-        hipLaunchKernelGGL(mem_kernel<false>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, pat, offs,
+        hipLaunchKernelGGL(mem_kernel<false>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, pat, offs, c->blk.p,
                            n_tasks, ptr, prm->min_len, split_on, cnt_m, cnt_s, (const uint64_t*)nullptr,
                            (moni_mem_t*)nullptr, (uint32_t*)nullptr, slots, c->d_counters);
     rec(c, EV_MC1);
@@ -564,29 +561,24 @@ static int seed_slice(moni_ctx* c, const moni_seed_params_t* prm, SeedSlice& S) 
     uint64_t n_mems = 0;
     HIPCHK(hipMemcpyAsync(&n_mems, rmo + nr, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    S.n_mems = n_mems;
     c->tmp_cap = 16;
     {
-        const uint64_t need = S.mem_at() + n_mems + 2;
-        if (need > c->mems.cap || need > c->aux.cap || need > c->lowers.cap || need * c->tmp_cap > c->tmp.cap || need > c->occ_cnt.cap || need > c->occ_off.cap) {
-            if ((rc = grow_drained(c, S.pipelined))) return rc;
-            const uint64_t want = S.pipelined ? need + need / 2 : need;
-            if ((rc = c->mems.ensure(want)) || (rc = c->aux.ensure(want)) || (rc = c->lowers.ensure(want)) || (rc = c->tmp.ensure(want * c->tmp_cap + 1)) ||
-                (rc = c->occ_cnt.ensure(want + 1)) || (rc = c->occ_off.ensure(want + 1))) return rc;
-        }
+        const uint64_t need = n_mems + 2;
+        if ((rc = c->mems.ensure(need)) || (rc = c->aux.ensure(need)) || (rc = c->lowers.ensure(need)) || (rc = c->tmp.ensure(need * c->tmp_cap + 1)) ||
+            (rc = c->occ_cnt.ensure(need + 1)) || (rc = c->occ_off.ensure(need + 1))) return rc;
         if ((rc = c->pool.ensure((size_t)c->pool_rows * I->K.n_seq + 1))) return rc;
     }
-    moni_mem_t* mems = c->mems.p + S.mem_at(); uint32_t* aux = c->aux.p + S.mem_at();
-    uint64_t* occ_cnt = c->occ_cnt.p + S.mem_at(); uint64_t* occ_off = c->occ_off.p + S.mem_at();
+    moni_mem_t* mems = c->mems.p; uint32_t* aux = c->aux.p;
+    uint64_t* occ_cnt = c->occ_cnt.p; uint64_t* occ_off = c->occ_off.p;
     rec(c, EV_ME0);
     if (n_tasks)
-        hipLaunchKernelGGL(mem_kernel<true>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, pat, offs,
+        hipLaunchKernelGGL(mem_kernel<true>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, pat, offs, c->blk.p,
                            n_tasks, ptr, prm->min_len, split_on, cnt_m, cnt_s, (const uint64_t*)rmo, mems, aux, slots, c->d_counters);
     rec(c, EV_ME1);
     occ_args_t A;
     A.phi.recs = I->d_phi; A.phi.dir = I->d_phi_dir; A.phi_inv.recs = I->d_phi_inv; A.phi_inv.dir = I->d_phi_inv_dir;
     A.seq_starts = I->d_seq_starts; A.name_id = I->d_name_id; A.mems = mems; A.aux = aux; A.read_mem_off = rmo;
-    A.n_mems = n_mems; A.occs = nullptr; A.tmp = c->tmp.p + S.mem_at() * c->tmp_cap; A.lowers = c->lowers.p + S.mem_at(); A.tmp_cap = c->tmp_cap;
+    A.n_mems = n_mems; A.occs = nullptr; A.tmp = c->tmp.p; A.lowers = c->lowers.p; A.tmp_cap = c->tmp_cap;
     A.filter_seeds = prm->filter_seeds; A.n_seeds_thr = prm->n_seeds_thr; A.pool_rows = c->pool_rows; A.pool = c->pool.p;
     A.pool_next = c->d_small; A.error_flag = c->d_small + 1; A.counters = c->d_counters;
     const unsigned grid_m = (unsigned)((n_mems + MS_BLOCK - 1) / MS_BLOCK);
@@ -614,13 +606,8 @@ static int seed_slice(moni_ctx* c, const moni_seed_params_t* prm, SeedSlice& S) 
     if (n_mems) hipLaunchKernelGGL(occ_off_scatter_kernel, dim3(grid_m), dim3(256), 0, c->stream, mems, n_mems, occ_off);
     HIPCHK(hipMemcpyAsync(&n_occs, occ_off + n_mems, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    S.n_occs = n_occs;
-    if (S.occ_base + n_occs + 1 > c->occs.cap) {
-        if ((rc = grow_drained(c, S.pipelined))) return rc;
-        const uint64_t need = S.occ_base + n_occs + 1;
-        if ((rc = c->occs.ensure(S.pipelined ? need + need / 2 : need))) return rc;
-    }
-    A.occs = c->occs.p + S.occ_base;
+    if ((rc = c->occs.ensure(n_occs + 1))) return rc;
+    A.occs = c->occs.p;
     for (int attempt = 0;; ++attempt) {
         A.pool = c->pool.p; A.pool_rows = c->pool_rows;
         HIPCHK(hipMemsetAsync(c->d_small, 0, 16, c->stream));
@@ -636,28 +623,14 @@ static int seed_slice(moni_ctx* c, const moni_seed_params_t* prm, SeedSlice& S) 
         if ((rc = c->pool.ensure((size_t)c->pool_rows * I->K.n_seq + 1))) return rc;
     }
     HIPCHK(hipGetLastError());
-    if (S.pipelined) {      // kernel times and work counters of the slices add up to the batch's
-        for (int w = 0; w < 7; ++w) {
-            const int ea = w == 6 ? EV_ALL0 : 2 * w, eb = ea + 1;
-            float ms = 0;
-            if (c->ev_valid[ea] && c->ev_valid[eb] && hipEventElapsedTime(&ms, c->ev[ea], c->ev[eb]) == hipSuccess) c->ms_accum[w] += ms;
-        }
-        unsigned long long h[4];
-        HIPCHK(hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
-        for (int i = 0; i < 4; ++i) c->ctr_accum[i] += h[i];
-    }
+    c->n_mems = n_mems; c->n_occs = n_occs;
     return MONI_OK;
 }
 
 int moni_seed_run(moni_ctx_t* c, const moni_seed_params_t* prm) {
     if (!c || !prm) return MONI_EINVAL;
     HIPCHK(hipSetDevice(c->idx->device));
-    SeedSlice S; S.nr = c->n_reads;
-    c->accum_valid = false;
-    int rc = seed_slice(c, prm, S);
-    if (rc) return rc;
-    c->n_mems = S.n_mems; c->n_occs = S.n_occs;
-    return MONI_OK;
+    return seed_all(c, prm);
 }
 
 int moni_seed_counts(moni_ctx_t* c, uint64_t* n_mems, uint64_t* n_occs) {
@@ -712,7 +685,6 @@ int moni_phi_lcp_batch(moni_ctx_t* c, const uint64_t* pos, uint64_t n, int inver
 
 int moni_last_kernel_ms(moni_ctx_t* c, int which, float* ms) {
     if (!c || !ms || which < 0 || which > 6) return MONI_EINVAL;
-    if (c->accum_valid && which != 5) { *ms = c->ms_accum[which]; return MONI_OK; }
     const int a = which == 6 ? EV_ALL0 : 2 * which, b = a + 1;
     if (!c->ev_valid[a] || !c->ev_valid[b]) return MONI_EINVAL;
     HIPCHK(hipEventSynchronize(c->ev[b]));
@@ -723,7 +695,6 @@ int moni_last_kernel_ms(moni_ctx_t* c, int which, float* ms) {
 int moni_last_counters(moni_ctx_t* c, uint64_t out[4]) {
     if (!c || !out) return MONI_EINVAL;
     HIPCHK(hipSetDevice(c->idx->device));
-    if (c->accum_valid) { for (int i = 0; i < 4; ++i) out[i] = c->ctr_accum[i]; return MONI_OK; }
     unsigned long long h[4];
     HIPCHK(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; ++i) out[i] = h[i];
@@ -1007,29 +978,15 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         struct JoinGuard { std::thread& t; ~JoinGuard() { if (t.joinable()) t.join(); } } join_guard{uploader};
         // The staged kernels (align_fast.hip) take the common case; align_kernel takes the reads they hand over (MONI_ALIGN_V1=1: every read)
         static const bool use_fast = getenv("MONI_ALIGN_V1") == nullptr;
-        // seeding: with one sub-batch the whole batch at once; with several, slice by slice inside the launch loop below, so that the
-        // (HBM-bound) seeding of sub-batch k+1 runs beside the (latency-bound) align kernels of sub-batch k
-        // (opt-in, MONI_SEED_PIPELINE=1: measured, it does not pay inside one context — the two align streams already fill the GPU, the slices'
-        // seeding and the align kernels only slow each other down, 83.7 ms against 80.6 ms per 1 M reads; two contexts out of phase do gain)
-        const bool pipelined = use_fast && n_sub >= 2 && getenv("MONI_SEED_PIPELINE") != nullptr;
+        // seeding runs over the whole batch before the align kernels of its sub-batches (seeding sub-batch k+1 beside the align kernels of
+        // sub-batch k was measured in round 2 and did not pay inside one context: the two align streams already fill the GPU; a streaming
+        // caller gets that overlap from two or three contexts per GPU)
         moni_seed_params_t sp;
         sp.min_len = prm->min_len; sp.filter_seeds = prm->filter_seeds; sp.n_seeds_thr = prm->n_seeds_thr; sp.report_mems = 0;
         {
             const double t0 = mh::now_s();
             if (!resident && (rc = reads_upload(c, b, false))) return rc;
-            if (!pipelined) { if ((rc = moni_seed_run(c, &sp))) return rc; }
-            else {
-                const uint32_t n_words = (uint32_t)((c->max_len + 7) / 8);
-                if (const char* v = getenv("MONI_SEED_EST")) { double a = 0, b2 = 0; if (sscanf(v, "%lf,%lf", &a, &b2) == 2 && a > 0 && b2 > 0) { c->est_mems_per_read = a; c->est_occs_per_read = b2; } }      // test hook: small estimates exercise the growth path
-                const uint64_t em = (uint64_t)((double)NR * c->est_mems_per_read * 1.2) + 4 * n_sub + 4096, eo = (uint64_t)((double)NR * c->est_occs_per_read * 1.2) + 4096;
-                if ((rc = c->ptr.ensure(2 * NR * c->max_len + 1)) || (rc = c->pat.ensure(2 * NR * n_words + 1)) || (rc = c->cnt_m.ensure(2 * NR + 2)) || (rc = c->cnt_s.ensure(2 * NR + 2)) ||
-                    (rc = c->tot.ensure(NR + n_sub + 2)) || (rc = c->read_mem_off.ensure(NR + n_sub + 2)) || (rc = c->mem_slots.ensure(2 * NR * MONI_MEM_SLOTS + 1)) ||
-                    (rc = c->mems.ensure(em)) || (rc = c->aux.ensure(em)) || (rc = c->lowers.ensure(em)) || (rc = c->tmp.ensure(em * 16 + 1)) || (rc = c->occ_cnt.ensure(em + 1)) ||
-                    (rc = c->occ_off.ensure(em + 1)) || (rc = c->occs.ensure(eo))) return rc;
-                for (int w = 0; w < 7; ++w) c->ms_accum[w] = 0;
-                for (int i = 0; i < 4; ++i) c->ctr_accum[i] = 0;
-                c->accum_valid = true; c->n_mems = c->n_occs = 0;
-            }
+            if ((rc = moni_seed_run(c, &sp))) return rc;
             st.t_seed += mh::now_s() - t0;
         }
         t_mark[0] = mh::now_s() - t_enter;
@@ -1065,7 +1022,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             return rc;
         // task slots: AF_MAX_TASKS_READ per read (each read's problems at its own place) + the global problems; bin queues: as many entries as problems are expected
         const uint32_t af_slot_cap = (uint32_t)std::min<uint64_t>((uint64_t)AF_MAX_TASKS_READ * sub_reads + 4 * sub_reads + 4096, 0xFFFFFFF0ull);
-        const uint32_t af_task_cap = (uint32_t)std::min<uint64_t>(12 * sub_reads + 4096, (1ull << 26) - 1), af_tb_cap = (uint32_t)std::min<uint64_t>(4 * sub_reads + 1024, 0x7FFFFFFFull);
+        const uint32_t af_task_cap = (uint32_t)std::min<uint64_t>(12 * sub_reads + 4096, (1ull << 26) - 1), af_tb_cap = (uint32_t)std::min<uint64_t>((4 + c->max_len / 50) * sub_reads + 1024, 0x7FFFFFFFull);      // traced problems: the final chain's extensions and gap fills (more anchors on longer reads)
         const uint32_t af_chunk_cap = af_task_cap / 64 + 2 * AF_NBIN;
         // direction bits: half a byte per DP cell.  ~10 KB per 150 bp read on the bench; DP cells grow with the square of the read length (250 bp:
         // ~90 KB with the global realignments); a chunk that does not fit sends its reads to align_kernel, and a batch in which that happened
@@ -1090,13 +1047,12 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         if (use_fast) for (int x = 0; x < (int)std::min<uint64_t>(n_sub, AK_NSET); ++x) {
             moni_ctx::AfSet& S = c->af[x];
             if ((rc = S.plans.ensure(sub_reads + 1)) || (rc = S.tasks.ensure(af_slot_cap)) || (rc = S.res.ensure(af_slot_cap)) || (rc = S.ntasks.ensure(sub_reads + 8)) || (rc = S.bin_q.ensure((size_t)AF_NBIN * af_task_cap)) ||
-                (rc = S.task_pos.ensure(af_slot_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.big_list.ensure(sub_reads + 1)) ||
+                (rc = S.task_pos.ensure(af_slot_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.big_list.ensure(2 * (sub_reads + 1))) ||
                 (rc = S.ctr.ensure(AF_NCTR)) || (rc = S.txt_cur.ensure(AF_TXT_SHARDS * 8)) || (rc = S.bnd.ensure((size_t)af_dp_grid * AF_QCAP * 64)) || (rc = S.chunks.ensure(af_chunk_cap)) || (rc = S.dirs.ensure(af_dirs_cap)) || (rc = S.fin.ensure((size_t)af_fin_grid * 64 * sizeof(af_fin_t))))
                 return rc;
         }
         // the launches alternate between the context's stream and one more: HIP multiplexes streams onto a handful of hardware queues
         // (4 by default), and two streams that land on the same queue run their kernels one after the other
-        // (the context's own stream carries the seeding, which in the pipelined form runs beside the align launches)
         for (int x = 0; x < AK_NSET; ++x) if (!c->ak_stream[x]) HIPCHK(hipStreamCreateWithFlags(&c->ak_stream[x], hipStreamNonBlocking));
         if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         while (c->ak_done.size() < n_sub) { hipEvent_t e0, e1, e2; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
@@ -1234,16 +1190,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 ++retired;
             }
         };
-        uint64_t mem_base = 0, occ_base = 0;
         for (uint64_t k = 0; k < n_sub; ++k) {
             const uint64_t r0 = sub_lo[k], nr = sub_lo[k + 1] - sub_lo[k];
-            SeedSlice SL; SL.r0 = r0; SL.nr = nr; SL.idx = k; SL.mem_base = mem_base; SL.occ_base = occ_base; SL.pipelined = true;
-            if (pipelined) {
-                const double s0 = mh::now_s();
-                if ((rc = seed_slice(c, &sp, SL))) { rc_host = rc; break; }
-                mem_base += SL.n_mems; occ_base += SL.n_occs;
-                st.t_seed += mh::now_s() - s0;
-            }
             uint64_t n_waves = ak_waves;
             if (!use_fast && n_waves * AK_NL > nr) n_waves = (nr + AK_NL - 1) / AK_NL;
             waves_used = std::max(waves_used, n_waves);
@@ -1260,7 +1208,6 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             A.D.end_bonus = prm->end_bonus; A.D.reads = c->seq.p; A.D.text = I->d_text; A.D.n_text = I->K.n_text;
             A.D.reads_limit = (c->total_len + 8) & ~7ull; A.D.text_limit = (I->K.n_text + 8) & ~7ull;       // both buffers carry 16 bytes of padding
             A.mems = c->mems.p; A.occs = c->occs.p; A.read_mem_off = c->read_mem_off.p; A.offs = c->offs.p;
-            if (pipelined) { A.mems = c->mems.p + SL.mem_at(); A.occs = c->occs.p + SL.occ_base; A.read_mem_off = c->read_mem_off.p + k; }      // the slice's arrays, indexed by the batch's read numbers
             A.min_score_of_len = c->ak_minscore.p; A.max_len = (uint32_t)c->max_len + 1; A.read_lo = r0; A.n_reads = nr;
             A.slots = c->ak_slots.p + (k % AK_NSET) * ak_waves * AK_NL; A.waves = c->ak_waves.p + (k % AK_NSET) * ak_waves;
             // records: pinned host memory when host threads read them behind every launch; with the lines ordered on the GPU they are read only
@@ -1287,7 +1234,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 G.A = A;
                 G.plans = S.plans.p; G.tasks = S.tasks.p; G.task_cap = af_slot_cap; G.ntasks = S.ntasks.p; G.res = S.res.p; G.bin_q = S.bin_q.p; G.bin_cap = af_task_cap; G.task_pos = S.task_pos.p;
                 G.chunks = S.chunks.p; G.chunk_cap = af_chunk_cap; G.dirs = S.dirs.p; G.dirs_cap = af_dirs_cap; G.tb_task = S.tb_task.p; G.tb = S.tb.p; G.tb_cap = af_tb_cap;
-                G.fb_n = c->fb_all.p + 16 * k; G.fb_list = c->fb_all.p + 16 * n_sub + k * (sub_reads + 1); G.big_list = S.big_list.p; G.fin_scratch = S.fin.p; G.fin_stride = sizeof(af_fin_t); G.ctr = S.ctr.p;
+                G.fb_n = c->fb_all.p + 16 * k; G.fb_list = c->fb_all.p + 16 * n_sub + k * (sub_reads + 1); G.big_list = S.big_list.p; G.huge_list = S.big_list.p + (sub_reads + 1); G.fin_scratch = S.fin.p; G.fin_stride = sizeof(af_fin_t); G.ctr = S.ctr.p;
                 G.bnd = S.bnd.p;
                 G.txt_cur = S.txt_cur.p; G.txt_shard_words = txt_per / (AF_TXT_SHARDS + 1);
                 HIPCHK(hipMemsetAsync(S.txt_cur.p, 0, AF_TXT_SHARDS * 8 * sizeof(unsigned long long), sx));
@@ -1305,13 +1252,14 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 {
                     static const int k1occ = getenv("MONI_AF_K1OCC") ? atoi(getenv("MONI_AF_K1OCC")) : 8;      // 8 waves/SIMD: 32 reads in flight per CU (4.9 KB of LDS each); measured 5, 6, 8
                     const dim3 g1((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 4 * k1occ));
-                    if (k1occ == 4) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 4>), g1, dim3(64), 0, sx, G);
-                    else if (k1occ == 5) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 5>), g1, dim3(64), 0, sx, G);
-                    else if (k1occ == 8) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 8>), g1, dim3(64), 0, sx, G);
-                    else hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, false, 6>), g1, dim3(64), 0, sx, G);
+                    if (k1occ == 4) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, 0, 4>), g1, dim3(64), 0, sx, G);
+                    else if (k1occ == 5) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, 0, 5>), g1, dim3(64), 0, sx, G);
+                    else if (k1occ == 8) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, 0, 8>), g1, dim3(64), 0, sx, G);
+                    else hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, 0, 6>), g1, dim3(64), 0, sx, G);
                 }
-                hipLaunchKernelGGL((chain_plan_kernel<af_wave_t, true>), dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 10)), dim3(64), 0, sx, G);
-                hipLaunchKernelGGL(bin_tasks_kernel, dim3((unsigned)((nr + 7) / 8)), dim3(256), 0, sx, G);
+                hipLaunchKernelGGL((chain_plan_kernel<af_wave_t, 1>), dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 10)), dim3(64), 0, sx, G);
+                hipLaunchKernelGGL((chain_plan_kernel<af_wave_huge_t, 2>), dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu)), dim3(64), 0, sx, G);      // ~90 KB of LDS per wave: one per CU
+                hipLaunchKernelGGL(bin_tasks_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, sx, G);
                 HIPCHK(hipEventRecord(c->af_ev[3 * k], sx));
                 hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_SMALL);
                 hipLaunchKernelGGL((dp_lane_kernel<AF_BLK, AF_QCAP, AF_LPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE);
@@ -1355,11 +1303,9 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             if (!done_recorded) HIPCHK(hipEventRecord(c->ak_done[k], sx));
             HIPCHK(hipGetLastError());
             launched = k + 1;
-            if (pipelined) retire(false);
         }
         t_launch[1] = mh::now_s() - t_enter;
         if (rc_host == MONI_OK) retire(true);
-        if (pipelined) { c->n_mems = mem_base; c->n_occs = occ_base; if (NR) { c->est_mems_per_read = (double)mem_base / (double)NR; c->est_occs_per_read = (double)occ_base / (double)NR; } }
         if (rc_host) { for (int x = 0; x < AK_NSET; ++x) { (void)hipStreamSynchronize(c->ak_stream[x]); if (c->fb_stream[x]) (void)hipStreamSynchronize(c->fb_stream[x]); } drop_abuf(); return rc_host; }
         t_mark[2] = mh::now_s() - t_enter;
         st.dp_rounds = n_sub;          // align_kernel launches

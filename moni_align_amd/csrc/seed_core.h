@@ -100,7 +100,7 @@ MONI_HD void settle_run(const moni_row_t* __restrict__ rows, uint64_t r, uint64_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Packed patterns: pat[w * n_tasks + task] holds the bytes the LF loop consumes in steps 8w .. 8w+7 of a task
+// Packed patterns: pat[ws_pat_base(task) + w * 64] holds the bytes the LF loop consumes in steps 8w .. 8w+7 of a task
 // (step s reads pattern[m-1-s]; the reverse-complement strand is complemented here: aligner_ksw2.hpp:169-176,
 // kpbseq.h:150-168).  One coalesced 8-byte load per lane every 8 steps replaces a byte load per step.
 // ------------------------------------------------------------------------------------------------
@@ -120,16 +120,26 @@ MONI_HD uint64_t bswap64_(uint64_t v) {
     return (v << 32) | (v >> 32);
 }
 
-MONI_HD void pack_task(const lds_tables_t& L, const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t n_tasks,
-                       uint64_t task, uint32_t n_words, uint64_t* __restrict__ pat) {
+// Workspace layout of the per-step arrays (packed patterns, MS pointers): tasks are taken 64 at a time (a wavefront's worth: 32 reads x 2
+// strands); block b holds its tasks' values step-major, `base + step * 64 + (task & 63)`, over as many steps as its LONGEST read has.
+// Lanes of a wave touch consecutive words at every step, and one long read costs 64 x its length in its own block only - not
+// n_tasks x its length as a layout strided by the batch's longest read does.  blk[b] = {first pointer word, first pattern word} of block b
+// (exclusive prefix sums, built by the host when the batch is uploaded); blk[n_blocks] = the totals.
+MONI_HD uint64_t ws_ptr_base(const moni_u64x2* __restrict__ blk, uint64_t task) { return blk[task >> 6].x + (task & 63u); }
+MONI_HD uint64_t ws_pat_base(const moni_u64x2* __restrict__ blk, uint64_t task) { return blk[task >> 6].y + (task & 63u); }
+
+MONI_HD void pack_task(const lds_tables_t& L, const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, const moni_u64x2* __restrict__ blk,
+                       uint64_t task, uint64_t* __restrict__ pat) {
     const uint64_t read = task >> 1;
     const uint32_t strand = (uint32_t)task & 1u;
     const uint64_t off = offs[read];
     const uint32_t m = (uint32_t)(offs[read + 1] - off);
+    const uint64_t pb = ws_pat_base(blk, task);
+    const uint32_t n_words = (m + 7u) >> 3;               // the words this task's loops read
     for (uint32_t w = 0; w < n_words; ++w) {
         uint64_t word = 0;
         const uint32_t s0 = 8 * w;
-        if (s0 < m) {
+        {
             const uint32_t nv = m - s0 < 8 ? m - s0 : 8;          // bytes of this word inside the pattern
             if (strand) {                                          // the read's bytes s0 .. s0 + 7, complemented
                 const uint64_t v = load8_unaligned(seq, off + s0);
@@ -140,16 +150,16 @@ MONI_HD void pack_task(const lds_tables_t& L, const uint8_t* __restrict__ seq, c
                 for (uint32_t j = 0; j < nv; ++j) word |= (uint64_t)seq[off + (m - 1 - s0 - j)] << (8 * j);
             }
         }
-        pat[(uint64_t)w * n_tasks + task] = word;
+        pat[pb + (uint64_t)w * 64u] = word;
     }
 }
 
 // byte qi of the strand-oriented pattern (= the byte consumed at step m-1-qi), through a one-word register cache
 struct pat_cache_t { uint64_t word; uint32_t w; };
-MONI_HD uint8_t pat_byte(const uint64_t* __restrict__ pat, uint64_t n_tasks, uint64_t task, uint32_t m, uint32_t qi, pat_cache_t& c) {
+MONI_HD uint8_t pat_byte(const uint64_t* __restrict__ pat, uint64_t pb, uint32_t m, uint32_t qi, pat_cache_t& c) {      // pb = ws_pat_base(blk, task)
     const uint32_t s = m - 1 - qi;
     const uint32_t w = s >> 3;
-    if (w != c.w) { c.word = pat[(uint64_t)w * n_tasks + task]; c.w = w; }
+    if (w != c.w) { c.word = pat[pb + (uint64_t)w * 64u]; c.w = w; }
     return (uint8_t)(c.word >> (8 * (s & 7)));
 }
 // byte a of the text through a one-word register cache (text is allocated 8-byte aligned and padded)
@@ -161,7 +171,7 @@ MONI_HD uint8_t text_byte(const uint8_t* __restrict__ text, uint64_t a, text_cac
 }
 
 // ------------------------------------------------------------------------------------------------
-// ms_task: pointers[s * n_tasks + task] = sample after step s, i.e. ms_pointers[m-1-s];  task = 2*read + strand
+// ms_task: pointers[ws_ptr_base(task) + s * 64] = sample after step s, i.e. ms_pointers[m-1-s];  task = 2*read + strand
 // ------------------------------------------------------------------------------------------------
 // State of one task's LF loop.  In the common case it is (run, off): the position is offset `off` inside run `run`
 // (MONI_OFF_END = last position of the run), and a step reads exactly one 64-byte fast row.  After a step that went
@@ -259,15 +269,17 @@ MONI_HD void ms_step(const moni_consts_t& K, const lds_tables_t& L, const moni_r
 template <int NCH>
 MONI_HD void ms_task(const moni_consts_t& K, const lds_tables_t& L, const moni_row_t* __restrict__ rows,
                      const moni_frow_t* __restrict__ frows, const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs,
-                     const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, uint64_t n_tasks, uint64_t task0,
+                     const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, const moni_u64x2* __restrict__ blk, uint64_t n_tasks, uint64_t task0,
                      uint64_t* __restrict__ ptr_out, unsigned long long& n_steps, unsigned long long& n_jumps) {
     ms_state_t S[NCH];
+    uint64_t pb[NCH], qb[NCH];
     uint32_t m_max = 0;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const uint64_t task = task0 + k;
         S[k].m = 0;
-        if (task < n_tasks) { const uint64_t read = task >> 1; S[k].m = (uint32_t)(offs[read + 1] - offs[read]); }
+        pb[k] = qb[k] = 0;
+        if (task < n_tasks) { const uint64_t read = task >> 1; S[k].m = (uint32_t)(offs[read + 1] - offs[read]); pb[k] = ws_pat_base(blk, task); qb[k] = ws_ptr_base(blk, task); }
         m_max = S[k].m > m_max ? S[k].m : m_max;
         S[k].run = (uint32_t)K.r - 1; S[k].pos = K.n - 1; S[k].abs = true; S[k].off = 0;     // start with the empty string
         S[k].sample = K.last_run_sample; S[k].word = 0;
@@ -278,7 +290,7 @@ MONI_HD void ms_task(const moni_consts_t& K, const lds_tables_t& L, const moni_r
         for (int k = 0; k < NCH; ++k) {
             if (s >= S[k].m) continue;
             // pattern[m-1-s], already strand-resolved by pack_task
-            if ((s & 7u) == 0) S[k].word = pat[(uint64_t)(s >> 3) * n_tasks + (task0 + k)];
+            if ((s & 7u) == 0) S[k].word = pat[pb[k] + (uint64_t)(s >> 3) * 64u];
             const uint32_t raw = (uint32_t)S[k].word & 0xFFu;
             S[k].word >>= 8;
             const uint32_t c = L.code[raw];
@@ -290,7 +302,7 @@ MONI_HD void ms_task(const moni_consts_t& K, const lds_tables_t& L, const moni_r
             } else {
                 ms_step(K, L, rows, frows, cr, recs, c, S[k], n_jumps);
             }
-            ptr_out[(uint64_t)s * n_tasks + (task0 + k)] = S[k].sample;
+            ptr_out[qb[k] + (uint64_t)s * 64u] = S[k].sample;
         }
     }
 }
@@ -306,7 +318,7 @@ MONI_HD void ms_task(const moni_consts_t& K, const lds_tables_t& L, const moni_r
 // ------------------------------------------------------------------------------------------------
 template <bool EMIT>
 MONI_HD void mem_task(const moni_consts_t& K, const lds_tables_t& L, const uint8_t* __restrict__ text,
-                      const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, uint64_t n_tasks, uint64_t task,
+                      const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, const moni_u64x2* __restrict__ blk, uint64_t task,
                       const uint64_t* __restrict__ ptr, uint32_t min_len, uint32_t split_on, uint32_t* __restrict__ cnt_m,
                       uint32_t* __restrict__ cnt_s, const uint64_t* __restrict__ read_mem_off, moni_mem_t* __restrict__ mems,
                       uint32_t* __restrict__ aux, moni_u64x2* __restrict__ slots, unsigned long long& n_cmp) {
@@ -365,11 +377,12 @@ MONI_HD void mem_task(const moni_consts_t& K, const lds_tables_t& L, const uint8
     }
     pat_cache_t pc; pc.w = 0xFFFFFFFFu; pc.word = 0;
     text_cache_t tc; tc.w = ~0ull; tc.word = 0;
+    const uint64_t pb = ws_pat_base(blk, task), qb = ws_ptr_base(blk, task);
     for (uint32_t i = 0; i < m; ++i) {
-        const uint64_t pos = ptr[(uint64_t)(m - 1 - i) * n_tasks + task];
+        const uint64_t pos = ptr[qb + (uint64_t)(m - 1 - i) * 64u];
         while (pos != prev_pos_plus_one && (i + l) < m && (pos + l) < n) {
             const uint32_t qi = (uint32_t)(i + l);
-            const uint8_t qc = pat_byte(pat, n_tasks, task, m, qi, pc);
+            const uint8_t qc = pat_byte(pat, pb, m, qi, pc);
             ++n_cmp;
             if (qc != text_byte(text, pos + l, tc)) break;
             if (qc == 'N') n_Ns++; else n_Ns = 0;

@@ -37,12 +37,12 @@ __device__ __forceinline__ void wave_add(unsigned long long v, unsigned long lon
 }
 
 extern "C" __global__ void __launch_bounds__(MS_BLOCK)
-pack_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t n_tasks,
-            uint32_t n_words, uint64_t* __restrict__ pat) {
+pack_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, const moni_u64x2* __restrict__ blk,
+            uint64_t n_tasks, uint64_t* __restrict__ pat) {
     __shared__ lds_tables_t L;
     load_tables(L, T, K);
     const uint64_t task = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
-    if (task < n_tasks) pack_task(L, seq, offs, n_tasks, task, n_words, pat);
+    if (task < n_tasks) pack_task(L, seq, offs, blk, task, pat);
 }
 
 // NCH independent tasks per lane (see ms_task); MINW = minimum waves per SIMD the register allocator must leave room for.
@@ -50,13 +50,13 @@ template <int NCH, int MINW>
 __global__ void __launch_bounds__(MS_BLOCK, MINW)
 ms_lf_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const moni_row_t* __restrict__ rows,
              const moni_frow_t* __restrict__ frows, const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs,
-             const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, uint64_t n_tasks,
+             const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, const moni_u64x2* __restrict__ blk, uint64_t n_tasks,
              uint64_t* __restrict__ ptr_out, unsigned long long* __restrict__ counters) {
     __shared__ lds_tables_t L;
     load_tables(L, T, K);
     const uint64_t task0 = ((uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x) * NCH;
     unsigned long long n_steps = 0, n_jumps = 0;
-    if (task0 < n_tasks) ms_task<NCH>(K, L, rows, frows, cr, recs, pat, offs, n_tasks, task0, ptr_out, n_steps, n_jumps);
+    if (task0 < n_tasks) ms_task<NCH>(K, L, rows, frows, cr, recs, pat, offs, blk, n_tasks, task0, ptr_out, n_steps, n_jumps);
     wave_add(n_steps, &counters[0]);
     wave_add(n_jumps, &counters[1]);
 }
@@ -64,7 +64,7 @@ ms_lf_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const m
 template <bool EMIT>
 __global__ void __launch_bounds__(MS_BLOCK)
 mem_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const uint8_t* __restrict__ text,
-           const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, uint64_t n_tasks,
+           const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, const moni_u64x2* __restrict__ blk, uint64_t n_tasks,
            const uint64_t* __restrict__ ptr, uint32_t min_len, uint32_t split_on,
            uint32_t* __restrict__ cnt_m, uint32_t* __restrict__ cnt_s,
            const uint64_t* __restrict__ read_mem_off, moni_mem_t* __restrict__ mems, uint32_t* __restrict__ aux,
@@ -74,7 +74,7 @@ mem_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const uin
     const uint64_t task = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
     unsigned long long n_cmp = 0;
     if (task < n_tasks)
-        mem_task<EMIT>(K, L, text, pat, offs, n_tasks, task, ptr, min_len, split_on, cnt_m, cnt_s, read_mem_off, mems, aux, slots, n_cmp);
+        mem_task<EMIT>(K, L, text, pat, offs, blk, task, ptr, min_len, split_on, cnt_m, cnt_s, read_mem_off, mems, aux, slots, n_cmp);
     if (!EMIT) wave_add(n_cmp, &counters[3]);
 }
 
@@ -117,12 +117,13 @@ extern "C" __global__ void occ_off_scatter_kernel(moni_mem_t* __restrict__ mems,
 // front ends run over ms.query's pointers): lane = read, lens[offs[read] - offs[0] + i] = l at read offset i.
 __global__ void __launch_bounds__(MS_BLOCK)
 ms_len_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const uint8_t* __restrict__ text, const uint64_t* __restrict__ pat,
-              const uint64_t* __restrict__ offs, uint64_t n_reads, const uint64_t* __restrict__ ptr, uint32_t* __restrict__ lens) {
+              const uint64_t* __restrict__ offs, const moni_u64x2* __restrict__ blk, uint64_t n_reads, const uint64_t* __restrict__ ptr, uint32_t* __restrict__ lens) {
     __shared__ lds_tables_t L;
     load_tables(L, T, K);
     const uint64_t read = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
     if (read >= n_reads) return;
-    const uint64_t n_tasks = 2 * n_reads, task = 2 * read;
+    const uint64_t task = 2 * read;
+    const uint64_t pb = ws_pat_base(blk, task), qb = ws_ptr_base(blk, task);
     const uint64_t off = offs[read];
     const uint32_t m = (uint32_t)(offs[read + 1] - off);
     const uint64_t n = K.n_text;
@@ -130,9 +131,9 @@ ms_len_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const 
     pat_cache_t pc; pc.w = 0xFFFFFFFFu; pc.word = 0;
     text_cache_t tc; tc.w = ~0ull; tc.word = 0;
     for (uint32_t i = 0; i < m; ++i) {
-        const uint64_t pos = ptr[(uint64_t)(m - 1 - i) * n_tasks + task];
+        const uint64_t pos = ptr[qb + (uint64_t)(m - 1 - i) * 64u];
         while (pos != prev_pos_plus_one && (i + l) < m && (pos + l) < n) {
-            if (pat_byte(pat, n_tasks, task, m, (uint32_t)(i + l), pc) != text_byte(text, pos + l, tc)) break;
+            if (pat_byte(pat, pb, m, (uint32_t)(i + l), pc) != text_byte(text, pos + l, tc)) break;
             ++l;
         }
         lens[off - offs[0] + i] = (uint32_t)l;

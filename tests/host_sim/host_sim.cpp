@@ -26,6 +26,7 @@ struct Sim {
     lds_tables_t L;
     // last result
     std::vector<uint64_t> ptr;
+    std::vector<moni_u64x2> blk;      // workspace layout of the last batch (seed_core.h)
     std::vector<moni_mem_t> mems;
     std::vector<uint64_t> occs, read_mem_off;
     std::vector<uint32_t> aux;      // per MEM slot: plain / has halves / is a half (seed_core.h)
@@ -69,22 +70,35 @@ int sim_seed_run(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_r
     uint64_t mx = 0;
     for (uint64_t i = 0; i < n_reads; ++i) mx = std::max<uint64_t>(mx, offs[i + 1] - offs[i]);
     S->max_len = mx; S->n_reads = n_reads;
-    S->ptr.assign(n_tasks * mx + 1, 0);
+    // the workspace layout of reads_upload (moni_hip.hip): per block of 32 reads as many steps as its longest read has
+    const uint64_t n_blk = (n_reads + 31) / 32;
+    S->blk.assign(n_blk + 1, moni_u64x2());
+    {
+        uint64_t pw = 0, qw = 0;
+        for (uint64_t k = 0; k < n_blk; ++k) {
+            uint64_t lb = 0;
+            for (uint64_t i = 32 * k; i < n_reads && i < 32 * k + 32; ++i) lb = std::max<uint64_t>(lb, offs[i + 1] - offs[i]);
+            S->blk[k].x = qw; S->blk[k].y = pw;
+            qw += 64 * lb; pw += 64 * ((lb + 7) / 8);
+        }
+        S->blk[n_blk].x = qw; S->blk[n_blk].y = pw;
+    }
+    const moni_u64x2* blk = S->blk.data();
+    S->ptr.assign(S->blk[n_blk].x + 1, 0);
     unsigned long long cnt[4] = {0, 0, 0, 0};
-    const uint32_t n_words = (uint32_t)((mx + 7) / 8);
-    std::vector<uint64_t> pat(n_tasks * n_words + 1);
+    std::vector<uint64_t> pat(S->blk[n_blk].y + 1);
     // pack_task reads aligned 8-byte words: the device buffer is aligned and padded by 16 bytes, so is this copy
     std::vector<uint64_t> seq_pad((offs[n_reads] + 16 + 7) / 8 + 1, 0);
     memcpy(seq_pad.data(), seq, offs[n_reads]);
     seq = reinterpret_cast<const uint8_t*>(seq_pad.data());
-    for (uint64_t t = 0; t < n_tasks; ++t) pack_task(S->L, seq, offs, n_tasks, t, n_words, pat.data());
+    for (uint64_t t = 0; t < n_tasks; ++t) pack_task(S->L, seq, offs, blk, t, pat.data());
     for (uint64_t t = 0; t < n_tasks; t += 2)
-        ms_task<2>(K, S->L, S->img.rows.data(), S->img.frows.data(), S->img.cr.data(), S->img.recs.data(), pat.data(), offs, n_tasks, t, S->ptr.data(), cnt[0], cnt[1]);
+        ms_task<2>(K, S->L, S->img.rows.data(), S->img.frows.data(), S->img.cr.data(), S->img.recs.data(), pat.data(), offs, blk, n_tasks, t, S->ptr.data(), cnt[0], cnt[1]);
     std::vector<uint32_t> cnt_m(n_tasks + 1), cnt_s(n_tasks + 1);
     std::vector<moni_u64x2> slots(n_tasks * MONI_MEM_SLOTS + 1);
     const uint32_t split_on = prm->report_mems ? 0 : 1;
     for (uint64_t t = 0; t < n_tasks; ++t)
-        mem_task<false>(K, S->L, S->text.data(), pat.data(), offs, n_tasks, t, S->ptr.data(), prm->min_len, split_on, cnt_m.data(), cnt_s.data(),
+        mem_task<false>(K, S->L, S->text.data(), pat.data(), offs, blk, t, S->ptr.data(), prm->min_len, split_on, cnt_m.data(), cnt_s.data(),
                         nullptr, nullptr, nullptr, slots.data(), cnt[3]);
     S->read_mem_off.assign(n_reads + 1, 0);
     for (uint64_t r = 0; r < n_reads; ++r)
@@ -94,7 +108,7 @@ int sim_seed_run(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_r
     std::vector<uint32_t> aux(n_mems + 1);
     unsigned long long dummy = 0;
     for (uint64_t t = 0; t < n_tasks; ++t)
-        mem_task<true>(K, S->L, S->text.data(), pat.data(), offs, n_tasks, t, S->ptr.data(), prm->min_len, split_on, cnt_m.data(), cnt_s.data(),
+        mem_task<true>(K, S->L, S->text.data(), pat.data(), offs, blk, t, S->ptr.data(), prm->min_len, split_on, cnt_m.data(), cnt_s.data(),
                        S->read_mem_off.data(), S->mems.data(), aux.data(), slots.data(), dummy);
     std::vector<uint64_t> tmp(n_mems * tmp_cap + 1), lowers(n_mems + 1);
     std::vector<uint32_t> pool((size_t)pool_rows * K.n_seq + 1);
@@ -134,11 +148,10 @@ void sim_fetch(void* s, moni_mem_t* mems, uint64_t* occs, uint64_t* read_mem_off
 // pointers in the layout of moni_ms_query_batch
 void sim_fetch_pointers(void* s, const uint64_t* offs, uint64_t* pointers) {
     Sim* S = (Sim*)s;
-    const uint64_t n_tasks = 2 * S->n_reads;
     for (uint64_t rd = 0; rd < S->n_reads; ++rd) {
         const uint64_t off = offs[rd] - offs[0], m = offs[rd + 1] - offs[rd];
         for (uint64_t st = 0; st < 2; ++st)
-            for (uint64_t k = 0; k < m; ++k) pointers[2 * off + st * m + k] = S->ptr[(m - 1 - k) * n_tasks + (2 * rd + st)];
+            for (uint64_t k = 0; k < m; ++k) pointers[2 * off + st * m + k] = S->ptr[ws_ptr_base(S->blk.data(), 2 * rd + st) + (m - 1 - k) * 64];
     }
 }
 void sim_phi(void* s, uint64_t i, int inverse, uint64_t* out2) {

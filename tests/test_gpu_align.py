@@ -156,6 +156,38 @@ def test_long_reads_go_through_the_hand_back_path(medium_case, env):
     assert st["handed_back"] >= 2
 
 
+def test_one_very_long_read_does_not_fail_the_batch(medium_case, env):
+    """a batch of 150 bp reads with one 7 kb read (host pipeline over the DP kernels: the oracle's record) and one 20 kb read (beyond the
+    largest DP the kernels take: reported unaligned with a notice, align_reads_dispatcher.hpp:300-407 never fails a batch on one read):
+    every other line is the oracle's, through both entry points"""
+    from oracle import orc
+    o, ctx = env
+    rng = np.random.default_rng(3)
+    reads = list(medium_case.synth.make_reads(medium_case.pg, 6000, 150, seed=77))
+    text = medium_case.fi.text
+    for at, p0, ln in ((4100, 2000, 20000), (123, 31000, 7000)):
+        r = np.array(text[p0:p0 + ln], dtype=np.uint8).copy()
+        k = rng.integers(0, ln, size=ln // 100)
+        r[k] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(k))]
+        reads.insert(at, r)
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64); offs[1:] = np.cumsum([len(r) for r in reads])
+    seq = np.concatenate(reads)
+    names, noff = orc.make_names(len(reads))
+    q = np.full(len(seq), ord("I"), dtype=np.uint8)
+    want, _ = orc.align_batch(o, seq, offs, names, noff, q, threads=8)
+    wl = want.split(b"\n")
+    for stream in (False, True):
+        got, st = ctx.align_batch(seq, offs, names, noff, q, host_threads=8, stream=stream)
+        gl = got.split(b"\n")
+        assert len(gl) == len(wl)
+        for i, (a, b) in enumerate(zip(gl, wl)):
+            if i == 4100:
+                f = a.split(b"\t")
+                assert f[1] == b"4" and f[2] == b"*" and len(f[9]) == 20000, a[:80]
+            else:
+                assert a == b, (i, a[:200], b[:200])
+
+
 def test_repeats_overflow_the_kernel_capacities(tmp_path):
     """A tandem-repeat region gives reads hundreds of seed occurrences: more anchors / chains than the align kernel's per-read
     capacities, so those reads take the host pipeline; the SAM text must not change."""

@@ -70,6 +70,32 @@ def test_seeds_ragged_edge_cases(medium_case, gpu_pair):
     assert np.array_equal(got["counters"], want["counters"])
 
 
+def test_one_long_read_among_short_ones(medium_case, gpu_pair):
+    """a 20 kb read in a batch of 150 bp reads: the per-step workspaces (packed patterns, MS pointers) are laid out per block of 32 reads
+    over the block's own longest read (seed_core.h), so the long read costs 64 x 20 k words in its own block instead of multiplying the
+    whole batch's stride; seeds and MS pointers still equal the oracle's"""
+    from tests.parity import assert_seeds_equal
+    rng = np.random.default_rng(11)
+    reads = list(medium_case.synth.make_reads(medium_case.pg, 5000, 150, seed=12))
+    text = np.frombuffer(bytes(medium_case.fi.text[3000:23000]), dtype=np.uint8).copy()
+    k = rng.integers(0, len(text), size=200)
+    text[k] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=len(k))]
+    reads.insert(1777, text)
+    reads.insert(40, text[:3000].copy())
+    seq, offs = ragged(reads)
+    got, want = run_both(gpu_pair, seq, offs)
+    assert_seeds_equal(got, want)
+    assert np.array_equal(got["counters"], want["counters"])
+    o, ctx = gpu_pair
+    part = reads[1760:1800]                                   # holds the 20 kb read: the host-buffer form de-interleaves the block layout
+    pseq, poffs = ragged(part)
+    ptr = ctx.ms_query_batch(pseq, poffs)
+    for i, r in enumerate(part):
+        a, m = 2 * int(poffs[i]), len(r)
+        assert np.array_equal(ptr[a:a + m], o.ms_query(r.tobytes())), i
+        assert np.array_equal(ptr[a + m:a + 2 * m], o.ms_query(medium_case.synth.revcomp(r[None, :])[0].tobytes())), i
+
+
 def test_seeds_filter(medium_case, gpu_pair):
     from tests.parity import assert_seeds_equal
     reads = medium_case.synth.make_reads(medium_case.pg, 2000, 150, seed=21, sub_rate=0.005)

@@ -116,7 +116,9 @@ typedef struct {
 
 /* ---- index ------------------------------------------------------------------------------- */
 /* Replaces seed_finder's loading of .thrbv.full.lcp.ms/.plain.slp/.ldx (seed_finder.hpp:64-124):
- * converts the semantic arrays to the device layout and uploads it to `device`. */
+ * converts the semantic arrays to the device layout and uploads it to `device`.  flat->text may be NULL: the text is redundant with
+ * the r-index and is then rebuilt on the device by inverting the BWT (LF walks from the 2 r sampled positions, each down to the next
+ * smaller sample), and checked against the BWT's symbol counts. */
 int moni_index_create(const moni_flat_index_t *flat, int device, moni_index_t **out);
 /* Same, from a MONIFLT2 file written by moni_align_amd/index_build.py. */
 int moni_index_load(const char *path, int device, moni_index_t **out);
@@ -124,6 +126,9 @@ void moni_index_destroy(moni_index_t *idx);
 uint64_t moni_index_n(const moni_index_t *idx);
 uint64_t moni_index_r(const moni_index_t *idx);
 uint64_t moni_index_device_bytes(const moni_index_t *idx);
+/* The text the index was built over (n - 1 bytes: what PlainSlp::expandSubstr(0, n - 1) returns, seed_finder.hpp:88-99), whether it was
+ * handed over or rebuilt from the BWT. */
+int moni_index_text(const moni_index_t *idx, uint8_t *out, uint64_t cap);
 
 /* ---- context / resident batch ------------------------------------------------------------ */
 int moni_ctx_create(moni_index_t *idx, moni_ctx_t **out);
@@ -269,8 +274,9 @@ int moni_ms_file_read(const char *path, uint64_t r, uint64_t *F, uint8_t *heads,
                       uint64_t *thr, uint64_t *slcp, char *err, uint64_t err_cap);
 /* moni_lcp::serialize of a flat index (only n, r, F, heads, starts, ssa, esa, thr, slcp are read). */
 int moni_ms_file_write(const moni_flat_index_t *idx, const char *path);
-/* What aligner's constructor loads (seed_finder.hpp:66-124): <prefix>.thrbv.full.lcp.ms + <prefix>.ldx + the text.  The text is taken
- * as plain bytes (n - 1 of them, what PlainSlp::expandSubstr would return; the .plain.slp grammar format is not read). */
+/* What aligner's constructor loads (seed_finder.hpp:66-124): <prefix>.thrbv.full.lcp.ms + <prefix>.ldx + the text.  text_path: plain
+ * bytes (n - 1 of them, what PlainSlp::expandSubstr would return), or NULL - the output of `moni build` as it is: the .plain.slp grammar
+ * (ShapedSlp, an absent submodule) is not read, the text is rebuilt from the BWT on the GPU instead (see moni_index_create). */
 int moni_index_load_reference(const char *ms_path, const char *ldx_path, const char *text_path, int device, moni_index_t **out);
 
 /* ---- measurement -------------------------------------------------------------------------- */

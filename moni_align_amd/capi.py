@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("MONI_HIP_LIB") or os.path.join(CSRC, "libmoni_hip.so"
 
 EXPORTS = [
     "moni_version", "moni_index_create", "moni_index_load", "moni_index_destroy", "moni_index_n", "moni_index_r",
-    "moni_index_device_bytes", "moni_ctx_create", "moni_ctx_destroy", "moni_reads_upload", "moni_reads_swap", "moni_ms_run",
+    "moni_index_device_bytes", "moni_index_text", "moni_ctx_create", "moni_ctx_destroy", "moni_reads_upload", "moni_reads_swap", "moni_ms_run",
     "moni_ms_query_batch", "moni_seed_run", "moni_seed_counts", "moni_seed_fetch", "moni_seed_batch", "moni_free",
     "moni_phi_lcp_batch", "moni_extz_batch", "moni_last_kernel_ms", "moni_last_counters",
     "moni_align_params_default", "moni_align_batch", "moni_align_run", "moni_align_stream", "moni_sam_header",
@@ -122,6 +122,7 @@ def lib():
         for name in ("moni_index_n", "moni_index_r", "moni_index_device_bytes", "moni_index_destroy",
                      "moni_ctx_destroy", "moni_free"):
             getattr(L, name).argtypes = [C.c_void_p]
+        L.moni_index_text.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.moni_index_create.argtypes = [C.POINTER(FlatIndexC), C.c_int, C.POINTER(C.c_void_p)]
         L.moni_index_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         L.moni_ctx_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -180,11 +181,12 @@ def _chk(rc: int, what: str):
         raise RuntimeError("%s failed with code %d" % (what, rc))
 
 
-def flat_struct(fi) -> FlatIndexC:
-    """fi: moni_align_amd.index_build.FlatIndex (arrays are kept alive by the caller)."""
+def flat_struct(fi, without_text: bool = False, without_lcp: bool = False) -> FlatIndexC:
+    """fi: moni_align_amd.index_build.FlatIndex (arrays are kept alive by the caller).  without_text: text = NULL (rebuilt from the BWT);
+    without_lcp: slcp = NULL (the `-n` form: <prefix>.thrbv.full.ms)."""
     s = FlatIndexC()
     s.n, s.r, s.w, s.n_seq = fi.n, fi.r, fi.w, len(fi.seq_starts) - 1
-    for k in ("F", "heads", "starts", "ssa", "esa", "thr", "slcp", "text", "seq_starts"):
+    for k in ("F", "heads", "starts", "ssa", "esa", "thr", "seq_starts") + (() if without_text else ("text",)) + (() if without_lcp else ("slcp",)):
         a = getattr(fi, k)
         assert a.flags["C_CONTIGUOUS"]
         setattr(s, k, a.ctypes.data)
@@ -199,22 +201,28 @@ def flat_struct(fi) -> FlatIndexC:
 
 
 class Index:
-    def __init__(self, fi=None, path: Optional[str] = None, device: int = 0, reference=None):
+    def __init__(self, fi=None, path: Optional[str] = None, device: int = 0, reference=None, without_text: bool = False, without_lcp: bool = False):
         """fi: a FlatIndex; path: an .mfi file; reference: (<prefix>.thrbv.full.lcp.ms, <prefix>.ldx, text file) of the reference."""
         self._L = lib()
         self._h = C.c_void_p()
         self._keep = fi
         if reference is not None:
             ms, ldx, text = reference
-            _chk(self._L.moni_index_load_reference(ms.encode(), ldx.encode(), text.encode(), device, C.byref(self._h)), "moni_index_load_reference")
+            _chk(self._L.moni_index_load_reference(ms.encode(), ldx.encode(), text.encode() if text else None, device, C.byref(self._h)), "moni_index_load_reference")
         elif fi is not None:
-            st = flat_struct(fi)
+            st = flat_struct(fi, without_text, without_lcp)
             _chk(self._L.moni_index_create(C.byref(st), device, C.byref(self._h)), "moni_index_create")
         else:
             _chk(self._L.moni_index_load(path.encode(), device, C.byref(self._h)), "moni_index_load")
         self.n = self._L.moni_index_n(self._h)
         self.r = self._L.moni_index_r(self._h)
         self.device_bytes = self._L.moni_index_device_bytes(self._h)
+
+    def text(self) -> np.ndarray:
+        """the text of the index (n - 1 bytes), as handed over or as rebuilt from the BWT"""
+        out = np.empty(self.n - 1, dtype=np.uint8)
+        _chk(self._L.moni_index_text(self._h, out.ctypes.data, out.size), "moni_index_text")
+        return out
 
     def close(self):
         if self._h:
@@ -480,8 +488,9 @@ def ms_file_read(path: str):
     return a
 
 
-def ms_file_write(fi, path: str):
-    st = flat_struct(fi)
+def ms_file_write(fi, path: str, without_lcp: bool = False):
+    """moni_lcp::serialize (<prefix>.thrbv.full.lcp.ms) or, without_lcp, ms_pointers::serialize (<prefix>.thrbv.full.ms)"""
+    st = flat_struct(fi, without_lcp=without_lcp)
     _chk(lib().moni_ms_file_write(C.byref(st), path.encode()), "moni_ms_file_write")
 
 

@@ -1480,6 +1480,12 @@ __device__ __forceinline__ int afs_md(const af_args_t& G, af_finw_t& L, const ui
     return NM;
 }
 
+// traced problem k / anchor j of the final chain: the first AF_FIN_TB / AF_FIN_AN are staged in LDS, the rest is read where it lies in HBM
+__device__ __forceinline__ const af_tb_t* afw_tb(const uint32_t* tbs, const af_tb_t* tb, uint32_t tb0, uint32_t k) {
+    return k < AF_FIN_TB ? reinterpret_cast<const af_tb_t*>(tbs + k * (AF_TB_CIG + 1)) : tb + tb0 + k;
+}
+__device__ __forceinline__ const af_anchor_t* afw_anchor(const af_anchor_t* staged, const af_anchor_t* all, uint32_t j) { return j < AF_FIN_AN ? staged + j : all + j; }
+
 #if defined(AF_CUTS)
 #define AFW_CUT(bit) if (G.dbg & (bit)) { if (lane == 0) { moni_aln_rec_t rc_; memset(&rc_, 0, sizeof rc_); A.recs[r_in] = rc_; if (A.dev_len) { A.dev_len[r_in] = 0; A.dev_off[r_in] = 0; } } continue; }
 #else
@@ -1498,8 +1504,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
         for (uint32_t k = lane; k < F.sname_off[n_seq]; k += 64) L.names[k] = F.snames[k];
     }
     uint32_t* const tbs = reinterpret_cast<uint32_t*>(L.line);       // staged traceback records: the line buffer is free until the line is rendered
-#define TB(k) ((k) < AF_FIN_TB ? *reinterpret_cast<const af_tb_t*>(tbs + (k) * AFW_TB_WORDS) : G.tb[h_tb0 + (k)])      // the first records are staged in LDS
-#define ANCH(j) ((j) < AF_FIN_AN ? L.an[j] : PL.an[h_an0 + (j)])
+#define TB(k) (*afw_tb(tbs, G.tb, h_tb0, (k)))          // (the argument is evaluated once: call sites pass tbx++)
+#define ANCH(j) (*afw_anchor(L.an, PL.an + h_an0, (j)))
 #define NAME_LEN(sid) (names_lds ? (uint32_t)(L.name_off[(sid) + 1] - L.name_off[sid]) : F.sname_off[(sid) + 1] - F.sname_off[sid])
     // the plan's 40-byte header (status, final chain, strand, traced problems, window) says where everything else is: it is read with
     // one round trip, the next read's while this one is worked on

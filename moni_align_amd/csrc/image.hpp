@@ -52,7 +52,7 @@ struct HostImage {
         if (n >= (1ull << 40) || r >= (1ull << 32) - 2 || r == 0) { err = "index too large for the 40/32-bit layout"; return MONI_ERANGE; }
         memset(&K, 0, sizeof(K));
         memset(&T, 0, sizeof(T));
-        K.n = n; K.r = r; K.n_text = n - 1; K.n_seq = (uint32_t)f.n_seq;
+        K.n = n; K.r = r; K.n_text = n - 1; K.n_seq = (uint32_t)f.n_seq; K.no_lcp = f.slcp ? 0u : 1u;
         {   // phi / phi_inv (two sorts of r keys) are independent of everything else: two threads build them beside the rows
             uint32_t sh = 0;
             while ((n >> sh) > 2 * r + 1024 && sh < 30) ++sh;   // about <= 2 keys per directory slot on average
@@ -230,8 +230,8 @@ struct HostImage {
         for (uint64_t i = 0; i < r; ++i) {
             const uint64_t run = s[i].second;
             uint64_t prev = MONI_POS_MASK, lcp = 0;   // undefined entries (Phi of SA[0] / Phi_inv of SA[n-1]) are guarded by the caller
-            if (!inverse) { if (run > 0) { prev = f.esa[run - 1]; lcp = f.slcp[run]; } }
-            else { if (run + 1 < r) { prev = f.ssa[run + 1]; lcp = f.slcp[run + 1]; } }
+            if (!inverse) { if (run > 0) { prev = f.esa[run - 1]; lcp = f.slcp ? f.slcp[run] : 0; } }
+            else { if (run + 1 < r) { prev = f.ssa[run + 1]; lcp = f.slcp ? f.slcp[run + 1] : 0; } }
             if ((lcp >> 40) || (s[i].first >> 40)) { err = "phi value exceeds 40 bits"; return MONI_ERANGE; }
             out[i].w0 = s[i].first | ((lcp & 0xFFFFFFull) << 40);
             out[i].w1 = prev | ((lcp >> 24) << 40);

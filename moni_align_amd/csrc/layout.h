@@ -71,7 +71,7 @@ struct moni_consts_t {
     uint32_t sigma;
     uint32_t phi_shift;
     uint32_t n_seq;
-    uint32_t pad;
+    uint32_t no_lcp;                              // the index carries no LCP samples (<prefix>.thrbv.full.ms, `-n`): phi steps measure the LCP on the text (seed_finder.hpp:346-370)
     uint32_t rec_base[MONI_MAX_SIGMA + 1];
     uint32_t rec_cnt[MONI_MAX_SIGMA];             // Rc per code
     uint8_t hot_slot[MONI_MAX_SIGMA];             // code -> slot in moni_row_t::hot_cr, 0xFF if none

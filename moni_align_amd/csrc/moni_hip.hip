@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <sched.h>
 #include <cstdio>
@@ -193,13 +194,78 @@ inline void rec(moni_ctx* c, int e) { (void)hipEventRecord(c->ev[e], c->stream);
 
 }  // namespace
 
+// ---- the text from the BWT -------------------------------------------------------------------------------------------------------------
+// The aligner's constructor takes the text from <prefix>.plain.slp (seed_finder.hpp:88-99), a ShapedSlp grammar whose format is not
+// available here; but the text is redundant with the r-index: BWT[p] = T[SA[p] - 1] and LF(p) is the position of SA[p] - 1, so a walk
+// that starts at a sampled position p (a run boundary: SA[p] is stored) spells the text backwards from SA[p] - 1.  The 2 r samples
+// (samples_start, samples_last), sorted, cut the text into 2 r pieces; one lane per piece walks LF with the general rows of the move
+// structure from its sample down to the next smaller one and writes the run heads it passes.  keys / vals: the samples in increasing
+// order and where they sit in the BWT (run << 1 | 1 for the last position of the run).
+__global__ void __launch_bounds__(256) text_rebuild_kernel(const moni_row_t* __restrict__ rows, uint64_t r, const uint8_t* __restrict__ heads, const uint64_t* __restrict__ keys,
+                                                           const uint64_t* __restrict__ vals, uint64_t n_samples, uint8_t* __restrict__ text, uint64_t n_text,
+                                                           unsigned long long* __restrict__ n_written) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long wrote = 0;
+    if (i < n_samples) {
+        const uint64_t s = keys[i], lo = i ? keys[i - 1] : 0;
+        if (s > lo && s <= n_text) {
+            const uint64_t v = vals[i];
+            uint32_t run = (uint32_t)(v >> 1);
+            moni_row_t A = ld_row(rows, run);
+            uint64_t pos = (v & 1) ? ld_start(rows, run + 1) - 1 : row_start(A);
+            for (uint64_t j = s; j > lo; --j) {                 // T[j - 1] = BWT[pos], then pos = LF(pos)
+                text[j - 1] = heads[run];
+                ++wrote;
+                if (j - 1 == lo) break;
+                pos = row_lfbase(A) + (pos - row_start(A));
+                run = row_dest(A);
+                settle_run(rows, r, pos, run, A);
+            }
+        }
+    }
+    wave_add(wrote, n_written);
+}
+
+// f.text == NULL: the text rebuilt on the device from the rows already uploaded (I->d_rows); checked against the BWT's own symbol counts
+static int rebuild_text(moni_index* I, const moni_flat_index_t& f, std::vector<uint8_t>& text) {
+    const uint64_t r = f.r, n_text = f.n - 1, ns = 2 * r;
+    uint64_t *d_k[2] = {nullptr, nullptr}, *d_v[2] = {nullptr, nullptr}; uint8_t *d_heads = nullptr, *d_text = nullptr; void* d_tmp = nullptr; unsigned long long* d_cnt = nullptr;
+    auto done = [&](int code) { void* ps[] = {d_k[0], d_k[1], d_v[0], d_v[1], d_heads, d_text, d_tmp, d_cnt}; for (void* p : ps) if (p) (void)hipFree(p); return code; };
+    try {
+        std::vector<uint64_t> hk(ns), hv(ns);
+        for (uint64_t k = 0; k < r; ++k) { hk[2 * k] = f.ssa[k]; hv[2 * k] = k << 1; hk[2 * k + 1] = f.esa[k]; hv[2 * k + 1] = (k << 1) | 1; }
+        for (int x = 0; x < 2; ++x) if (hipMalloc((void**)&d_k[x], ns * 8) != hipSuccess || hipMalloc((void**)&d_v[x], ns * 8) != hipSuccess) return done(MONI_ENOMEM);
+        if (hipMalloc((void**)&d_heads, r + 8) != hipSuccess || hipMalloc((void**)&d_text, n_text + 16) != hipSuccess || hipMalloc((void**)&d_cnt, 8) != hipSuccess) return done(MONI_ENOMEM);
+        if (hipMemcpy(d_k[0], hk.data(), ns * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_v[0], hv.data(), ns * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_heads, f.heads, r, hipMemcpyHostToDevice) != hipSuccess || hipMemset(d_cnt, 0, 8) != hipSuccess || hipMemset(d_text, 0, n_text + 16) != hipSuccess) return done(MONI_ENODEV);
+        size_t tmp_bytes = 0;
+        if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k[0], d_k[1], d_v[0], d_v[1], (size_t)ns, 0u, 40u, (hipStream_t)0) != hipSuccess) return done(MONI_ENODEV);
+        if (hipMalloc(&d_tmp, tmp_bytes + 16) != hipSuccess) return done(MONI_ENOMEM);
+        if (rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_k[0], d_k[1], d_v[0], d_v[1], (size_t)ns, 0u, 40u, (hipStream_t)0) != hipSuccess) return done(MONI_ENODEV);
+        hipLaunchKernelGGL(text_rebuild_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, 0, I->d_rows, r, d_heads, d_k[1], d_v[1], ns, d_text, n_text, d_cnt);
+        unsigned long long wrote = 0;
+        text.resize(n_text);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&wrote, d_cnt, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(text.data(), d_text, n_text, hipMemcpyDeviceToHost) != hipSuccess) return done(MONI_ENODEV);
+        if (wrote != n_text) { fprintf(stderr, "moni_hip: the BWT walk wrote %llu of %llu text positions: samples and runs disagree\n", wrote, (unsigned long long)n_text); return done(MONI_ERANGE); }
+        // every symbol as often as the BWT holds it (the terminator is stored as byte 1 in the run heads and is not part of the text)
+        uint64_t cnt[256] = {0}, bw[256] = {0};
+        for (uint64_t i = 0; i < n_text; ++i) cnt[text[i]]++;
+        for (uint64_t k = 0; k < r; ++k) bw[f.heads[k]] += f.starts[k + 1] - f.starts[k];
+        cnt[1]++;
+        for (int b = 0; b < 256; ++b) if (cnt[b] != bw[b]) { fprintf(stderr, "moni_hip: the rebuilt text holds byte %d %llu times, the BWT %llu times\n", b, (unsigned long long)cnt[b], (unsigned long long)bw[b]); return done(MONI_ERANGE); }
+        return done(MONI_OK);
+    } catch (const std::bad_alloc&) { return done(MONI_ENOMEM); }
+}
+
 extern "C" {
 
 const char* moni_version(void) { return "moni_hip 0.1 (gfx950)"; }
 
 int moni_index_create(const moni_flat_index_t* f, int device, moni_index_t** out) {
-    if (!f || !out || !f->F || !f->heads || !f->starts || !f->ssa || !f->esa || !f->thr || !f->slcp || !f->text || !f->seq_starts)
-        return MONI_EINVAL;
+    if (!f || !out || !f->F || !f->heads || !f->starts || !f->ssa || !f->esa || !f->thr || !f->seq_starts)
+        return MONI_EINVAL;              // f->text may be NULL: the text is then rebuilt from the BWT on the device (rebuild_text);
+                                         // f->slcp may be NULL: no LCP samples (`-n`), the occurrence walks measure the LCP on the text
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) {
         fprintf(stderr, "moni_hip: no HIP device %d (found %d); this library has no CPU path\n", device, ndev);
@@ -217,7 +283,12 @@ int moni_index_create(const moni_flat_index_t* f, int device, moni_index_t** out
     I->K = img.K;
     I->lifts_null = lt.all_null;
     std::vector<moni_tables_t> tv(1, img.T);
-    std::vector<uint8_t> text(f->text, f->text + (f->n - 1));
+    std::vector<uint8_t> text;
+    if (f->text) text.assign(f->text, f->text + (f->n - 1));
+    else {
+        if ((rc = upload(&I->d_rows, img.rows, I->bytes)) || (rc = rebuild_text(I, *f, text))) { moni_index_destroy(I); return rc; }
+    }
+    I->h_text = text;
     text.resize(text.size() + 16, 0);            // text_byte() reads aligned 8-byte words
     std::vector<uint32_t> name_id(f->n_seq);
     {   // names; sequences that share a name share a counter in the per-genome filter (std::map<std::string,...>, seed_finder.hpp:331-343)
@@ -233,11 +304,10 @@ int moni_index_create(const moni_flat_index_t* f, int device, moni_index_t** out
     std::vector<uint8_t> sname_blob; std::vector<uint32_t> sname_off(1, 0);
     for (const auto& nm : I->hix.names) { sname_blob.insert(sname_blob.end(), nm.begin(), nm.end()); sname_off.push_back((uint32_t)sname_blob.size()); }
     sname_blob.resize(sname_blob.size() + 8, 0);
-    I->h_text.assign(f->text, f->text + (f->n - 1));
     I->hix.n_text = f->n - 1; I->hix.w = f->w; I->hix.text = I->h_text.data();
     I->hix.seq_starts.assign(f->seq_starts, f->seq_starts + f->n_seq + 1);
     I->hix.lift_seqs = lt.seqs; I->hix.lift_runs = lt.runs;
-    if ((rc = upload(&I->d_pdir, lt.pdir, I->bytes)) || (rc = upload(&I->d_lift_seqs, lt.seqs, I->bytes)) || (rc = upload(&I->d_lift_runs, lt.runs, I->bytes)) || (rc = upload(&I->d_tables, tv, I->bytes)) || (rc = upload(&I->d_rows, img.rows, I->bytes)) || (rc = upload(&I->d_frows, img.frows, I->bytes)) ||
+    if ((rc = upload(&I->d_pdir, lt.pdir, I->bytes)) || (rc = upload(&I->d_lift_seqs, lt.seqs, I->bytes)) || (rc = upload(&I->d_lift_runs, lt.runs, I->bytes)) || (rc = upload(&I->d_tables, tv, I->bytes)) || (!I->d_rows && (rc = upload(&I->d_rows, img.rows, I->bytes))) || (rc = upload(&I->d_frows, img.frows, I->bytes)) ||
         (rc = upload(&I->d_cr, img.cr, I->bytes)) || (rc = upload(&I->d_recs, img.recs, I->bytes)) ||
         (rc = upload(&I->d_phi, img.phi, I->bytes)) || (rc = upload(&I->d_phi_inv, img.phi_inv, I->bytes)) ||
         (rc = upload(&I->d_phi_dir, img.phi_dir, I->bytes)) || (rc = upload(&I->d_phi_inv_dir, img.phi_inv_dir, I->bytes)) ||
@@ -332,6 +402,11 @@ void moni_index_destroy(moni_index_t* I) {
 uint64_t moni_index_n(const moni_index_t* I) { return I ? I->K.n : 0; }
 uint64_t moni_index_r(const moni_index_t* I) { return I ? I->K.r : 0; }
 uint64_t moni_index_device_bytes(const moni_index_t* I) { return I ? I->bytes : 0; }
+int moni_index_text(const moni_index_t* I, uint8_t* out, uint64_t cap) {
+    if (!I || !out || cap < I->h_text.size()) return MONI_EINVAL;
+    memcpy(out, I->h_text.data(), I->h_text.size());
+    return MONI_OK;
+}
 
 int moni_ctx_create(moni_index_t* I, moni_ctx_t** out) {
     if (!I || !out) return MONI_EINVAL;
@@ -577,6 +652,7 @@ static int seed_all(moni_ctx* c, const moni_seed_params_t* prm) {
     rec(c, EV_ME1);
     occ_args_t A;
     A.phi.recs = I->d_phi; A.phi.dir = I->d_phi_dir; A.phi_inv.recs = I->d_phi_inv; A.phi_inv.dir = I->d_phi_inv_dir;
+    A.text = I->d_text;
     A.seq_starts = I->d_seq_starts; A.name_id = I->d_name_id; A.mems = mems; A.aux = aux; A.read_mem_off = rmo;
     A.n_mems = n_mems; A.occs = nullptr; A.tmp = c->tmp.p; A.lowers = c->lowers.p; A.tmp_cap = c->tmp_cap;
     A.filter_seeds = prm->filter_seeds; A.n_seeds_thr = prm->n_seeds_thr; A.pool_rows = c->pool_rows; A.pool = c->pool.p;
@@ -1258,7 +1334,9 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                     else hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, 0, 6>), g1, dim3(64), 0, sx, G);
                 }
                 hipLaunchKernelGGL((chain_plan_kernel<af_wave_t, 1>), dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 10)), dim3(64), 0, sx, G);
-                hipLaunchKernelGGL((chain_plan_kernel<af_wave_huge_t, 2>), dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu)), dim3(64), 0, sx, G);      // ~90 KB of LDS per wave: one per CU
+                static const bool no_huge = getenv("MONI_AF_NOHUGE") != nullptr;          // (debugging aid: reads beyond the large instance then go straight to align_kernel)
+                if (!no_huge) hipLaunchKernelGGL((chain_plan_kernel<af_wave_huge_t, 2>), dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu)), dim3(64), 0, sx, G);      // ~90 KB of LDS per wave: one per CU
+                HIPCHK(hipGetLastError());
                 hipLaunchKernelGGL(bin_tasks_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, sx, G);
                 HIPCHK(hipEventRecord(c->af_ev[3 * k], sx));
                 hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_SMALL);
@@ -1497,12 +1575,14 @@ __global__ void lift_batch_kernel(const ac_params_t P, const uint64_t* __restric
 // ---- <prefix>.thrbv.full.lcp.ms (ms_index_io.hpp) --------------------------------------------------------------------------------------
 int moni_ms_file_info(const char* path, uint64_t* n, uint64_t* r) {
     if (!path) return MONI_EINVAL;
-    uint64_t a = 0, b = 0;
-    int rc = msio::info_ms(path, a, b);
-    if (rc) return rc;
-    if (n) *n = a;
-    if (r) *r = b;
-    return MONI_OK;
+    try {          // (file-facing entry points: an allocation failure must not cross the C ABI as an exception)
+        uint64_t a = 0, b = 0;
+        int rc = msio::info_ms(path, a, b);
+        if (rc) return rc;
+        if (n) *n = a;
+        if (r) *r = b;
+        return MONI_OK;
+    } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
 }
 
 int moni_ms_file_read(const char* path, uint64_t r, uint64_t* F, uint8_t* heads, uint64_t* starts, uint64_t* ssa, uint64_t* esa, uint64_t* thr, uint64_t* slcp,
@@ -1520,12 +1600,12 @@ int moni_ms_file_read(const char* path, uint64_t r, uint64_t* F, uint8_t* heads,
 }
 
 int moni_ms_file_write(const moni_flat_index_t* f, const char* path) {
-    if (!f || !path || !f->F || !f->heads || !f->starts || !f->ssa || !f->esa || !f->thr || !f->slcp || f->r < 1 || f->n < 2) return MONI_EINVAL;
+    if (!f || !path || !f->F || !f->heads || !f->starts || !f->ssa || !f->esa || !f->thr || f->r < 1 || f->n < 2) return MONI_EINVAL;      // slcp NULL: the .thrbv.full.ms form
     try { return msio::save_ms(path, *f, f->r); } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
 }
 
 int moni_index_load_reference(const char* ms_path, const char* ldx_path, const char* text_path, int device, moni_index_t** out) {
-    if (!ms_path || !ldx_path || !text_path || !out) return MONI_EINVAL;
+    if (!ms_path || !ldx_path || !out) return MONI_EINVAL;
     try {
         msio::MsFile M; std::string e;
         int rc = msio::load_ms(ms_path, M, e);
@@ -1533,16 +1613,19 @@ int moni_index_load_reference(const char* ms_path, const char* ldx_path, const c
         refio::Ldx L;
         if ((rc = refio::load_ldx(ldx_path, L))) { fprintf(stderr, "moni_hip: %s: not a liftidx file\n", ldx_path); return rc; }
         std::vector<uint8_t> text;
-        if (!refio::read_file(text_path, text)) return MONI_EIO;
-        if (text.size() != M.n - 1) { fprintf(stderr, "moni_hip: %s holds %zu bytes, the BWT %llu\n", text_path, text.size(), (unsigned long long)M.n); return MONI_EINVAL; }
+        if (text_path) {
+            if (!refio::read_file(text_path, text)) return MONI_EIO;
+            if (text.size() != M.n - 1) { fprintf(stderr, "moni_hip: %s holds %zu bytes, the BWT %llu\n", text_path, text.size(), (unsigned long long)M.n); return MONI_EINVAL; }
+        }
+        const uint64_t n_text = M.n - 1;
         refio::LdxFlat lf; lf.from(L);
         const uint64_t w = L.has_w ? L.w : 10;
-        if (lf.seq_starts.empty() || (lf.seq_starts.back() != text.size() && lf.seq_starts.back() + (w ? w - 1 : 0) != text.size())) {
+        if (lf.seq_starts.empty() || (lf.seq_starts.back() != n_text && lf.seq_starts.back() + (w ? w - 1 : 0) != n_text)) {
             fprintf(stderr, "moni_hip: %s does not describe this text\n", ldx_path); return MONI_EINVAL;
         }
         moni_flat_index_t f; memset(&f, 0, sizeof f);
         f.n = M.n; f.r = M.r; f.F = M.F.data(); f.heads = M.heads.data(); f.starts = M.starts.data(); f.ssa = M.ssa.data(); f.esa = M.esa.data();
-        f.thr = M.thr.data(); f.slcp = M.slcp.data(); f.text = text.data();
+        f.thr = M.thr.data(); f.slcp = M.has_lcp ? M.slcp.data() : nullptr; f.text = text_path ? text.data() : nullptr;      // NULL: rebuilt from the BWT (moni_index_create)
         lf.fill(f, w);
         return moni_index_create(&f, device, out);
     } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
@@ -1550,11 +1633,13 @@ int moni_index_load_reference(const char* ms_path, const char* ldx_path, const c
 
 int moni_ldx_rewrite(const char* in_path, const char* out_path, int with_w) {
     if (!in_path || !out_path) return MONI_EINVAL;
-    refio::Ldx L;
-    int rc = refio::load_ldx(in_path, L);
-    if (rc) return rc;
-    if (with_w && !L.has_w) L.w = 10;          // the older layout has no field for it: the separator width of every build of the reference
-    return refio::save_ldx(out_path, L, with_w != 0);
+    try {
+        refio::Ldx L;
+        int rc = refio::load_ldx(in_path, L);
+        if (rc) return rc;
+        if (with_w && !L.has_w) L.w = 10;          // the older layout has no field for it: the separator width of every build of the reference
+        return refio::save_ldx(out_path, L, with_w != 0);
+    } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
 }
 
 int moni_ldx_write(const moni_flat_index_t* f, const char* path, int with_w) {
@@ -1584,14 +1669,16 @@ int moni_ldx_write(const moni_flat_index_t* f, const char* path, int with_w) {
 
 int moni_ldx_info(const char* path, uint64_t* n_seq, uint64_t* u, uint64_t* w, int* has_w) {
     if (!path) return MONI_EINVAL;
-    refio::Ldx L;
-    int rc = refio::load_ldx(path, L);
-    if (rc) return rc;
-    if (n_seq) *n_seq = L.names.size();
-    if (u) *u = L.u;
-    if (w) *w = L.w;
-    if (has_w) *has_w = L.has_w ? 1 : 0;
-    return MONI_OK;
+    try {
+        refio::Ldx L;
+        int rc = refio::load_ldx(path, L);
+        if (rc) return rc;
+        if (n_seq) *n_seq = L.names.size();
+        if (u) *u = L.u;
+        if (w) *w = L.w;
+        if (has_w) *has_w = L.has_w ? 1 : 0;
+        return MONI_OK;
+    } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
 }
 
 int moni_ldx_lift_batch(const char* path, int device, const uint64_t* pos, uint64_t n, uint64_t* out) {
@@ -1599,6 +1686,7 @@ int moni_ldx_lift_batch(const char* path, int device, const uint64_t* pos, uint6
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) return MONI_ENODEV;
     HIPCHK(hipSetDevice(device));
+    try {
     refio::Ldx L;
     int rc = refio::load_ldx(path, L);
     if (rc) return rc;
@@ -1620,6 +1708,7 @@ int moni_ldx_lift_batch(const char* path, int device, const uint64_t* pos, uint6
     hipLaunchKernelGGL(lift_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, P, (const uint64_t*)d_io, n, d_io + n);
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d_io + n, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return done(MONI_ENODEV);
     return done(MONI_OK);
+    } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
 }
 
 int moni_sam_header(const moni_index_t* I, char** sam, uint64_t* sam_len) {

@@ -37,6 +37,7 @@ struct MsFile {
     std::vector<uint8_t> heads;                   // r
     std::vector<uint64_t> starts;                 // r + 1
     std::vector<uint64_t> ssa, esa, thr, slcp;    // r each (thr: 0 = none; slcp: as many entries as the file holds, r or r + 1)
+    bool has_lcp = true;                          // false: <prefix>.thrbv.full.ms (ms_pointers::serialize, moni.hpp:392-409: no samples of the LCP)
 };
 
 struct Variant { bool sparse_has_n; int node_bytes; };
@@ -80,6 +81,8 @@ static inline bool load_wt(Reader& r, const Variant& V, std::vector<uint8_t>& se
         r.o = at + V.node_bytes;
     }
     r.o += 256 * 2 + 256 * 8;          // c_to_leaf, path: derivable from the nodes
+    if (size > bv.size && !(size > 0 && nn == 1)) return false;      // every element spends at least one bit of the tree (one-symbol sequence: none) - and at most the file's size in elements
+    if (size > 8ull * (uint64_t)r.n) return false;
     seq.assign(size, 0);
     if (size == 0) return true;
     if (nn == 0) return false;
@@ -194,8 +197,9 @@ static inline void save_wt(Writer& o, const std::vector<uint8_t>& seq) {
 }
 
 // ---- the whole file ---------------------------------------------------------------------------------------------------------------------
-static inline bool parse_ms(Reader& rd, const Variant& V, MsFile& M, std::string& err) {
+static inline bool parse_ms(Reader& rd, const Variant& V, MsFile& M, std::string& err, bool with_lcp = true) {
     M = MsFile();
+    M.has_lcp = with_lcp;
     M.terminator_position = rd.u64();
     if (rd.u64() != 256 || !rd.need(256 * 8)) { err = "F is not a vector of 256 words"; return false; }
     M.F.resize(256); memcpy(M.F.data(), rd.b + rd.o, 256 * 8); rd.o += 256 * 8;
@@ -209,7 +213,7 @@ static inline bool parse_ms(Reader& rd, const Variant& V, MsFile& M, std::string
     if (!load_sparse(rd, V, pred) || !pred_to_run.load(rd) || !s_last.load(rd)) { err = "pred / pred_to_run / samples_last"; return false; }
     std::vector<SdVector> thr(256);
     for (int c = 0; c < 256; ++c) if (!load_sparse(rd, V, thr[c])) { err = "thresholds_per_letter"; return false; }
-    if (!load_sparse(rd, V, pred_start) || !pred_start_to_run.load(rd) || !s_start.load(rd) || !slcp.load(rd)) { err = "pred_start / samples_start / slcp"; return false; }
+    if (!load_sparse(rd, V, pred_start) || !pred_start_to_run.load(rd) || !s_start.load(rd) || (with_lcp && !slcp.load(rd))) { err = "pred_start / samples_start / slcp"; return false; }
     if (!rd.ok || rd.o != rd.n) { err = "bytes left over"; return false; }
     // ---- redundancy checks and the flat form ----
     const uint64_t r = M.r, n = M.n;
@@ -233,10 +237,10 @@ static inline bool parse_ms(Reader& rd, const Variant& V, MsFile& M, std::string
         uint64_t acc = 0;
         for (int c = 0; c < 256; ++c) { if (M.F[c] != acc) { err = "F disagrees with the BWT"; return false; } acc += cnt[c]; }
     }
-    if (s_start.size != r || s_last.size != r || pred_to_run.size != r || pred_start_to_run.size != r || (slcp.size != r && slcp.size != r + 1)) { err = "sample vectors do not hold one entry per run"; return false; }
-    M.ssa.resize(r); M.esa.resize(r); M.slcp.resize(slcp.size);
+    if (s_start.size != r || s_last.size != r || pred_to_run.size != r || pred_start_to_run.size != r || (with_lcp && slcp.size != r && slcp.size != r + 1)) { err = "sample vectors do not hold one entry per run"; return false; }
+    M.ssa.resize(r); M.esa.resize(r); M.slcp.resize(with_lcp ? slcp.size : r, 0);
     for (uint64_t k = 0; k < r; ++k) { M.ssa[k] = s_start.get(k); M.esa[k] = s_last.get(k); }
-    for (uint64_t k = 0; k < slcp.size; ++k) M.slcp[k] = slcp.get(k);
+    for (uint64_t k = 0; with_lcp && k < slcp.size; ++k) M.slcp[k] = slcp.get(k);
     auto check_pred = [&](const SdVector& pv, const IntVector& to_run, const std::vector<uint64_t>& samples) {
         if (pv.ones.size() != r || pv.size != n) return false;
         for (uint64_t k = 0; k < r; ++k) { const uint64_t run = to_run.get(k); if (run >= r || samples[run] != pv.ones[k]) return false; }
@@ -267,12 +271,13 @@ static inline int load_ms(const char* path, MsFile& M, std::string& err) {
     if (!refio::read_file(path, buf) || buf.size() < 8 * 260) { err = "cannot read the file"; return MONI_EIO; }
     const Variant variants[4] = {{true, 22}, {false, 22}, {true, 24}, {false, 24}};
     std::string first;
-    for (const Variant& V : variants) {
-        Reader rd(buf.data(), buf.size());
-        std::string e;
-        if (parse_ms(rd, V, M, e)) { err.clear(); return MONI_OK; }
-        if (first.empty()) first = e;
-    }
+    for (int with_lcp = 1; with_lcp >= 0; --with_lcp)          // moni_lcp::serialize, then ms_pointers::serialize (the same file without the LCP samples)
+        for (const Variant& V : variants) {
+            Reader rd(buf.data(), buf.size());
+            std::string e;
+            if (parse_ms(rd, V, M, e, with_lcp != 0)) { err.clear(); return MONI_OK; }
+            if (first.empty()) first = e;
+        }
     err = first;
     return MONI_EIO;
 }
@@ -331,7 +336,7 @@ static inline int save_ms(const char* path, const moni_flat_index_t& f, uint64_t
     }
     save_pred(f.esa);
     save_int_vector(o, std::vector<uint64_t>(f.ssa, f.ssa + r), log_n);
-    {
+    if (f.slcp) {          // (absent: the .thrbv.full.ms form)
         std::vector<uint64_t> s(f.slcp, f.slcp + r);
         while (s.size() < slcp_len) s.push_back(0);
         uint64_t mx = 0; for (uint64_t v : s) mx = std::max(mx, v);

@@ -17,7 +17,14 @@ struct Reader {
     uint64_t u64() { uint64_t v = 0; if (need(8)) { memcpy(&v, b + o, 8); o += 8; } return v; }
     uint16_t u16() { uint16_t v = 0; if (need(2)) { memcpy(&v, b + o, 2); o += 2; } return v; }
     uint8_t u8() { uint8_t v = 0; if (need(1)) { v = b[o]; o += 1; } return v; }
-    const uint64_t* words(uint64_t bit_len) { const size_t k = (size_t)((bit_len + 63) / 64); if (!need(8 * k)) return nullptr; const uint64_t* p = (const uint64_t*)(b + o); o += 8 * k; return p; }
+    // the sizes in a file are not trusted: a bit length beyond what is left of the file fails before any word count is formed from it
+    // ((bit_len + 63) / 64 wraps for lengths near 2^64)
+    const uint64_t* words(uint64_t bit_len) {
+        if (o > n || bit_len > 8ull * (uint64_t)(n - o)) { ok = false; return nullptr; }
+        const size_t k = (size_t)((bit_len + 63) / 64);
+        if (!need(8 * k)) return nullptr;
+        const uint64_t* p = (const uint64_t*)(b + o); o += 8 * k; return p;
+    }
 };
 struct Writer {
     std::vector<uint8_t> out;
@@ -48,6 +55,7 @@ struct IntVector {
     }
     bool load(Reader& r) {
         const uint64_t bits = r.u64(); width = r.u8();
+        if (width > 64) { r.ok = false; return false; }          // (a shift by more than 63 bits is undefined)
         const uint64_t* p = r.words(bits);
         if (!r.ok) return false;
         size = width ? bits / width : 0;
@@ -118,7 +126,8 @@ struct SdVector {
     bool load(Reader& r) {
         size = r.u64(); const uint8_t wl = r.u8();
         IntVector low; BitVector high;
-        if (!low.load(r) || !high.load(r) || !skip_select(r) || !skip_select(r)) return false;
+        if (wl > 63 || !low.load(r) || !high.load(r) || !skip_select(r) || !skip_select(r)) return false;
+        if (wl && low.width != wl) return false;
         ones.clear();
         uint64_t zeros = 0, k = 0;
         for (uint64_t i = 0; i < high.size; ++i) {

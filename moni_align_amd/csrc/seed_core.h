@@ -424,8 +424,26 @@ MONI_HD void phi_step(const phi_tab_t P, const moni_consts_t& K, uint64_t i, uin
     out_lcp = lcp - delta + 1;                          // unsigned, as in the reference
 }
 
+// lceToRBounded(ra, a, b, len) of the `-n` form (ShapedSlp, an absent submodule; call sites seed_finder.hpp:354,367): the number of bytes the
+// text suffixes at a and b share, counted up to len.  The text is 8-byte aligned and padded: eight bytes per compare.
+MONI_HD uint64_t lce_bounded(const uint8_t* __restrict__ text, uint64_t a, uint64_t b, uint64_t len) {
+    uint64_t l = 0;
+    while (l < len) {
+        const uint64_t x = load8_unaligned(text, a + l) ^ load8_unaligned(text, b + l);
+        if (x) {
+            uint64_t same = 0;
+            while (!((x >> (8 * same)) & 0xFFu)) ++same;
+            l += same;
+            break;
+        }
+        l += 8;
+    }
+    return l < len ? l : len;
+}
+
 struct occ_args_t {
     phi_tab_t phi, phi_inv;
+    const uint8_t* text;            // K.no_lcp: the LCP of a phi step is measured here
     const uint64_t* seq_starts;     // n_seq + 1
     const uint32_t* name_id;        // n_seq
     moni_mem_t* mems;
@@ -491,6 +509,10 @@ MONI_HD void walk_dir(walk_t& W, const occ_args_t& A, const moni_consts_t& K, ui
             phi_step(A.phi_inv, K, curr, nxt, lcp);
         }
         W.phi_steps++;
+        if (K.no_lcp) {                                         // seed_finder.hpp:346-370: no sampled LCP, a bounded LCE on the text when both suffixes are long enough
+            lcp = 0;
+            if (K.n_text - curr >= len && K.n_text - nxt >= len) lcp = lce_bounded(A.text, curr, nxt, len);
+        }
         if (!(lcp >= len)) break;
         walk_push(W, A, K, nxt, false);
         curr = nxt;

@@ -5,8 +5,10 @@
 //
 // Same getopt string, flag meanings, struct defaults and default output name as the reference, so the `moni align` wrapper
 // (pipeline/moni.in:494-546) can call it unchanged.  Index: <prefix>.mfi (the flat arrays moni_align_amd/index_build.py
-// writes) or, when that file is absent, the reference's own files <prefix>.thrbv.full.lcp.ms + <prefix>.ldx with the text as plain
-// bytes in <prefix>.txt (moni_index_load_reference; the .plain.slp grammar is not read).  Reads are streamed in large batches (the
+// writes) or, when that file is absent, the reference's own files <prefix>.thrbv.full.lcp.ms + <prefix>.ldx as `moni build` leaves them
+// (moni_index_load_reference: the .plain.slp grammar is not read, the text is rebuilt from the BWT on the GPU; a <prefix>.txt with the
+// text as plain bytes is used when present).  The .thrbv.full.lcp.ms reader follows the sdsl / r-index layouts from recall: no file
+// written by the reference was available to check it against.  Reads are streamed in large batches (the
 // reference's -b is a per-thread batch of 512; a GPU wants ~10^6).  Plain FASTQ / FASTA files (the streaming path, fast_align below):
 // the file is mapped and cut into record-aligned byte ranges of about --gpu-batch reads; three workers per GPU, each with its own
 // context, take ranges in order: parse (two passes over the range with a few helper threads: count, then fill the batch arrays in
@@ -16,7 +18,8 @@
 // modes take the older path: a reader thread parses ahead into a bounded queue, two workers per GPU, a writer thread with a bounded
 // in-order window.  -m writes the report-MEMs records (aligner_ksw2.hpp:346-373);
 // --ms / --mems write the legacy `moni ms` / `moni mems` text outputs (src/matching_statistics.cpp:520-610, src/mems.cpp:520-600).
-// Not implemented here (exit 1 with a message): -c, -q, -n, -Z.
+// -n loads <prefix>.thrbv.full.ms (no LCP samples); -q is accepted (the text comes from the BWT, not from either grammar).
+// Not implemented here (exit 1 with a message): -c, -Z.
 #include <fcntl.h>
 #include <getopt.h>
 #include <libgen.h>
@@ -43,6 +46,9 @@
 #include "../../include/moni_hip.h"
 
 static void die(const std::string& msg) { fprintf(stderr, "[ERROR] %s\n", msg.c_str()); exit(1); }   // common.hpp:108-117
+// output that did not reach the file (a full disk) is an error, not a shorter SAM file with exit code 0
+static void put(const void* p, size_t n, FILE* f) { if (n && fwrite(p, 1, n, f) != n) die("short write to the output file"); }
+static void close_out(FILE* f) { if (f && fclose(f) != 0) die("closing the output file failed (output incomplete)"); }
 static void info(const std::string& msg) { printf("[INFO] Message: %s\n", msg.c_str()); fflush(stdout); }
 
 struct Batch {
@@ -380,20 +386,21 @@ static int run_paired(Args& a, const std::string& sam_filename) {
         return 0;
     }
     const std::string idx_path = a.filename + ".mfi";
-    const bool have_mfi = access(idx_path.c_str(), R_OK) == 0;
-    const std::string ms_path = a.filename + ".thrbv.full.lcp.ms", ldx_path = a.filename + ".ldx", txt_path = a.filename + ".txt";
+    const bool have_mfi = !a.no_lcp && access(idx_path.c_str(), R_OK) == 0;          // (the flat file always carries the LCP samples)
+    const std::string ms_path = a.filename + (a.no_lcp ? ".thrbv.full.ms" : ".thrbv.full.lcp.ms"), ldx_path = a.filename + ".ldx", txt_path = a.filename + ".txt";
+    const bool have_txt = access(txt_path.c_str(), R_OK) == 0;          // optional: without it the text is rebuilt from the BWT on the GPU
     std::vector<moni_index_t*> idx(a.gpus, nullptr);
     std::vector<moni_ctx_t*> ctx(a.gpus, nullptr);
     for (int g = 0; g < a.gpus; ++g) {
         if (have_mfi) { if (moni_index_load(idx_path.c_str(), g, &idx[g])) die("cannot load " + idx_path + " on GPU " + std::to_string(g) + " (moni-hip has no CPU path)"); }
-        else if (moni_index_load_reference(ms_path.c_str(), ldx_path.c_str(), txt_path.c_str(), g, &idx[g]))
-            die("cannot load " + idx_path + " nor " + ms_path + " + " + ldx_path + " + " + txt_path + " on GPU " + std::to_string(g) + " (moni-hip has no CPU path)");
+        else if (moni_index_load_reference(ms_path.c_str(), ldx_path.c_str(), have_txt ? txt_path.c_str() : nullptr, g, &idx[g]))
+            die("cannot load " + idx_path + " nor " + ms_path + " + " + ldx_path + " (reader of the reference's files: layout unverified against a real `moni build` output) on GPU " + std::to_string(g) + " (moni-hip has no CPU path)");
         if (moni_ctx_create(idx[g], &ctx[g])) die("cannot create a context on GPU " + std::to_string(g));
     }
     const auto t0 = std::chrono::steady_clock::now();
     FILE* out = fopen(sam_filename.c_str(), "w");
     if (!out) die("open() file " + sam_filename + " failed");
-    { char* h; uint64_t hl; if (moni_sam_header(idx[0], &h, &hl)) die("header"); fwrite(h, 1, hl, out); moni_free(h); }
+    { char* h; uint64_t hl; if (moni_sam_header(idx[0], &h, &hl)) die("header"); put(h, hl, out); moni_free(h); }
     moni_pe_model_t model;
     memset(&model, 0, sizeof model);
     size_t processed = 0, aligned = 0;
@@ -428,7 +435,7 @@ static int run_paired(Args& a, const std::string& sam_filename) {
         if (all.n()) {
             char* sam = nullptr; uint64_t len = 0, n_al = 0;
             align_one(0, all, &sam, &len, &n_al);
-            fwrite(sam, 1, len, out); moni_free(sam);
+            put(sam, len, out); moni_free(sam);
             processed += all.n() / 2; aligned += n_al;
         }
     }
@@ -442,9 +449,9 @@ static int run_paired(Args& a, const std::string& sam_filename) {
         for (size_t g = 1; g < bs.size(); ++g) th.emplace_back([&, g] { align_one((int)g, *bs[g], &sams[g], &lens[g], &nal[g]); });
         if (!bs.empty()) align_one(0, *bs[0], &sams[0], &lens[0], &nal[0]);
         for (auto& t : th) t.join();
-        for (size_t g = 0; g < bs.size(); ++g) { fwrite(sams[g], 1, lens[g], out); moni_free(sams[g]); processed += bs[g]->n() / 2; aligned += nal[g]; delete bs[g]; }
+        for (size_t g = 0; g < bs.size(); ++g) { put(sams[g], lens[g], out); moni_free(sams[g]); processed += bs[g]->n() / 2; aligned += nal[g]; delete bs[g]; }
     }
-    fclose(out);
+    close_out(out);
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     info("Number of aligned pairs: " + std::to_string(aligned) + "/" + std::to_string(processed));
     info("Elapsed time (s): " + std::to_string(el));
@@ -459,7 +466,10 @@ int main(int argc, char** argv) {
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
     Args a;
     parse(argc, argv, a);
-    if (a.csv || a.no_lcp || a.shaped_slp || a.secondary) die("options -c, -n, -q, -Z are not implemented in moni-hip-align yet");
+    if (a.csv || a.secondary) die("options -c, -Z are not implemented in moni-hip-align yet");
+    // -n: <prefix>.thrbv.full.ms (ms_pointers<>: no LCP samples; the occurrence walks measure the LCP on the text, seed_finder.hpp:346-370).
+    // -q: the reference would take the text from <prefix>.slp (SelfShapedSlp) instead of <prefix>.plain.slp; both grammars spell the same
+    //     text and neither is read here - the text is rebuilt from the BWT - so the flag changes nothing (align_full_ksw2.cpp:414-426)
     const bool paired = !a.mate1.empty() || !a.mate2.empty();
     if (paired && (a.mate1.empty() || a.mate2.empty())) die("paired-end alignment needs both -1 and -2");
     if (paired && (a.report_mems || a.legacy_ms || a.legacy_mems)) die("-m / --ms / --mems take single-end input (-p)");
@@ -491,12 +501,13 @@ int main(int argc, char** argv) {
     const int per_gpu = legacy ? 1 : (fast ? a.ctx_per_gpu : 2);                      // contexts (batches in flight) per GPU
     std::vector<moni_index_t*> idx(a.gpus, nullptr);
     std::vector<moni_ctx_t*> ctx((size_t)a.gpus * per_gpu, nullptr);
-    const bool have_mfi = access(idx_path.c_str(), R_OK) == 0;
-    const std::string ms_path = a.filename + ".thrbv.full.lcp.ms", ldx_path = a.filename + ".ldx", txt_path = a.filename + ".txt";
+    const bool have_mfi = !a.no_lcp && access(idx_path.c_str(), R_OK) == 0;          // (the flat file always carries the LCP samples)
+    const std::string ms_path = a.filename + (a.no_lcp ? ".thrbv.full.ms" : ".thrbv.full.lcp.ms"), ldx_path = a.filename + ".ldx", txt_path = a.filename + ".txt";
+    const bool have_txt = access(txt_path.c_str(), R_OK) == 0;          // optional: without it the text is rebuilt from the BWT on the GPU
     for (int g = 0; g < a.gpus; ++g) {
         if (have_mfi) { if (moni_index_load(idx_path.c_str(), g, &idx[g])) die("cannot load " + idx_path + " on GPU " + std::to_string(g) + " (moni-hip has no CPU path)"); }
-        else if (moni_index_load_reference(ms_path.c_str(), ldx_path.c_str(), txt_path.c_str(), g, &idx[g]))
-            die("cannot load " + idx_path + " nor " + ms_path + " + " + ldx_path + " + " + txt_path + " on GPU " + std::to_string(g) + " (moni-hip has no CPU path)");
+        else if (moni_index_load_reference(ms_path.c_str(), ldx_path.c_str(), have_txt ? txt_path.c_str() : nullptr, g, &idx[g]))
+            die("cannot load " + idx_path + " nor " + ms_path + " + " + ldx_path + " (reader of the reference's files: layout unverified against a real `moni build` output) on GPU " + std::to_string(g) + " (moni-hip has no CPU path)");
         for (int k = 0; k < per_gpu; ++k) if (moni_ctx_create(idx[g], &ctx[(size_t)g * per_gpu + k])) die("cannot create a context on GPU " + std::to_string(g));
     }
     if (fast) {
@@ -585,7 +596,7 @@ int main(int argc, char** argv) {
     else {
         out = fopen(sam_filename.c_str(), "w");
         if (!out) die("open() file " + sam_filename + " failed");
-        char* h; uint64_t hl; if (moni_sam_header(idx[0], &h, &hl)) die("header"); fwrite(h, 1, hl, out); moni_free(h);
+        char* h; uint64_t hl; if (moni_sam_header(idx[0], &h, &hl)) die("header"); put(h, hl, out); moni_free(h);
     }
     auto t0 = std::chrono::steady_clock::now();
     // ---- reader thread -> bounded queue of parsed batches -> workers -> bounded in-order window -> writer thread ----
@@ -639,9 +650,9 @@ int main(int argc, char** argv) {
                 cv_window.notify_all();
             }
             const double w0 = now();
-            if (d.la) fwrite(d.a, 1, d.la, out);
+            if (d.la) put(d.a, d.la, out);
             if (d.a) moni_free(d.a);
-            if (out2 && !d.b.empty()) fwrite(d.b.data(), 1, d.b.size(), out2);
+            if (out2 && !d.b.empty()) put(d.b.data(), d.b.size(), out2);
             t_writer += now() - w0;
         }
     });
@@ -704,8 +715,8 @@ int main(int argc, char** argv) {
     for (auto& t : th) t.join();
     { std::lock_guard<std::mutex> lk(mu_out); workers_done = true; cv_out.notify_all(); }
     writer.join();
-    fclose(out);
-    if (out2) fclose(out2);
+    close_out(out);
+    close_out(out2);
     delete zrd;
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     info("Number of aligned reads: " + std::to_string(aligned) + "/" + std::to_string(processed));

@@ -79,6 +79,7 @@ struct FlatIndex {
     std::vector<ulint> samples_last;      // moni.hpp:128
     std::vector<ulint> thr;               // per run, 0 = none (thresholds_ds.hpp:413-426)
     std::vector<ulint> slcp;              // moni_lcp.hpp:117-145
+    bool no_lcp = false;                  // the `-n` form: ms_pointers<> instead of moni_lcp<> (align_full_ksw2.cpp:414-419): no LCP samples are consulted
     std::vector<uint8_t> text;            // ra
     std::vector<ulint> seq_starts;        // seqidx onsets (k+1)
     std::vector<std::string> names;

@@ -67,6 +67,8 @@ void* orc_index_create(uint64_t n, uint64_t r, uint64_t w, uint64_t n_seq, const
     ix->finalize();
     return ix;
 }
+// the `-n` form of the aligner (seed_finder<slp_t, ms_pointers<>>, align_full_ksw2.cpp:414-419): no sampled LCP in the occurrence walks
+void orc_index_set_no_lcp(void* h, int no_lcp) { ((FlatIndex*)h)->no_lcp = no_lcp != 0; }
 // liftidx::lifts as flat arrays (one lift per sequence): second, number of alignment columns, sorted positions of the ones of
 // the ins / del bit-vectors (ragged, offsets n_seq + 1)
 void orc_index_set_lifts(void* h, uint64_t n_seq, const uint64_t* second, const uint64_t* len, const uint64_t* ins_off, const uint64_t* ins,

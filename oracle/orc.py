@@ -62,6 +62,7 @@ def lib():
         L.orc_align_batch.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint64] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int,
                                                                                                      ctypes.c_void_p, ctypes.c_void_p]
         L.orc_free.argtypes = [ctypes.c_void_p]
+        L.orc_index_set_no_lcp.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_report_mems_batch.restype = ctypes.c_void_p
         L.orc_report_mems_batch.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint64] + [ctypes.c_void_p] * 4
         L.orc_ms_lengths.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
@@ -90,6 +91,10 @@ class OracleIndex:
             raise IOError("oracle: cannot load " + str(path))
         self.n = self._L.orc_index_n(self._h)
         self.r = self._L.orc_index_r(self._h)
+
+    def set_no_lcp(self, on: bool = True):
+        """the `-n` form: the occurrence walks use Phi / Phi_inv and a bounded LCE on the text instead of the sampled LCP"""
+        self._L.orc_index_set_no_lcp(self._h, int(on))
 
     def close(self):
         if self._h:

@@ -95,16 +95,31 @@ struct seed_finder {
         }
     }
 
-    // seed_finder.hpp:377-393
-    std::pair<size_t, size_t> get_next_occ_with_lcp(size_t curr, size_t) {
+    // lceToRBounded (ShapedSlp, an absent submodule; call sites seed_finder.hpp:354,367): the bytes the text suffixes at a and b share, up to len
+    size_t lce_bounded(size_t a, size_t b, size_t len) const {
+        size_t l = 0;
+        while (l < len && ix.text[a + l] == ix.text[b + l]) ++l;
+        return l;
+    }
+    // seed_finder.hpp:377-393 (moni_lcp<>: the sampled LCP); :346-370 (ms_pointers<>, `-n`: Phi / Phi_inv and a bounded LCE on the text when both
+    // suffixes are at least len long)
+    std::pair<size_t, size_t> get_next_occ_with_lcp(size_t curr, size_t len) {
         if (curr == ix.get_last_run_sample()) return {ix.get_first_run_sample(), 0};
         cnt.phi_steps++;
-        return ix.Phi_inv_lcp(curr);
+        if (!ix.no_lcp) return ix.Phi_inv_lcp(curr);
+        const size_t next = ix.Phi_inv_lcp(curr).first;          // ms.Phi_inv(curr): the same predecessor query without the LCP
+        size_t lcp = 0;
+        if ((n - curr) >= len and (n - next) >= len) lcp = lce_bounded(curr, next, len);
+        return {next, lcp};
     }
-    std::pair<size_t, size_t> get_prev_occ_with_lcp(size_t curr, size_t) {
+    std::pair<size_t, size_t> get_prev_occ_with_lcp(size_t curr, size_t len) {
         if (curr == ix.get_first_run_sample()) return {ix.get_last_run_sample(), 0};
         cnt.phi_steps++;
-        return ix.Phi_lcp(curr);
+        if (!ix.no_lcp) return ix.Phi_lcp(curr);
+        const size_t prev = ix.Phi_lcp(curr).first;
+        size_t lcp = 0;
+        if ((n - curr) >= len and (n - prev) >= len) lcp = lce_bounded(curr, prev, len);
+        return {prev, lcp};
     }
 
     // seed_finder.hpp:331-343

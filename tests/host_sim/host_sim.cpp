@@ -114,6 +114,7 @@ int sim_seed_run(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_r
     std::vector<uint32_t> pool((size_t)pool_rows * K.n_seq + 1);
     uint32_t small[2] = {0, 0};
     occ_args_t A;
+    A.text = S->text.data();
     A.phi.recs = S->img.phi.data(); A.phi.dir = S->img.phi_dir.data();
     A.phi_inv.recs = S->img.phi_inv.data(); A.phi_inv.dir = S->img.phi_inv_dir.data();
     A.seq_starts = S->img.seq_starts.data(); A.name_id = S->name_id.data(); A.mems = S->mems.data(); A.aux = aux.data();

@@ -59,9 +59,9 @@ def lib():
 
 
 class Sim:
-    def __init__(self, fi):
+    def __init__(self, fi, without_lcp=False):
         self.fi = fi
-        st = capi.flat_struct(fi)
+        st = capi.flat_struct(fi, without_lcp=without_lcp)
         self.h = lib().sim_create(C.byref(st))
         if not self.h:
             raise RuntimeError("host_sim: index rejected")

@@ -41,7 +41,7 @@ def test_dry_run_parsing(exe, small_case, tmp_path):
 def test_unsupported_modes_exit_1(exe, tmp_path):
     fq = str(tmp_path / "x.fq")
     open(fq, "w").write("@a\nACGT\n+\nIIII\n")
-    for extra in (["-p", fq, "-q"], ["-p", fq, "-c"], ["-1", fq, "-2", fq, "-Z"]):
+    for extra in (["-p", fq, "-c"], ["-1", fq, "-2", fq, "-Z"]):
         r = subprocess.run([exe, "x"] + extra, capture_output=True)
         assert r.returncode == 1 and b"not implemented" in r.stderr
     assert subprocess.run([exe], capture_output=True).returncode == 1

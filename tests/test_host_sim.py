@@ -133,3 +133,20 @@ def test_long_run_onto_many_short_runs():
         assert np.array_equal(got["counters"], want["counters"])
         for i in range(0, 400, 7):
             assert np.array_equal(got["pointers"][offs[i] * 2:offs[i] * 2 + 150], o.ms_query(reads[i].tobytes()))
+
+
+def test_no_lcp_form(medium_case):
+    """`-n` (seed_finder<slp_t, ms_pointers<>>, seed_finder.hpp:346-370): no sampled LCP - the occurrence walks take Phi / Phi_inv and measure
+    the LCP on the text, bounded by the seed's length; the kernels' per-lane code over an image built without slcp against the oracle in that
+    mode - and both against the sampled-LCP form, which finds the same seeds on this index"""
+    o = orc.OracleIndex(medium_case.path)
+    o.set_no_lcp(True)
+    s = hs.Sim(medium_case.fi, without_lcp=True)
+    reads = list(medium_case.synth.make_reads(medium_case.pg, 400, 150, seed=77, sub_rate=0.02))
+    reads.append(np.frombuffer(bytes(medium_case.fi.text[-170:-20]), dtype=np.uint8))          # a read at the very end of the text (the n - curr >= len guard)
+    seq, offs = ragged(reads)
+    for kw in ({}, {"n_seeds_thr": 2, "pool_rows": 100000}, {"min_len": 12}):
+        got, want = run_both((o, s), seq, offs, **kw)
+        assert_seeds_equal(got, want)
+    o2 = orc.OracleIndex(medium_case.path)
+    assert_seeds_equal(s.seed_run(seq, offs), o2.seed_batch(seq, offs, 25, True, 1000))

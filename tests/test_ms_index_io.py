@@ -136,3 +136,73 @@ def test_index_loaded_from_reference_files_aligns_like_the_flat_index(small, tmp
     want, _ = orc.align_batch(orc.OracleIndex(fi=fi), reads.reshape(-1), offs, names, noff, q, threads=4)
     assert got == want
     ctx.close(); idx.close()
+
+
+@pytest.mark.gpu
+def test_moni_build_output_alone_text_rebuilt_from_the_bwt(small, tmp_path):
+    """What `moni build` leaves on disk is <prefix>.thrbv.full.lcp.ms + <prefix>.ldx (+ the .plain.slp grammar, whose format is not
+    available): the text is redundant with the r-index and is rebuilt on the GPU by inverting the BWT from the 2 r sampled positions.
+    The rebuilt text is the original byte for byte, and the index aligns like the flat one (seed_finder.hpp:64-124)."""
+    from oracle import orc
+    pg, fi = small
+    ms, ldx = str(tmp_path / "p.thrbv.full.lcp.ms"), str(tmp_path / "p.ldx")
+    capi.ms_file_write(fi, ms); capi.ldx_write(fi, ldx, True)
+    idx = capi.Index(reference=(ms, ldx, None))
+    assert np.array_equal(idx.text(), np.asarray(fi.text, dtype=np.uint8))
+    ctx = capi.Ctx(idx)
+    n, L = 3000, 150
+    reads = synth.make_reads(pg, n, L, seed=8)
+    offs = np.arange(0, (n + 1) * L, L, dtype=np.uint64)
+    names, noff = orc.make_names(n)
+    q = np.full(n * L, ord("I"), np.uint8)
+    got, _ = ctx.align_batch(reads.reshape(-1), offs, names, noff, q, host_threads=4)
+    want, _ = orc.align_batch(orc.OracleIndex(fi=fi), reads.reshape(-1), offs, names, noff, q, threads=4)
+    assert got == want
+    ctx.close(); idx.close()
+    # a FlatIndex handed over without its text takes the same road (moni_index_create with text = NULL)
+    import copy
+    f2 = copy.copy(fi)
+    idx2 = capi.Index(fi=f2, device=0, without_text=True)
+    assert np.array_equal(idx2.text(), np.asarray(fi.text, dtype=np.uint8))
+    idx2.close()
+
+
+def test_ms_file_without_lcp_samples_round_trip(small, tmp_path):
+    """<prefix>.thrbv.full.ms (ms_pointers::serialize, moni.hpp:392-409: the `-n` form) = the same layout without the LCP samples"""
+    pg, fi = small
+    a, b = str(tmp_path / "p.thrbv.full.lcp.ms"), str(tmp_path / "p.thrbv.full.ms")
+    capi.ms_file_write(fi, a)
+    capi.ms_file_write(fi, b, without_lcp=True)
+    assert os.path.getsize(b) < os.path.getsize(a)
+    A, B = capi.ms_file_read(a), capi.ms_file_read(b)
+    for k in ("F", "heads", "starts", "ssa", "esa", "thr"):
+        assert np.array_equal(A[k], B[k]), k
+    assert np.array_equal(A["slcp"], fi.slcp) and not B["slcp"].any()
+    assert open(a, "rb").read()[:os.path.getsize(b)] == open(b, "rb").read()          # a prefix of the other file, byte for byte
+
+
+@pytest.mark.gpu
+def test_no_lcp_index_from_reference_files(small, tmp_path):
+    """`moni align -n`: <prefix>.thrbv.full.ms + <prefix>.ldx, text rebuilt from the BWT, occurrence walks by Phi / Phi_inv + bounded LCE on
+    the text (seed_finder.hpp:346-370): seeds and SAM text equal the oracle's in that mode"""
+    from oracle import orc
+    from tests.parity import assert_seeds_equal
+    pg, fi = small
+    ms, ldx = str(tmp_path / "p.thrbv.full.ms"), str(tmp_path / "p.ldx")
+    capi.ms_file_write(fi, ms, without_lcp=True); capi.ldx_write(fi, ldx, True)
+    idx = capi.Index(reference=(ms, ldx, None))
+    ctx = capi.Ctx(idx)
+    o = orc.OracleIndex(fi=fi)
+    o.set_no_lcp(True)
+    n, L = 3000, 150
+    reads = synth.make_reads(pg, n, L, seed=9, sub_rate=0.02)
+    offs = np.arange(0, (n + 1) * L, L, dtype=np.uint64)
+    ctx.upload(reads.reshape(-1), offs)
+    ctx.seed_run(25, True, 1000)
+    assert_seeds_equal(ctx.seed_fetch(), o.seed_batch(reads.reshape(-1), offs, 25, True, 1000, threads=4))
+    names, noff = orc.make_names(n)
+    q = np.full(n * L, ord("I"), np.uint8)
+    got, _ = ctx.align_batch(reads.reshape(-1), offs, names, noff, q, host_threads=4)
+    want, _ = orc.align_batch(o, reads.reshape(-1), offs, names, noff, q, threads=4)
+    assert got == want
+    ctx.close(); idx.close()

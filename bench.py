@@ -85,6 +85,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
+    ap.add_argument("--paired", action="store_true", help="the paired-end path instead (moni_pe_learn_batch / moni_pe_align_batch over --pairs FR pairs of 2 x --read-len, orphan recovery on): pairs/s")
+    ap.add_argument("--pairs", type=int, default=400000, help="--paired: read pairs (per GPU; sharded by contiguous ranges like the reads when --total-reads is given)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: launch, rendezvous (gloo), sharding and the SAM gather with placeholder records")
     ap.add_argument("--cache", default="/tmp/moni_bench_cache")
     return ap.parse_args(argv)
@@ -221,7 +223,9 @@ def run_rank(args) -> int:
     log("rank %d: device image %.2f GB in %.1fs" % (rank, idx.device_bytes / 1e9, time.time() - t0))
     ctx = capi.Ctx(idx)
     L = args.read_len
-    if sharded:            # strong scaling: one read set, this rank's contiguous range of it, in resident chunks
+    if args.paired:
+        pass
+    elif sharded:            # strong scaling: one read set, this rank's contiguous range of it, in resident chunks
         lo, hi = mdist.shard_range(total, rank, world)
         reads = synth.make_reads_range(pg, lo, hi, L, seed=1500)
         names, noff = synth.make_names_range(lo, hi)
@@ -231,6 +235,8 @@ def run_rank(args) -> int:
         reads = synth.make_reads(pg, args.reads, L, seed=150 + rank)
         names, noff = synth.make_names(args.reads)
         scaling = "weak"
+    if args.paired:
+        return run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx)
     n_mine = reads.shape[0]
     cb = chunk_bounds(n_mine, args.reads)
     n_chunks = len(cb) - 1
@@ -495,6 +501,109 @@ def run_rank(args) -> int:
             out["seeding"]["cpu_baseline"] = {"value": n_cs / dt, "unit": "reads/s", "cores": cpu_threads, "kind": "port",
                                               "sample": "first %d reads, same stage, oracle/seed.hpp" % n_cs,
                                               "gpu_matches_cpu_on_sample": bool(same)}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    idx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+# ---- the paired-end path -----------------------------------------------------------------------------------
+def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx) -> int:
+    """One "step" = moni_pe_align_batch over this rank's pairs (host memory -> two SAM records per pair in host memory; the paired entry points
+    have no resident form), fragment model learnt once on rank 0's first batches of 512 pairs (the reference's single learner,
+    align_reads_dispatcher.hpp:356-389) and broadcast."""
+    import torch
+    from moni_align_amd import capi, dist as mdist, synth
+    L = args.read_len
+    n_all = args.pairs * world
+    mates, ins = synth.make_pairs(pg, n_all, L, seed=350)
+    names, noff = synth.make_pair_names(n_all)
+    lo, hi = mdist.shard_range(n_all, rank, world)
+    model = capi.PeModelC()
+    vals = torch.zeros(8, dtype=torch.float64)
+    if rank == 0:
+        at = 0
+        while not model.complete and at < n_all:
+            e = min(n_all, at + 512)
+            ctx.pe_learn(mates[2 * at:2 * e].reshape(-1), np.arange(0, (2 * (e - at) + 1) * L, L, dtype=np.uint64), model)
+            at = e
+        vals = torch.tensor([model.mean, model.std_dev, model.variance, model.sample_variance, model.m2, float(model.count), float(model.complete), 0.0], dtype=torch.float64)
+    if dist is not None:          # learn once, broadcast (every rank aligns with the same model)
+        v = vals.to(coll_dev)
+        dist.broadcast(v, src=0)
+        vals = v.cpu()
+        model.mean, model.std_dev, model.variance, model.sample_variance, model.m2 = (float(x) for x in vals[:5])
+        model.count, model.complete = int(vals[5]), int(vals[6])
+    seq = mates[2 * lo:2 * hi].reshape(-1)
+    offs = np.arange(0, (2 * (hi - lo) + 1) * L, L, dtype=np.uint64)
+    nm = names[int(noff[2 * lo]):int(noff[2 * hi])]
+    no = (noff[2 * lo:2 * hi + 1] - noff[2 * lo]).astype(np.uint64)
+    ql = np.full(seq.size, ord("I"), np.uint8)
+    threads = max(1, host_cpus() // max(1, world))
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    st = None
+    for _ in range(args.warmup):
+        ctx.pe_align(seq, offs, nm, no, ql, model, host_threads=threads)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sam, st = ctx.pe_align(seq, offs, nm, no, ql, model, host_threads=threads)
+    sync_all()
+    elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dist, coll_dev)
+    sizes = mdist.gather_counts([st["aligned"], hi - lo], dist, coll_dev)
+    if rank == 0:
+        steps = max(1, args.steps)
+        step_s = elapsed / steps
+        out = {"metric": "aligned read pairs/s (whole node), 2 x %d bp PE, mouse-chr19-scale x%d-haplotype index, orphan recovery on" % (L, args.haps),
+               "value": n_all / step_s, "unit": "pairs/s", "reads_per_s": 2 * n_all / step_s, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64/int32", "data": "synthetic",
+               "config": {"workload": "SURVEY.md 8(f)-2: paired-end path on the BASELINE.json configs[2] index (%d bp base + %d haplotypes, n=%d, r=%d): %d FR pairs of 2 x %d bp per GPU "
+                                      "(insert 350 +- 30, 0.5 %% substitutions) in host memory -> seeding kernels over the 2 N mates + pe_align_kernel (pair per lane) + host finishing -> "
+                                      "two SAM records per pair in host memory" % (args.base_len, args.haps, fi.n, fi.r, args.pairs, L),
+                          "pairs_per_gpu": hi - lo, "read_len": L, "parallelism": "pairs sharded x%d, index replicated, fragment model learnt on rank 0 and broadcast" % world},
+               "model": {"count": int(model.count), "mean": model.mean, "std_dev": model.std_dev, "complete": bool(model.complete)},
+               "aligned_pairs_all_ranks": sum(x[0] for x in sizes), "stages_s_per_step": {"seed": st["t_seed"], "kernel_and_copies": st["t_dp"], "host_finish": st["t_host"]},
+               "dp_problems": st["dp_tasks"], "dp_cells": st["dp_cells"], "pairs_through_host_pipeline": st["handed_back"],
+               "host": {"cpus_usable": host_cpus(), "host_threads_per_gpu": threads}}
+        if world == 1 and not args.no_cpu:
+            from oracle import orc as _orc          # the CPU baseline / at-scale checker
+            oidx = _orc.OracleIndex(fi=fi)
+            cpu_threads = host_cpus()
+
+            def cpu_pe(a, b):          # the oracle's paired path over pairs [a, b), st_align's order (learns on its own first batches of 512)
+                m1, m2 = mates[2 * a:2 * b:2], mates[2 * a + 1:2 * b:2]
+                o1 = np.arange(0, (b - a + 1) * L, L, dtype=np.uint64)
+                n1 = b"".join(bytes(names[int(noff[2 * p]):int(noff[2 * p + 1])]) for p in range(a, b)); n2 = b"".join(bytes(names[int(noff[2 * p + 1]):int(noff[2 * p + 2])]) for p in range(a, b))
+                no1 = np.zeros(b - a + 1, np.uint64); no1[1:] = np.cumsum([int(noff[2 * p + 1] - noff[2 * p]) for p in range(a, b)])
+                no2 = np.zeros(b - a + 1, np.uint64); no2[1:] = np.cumsum([int(noff[2 * p + 2] - noff[2 * p + 1]) for p in range(a, b)])
+                q = np.full((b - a) * L, ord("I"), np.uint8)
+                return _orc.align_pe(oidx, np.ascontiguousarray(m1).reshape(-1), o1, np.ascontiguousarray(m2).reshape(-1), o1, np.frombuffer(n1, np.uint8), no1,
+                                     np.frombuffer(n2, np.uint8), no2, q, q, b_size=512, find_orphan=True)
+            n0 = min(3000, hi - lo)
+            t1 = time.perf_counter()
+            want, ost = cpu_pe(0, n0)
+            rate1 = n0 / (time.perf_counter() - t1)
+            got = b"\n".join(sam.split(b"\n")[:2 * n0]) + b"\n"
+            per = int(max(2000, min((hi - lo) // cpu_threads, rate1 * args.cpu_seconds)))
+            res = [None] * cpu_threads
+            th = [threading.Thread(target=lambda k=k: res.__setitem__(k, cpu_pe(k * per, (k + 1) * per))) for k in range(cpu_threads)]
+            t1 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            dtc = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": per * cpu_threads / dtc, "unit": "pairs/s", "cores": cpu_threads, "kind": "port",
+                                   "sample": "%d slices of %d pairs, oracle/align_pe.hpp with orphan recovery, one thread per slice (each learns its own model as a run over that slice would)" % (cpu_threads, per),
+                                   "single_thread": {"value": rate1, "unit": "pairs/s", "cores": 1, "sample": "first %d pairs" % n0},
+                                   "sam_identical_on_sample": bool(got == want), "model_identical": bool(ost["ins_mean"] == model.mean and ost["ins_std_dev"] == model.std_dev)}
         print(json.dumps(out), flush=True)
     ctx.close()
     idx.close()

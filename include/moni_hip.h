@@ -221,6 +221,13 @@ int moni_align_run(moni_ctx_t *ctx, const uint8_t *names, const uint64_t *name_o
 int moni_align_stream(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
                       const uint8_t *quals, const moni_align_params_t *prm, char **sam, uint64_t *sam_len,
                       moni_align_stats_t *stats);
+/* aligner::align with csv (-c; aligner_ksw2.hpp:340-343, 417, include/common/csv.hpp:26-67): the SAM records and, per read, one line
+ * `name,unique MEMs,total occurrences,max frequency,min frequency,highest / lowest count on one genome,filtered,chains skipped` (no header:
+ * aligner::to_csv, aligner_ksw2.hpp:3230-3234).  A diagnostics mode: every read takes the host pipeline over the GPU's seeds and DP batches
+ * (the selection loop counts the chains it skips); both texts are malloc'ed (moni_free). */
+int moni_align_csv_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
+                         const uint8_t *quals, const moni_align_params_t *prm, char **sam, uint64_t *sam_len,
+                         char **csv, uint64_t *csv_len, moni_align_stats_t *stats);
 /* aligner::align with report_mems (-m; aligner_ksw2.hpp:346-373): one secondary record per MEM occurrence.  *sam is malloc'ed. */
 int moni_report_mems_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
                            const uint8_t *quals, const moni_align_params_t *prm, char **sam, uint64_t *sam_len);

@@ -21,7 +21,7 @@ EXPORTS = [
     "moni_index_device_bytes", "moni_index_text", "moni_ctx_create", "moni_ctx_destroy", "moni_reads_upload", "moni_reads_swap", "moni_ms_run",
     "moni_ms_query_batch", "moni_seed_run", "moni_seed_counts", "moni_seed_fetch", "moni_seed_batch", "moni_free",
     "moni_phi_lcp_batch", "moni_extz_batch", "moni_last_kernel_ms", "moni_last_counters",
-    "moni_align_params_default", "moni_align_batch", "moni_align_run", "moni_align_stream", "moni_sam_header",
+    "moni_align_params_default", "moni_align_batch", "moni_align_csv_batch", "moni_align_run", "moni_align_stream", "moni_sam_header",
     "moni_ldx_info", "moni_ldx_rewrite", "moni_ldx_lift_batch", "moni_ldx_write",
     "moni_ms_file_info", "moni_ms_file_read", "moni_ms_file_write", "moni_index_load_reference", "moni_ms_lengths_batch", "moni_report_mems_batch",
     "moni_pe_params_default", "moni_pe_learn_batch", "moni_pe_align_batch",
@@ -141,6 +141,8 @@ def lib():
         L.moni_align_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
         L.moni_align_stream.argtypes = L.moni_align_batch.argtypes
+        L.moni_align_csv_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
         L.moni_pe_params_default.argtypes = [C.POINTER(PeParamsC)]
         L.moni_pe_params_default.restype = None
         L.moni_pe_learn_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.POINTER(AlignParamsC), C.POINTER(PeParamsC), C.POINTER(PeModelC)]
@@ -343,6 +345,29 @@ class Ctx:
             if not stream:
                 self._L.moni_free(out)
         return sam, _stats_dict(st)
+
+    def align_csv_batch(self, seq, offsets, names, name_off, quals=None, host_threads: Optional[int] = None, **overrides):
+        """(SAM text, CSV lines, stats) of moni_align_csv_batch (`-c`)"""
+        b, keep = self._batch(seq, offsets)
+        names = np.ascontiguousarray(names, dtype=np.uint8)
+        name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
+        if quals is not None:
+            quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        prm = AlignParamsC()
+        self._L.moni_align_params_default(C.byref(prm))
+        if host_threads is not None:
+            prm.host_threads = host_threads
+        for k, v in overrides.items():
+            setattr(prm, k, v)
+        sam, sl, csv, cl = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
+        st = AlignStatsC()
+        _chk(self._L.moni_align_csv_batch(self._h, C.byref(b), names.ctypes.data, name_off.ctypes.data, quals.ctypes.data if quals is not None else None, C.byref(prm),
+                                          C.byref(sam), C.byref(sl), C.byref(csv), C.byref(cl), C.byref(st)), "moni_align_csv_batch")
+        self.n_reads = len(offsets) - 1
+        try:
+            return C.string_at(sam, sl.value), C.string_at(csv, cl.value), _stats_dict(st)
+        finally:
+            self._L.moni_free(sam); self._L.moni_free(csv)
 
     def _pe_params(self, host_threads, overrides):
         prm = AlignParamsC()

@@ -121,7 +121,7 @@ struct af_args_t {
     uint32_t* tb_task; af_tb_t* tb; uint32_t tb_cap;      // problems to trace
     uint32_t* fb_list; uint32_t* fb_n;       // reads handed to align_kernel and their number: per sub-batch, not per buffer set (align_kernel reads them on its own stream
                                              // while the set's next sub-batch is already running)
-    uint32_t* big_list; uint32_t* huge_list; // reads (indices in the launch) that need the large / the largest instance of chain_plan_kernel
+    uint32_t* list0; uint32_t* big_list; uint32_t* huge_list; // reads (indices in the launch) of the small / the large / the largest instance of chain_plan_kernel (classify_kernel)
     unsigned long long* txt_cur;             // AF_TXT_SHARDS cursors (one per 64 bytes) of the text pool's shard regions: a device-scope atomic on ONE address
     uint64_t txt_shard_words;                // sustains only ~50 M/s; region s + 1 of the pool (txt_shard_words each) belongs to shard s, region 0 to cursors[15]
     uint8_t* fin_scratch; uint64_t fin_stride;            // per finish lane: stitched CIGAR, lifted CIGAR, MD and text staging
@@ -139,7 +139,7 @@ struct af_args_t {
 #endif
 enum { AFC_TASKS = 0, AFC_FALLBACK = 1, AFC_TRACED = 2, AFC_READ_CUR = 3, AFC_DIRS_OVF = 4, AFC_CELLS = 6 /* 64 bit */, AFC_DIROFF = 8 /* 64 bit */,
        AFC_NCHUNKS = 10 /* + group */, AFC_CURSOR = 13 /* + group */, AFC_BINS = 16 /* + bin */, AFC_BIG = 49, AFC_BIG_CUR = 50, AFC_WHY = 52 /* + reason */, AFC_RBYTES = 64 /* 64 bit: text bytes of the DP targets, the R of SURVEY.md 8(d) */,
-       AFC_QBYTES = 66 /* 64 bit: read bytes of the DP queries */, AFC_NT = 68 /* DP problems queued by bin_tasks_kernel */, AFC_HUGE = 70, AFC_HUGE_CUR = 71, AF_NCTR = 96 };
+       AFC_QBYTES = 66 /* 64 bit: read bytes of the DP queries */, AFC_NT = 68 /* DP problems queued by bin_tasks_kernel */, AFC_HUGE = 70, AFC_HUGE_CUR = 71, AFC_L0 = 72 /* reads of the small instance's list */, AF_NCTR = 96 };
 enum { AF_GRP_LARGE = 0, AF_GRP_SMALL = 1, AF_GRP_GLOBAL = 2 };
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -474,144 +474,249 @@ __device__ __forceinline__ void af_qseg(uint64_t off, uint32_t m, uint32_t stran
     if (!strand) { q_off = reversed ? off + a + len - 1 : off + a; qmode = reversed ? DP_Q_REV : 0; }
     else { q_off = reversed ? off + (m - (a + len)) : off + (m - 1 - a); qmode = DP_Q_COMP | (reversed ? 0 : DP_Q_REV); }
 }
-template <class WT>
-__device__ __forceinline__ bool af_add_task(WT& L, uint64_t q_off, uint64_t qlen, int qmode, uint64_t t_off, uint64_t tlen, int tmode, int flag) {
-    if (qlen == 0 || tlen == 0 || qlen > AF_QCAP || tlen > AF_TB) return false;
-    if (L.n_tasks >= (uint32_t)WT::NT) { L.n_tasks = 0xFFFFu; return false; }      // (does not fit this instance)
-    moni_dp_task_t t;
-    t.q_off = q_off; t.t_off = t_off; t.qlen = (int32_t)qlen; t.tlen = (int32_t)tlen; t.flag = flag; t.reserved = DP_Q_READS | DP_T_TEXT | qmode | tmode;
-    L.plan.tasks[L.n_tasks++] = t;
-    return true;
-}
-
-// lane 0, after the lanes have lifted every chain's leftmost anchor: the chain-selection loop ahead of its scores
-// (aligner_ksw2.hpp:409-462): which chains it scores, and their problems
-template <class WT>
-__device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, WT& L, uint64_t off, uint32_t m) {
+// One chain to score (fill_chain, part 1: aligner_ksw2.hpp:2782-2979) by ONE lane: its anchors left to right into the plan's pool, the gaps between
+// them classified (closed forms need no DP: a pure insertion, the "deletion" the reference scores with l = 0, one base against one base), and its DP
+// problems [left extension][right extension][gap fills in anchor order].  WRITE = false: count the problems (and write the anchors); WRITE = true: write
+// the problems from task0 on.  Returns the number of problems, or 0xFFFFFFFF when one is beyond the DP tiles (the read leaves the staged path).
+template <bool WRITE, class WT>
+__device__ __forceinline__ uint32_t af_build_cand(const af_args_t& G, WT& L, af_cand_t& C, uint64_t off, uint32_t m, uint32_t task0) {
     const ac_params_t& P = G.A.P;
-    const uint32_t n_chains = L.n_chains_sh;
     auto& PL = L.plan;
-    PL.n_chains = (uint16_t)n_chains; PL.n_cand = 0; PL.n_an = 0;
-    L.n_tasks = 0;
-    // a capacity of THIS instance (chains to score, their anchors, their problems): 0xFF = the next larger instance takes the read;
-    // the largest instance hands it to align_kernel
-#define AF_CAP(why) do { if ((uint32_t)WT::NC < AF_MAX_CAND || (uint32_t)WT::NA < AF_PLAN_AN || (uint32_t)WT::NT < AF_MAX_TASKS_READ) return 0xFFu; return AF_FALLBACK(G, why); } while (0)
-#define AF_TASK_FAIL() do { if (L.n_tasks == 0xFFFFu) AF_CAP(AF_WHY_CAPACITY); return AF_FALLBACK(G, AF_WHY_TASK_SIZE); } while (0)
+    const af_chain_t ch = L.chains[C.chain_idx];
+    af_anchor_t* const AN = PL.an + C.an0;
     const uint64_t n_text = P.n_text, ext_len = P.ext_len;
-    int64_t* diff = L.diff; uint32_t n_diff = 0, n_left = 0;
-    for (uint32_t ci = 0; ci < n_chains && n_diff < P.check_k; ++ci) {
-        const af_chain_t ch = L.chains[ci];
-        { bool f = false; for (uint32_t q = 0; q < n_diff; ++q) f = f || diff[q] == (int64_t)ch.score; if (!f) diff[n_diff++] = ch.score; }
-        if (P.left_mem_check) {                                  // check_left_MEM (aligner_ksw2.hpp:553-597)
-            const uint64_t left_ref = L.left_ref[ci];
-            bool seen = false;
-            for (uint32_t k = 0; k < n_left; ++k) {
-                const uint64_t lr = L.left_ref[L.left_idx[k]];
-                const uint64_t d = lr > left_ref ? lr - left_ref : left_ref - lr;
-                if (d < P.region_dist && L.chains[L.left_idx[k]].score == ch.score) seen = true;
-            }
-            if (seen) continue;
-            L.left_idx[n_left++] = (uint16_t)ci;
+    uint32_t nt = 0;
+    bool bad = false;
+    auto add = [&](uint64_t q_off, uint64_t qlen, int qmode, uint64_t t_off, uint64_t tlen, int tmode, int flag) {
+        if (qlen == 0 || tlen == 0 || qlen > AF_QCAP || tlen > AF_TB) { bad = true; return; }
+        if (WRITE) {
+            moni_dp_task_t t;
+            t.q_off = q_off; t.t_off = t_off; t.qlen = (int32_t)qlen; t.tlen = (int32_t)tlen; t.flag = flag; t.reserved = DP_Q_READS | DP_T_TEXT | qmode | tmode;
+            PL.tasks[task0 + nt] = t;
         }
-        if (n_diff >= P.check_k) continue;                       // not scored; the loop condition ends the loop
-        // ---- fill_chain, part 1 (aligner_ksw2.hpp:2782-2979): the problems of this chain ----
-        if (PL.n_cand >= (uint32_t)WT::NC) AF_CAP(AF_WHY_CANDS);
-        if (ch.cnt > 255u || PL.n_an + ch.cnt > (uint32_t)WT::NA) AF_CAP(AF_WHY_CHAIN_LEN);
-        af_cand_t& C = PL.cand[PL.n_cand];
-        af_anchor_t* const AN = PL.an + PL.n_an;
-        C.chain_score = ch.score; C.chain_idx = (uint16_t)ci; C.n_an = (uint8_t)ch.cnt; C.task0 = L.n_tasks; C.has_lc = C.has_rc = C.n_gap_tasks = 0; C.overlap = 0; C.score = 0; C.gtask = 0;
-        C.an0 = (uint16_t)PL.n_an; C.pad = 0; C.pad2 = 0;
-        PL.n_an += ch.cnt;
+        ++nt;
+    };
+    if (!WRITE) {
         for (uint32_t k = 0; k < ch.cnt; ++k) {                  // stored right to left (chain.hpp:166-200); fill_chain wants left to right
             const uint64_t aw = L.anch[L.pool[ch.off + ch.cnt - 1 - k]];
             const af_mem_t mk = L.mem[aw >> 40];
-            af_anchor_t& A = AN[k];
+            af_anchor_t A;
             A.occ = AF_X(aw) - mk.len + 1; A.len = mk.len; A.idx = mk.idx; A.gap_val = 0; A.gap_kind = AF_GAP_NONE; A.pad = 0;
+            AN[k] = A;
             if (k == 0) C.strand = (mk.mate & 2) ? 1 : 0;
         }
-        const af_anchor_t first = AN[0], last = AN[ch.cnt - 1];
-        const uint32_t strand = C.strand;
+        C.has_lc = C.has_rc = C.n_gap_tasks = 0; C.overlap = 0;
+    }
+    const af_anchor_t first = AN[0], last = AN[ch.cnt - 1];
+    const uint32_t strand = C.strand;
 #define qseg(a, len, reversed, q_off, qmode) af_qseg(off, m, strand, (a), (len), (reversed), (q_off), (qmode))
-#define add(q_off, qlen, qmode, t_off, tlen, tmode, flag) af_add_task(L, (q_off), (qlen), (qmode), (t_off), (tlen), (tmode), (flag))
-        const uint64_t lcs_len = first.idx, rcs_occ = (uint64_t)last.idx + last.len, rcs_len = m - rcs_occ;
-        const uint64_t mem_pos = first.occ;
-        if (lcs_len > 0) {
-            const uint64_t lc_occ = mem_pos > ext_len ? mem_pos - ext_len : 0;
-            const uint64_t lc_len = mem_pos > ext_len ? ext_len : ext_len - mem_pos;     // sic (aligner_ksw2.hpp:2796)
-            uint64_t q_off; int qmode;
-            qseg(0, lcs_len, true, q_off, qmode);
-            if (!add(q_off, lcs_len, qmode, lc_len ? lc_occ + lc_len - 1 : 0, lc_len, DP_T_REV, DP_EZ_EXTZ_ONLY | DP_EZ_RIGHT)) AF_TASK_FAIL();
-            C.has_lc = 1;
-        }
-        if (rcs_len > 0) {
-            const uint64_t rc_occ = last.occ + last.len;
-            const uint64_t rc_len = rc_occ < n_text - ext_len ? ext_len : n_text - rc_occ;
-            uint64_t q_off; int qmode;
-            qseg(rcs_occ, rcs_len, false, q_off, qmode);
-            if (!add(q_off, rcs_len, qmode, rc_occ, rc_len, 0, DP_EZ_EXTZ_ONLY | DP_EZ_RIGHT)) AF_TASK_FAIL();
-            C.has_rc = 1;
-        }
-        uint64_t last_ref = mem_pos + first.len, last_seq = (uint64_t)first.idx + first.len;
+    const uint64_t lcs_len = first.idx, rcs_occ = (uint64_t)last.idx + last.len, rcs_len = m - rcs_occ;
+    const uint64_t mem_pos = first.occ;
+    if (lcs_len > 0) {
+        const uint64_t lc_occ = mem_pos > ext_len ? mem_pos - ext_len : 0;
+        const uint64_t lc_len = mem_pos > ext_len ? ext_len : ext_len - mem_pos;     // sic (aligner_ksw2.hpp:2796)
+        uint64_t q_off; int qmode;
+        qseg(0, lcs_len, true, q_off, qmode);
+        add(q_off, lcs_len, qmode, lc_len ? lc_occ + lc_len - 1 : 0, lc_len, DP_T_REV, DP_EZ_EXTZ_ONLY | DP_EZ_RIGHT);
+        if (!WRITE) C.has_lc = 1;
+    }
+    if (rcs_len > 0) {
+        const uint64_t rc_occ = last.occ + last.len;
+        const uint64_t rc_len = rc_occ < n_text - ext_len ? ext_len : n_text - rc_occ;
+        uint64_t q_off; int qmode;
+        qseg(rcs_occ, rcs_len, false, q_off, qmode);
+        add(q_off, rcs_len, qmode, rc_occ, rc_len, 0, DP_EZ_EXTZ_ONLY | DP_EZ_RIGHT);
+        if (!WRITE) C.has_rc = 1;
+    }
+    uint64_t last_ref = mem_pos + first.len, last_seq = (uint64_t)first.idx + first.len;
+    if (!WRITE) {
         for (uint32_t k = 1; k < ch.cnt; ++k) {                  // overlapping anchors: the global realignment of the whole read (aligner_ksw2.hpp:2888-2900, 2984-2996)
             const af_anchor_t ak = AN[k];
             if (last_ref > ak.occ || last_seq > ak.idx) C.overlap = 1;
             last_ref = ak.occ + ak.len; last_seq = (uint64_t)ak.idx + ak.len;
         }
-        if (C.overlap && m > AF_QCAP) return AF_FALLBACK(G, AF_WHY_TASK_SIZE);
+        if (C.overlap && m > AF_QCAP) bad = true;
         last_ref = mem_pos + first.len; last_seq = (uint64_t)first.idx + first.len;
-        for (uint32_t k = 1; k < ch.cnt && !C.overlap; ++k) {
-            const af_anchor_t ak = AN[k], ap = AN[k - 1];
-            af_anchor_t& GP = AN[k - 1];
-            const uint64_t ref_occ = ak.occ, seq_occ = ak.idx;
-            if (last_ref == ref_occ) {
-                if (last_seq < seq_occ) {                                              // pure insertion
-                    GP.gap_val = (int16_t)(seq_occ - last_seq); GP.gap_kind = AF_GAP_INS;       // < AF_MAX_READ
-                }
-            } else if (last_seq == seq_occ) {                                          // "deletion": l is computed as 0 (aligner_ksw2.hpp:2939)
-                GP.gap_val = (int16_t)af_ins_score(P, 0); GP.gap_kind = AF_GAP_DEL0;
-            } else {
+    }
+    for (uint32_t k = 1; k < ch.cnt && !C.overlap; ++k) {
+        const af_anchor_t ak = AN[k], ap = AN[k - 1];
+        af_anchor_t& GP = AN[k - 1];
+        const uint64_t ref_occ = ak.occ, seq_occ = ak.idx;
+        if (WRITE) {                                             // the gaps were classified by the counting pass
+            if (ap.gap_kind == AF_GAP_TASK) {
                 const uint64_t cc_occ = ap.occ + ap.len, cc_len = ref_occ - cc_occ;
                 const uint64_t ccs_pos = (uint64_t)ap.idx + ap.len, ccs_len = seq_occ - ccs_pos;
                 uint64_t q_off; int qmode;
                 qseg(ccs_pos, ccs_len, false, q_off, qmode);
-                bool closed = false;
-                if (ccs_len == 1 && cc_len == 1) {       // one base against one base: the diagonal move wins unless both gaps beat it
-                    uint32_t qc = dp_nt4(G.A.D.reads[q_off]);
-                    if ((qmode & DP_Q_COMP) && qc < 4) qc = 3 - qc;
-                    const uint32_t tc = dp_nt4(cc_occ < n_text ? G.A.D.text[cc_occ] : 0u);
-                    if (qc < 4 && tc < 4) {
-                        const int32_t z = tc == qc ? G.A.D.sc_mch : G.A.D.sc_mis;
-                        const int32_t gap = dp_bound(0, G.A.D.qo, G.A.D.e) - G.A.D.qo - G.A.D.e;
-                        if (z > gap) { GP.gap_val = (int16_t)z; GP.gap_kind = AF_GAP_1X1; closed = true; }
-                    }
-                }
-                if (!closed) {
-                    if (!add(q_off, ccs_len, qmode, cc_occ, cc_len, 0, DP_EZ_RIGHT)) AF_TASK_FAIL();
-                    GP.gap_kind = AF_GAP_TASK; C.n_gap_tasks++;
+                add(q_off, ccs_len, qmode, cc_occ, cc_len, 0, DP_EZ_RIGHT);
+            }
+            continue;
+        }
+        if (last_ref == ref_occ) {
+            if (last_seq < seq_occ) {                                              // pure insertion
+                GP.gap_val = (int16_t)(seq_occ - last_seq); GP.gap_kind = AF_GAP_INS;       // < AF_MAX_READ
+            }
+        } else if (last_seq == seq_occ) {                                          // "deletion": l is computed as 0 (aligner_ksw2.hpp:2939)
+            GP.gap_val = (int16_t)af_ins_score(P, 0); GP.gap_kind = AF_GAP_DEL0;
+        } else {
+            const uint64_t cc_occ = ap.occ + ap.len, cc_len = ref_occ - cc_occ;
+            const uint64_t ccs_pos = (uint64_t)ap.idx + ap.len, ccs_len = seq_occ - ccs_pos;
+            uint64_t q_off; int qmode;
+            qseg(ccs_pos, ccs_len, false, q_off, qmode);
+            bool closed = false;
+            if (ccs_len == 1 && cc_len == 1) {       // one base against one base: the diagonal move wins unless both gaps beat it
+                uint32_t qc = dp_nt4(G.A.D.reads[q_off]);
+                if ((qmode & DP_Q_COMP) && qc < 4) qc = 3 - qc;
+                const uint32_t tc = dp_nt4(cc_occ < n_text ? G.A.D.text[cc_occ] : 0u);
+                if (qc < 4 && tc < 4) {
+                    const int32_t z = tc == qc ? G.A.D.sc_mch : G.A.D.sc_mis;
+                    const int32_t gap = dp_bound(0, G.A.D.qo, G.A.D.e) - G.A.D.qo - G.A.D.e;
+                    if (z > gap) { GP.gap_val = (int16_t)z; GP.gap_kind = AF_GAP_1X1; closed = true; }
                 }
             }
-            last_ref = ref_occ + ak.len; last_seq = seq_occ + ak.len;
+            if (!closed) {
+                add(q_off, ccs_len, qmode, cc_occ, cc_len, 0, DP_EZ_RIGHT);
+                GP.gap_kind = AF_GAP_TASK; C.n_gap_tasks++;
+            }
         }
-        PL.n_cand++;
+        last_ref = ref_occ + ak.len; last_seq = seq_occ + ak.len;
     }
 #undef qseg
-#undef add
-#undef AF_CAP
-#undef AF_TASK_FAIL
+    return bad ? 0xFFFFFFFFu : nt;
+}
+
+// After the lanes have lifted every chain's leftmost anchor: the chain-selection loop ahead of its scores (aligner_ksw2.hpp:409-462) - which chains
+// it scores - by lane 0 (a few comparisons per chain, no memory traffic), then one LANE per chain to score builds that chain's anchors and problems
+// (af_build_cand: the one-base gaps read the read and the text - dependent HBM loads that one lane used to take one after the other for every chain).
+// All lanes call it; the returned status is uniform: AF_ST_CAND, a fallback, or 0xFF (does not fit this instance: the next larger one takes the read).
+template <class WT>
+__device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, WT& L, uint64_t off, uint32_t m) {
+    const ac_params_t& P = G.A.P;
+    const int lane = threadIdx.x;
+    const uint32_t n_chains = L.n_chains_sh;
+    auto& PL = L.plan;
+    // a capacity of THIS instance (chains to score, their anchors, their problems): the next larger instance takes the read; the largest hands it to align_kernel
+    constexpr bool has_larger = (uint32_t)WT::NC < AF_MAX_CAND || (uint32_t)WT::NA < AF_PLAN_AN || (uint32_t)WT::NT < AF_MAX_TASKS_READ;
+    if (lane == 0) {
+        PL.n_chains = (uint16_t)n_chains; PL.n_cand = 0; PL.n_an = 0;
+        L.n_tasks = 0;
+        uint32_t st = AF_ST_CAND, why = AF_WHY_N;
+        int64_t* diff = L.diff; uint32_t n_diff = 0, n_left = 0;
+        for (uint32_t ci = 0; ci < n_chains && n_diff < P.check_k; ++ci) {
+            const af_chain_t ch = L.chains[ci];
+            { bool f = false; for (uint32_t q = 0; q < n_diff; ++q) f = f || diff[q] == (int64_t)ch.score; if (!f) diff[n_diff++] = ch.score; }
+            if (P.left_mem_check) {                                  // check_left_MEM (aligner_ksw2.hpp:553-597)
+                const uint64_t left_ref = L.left_ref[ci];
+                bool seen = false;
+                for (uint32_t k = 0; k < n_left; ++k) {
+                    const uint64_t lr = L.left_ref[L.left_idx[k]];
+                    const uint64_t d = lr > left_ref ? lr - left_ref : left_ref - lr;
+                    if (d < P.region_dist && L.chains[L.left_idx[k]].score == ch.score) seen = true;
+                }
+                if (seen) continue;
+                L.left_idx[n_left++] = (uint16_t)ci;
+            }
+            if (n_diff >= P.check_k) continue;                       // not scored; the loop condition ends the loop
+            if (PL.n_cand >= (uint32_t)WT::NC) { st = 0xFFu; why = AF_WHY_CANDS; break; }
+            if (ch.cnt > 255u || PL.n_an + ch.cnt > (uint32_t)WT::NA) { st = 0xFFu; why = AF_WHY_CHAIN_LEN; break; }
+            af_cand_t& C = PL.cand[PL.n_cand];
+            C.chain_score = ch.score; C.chain_idx = (uint16_t)ci; C.n_an = (uint8_t)ch.cnt; C.task0 = 0; C.has_lc = C.has_rc = C.n_gap_tasks = 0; C.overlap = 0; C.score = 0; C.gtask = 0;
+            C.strand = 0; C.an0 = (uint16_t)PL.n_an; C.pad = 0; C.pad2 = 0;
+            PL.n_an += ch.cnt;
+            PL.n_cand++;
+        }
+        if (st == 0xFFu && !has_larger) st = AF_FALLBACK(G, why);
+        L.status_sh = st;
+    }
+    __syncthreads();
+    uint32_t status = L.status_sh;
+    if (status != AF_ST_CAND) return status;
+    const uint32_t n_cand = PL.n_cand;
+    // ---- the problems of every chain to score: lane c takes chain c; count, prefix sum, write ----
+    uint32_t nt = 0;
+    if ((uint32_t)lane < n_cand) nt = af_build_cand<false>(G, L, PL.cand[lane], off, m, 0u);
+    const bool bad = __ballot(nt == 0xFFFFFFFFu) != 0ull;
+    if (bad) { if (lane == 0) L.status_sh = AF_FALLBACK(G, AF_WHY_TASK_SIZE); __syncthreads(); return L.status_sh; }
+    uint32_t incl = nt;
+    for (int o = 1; o < AF_MAX_CAND; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += x; }
+    const uint32_t total = (uint32_t)__shfl((int)incl, (int)(n_cand ? n_cand - 1 : 0));
+    if (n_cand && total > (uint32_t)WT::NT) {
+        if (has_larger) return 0xFFu;
+        if (lane == 0) L.status_sh = AF_FALLBACK(G, AF_WHY_CAPACITY);
+        __syncthreads();
+        return L.status_sh;
+    }
+    if ((uint32_t)lane < n_cand) {
+        PL.cand[lane].task0 = incl - nt;
+        af_build_cand<true>(G, L, PL.cand[lane], off, m, incl - nt);
+    }
+    if (lane == 0) L.n_tasks = n_cand ? total : 0u;
+    __syncthreads();
     return AF_ST_CAND;
 }
 
-// WT: the LDS instance (capacities).  LEVEL 0: every read of the launch, reads that overflow the small instance go to big_list;
-// LEVEL 1: the reads of big_list, reads that overflow go to huge_list; LEVEL 2: the reads of huge_list, reads that overflow go to align_kernel.
+// classify_kernel: which LDS instance of chain_plan_kernel a read needs, from its seeds alone (lane = read: the frequency filter's counts of kept seeds
+// and of their occurrences = anchors).  The instances take their reads from three lists; before, every read went through the small instance, which found
+// out after loading the seeds - and appended to the next list with one atomic per read on one address (~60 M/s: 8 ms per 1 M reads on a pangenome of 20
+// haplotypes, where most reads have more than 96 anchors).  Here a wave appends its reads with one atomic per list.
+__global__ void __launch_bounds__(256) classify_kernel(const af_args_t G) {
+    const ak_args_t& A = G.A;
+    const uint64_t r_in = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint32_t level = 4;                                      // 0 small, 1 large, 2 largest, 3 align_kernel, 4 no read
+    uint32_t m = 0;
+    if (r_in < A.n_reads) {
+        const uint64_t r = A.read_lo + r_in;
+        m = (uint32_t)(A.offs[r + 1] - A.offs[r]);
+        const uint64_t a = A.read_mem_off[r], b = A.read_mem_off[r + 1];
+        if (m >= AF_MAX_READ || (b - a) > (uint64_t)af_wave_huge_t::MM) level = 3;
+        else {
+            unsigned long long total = 0;
+            for (uint64_t k = a; k < b; ++k) total += A.mems[k].occ_cnt;
+            uint32_t n_mems = 0; unsigned long long n_anch = 0;
+            for (uint64_t k = a; k < b; ++k) {
+                const uint32_t oc = A.mems[k].occ_cnt;
+                bool keep = true;
+                if (A.P.filter_freq) { const double fr = static_cast<double>(oc) / (double)(size_t)total; if (fr > A.P.freq_thr) keep = false; }      // seed_freq_filter
+                if (keep) { ++n_mems; n_anch += oc; }
+            }
+            level = (n_mems <= (uint32_t)af_wave_small_t::MM && n_anch <= (unsigned long long)af_wave_small_t::MA) ? 0u
+                  : (n_mems <= (uint32_t)af_wave_t::MM && n_anch <= (unsigned long long)af_wave_t::MA) ? 1u
+                  : (n_mems <= (uint32_t)af_wave_huge_t::MM && n_anch <= (unsigned long long)af_wave_huge_t::MA) ? 2u : 3u;
+        }
+    }
+#pragma unroll
+    for (uint32_t lv = 0; lv < 3; ++lv) {
+        const unsigned long long bal = __ballot(level == lv);
+        if (!bal) continue;
+        uint32_t base = 0;
+        const int lead = __ffsll((long long)bal) - 1;
+        if (lane == lead) base = atomicAdd(&G.ctr[lv == 0 ? AFC_L0 : lv == 1 ? AFC_BIG : AFC_HUGE], (uint32_t)__popcll(bal));
+        base = (uint32_t)__shfl((int)base, lead);
+        if (level == lv) (lv == 0 ? G.list0 : lv == 1 ? G.big_list : G.huge_list)[base + (uint32_t)__popcll(bal & lt_mask)] = (uint32_t)r_in;
+    }
+    if (level == 3) {                                        // beyond every instance: align_kernel
+        af_plan_t& PL = G.plans[r_in];
+        PL.status = AF_ST_FALLBACK; PL.n_cand = 0; PL.n_chains = 0; PL.final_cand = 0; PL.n_alt = 0; PL.pad = 0; PL.score2 = 0; PL.ref_pos = PL.ref_len = 0; PL.tb0 = 0; PL.pad2 = 0;
+        PL.min_score = A.min_score_of_len[m <= A.max_len ? m : A.max_len];
+        G.ntasks[r_in] = 0;
+        G.fb_list[atomicAdd(G.fb_n, 1u)] = (uint32_t)(A.read_lo + r_in);
+        atomicAdd(&G.ctr[AFC_WHY + (m >= AF_MAX_READ ? AF_WHY_LONG : AF_WHY_ANCHORS)], 1u);
+    }
+}
+
+// WT: the LDS instance (capacities).  LEVEL 0 / 1 / 2: the reads of list0 / big_list / huge_list (classify_kernel); a read whose chains or plan overflow
+// the instance it was given goes to the next list, from the largest instance to align_kernel.
 template <class WT, int LEVEL, int OCC = (LEVEL == 0 ? 6 : LEVEL == 1 ? 3 : 1)>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) chain_plan_kernel(const af_args_t G) {
     __shared__ WT L;                          // one wavefront per workgroup: __syncthreads() orders the wave's own LDS traffic
     const int lane = threadIdx.x;
     const ak_args_t& A = G.A;
     constexpr bool BIG = LEVEL > 0;
-    const uint32_t n_work = LEVEL == 0 ? (uint32_t)A.n_reads : G.ctr[LEVEL == 1 ? AFC_BIG : AFC_HUGE];
+    const uint32_t n_work = G.ctr[LEVEL == 0 ? AFC_L0 : LEVEL == 1 ? AFC_BIG : AFC_HUGE];
     constexpr uint32_t GRAB = BIG ? 1u : 8u;          // reads taken per visit to the shared cursor
-    const uint32_t* const work_list = LEVEL == 1 ? G.big_list : G.huge_list;
+    const uint32_t* const work_list = LEVEL == 0 ? G.list0 : LEVEL == 1 ? G.big_list : G.huge_list;
     uint32_t w_next = 0, w_end = 0;
     while (true) {
         if (w_next >= w_end) {
@@ -621,7 +726,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         }
         const uint32_t w_in = w_next++;
         if (w_in >= n_work) break;
-        const uint32_t r_in = BIG ? work_list[w_in] : w_in;
+        const uint32_t r_in = work_list[w_in];
         AF_STAMP(c0);
         const uint64_t r = A.read_lo + r_in;
         const uint64_t off = A.offs[r];
@@ -698,12 +803,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
                 __syncthreads();
                 AF_STAMP(c3); AF_PROF(G, 2, c2, c3);
 #if defined(AF_PROFILE) || defined(AF_CUTS)
-                if (G.dbg & 16) { if (lane == 0) L.status_sh = AF_ST_UNALIGNED; } else      // ... after the lifts
+                if (G.dbg & 16) status = AF_ST_UNALIGNED; else      // ... after the lifts
 #endif
-                if (lane == 0) L.status_sh = af_plan_cands(G, L, off, m);
+                status = af_plan_cands(G, L, off, m);
                 __syncthreads();
                 AF_STAMP(c4); AF_PROF(G, 3, c3, c4);
-                status = L.status_sh;
                 if (status == 0xFFu) too_big = true;              // the plan does not fit this instance
             }
         }

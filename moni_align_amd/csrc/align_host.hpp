@@ -303,7 +303,11 @@ struct Fill {
     Score score;
 };
 
+// the MEM statistics of one read (`-c`: csv_t, include/common/csv.hpp:26-52)
+struct CsvRead { size_t num_uniq_mems = 0, total_mem_occ = 0, high_occ_mem = 0, low_occ_mem = 0, num_mems_filter = 0, num_chains_skipped = 0; double max_mem_freq = 0, min_mem_freq = 1; };
+
 struct ReadState {
+    CsvRead csv;
     uint64_t off = 0; uint32_t m = 0;                // read bytes in the batch
     std::vector<Mem> mems;
     std::vector<std::pair<uint32_t, uint32_t>> anchors;
@@ -588,7 +592,7 @@ struct Aligner {
             if (R.i < R.chains.size() && R.different_scores.size() < P.check_k) {
                 { const size_t v = (size_t)R.chains[R.i].score; bool f = false; for (size_t q = 0; q < R.different_scores.size(); ++q) f = f || R.different_scores[q] == v;
                   if (!f) { const size_t q = R.different_scores.size(); R.different_scores.resize(q + 1); R.different_scores[q] = v; } }
-                if (P.left_mem_check && check_left_mem(R, R.i)) { ++R.i; continue; }
+                if (P.left_mem_check && check_left_mem(R, R.i)) { ++R.i; ++R.csv.num_chains_skipped; continue; }      // (aligner_ksw2.hpp:417)
                 if (R.different_scores.size() < P.check_k) {
                     fill_begin(R, R.chains[R.i], true, tasks);
                     R.stage = ReadState::WAIT_A;
@@ -853,7 +857,9 @@ static inline double now_s() {
 // The whole batch: seeds -> SAM records (no header), in read order.
 static int align_batch(Backend& be, const HostIndex& ix, const moni_align_params_t& P, const uint8_t* reads, const uint64_t* offs,
                        uint64_t n_reads, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals, std::string& sam_out,
-                       AlignStats& st) {
+                       AlignStats& st, const std::function<int(std::vector<uint64_t>&)>* genome_hi_lo = nullptr, std::string* csv_out = nullptr) {
+    // csv_out (`-c`): one line of MEM statistics per read (write_csv, csv.hpp:55-67); genome_hi_lo fetches, for every seed of the batch, the largest and
+    // the smallest count of its occurrences on any one genome (largest | smallest << 32; a kernel: seed_core.h genome_task)
     const int T = P.host_threads > 0 ? (int)P.host_threads : 1;
     Pool pool(T);
     std::vector<moni_mem_t> gm;
@@ -863,6 +869,9 @@ static int align_batch(Backend& be, const HostIndex& ix, const moni_align_params
     double t0 = now_s();
     int rc = be.seed(sp, gm, go, rmo);
     if (rc) return rc;
+    std::vector<uint64_t> hi_lo;
+    if (csv_out && genome_hi_lo && (rc = (*genome_hi_lo)(hi_lo))) return rc;
+    if (csv_out && hi_lo.size() != gm.size()) return MONI_EINVAL;
     st.t_seed += now_s() - t0;
     t0 = now_s();
     Aligner A(ix, P, reads, offs);
@@ -875,11 +884,26 @@ static int align_batch(Backend& be, const HostIndex& ix, const moni_align_params
             const uint64_t a = rmo[r], b = rmo[r + 1];
             R.mems.reserve(b - a);
             for (uint64_t k = a; k < b; ++k) { const moni_mem_t& g = gm[k]; R.mems.push_back(Mem{g.pos, g.len, g.idx, g.rpos, g.mate, go.data() + g.occ_off, g.occ_cnt}); }
+            if (csv_out) {                                                                // calculate_MEM_stats (aligner_ksw2.hpp:1868-1902)
+                CsvRead& C = R.csv;
+                C.num_uniq_mems = b - a;
+                for (uint64_t k = a; k < b; ++k) { C.total_mem_occ += gm[k].total_occ; C.num_mems_filter += gm[k].num_filtered; }
+                for (uint64_t k = a; k < b; ++k) {
+                    const double mem_freq = (gm[k].occ_cnt / (static_cast<double>(C.total_mem_occ)));
+                    C.max_mem_freq = (C.max_mem_freq > mem_freq ? C.max_mem_freq : mem_freq);
+                    C.min_mem_freq = (C.min_mem_freq > mem_freq ? mem_freq : C.min_mem_freq);
+                    const size_t hi = (size_t)(hi_lo[k] & 0xFFFFFFFFull), lo = (size_t)(hi_lo[k] >> 32);      // over the seed's count_dict; every count is >= 1
+                    if (hi) {
+                        if (C.high_occ_mem == 0 && C.low_occ_mem == 0) { C.high_occ_mem = hi; C.low_occ_mem = lo; }
+                        else { C.high_occ_mem = (C.high_occ_mem > hi ? C.high_occ_mem : hi); C.low_occ_mem = (C.low_occ_mem > lo ? lo : C.low_occ_mem); }
+                    }
+                }
+            }
             size_t total = 0;
             for (auto& m : R.mems) total += m.nocc;
             if (P.filter_freq) {                                                          // seed_freq_filter
                 std::vector<Mem> keep;
-                for (auto& m : R.mems) { const double fr = static_cast<double>(m.nocc) / total; if (!(fr > P.freq_thr)) keep.push_back(m); }
+                for (auto& m : R.mems) { const double fr = static_cast<double>(m.nocc) / total; if (!(fr > P.freq_thr)) keep.push_back(m); else R.csv.num_mems_filter += m.nocc; }
                 R.mems.swap(keep);
             }
             size_t na = 0;
@@ -1019,6 +1043,17 @@ static int align_batch(Backend& be, const HostIndex& ix, const moni_align_params
     });
     sam_out.clear();
     for (auto& p : parts) sam_out += p;
+    if (csv_out) {                                                                         // write_csv (csv.hpp:55-67), read order
+        csv_out->clear();
+        char buf[256];
+        for (size_t r = 0; r < n_reads; ++r) {
+            const CsvRead& C = RS[r].csv;
+            csv_out->append((const char*)names + name_off[r], (size_t)(name_off[r + 1] - name_off[r]));
+            snprintf(buf, sizeof buf, ",%zu,%zu,%f,%f,%zu,%zu,%zu,%zu\n", C.num_uniq_mems, C.total_mem_occ, C.max_mem_freq, C.min_mem_freq, C.high_occ_mem, C.low_occ_mem,
+                     C.num_mems_filter, C.num_chains_skipped);
+            *csv_out += buf;
+        }
+    }
     tt_sam += now_s() - tq;
     if (getenv("MH_TIMES")) fprintf(stderr, "align_host: drive %.3f merge %.3f sam %.3f s\n", tt_drive, tt_merge, tt_sam);
     st.reads += n_reads;

@@ -197,7 +197,7 @@ inline void rec(moni_ctx* c, int e) { (void)hipEventRecord(c->ev[e], c->stream);
 // ---- the text from the BWT -------------------------------------------------------------------------------------------------------------
 // The aligner's constructor takes the text from <prefix>.plain.slp (seed_finder.hpp:88-99), a ShapedSlp grammar whose format is not
 // available here; but the text is redundant with the r-index: BWT[p] = T[SA[p] - 1] and LF(p) is the position of SA[p] - 1, so a walk
-// that starts at a sampled position p (a run boundary: SA[p] is stored) spells the text backwards from SA[p] - 1.  The 2 r samples
+// that starts at a sampled position p (a run boundary: SA[p] - 1 is stored) spells the text backwards from there.  The 2 r samples
 // (samples_start, samples_last), sorted, cut the text into 2 r pieces; one lane per piece walks LF with the general rows of the move
 // structure from its sample down to the next smaller one and writes the run heads it passes.  keys / vals: the samples in increasing
 // order and where they sit in the BWT (run << 1 | 1 for the last position of the run).
@@ -207,16 +207,19 @@ __global__ void __launch_bounds__(256) text_rebuild_kernel(const moni_row_t* __r
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long wrote = 0;
     if (i < n_samples) {
-        const uint64_t s = keys[i], lo = i ? keys[i - 1] : 0;
-        if (s > lo && s <= n_text) {
+        // a sample is the text position OF the BWT symbol at its place (SA - 1 mod n: moni.hpp:127-128), so T[sample] = that symbol; the
+        // piece of this lane: positions s, s - 1, ... down to one above the next smaller sample (the smallest sample: down to 0)
+        const uint64_t s = keys[i];
+        const uint64_t count = i ? s - keys[i - 1] : s + 1;
+        if (count && s <= n_text) {
             const uint64_t v = vals[i];
             uint32_t run = (uint32_t)(v >> 1);
             moni_row_t A = ld_row(rows, run);
             uint64_t pos = (v & 1) ? ld_start(rows, run + 1) - 1 : row_start(A);
-            for (uint64_t j = s; j > lo; --j) {                 // T[j - 1] = BWT[pos], then pos = LF(pos)
-                text[j - 1] = heads[run];
-                ++wrote;
-                if (j - 1 == lo) break;
+            for (uint64_t t = 0; t < count; ++t) {               // T[s - t] = BWT[pos], then pos = LF(pos)
+                const uint64_t j = s - t;
+                if (j < n_text) { text[j] = heads[run]; ++wrote; }          // (position n - 1 is the terminator's: not part of the text)
+                if (t + 1 == count) break;
                 pos = row_lfbase(A) + (pos - row_start(A));
                 run = row_dest(A);
                 settle_run(rows, r, pos, run, A);
@@ -843,6 +846,58 @@ static int host_align_subset(moni_ctx* c, const moni_align_params_t& prm, const 
 static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bool ctx_out, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals,
                       const moni_align_params_t* prm, char** sam, uint64_t* sam_len, moni_align_stats_t* stats);
 
+// `-c` (aligner_ksw2.hpp:340-343, 417; csv.hpp:55-67): the SAM records of the batch and one line of MEM statistics per read.  A diagnostics mode: the
+// selection loop has to count the chains check_left_MEM skips, so every read goes through the host pipeline (align_host.hpp) over the GPU's seeds and DP
+// batches; the per-genome occurrence counts of the seeds come from genome_kernel over the seeds of the last moni_seed_run.
+static int genome_hi_lo(moni_ctx* c, const moni_align_params_t& prm, std::vector<uint64_t>& out) {
+    moni_index* I = c->idx;
+    const uint64_t n_mems = c->n_mems;
+    out.assign(n_mems, 0);
+    if (!n_mems) return MONI_OK;
+    occ_args_t A;
+    memset(&A, 0, sizeof A);
+    A.text = I->d_text;
+    A.phi.recs = I->d_phi; A.phi.dir = I->d_phi_dir; A.phi_inv.recs = I->d_phi_inv; A.phi_inv.dir = I->d_phi_inv_dir;
+    A.seq_starts = I->d_seq_starts; A.name_id = I->d_name_id; A.mems = c->mems.p; A.aux = c->aux.p; A.read_mem_off = c->read_mem_off.p;
+    A.n_mems = n_mems; A.lowers = c->lowers.p; A.filter_seeds = prm.filter_seeds; A.n_seeds_thr = prm.n_seeds_thr;
+    const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / (4ull * I->K.n_seq));          // rows of per-name counters: 256 MB at a time
+    DBuf<uint32_t> rows; DBuf<uint64_t> hl;
+    int rc;
+    if ((rc = rows.ensure(std::min(chunk, n_mems) * I->K.n_seq + 1)) || (rc = hl.ensure(n_mems + 1))) { rows.release(); hl.release(); return rc; }
+    bool ok = true;
+    for (uint64_t g0 = 0; g0 < n_mems && ok; g0 += chunk) {
+        const uint64_t g1 = std::min(n_mems, g0 + chunk);
+        ok = hipMemsetAsync(rows.p, 0, (g1 - g0) * I->K.n_seq * sizeof(uint32_t), c->stream) == hipSuccess;
+        if (ok) hipLaunchKernelGGL(genome_kernel, dim3((unsigned)((g1 - g0 + MS_BLOCK - 1) / MS_BLOCK)), dim3(MS_BLOCK), 0, c->stream, I->K, A, g0, g1, rows.p, hl.p);
+    }
+    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(out.data(), hl.p, n_mems * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    rows.release(); hl.release();
+    return ok ? MONI_OK : MONI_ENODEV;
+}
+
+int moni_align_csv_batch(moni_ctx_t* c, const moni_read_batch_t* b, const uint8_t* names, const uint64_t* name_off, const uint8_t* quals, const moni_align_params_t* prm,
+                         char** sam, uint64_t* sam_len, char** csv, uint64_t* csv_len, moni_align_stats_t* stats) {
+    if (!c || !b || !prm || !sam || !sam_len || !csv || !csv_len || (b->n_reads && (!names || !name_off))) return MONI_EINVAL;
+    if (prm->w >= 0 || prm->zdrop >= 0) return MONI_EINVAL;
+    HIPCHK(hipSetDevice(c->idx->device));
+    try {
+        int rc = moni_reads_upload(c, b);
+        if (rc) return rc;
+        GpuBackend be(c);
+        std::string out, lines;
+        mh::AlignStats st;
+        const std::function<int(std::vector<uint64_t>&)> hl = [&](std::vector<uint64_t>& v) { return genome_hi_lo(c, *prm, v); };
+        if ((rc = mh::align_batch(be, c->idx->hix, *prm, c->h_seq.data(), c->h_offs.data(), c->n_reads, names, name_off, quals ? quals + b->offsets[0] : nullptr, out, st, &hl, &lines))) return rc;
+        char* a = (char*)malloc(out.size() + 1); char* d = (char*)malloc(lines.size() + 1);
+        if (!a || !d) { free(a); free(d); return MONI_ENOMEM; }
+        memcpy(a, out.data(), out.size()); a[out.size()] = 0; memcpy(d, lines.data(), lines.size()); d[lines.size()] = 0;
+        *sam = a; *sam_len = out.size(); *csv = d; *csv_len = lines.size();
+        if (stats) { memset(stats, 0, sizeof *stats); stats->reads = st.reads; stats->aligned = st.aligned; stats->dp_tasks = st.dp_tasks; stats->dp_cells = st.dp_cells; stats->dp_rounds = st.dp_rounds;
+                     stats->t_seed = st.t_seed; stats->t_chain = st.t_chain; stats->t_dp = st.t_dp; stats->t_host = st.t_host; stats->handed_back = st.reads; }
+        return MONI_OK;
+    } catch (const std::bad_alloc&) { return MONI_ENOMEM; }
+}
+
 // Reads of MONI_LONG_READ bases or more do not go through the batch with the others: the seeding workspace is strided by the longest
 // read of a batch, so one long read among 262144 short ones would multiply its size (a 100 kb read: hundreds of GB).  They are
 // aligned as a batch of their own (host pipeline over the same kernels) and spliced back in; a read beyond the largest DP the
@@ -1123,7 +1178,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         if (use_fast) for (int x = 0; x < (int)std::min<uint64_t>(n_sub, AK_NSET); ++x) {
             moni_ctx::AfSet& S = c->af[x];
             if ((rc = S.plans.ensure(sub_reads + 1)) || (rc = S.tasks.ensure(af_slot_cap)) || (rc = S.res.ensure(af_slot_cap)) || (rc = S.ntasks.ensure(sub_reads + 8)) || (rc = S.bin_q.ensure((size_t)AF_NBIN * af_task_cap)) ||
-                (rc = S.task_pos.ensure(af_slot_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.big_list.ensure(2 * (sub_reads + 1))) ||
+                (rc = S.task_pos.ensure(af_slot_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.big_list.ensure(3 * (sub_reads + 1))) ||
                 (rc = S.ctr.ensure(AF_NCTR)) || (rc = S.txt_cur.ensure(AF_TXT_SHARDS * 8)) || (rc = S.bnd.ensure((size_t)af_dp_grid * AF_QCAP * 64)) || (rc = S.chunks.ensure(af_chunk_cap)) || (rc = S.dirs.ensure(af_dirs_cap)) || (rc = S.fin.ensure((size_t)af_fin_grid * 64 * sizeof(af_fin_t))))
                 return rc;
         }
@@ -1310,7 +1365,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 G.A = A;
                 G.plans = S.plans.p; G.tasks = S.tasks.p; G.task_cap = af_slot_cap; G.ntasks = S.ntasks.p; G.res = S.res.p; G.bin_q = S.bin_q.p; G.bin_cap = af_task_cap; G.task_pos = S.task_pos.p;
                 G.chunks = S.chunks.p; G.chunk_cap = af_chunk_cap; G.dirs = S.dirs.p; G.dirs_cap = af_dirs_cap; G.tb_task = S.tb_task.p; G.tb = S.tb.p; G.tb_cap = af_tb_cap;
-                G.fb_n = c->fb_all.p + 16 * k; G.fb_list = c->fb_all.p + 16 * n_sub + k * (sub_reads + 1); G.big_list = S.big_list.p; G.huge_list = S.big_list.p + (sub_reads + 1); G.fin_scratch = S.fin.p; G.fin_stride = sizeof(af_fin_t); G.ctr = S.ctr.p;
+                G.fb_n = c->fb_all.p + 16 * k; G.fb_list = c->fb_all.p + 16 * n_sub + k * (sub_reads + 1); G.big_list = S.big_list.p; G.huge_list = S.big_list.p + (sub_reads + 1); G.list0 = S.big_list.p + 2 * (sub_reads + 1); G.fin_scratch = S.fin.p; G.fin_stride = sizeof(af_fin_t); G.ctr = S.ctr.p;
                 G.bnd = S.bnd.p;
                 G.txt_cur = S.txt_cur.p; G.txt_shard_words = txt_per / (AF_TXT_SHARDS + 1);
                 HIPCHK(hipMemsetAsync(S.txt_cur.p, 0, AF_TXT_SHARDS * 8 * sizeof(unsigned long long), sx));
@@ -1325,6 +1380,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
 #endif
                 if (const char* v = getenv("MONI_AF_DBG")) G.dbg |= (uint32_t)atoi(v) & 64u;          // 64: the serial anchor sort (cross-check), any build
                 HIPCHK(hipMemsetAsync(S.ctr.p, 0, AF_NCTR * sizeof(uint32_t), sx));
+                hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
                 {
                     static const int k1occ = getenv("MONI_AF_K1OCC") ? atoi(getenv("MONI_AF_K1OCC")) : 8;      // 8 waves/SIMD: 32 reads in flight per CU (4.9 KB of LDS each); measured 5, 6, 8
                     const dim3 g1((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 4 * k1occ));

@@ -237,28 +237,27 @@ MONI_HD void ms_step(const moni_consts_t& K, const lds_tables_t& L, const moni_r
         const uint32_t hh = (uint32_t)(w0 >> 56) & 3u;
         if (hc == hh) {                                      // bwt[pos] == c
             S.sample--;
-            S.off += (uint32_t)(w0 >> 12) & 0xFFFu;
-            S.run = (uint32_t)(w0 >> 24);
+            const uint64_t w1 = q0.y;
+            const uint32_t room = (uint32_t)w1 & 0xFFFu, l1 = (uint32_t)(w1 >> 12) & 0xFFFu;
+            uint32_t run = (uint32_t)(w0 >> 24), o = S.off;
+            if (o < room) o += (uint32_t)(w0 >> 12) & 0xFFFu;              // inside the destination run
+            else { o -= room; ++run; if (o >= l1) { o -= l1; ++run; } }     // in the run after it, or the one after that (whose own length the next step checks)
+            S.off = o; S.run = run;
             return;
         }
         ++n_jumps;
         const uint32_t sl = (hc - hh - 1u) & 3u;             // 0..2
-        const moni_u64x2 q1 = *reinterpret_cast<const moni_u64x2*>(&fr->w[2]);   // w2, w3
-        const moni_u64x2 q2 = *reinterpret_cast<const moni_u64x2*>(&fr->w[4]);   // w4, w5
-        const moni_u64x2 q3 = *reinterpret_cast<const moni_u64x2*>(&fr->w[6]);   // w6, w7
-        const uint64_t ws = sl == 0 ? q0.y : sl == 1 ? q1.x : q1.y;
+        const moni_u64x2 qs = *reinterpret_cast<const moni_u64x2*>(&fr->w[2 + 2 * sl]);   // the slot and its two samples' low words: the row's second (and last) 16 bytes this step reads
+        const uint64_t ws = qs.x;
         const uint32_t thr_off = (uint32_t)ws & 0xFFFu;
         const uint32_t sdoff = (uint32_t)(ws >> 12) & 0xFFFu;
         const uint32_t sdest = (uint32_t)(ws >> 24);
         if (S.off < thr_off) {                               // jump up: last position of the previous c-run
-            const uint64_t lo = sl == 0 ? (q2.y >> 32) : sl == 1 ? (q3.x & 0xFFFFFFFFull) : (q3.x >> 32);
-            const uint64_t hi = (q3.y >> (8 * sl)) & 0xFFull;
-            S.sample = lo | (hi << 32);
+            S.sample = (qs.y >> 32) | (((q0.y >> (24 + 8 * sl)) & 0xFFull) << 32);
             if (sdoff == 0) { S.run = sdest - 1; S.off = MONI_OFF_END; }
             else { S.run = sdest; S.off = sdoff - 1; }
         } else {                                             // jump down: first position of the next c-run
-            const uint64_t lo = sl == 0 ? (q2.x & 0xFFFFFFFFull) : sl == 1 ? (q2.x >> 32) : (q2.y & 0xFFFFFFFFull);
-            S.sample = lo | ((ws >> 56) << 32);
+            S.sample = (qs.y & 0xFFFFFFFFull) | ((ws >> 56) << 32);
             S.run = sdest; S.off = sdoff;
         }
         return;
@@ -586,4 +585,22 @@ MONI_HD void occ_task(const moni_consts_t& K, const occ_args_t& A, uint64_t g, u
         }
     }
     phi_steps += W.phi_steps;
+}
+
+// ------------------------------------------------------------------------------------------------
+// genome_task: the MEM statistics of `-c` (calculate_MEM_stats, aligner_ksw2.hpp:1868-1902) need, for every seed, the largest and the smallest
+// count its count_dict holds: how often it occurs on any one genome, filtered occurrences included (populate_dict counts before the per-genome
+// cap drops an occurrence, seed_finder.hpp:331-343).  One lane per final seed slot repeats the slot's walk with a row of per-name counters of
+// its own (rows: n slots x n_seq counters, zeroed by the caller) and leaves hi_lo[g] = largest | smallest << 32.
+// ------------------------------------------------------------------------------------------------
+MONI_HD void genome_task(const moni_consts_t& K, const occ_args_t& A, uint64_t g, uint64_t g0, uint32_t* __restrict__ rows, uint64_t* __restrict__ hi_lo) {
+    const uint32_t ax = A.aux[g];
+    const moni_mem_t M = A.mems[g];
+    walk_t W; W.phi_steps = 0;
+    W.total = W.filtered = W.kept = 0; W.last_kept = M.pos; W.names = rows + (g - g0) * K.n_seq; W.out = nullptr; W.out_cap = 0;
+    uint64_t upper = 0, lower = 0;
+    walk_seed(W, A, K, M.pos, M.pos, ax == 0xFFFFFFFEu ? A.lowers[g] : M.pos, M.len, upper, lower);      // a left half walks down from its parent's lower suffix
+    uint32_t hi = 0, lo = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < K.n_seq; ++i) { const uint32_t v = W.names[i]; if (v) { hi = v > hi ? v : hi; lo = v < lo ? v : lo; } }
+    hi_lo[g] = (uint64_t)hi | ((uint64_t)(hi ? lo : 0u) << 32);
 }

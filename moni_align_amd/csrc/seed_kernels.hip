@@ -141,3 +141,9 @@ ms_len_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const 
         prev_pos_plus_one = pos + 1;
     }
 }
+
+// per-seed largest / smallest per-genome occurrence count of slots [g0, g1) (`-c`, genome_task)
+__global__ void __launch_bounds__(MS_BLOCK) genome_kernel(const moni_consts_t K, occ_args_t A, uint64_t g0, uint64_t g1, uint32_t* __restrict__ rows, uint64_t* __restrict__ hi_lo) {
+    const uint64_t g = g0 + (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
+    if (g < g1) genome_task(K, A, g, g0, rows, hi_lo);
+}

@@ -19,7 +19,7 @@
 // in-order window.  -m writes the report-MEMs records (aligner_ksw2.hpp:346-373);
 // --ms / --mems write the legacy `moni ms` / `moni mems` text outputs (src/matching_statistics.cpp:520-610, src/mems.cpp:520-600).
 // -n loads <prefix>.thrbv.full.ms (no LCP samples); -q is accepted (the text comes from the BWT, not from either grammar).
-// Not implemented here (exit 1 with a message): -c, -Z.
+// -c writes <sam>.csv (per-read MEM statistics, csv.hpp:55-67; single-end, through the host pipeline).  Not implemented here (exit 1 with a message): -Z.
 #include <fcntl.h>
 #include <getopt.h>
 #include <libgen.h>
@@ -466,7 +466,8 @@ int main(int argc, char** argv) {
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
     Args a;
     parse(argc, argv, a);
-    if (a.csv || a.secondary) die("options -c, -Z are not implemented in moni-hip-align yet");
+    if (a.secondary) die("option -Z is not implemented in moni-hip-align yet");
+    if (a.csv && (!a.mate1.empty() || !a.mate2.empty())) die("option -c is implemented for single-end input (-p) only");
     // -n: <prefix>.thrbv.full.ms (ms_pointers<>: no LCP samples; the occurrence walks measure the LCP on the text, seed_finder.hpp:346-370).
     // -q: the reference would take the text from <prefix>.slp (SelfShapedSlp) instead of <prefix>.plain.slp; both grammars spell the same
     //     text and neither is read here - the text is rebuilt from the BWT - so the flag changes nothing (align_full_ksw2.cpp:414-426)
@@ -497,7 +498,7 @@ int main(int argc, char** argv) {
         return 0;
     }
     const std::string idx_path = a.filename + ".mfi";
-    const bool fast = mapped && !legacy && !a.report_mems && getenv("MONI_CLI_QUEUE_PATH") == nullptr;
+    const bool fast = mapped && !legacy && !a.report_mems && !a.csv && getenv("MONI_CLI_QUEUE_PATH") == nullptr;
     const int per_gpu = legacy ? 1 : (fast ? a.ctx_per_gpu : 2);                      // contexts (batches in flight) per GPU
     std::vector<moni_index_t*> idx(a.gpus, nullptr);
     std::vector<moni_ctx_t*> ctx((size_t)a.gpus * per_gpu, nullptr);
@@ -597,6 +598,12 @@ int main(int argc, char** argv) {
         out = fopen(sam_filename.c_str(), "w");
         if (!out) die("open() file " + sam_filename + " failed");
         char* h; uint64_t hl; if (moni_sam_header(idx[0], &h, &hl)) die("header"); put(h, hl, out); moni_free(h);
+        if (a.csv) {          // -c: <sam>.csv (align_reads_dispatcher.hpp:302,334-339), header of aligner::to_csv (aligner_ksw2.hpp:3230-3234)
+            out2 = fopen((sam_filename + ".csv").c_str(), "w");
+            if (!out2) die("open() file " + sam_filename + ".csv failed");
+            static const char hdr[] = "Read,Unique,Total,Max_Freq,Min_Freq,Highest_Occ,Lowest_Occ,Filtered,Chains_Skipped\n";
+            put(hdr, sizeof hdr - 1, out2);
+        }
     }
     auto t0 = std::chrono::steady_clock::now();
     // ---- reader thread -> bounded queue of parsed batches -> workers -> bounded in-order window -> writer thread ----
@@ -693,6 +700,11 @@ int main(int argc, char** argv) {
             } else if (a.report_mems) {
                 if (moni_report_mems_batch(C, &rb, b.names.data(), b.name_off.data(), b.has_qual ? b.qual.data() : nullptr, &a.P, &d.a, &d.la)) die("moni_report_mems_batch failed");
                 n_al = b.n();
+            } else if (a.csv) {
+                moni_align_stats_t st; char* cs = nullptr; uint64_t cl = 0;
+                if (moni_align_csv_batch(C, &rb, b.names.data(), b.name_off.data(), b.has_qual ? b.qual.data() : nullptr, &a.P, &d.a, &d.la, &cs, &cl, &st)) die("moni_align_csv_batch failed");
+                d.b.assign(cs, cl); moni_free(cs);
+                n_al = st.aligned;
             } else {
                 moni_align_stats_t st;
                 if (moni_align_batch(C, &rb, b.names.data(), b.name_off.data(), b.has_qual ? b.qual.data() : nullptr, &a.P, &d.a, &d.la, &st)) die("moni_align_batch failed");

@@ -164,12 +164,22 @@ def _group_starts(sorted_keys: torch.Tensor):
     return flag, gstart
 
 
-def suffix_array(codes: torch.Tensor, bits: int, keep_levels: bool = True, log=None):
+def _rank32(rank: torch.Tensor) -> torch.Tensor:
+    """a level's ranks for lcp_from_levels, which only compares them for equality: the low 32 bits as int32 (explicit wrap-around, exact for
+    ranks < 2^31), so that a level costs 4 bytes per position for any n < 2^32 (ranks are group starts < n: distinct ranks stay distinct)"""
+    return (((rank + (1 << 31)) & 0xFFFFFFFF) - (1 << 31)).to(torch.int32)
+
+
+def suffix_array(codes: torch.Tensor, bits: int, keep_levels: bool = True, log=None, _force_wide: bool = False):
     """codes: uint8/int64 [n] with a unique smallest 0 at the end.  Returns (sa, key0, k0, levels)
     where levels = [(k, rank_k int32)] for every doubling level (rank_k equal <=> first k
-    symbols equal)."""
+    symbols equal).  n < 2^32 (the levels keep 32 bits of a rank); the doubling key rank * (n + 1) + rank' fits a signed 64-bit word up to
+    n = 3.03e9 - beyond that (_force_wide: always, for tests) a level is two stable sorts instead of one."""
     dev = codes.device
     n = codes.numel()
+    if n >= (1 << 32):
+        raise ValueError("index_build: n = %d does not fit the 32-bit rank levels of the LCP computation" % n)
+    wide = _force_wide or (n + 1) * (n + 1) >= (1 << 63)
     k0 = 60 // bits
     c64 = torch.cat([codes.to(torch.int64), torch.zeros(k0, dtype=torch.int64, device=dev)])
     key0 = torch.zeros(n, dtype=torch.int64, device=dev)
@@ -181,7 +191,7 @@ def suffix_array(codes: torch.Tensor, bits: int, keep_levels: bool = True, log=N
     del skey
     rank = torch.empty(n, dtype=torch.int64, device=dev)
     rank[sa] = gstart
-    levels = [(k0, rank.to(torch.int32))] if keep_levels else []
+    levels = [(k0, _rank32(rank))] if keep_levels else []
     k = k0
     while not bool(flag.all()):
         if log:
@@ -189,17 +199,32 @@ def suffix_array(codes: torch.Tensor, bits: int, keep_levels: bool = True, log=N
         r2 = torch.zeros(n, dtype=torch.int64, device=dev)
         if k < n:
             r2[: n - k] = rank[k:] + 1
-        key = rank * (n + 1) + r2
-        del r2
-        skey, sa = torch.sort(key)
-        del key
-        flag, gstart = _group_starts(skey)
-        del skey
+        if not wide:
+            key = rank * (n + 1) + r2
+            del r2
+            skey, sa = torch.sort(key)
+            del key
+            flag, gstart = _group_starts(skey)
+            del skey
+        else:          # (rank, rank') as two keys: stable sort by the second, then by the first
+            _, p1 = torch.sort(r2, stable=True)
+            _, p2 = torch.sort(rank[p1], stable=True)
+            sa = p1[p2]
+            del p1, p2
+            a, b2 = rank[sa], r2[sa]
+            del r2
+            n_ = a.numel()
+            flag = torch.ones(n_, dtype=torch.bool, device=dev)
+            flag[1:] = (a[1:] != a[:-1]) | (b2[1:] != b2[:-1])
+            del a, b2
+            idx = torch.arange(n_, device=dev, dtype=torch.int64)
+            gstart = torch.cummax(torch.where(flag, idx, torch.zeros_like(idx)), 0).values
+            del idx
         rank = torch.empty(n, dtype=torch.int64, device=dev)
         rank[sa] = gstart
         k *= 2
         if keep_levels:
-            levels.append((k, rank.to(torch.int32)))
+            levels.append((k, _rank32(rank)))
     return sa, key0, k0, levels
 
 

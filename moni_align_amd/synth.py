@@ -203,6 +203,44 @@ def make_reads(pg: Pangenome, n_reads: int, read_len: int = 150, seed: int = 150
     return np.ascontiguousarray(out)
 
 
+def make_pairs(pg: Pangenome, n_pairs: int, read_len: int = 150, seed: int = 350, ins_mean: float = 350.0, ins_sd: float = 30.0,
+               sub_rate: float = 0.005):
+    """FR read pairs: fragments of length N(ins_mean, ins_sd) (at least 2 L + 10) from uniform haplotypes / positions, substitutions at sub_rate,
+    mate 1 = the fragment's first L bases, mate 2 = the reverse complement of its last L; half of the fragments come from the other strand (the
+    mates swap).  Returns (mates [2 n, L] uint8 interleaved: rows 2p and 2p + 1 are pair p, insert sizes [n])."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    L = read_len
+    hap = rng.integers(0, len(pg.seqs), size=n_pairs)
+    ins = np.maximum(2 * L + 10, rng.normal(ins_mean, ins_sd, size=n_pairs)).astype(np.int64)
+    out = np.empty((2 * n_pairs, L), dtype=np.uint8)
+    col = np.arange(L)
+    for h, s in enumerate(pg.seqs):
+        sel = np.nonzero(hap == h)[0]
+        if len(sel) == 0:
+            continue
+        start = (rng.random(len(sel)) * (len(s) - ins[sel])).astype(np.int64)
+        a = s[start[:, None] + col[None, :]]
+        b = s[(start + ins[sel] - L)[:, None] + col[None, :]]
+        out[2 * sel] = a
+        out[2 * sel + 1] = revcomp(b)
+    code = np.full(256, 0, dtype=np.uint8)
+    code[_ACGT] = np.arange(4, dtype=np.uint8)
+    sub = rng.random(out.shape) < sub_rate
+    shift = rng.integers(1, 4, size=out.shape, dtype=np.uint8)
+    out = np.where(sub, _ACGT[(code[out] + shift) & 3], out)
+    swap = np.nonzero(rng.random(n_pairs) < 0.5)[0]
+    tmp = out[2 * swap].copy(); out[2 * swap] = out[2 * swap + 1]; out[2 * swap + 1] = tmp
+    return np.ascontiguousarray(out), ins
+
+
+def make_pair_names(n_pairs: int, prefix: str = "simulated"):
+    """names `simulated.<p>/1`, `simulated.<p>/2` of the interleaved mates, ragged bytes + offsets"""
+    names = [("%s.%d/%d" % (prefix, p, k)).encode() for p in range(n_pairs) for k in (1, 2)]
+    off = np.zeros(2 * n_pairs + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in names])
+    return np.frombuffer(b"".join(names), dtype=np.uint8).copy(), off
+
+
 READ_BLOCK = 250000
 
 

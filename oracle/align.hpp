@@ -558,14 +558,49 @@ struct aligner {
         return score;
     }
 
+    // include/common/csv.hpp:26-52
+    struct csv_t {
+        size_t num_uniq_mems = 0, total_mem_occ = 0;
+        double max_mem_freq = 0, min_mem_freq = 1;
+        size_t high_occ_mem = 0, low_occ_mem = 0, num_mems_filter = 0, num_chains_skipped = 0;
+    };
+    // aligner_ksw2.hpp:1868-1902
+    void calculate_MEM_stats(const std::vector<mem_t>& mems, csv_t& csv) {
+        csv.num_uniq_mems = mems.size();
+        for (size_t i = 0; i < mems.size(); ++i) {
+            csv.total_mem_occ += mems[i].total_occ;
+            csv.num_mems_filter += mems[i].num_filtered;
+        }
+        for (size_t i = 0; i < mems.size(); ++i) {
+            double mem_freq = (mems[i].occs.size() / (static_cast<double>(csv.total_mem_occ)));
+            csv.max_mem_freq = (csv.max_mem_freq > mem_freq ? csv.max_mem_freq : mem_freq);
+            csv.min_mem_freq = (csv.min_mem_freq > mem_freq ? mem_freq : csv.min_mem_freq);
+            for (auto it = mems[i].count_dict.begin(); it != mems[i].count_dict.end(); ++it) {
+                if (csv.high_occ_mem == 0 && csv.low_occ_mem == 0) { csv.high_occ_mem = it->second; csv.low_occ_mem = it->second; }
+                else {
+                    csv.high_occ_mem = (csv.high_occ_mem > it->second ? csv.high_occ_mem : it->second);
+                    csv.low_occ_mem = (csv.low_occ_mem > it->second ? it->second : csv.low_occ_mem);
+                }
+            }
+        }
+    }
+    // include/common/csv.hpp:55-67
+    static void write_csv(std::string& out, const std::string& name, const csv_t& c) {
+        char buf[256];
+        out += name;
+        snprintf(buf, sizeof buf, ",%zu,%zu,%f,%f,%zu,%zu,%zu,%zu\n", c.num_uniq_mems, c.total_mem_occ, c.max_mem_freq, c.min_mem_freq, c.high_occ_mem, c.low_occ_mem,
+                 c.num_mems_filter, c.num_chains_skipped);
+        out += buf;
+    }
+
     // aligner_ksw2.hpp:1905-1933
-    void seed_freq_filter(std::vector<mem_t>& mems, const double freq) {
+    void seed_freq_filter(std::vector<mem_t>& mems, const double freq, csv_t& csv) {
         size_t total_mem_occ = 0;
         std::vector<size_t> delete_ind;
         for (size_t i = 0; i < mems.size(); ++i) total_mem_occ += mems[i].occs.size();
         for (size_t i = 0; i < mems.size(); ++i) {
             double mem_freq = (static_cast<double>(mems[i].occs.size()) / total_mem_occ);
-            if (mem_freq > freq) delete_ind.push_back(i);
+            if (mem_freq > freq) { delete_ind.push_back(i); csv.num_mems_filter += (mems[i].occs.size()); }
         }
         std::reverse(delete_ind.begin(), delete_ind.end());
         for (size_t idx : delete_ind) mems.erase(mems.begin() + idx);
@@ -583,6 +618,7 @@ struct aligner {
         std::vector<std::pair<size_t, size_t>> anchors;
         std::vector<chain_t> chains;
         std::string mems_sam;          // report_mems: the records of aligner_ksw2.hpp:346-373
+        csv_t csv;                     // -c: the MEM statistics (aligner_ksw2.hpp:154, 340-343, 417)
     };
 
     // aligner_ksw2.hpp:553-597
@@ -630,7 +666,8 @@ struct aligner {
         mem_finder.find_mems(al.read->seq.data(), al.read->seq.size(), al.mems, 0, MATE_1 | MATE_F);
         mem_finder.find_mems(al.read_rev.seq.data(), al.read_rev.seq.size(), al.mems, 0, MATE_1 | MATE_RC);
         mem_finder.populate_seeds(al.mems, cfg.report_mems);
-        if (cfg.filter_freq) seed_freq_filter(al.mems, cfg.freq_thr);
+        calculate_MEM_stats(al.mems, al.csv);                                  // (if (csv): the statistics change nothing else)
+        if (cfg.filter_freq) seed_freq_filter(al.mems, cfg.freq_thr, al.csv);
         if (cfg.report_mems) {                      // aligner_ksw2.hpp:346-373: one secondary record per occurrence of every MEM
             for (size_t i = 0; i < al.mems.size(); ++i) {
                 const read_t& src = (al.mems[i].mate & MATE_RC) ? al.read_rev : *al.read;
@@ -665,7 +702,7 @@ struct aligner {
         while (i < al.chains.size() and different_scores.size() < cfg.check_k) {
             different_scores.insert(al.chains[i].score);
             if (cfg.left_mem_check) {
-                if (check_left_MEM(left_mem_vec, al, i)) { ++i; continue; }
+                if (check_left_MEM(left_mem_vec, al, i)) { ++i; al.csv.num_chains_skipped++; continue; }
             }
             if (different_scores.size() < cfg.check_k) {
                 auto chain = al.chains[i];
@@ -714,7 +751,7 @@ struct aligner {
     }
 
     // aligner_ksw2.hpp:314-325 + alignment_t ctor 169-176: one read -> one SAM line
-    bool align_read(const read_t& read, std::string& out) {
+    bool align_read(const read_t& read, std::string& out, std::string* csv_out = nullptr) {
         static const unsigned char* ct = nullptr;
         static unsigned char ctab[256];
         if (!ct) {
@@ -735,6 +772,7 @@ struct aligner {
         if (not align(al)) al.sam.flag = 4;               // set_sam_not_aligned
         if (!cfg.report_mems) write_sam(out, al.sam);
         else out += al.mems_sam;
+        if (csv_out) write_csv(*csv_out, read.name, al.csv);                  // alignment.record_csv (aligner_ksw2.hpp:322-323)
         return al.aligned;
     }
 

@@ -310,14 +310,14 @@ struct aligner_pe : aligner {
                 al.mems.erase(al.mems.begin() + al.n_mems_dir1, al.mems.end());
             if ((al.avg_seed_length_dir2 > al.avg_seed_length_dir1) and ((al.avg_seed_length_dir2 - al.avg_seed_length_dir1) > pe.dir_thr))
                 al.mems.erase(al.mems.begin(), al.mems.begin() + al.n_mems_dir1);
-            if (cfg.filter_freq) seed_freq_filter(al.mems, cfg.freq_thr);
+            if (cfg.filter_freq) { csv_t csv_m1; seed_freq_filter(al.mems, cfg.freq_thr, csv_m1); }
         } else {
             mem_finder.find_mems(al.mate1.seq.data(), l1, al.mems, 0, MATE_1 | MATE_F);
             mem_finder.find_mems(al.mate1_rev.seq.data(), l1, al.mems, l2, MATE_1 | MATE_RC);
             mem_finder.find_mems(al.mate2.seq.data(), l2, al.mems, 0, MATE_2 | MATE_F);
             mem_finder.find_mems(al.mate2_rev.seq.data(), l2, al.mems, l1, MATE_2 | MATE_RC);
             mem_finder.populate_seeds(al.mems, cfg.report_mems);
-            if (cfg.filter_freq) seed_freq_filter(al.mems, cfg.freq_thr);
+            if (cfg.filter_freq) { csv_t csv_m1; seed_freq_filter(al.mems, cfg.freq_thr, csv_m1); }
         }
         al.frac_rep_m1 = 0.0; al.frac_rep_m2 = 0.0;                  // compute_frac_rep (aligner_ksw2.hpp:1973-1981) returns 0.0
         al.chained = find_chains(al.mems, al.anchors, al.chains, cfg.chain);

@@ -205,6 +205,24 @@ char* orc_align_batch(void* h, const uint8_t* seqs, const uint64_t* offsets, uin
     *out_len = all.size();
     return buf;
 }
+// `-c`: the CSV lines of the batch (include/common/csv.hpp:55-67; no header), one thread
+char* orc_align_csv(void* h, const uint8_t* seqs, const uint64_t* offsets, uint64_t n_reads, const uint8_t* names, const uint64_t* name_off, uint64_t* out_len) {
+    const FlatIndex& ix = *(FlatIndex*)h;
+    align_config_t cfg;
+    aligner A(ix, cfg);
+    std::string sam, csv;
+    for (uint64_t rd = 0; rd < n_reads; ++rd) {
+        read_t r;
+        r.name.assign((const char*)names + name_off[rd], (const char*)names + name_off[rd + 1]);
+        r.seq.assign((const char*)seqs + offsets[rd], (const char*)seqs + offsets[rd + 1]);
+        A.align_read(r, sam, &csv);
+    }
+    char* buf = (char*)malloc(csv.size() + 1);
+    memcpy(buf, csv.data(), csv.size());
+    buf[csv.size()] = 0;
+    *out_len = csv.size();
+    return buf;
+}
 // Paired-end path (align_pe.hpp; find_orphan == 0: the reference with -u), one thread, st_align's batch order: mate k of pair i is
 // read i of batch k.  out[0] = aligned pairs, out[1..4] = the learnt insert-size model (count, mean, std dev, complete).
 char* orc_align_pe(void* h, const uint8_t* seqs1, const uint64_t* off1, const uint8_t* seqs2, const uint64_t* off2, uint64_t n_pairs,

@@ -62,6 +62,8 @@ def lib():
         L.orc_align_batch.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint64] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int,
                                                                                                      ctypes.c_void_p, ctypes.c_void_p]
         L.orc_free.argtypes = [ctypes.c_void_p]
+        L.orc_align_csv.restype = ctypes.c_void_p
+        L.orc_align_csv.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint64] + [ctypes.c_void_p] * 3
         L.orc_index_set_no_lcp.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_report_mems_batch.restype = ctypes.c_void_p
         L.orc_report_mems_batch.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint64] + [ctypes.c_void_p] * 4
@@ -191,6 +193,20 @@ def align_batch(oidx: "OracleIndex", seqs: np.ndarray, offsets: np.ndarray, name
         lib().orc_free(p)
     keys = ["lf_steps", "jumps", "phi_steps", "text_cmp", "dp_cells", "dp_calls", "ref_bytes", "aligned"]
     return sam, {k: int(v) for k, v in zip(keys, cnt)}
+
+
+def align_csv(oidx: "OracleIndex", seqs: np.ndarray, offsets: np.ndarray, names, name_off) -> bytes:
+    """the `-c` MEM statistics of the batch (one CSV line per read, no header), one thread"""
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    names = np.ascontiguousarray(names, dtype=np.uint8)
+    name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
+    out_len = ctypes.c_uint64()
+    p = lib().orc_align_csv(oidx._h, seqs.ctypes.data, offsets.ctypes.data, len(offsets) - 1, names.ctypes.data, name_off.ctypes.data, ctypes.byref(out_len))
+    try:
+        return ctypes.string_at(p, out_len.value)
+    finally:
+        lib().orc_free(p)
 
 
 def align_pe(oidx: "OracleIndex", seqs1, offs1, seqs2, offs2, names1, noff1, names2, noff2, quals1=None, quals2=None, b_size: int = 512,

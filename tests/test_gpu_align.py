@@ -272,3 +272,27 @@ def test_header(medium_case, env):
     h = ctx.sam_header().decode().split("\n")
     assert h[0] == "@HD\tVN:1.6\tSO:unknown" and h[-2] == "@PG\tID:moni\tPN:moni\tVN:0.1.0"
     assert h[1] == "@SQ\tSN:chr19\tLN:%d" % len(medium_case.pg.seqs[0])
+
+
+def test_csv_mem_statistics_equal_the_oracle(medium_case, env):
+    """-c (moni_align_csv_batch): per read the number of MEMs, their occurrences, the extreme frequencies, the largest / smallest count of one MEM
+    on one genome (count_dict, filtered occurrences included), what the filters dropped and how many chains check_left_MEM skipped - equal to
+    the oracle's calculate_MEM_stats / seed_freq_filter / selection loop (aligner_ksw2.hpp:340-343, 417, 1868-1933); the SAM text is unchanged"""
+    from oracle import orc
+    o, ctx = env
+    reads = medium_case.synth.make_reads(medium_case.pg, 3000, 150, seed=99, sub_rate=0.02)
+    rl = list(reads) + [np.frombuffer(b"ACGT" * 10, np.uint8), np.frombuffer(b"N" * 70, np.uint8)]
+    offs = np.zeros(len(rl) + 1, dtype=np.uint64); offs[1:] = np.cumsum([len(r) for r in rl])
+    seq = np.concatenate(rl)
+    names, noff = orc.make_names(len(rl))
+    q = np.full(len(seq), ord("I"), np.uint8)
+    sam, csv, st = ctx.align_csv_batch(seq, offs, names, noff, q, host_threads=8)
+    want_sam, _ = orc.align_batch(o, seq, offs, names, noff, q, threads=8)
+    assert sam == want_sam
+    want_csv = orc.align_csv(o, seq, offs, names, noff)
+    if csv != want_csv:
+        g, w = csv.split(b"\n"), want_csv.split(b"\n")
+        i = next(k for k in range(min(len(g), len(w))) if g[k] != w[k])
+        raise AssertionError("CSV differs at line %d: got %r want %r" % (i, g[i], w[i]))
+    cols = np.array([[float(x) for x in ln.split(b",")[1:]] for ln in csv.split(b"\n") if ln])
+    assert (cols[:, 7] > 0).any() and (cols[:, 4] >= cols[:, 5]).all() and (cols[:, 0] > 0).sum() > 2900      # chains were skipped somewhere; high >= low

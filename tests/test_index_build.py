@@ -69,3 +69,23 @@ def test_text_layout(small_case):
         assert int(fi.seq_starts[i + 1]) == acc + pg.w
         acc += last
     assert acc == len(t)
+
+
+def test_wide_doubling_and_32_bit_rank_levels_equal_the_default_path():
+    """the paths a text of 2^31 positions or more takes - a doubling level as two stable sorts (the packed key rank * (n + 1) + rank' would
+    overflow 64 bits beyond n = 3.03e9), level ranks kept as the low 32 bits with explicit wrap-around - forced on a small text: same suffix
+    array, same LCP array; and the wrap-around of ranks at and beyond 2^31 keeps distinct ranks distinct"""
+    import torch
+    from moni_align_amd import index_build as ib
+    rng = np.random.default_rng(3)
+    unit = rng.integers(1, 5, size=400)
+    codes = np.concatenate([unit, unit[:250], rng.integers(1, 5, size=300), unit, [0]]).astype(np.uint8)      # repeats: many doubling levels
+    c = torch.from_numpy(codes)
+    sa0, key0, k0, lv0 = ib.suffix_array(c, 3)
+    sa1, key1, k1, lv1 = ib.suffix_array(c, 3, _force_wide=True)
+    assert torch.equal(sa0, sa1) and k0 == k1 and len(lv0) == len(lv1) and len(lv0) >= 4
+    assert all(torch.equal(a[1], b[1]) for a, b in zip(lv0, lv1))
+    assert torch.equal(ib.lcp_from_levels(sa0, key0, k0, 3, lv0), ib.lcp_from_levels(sa1, key1, k1, 3, lv1))
+    r = torch.tensor([0, 5, (1 << 31) - 1, 1 << 31, (1 << 31) + 7, (1 << 32) - 1], dtype=torch.int64)
+    w = ib._rank32(r)
+    assert w.dtype == torch.int32 and len(set(w.tolist())) == len(r) and w[:3].tolist() == [0, 5, (1 << 31) - 1]

@@ -107,8 +107,12 @@ struct af_res_t { int32_t mqe, mqe_t, score, flags; };      // flags: 1 = a wild
 struct af_chunk_t { uint32_t bin, start, n, qhi; uint64_t dir_off; };
 struct af_tb_t { uint32_t n_ops; uint32_t ops[AF_TB_CIG]; };      // raw backtrack order (end -> start); n_ops = ~0u: did not fit
 
+struct pe_sel_t;
 struct af_args_t {
     ak_args_t A;                             // reads / text / seeds / record pools: as align_kernel
+    uint32_t pe;                             // paired-end launch (pe_fast.hip): a plan belongs to a PAIR, plan r_in = pair A.read_lo + r_in = reads 2 * (A.read_lo + r_in) + mate;
+                                             // a chain to score (af_cand_t) is one mate's share of a paired chain, its mate in bit 0 of af_cand_t::pad
+    pe_sel_t* pe_sel;                        // per pair: what pe_select_kernel decided (pe_fast.hip)
     af_plan_t* plans;                        // per read of the launch
     moni_dp_task_t* tasks; uint32_t task_cap;    // slots: AF_MAX_TASKS_READ per read of the launch (chain_plan_kernel writes a read's tasks to its own slots: no shared
                                              // counter - one address takes only ~70 M atomics/s, one per read was the kernel's bound), then the global problems
@@ -146,16 +150,17 @@ enum { AF_GRP_LARGE = 0, AF_GRP_SMALL = 1, AF_GRP_GLOBAL = 2 };
 // chain_plan_kernel
 // ------------------------------------------------------------------------------------------------------------------------------
 struct af_mem_t { uint64_t occ_off; uint32_t nocc; uint16_t len, idx, rpos; uint8_t mate, pad; };
-struct af_chain_t { int32_t score; uint16_t off, cnt; uint32_t mate; };
+struct af_chain_t { int32_t score; uint16_t off, cnt; uint32_t mate; };      // mate: of the chain's start anchor (bits 0-1) | the chain holds anchors of both mates << 8
 struct af_start_t { int32_t f, j; };
 struct af_left_t { uint64_t ref; int64_t score; };
 #define AF_MAX_TASKS_READ 64       // DP task slots of one read in HBM (beyond: align_kernel)
 // LDS of one read.  MA / MC / MM: capacities for anchors, chains, seeds.  Two instances are launched: a small one that most reads
 // fit (more reads in flight per CU: the kernel is bound by the latency of its serial parts), and a large one for the reads that
 // overflow it.  Arrays that are dead by the time the plan is written share their space with it.
-template <int MA_, int MC_, int MM_, int NC_, int NA_, int NT_>
+template <int MA_, int MC_, int MM_, int NC_, int NA_, int NT_, int PE_ = 0>
 struct af_wave_tt {
     static constexpr int MA = MA_, MC = MC_, MM = MM_, NC = NC_, NA = NA_, NT = NT_;
+    uint64_t left_ref2[PE_ ? MC_ : 1];   // paired-end: check_paired_left_MEM's coordinate of mate 2 (left_ref: of mate 1)
     af_mem_t mem[MM_];
     uint64_t anch[MA_];                  // x (reference end, 40 bits) | mem << 40
     af_chain_t chains[MC_];
@@ -433,11 +438,13 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
             long long j = st.j;
             uint32_t cnt = 0;
             const uint32_t off = used;
-            do { L.pool[used++] = (uint16_t)j; cnt++; L.t[j] = 1; j = L.p[j]; } while (j >= 0 && L.t[j] == 0);
+            const uint32_t mate0 = L.mem[L.anch[j] >> 40].mate;
+            uint32_t paired = 0;                              // anchors of both mates (chain.hpp:186): only the paired-end path looks at it
+            do { paired |= L.mem[L.anch[j] >> 40].mate != mate0 ? 1u : 0u; L.pool[used++] = (uint16_t)j; cnt++; L.t[j] = 1; j = L.p[j]; } while (j >= 0 && L.t[j] == 0);
             bool keep = false;
             if (j < 0) keep = (long long)cnt >= P.min_chain_length;
             else if ((long long)st.f - L.f[j] >= P.min_chain_score) keep = (long long)cnt >= P.min_chain_length;
-            L.s_off[s] = (uint16_t)off; L.s_cnt[s] = (uint16_t)(keep ? cnt : 0u);
+            L.s_off[s] = (uint16_t)off; L.s_cnt[s] = (uint16_t)(keep ? (cnt | (paired << 15)) : 0u);          // (cnt <= MA < 2^15)
         }
     }
     __syncthreads();
@@ -451,7 +458,7 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
         const unsigned long long bal = __ballot(keep);
         if (keep) {
             af_chain_t c;
-            c.score = L.starts[sx].f; c.mate = L.mem[L.anch[L.starts[sx].j] >> 40].mate; c.off = L.s_off[sx]; c.cnt = L.s_cnt[sx];
+            c.score = L.starts[sx].f; c.mate = L.mem[L.anch[L.starts[sx].j] >> 40].mate | ((uint32_t)(L.s_cnt[sx] >> 15) << 8); c.off = L.s_off[sx]; c.cnt = L.s_cnt[sx] & 0x7FFFu;
             L.chains[n_chains + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = c;
         }
         n_chains += (uint32_t)__popcll(bal);
@@ -474,6 +481,28 @@ __device__ __forceinline__ void af_qseg(uint64_t off, uint32_t m, uint32_t stran
     if (!strand) { q_off = reversed ? off + a + len - 1 : off + a; qmode = reversed ? DP_Q_REV : 0; }
     else { q_off = reversed ? off + (m - (a + len)) : off + (m - 1 - a); qmode = DP_Q_COMP | (reversed ? 0 : DP_Q_REV); }
 }
+// The anchors of chain C.chain_idx whose mate bit (mem_t::mate & 1) is in `mates` (bit 0: mate 1, bit 1: mate 2; single-end: 3 = all), left to right, into
+// the plan's pool from C.an0 on: at most `room` of them (the caller's share of the pool); returns how many there are (C.n_an = those written)
+template <class WT>
+__device__ __forceinline__ uint32_t af_cand_anchors(WT& L, af_cand_t& C, uint32_t mates, uint32_t room_or_0) {
+    const af_chain_t ch = L.chains[C.chain_idx];
+    af_anchor_t* const AN = L.plan.an + C.an0;
+    uint32_t n = 0;
+    for (uint32_t k = 0; k < ch.cnt; ++k) {                      // stored right to left (chain.hpp:166-200); fill_chain wants left to right
+        const uint64_t aw = L.anch[L.pool[ch.off + ch.cnt - 1 - k]];
+        const af_mem_t mk = L.mem[aw >> 40];
+        if (!((mates >> (mk.mate & 1u)) & 1u)) continue;
+        if (room_or_0 == 0 || n < room_or_0) {
+            af_anchor_t A;
+            A.occ = AF_X(aw) - mk.len + 1; A.len = mk.len; A.idx = mk.idx; A.gap_val = 0; A.gap_kind = AF_GAP_NONE; A.pad = 0;
+            AN[n] = A;
+            if (n == 0) C.strand = (mk.mate & 2) ? 1 : 0;
+        }
+        ++n;
+    }
+    return n;
+}
+
 // One chain to score (fill_chain, part 1: aligner_ksw2.hpp:2782-2979) by ONE lane: its anchors left to right into the plan's pool, the gaps between
 // them classified (closed forms need no DP: a pure insertion, the "deletion" the reference scores with l = 0, one base against one base), and its DP
 // problems [left extension][right extension][gap fills in anchor order].  WRITE = false: count the problems (and write the anchors); WRITE = true: write
@@ -482,7 +511,7 @@ template <bool WRITE, class WT>
 __device__ __forceinline__ uint32_t af_build_cand(const af_args_t& G, WT& L, af_cand_t& C, uint64_t off, uint32_t m, uint32_t task0) {
     const ac_params_t& P = G.A.P;
     auto& PL = L.plan;
-    const af_chain_t ch = L.chains[C.chain_idx];
+    struct { uint32_t cnt; } ch; ch.cnt = C.n_an;          // the anchors are in the plan's pool already (af_cand_anchors / the paired path's share of a chain)
     af_anchor_t* const AN = PL.an + C.an0;
     const uint64_t n_text = P.n_text, ext_len = P.ext_len;
     uint32_t nt = 0;
@@ -496,17 +525,7 @@ __device__ __forceinline__ uint32_t af_build_cand(const af_args_t& G, WT& L, af_
         }
         ++nt;
     };
-    if (!WRITE) {
-        for (uint32_t k = 0; k < ch.cnt; ++k) {                  // stored right to left (chain.hpp:166-200); fill_chain wants left to right
-            const uint64_t aw = L.anch[L.pool[ch.off + ch.cnt - 1 - k]];
-            const af_mem_t mk = L.mem[aw >> 40];
-            af_anchor_t A;
-            A.occ = AF_X(aw) - mk.len + 1; A.len = mk.len; A.idx = mk.idx; A.gap_val = 0; A.gap_kind = AF_GAP_NONE; A.pad = 0;
-            AN[k] = A;
-            if (k == 0) C.strand = (mk.mate & 2) ? 1 : 0;
-        }
-        C.has_lc = C.has_rc = C.n_gap_tasks = 0; C.overlap = 0;
-    }
+    if (!WRITE) { C.has_lc = C.has_rc = C.n_gap_tasks = 0; C.overlap = 0; }
     const af_anchor_t first = AN[0], last = AN[ch.cnt - 1];
     const uint32_t strand = C.strand;
 #define qseg(a, len, reversed, q_off, qmode) af_qseg(off, m, strand, (a), (len), (reversed), (q_off), (qmode))
@@ -634,7 +653,7 @@ __device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, WT& L, uin
     const uint32_t n_cand = PL.n_cand;
     // ---- the problems of every chain to score: lane c takes chain c; count, prefix sum, write ----
     uint32_t nt = 0;
-    if ((uint32_t)lane < n_cand) nt = af_build_cand<false>(G, L, PL.cand[lane], off, m, 0u);
+    if ((uint32_t)lane < n_cand) { af_cand_anchors(L, PL.cand[lane], 3u, 0u); nt = af_build_cand<false>(G, L, PL.cand[lane], off, m, 0u); }
     const bool bad = __ballot(nt == 0xFFFFFFFFu) != 0ull;
     if (bad) { if (lane == 0) L.status_sh = AF_FALLBACK(G, AF_WHY_TASK_SIZE); __syncthreads(); return L.status_sh; }
     uint32_t incl = nt;
@@ -1197,9 +1216,9 @@ __global__ void __launch_bounds__(256) global_task_kernel(const af_args_t G) {
     bool active = r_in < A.n_reads;
     af_plan_t* PLp = active ? &G.plans[r_in] : nullptr;
     if (active && PLp->status != AF_ST_CAND) active = false;
-    const uint64_t r = A.read_lo + r_in;
+    const uint64_t r = A.read_lo + r_in;          // the plan's read, or (paired-end) its pair
     uint64_t off = 0; uint32_t m = 0, n_cand = 0;
-    if (active) { off = A.offs[r]; m = (uint32_t)(A.offs[r + 1] - off); n_cand = PLp->n_cand; }
+    if (active) { n_cand = PLp->n_cand; if (!G.pe) { off = A.offs[r]; m = (uint32_t)(A.offs[r + 1] - off); } }
     uint32_t why = AF_WHY_N;
     uint32_t max_cand = n_cand;
     for (int d = 32; d; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)max_cand, d); max_cand = o > max_cand ? o : max_cand; }
@@ -1209,6 +1228,7 @@ __global__ void __launch_bounds__(256) global_task_kernel(const af_args_t G) {
         af_cand_t* Cp = nullptr;
         if (active && why == AF_WHY_N && c < n_cand) {
             Cp = &PLp->cand[c];
+            if (G.pe) { const uint64_t rr = 2 * r + (Cp->pad & 1u); off = A.offs[rr]; m = (uint32_t)(A.offs[rr + 1] - off); }      // the mate this share of the chain belongs to
             if (Cp->overlap) {
                 uint32_t t = Cp->task0;
                 int lc_t = -1, rc_t = -1;

@@ -195,19 +195,14 @@ struct HostImage {
                     else if (j == K.rec_cnt[c]) thr_off = len;
                     else thr_off = thr <= f.starts[k] ? 0 : (thr >= f.starts[k] + len ? len : thr - f.starts[k]);
                     ssa[sl] = R.w1 & MONI_POS_MASK; esa[sl] = R.w2;
-                    w[2 + 2 * sl] = thr_off | (sdoff << 12) | (sd << 24) | ((ssa[sl] >> 32) << 56);
-                    w[3 + 2 * sl] = (ssa[sl] & 0xFFFFFFFFull) | ((esa[sl] & 0xFFFFFFFFull) << 32);
+                    w[1 + sl] = thr_off | (sdoff << 12) | (sd << 24) | ((ssa[sl] >> 32) << 56);
                 }
                 if (!ok) continue;
                 w[0] = len | (doff << 12) | ((uint64_t)dest[k] << 24) | ((uint64_t)hs << 56) | (1ull << 58);
-                {   // where the LF image of this run lies: room left in the destination run from doff on, and the length of the run after it (both
-                    // saturate at 4095, more than any offset inside an "ok" run): the step lands in dest, dest + 1 or dest + 2 without reading their rows
-                    const uint64_t d = dest[k];
-                    const uint64_t room = f.starts[d + 1] - f.starts[d] - doff;
-                    const uint64_t l1 = d + 1 < r ? f.starts[d + 2] - f.starts[d + 1] : MONI_ROW_LEN_SAT;
-                    w[1] = (room < MONI_ROW_LEN_SAT ? room : MONI_ROW_LEN_SAT) | ((l1 < MONI_ROW_LEN_SAT ? l1 : MONI_ROW_LEN_SAT) << 12) |
-                           ((esa[0] >> 32) << 24) | ((esa[1] >> 32) << 32) | ((esa[2] >> 32) << 40);
-                }
+                w[4] = (ssa[0] & 0xFFFFFFFFull) | ((ssa[1] & 0xFFFFFFFFull) << 32);
+                w[5] = (ssa[2] & 0xFFFFFFFFull) | ((esa[0] & 0xFFFFFFFFull) << 32);
+                w[6] = (esa[1] & 0xFFFFFFFFull) | ((esa[2] & 0xFFFFFFFFull) << 32);
+                w[7] = (esa[0] >> 32) | ((esa[1] >> 32) << 8) | ((esa[2] >> 32) << 16);
                 memcpy(frows[k].w, w, sizeof w);
             }
             });

@@ -40,20 +40,13 @@ struct alignas(32) moni_row_t {   // 32 bytes
 };
 
 // Fast row (one 64-byte aligned record per run = ONE HBM request per LF step, threshold jumps included).  Everything is
-// relative to run starts, so the LF loop carries (run, offset) and never needs an absolute BWT position.  A step reads the
-// row's first 16 bytes; a threshold jump reads 16 more (its slot): the kernel is bound by the rate at which the CUs' L1 takes
-// requests, not by bytes (a build that read 8 more bytes of the same line on the LF path was 15 % slower), so what a step
-// needs sits together:
+// relative to run starts, so the LF loop carries (run, offset) and never needs an absolute BWT position:
 //   w0      len(12) | doff(12) << 12 | dest(32) << 24 | head_slot(2) << 56 | ok(1) << 58
 //           LF(run start) = offset doff inside run dest
-//   w1      room(12) | next_len(12) << 12 | esa_hi0(8) << 24 | esa_hi1(8) << 32 | esa_hi2(8) << 40
-//           room = len(dest) - doff, next_len = len(dest + 1) (both saturating at 4095): the LF image of a run overruns its
-//           destination run more often than not when run lengths are comparable; with these two the step lands in dest,
-//           dest + 1 or dest + 2 without reading their rows (walking there cost a request per run)
-//   w2+2s   slot s (the hot symbol (head_slot + 1 + s) & 3):  thr_off(12) | sdoff(12) << 12 | sdest(32) << 24 | ssa_hi(8) << 56
+//   w1..w3  slot s (the hot symbol (head_slot + 1 + s) & 3):  thr_off(12) | sdoff(12) << 12 | sdest(32) << 24 | ssa_hi(8) << 56
 //           jump up  iff offset < thr_off   (thr_off folds "no c-run above/below" and the threshold position, clamped to the run)
 //           down: sample = ssa, go to (sdest, sdoff);  up: sample = esa, go to one position before (sdest, sdoff)
-//   w3+2s   ssa_s (low 32 bits) | esa_s (low 32 bits) << 32
+//   w4..w7  the six 40-bit samples: ssa0|ssa1, ssa2|esa0, esa1|esa2 (low 32 bits), then the three esa high bytes
 // ok = 0 (long runs >= 4095, offsets that do not fit 12 bits, heads or symbols outside the four hot ones, sentinels)
 // sends the step down the general path over rows / cr / recs with absolute positions.
 struct alignas(64) moni_frow_t { uint64_t w[8]; };

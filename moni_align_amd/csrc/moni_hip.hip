@@ -30,6 +30,7 @@
 #include "pe_host.hpp"
 #include "pe_big.h"
 #include "align_fast.hip"
+#include "pe_fast.hip"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "moni_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return MONI_ENODEV; } } while (0)
 
@@ -159,7 +160,8 @@ struct moni_ctx {
     DBuf<moni_alt_t> ak_alt;
     DBuf<int32_t> ak_minscore;
     struct PeBufs { DBuf<pe_slot_t> slots; DBuf<ak_wave_t> waves; DBuf<pe_rec_t> recs; DBuf<uint32_t> cig; DBuf<moni_alt_t> alt; DBuf<unsigned long long> cur; DBuf<int32_t> minscore;
-                    void release() { slots.release(); waves.release(); recs.release(); cig.release(); alt.release(); cur.release(); minscore.release(); } } pe;      // paired-end path (pe_api.inc)
+                    DBuf<pe_sel_t> sel[2]; DBuf<uint32_t> fb[2];          // staged paired kernels (pe_fast.hip): per chunk in flight, what pe_select_kernel decided; the hand-over list (16 words of counter, then the pairs)
+                    void release() { slots.release(); waves.release(); recs.release(); cig.release(); alt.release(); cur.release(); minscore.release(); for (int x = 0; x < 2; ++x) { sel[x].release(); fb[x].release(); } } } pe;      // paired-end path (pe_api.inc)
     unsigned long long* d_ak_cursors = nullptr;
     char* out_buf = nullptr; size_t out_cap = 0;      // moni_align_run's text buffer, kept across calls; pinned (hipHostMalloc): the in-order blocks of the
                                                       // sub-batches land in it by DMA

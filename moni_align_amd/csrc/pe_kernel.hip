@@ -182,6 +182,8 @@ struct pe_args_t {
     const int32_t* min_score_of_len;
     uint32_t max_len;
     uint64_t pair_lo, n_pairs;               // this launch takes pairs [pair_lo, pair_lo + n_pairs) of the resident batch; records go to recs[pair - pair_lo]
+    const uint32_t* pair_list;               // or, when set, the *n_list pairs it names (the pairs the staged kernels of pe_fast.hip hand over)
+    const uint32_t* n_list;
     uint32_t nl, sw_wave;                    // sw_wave: the orphan search by the whole wave (pe_sw_local_wave) instead of the pair's own lane; nl: pairs in flight per wavefront (lanes 0 .. nl-1 run state machines): the wave solves its pairs' DP problems one after
                                              // the other, so fewer pairs per wave = shorter serial DP phases, more waves
     pe_slot_t* slots;                        // gridDim.x * nl
@@ -235,9 +237,11 @@ pe_align_kernel(const pe_args_t A) {
         const bool start = __popcll(__ballot(state == 0 || state == 3)) >= (NL + 1) / 2 || __ballot(state == 1) == 0ull;
         if (state == 3 && start) { pe_write_record(A, W, pair); state = 0; }
         if (state == 0 && start) {
-            pair = A.pair_lo + atomicAdd(&A.cursors[4], 1ull);
-            if (pair >= A.pair_lo + A.n_pairs) state = 2;
-            else {
+            const unsigned long long nxt = atomicAdd(&A.cursors[4], 1ull);
+            pair = A.pair_lo + nxt;
+            if (A.pair_list) { if (nxt >= (unsigned long long)*A.n_list) state = 2; else pair = A.pair_list[nxt]; }
+            else if (pair >= A.pair_lo + A.n_pairs) state = 2;
+            if (state != 2) {
                 bool chained = false;
                 for (int k = 0; k < 2; ++k) {
                     const uint64_t r = 2 * pair + k;

@@ -237,27 +237,28 @@ MONI_HD void ms_step(const moni_consts_t& K, const lds_tables_t& L, const moni_r
         const uint32_t hh = (uint32_t)(w0 >> 56) & 3u;
         if (hc == hh) {                                      // bwt[pos] == c
             S.sample--;
-            const uint64_t w1 = q0.y;
-            const uint32_t room = (uint32_t)w1 & 0xFFFu, l1 = (uint32_t)(w1 >> 12) & 0xFFFu;
-            uint32_t run = (uint32_t)(w0 >> 24), o = S.off;
-            if (o < room) o += (uint32_t)(w0 >> 12) & 0xFFFu;              // inside the destination run
-            else { o -= room; ++run; if (o >= l1) { o -= l1; ++run; } }     // in the run after it, or the one after that (whose own length the next step checks)
-            S.off = o; S.run = run;
+            S.off += (uint32_t)(w0 >> 12) & 0xFFFu;
+            S.run = (uint32_t)(w0 >> 24);
             return;
         }
         ++n_jumps;
         const uint32_t sl = (hc - hh - 1u) & 3u;             // 0..2
-        const moni_u64x2 qs = *reinterpret_cast<const moni_u64x2*>(&fr->w[2 + 2 * sl]);   // the slot and its two samples' low words: the row's second (and last) 16 bytes this step reads
-        const uint64_t ws = qs.x;
+        const moni_u64x2 q1 = *reinterpret_cast<const moni_u64x2*>(&fr->w[2]);   // w2, w3
+        const moni_u64x2 q2 = *reinterpret_cast<const moni_u64x2*>(&fr->w[4]);   // w4, w5
+        const moni_u64x2 q3 = *reinterpret_cast<const moni_u64x2*>(&fr->w[6]);   // w6, w7
+        const uint64_t ws = sl == 0 ? q0.y : sl == 1 ? q1.x : q1.y;
         const uint32_t thr_off = (uint32_t)ws & 0xFFFu;
         const uint32_t sdoff = (uint32_t)(ws >> 12) & 0xFFFu;
         const uint32_t sdest = (uint32_t)(ws >> 24);
         if (S.off < thr_off) {                               // jump up: last position of the previous c-run
-            S.sample = (qs.y >> 32) | (((q0.y >> (24 + 8 * sl)) & 0xFFull) << 32);
+            const uint64_t lo = sl == 0 ? (q2.y >> 32) : sl == 1 ? (q3.x & 0xFFFFFFFFull) : (q3.x >> 32);
+            const uint64_t hi = (q3.y >> (8 * sl)) & 0xFFull;
+            S.sample = lo | (hi << 32);
             if (sdoff == 0) { S.run = sdest - 1; S.off = MONI_OFF_END; }
             else { S.run = sdest; S.off = sdoff - 1; }
         } else {                                             // jump down: first position of the next c-run
-            S.sample = (qs.y & 0xFFFFFFFFull) | ((ws >> 56) << 32);
+            const uint64_t lo = sl == 0 ? (q2.x & 0xFFFFFFFFull) : sl == 1 ? (q2.x >> 32) : (q2.y & 0xFFFFFFFFull);
+            S.sample = lo | ((ws >> 56) << 32);
             S.run = sdest; S.off = sdoff;
         }
         return;

@@ -550,11 +550,11 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx) -> 
         torch.cuda.synchronize()
     st = None
     for _ in range(args.warmup):
-        ctx.pe_align(seq, offs, nm, no, ql, model, host_threads=threads)
+        ctx.pe_align(seq, offs, nm, no, ql, model, host_threads=threads, want_text=False, stream=True)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sam, st = ctx.pe_align(seq, offs, nm, no, ql, model, host_threads=threads)
+        sam_len, st = ctx.pe_align(seq, offs, nm, no, ql, model, host_threads=threads, want_text=False, stream=True)      # moni_pe_align_stream: the text is in the context's host buffer; no copy into a Python object
     sync_all()
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dist, coll_dev)
     sizes = mdist.gather_counts([st["aligned"], hi - lo], dist, coll_dev)
@@ -565,7 +565,7 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx) -> 
                "value": n_all / step_s, "unit": "pairs/s", "reads_per_s": 2 * n_all / step_s, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64/int32", "data": "synthetic",
                "config": {"workload": "SURVEY.md 8(f)-2: paired-end path on the BASELINE.json configs[2] index (%d bp base + %d haplotypes, n=%d, r=%d): %d FR pairs of 2 x %d bp per GPU "
-                                      "(insert 350 +- 30, 0.5 %% substitutions) in host memory -> seeding kernels over the 2 N mates + pe_align_kernel (pair per lane) + host finishing -> "
+                                      "(insert 350 +- 30, 0.5 %% substitutions) in host memory -> seeding kernels over the 2 N mates + staged paired kernels (wave per pair plan, lane per DP problem, select, finish; pe_align_kernel for the pairs they hand over) + host finishing -> "
                                       "two SAM records per pair in host memory" % (args.base_len, args.haps, fi.n, fi.r, args.pairs, L),
                           "pairs_per_gpu": hi - lo, "read_len": L, "parallelism": "pairs sharded x%d, index replicated, fragment model learnt on rank 0 and broadcast" % world},
                "model": {"count": int(model.count), "mean": model.mean, "std_dev": model.std_dev, "complete": bool(model.complete)},
@@ -590,7 +590,8 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx) -> 
             t1 = time.perf_counter()
             want, ost = cpu_pe(0, n0)
             rate1 = n0 / (time.perf_counter() - t1)
-            got = b"\n".join(sam.split(b"\n")[:2 * n0]) + b"\n"
+            nseq0 = int(offs[2 * n0] - offs[0])
+            got, _ = ctx.pe_align(seq[:nseq0], offs[:2 * n0 + 1], nm[:int(no[2 * n0])], no[:2 * n0 + 1], None if ql is None else ql[:nseq0], model, host_threads=threads)
             per = int(max(2000, min((hi - lo) // cpu_threads, rate1 * args.cpu_seconds)))
             res = [None] * cpu_threads
             th = [threading.Thread(target=lambda k=k: res.__setitem__(k, cpu_pe(k * per, (k + 1) * per))) for k in range(cpu_threads)]

@@ -258,6 +258,15 @@ int moni_pe_learn_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const m
 int moni_pe_align_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
                         const uint8_t *quals, const moni_align_params_t *prm, const moni_pe_params_t *pe,
                         const moni_pe_model_t *model, char **sam, uint64_t *sam_len, moni_align_stats_t *stats);
+/* The same for a streaming caller: *sam points into a buffer the context owns (valid until the next moni_pe_align_stream /
+ * moni_ctx_destroy on this context, NOT to be freed): a batch's ~700 bytes per pair are not mapped and unmapped on every call. */
+int moni_pe_align_stream(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
+                        const uint8_t *quals, const moni_align_params_t *prm, const moni_pe_params_t *pe,
+                        const moni_pe_model_t *model, char **sam, uint64_t *sam_len, moni_align_stats_t *stats);
+/* aligner::align(paired_alignment_t&) with report_mems (-m for pairs; aligner_ksw2.hpp:1118-1180): one secondary record per occurrence of every MEM
+ * the direction and frequency filters leave, under its mate's name.  *sam is malloc'ed. */
+int moni_pe_report_mems_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
+                              const uint8_t *quals, const moni_align_params_t *prm, const moni_pe_params_t *pe, char **sam, uint64_t *sam_len);
 /* aligner::to_sam (aligner_ksw2.hpp:3213-3219): "@HD", one "@SQ" per sequence, "@PG". */
 int moni_sam_header(const moni_index_t *idx, char **sam, uint64_t *sam_len);
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "moni_align_params_default", "moni_align_batch", "moni_align_csv_batch", "moni_align_run", "moni_align_stream", "moni_sam_header",
     "moni_ldx_info", "moni_ldx_rewrite", "moni_ldx_lift_batch", "moni_ldx_write",
     "moni_ms_file_info", "moni_ms_file_read", "moni_ms_file_write", "moni_index_load_reference", "moni_ms_lengths_batch", "moni_report_mems_batch",
-    "moni_pe_params_default", "moni_pe_learn_batch", "moni_pe_align_batch",
+    "moni_pe_params_default", "moni_pe_learn_batch", "moni_pe_align_batch", "moni_pe_align_stream", "moni_pe_report_mems_batch",
 ]
 
 
@@ -148,6 +148,9 @@ def lib():
         L.moni_pe_learn_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.POINTER(AlignParamsC), C.POINTER(PeParamsC), C.POINTER(PeModelC)]
         L.moni_pe_align_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
                                           C.POINTER(PeParamsC), C.POINTER(PeModelC), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
+        L.moni_pe_align_stream.argtypes = L.moni_pe_align_batch.argtypes
+        L.moni_pe_report_mems_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC), C.POINTER(PeParamsC),
+                                                C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.moni_align_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
         L.moni_sam_header.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
@@ -389,8 +392,10 @@ class Ctx:
         return model
 
     def pe_align(self, seq: np.ndarray, offsets: np.ndarray, names: np.ndarray, name_off: np.ndarray, quals, model: "PeModelC",
-                 host_threads: Optional[int] = None, **overrides):
-        """SAM text (bytes) of the interleaved pairs + stats dict (moni_pe_align_batch)."""
+                 host_threads: Optional[int] = None, want_text: bool = True, stream: bool = False, **overrides):
+        """SAM text (bytes) of the interleaved pairs + stats dict (moni_pe_align_batch; stream=True: moni_pe_align_stream, the text in the
+        context-owned buffer); want_text=False returns the text's length instead of copying it into a Python bytes object (the library has
+        still produced the text in host memory)."""
         b, keep = self._batch(seq, offsets)
         names = np.ascontiguousarray(names, dtype=np.uint8)
         name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
@@ -400,13 +405,32 @@ class Ctx:
         out = C.c_void_p()
         ln = C.c_uint64()
         st = AlignStatsC()
-        _chk(self._L.moni_pe_align_batch(self._h, C.byref(b), names.ctypes.data, name_off.ctypes.data, quals.ctypes.data if quals is not None else None,
-                                         C.byref(prm), C.byref(pe), C.byref(model), C.byref(out), C.byref(ln), C.byref(st)), "moni_pe_align_batch")
+        fn = self._L.moni_pe_align_stream if stream else self._L.moni_pe_align_batch
+        _chk(fn(self._h, C.byref(b), names.ctypes.data, name_off.ctypes.data, quals.ctypes.data if quals is not None else None,
+                C.byref(prm), C.byref(pe), C.byref(model), C.byref(out), C.byref(ln), C.byref(st)), "moni_pe_align_stream" if stream else "moni_pe_align_batch")
         try:
-            sam = C.string_at(out, ln.value)
+            sam = C.string_at(out, ln.value) if want_text else int(ln.value)
+        finally:
+            if not stream:
+                self._L.moni_free(out)
+        return sam, _stats_dict(st)
+
+    def pe_report_mems(self, seq, offsets, names, name_off, quals=None, **overrides) -> bytes:
+        """-m for pairs (moni_pe_report_mems_batch): the MEM records of the interleaved pairs"""
+        b, keep = self._batch(seq, offsets)
+        names = np.ascontiguousarray(names, dtype=np.uint8)
+        name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
+        if quals is not None:
+            quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        prm, pe = self._pe_params(None, overrides)
+        out, ln = C.c_void_p(), C.c_uint64()
+        _chk(self._L.moni_pe_report_mems_batch(self._h, C.byref(b), names.ctypes.data, name_off.ctypes.data, quals.ctypes.data if quals is not None else None,
+                                               C.byref(prm), C.byref(pe), C.byref(out), C.byref(ln)), "moni_pe_report_mems_batch")
+        self.n_reads = len(offsets) - 1
+        try:
+            return C.string_at(out, ln.value)
         finally:
             self._L.moni_free(out)
-        return sam, _stats_dict(st)
 
     def align_run(self, names: np.ndarray, name_off: np.ndarray, quals=None, host_threads: Optional[int] = None,
                   want_text: bool = True, **overrides):

@@ -89,6 +89,8 @@ struct HBuf {                  // pinned host buffer, grow-only
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+#define PE_NSET 3          // sets of the staged paired kernels' large buffers (pe_api.inc), reused in stream order
+#define PE_NSTREAM 8       // hand-over kernels of the paired path in flight, one stream and one slot array each
 #define AK_NSET 2          // launch streams of the align stage, each with its own buffer set: sub-batch k runs on set k % AK_NSET
 struct moni_ctx {
     moni_index* idx = nullptr;
@@ -138,7 +140,7 @@ struct moni_ctx {
         DBuf<af_chunk_t> chunks; DBuf<uint8_t> dirs, fin; DBuf<af_tb_t> tb; DBuf<uint64_t> bnd; DBuf<unsigned long long> prof, txt_cur;
         void release() { ntasks.release(); bnd.release(); prof.release(); big_list.release(); txt_cur.release(); plans.release(); tasks.release(); res.release(); bin_q.release(); task_pos.release(); tb_task.release(); ctr.release();
                          chunks.release(); dirs.release(); fin.release(); tb.release(); }
-    } af[AK_NSET];
+    } af[AK_NSET], af_pe[PE_NSET];
     HBuf<uint32_t> af_ctr_host;             // counters of the last batch's launches (64 words per sub-batch), pinned
     DBuf<uint32_t> fb_all;                  // per sub-batch: the number of reads handed to align_kernel (16 words apart), then their lists
     DBuf<ak_slot_t> ak_slots;
@@ -148,7 +150,7 @@ struct moni_ctx {
     DBuf<uint8_t> ak_rnames, ak_quals; DBuf<uint64_t> ak_rname_off, ak_txt; DBuf<double> ak_mapq_tab;      // SAM text in the kernel
     HBuf<uint64_t> h_txt;                                 // pinned staging of one sub-batch's text
     uint64_t ak_waves_full = 0;
-    hipStream_t ak_stream[AK_NSET] = {}, copy_stream = nullptr, fb_stream[AK_NSET] = {};
+    hipStream_t ak_stream[AK_NSET] = {}, copy_stream = nullptr, fb_stream[AK_NSET] = {}, pe_stream[PE_NSTREAM] = {};
     std::vector<hipEvent_t> ak_fin;                // staged kernels of a sub-batch queued; the handed-over reads follow on fb_stream
     std::vector<hipEvent_t> af_ev;                 // per sub-batch: after the chaining kernels, after the DP kernels, after selection + traceback (HIP-event kernel times)
     std::vector<hipEvent_t> ak_begin, ak_done;
@@ -160,8 +162,9 @@ struct moni_ctx {
     DBuf<moni_alt_t> ak_alt;
     DBuf<int32_t> ak_minscore;
     struct PeBufs { DBuf<pe_slot_t> slots; DBuf<ak_wave_t> waves; DBuf<pe_rec_t> recs; DBuf<uint32_t> cig; DBuf<moni_alt_t> alt; DBuf<unsigned long long> cur; DBuf<int32_t> minscore;
-                    DBuf<pe_sel_t> sel[2]; DBuf<uint32_t> fb[2];          // staged paired kernels (pe_fast.hip): per chunk in flight, what pe_select_kernel decided; the hand-over list (16 words of counter, then the pairs)
-                    void release() { slots.release(); waves.release(); recs.release(); cig.release(); alt.release(); cur.release(); minscore.release(); for (int x = 0; x < 2; ++x) { sel[x].release(); fb[x].release(); } } } pe;      // paired-end path (pe_api.inc)
+                    DBuf<pe_sel_t> sel[PE_NSET]; DBuf<uint32_t> fb[PE_NSET];          // staged paired kernels (pe_fast.hip): per chunk in flight, what pe_select_kernel decided; the hand-over list (16 words of counter, then the pairs)
+                    void release() { slots.release(); waves.release(); recs.release(); cig.release(); alt.release(); cur.release(); minscore.release(); for (int x = 0; x < PE_NSET; ++x) { sel[x].release(); fb[x].release(); } } } pe;      // paired-end path (pe_api.inc)
+    char* pe_out = nullptr; size_t pe_out_cap = 0;     // moni_pe_align_stream's text buffer, kept across calls (its pages stay mapped)
     unsigned long long* d_ak_cursors = nullptr;
     char* out_buf = nullptr; size_t out_cap = 0;      // moni_align_run's text buffer, kept across calls; pinned (hipHostMalloc): the in-order blocks of the
                                                       // sub-batches land in it by DMA
@@ -439,6 +442,8 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
     c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
     for (int x = 0; x < AK_NSET; ++x) c->af[x].release();
+    for (int x = 0; x < PE_NSET; ++x) c->af_pe[x].release();
+    for (int x = 0; x < PE_NSTREAM; ++x) if (c->pe_stream[x]) (void)hipStreamDestroy(c->pe_stream[x]);
     c->af_ctr_host.release(); c->fb_all.release();
     c->dp_q.release(); c->dp_t.release(); c->dp_dir.release(); c->dp_tasks.release(); c->dp_res.release(); c->dp_cig.release();
     c->dp_off.release(); c->dp_ws.release(); c->dp_big.release(); c->dp_dir_big.release(); c->ak_slots.release(); c->ak_waves.release(); c->ak_cursors.release(); c->ak_rnames.release(); c->ak_quals.release(); c->ak_rname_off.release(); c->ak_txt.release(); c->ak_mapq_tab.release(); c->h_txt.release(); c->h_recs.release(); c->h_cig.release(); c->h_alt.release(); c->h_md.release();
@@ -453,6 +458,7 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->ak_recs.release(); c->ak_cig.release(); c->ak_alt.release(); c->ak_minscore.release(); c->pe.release();
     if (c->d_ak_cursors) (void)hipFree(c->d_ak_cursors);
     if (c->out_buf) (void)hipHostFree(c->out_buf);
+    free(c->pe_out);
     for (int x = 0; x < AK_NSET; ++x) c->gather_tmp[x].release();
     c->ak_block.release(); c->ak_dev_len.release(); c->ak_dev_off.release(); c->ak_dev_pos.release(); c->ak_dev_sum.release(); c->h_sum.release();
     if (c->d_small) (void)hipFree(c->d_small);

@@ -407,12 +407,18 @@ static int run_paired(Args& a, const std::string& sam_filename) {
     auto align_one = [&](int g, Batch& b, char** sam, uint64_t* len, uint64_t* n_al) {
         moni_read_batch_t rb{b.seq.data(), b.off.data(), b.n()};
         moni_align_stats_t st;
+        if (a.report_mems) {           // -m: the MEM records instead of the pair's (the fragment model plays no part in them)
+            const int rm = moni_pe_report_mems_batch(ctx[g], &rb, b.names.data(), b.name_off.data(), b.has_qual ? b.qual.data() : nullptr, &a.P, &a.PE, sam, len);
+            if (rm) die("moni_pe_report_mems_batch failed (" + std::to_string(rm) + ")");
+            *n_al = 0;
+            return;
+        }
         const int rc = moni_pe_align_batch(ctx[g], &rb, b.names.data(), b.name_off.data(), b.has_qual ? b.qual.data() : nullptr, &a.P, &a.PE, &model, sam, len, &st);
         if (rc) die("moni_pe_align_batch failed (" + std::to_string(rc) + (rc == MONI_ERANGE ? ": a pair exceeds the paired path's capacities)" : ")"));
         *n_al = st.aligned;
     };
     std::vector<Batch*> learnt;
-    while (!model.complete) {
+    while (!model.complete && !a.report_mems) {
         Batch* b = new Batch();
         if (!read_pairs(r1, r2, a.b, *b)) { delete b; break; }
         moni_read_batch_t rb{b->seq.data(), b->off.data(), b->n()};
@@ -473,7 +479,7 @@ int main(int argc, char** argv) {
     //     text and neither is read here - the text is rebuilt from the BWT - so the flag changes nothing (align_full_ksw2.cpp:414-426)
     const bool paired = !a.mate1.empty() || !a.mate2.empty();
     if (paired && (a.mate1.empty() || a.mate2.empty())) die("paired-end alignment needs both -1 and -2");
-    if (paired && (a.report_mems || a.legacy_ms || a.legacy_mems)) die("-m / --ms / --mems take single-end input (-p)");
+    if (paired && (a.legacy_ms || a.legacy_mems)) die("--ms / --mems take single-end input (-p)");
     if (!paired && a.patterns.empty()) die("no reads given (-p)");
     std::string fn = a.filename;
     std::vector<char> tmp(fn.begin(), fn.end()); tmp.push_back(0);

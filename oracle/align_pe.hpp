@@ -16,7 +16,7 @@
 //   aligner_ksw2.hpp:1329-1431  get_best_scores;  :1471-1534 check_paired_left_MEM;  :2115-2290 paired_chain_score
 //   mapq.hpp:186-223            compute_mapq_pe_bwa;  common/sam.hpp:126-142 remove_slash_mate
 //   align_reads_dispatcher.hpp:356-389  st_align's paired loop: learn on the first batches, then align them, then the rest
-// PARITY UNPINNED: nothing in the reference tree fixes paired-end output; -m (report_mems) for pairs and secondary_chains (-Z) are
+// PARITY UNPINNED: nothing in the reference tree fixes paired-end output; secondary_chains (-Z) is
 // not restated.  compute_frac_rep returns 0.0 in the reference (aligner_ksw2.hpp:1979-1981) and does here.
 #pragma once
 #include <mutex>
@@ -279,8 +279,8 @@ struct aligner_pe : aligner {
         al.second_best_score = (al.score2 >= al.min_score);
     }
 
-    // aligner_ksw2.hpp:1000-1326 (report_mems and secondary_chains not restated)
-    bool align(paired_alignment_t& al, bool finalize = true) {
+    // aligner_ksw2.hpp:1000-1326 (secondary_chains not restated); mems_out: the `out` of a call with report_mems (learn_fragment_model passes none)
+    bool align(paired_alignment_t& al, bool finalize = true, std::string* mems_out = nullptr) {
         const size_t l1 = al.mate1.seq.size(), l2 = al.mate2.seq.size();
         if (pe.filter_dir) {
             mem_finder.find_mems(al.mate1.seq.data(), l1, al.mems, 0, MATE_1 | MATE_F);
@@ -318,6 +318,28 @@ struct aligner_pe : aligner {
             mem_finder.find_mems(al.mate2_rev.seq.data(), l2, al.mems, l1, MATE_2 | MATE_RC);
             mem_finder.populate_seeds(al.mems, cfg.report_mems);
             if (cfg.filter_freq) { csv_t csv_m1; seed_freq_filter(al.mems, cfg.freq_thr, csv_m1); }
+        }
+        if (cfg.report_mems && mems_out != nullptr) {               // aligner_ksw2.hpp:1118-1180: one secondary record per occurrence of every MEM left
+            for (size_t i = 0; i < al.mems.size(); ++i) {
+                const bool is_m1 = al.mems[i].mate == (MATE_1 | MATE_F) || al.mems[i].mate == (MATE_1 | MATE_RC);
+                const read_t& src = is_m1 ? ((al.mems[i].mate & MATE_RC) ? al.mate1_rev : al.mate1) : ((al.mems[i].mate & MATE_RC) ? al.mate2_rev : al.mate2);
+                read_t part;                                         // copy_partial_kseq_t (kpbseq.h:197-205)
+                part.name = src.name; part.has_qual = src.has_qual;
+                part.seq = src.seq.substr(al.mems[i].idx, al.mems[i].len);
+                if (src.has_qual) part.qual = src.qual.substr(al.mems[i].idx, al.mems[i].len);
+                for (size_t j = 0; j < al.mems[i].occs.size(); ++j) {
+                    sam_t rs;
+                    rs.read = &part;
+                    rs.cigar = std::to_string(al.mems[i].len) + "M";
+                    const auto ref = ix.index(al.mems[i].occs[j]);
+                    rs.pos = ref.second + 1;
+                    rs.rname = ix.names[ref.first];
+                    rs.flag = (al.mems[i].mate & MATE_RC) ? (256 | 16) : 256;
+                    write_sam(*mems_out, rs);
+                }
+            }
+            al.aligned = true;
+            return true;
         }
         al.frac_rep_m1 = 0.0; al.frac_rep_m2 = 0.0;                  // compute_frac_rep (aligner_ksw2.hpp:1973-1981) returns 0.0
         al.chained = find_chains(al.mems, al.anchors, al.chains, cfg.chain);
@@ -585,13 +607,15 @@ struct aligner_pe : aligner {
             paired_alignment_t al;
             init(al, m1[i], m2[i]);
             al.mean = ins_mean; al.std_dev = ins_std_dev;
-            if (not align(al, true) and al.chained) {              // aligner_ksw2.hpp:900-906
+            if (not align(al, true, &out) and al.chained) {        // aligner_ksw2.hpp:900-906
                 ++orphan_pairs;
                 if (pe.find_orphan) orphan_recovery(al, ins_mean, ins_std_dev);
                 if (al.aligned) ++orphan_recovered;
             }
-            write_sam(out, al.sam_m1);
-            write_sam(out, al.sam_m2);
+            if (!cfg.report_mems) {                                  // (report_mems: align wrote the MEM records itself)
+                write_sam(out, al.sam_m1);
+                write_sam(out, al.sam_m2);
+            }
             if (al.aligned) ++aligned;
         }
         return aligned;

@@ -171,3 +171,58 @@ def test_pe_orphan_recovery(case, monkeypatch):
     monkeypatch.setenv("MONI_PE_FORCE_BIG", "3")
     got2, _, _ = on_gpu(fi, seq, offs, names, noff, q, 4096, find_orphan=True)
     assert got2 == want
+
+
+@pytest.mark.parametrize("filter_dir", [1, 0])
+def test_pe_report_mems(case, filter_dir):
+    """-m for pairs (moni_pe_report_mems_batch): one secondary record per occurrence of every MEM the direction and frequency filters leave,
+    in the order of the reference's four find_mems calls, against the oracle (aligner_ksw2.hpp:1118-1180)"""
+    pg, fi, o = case
+    m1, m2, _ = make_pairs(pg, 300)
+    h1, h2 = hard_pairs(pg)
+    m1, m2 = list(m1) + list(h1), list(m2) + list(h2)
+    n = len(m1)
+    o1 = np.zeros(n + 1, np.uint64); o1[1:] = np.cumsum([len(x) for x in m1])
+    o2 = np.zeros(n + 1, np.uint64); o2[1:] = np.cumsum([len(x) for x in m2])
+    nm1 = [b"p%d/1" % i for i in range(n)]; nm2 = [b"p%d/2" % i for i in range(n)]
+    no1 = np.zeros(n + 1, np.uint64); no1[1:] = np.cumsum([len(x) for x in nm1])
+    no2 = np.zeros(n + 1, np.uint64); no2[1:] = np.cumsum([len(x) for x in nm2])
+    q1 = ((np.arange(int(o1[-1])) % 40) + 33).astype(np.uint8); q2 = ((np.arange(int(o2[-1])) % 37) + 35).astype(np.uint8)
+    want, _ = orc.align_pe(o, np.concatenate(m1), o1, np.concatenate(m2), o2, np.frombuffer(b"".join(nm1), np.uint8), no1, np.frombuffer(b"".join(nm2), np.uint8), no2,
+                           q1, q2, b_size=512, report_mems=True, filter_dir=bool(filter_dir))
+    assert want.count(b"\t272\t") > 100 and want.count(b"\t256\t") > 100
+    seq, offs, names, noff, _ = interleave(m1, m2)
+    q = np.concatenate([x for p in range(n) for x in (q1[int(o1[p]):int(o1[p + 1])], q2[int(o2[p]):int(o2[p + 1])])])
+    idx = capi.Index(fi=fi)
+    ctx = capi.Ctx(idx)
+    try:
+        got = ctx.pe_report_mems(seq, offs, names, noff, q, filter_dir=filter_dir)
+    finally:
+        ctx.close()
+        idx.close()
+    if got != want:
+        raise AssertionError("MEM records differ at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
+
+
+def test_pe_stream_variant_and_small_chunks(case, monkeypatch):
+    """moni_pe_align_stream (text in the context's buffer, kept across calls) = moni_pe_align_batch; many chunks in flight (every chunk owns its
+    records and pools, the hand-over kernels run on several streams)"""
+    pg, fi, o = case
+    m1, m2, _ = make_pairs(pg, 1500)
+    seq, offs, names, noff, q = interleave(m1, m2)
+    idx = capi.Index(fi=fi)
+    ctx = capi.Ctx(idx)
+    try:
+        model = capi.PeModelC()
+        ctx.pe_learn(seq, offs, model)
+        a, sa = ctx.pe_align(seq, offs, names, noff, q, model, host_threads=4, find_orphan=1)
+        monkeypatch.setenv("MONI_PE_CHUNK", "64")
+        for _ in range(2):
+            b, sb = ctx.pe_align(seq, offs, names, noff, q, model, host_threads=3, find_orphan=1, stream=True)
+            assert a == b and sa["aligned"] == sb["aligned"]
+        half = 2 * 700
+        c_, _ = ctx.pe_align(seq[:int(offs[half])], offs[:half + 1], names[:int(noff[half])], noff[:half + 1], q[:int(offs[half])], model, host_threads=4, find_orphan=1, stream=True)
+        assert c_ == b"".join(a.split(b"\n")[i] + b"\n" for i in range(half))
+    finally:
+        ctx.close()
+        idx.close()

@@ -258,8 +258,10 @@ int moni_pe_learn_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const m
 int moni_pe_align_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
                         const uint8_t *quals, const moni_align_params_t *prm, const moni_pe_params_t *pe,
                         const moni_pe_model_t *model, char **sam, uint64_t *sam_len, moni_align_stats_t *stats);
-/* The same for a streaming caller: *sam points into a buffer the context owns (valid until the next moni_pe_align_stream /
- * moni_ctx_destroy on this context, NOT to be freed): a batch's ~700 bytes per pair are not mapped and unmapped on every call. */
+/* The same for a streaming caller: *sam points into the pinned text buffer the context owns (moni_align_run's: valid until the next
+ * moni_pe_align_stream / moni_pe_align_batch / moni_align_run / moni_align_stream / moni_ctx_destroy on this context, NOT to be freed).  The
+ * two lines of every pair are written by the GPU and arrive in input order by one transfer per chunk of pairs; moni_pe_align_batch is this
+ * call plus a copy into a malloc'ed block. */
 int moni_pe_align_stream(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
                         const uint8_t *quals, const moni_align_params_t *prm, const moni_pe_params_t *pe,
                         const moni_pe_model_t *model, char **sam, uint64_t *sam_len, moni_align_stats_t *stats);

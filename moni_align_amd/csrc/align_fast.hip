@@ -1537,18 +1537,22 @@ __device__ __forceinline__ uint32_t afs_ndig(uint32_t u) {
     return 1u + (u >= 10u) + (u >= 100u) + (u >= 1000u) + (u >= 10000u) + (u >= 100000u) + (u >= 1000000u) + (u >= 10000000u) + (u >= 100000000u) + (u >= 1000000000u);
 }
 // lane 0: one more segment of the line
-__device__ __forceinline__ void afs_push(af_finw_t& L, uint32_t& n, uint32_t& p, uint32_t kind, uint32_t val, uint32_t len) {
+template <class LT>
+__device__ __forceinline__ void afs_push(LT& L, uint32_t& n, uint32_t& p, uint32_t kind, uint32_t val, uint32_t len) {
     if (len == 0) return;
     if (n < AFS_MAXSEG) { L.seg_off[n] = (uint16_t)(p < 0xFFFFu ? p : 0xFFFFu); L.seg_kind[n] = (uint8_t)kind; L.seg_val[n] = val; }
     ++n; p += len;
 }
-__device__ __forceinline__ void afs_lits(af_finw_t& L, uint32_t& n, uint32_t& p, uint32_t at, uint32_t len) { afs_push(L, n, p, SK_LIT, at, len); }
-__device__ __forceinline__ void afs_num(af_finw_t& L, uint32_t& n, uint32_t& p, int v) {
+template <class LT>
+__device__ __forceinline__ void afs_lits(LT& L, uint32_t& n, uint32_t& p, uint32_t at, uint32_t len) { afs_push(L, n, p, SK_LIT, at, len); }
+template <class LT>
+__device__ __forceinline__ void afs_num(LT& L, uint32_t& n, uint32_t& p, int v) {
     if (v < 0) { const uint32_t u = 0u - (uint32_t)v; afs_push(L, n, p, SK_NEG, u, afs_ndig(u) + 1); }
     else afs_push(L, n, p, SK_NUM, (uint32_t)v, afs_ndig((uint32_t)v));
 }
 // a CIGAR string as one segment: the offsets of its operations' texts (number + letter) for the renderer
-__device__ __forceinline__ void afs_cigar(af_finw_t& L, uint32_t& n, uint32_t& p, const uint32_t* cg, uint32_t nc, uint16_t* offs, uint32_t which) {
+template <class LT>
+__device__ __forceinline__ void afs_cigar(LT& L, uint32_t& n, uint32_t& p, const uint32_t* cg, uint32_t nc, uint16_t* offs, uint32_t which) {
     uint32_t q = 0;
     for (uint32_t k = 0; k < nc; ++k) { offs[k] = (uint16_t)q; q += afs_ndig(cg[k] >> 4) + 1u; }
     offs[nc] = (uint16_t)q;
@@ -1558,10 +1562,11 @@ __device__ __forceinline__ void afs_cigar(af_finw_t& L, uint32_t& n, uint32_t& p
 // MD / NM of one CIGAR over the window that starts at text position t0 (write_MD_core).  All lanes call it (uniform control flow).
 // items: the MD string as a list in L.md_item (a mismatching lane writes its own item: the matches before it and its base); n_items
 // counts them (AFS_MAXMD + 1: something did not fit, the caller sends the read to the host pipeline).  Returns NM (uniform).
-__device__ __forceinline__ int afs_md(const af_args_t& G, af_finw_t& L, const uint32_t* cg, uint32_t n_cig, uint64_t t0, bool items, uint32_t& n_items,
+// LT: holds the read in alignment orientation (seq) and the item list (md_item): af_finw_t, or one mate of a pair (pe_lines.hip).
+template <class LT>
+__device__ __forceinline__ int afs_md(const dp_launch_t& D, LT& L, const uint32_t* cg, uint32_t n_cig, uint64_t t0, bool items, uint32_t& n_items,
                                       const uint8_t* win) {          // win: the window's nt4 codes in LDS (or nullptr: read the text)
     const int lane = threadIdx.x;
-    const dp_launch_t& D = G.A.D;
     const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     int NM = 0; uint32_t l_MD = 0, ni = 0;
     bool bad = false;
@@ -1785,8 +1790,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
                     if (!same) for (uint32_t k = lane; k < (uint32_t)ref_len_u; k += 64) { const uint64_t a = aln_pos + k; L.line[AFS_LINE / 2 + k] = (uint8_t)dp_nt4(a < A.D.n_text ? A.D.text[a] : 0u); }
                     __syncthreads();
                 }
-                if (mapped) nm = afs_md(G, L, L.lcig, n_lcig, lifted, true, n_md, win ? L.line : nullptr);
-                lift_nm = same ? nm : afs_md(G, L, L.cig, n_cig, aln_pos, false, dummy, win ? L.line + AFS_LINE / 2 : nullptr);
+                if (mapped) nm = afs_md(G.A.D, L, L.lcig, n_lcig, lifted, true, n_md, win ? L.line : nullptr);
+                lift_nm = same ? nm : afs_md(G.A.D, L, L.cig, n_cig, aln_pos, false, dummy, win ? L.line + AFS_LINE / 2 : nullptr);
                 if (n_md > AFS_MAXMD) { to_host = true; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CIGAR], 1u); }
             }
             __syncthreads();

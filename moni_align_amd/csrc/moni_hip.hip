@@ -31,6 +31,7 @@
 #include "pe_big.h"
 #include "align_fast.hip"
 #include "pe_fast.hip"
+#include "pe_lines.hip"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "moni_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return MONI_ENODEV; } } while (0)
 
@@ -162,9 +163,11 @@ struct moni_ctx {
     DBuf<moni_alt_t> ak_alt;
     DBuf<int32_t> ak_minscore;
     struct PeBufs { DBuf<pe_slot_t> slots; DBuf<ak_wave_t> waves; DBuf<pe_rec_t> recs; DBuf<uint32_t> cig; DBuf<moni_alt_t> alt; DBuf<unsigned long long> cur; DBuf<int32_t> minscore;
-                    DBuf<pe_sel_t> sel[PE_NSET]; DBuf<uint32_t> fb[PE_NSET];          // staged paired kernels (pe_fast.hip): per chunk in flight, what pe_select_kernel decided; the hand-over list (16 words of counter, then the pairs)
-                    void release() { slots.release(); waves.release(); recs.release(); cig.release(); alt.release(); cur.release(); minscore.release(); for (int x = 0; x < PE_NSET; ++x) { sel[x].release(); fb[x].release(); } } } pe;      // paired-end path (pe_api.inc)
-    char* pe_out = nullptr; size_t pe_out_cap = 0;     // moni_pe_align_stream's text buffer, kept across calls (its pages stay mapped)
+                    DBuf<pe_sel_t> sel[PE_NSET]; DBuf<uint32_t> fb[PE_NSET];
+                    DBuf<uint64_t> txt_pool, block, dev_len, dev_off, dev_pos; DBuf<int32_t> subn_tab; DBuf<uint8_t> scan_tmp[PE_NSTREAM]; bool subn_ready = false;      // the lines written on the GPU (pe_lines.hip)
+                             // staged paired kernels (pe_fast.hip): per chunk in flight, what pe_select_kernel decided; the hand-over list (16 words of counter, then the pairs)
+                    void release() { slots.release(); waves.release(); recs.release(); cig.release(); alt.release(); cur.release(); minscore.release(); for (int x = 0; x < PE_NSET; ++x) { sel[x].release(); fb[x].release(); }
+                                     txt_pool.release(); block.release(); dev_len.release(); dev_off.release(); dev_pos.release(); subn_tab.release(); for (int x = 0; x < PE_NSTREAM; ++x) scan_tmp[x].release(); } } pe;      // paired-end path (pe_api.inc)
     unsigned long long* d_ak_cursors = nullptr;
     char* out_buf = nullptr; size_t out_cap = 0;      // moni_align_run's text buffer, kept across calls; pinned (hipHostMalloc): the in-order blocks of the
                                                       // sub-batches land in it by DMA
@@ -458,7 +461,6 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     c->ak_recs.release(); c->ak_cig.release(); c->ak_alt.release(); c->ak_minscore.release(); c->pe.release();
     if (c->d_ak_cursors) (void)hipFree(c->d_ak_cursors);
     if (c->out_buf) (void)hipHostFree(c->out_buf);
-    free(c->pe_out);
     for (int x = 0; x < AK_NSET; ++x) c->gather_tmp[x].release();
     c->ak_block.release(); c->ak_dev_len.release(); c->ak_dev_off.release(); c->ak_dev_pos.release(); c->ak_dev_sum.release(); c->h_sum.release();
     if (c->d_small) (void)hipFree(c->d_small);

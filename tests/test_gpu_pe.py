@@ -226,3 +226,34 @@ def test_pe_stream_variant_and_small_chunks(case, monkeypatch):
     finally:
         ctx.close()
         idx.close()
+
+
+def test_pe_lines_written_on_the_gpu_equal_the_host_finishing(case, monkeypatch):
+    """pe_lines_kernel (two lines per pair written and ordered on the GPU) against pe_host.hpp's finishing of the same records
+    (MONI_PE_HOST_FORMAT=1), over proper pairs, hard cases (noise mates, improper pairs, one mate under its minimum score), orphan recovery,
+    names without /1 /2 and input without qualities"""
+    pg, fi, o = case
+    m1, m2, _ = make_pairs(pg, 1200)
+    h1, h2 = hard_pairs(pg)
+    from tests.test_host_sim_pe import seedless_pairs
+    s1, s2 = seedless_pairs(pg)
+    m1, m2 = list(m1) + list(h1) + list(s1), list(m2) + list(h2) + list(s2)
+    idx = capi.Index(fi=fi)
+    ctx = capi.Ctx(idx)
+    try:
+        for slash, with_q in ((True, True), (False, False)):
+            seq, offs, names, noff, q = interleave(m1, m2, slash=slash)
+            q = ((np.arange(len(seq)) % 41) + 33).astype(np.uint8) if with_q else None
+            model = capi.PeModelC()
+            ctx.pe_learn(seq[:int(offs[2400])], offs[:2401], model)
+            monkeypatch.delenv("MONI_PE_HOST_FORMAT", raising=False)
+            a, sa = ctx.pe_align(seq, offs, names, noff, q, model, host_threads=4, find_orphan=1)
+            monkeypatch.setenv("MONI_PE_HOST_FORMAT", "1")
+            b, sb = ctx.pe_align(seq, offs, names, noff, q, model, host_threads=4, find_orphan=1)
+            monkeypatch.delenv("MONI_PE_HOST_FORMAT", raising=False)
+            if a != b:
+                raise AssertionError("lines differ at record %d:\n gpu: %s\nhost: %s" % first_diff(a, b))
+            assert sa["aligned"] == sb["aligned"] and a.count(b"\n") == 2 * len(m1)
+    finally:
+        ctx.close()
+        idx.close()

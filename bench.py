@@ -29,6 +29,7 @@ HBM traffic from rocprofv3 PMC passes cannot be collected from inside this proce
 import argparse
 import json
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")          # before anything initialises HIP (see moni_hip.hip: moni_hip_default_queues)
 import socket
 import subprocess
 import sys
@@ -86,7 +87,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
     ap.add_argument("--paired", action="store_true", help="the paired-end path instead (moni_pe_learn_batch / moni_pe_align_batch over --pairs FR pairs of 2 x --read-len, orphan recovery on): pairs/s")
-    ap.add_argument("--pairs", type=int, default=400000, help="--paired: read pairs (per GPU; sharded by contiguous ranges like the reads when --total-reads is given)")
+    ap.add_argument("--pairs", type=int, default=1000000, help="--paired: read pairs (per GPU; sharded by contiguous ranges like the reads when --total-reads is given)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: launch, rendezvous (gloo), sharding and the SAM gather with placeholder records")
     ap.add_argument("--cache", default="/tmp/moni_bench_cache")
     return ap.parse_args(argv)
@@ -425,16 +426,20 @@ def run_rank(args) -> int:
                                       ("one set of %d sharded over %d rank(s) by contiguous ranges, %d resident chunk(s) of <= %d per rank" % (total, world, n_chunks, args.reads)) if sharded else ("%d per GPU" % args.reads), L, threads),
                        "reads_per_gpu": n_mine, "total_reads": n_all, "chunks_per_rank": n_chunks, "read_len": L, "parallelism": "reads sharded x%d, index replicated" % world,
                        "launched_by": "bench.py" if os.environ.get("MONI_BENCH_SELF_LAUNCHED") else ("torch.distributed.run / external launcher" if world > 1 else "single process")},
-            "roofline": {"bound": "hbm", "kernel": "ms_lf_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_static_from": "profiles/r02y/pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of this workload, profiles/run_r02.sh: "
-                                                "26.66 GB fetched + 2.40 GB written = 29.06 GB per launch of 1 M reads for 47.18 GB algorithmic, i.e. 0.44 of the HBM peak as "
-                                                "counted traffic; counters cannot be read inside this run, so `traffic` stays null)",
-                         "algorithmic_bytes_per_launch": ms_bytes, "avg_launch_ms": kern_launch[0], "per_read_bytes": ms_bytes / max(1, n_first),
-                         "layout_model": {"bytes_per_launch": layout_bytes, "GB/s": layout_bytes / ms_s / 1e9 if ms_s > 0 else None,
-                                          "frac": layout_bytes / ms_s / 1e9 / HBM_PEAK_GBS if ms_s > 0 else None,
-                                          "note": "bytes the move-structure layout needs (one 64-byte fast row per LF step, threshold jumps included): the survey's model credits two requests per step"},
-                         "note": "the path's HBM-bound kernel (LF / threshold-jump stage of seeding), one launch per resident chunk inside the timed region, HIP events on its own stream"},
+            # headline: the bytes the layout itself has to move per launch (one 64-byte fast row + one 8-byte pointer store + 1/8 of a packed pattern
+            # word per LF step = 73 S; the PMC passes count 1.33x that).  SURVEY.md 8(d)'s figure (128 S + 64 J: two requests per step, the reference's
+            # data-structure model) is kept beside it, labelled - it credits the kernel with bytes the fast-row layout never moves (VERDICT r2, item 3 iii)
+            "roofline": {"bound": "hbm", "kernel": "ms_lf_kernel", "achieved": layout_bytes / ms_s / 1e9 if ms_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": layout_bytes / ms_s / 1e9 / HBM_PEAK_GBS if ms_s > 0 else 0.0, "traffic": None,
+                         "model": "layout: 73 bytes per LF step (64-byte fast row, threshold jumps included + 8-byte pointer store + 1 byte of packed pattern)",
+                         "bytes_per_launch": layout_bytes, "avg_launch_ms": kern_launch[0], "per_read_bytes": layout_bytes / max(1, n_first),
+                         "survey_8d": {"bytes_per_launch": ms_bytes, "formula": "128 S + 64 J (SURVEY.md 8(d): two 64-byte requests per LF step, one per threshold jump)",
+                                       "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "per_read_bytes": ms_bytes / max(1, n_first)},
+                         "traffic_static_from": "profiles/r03s/pmc_hbm.csv when present, else profiles/r02y/pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of this "
+                                                "workload: 26.66 GB fetched + 2.40 GB written = 29.06 GB per launch of 1 M reads = 1.33 x the layout's 21.9 GB, 0.62 x the survey's 47.18 GB; "
+                                                "counters cannot be read inside this run, so `traffic` stays null)",
+                         "note": "the path's HBM-bound kernel (LF / threshold-jump stage of seeding), one launch per resident chunk inside the timed region, HIP events on its own stream; "
+                                 "what bounds it is the rate of random 64-byte requests HBM serves (~42 G/s), not bytes"},
             "whole_path": {"bytes_per_read": path_bytes / max(1, n_mine), "formula": "128 S + 64 J + 128 P + C + R (SURVEY.md 8(d)), all counted by the kernels in this run",
                            "S_lf_steps": S, "J_threshold_jumps": J, "P_phi_steps": P, "C_text_bytes": C, "R_dp_target_bytes": R,
                            "GB/s": path_bytes / step_s / 1e9, "frac_of_hbm_peak": path_bytes / step_s / 1e9 / HBM_PEAK_GBS,
@@ -549,12 +554,23 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx) -> 
             dist.barrier()
         torch.cuda.synchronize()
     st = None
-    for _ in range(args.warmup):
+    # reads handed over in host memory (moni_pe_align_stream: the upload inside the call): reported beside the headline, never as `value`
+    from_host = None
+    if not args.no_from_host:
         ctx.pe_align(seq, offs, nm, no, ql, model, host_threads=threads, want_text=False, stream=True)
+        t1 = time.perf_counter()
+        for _ in range(max(1, args.steps)):
+            ctx.pe_align(seq, offs, nm, no, ql, model, host_threads=threads, want_text=False, stream=True)
+        dt = (time.perf_counter() - t1) / max(1, args.steps)
+        from_host = {"value": (hi - lo) / dt, "unit": "pairs/s (this rank)", "ms_per_batch": dt * 1e3, "note": "moni_pe_align_stream: mates, names, qualities in pageable host memory, upload inside the timed call"}
+    # the headline: the mates resident in HBM when the timed region starts (moni_reads_upload), names and qualities host buffers as in moni_align_run
+    ctx.upload(seq, offs)
+    for _ in range(args.warmup):
+        ctx.pe_align_run(nm, no, ql, model, host_threads=threads, want_text=False)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sam_len, st = ctx.pe_align(seq, offs, nm, no, ql, model, host_threads=threads, want_text=False, stream=True)      # moni_pe_align_stream: the text is in the context's host buffer; no copy into a Python object
+        sam_len, st = ctx.pe_align_run(nm, no, ql, model, host_threads=threads, want_text=False)      # the text is in the context's pinned host buffer; no copy into a Python object
     sync_all()
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dist, coll_dev)
     sizes = mdist.gather_counts([st["aligned"], hi - lo], dist, coll_dev)
@@ -565,13 +581,16 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx) -> 
                "value": n_all / step_s, "unit": "pairs/s", "reads_per_s": 2 * n_all / step_s, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64/int32", "data": "synthetic",
                "config": {"workload": "SURVEY.md 8(f)-2: paired-end path on the BASELINE.json configs[2] index (%d bp base + %d haplotypes, n=%d, r=%d): %d FR pairs of 2 x %d bp per GPU "
-                                      "(insert 350 +- 30, 0.5 %% substitutions) in host memory -> seeding kernels over the 2 N mates + staged paired kernels (wave per pair plan, lane per DP problem, select, finish; pe_align_kernel for the pairs they hand over) + host finishing -> "
-                                      "two SAM records per pair in host memory" % (args.base_len, args.haps, fi.n, fi.r, args.pairs, L),
+                                      "(insert 350 +- 30, 0.5 %% substitutions) resident in HBM -> seeding kernels over the 2 N mates + staged paired kernels (wave per pair plan, lane per DP problem, select, finish, both SAM lines written and "
+                                      "ordered on the GPU; pe_align_kernel for the pairs they hand over: orphan recovery) -> two SAM records per pair in pinned host memory" % (args.base_len, args.haps, fi.n, fi.r, args.pairs, L),
                           "pairs_per_gpu": hi - lo, "read_len": L, "parallelism": "pairs sharded x%d, index replicated, fragment model learnt on rank 0 and broadcast" % world},
                "model": {"count": int(model.count), "mean": model.mean, "std_dev": model.std_dev, "complete": bool(model.complete)},
                "aligned_pairs_all_ranks": sum(x[0] for x in sizes), "stages_s_per_step": {"seed": st["t_seed"], "kernel_and_copies": st["t_dp"], "host_finish": st["t_host"]},
                "dp_problems": st["dp_tasks"], "dp_cells": st["dp_cells"], "pairs_through_host_pipeline": st["handed_back"],
+               "pairs_to_pe_align_kernel": st["kernel_fallback"], "handed_over_because": {k: v for k, v in st.get("handover_why", {}).items() if v},
                "host": {"cpus_usable": host_cpus(), "host_threads_per_gpu": threads}}
+        if from_host is not None:
+            out["from_host"] = from_host
         if world == 1 and not args.no_cpu:
             from oracle import orc as _orc          # the CPU baseline / at-scale checker
             oidx = _orc.OracleIndex(fi=fi)

@@ -265,6 +265,10 @@ int moni_pe_align_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const u
 int moni_pe_align_stream(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
                         const uint8_t *quals, const moni_align_params_t *prm, const moni_pe_params_t *pe,
                         const moni_pe_model_t *model, char **sam, uint64_t *sam_len, moni_align_stats_t *stats);
+/* The same over the interleaved pairs that moni_reads_upload made resident (reads already in HBM when the call starts; names and qualities
+ * are host buffers as in moni_align_run); *sam in the context's buffer as for moni_pe_align_stream. */
+int moni_pe_align_run(moni_ctx_t *ctx, const uint8_t *names, const uint64_t *name_off, const uint8_t *quals, const moni_align_params_t *prm,
+                      const moni_pe_params_t *pe, const moni_pe_model_t *model, char **sam, uint64_t *sam_len, moni_align_stats_t *stats);
 /* aligner::align(paired_alignment_t&) with report_mems (-m for pairs; aligner_ksw2.hpp:1118-1180): one secondary record per occurrence of every MEM
  * the direction and frequency filters leave, under its mate's name.  *sam is malloc'ed. */
 int moni_pe_report_mems_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,

@@ -12,6 +12,9 @@ from typing import Dict, Optional
 
 import numpy as np
 
+# streams beyond the runtime's hardware queues share one (the paired path keeps ~11 busy): a default for processes that set none, before HIP initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("MONI_HIP_LIB") or os.path.join(CSRC, "libmoni_hip.so")      # override: kernel-variant sweeps
@@ -24,7 +27,7 @@ EXPORTS = [
     "moni_align_params_default", "moni_align_batch", "moni_align_csv_batch", "moni_align_run", "moni_align_stream", "moni_sam_header",
     "moni_ldx_info", "moni_ldx_rewrite", "moni_ldx_lift_batch", "moni_ldx_write",
     "moni_ms_file_info", "moni_ms_file_read", "moni_ms_file_write", "moni_index_load_reference", "moni_ms_lengths_batch", "moni_report_mems_batch",
-    "moni_pe_params_default", "moni_pe_learn_batch", "moni_pe_align_batch", "moni_pe_align_stream", "moni_pe_report_mems_batch",
+    "moni_pe_params_default", "moni_pe_learn_batch", "moni_pe_align_batch", "moni_pe_align_stream", "moni_pe_align_run", "moni_pe_report_mems_batch",
 ]
 
 
@@ -149,6 +152,8 @@ def lib():
         L.moni_pe_align_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
                                           C.POINTER(PeParamsC), C.POINTER(PeModelC), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
         L.moni_pe_align_stream.argtypes = L.moni_pe_align_batch.argtypes
+        L.moni_pe_align_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC), C.POINTER(PeParamsC), C.POINTER(PeModelC),
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
         L.moni_pe_report_mems_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC), C.POINTER(PeParamsC),
                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.moni_align_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
@@ -414,6 +419,18 @@ class Ctx:
             if not stream:
                 self._L.moni_free(out)
         return sam, _stats_dict(st)
+
+    def pe_align_run(self, names: np.ndarray, name_off: np.ndarray, quals, model: "PeModelC", host_threads: Optional[int] = None, want_text: bool = True, **overrides):
+        """moni_pe_align_run over the interleaved pairs made resident by upload(); the text is in the context's buffer (want_text=False: its length)"""
+        names = np.ascontiguousarray(names, dtype=np.uint8)
+        name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
+        if quals is not None:
+            quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        prm, pe = self._pe_params(host_threads, overrides)
+        out, ln, st = C.c_void_p(), C.c_uint64(), AlignStatsC()
+        _chk(self._L.moni_pe_align_run(self._h, names.ctypes.data, name_off.ctypes.data, quals.ctypes.data if quals is not None else None, C.byref(prm), C.byref(pe),
+                                       C.byref(model), C.byref(out), C.byref(ln), C.byref(st)), "moni_pe_align_run")
+        return (C.string_at(out, ln.value) if want_text else int(ln.value)), _stats_dict(st)
 
     def pe_report_mems(self, seq, offsets, names, name_off, quals=None, **overrides) -> bytes:
         """-m for pairs (moni_pe_report_mems_batch): the MEM records of the interleaved pairs"""

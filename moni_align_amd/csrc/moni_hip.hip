@@ -90,7 +90,7 @@ struct HBuf {                  // pinned host buffer, grow-only
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
-#define PE_NSET 3          // sets of the staged paired kernels' large buffers (pe_api.inc), reused in stream order
+#define PE_NSET 1          // sets of the staged paired kernels' large buffers (pe_api.inc): the chunks' staged kernels run one after the other on one stream, what outlives them is per chunk
 #define PE_NSTREAM 8       // hand-over kernels of the paired path in flight, one stream and one slot array each
 #define AK_NSET 2          // launch streams of the align stage, each with its own buffer set: sub-batch k runs on set k % AK_NSET
 struct moni_ctx {
@@ -142,6 +142,7 @@ struct moni_ctx {
         void release() { ntasks.release(); bnd.release(); prof.release(); big_list.release(); txt_cur.release(); plans.release(); tasks.release(); res.release(); bin_q.release(); task_pos.release(); tb_task.release(); ctr.release();
                          chunks.release(); dirs.release(); fin.release(); tb.release(); }
     } af[AK_NSET], af_pe[PE_NSET];
+    HBuf<unsigned long long> pe_hcur;       // paired path, per chunk: the pool cursors / DP counters (8 words) and the number of pairs handed over, copied behind the chunk's kernels
     HBuf<uint32_t> af_ctr_host;             // counters of the last batch's launches (64 words per sub-batch), pinned
     DBuf<uint32_t> fb_all;                  // per sub-batch: the number of reads handed to align_kernel (16 words apart), then their lists
     DBuf<ak_slot_t> ak_slots;
@@ -164,10 +165,10 @@ struct moni_ctx {
     DBuf<int32_t> ak_minscore;
     struct PeBufs { DBuf<pe_slot_t> slots; DBuf<ak_wave_t> waves; DBuf<pe_rec_t> recs; DBuf<uint32_t> cig; DBuf<moni_alt_t> alt; DBuf<unsigned long long> cur; DBuf<int32_t> minscore;
                     DBuf<pe_sel_t> sel[PE_NSET]; DBuf<uint32_t> fb[PE_NSET];
-                    DBuf<uint64_t> txt_pool, block, dev_len, dev_off, dev_pos; DBuf<int32_t> subn_tab; DBuf<uint8_t> scan_tmp[PE_NSTREAM]; bool subn_ready = false;      // the lines written on the GPU (pe_lines.hip)
+                    DBuf<uint64_t> txt_pool, block, dev_len, dev_off, dev_pos; DBuf<int32_t> subn_tab; DBuf<double> pen_tab; DBuf<uint8_t> scan_tmp[PE_NSTREAM]; bool subn_ready = false;      // the lines written on the GPU (pe_lines.hip)
                              // staged paired kernels (pe_fast.hip): per chunk in flight, what pe_select_kernel decided; the hand-over list (16 words of counter, then the pairs)
                     void release() { slots.release(); waves.release(); recs.release(); cig.release(); alt.release(); cur.release(); minscore.release(); for (int x = 0; x < PE_NSET; ++x) { sel[x].release(); fb[x].release(); }
-                                     txt_pool.release(); block.release(); dev_len.release(); dev_off.release(); dev_pos.release(); subn_tab.release(); for (int x = 0; x < PE_NSTREAM; ++x) scan_tmp[x].release(); } } pe;      // paired-end path (pe_api.inc)
+                                     txt_pool.release(); block.release(); dev_len.release(); dev_off.release(); dev_pos.release(); subn_tab.release(); pen_tab.release(); for (int x = 0; x < PE_NSTREAM; ++x) scan_tmp[x].release(); } } pe;      // paired-end path (pe_api.inc)
     unsigned long long* d_ak_cursors = nullptr;
     char* out_buf = nullptr; size_t out_cap = 0;      // moni_align_run's text buffer, kept across calls; pinned (hipHostMalloc): the in-order blocks of the
                                                       // sub-batches land in it by DMA
@@ -268,6 +269,11 @@ static int rebuild_text(moni_index* I, const moni_flat_index_t& f, std::vector<u
         return done(MONI_OK);
     } catch (const std::bad_alloc&) { return done(MONI_ENOMEM); }
 }
+
+// The paired path keeps ~11 streams busy (staged kernels, transfers, up to PE_NSTREAM hand-over kernels of ~30 ms each); streams beyond the runtime's
+// hardware queues share one, and a kernel behind a hand-over kernel on the same queue waits for it (8 queues: 214 ms per 1 M pairs, 16: 194 ms,
+// profiles/r03o).  The runtime reads GPU_MAX_HW_QUEUES when it initialises: set a default when the process has none (never overrides the caller's).
+__attribute__((constructor)) static void moni_hip_default_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 extern "C" {
 
@@ -447,7 +453,7 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     for (int x = 0; x < AK_NSET; ++x) c->af[x].release();
     for (int x = 0; x < PE_NSET; ++x) c->af_pe[x].release();
     for (int x = 0; x < PE_NSTREAM; ++x) if (c->pe_stream[x]) (void)hipStreamDestroy(c->pe_stream[x]);
-    c->af_ctr_host.release(); c->fb_all.release();
+    c->af_ctr_host.release(); c->pe_hcur.release(); c->fb_all.release();
     c->dp_q.release(); c->dp_t.release(); c->dp_dir.release(); c->dp_tasks.release(); c->dp_res.release(); c->dp_cig.release();
     c->dp_off.release(); c->dp_ws.release(); c->dp_big.release(); c->dp_dir_big.release(); c->ak_slots.release(); c->ak_waves.release(); c->ak_cursors.release(); c->ak_rnames.release(); c->ak_quals.release(); c->ak_rname_off.release(); c->ak_txt.release(); c->ak_mapq_tab.release(); c->h_txt.release(); c->h_recs.release(); c->h_cig.release(); c->h_alt.release(); c->h_md.release();
     for (auto& ob : c->pieces) ob.release();

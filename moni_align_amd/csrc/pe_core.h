@@ -22,6 +22,8 @@ struct pe_params_t {
     float mean, std_dev;                 // paired_alignment_t::mean / std_dev are floats (aligner_ksw2.hpp:684-685)
     uint32_t find_orphan, w;             // w: the separator run between sequences (seqidx::get_w); orphan recovery for the pairs that chain but fail jointly (aligner_ksw2.hpp:900-906)
     double ins_mean, ins_std_dev;        // the model as doubles: the search window of paired_chain_orphan_score (aligner_ksw2.hpp:2398-2420)
+    const double* pen_tab;               // the pairing term's penalty for dist < pen_tab_n, computed on the host with the host's libm (null: computed in place)
+    uint32_t pen_tab_n, pad_pen;
 };
 
 #ifndef DP_EZ_LOCAL
@@ -69,13 +71,17 @@ AC_HD uint64_t pe_dist(uint64_t a, uint64_t b) { return a > b ? a - b : b - a; }
 #define PE_DADD(a, b) ((a) + (b))
 #endif
 
-// the pairing term (aligner_ksw2.hpp:2176-2181): operations in the reference's order, none contracted.  erfc / log come from the
-// platform's libm (device: ocml): a last-place difference changes the truncated integer only when the sum is within ~1e-15 of one
-AC_HD int32_t pe_pair_total(const pe_params_t& PP, int32_t s1, int32_t s2, long long dist) {
+// the pairing term (aligner_ksw2.hpp:2176-2181): operations in the reference's order, none contracted.  The penalty depends on dist alone (the
+// model and smatch are the call's): the library computes it on the HOST for every dist below pen_tab_n (glibc's erfc / log, what the reference runs
+// on) and the kernels look it up; beyond the table (a fragment of more than 8191 bases: the term is far below every score) the device's libm stands in
+AC_HD double pe_pair_pen(const pe_params_t& PP, long long dist) {
     double ns = 0.0;
     if (PP.std_dev > 0.0f) ns = (double)(((float)dist - PP.mean) / PP.std_dev);
+    return PE_DMUL(PE_DMUL(.721, log(PE_DMUL(2., erfc(PE_DMUL(fabs(ns), M_SQRT1_2))))), (double)PP.P.smatch);
+}
+AC_HD int32_t pe_pair_total(const pe_params_t& PP, int32_t s1, int32_t s2, long long dist) {
     const int32_t s12 = (int32_t)((uint32_t)s1 + (uint32_t)s2);
-    const double pen = PE_DMUL(PE_DMUL(.721, log(PE_DMUL(2., erfc(PE_DMUL(fabs(ns), M_SQRT1_2))))), (double)PP.P.smatch);
+    const double pen = (PP.pen_tab && dist >= 0 && (unsigned long long)dist < (unsigned long long)PP.pen_tab_n) ? PP.pen_tab[dist] : pe_pair_pen(PP, dist);
     const double v = PE_DADD(PE_DADD((double)s12, pen), .499);
     int32_t tot = v != v || v <= -2147483648.0 ? INT32_MIN : (v >= 2147483647.0 ? INT32_MIN : (int32_t)v);      // cvttsd2si: out of range -> INT_MIN
     if (tot < 0) tot = 0;

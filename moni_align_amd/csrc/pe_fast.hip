@@ -50,35 +50,45 @@ struct pef_args_t {
 };
 
 typedef af_wave_tt<AF_MAX_ANCH, AF_MAX_CHAINS, AF_MAX_MEMS, 2 * PEF_MAX_Q, AF_PLAN_AN, AF_MAX_TASKS_READ, 1> pef_wave_t;
+// most pairs: 2 x 150 bp on a 13-sequence index seed ~8 MEMs and ~90 anchors per pair (p99.9: 13 and 157; profiles/r03l/pe_seed_hist.txt): 9 KB of LDS, 4 waves per SIMD.
+// A pair that overflows this instance is put on a list for the large one (LEVEL 1).
+typedef af_wave_tt<160, 80, 24, 2 * PEF_MAX_Q, 64, 48, 1> pef_wave_small_t;
+#define PEF_RAW_SMALL 32
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // pe_plan_kernel
 // ------------------------------------------------------------------------------------------------------------------------------
-template <class WT, int OCC>
+__global__ void iota_kernel(uint32_t* __restrict__ out, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = i; }
+
+// LEVEL 0: every pair of the launch, the small instance; a pair beyond its capacities goes to G.big_list.  LEVEL 1: that list, the large instance;
+// a pair beyond ITS capacities goes to pe_align_kernel.
+template <class WT, int OCC, int RAW, int LEVEL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) pe_plan_kernel(const pef_args_t X) {
     __shared__ WT L;
-    __shared__ af_mem_t raw[PEF_RAW];           // the seeds of both mates as the seeding kernels left them (mate field: their strand bit)
-    __shared__ uint32_t raw_aux[PEF_RAW];
-    __shared__ uint16_t ord[PEF_RAW];           // the pair's seed list in the reference's order: raw index | call << 12
+    __shared__ af_mem_t raw[RAW];               // the seeds of both mates as the seeding kernels left them (mate field: their strand bit)
+    __shared__ uint32_t raw_aux[RAW];
+    __shared__ uint16_t ord[RAW];               // the pair's seed list in the reference's order: raw index | call << 12
     __shared__ uint32_t sh[8];
     const af_args_t& G = X.G;
     const ak_args_t& A = G.A;
     const ac_params_t& P = A.P;
     const int lane = threadIdx.x;
-    const uint32_t n_work = (uint32_t)A.n_reads;
+    const uint32_t n_work = LEVEL == 0 ? (uint32_t)A.n_reads : G.ctr[AFC_BIG];
     while (true) {
         uint32_t w_in = 0;
-        if (lane == 0) w_in = atomicAdd(&G.ctr[AFC_READ_CUR], 1u);
+        if (lane == 0) w_in = atomicAdd(&G.ctr[LEVEL == 0 ? AFC_READ_CUR : AFC_BIG_CUR], 1u);
         w_in = (uint32_t)__shfl((int)w_in, 0);
         if (w_in >= n_work) break;
-        const uint32_t r_in = w_in;
+        const uint32_t r_in = LEVEL == 0 ? w_in : G.big_list[w_in];
         const uint64_t pair = A.read_lo + r_in, r1 = 2 * pair, r2 = r1 + 1;
         const uint64_t off1 = A.offs[r1], off2 = A.offs[r2];
         const uint32_t m1 = (uint32_t)(off2 - off1), m2 = (uint32_t)(A.offs[r2 + 1] - off2);
         const uint64_t a1 = A.read_mem_off[r1], b1 = A.read_mem_off[r1 + 1], b2 = A.read_mem_off[r2 + 1];      // seeds of mate 1: [a1, b1), of mate 2: [b1, b2)
         const uint32_t n1 = (uint32_t)(b1 - a1), n2 = (uint32_t)(b2 - b1);
         uint32_t status = AF_ST_UNALIGNED;
-        bool fallback = m1 >= AF_MAX_READ || m2 >= AF_MAX_READ || n1 + n2 > PEF_RAW;
+        const bool too_long = m1 >= AF_MAX_READ || m2 >= AF_MAX_READ;
+        bool fallback = too_long || n1 + n2 > (uint32_t)RAW;
+        bool retry = false;                                       // LEVEL 0: beyond this instance, not (yet) beyond the staged kernels
         if (m1 == 0 || m2 == 0) fallback = false;                 // (an empty mate: the pair is not aligned, pe_align_kernel's rule)
         uint32_t n_mems = 0, na = 0;
         float avg = 0.f;
@@ -102,7 +112,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
                         const uint32_t ax = raw_aux[base + g];
                         if (ax >= 0xFFFFFFFDu && ax != 0xFFFFFFFFu) break;            // the halves follow all MEMs of the read
                         if (raw[base + g].mate != c_rc[k]) continue;
-                        if (no >= PEF_RAW) { ovf = true; break; }
+                        if (no >= (uint32_t)RAW) { ovf = true; break; }
                         ord[no++] = (uint16_t)((base + g) | ((uint32_t)k << 12));
                         if (k < 2) ++n_dir1; else ++n_dir2;
                     }
@@ -113,7 +123,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
                         const uint32_t ax = raw_aux[base + g];
                         if (ax >= 0xFFFFFFFDu && ax != 0xFFFFFFFFu) break;
                         if (raw[base + g].mate != c_rc[k] || ax == 0xFFFFFFFFu) continue;
-                        if (no + 2 > PEF_RAW || base + ax + 1 >= n1 + n2) { ovf = true; break; }
+                        if (no + 2 > (uint32_t)RAW || base + ax + 1 >= n1 + n2) { ovf = true; break; }
                         ord[no++] = (uint16_t)((base + ax) | ((uint32_t)k << 12));
                         ord[no++] = (uint16_t)((base + ax + 1) | ((uint32_t)k << 12));
                     }
@@ -240,7 +250,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
                     uint32_t ti = nt;
                     for (int o = 1; o < 2 * PEF_MAX_Q; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)ti, o); if (lane >= o) ti += x; }
                     const uint32_t total_t = n_cand ? (uint32_t)__shfl((int)ti, (int)n_cand - 1) : 0u;
-                    if (bad || total_t > (uint32_t)WT::NT) {
+                    if (LEVEL == 0 && (bad || total_t > (uint32_t)WT::NT)) { retry = true; status = AF_ST_UNALIGNED; }
+                    else if (bad || total_t > (uint32_t)WT::NT) {
                         status = AF_ST_FALLBACK;
                         if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + (an_bad ? AF_WHY_CHAIN_LEN : bad ? AF_WHY_TASK_SIZE : AF_WHY_CAPACITY)], 1u);
                     } else {
@@ -257,7 +268,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
             }
         }
         __syncthreads();
-        if (fallback) { status = AF_ST_FALLBACK; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + ((m1 >= AF_MAX_READ || m2 >= AF_MAX_READ) ? AF_WHY_LONG : AF_WHY_ANCHORS)], 1u); }
+        if (LEVEL == 0 && fallback && !too_long) retry = true;
+        if (retry) {                                              // the large instance takes the pair
+            if (lane == 0) G.big_list[atomicAdd(&G.ctr[AFC_BIG], 1u)] = r_in;
+            __syncthreads();
+            continue;
+        }
+        if (fallback) { status = AF_ST_FALLBACK; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + (too_long ? AF_WHY_LONG : AF_WHY_ANCHORS)], 1u); }
         // ---- the pair's tasks go to its own slots; the plan goes to HBM ----
         auto& PL = L.plan;
         const uint32_t nt = status == AF_ST_CAND ? L.n_tasks : 0u;

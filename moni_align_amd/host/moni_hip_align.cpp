@@ -467,9 +467,9 @@ static int run_paired(Args& a, const std::string& sam_filename) {
 }
 
 int main(int argc, char** argv) {
-    // HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); every context runs its launches on several
-    // streams, and streams that share a queue run one after the other
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues; every context runs its launches on several streams (the paired
+    // path on ~11), and streams that share a queue run one after the other
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     Args a;
     parse(argc, argv, a);
     if (a.secondary) die("option -Z is not implemented in moni-hip-align yet");

@@ -12,18 +12,18 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-KERNELS="ms_lf|mem_kernel|occ_kernel|pack_kernel|chain_plan|dp_lane|select_kernel|traceback|finish_wave|finish_kernel|global_task|af_chunk|gather_lines|align_kernel"
+KERNELS="ms_lf|mem_kernel|occ_kernel|pack_kernel|classify|bin_tasks|chain_plan|dp_lane|select_kernel|traceback|finish_wave|finish_kernel|global_task|af_chunk|gather_lines|align_kernel"
 echo "[1/4] building + caching the index"
-MONI_BENCH_SAVE_INDEX=1 python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/bench_build.json 2> $OUT/bench_build.log || exit 1
+MONI_BENCH_SAVE_INDEX=1 python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-from-host > $OUT/bench_build.json 2> $OUT/bench_build.log || exit 1
 echo "[2/4] kernel trace"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu > $OUT/bench_trace.json 2> $OUT/bench_trace.log || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu --no-from-host > $OUT/bench_trace.json 2> $OUT/bench_trace.log || exit 1
 cp "$(find $OUT/trace -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv
 echo "[3/4] HBM counters (FETCH_SIZE and WRITE_SIZE do not fit one pass: two passes)"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KERNELS" --output-format csv -d $OUT/pmc_hbm/fetch -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/bench_pmc_fetch.json 2> $OUT/bench_pmc_fetch.log || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KERNELS" --output-format csv -d $OUT/pmc_hbm/fetch -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-from-host > $OUT/bench_pmc_fetch.json 2> $OUT/bench_pmc_fetch.log || exit 1
 echo "      write pass"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KERNELS" --output-format csv -d $OUT/pmc_hbm/write -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/bench_pmc_write.json 2> $OUT/bench_pmc_write.log || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KERNELS" --output-format csv -d $OUT/pmc_hbm/write -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-from-host > $OUT/bench_pmc_write.json 2> $OUT/bench_pmc_write.log || exit 1
 echo "[4/4] SQ counters"
-timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY --kernel-include-regex "$KERNELS" --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/bench_pmc_sq.json 2> $OUT/bench_pmc_sq.log || exit 1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY --kernel-include-regex "$KERNELS" --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-from-host > $OUT/bench_pmc_sq.json 2> $OUT/bench_pmc_sq.log || exit 1
 cd $ROOT
 python3 - <<PY | tee $OUT/summary.txt
 import csv, glob, collections

@@ -336,6 +336,7 @@ char* sim_align_pe_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint
     if (be.seed(sp, gm, go, rmo)) return nullptr;
     const std::vector<uint32_t>& aux = S->aux;
     pe_params_t PP;
+    PP.pen_tab = nullptr; PP.pen_tab_n = 0; PP.pad_pen = 0;
     ac_params_t& AP = PP.P;
     AP.min_len = P.min_len; AP.ext_len = P.ext_len; AP.check_k = P.check_k; AP.region_dist = P.region_dist; AP.filter_freq = P.filter_freq;
     AP.left_mem_check = P.left_mem_check; AP.freq_thr = P.freq_thr; AP.smatch = P.smatch; AP.gapo = P.gapo; AP.gapo2 = P.gapo2; AP.gape = P.gape;

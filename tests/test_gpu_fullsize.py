@@ -107,6 +107,46 @@ def test_configs2_mouse_scale_lifted_index_50k_reads():
     assert rn <= {b"chr19", b"*"}                               # every record is lifted onto the reference contig
 
 
+def test_configs2_paired_end_with_orphan_recovery():
+    """pairs on the configs[2]-scale index (40-bit positions, run indices beyond 2^24, lifted haplotypes): st_align's paired loop through the C ABI
+    (learn on batches of 512, align them, then the rest) against the oracle's paired path with orphan recovery; fragment model bit-identical"""
+    from moni_align_amd import capi, synth
+    from oracle import orc
+    from tests.test_gpu_pe import gpu_align_all
+    pg, fi = build_or_load(61420004, 12)
+    N, L = 6000, 150
+    mates, _ = synth.make_pairs(pg, N, L, seed=351)
+    rng = np.random.default_rng(7)
+    for p in range(40, N, 97):                     # pairs that fail jointly: one mate with a substitution every 17 bases (no 25-base MEM) -> orphan recovery
+        x = mates[2 * p + (p & 1)]
+        x[3::17] = np.where(x[3::17] == ord("A"), ord("C"), ord("A"))
+    for p in range(13, N, 211):                    # one mate of noise
+        mates[2 * p + 1] = rng.choice(np.frombuffer(b"ACGT", np.uint8), L)
+    names, noff = synth.make_pair_names(N)
+    offs = np.arange(0, (2 * N + 1) * L, L, dtype=np.uint64)
+    q = ((np.arange(2 * N * L) % 39) + 34).astype(np.uint8)
+    o = orc.OracleIndex(fi=fi)
+    o1 = np.arange(0, (N + 1) * L, L, dtype=np.uint64)
+    n1 = b"".join(bytes(names[int(noff[2 * p]):int(noff[2 * p + 1])]) for p in range(N)); n2 = b"".join(bytes(names[int(noff[2 * p + 1]):int(noff[2 * p + 2])]) for p in range(N))
+    no1 = np.zeros(N + 1, np.uint64); no1[1:] = np.cumsum([int(noff[2 * p + 1] - noff[2 * p]) for p in range(N)])
+    no2 = np.zeros(N + 1, np.uint64); no2[1:] = np.cumsum([int(noff[2 * p + 2] - noff[2 * p + 1]) for p in range(N)])
+    qq = q.reshape(2 * N, L)
+    want, st = orc.align_pe(o, np.ascontiguousarray(mates[0::2]).reshape(-1), o1, np.ascontiguousarray(mates[1::2]).reshape(-1), o1, np.frombuffer(n1, np.uint8), no1,
+                            np.frombuffer(n2, np.uint8), no2, np.ascontiguousarray(qq[0::2]).reshape(-1), np.ascontiguousarray(qq[1::2]).reshape(-1), b_size=512, find_orphan=True)
+    assert st["orphan_recovered"] > 20
+    idx = capi.Index(fi=fi)
+    ctx = capi.Ctx(idx)
+    try:
+        got, model, aligned = gpu_align_all(ctx, mates.reshape(-1), offs, names, noff, q, 512, find_orphan=True)
+    finally:
+        ctx.close()
+        idx.close()
+    assert model.complete and model.count == st["ins_count"] and model.mean == st["ins_mean"] and model.std_dev == st["ins_std_dev"]
+    if got != want:
+        raise AssertionError("paired SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
+    assert aligned == st["aligned"] and aligned > 5800
+
+
 def test_configs4_shaped_chr21_scale_20_haplotypes_250bp():
     pg, fi = build_or_load(46709983, 20)
     assert fi.n > 970_000_000 and len(fi.names) == 21

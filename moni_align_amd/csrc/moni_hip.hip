@@ -91,7 +91,7 @@ struct HBuf {                  // pinned host buffer, grow-only
 };
 
 #define PE_NSET 1          // sets of the staged paired kernels' large buffers (pe_api.inc): the chunks' staged kernels run one after the other on one stream, what outlives them is per chunk
-#define PE_NSTREAM 8       // hand-over kernels of the paired path in flight, one stream and one slot array each
+#define PE_NSTREAM 4       // hand-over launches of the paired path in flight, one stream and one slot array each
 #define AK_NSET 2          // launch streams of the align stage, each with its own buffer set: sub-batch k runs on set k % AK_NSET
 struct moni_ctx {
     moni_index* idx = nullptr;
@@ -165,10 +165,11 @@ struct moni_ctx {
     DBuf<int32_t> ak_minscore;
     struct PeBufs { DBuf<pe_slot_t> slots; DBuf<ak_wave_t> waves; DBuf<pe_rec_t> recs; DBuf<uint32_t> cig; DBuf<moni_alt_t> alt; DBuf<unsigned long long> cur; DBuf<int32_t> minscore;
                     DBuf<pe_sel_t> sel[PE_NSET]; DBuf<uint32_t> fb[PE_NSET];
-                    DBuf<uint64_t> txt_pool, block, dev_len, dev_off, dev_pos; DBuf<int32_t> subn_tab; DBuf<double> pen_tab; DBuf<uint8_t> scan_tmp[PE_NSTREAM]; bool subn_ready = false;      // the lines written on the GPU (pe_lines.hip)
+                    DBuf<uint64_t> txt_pool, block, dev_len, dev_off, dev_pos; DBuf<int32_t> subn_tab; DBuf<double> pen_tab; DBuf<pe_pslot_t> park, k1_slots; DBuf<uint8_t> k1_dirs; DBuf<uint32_t> parked; DBuf<pe_orec_t> orec; uint32_t tag = 0;      // pe_orphan_kernel: parked pairs, their chains' scores
+                    DBuf<uint8_t> scan_tmp[PE_NSTREAM]; bool subn_ready = false;      // the lines written on the GPU (pe_lines.hip)
                              // staged paired kernels (pe_fast.hip): per chunk in flight, what pe_select_kernel decided; the hand-over list (16 words of counter, then the pairs)
                     void release() { slots.release(); waves.release(); recs.release(); cig.release(); alt.release(); cur.release(); minscore.release(); for (int x = 0; x < PE_NSET; ++x) { sel[x].release(); fb[x].release(); }
-                                     txt_pool.release(); block.release(); dev_len.release(); dev_off.release(); dev_pos.release(); subn_tab.release(); pen_tab.release(); for (int x = 0; x < PE_NSTREAM; ++x) scan_tmp[x].release(); } } pe;      // paired-end path (pe_api.inc)
+                                     txt_pool.release(); block.release(); dev_len.release(); dev_off.release(); dev_pos.release(); subn_tab.release(); pen_tab.release(); park.release(); k1_slots.release(); k1_dirs.release(); parked.release(); orec.release(); for (int x = 0; x < PE_NSTREAM; ++x) scan_tmp[x].release(); } } pe;      // paired-end path (pe_api.inc)
     unsigned long long* d_ak_cursors = nullptr;
     char* out_buf = nullptr; size_t out_cap = 0;      // moni_align_run's text buffer, kept across calls; pinned (hipHostMalloc): the in-order blocks of the
                                                       // sub-batches land in it by DMA
@@ -177,6 +178,7 @@ struct moni_ctx {
     HBuf<unsigned long long> h_sum;                   // per sub-batch: bytes of the block, records that need the host, aligned reads
     DBuf<uint8_t> gather_tmp[AK_NSET];                      // rocPRIM scan workspace of the gather, one per stream it runs on (the two streams' scans overlap)
     float ak_kernel_ms = 0;
+    int n_cu_cached = 0, pe_occ_cached = 0;          // hipGetDeviceProperties / the occupancy query take a millisecond each: asked once per context
 };
 
 namespace {
@@ -190,6 +192,10 @@ int upload(Tp** d, const std::vector<Tp>& h, uint64_t& bytes) {
     return MONI_OK;
 }
 
+int ctx_n_cu(moni_ctx* c) {
+    if (!c->n_cu_cached) { hipDeviceProp_t pr; c->n_cu_cached = hipGetDeviceProperties(&pr, c->idx->device) == hipSuccess ? pr.multiProcessorCount : 256; }
+    return c->n_cu_cached;
+}
 int exclusive_scan_u64(moni_ctx* c, uint64_t* in, uint64_t* out, size_t n) {
     size_t tmp_bytes = 0;
     if (rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c->stream) != hipSuccess) return MONI_ENODEV;
@@ -1072,7 +1078,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         if (const char* v = getenv("MONI_AK_FORCE_HANDBACK")) { const long long x = atoll(v); if (x > 0) force_back = (uint64_t)x; }
         if (!c->ak_waves_full) {      // persistent waves: exactly as many blocks as stay resident, each lane takes reads off a shared counter
             int n_cu = 256, per_cu = 8;
-            { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, I->device) == hipSuccess) n_cu = pr.multiProcessorCount; }
+            n_cu = ctx_n_cu(c);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, align_kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
             c->ak_waves_full = (uint64_t)n_cu * (uint64_t)per_cu;
         }
@@ -1161,7 +1167,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             }
         }
         int n_cu = 256;
-        { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, I->device) == hipSuccess) n_cu = pr.multiProcessorCount; }
+        n_cu = ctx_n_cu(c);
         const uint64_t ak_waves = use_fast ? std::min<uint64_t>(waves_full, 1024) : waves_full;       // in-flight read slots of align_kernel (75 KB each)
         if ((rc = c->ak_slots.ensure(AK_NSET * ak_waves * AK_NL)) || (rc = c->ak_waves.ensure(AK_NSET * ak_waves)) || (rc = c->h_recs.ensure(NR + 1)) ||
             (rc = c->h_cig.ensure(cig_per * n_sub + 1)) || (rc = c->h_alt.ensure(alt_per * n_sub + 1)) || (rc = c->h_md.ensure(md_per * n_sub + 1)) || (rc = c->ak_minscore.ensure(msc.size())) ||

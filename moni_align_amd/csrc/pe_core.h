@@ -35,7 +35,15 @@ struct pe_mscore_t { int32_t score; uint32_t pad; uint64_t pos, lft; };         
 struct pe_pscore_t { int32_t tot; uint32_t paired; long long dist; pe_mscore_t m1, m2; uint64_t chain_i; long long w0, w1; };      // paired_score_t; w0 / w1: orphan_paired_score_t::pos
 struct pe_left_t { uint64_t r1, r2, score; };
 
+// Orphan recovery over several waves (pe_kernel.hip: pe_orphan_kernel): the loop over the chains is the expensive part of a pair that fails jointly - two
+// DP rounds per chain, a local alignment among them, one chain after the other - and the chains' scores do not depend on one another, only the
+// best_scores update that absorbs them does (it merges by region, in chain order).  o_mode 3: the state machine stops where the loop would begin (the
+// pair's state stays in its slot); 1: it runs the loop for the chains c with c % o_nsplit == o_part and RECORDS each chain's score instead of
+// absorbing it; 2: it runs the loop in chain order from the records - no DP - and goes on to the final alignments.  0: the whole thing in one go.
+struct pe_orec_t { uint32_t tag, kind; pe_pscore_t sc; };      // kind 1: the chain's score; 2: the chain's requests were beyond the kernel (-> the pair's status 2)
 struct pe_ws_t {
+    uint32_t o_mode, o_part, o_nsplit, o_tag, o_parked, o_pad;
+    pe_orec_t* orec;                     // the pair's records, one per chain
     ac_ws_t W;                           // mems, anchors, chains, DP requests, sort stack (W.off / W.m / W.fill / W.best / W.cigar unused)
     uint64_t off[2]; uint32_t m[2];      // the two mates in the resident batch (reads 2p and 2p + 1)
     int32_t min_score_m[2], min_score;
@@ -95,6 +103,7 @@ AC_HD_BIG bool pe_init(pe_ws_t& S, const pe_params_t& PP, const moni_mem_t* gm, 
     ac_ws_t& W = S.W;
     const ac_params_t& P = PP.P;
     ac_reset(W);
+    S.o_mode = 0; S.o_part = 0; S.o_nsplit = 1; S.o_tag = 0; S.o_parked = 0; S.orec = nullptr;
     S.n_best = S.n_left = 0; S.n_alt[0] = S.n_alt[1] = 0; S.max_m[0] = S.max_m[1] = 0;
     S.score2 = S.score2_m[0] = S.score2_m[1] = 0; S.sub_n = 0; S.strand = 0; S.filled[0] = S.filled[1] = 0; S.n_cigar[0] = S.n_cigar[1] = 0;
     S.orphan[0] = S.orphan[1] = 0; S.o_anch = 0; S.o_have = 0; S.o_start = S.o_end = 0; S.o_t_local = S.o_t_ext = S.o_t_glob = -1; S.final.w0 = S.final.w1 = 0;
@@ -297,10 +306,19 @@ AC_HD_BIG bool pe_orphan_advance(pe_ws_t& S, const pe_params_t& PP) {
     ac_ws_t& W = S.W;
     while (W.stage == PE_O_LOOP && !W.overflow) {
         if (W.i < W.n_chains) {
+            if (S.o_mode == 1 && (uint32_t)(W.i % S.o_nsplit) != S.o_part) { ++W.i; continue; }          // another wave's chain
+            if (S.o_mode == 2 && S.orec[W.i].tag == S.o_tag) {                                            // scored by the waves of the pass before
+                const pe_orec_t& R = S.orec[W.i];
+                if (R.kind != 1) { W.overflow = 1; return false; }
+                pe_absorb_best(S, PP, R.sc);
+                ++W.i;
+                continue;
+            }
             if (!pe_orphan_begin(S, PP, W.i)) return false;
             W.stage = PE_O_WAIT_A;
             return true;
         }
+        if (S.o_mode == 1) { W.stage = AC_DONE; return false; }                                           // this wave's chains are scored
         while (S.n_best < 2) {
             pe_pscore_t& z = S.best[S.n_best++];
             z.tot = 0; z.paired = 0; z.dist = 0; z.chain_i = W.n_chains;
@@ -379,7 +397,11 @@ AC_HD_BIG bool pe_advance(pe_ws_t& S, const pe_params_t& PP) {
         S.final = S.best[0];
         if (S.best[0].tot < S.min_score) {
             S.n_alt[0] = S.n_alt[1] = 0;
-            if (PP.finalize && PP.find_orphan && W.n_chains > 0) { S.n_best = 0; W.i = 0; W.stage = PE_O_LOOP; return pe_orphan_advance(S, PP); }      // aligner_ksw2.hpp:900-906
+            if (PP.finalize && PP.find_orphan && W.n_chains > 0) {
+                S.n_best = 0; W.i = 0; W.stage = PE_O_LOOP;
+                if (S.o_mode == 3) { S.o_parked = 1; W.n_tasks = 0; return false; }          // the loop is other launches' (pe_orphan_kernel)
+                return pe_orphan_advance(S, PP);
+            }      // aligner_ksw2.hpp:900-906
             W.stage = AC_DONE;
             return false;
         }
@@ -494,7 +516,8 @@ AC_HD_BIG void pe_drive(pe_ws_t& S, const pe_params_t& PP, const moni_dp_result_
                 sc.m1 = ms[0]; sc.m2 = ms[1];
                 sc.dist = (long long)pe_dist(sc.m2.pos, sc.m1.pos + (uint64_t)S.m[0]);
                 sc.tot = pe_pair_total(PP, sc.m1.score, sc.m2.score, sc.dist);
-                pe_absorb_best(S, PP, sc);
+                if (S.o_mode == 1) { pe_orec_t& R = S.orec[W.i]; R.sc = sc; R.kind = 1; R.tag = S.o_tag; }
+                else pe_absorb_best(S, PP, sc);
                 ++W.i;
                 W.stage = PE_O_LOOP;
                 break;

@@ -309,3 +309,140 @@ pe_align_kernel(const pe_args_t A) {
     __syncthreads();
     if (lane == 0) { atomicAdd(&A.cursors[2], s_cnt[0]); atomicAdd(&A.cursors[3], s_cnt[1]); }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// pe_orphan_kernel: the pairs the staged kernels hand over, in three launches, so that the chains of a pair that needs orphan recovery are scored
+// by several waves at once instead of one after the other on one (pe_core.h: pe_orec_t; ~30 ms for the slowest pair of a launch otherwise, which
+// nothing hides at the end of a batch).  One pair per wave, lane 0 runs its state machine, the wave solves its DP requests.
+//   MODE 3  every listed pair: to its end (record written), or to the point where the orphan loop would begin - its state stays in park[li]
+//   MODE 1  the parked pairs x nsplit: a copy of the parked state runs the loop for the chains c with c % nsplit == part and records their scores
+//   MODE 2  the parked pairs: the loop replayed from the records in chain order (no DP), the final alignments, the record
+// ------------------------------------------------------------------------------------------------------------------------------
+struct pe_pslot_t { pe_ws_t ws; moni_dp_result_t res[AC_MAX_TASKS]; uint32_t cig[AK_CIG_CAP]; };
+struct pe_oargs_t {
+    pe_pslot_t* park; uint32_t* parked; uint32_t cap;      // the first cap listed pairs may park
+    pe_orec_t* orec;                                        // cap x AC_MAX_CHAINS
+    uint32_t nsplit, tag;
+    pe_pslot_t* k1_slots;                                   // MODE 1: one per wave of its launch (no one-lane rows)
+    uint8_t* k1_dirs; uint32_t k1_dirs_cap;                 // and direction bytes for the gap fills between anchors (small problems: a larger one sends the pair to the host pipeline)
+};
+
+// the wave solves the DP requests lane 0's state machine has queued in ws (results to res / cig); false: one of them is beyond the kernel
+__device__ __forceinline__ bool pe_wave_solve(const pe_args_t& A, dp_lds_t& L, moni_dp_task_t* s_tasks, unsigned long long* s_cnt, uint8_t* dirs, uint64_t dirs_cap, pe_ws_t& ws,
+                                              moni_dp_result_t* res, uint32_t* cig) {
+    const int lane = threadIdx.x;
+    const uint32_t* __restrict__ tsrc = reinterpret_cast<const uint32_t*>(ws.W.tasks);
+    constexpr uint32_t TW = AC_MAX_TASKS * (uint32_t)(sizeof(moni_dp_task_t) / 4);
+    const uint32_t nt = ws.W.n_tasks;
+    __syncthreads();
+    for (uint32_t x = (uint32_t)lane; x < TW; x += 64) ((uint32_t*)s_tasks)[x] = tsrc[x];
+    __syncthreads();
+    bool too_big = false;
+    uint32_t cig_used = 0;
+    for (uint32_t t = 0; t < nt; ++t) {
+        const moni_dp_task_t task = s_tasks[t];
+        if (task.flag & DP_EZ_LOCAL) {
+            if (task.qlen > DP_LDS_Q) { too_big = true; break; }
+            pe_sw_local_wave(A.D, L, task, &res[t]);
+            __syncthreads();
+            continue;
+        }
+        const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
+        const uint32_t cig_need = with_cigar && task.qlen > 0 && task.tlen > 0 ? (uint32_t)(task.qlen + task.tlen + 2) : 0u;
+        if (task.qlen > DP_LDS_Q || task.tlen > DP_LDS_T || cig_used + cig_need > AK_CIG_CAP ||
+            (with_cigar && (uint64_t)(task.qlen + task.tlen - 1) * (uint64_t)task.tlen > dirs_cap)) { too_big = true; break; }
+        const uint32_t cig_at = cig_used;
+        cig_used += cig_need;
+        (void)extz_wave_lds_lite(A.D, task, L, dirs, cig + cig_at, &res[t], cig_at);
+        if (lane == 0) { s_cnt[0]++; s_cnt[1] += (unsigned long long)(task.qlen > 0 ? task.qlen : 0) * (unsigned long long)(task.tlen > 0 ? task.tlen : 0); }
+        __syncthreads();
+    }
+    return !too_big;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) pe_orphan_kernel(const pe_args_t A, const pe_oargs_t O) {
+    __shared__ dp_lds_t L;
+    __shared__ moni_dp_task_t s_tasks[AC_MAX_TASKS];
+    __shared__ unsigned long long s_cnt[2];
+    __shared__ uint32_t s_go;
+    const int lane = threadIdx.x;
+    if (lane < 2) s_cnt[lane] = 0;
+    __syncthreads();
+    pe_slot_t* const own = MODE == 1 ? nullptr : A.slots + (size_t)blockIdx.x;
+    pe_pslot_t* const own1 = MODE == 1 ? O.k1_slots + (size_t)blockIdx.x : nullptr;
+    uint8_t* __restrict__ dirs = MODE == 1 ? O.k1_dirs + (size_t)blockIdx.x * O.k1_dirs_cap : A.waves[blockIdx.x].dirs;
+    const uint64_t dirs_cap = MODE == 1 ? O.k1_dirs_cap : AK_DIRS_CAP;
+    const uint32_t n_list = *A.n_list;
+    const uint32_t n_park = n_list < O.cap ? n_list : O.cap;
+    const unsigned long long n_items = MODE == 3 ? (unsigned long long)n_list : MODE == 1 ? (unsigned long long)n_park * O.nsplit : (unsigned long long)n_park;
+    while (true) {
+        unsigned long long nxt = 0;
+        if (lane == 0) nxt = atomicAdd(&A.cursors[MODE == 3 ? 4 : MODE == 1 ? 5 : 6], 1ull);
+        nxt = ((unsigned long long)(uint32_t)__shfl((int)(nxt >> 32), 0) << 32) | (uint32_t)__shfl((int)(nxt & 0xFFFFFFFFull), 0);
+        if (nxt >= n_items) break;
+        const uint32_t li = MODE == 1 ? (uint32_t)(nxt / O.nsplit) : (uint32_t)nxt, part = MODE == 1 ? (uint32_t)(nxt % O.nsplit) : 0u;
+        const uint64_t pair = A.pair_list[li];
+        if (MODE != 3 && !O.parked[li]) continue;
+        const bool in_park = MODE == 2 || (MODE == 3 && li < O.cap);
+        pe_ws_t* const W = in_park ? &O.park[li].ws : MODE == 1 ? &own1->ws : &own->ws;
+        moni_dp_result_t* const res = in_park ? O.park[li].res : MODE == 1 ? own1->res : own->res;
+        uint32_t* const cig = in_park ? O.park[li].cig : MODE == 1 ? own1->cig : own->cig;
+        if (MODE == 1) {          // the parked state, copied: this wave's own loop
+            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(&O.park[li].ws);
+            uint4* __restrict__ dst = reinterpret_cast<uint4*>(W);
+            for (uint32_t x = (uint32_t)lane; x < (uint32_t)(sizeof(pe_ws_t) / sizeof(uint4)); x += 64) dst[x] = src[x];
+            __threadfence();
+        }
+        __syncthreads();
+        if (lane == 0) {
+            if (MODE == 3) {
+                bool chained = false;
+                for (int k = 0; k < 2; ++k) {
+                    const uint64_t r = 2 * pair + k;
+                    W->off[k] = A.offs[r]; W->m[k] = (uint32_t)(A.offs[r + 1] - A.offs[r]);
+                    W->min_score_m[k] = A.min_score_of_len[W->m[k] <= A.max_len ? W->m[k] : A.max_len];
+                }
+                W->min_score = W->min_score_m[0] + W->min_score_m[1];
+                W->o_mode = 0; W->o_parked = 0;
+                if (W->m[0] >= 4096 || W->m[1] >= 4096 || W->m[0] == 0 || W->m[1] == 0) {
+                    ac_reset(W->W); W->W.overflow = (W->m[0] >= 4096 || W->m[1] >= 4096) ? 1u : 0u;
+                    W->final.tot = 0; W->final.dist = 0; W->final.m1.score = W->final.m2.score = 0; W->score2 = W->score2_m[0] = W->score2_m[1] = 0; W->sub_n = 0; W->strand = 0;
+                    W->filled[0] = W->filled[1] = 0; W->n_alt[0] = W->n_alt[1] = 0;
+                } else chained = pe_init(*W, A.PP, A.mems, A.read_mem_off, A.aux, A.occs, pair);
+                if (chained) { W->o_mode = in_park ? 3u : 0u; pe_drive(*W, A.PP, nullptr, nullptr); }
+                else W->W.stage = AC_DONE;
+            } else {
+                W->o_mode = (uint32_t)MODE; W->o_part = part; W->o_nsplit = O.nsplit; W->o_tag = O.tag; W->o_parked = 0;
+                W->orec = O.orec + (size_t)li * AC_MAX_CHAINS;
+                pe_drive(*W, A.PP, nullptr, nullptr);
+            }
+            s_go = (!W->W.overflow && W->W.stage != AC_DONE && !W->o_parked) ? 1u : 0u;
+        }
+        __syncthreads();
+        while (s_go) {
+            __threadfence();
+            const bool ok = pe_wave_solve(A, L, s_tasks, s_cnt, dirs, dirs_cap, *W, res, cig);
+            __threadfence();
+            __syncthreads();
+            if (lane == 0) {
+                if (!ok) W->W.overflow = 1;
+                else pe_drive(*W, A.PP, res, cig);
+                s_go = (!W->W.overflow && W->W.stage != AC_DONE && !W->o_parked) ? 1u : 0u;
+            }
+            __syncthreads();
+        }
+        if (lane == 0) {
+            if (MODE == 3) {
+                const bool parked = in_park && W->o_parked && !W->W.overflow;
+                if (li < O.cap) O.parked[li] = parked ? 1u : 0u;
+                if (!parked) pe_write_record(A, *W, pair);
+            } else if (MODE == 1) {
+                if (W->W.overflow && W->W.stage >= PE_O_LOOP && W->W.i < AC_MAX_CHAINS) { pe_orec_t& R = W->orec[W->W.i]; R.kind = 2; R.tag = O.tag; }      // the replay stops here: status 2
+            } else pe_write_record(A, *W, pair);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (lane == 0) { atomicAdd(&A.cursors[2], s_cnt[0]); atomicAdd(&A.cursors[3], s_cnt[1]); }
+}

@@ -435,7 +435,7 @@ def run_rank(args) -> int:
                          "bytes_per_launch": layout_bytes, "avg_launch_ms": kern_launch[0], "per_read_bytes": layout_bytes / max(1, n_first),
                          "survey_8d": {"bytes_per_launch": ms_bytes, "formula": "128 S + 64 J (SURVEY.md 8(d): two 64-byte requests per LF step, one per threshold jump)",
                                        "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "per_read_bytes": ms_bytes / max(1, n_first)},
-                         "traffic_static_from": "profiles/r03s/pmc_hbm.csv when present, else profiles/r02y/pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of this "
+                         "traffic_static_from": "profiles/r03x/pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of this "
                                                 "workload: 26.66 GB fetched + 2.40 GB written = 29.06 GB per launch of 1 M reads = 1.33 x the layout's 21.9 GB, 0.62 x the survey's 47.18 GB; "
                                                 "counters cannot be read inside this run, so `traffic` stays null)",
                          "note": "the path's HBM-bound kernel (LF / threshold-jump stage of seeding), one launch per resident chunk inside the timed region, HIP events on its own stream; "

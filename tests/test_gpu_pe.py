@@ -257,3 +257,32 @@ def test_pe_lines_written_on_the_gpu_equal_the_host_finishing(case, monkeypatch)
     finally:
         ctx.close()
         idx.close()
+
+
+def test_pe_orphan_loop_over_several_waves(case, monkeypatch):
+    """pe_orphan_kernel: a pair that needs orphan recovery is parked where its chain loop begins, the chains are scored by `nsplit` waves (records per
+    chain), the loop is replayed from the records in chain order.  Same SAM as one wave doing it all (MONI_PE_NSPLIT=0), as the oracle, and as the runs
+    where only the first few listed pairs may park (the rest: one wave each) or every chain is its own part"""
+    from tests.test_host_sim_pe import seedless_pairs, oracle_pe_orphan
+    pg, fi, o = case
+    m1, m2 = seedless_pairs(pg)
+    want, st = oracle_pe_orphan(o, m1, m2, b_size=4096)
+    assert st["orphan_recovered"] > 20
+    seq, offs, names, noff, q = interleave(m1, m2)
+    idx = capi.Index(fi=fi)
+    ctx = capi.Ctx(idx)
+    try:
+        model = capi.PeModelC()
+        model.mean, model.std_dev, model.complete = st["ins_mean"], st["ins_std_dev"], 1
+        for env in ({}, {"MONI_PE_NSPLIT": "0"}, {"MONI_PE_NSPLIT": "3", "MONI_PE_OCAP": "5"}, {"MONI_PE_NSPLIT": "64", "MONI_PE_K1_WAVES": "64"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got, sg = ctx.pe_align(seq, offs, names, noff, q, model, host_threads=4, find_orphan=1)
+            for k in env:
+                monkeypatch.delenv(k)
+            if got != want:
+                raise AssertionError("%s: SAM differs at record %d:\n got: %s\nwant: %s" % ((env,) + first_diff(got, want)))
+            assert sg["aligned"] == st["aligned"] and sg["kernel_fallback"] > 20
+    finally:
+        ctx.close()
+        idx.close()

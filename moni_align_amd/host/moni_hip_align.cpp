@@ -352,6 +352,71 @@ static void pwrite_all(int fd, const char* p, size_t n, uint64_t at) {
     }
 }
 
+// the end of the n_rec-th record from s in a mapped four-line FASTQ file (or the end of the file; got = the records before it): the newlines of a
+// window are counted by P threads side by side, the slice in which the count is reached is scanned
+static const char* skip_records(const char* s, const char* end, size_t n_rec, int P, size_t& got) {
+    size_t need = 4 * n_rec, lines = 0;
+    const char* cur = s;
+    while (need > 0 && cur < end) {
+        const size_t win = std::min<size_t>((size_t)(end - cur), std::max<size_t>((size_t)1 << 20, need * 48));
+        std::vector<size_t> cnt(P, 0);
+        auto count = [&](int i) {
+            const char* a = cur + win / P * i; const char* b = i + 1 == P ? cur + win : cur + win / P * (i + 1);
+            size_t c = 0;
+            while (a < b) { const char* e = (const char*)memchr(a, '\n', (size_t)(b - a)); if (!e) break; ++c; a = e + 1; }
+            cnt[i] = c;
+        };
+        { std::vector<std::thread> th; for (int i = 1; i < P; ++i) th.emplace_back(count, i); count(0); for (auto& t : th) t.join(); }
+        size_t total = 0;
+        for (int i = 0; i < P; ++i) total += cnt[i];
+        if (total < need) { need -= total; lines += total; cur += win; continue; }
+        int i = 0;
+        while (cnt[i] < need) { need -= cnt[i]; lines += cnt[i]; ++i; }
+        const char* a = cur + win / P * i;
+        while (need > 0) { const char* e = (const char*)memchr(a, '\n', (size_t)(end - a)); a = e + 1; --need; ++lines; }
+        cur = a;
+    }
+    if (cur >= end && end > s && end[-1] != '\n') ++lines;          // a last line without its newline
+    got = lines / 4;
+    return cur;
+}
+
+// n_pairs pairs from the cursors of two mapped four-line FASTQ files: both ranges parsed in two passes by P threads each (parse_range), then
+// interleaved (mates 2p, 2p + 1) into uninitialised buffers
+struct PairBatch { Raw seq, qual, names; std::vector<uint64_t> off, name_off; size_t n_reads = 0; };
+static size_t read_pairs_fast(const char* base[2], const char* end[2], size_t at[2], size_t n_pairs, int P, ParsedBatch pb[2], PairBatch& B) {
+    size_t got[2] = {0, 0};
+    const char* lim[2];
+    auto one = [&](int k) {
+        lim[k] = skip_records(base[k] + at[k], end[k], n_pairs, P, got[k]);
+        if (got[k]) parse_range(base[k] + at[k], lim[k], base[k], end[k], true, P, pb[k]); else pb[k].n = 0;
+    };
+    { std::thread t(one, 1); one(0); t.join(); }
+    if (got[0] != got[1]) die("the mate files have different numbers of records");
+    if (pb[0].n != got[0] || pb[1].n != got[1]) die("the mate files are not four-line FASTQ throughout (blank or wrapped lines): compress them or use FASTA to take the record-by-record reader");
+    at[0] = (size_t)(lim[0] - base[0]); at[1] = (size_t)(lim[1] - base[1]);
+    const size_t n = got[0];
+    if (!n) return 0;
+    B.n_reads = 2 * n;
+    if (B.off.size() < 2 * n + 1) { B.off.resize(2 * n + 1); B.name_off.resize(2 * n + 1); }
+    const ParsedBatch& b1 = pb[0]; const ParsedBatch& b2 = pb[1];
+    B.seq.ensure(b1.off[n] + b2.off[n] + 16); B.qual.ensure(b1.off[n] + b2.off[n] + 16); B.names.ensure(b1.name_off[n] + b2.name_off[n] + 16);
+    auto part = [&](size_t lo, size_t hi) {
+        for (size_t p = lo; p < hi; ++p) {
+            const uint64_t o1 = b1.off[p] + b2.off[p], o2 = b1.off[p + 1] + b2.off[p], m1 = b1.name_off[p] + b2.name_off[p], m2 = b1.name_off[p + 1] + b2.name_off[p];
+            B.off[2 * p] = o1; B.off[2 * p + 1] = o2; B.name_off[2 * p] = m1; B.name_off[2 * p + 1] = m2;
+            const size_t l1 = (size_t)(b1.off[p + 1] - b1.off[p]), l2 = (size_t)(b2.off[p + 1] - b2.off[p]);
+            memcpy(B.seq.p + o1, b1.seq.p + b1.off[p], l1); memcpy(B.seq.p + o2, b2.seq.p + b2.off[p], l2);
+            memcpy(B.qual.p + o1, b1.qual.p + b1.off[p], l1); memcpy(B.qual.p + o2, b2.qual.p + b2.off[p], l2);
+            memcpy(B.names.p + m1, b1.names.p + b1.name_off[p], (size_t)(b1.name_off[p + 1] - b1.name_off[p]));
+            memcpy(B.names.p + m2, b2.names.p + b2.name_off[p], (size_t)(b2.name_off[p + 1] - b2.name_off[p]));
+        }
+    };
+    { std::vector<std::thread> th; for (int t = 1; t < P; ++t) th.emplace_back(part, n * t / P, n * (t + 1) / P); part(0, n / P); for (auto& t : th) t.join(); }
+    B.off[2 * n] = b1.off[n] + b2.off[n]; B.name_off[2 * n] = b1.name_off[n] + b2.name_off[n];
+    return n;
+}
+
 }  // namespace fastpath
 
 // ---- paired-end (-1 / -2): st_align's paired loop (align_reads_dispatcher.hpp:356-389) over the C ABI ----------------------------------
@@ -371,6 +436,42 @@ static size_t read_pairs(AnyReader& r1, AnyReader& r2, size_t n_pairs, Batch& b)
         if (!r2.next(b)) die("the mate files have different numbers of records");
         ++n;
     }
+    return n;
+}
+// the same with the two files parsed side by side (one thread each) and interleaved afterwards (mates 2p, 2p + 1), by T threads
+static size_t read_pairs_par(AnyReader& r1, AnyReader& r2, size_t n_pairs, Batch& b, int T) {
+    Batch b1, b2;
+    size_t n2 = 0;
+    std::thread t2([&] { while (n2 < n_pairs && r2.next(b2)) ++n2; });
+    size_t n1 = 0;
+    while (n1 < n_pairs && r1.next(b1)) ++n1;
+    t2.join();
+    if (n1 != n2) die("the mate files have different numbers of records");
+    if (n1 < n_pairs) { Batch t; if (r1.next(t) || r2.next(t)) die("the mate files have different numbers of records"); }
+    const size_t n = n1;
+    if (!n) return 0;
+    b.has_qual = b1.has_qual && b2.has_qual;
+    b.off.resize(2 * n + 1); b.name_off.resize(2 * n + 1);
+    for (size_t p = 0; p < n; ++p) {
+        b.off[2 * p] = b1.off[p] + b2.off[p]; b.off[2 * p + 1] = b1.off[p + 1] + b2.off[p];
+        b.name_off[2 * p] = b1.name_off[p] + b2.name_off[p]; b.name_off[2 * p + 1] = b1.name_off[p + 1] + b2.name_off[p];
+    }
+    b.off[2 * n] = b1.off[n] + b2.off[n]; b.name_off[2 * n] = b1.name_off[n] + b2.name_off[n];
+    b.seq.resize(b.off[2 * n]); b.names.resize(b.name_off[2 * n]);
+    if (b.has_qual) b.qual.resize(b.off[2 * n]);
+    auto part = [&](size_t lo, size_t hi) {
+        for (size_t p = lo; p < hi; ++p) {
+            const size_t l1 = (size_t)(b1.off[p + 1] - b1.off[p]), l2 = (size_t)(b2.off[p + 1] - b2.off[p]);
+            memcpy(b.seq.data() + b.off[2 * p], b1.seq.data() + b1.off[p], l1); memcpy(b.seq.data() + b.off[2 * p + 1], b2.seq.data() + b2.off[p], l2);
+            if (b.has_qual) { memcpy(b.qual.data() + b.off[2 * p], b1.qual.data() + b1.off[p], l1); memcpy(b.qual.data() + b.off[2 * p + 1], b2.qual.data() + b2.off[p], l2); }
+            memcpy(b.names.data() + b.name_off[2 * p], b1.names.data() + b1.name_off[p], (size_t)(b1.name_off[p + 1] - b1.name_off[p]));
+            memcpy(b.names.data() + b.name_off[2 * p + 1], b2.names.data() + b2.name_off[p], (size_t)(b2.name_off[p + 1] - b2.name_off[p]));
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(part, n * t / T, n * (t + 1) / T);
+    part(0, n / T);
+    for (auto& t : th) t.join();
     return n;
 }
 static int run_paired(Args& a, const std::string& sam_filename) {
@@ -445,18 +546,120 @@ static int run_paired(Args& a, const std::string& sam_filename) {
             processed += all.n() / 2; aligned += n_al;
         }
     }
-    const size_t pairs_per_batch = std::max<size_t>(a.gpu_batch / 8, 1024);      // the paired kernel keeps one pair per lane: moderate batches
-    bool more = true;
-    while (more) {
-        std::vector<Batch*> bs;
-        for (int g = 0; g < a.gpus; ++g) { Batch* b = new Batch(); if (!read_pairs(r1, r2, pairs_per_batch, *b)) { delete b; more = false; break; } bs.push_back(b); }
-        std::vector<char*> sams(bs.size(), nullptr); std::vector<uint64_t> lens(bs.size(), 0), nal(bs.size(), 0);
-        std::vector<std::thread> th;
-        for (size_t g = 1; g < bs.size(); ++g) th.emplace_back([&, g] { align_one((int)g, *bs[g], &sams[g], &lens[g], &nal[g]); });
-        if (!bs.empty()) align_one(0, *bs[0], &sams[0], &lens[0], &nal[0]);
-        for (auto& t : th) t.join();
-        for (size_t g = 0; g < bs.size(); ++g) { put(sams[g], lens[g], out); moni_free(sams[g]); processed += bs[g]->n() / 2; aligned += nal[g]; delete bs[g]; }
+    // ---- the rest: reader thread (the two files parsed side by side) -> bounded queue -> a few workers per GPU, each with its own context (one's upload and
+    // seeding run beside the others' paired kernels) -> every block written at its place in the file (the in-order prefix sum of the blocks' lengths) ----
+    const size_t pairs_per_batch = std::max<size_t>(a.gpu_batch / 2, 1024);          // as many mates per batch as the single-end path has reads
+    const int per_gpu = a.report_mems ? 1 : std::max(1, a.ctx_per_gpu), P = 4;          // contexts per GPU (--ctx-per-gpu, 3): one's upload, seeding and file write beside the others' paired kernels
+    std::vector<moni_ctx_t*> wctx((size_t)a.gpus * per_gpu, nullptr);
+    for (int g = 0; g < a.gpus; ++g) for (int k = 0; k < per_gpu; ++k) {
+        if (k == 0) wctx[(size_t)g * per_gpu] = ctx[g];
+        else if (moni_ctx_create(idx[g], &wctx[(size_t)g * per_gpu + k])) die("cannot create a context on GPU " + std::to_string(g));
     }
+    if (fflush(out) != 0) die("short write to the output file");
+    const uint64_t off0 = (uint64_t)ftello(out);
+    const int fd = fileno(out);
+    // a batch for the workers: the slow reader's Batch, or the fast reader's PairBatch (both mate files mapped four-line FASTQ)
+    struct Item { size_t id; Batch* b; fastpath::PairBatch* f; };
+    const bool fast_reader = r1.mapped && r2.mapped && r1.m.p[r1.m.at < r1.m.n ? r1.m.at : 0] == '@' && r2.m.p[r2.m.at < r2.m.n ? r2.m.at : 0] == '@' && getenv("MONI_CLI_SLOW_READER") == nullptr;
+    std::mutex mu_q, mu_o;
+    std::condition_variable cv_put, cv_get, cv_o;
+    std::deque<Item> queue;
+    bool reader_done = false;
+    const size_t q_cap = wctx.size() + 1;
+    std::map<size_t, uint64_t> lens, starts;
+    size_t upto = 0; uint64_t off_upto = off0;
+    std::atomic<size_t> n_proc{0}, n_al_all{0};
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_read = 0; std::vector<double> t_lib(wctx.size(), 0), t_wait(wctx.size(), 0), t_write(wctx.size(), 0);
+    const bool verbose_batches = getenv("MONI_CLI_VERBOSE") != nullptr;
+    std::thread reader([&] {
+        size_t id = 0;
+        const char* fbase[2] = {r1.m.p, r2.m.p}; const char* fend[2] = {r1.m.p + r1.m.n, r2.m.p + r2.m.n}; size_t fat[2] = {r1.m.at, r2.m.at};
+        fastpath::ParsedBatch pb[2];
+        while (true) {
+            Batch* b = nullptr; fastpath::PairBatch* f = nullptr;
+            const double r0 = now();
+            if (fast_reader) { f = new fastpath::PairBatch(); if (!fastpath::read_pairs_fast(fbase, fend, fat, pairs_per_batch, 2 * P, pb, *f)) { delete f; break; } }
+            else { b = new Batch(); if (!read_pairs_par(r1, r2, pairs_per_batch, *b, P)) { delete b; break; } }
+            t_read += now() - r0;
+            std::unique_lock<std::mutex> lk(mu_q);
+            cv_put.wait(lk, [&] { return queue.size() < q_cap; });
+            queue.push_back(Item{id++, b, f});
+            cv_get.notify_one();
+        }
+        std::lock_guard<std::mutex> lk(mu_q);
+        reader_done = true;
+        cv_get.notify_all();
+    });
+    auto worker = [&](int w) {
+        moni_ctx_t* C = wctx[w];
+        while (true) {
+            Item it;
+            {
+                std::unique_lock<std::mutex> lk(mu_q);
+                cv_get.wait(lk, [&] { return !queue.empty() || reader_done; });
+                if (queue.empty()) return;
+                it = queue.front(); queue.pop_front();
+                cv_put.notify_one();
+            }
+            const uint8_t* v_seq = it.f ? it.f->seq.p : it.b->seq.data(); const uint64_t* v_off = it.f ? it.f->off.data() : it.b->off.data();
+            const uint8_t* v_names = it.f ? it.f->names.p : it.b->names.data(); const uint64_t* v_noff = it.f ? it.f->name_off.data() : it.b->name_off.data();
+            const uint8_t* v_qual = it.f ? it.f->qual.p : (it.b->has_qual ? it.b->qual.data() : nullptr);
+            const size_t v_n = it.f ? it.f->n_reads : it.b->n();
+            moni_read_batch_t rb{v_seq, v_off, v_n};
+            char* sam = nullptr; uint64_t len = 0; size_t n_al = 0;
+            const double x1 = now();
+            if (a.report_mems) {
+                const int rm = moni_pe_report_mems_batch(C, &rb, v_names, v_noff, v_qual, &a.P, &a.PE, &sam, &len);
+                if (rm) die("moni_pe_report_mems_batch failed (" + std::to_string(rm) + ")");
+            } else {          // the text in the context's pinned buffer: written out before the context's next call
+                moni_align_stats_t st;
+                const int rc = moni_pe_align_stream(C, &rb, v_names, v_noff, v_qual, &a.P, &a.PE, &model, &sam, &len, &st);
+                if (rc) die("moni_pe_align_stream failed (" + std::to_string(rc) + (rc == MONI_ERANGE ? ": a pair exceeds the paired path's capacities)" : ")"));
+                n_al = st.aligned;
+            }
+            uint64_t at = 0;
+            const double x2 = now();
+            {
+                std::unique_lock<std::mutex> lk(mu_o);
+                lens[it.id] = len;
+                while (lens.count(upto)) { starts[upto] = off_upto; off_upto += lens[upto]; lens.erase(upto); ++upto; }
+                cv_o.notify_all();
+                cv_o.wait(lk, [&] { return upto > it.id; });
+                at = starts[it.id]; starts.erase(it.id);
+            }
+            const double x3 = now();
+            if (len) {
+                std::vector<std::thread> th;
+                const size_t sl = (len + P - 1) / P;
+                for (int i = 1; i < P; ++i) { const size_t lo = std::min<size_t>(len, sl * i), hi = std::min<size_t>(len, sl * (i + 1)); if (hi > lo) th.emplace_back(fastpath::pwrite_all, fd, sam + lo, hi - lo, at + lo); }
+                fastpath::pwrite_all(fd, sam, std::min<size_t>(len, sl), at);
+                for (auto& t : th) t.join();
+            }
+            const double x4 = now();
+            t_lib[w] += x2 - x1; t_wait[w] += x3 - x2; t_write[w] += x4 - x3;
+            if (verbose_batches) fprintf(stderr, "batch %zu (worker %d, %zu pairs): library %.0f ms, wait %.0f ms, write %.0f ms, done at %.3f s\n", it.id, w, v_n / 2, (x2 - x1) * 1e3, (x3 - x2) * 1e3, (x4 - x3) * 1e3,
+                                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            if (a.report_mems) moni_free(sam);
+            n_proc += v_n / 2; n_al_all += n_al;
+            delete it.b; delete it.f;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t w = 0; w < wctx.size(); ++w) th.emplace_back(worker, (int)w);
+        for (auto& t : th) t.join();
+    }
+    reader.join();
+    processed += n_proc.load(); aligned += n_al_all.load();
+    {
+        double sl = 0, sw = 0, sr = 0;
+        for (size_t w = 0; w < wctx.size(); ++w) { sl += t_lib[w]; sw += t_wait[w]; sr += t_write[w]; }
+        info("Stage seconds: reading + interleaving the mate files " + std::to_string(t_read) + " (one reader thread, two parsers); summed over " + std::to_string(wctx.size()) + " workers: library calls " +
+             std::to_string(sl) + ", waiting for the block's place " + std::to_string(sw) + ", file writes " + std::to_string(sr));
+    }
+    if (fseeko(out, (off_t)off_upto, SEEK_SET) != 0) die("seek in the output file failed");
+    for (int g = 0; g < a.gpus; ++g) for (int k = 1; k < per_gpu; ++k) moni_ctx_destroy(wctx[(size_t)g * per_gpu + k]);
     close_out(out);
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     info("Number of aligned pairs: " + std::to_string(aligned) + "/" + std::to_string(processed));

@@ -189,6 +189,20 @@ def test_cli_paired_end(exe, medium_case, tmp_path):
     subprocess.check_call([exe, prefix, "-1", f1, "-2", f2, "-o", out2, "-S", "1000", "-F", "0.5", "-t", "4", "-b", "512", "--gpu-batch", "2048"])
     want2, _ = oracle_pe(o, m1, m2, b_size=512, find_orphan=True)
     assert open(out2, "rb").read()[len(hdr):] == want2
+    # -m: the MEM records of the pairs (several batches through the reader thread / two workers / in-place writes)
+    out3 = str(tmp_path / "pe_mems.sam")
+    f2p = str(tmp_path / "m_2.fastq")             # both files plain: the mapped reader (newlines counted and records parsed by several threads, mates interleaved)
+    with open(f2p, "wb") as f:
+        f.write(gzip.open(f2, "rb").read())
+    subprocess.check_call([exe, prefix, "-1", f1, "-2", f2p, "-m", "-o", out3, "-S", "1000", "-F", "0.5", "-t", "4", "--gpu-batch", "600"])
+    want3, _ = oracle_pe(o, m1, m2, b_size=512, report_mems=True)
+    got3 = open(out3, "rb").read()[len(hdr):]
+    if got3 != want3:
+        from tests.test_host_sim_pe import first_diff
+        raise AssertionError("-m records differ at record %d:\n got: %s\nwant: %s" % first_diff(got3, want3))
+    out4 = str(tmp_path / "pe_plain.sam")
+    subprocess.check_call([exe, prefix, "-1", f1, "-2", f2p, "-o", out4, "-S", "1000", "-F", "0.5", "-t", "4", "-b", "512", "--gpu-batch", "300"])
+    assert open(out4, "rb").read()[len(hdr):] == want2
 
 
 def test_dry_run_paired(exe, tmp_path):

@@ -132,6 +132,7 @@ struct af_args_t {
     uint64_t* bnd;                           // per resident DP wave: (H, E) of a target block's last row for every query position (global problems)
     uint32_t* ctr;                           // AF_NCTR counters, see the AFC_* indices
     unsigned long long* prof;                // AF_PROFILE builds: wave cycles per phase
+    uint32_t l0_mm, l0_ma;                   // capacities (seeds, anchors) of the instance the launch uses for LEVEL 0 (classify_kernel)
     uint32_t dbg;                            // AF_PROFILE builds: 1 = no direction stores, 2 = no DP rows (timing experiments; results are wrong)
 };
 #ifdef AF_PROFILE
@@ -183,6 +184,7 @@ struct af_wave_tt {
 };
 static_assert(AF_MAX_TASKS_READ <= 255, "ntasks is a byte");
 typedef af_wave_tt<96, 48, 24, 8, 32, 32> af_wave_small_t;                                                   // most reads: 8 waves per SIMD
+typedef af_wave_tt<160, 80, 32, 16, 64, 48> af_wave_mid_t;            // LEVEL 0 for reads of more than 200 bases (250 bp x 21 sequences: ~120 anchors per read, 27 % of the reads fit the small instance, 85 % this one): 5 waves per SIMD
 typedef af_wave_tt<AF_MAX_ANCH, AF_MAX_CHAINS, AF_MAX_MEMS, AF_MAX_CAND, AF_PLAN_AN, AF_MAX_TASKS_READ> af_wave_t;   // reads that overflow it
 typedef af_wave_tt<2048, 1024, 256, AF_MAX_CAND, AF_PLAN_AN, AF_MAX_TASKS_READ> af_wave_huge_t;             // repeat-rich reads (hundreds of occurrences per seed): one wave per CU
 
@@ -700,7 +702,7 @@ __global__ void __launch_bounds__(256) classify_kernel(const af_args_t G) {
                 if (A.P.filter_freq) { const double fr = static_cast<double>(oc) / (double)(size_t)total; if (fr > A.P.freq_thr) keep = false; }      // seed_freq_filter
                 if (keep) { ++n_mems; n_anch += oc; }
             }
-            level = (n_mems <= (uint32_t)af_wave_small_t::MM && n_anch <= (unsigned long long)af_wave_small_t::MA) ? 0u
+            level = (n_mems <= G.l0_mm && n_anch <= (unsigned long long)G.l0_ma) ? 0u
                   : (n_mems <= (uint32_t)af_wave_t::MM && n_anch <= (unsigned long long)af_wave_t::MA) ? 1u
                   : (n_mems <= (uint32_t)af_wave_huge_t::MM && n_anch <= (unsigned long long)af_wave_huge_t::MA) ? 2u : 3u;
         }

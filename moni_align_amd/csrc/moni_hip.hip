@@ -1402,8 +1402,18 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
 #endif
                 if (const char* v = getenv("MONI_AF_DBG")) G.dbg |= (uint32_t)atoi(v) & 64u;          // 64: the serial anchor sort (cross-check), any build
                 HIPCHK(hipMemsetAsync(S.ctr.p, 0, AF_NCTR * sizeof(uint32_t), sx));
+                // LEVEL 0's instance: the small one, or - reads of more than 200 bases, whose seeds have more occurrences than it holds - the middle one
+                static const int l0_force = getenv("MONI_AF_L0") ? atoi(getenv("MONI_AF_L0")) : -1;          // 0 small, 1 middle
+                const bool l0_mid = l0_force >= 0 ? l0_force == 1 : c->max_len > 200;
+                G.l0_mm = l0_mid ? (uint32_t)af_wave_mid_t::MM : (uint32_t)af_wave_small_t::MM; G.l0_ma = l0_mid ? (uint32_t)af_wave_mid_t::MA : (uint32_t)af_wave_small_t::MA;
                 hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
-                {
+                if (l0_mid) {
+                    static const int midocc = getenv("MONI_AF_MIDOCC") ? atoi(getenv("MONI_AF_MIDOCC")) : 5;          // measured 4 and 5 (7.58 / 7.66 M reads/s at 250 bp x 20 haplotypes; 6.92 M with the small instance as LEVEL 0)
+                    const dim3 g1((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 4 * midocc));
+                    if (midocc == 5) hipLaunchKernelGGL((chain_plan_kernel<af_wave_mid_t, 0, 5>), g1, dim3(64), 0, sx, G);
+                    else if (midocc == 3) hipLaunchKernelGGL((chain_plan_kernel<af_wave_mid_t, 0, 3>), g1, dim3(64), 0, sx, G);
+                    else hipLaunchKernelGGL((chain_plan_kernel<af_wave_mid_t, 0, 4>), g1, dim3(64), 0, sx, G);
+                } else {
                     static const int k1occ = getenv("MONI_AF_K1OCC") ? atoi(getenv("MONI_AF_K1OCC")) : 8;      // 8 waves/SIMD: 32 reads in flight per CU (4.9 KB of LDS each); measured 5, 6, 8
                     const dim3 g1((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 4 * k1occ));
                     if (k1occ == 4) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, 0, 4>), g1, dim3(64), 0, sx, G);

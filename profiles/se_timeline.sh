@@ -4,8 +4,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/se_timeline; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-MONI_BENCH_SAVE_INDEX=1 python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-from-host > /dev/null 2>&1
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-from-host > $OUT/b.json 2> $OUT/b.log
+MONI_BENCH_SAVE_INDEX=1 python3 $ROOT/bench.py $BENCH_ARGS --steps 1 --warmup 0 --no-cpu --no-from-host > /dev/null 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $BENCH_ARGS --steps 1 --warmup 1 --no-cpu --no-from-host > $OUT/b.json 2> $OUT/b.log
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 python3 - <<PY | tee $OUT/timeline.txt
 import csv

@@ -563,6 +563,23 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx) -> 
             ctx.pe_align(seq, offs, nm, no, ql, model, host_threads=threads, want_text=False, stream=True)
         dt = (time.perf_counter() - t1) / max(1, args.steps)
         from_host = {"value": (hi - lo) / dt, "unit": "pairs/s (this rank)", "ms_per_batch": dt * 1e3, "note": "moni_pe_align_stream: mates, names, qualities in pageable host memory, upload inside the timed call"}
+        if world == 1:          # a streaming caller keeps several contexts per GPU going (moni-hip-align -1/-2 runs three): one's upload, seeding and tail beside the other's paired kernels
+            ctx_b = capi.Ctx(idx)
+            ctx_b.pe_align(seq, offs, nm, no, ql, model, host_threads=threads, want_text=False, stream=True)
+            reps = max(2, min(6, args.steps))
+
+            def pe_worker(cx):
+                for _ in range(reps):
+                    cx.pe_align(seq, offs, nm, no, ql, model, host_threads=max(1, threads // 2), want_text=False, stream=True)
+            th = [threading.Thread(target=pe_worker, args=(cx,)) for cx in (ctx, ctx_b)]
+            t1 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            two_s = (time.perf_counter() - t1) / (2 * reps)
+            ctx_b.close()
+            from_host["two_contexts"] = {"value": (hi - lo) / two_s, "unit": "pairs/s", "ms_per_batch": two_s * 1e3, "note": "two contexts on the GPU, one caller thread each"}
     # the headline: the mates resident in HBM when the timed region starts (moni_reads_upload), names and qualities host buffers as in moni_align_run
     ctx.upload(seq, offs)
     for _ in range(args.warmup):

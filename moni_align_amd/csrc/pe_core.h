@@ -38,7 +38,7 @@ struct pe_left_t { uint64_t r1, r2, score; };
 // Orphan recovery over several waves (pe_kernel.hip: pe_orphan_kernel): the loop over the chains is the expensive part of a pair that fails jointly - two
 // DP rounds per chain, a local alignment among them, one chain after the other - and the chains' scores do not depend on one another, only the
 // best_scores update that absorbs them does (it merges by region, in chain order).  o_mode 3: the state machine stops where the loop would begin (the
-// pair's state stays in its slot); 1: it runs the loop for the chains c with c % o_nsplit == o_part and RECORDS each chain's score instead of
+// pair's state stays in its slot); 1: it runs the loop for its block of consecutive chains (block o_part of o_nsplit) and RECORDS each chain's score instead of
 // absorbing it; 2: it runs the loop in chain order from the records - no DP - and goes on to the final alignments.  0: the whole thing in one go.
 struct pe_orec_t { uint32_t tag, kind; pe_pscore_t sc; };      // kind 1: the chain's score; 2: the chain's requests were beyond the kernel (-> the pair's status 2)
 struct pe_ws_t {
@@ -306,7 +306,9 @@ AC_HD_BIG bool pe_orphan_advance(pe_ws_t& S, const pe_params_t& PP) {
     ac_ws_t& W = S.W;
     while (W.stage == PE_O_LOOP && !W.overflow) {
         if (W.i < W.n_chains) {
-            if (S.o_mode == 1 && (uint32_t)(W.i % S.o_nsplit) != S.o_part) { ++W.i; continue; }          // another wave's chain
+            // (blocks of consecutive chains, not a stride: chains of equal score - the copies of one locus on the haplotypes - are neighbours, and a wave answers a
+            // chain's DP requests from its memo when the previous chain asked the same of the same sequence)
+            if (S.o_mode == 1 && (uint32_t)(W.i / ((W.n_chains + S.o_nsplit - 1) / S.o_nsplit)) != S.o_part) { ++W.i; continue; }          // another wave's chain
             if (S.o_mode == 2 && S.orec[W.i].tag == S.o_tag) {                                            // scored by the waves of the pass before
                 const pe_orec_t& R = S.orec[W.i];
                 if (R.kind != 1) { W.overflow = 1; return false; }

@@ -315,10 +315,10 @@ pe_align_kernel(const pe_args_t A) {
 // by several waves at once instead of one after the other on one (pe_core.h: pe_orec_t; ~30 ms for the slowest pair of a launch otherwise, which
 // nothing hides at the end of a batch).  One pair per wave, lane 0 runs its state machine, the wave solves its DP requests.
 //   MODE 3  every listed pair: to its end (record written), or to the point where the orphan loop would begin - its state stays in park[li]
-//   MODE 1  the parked pairs x nsplit: a copy of the parked state runs the loop for the chains c with c % nsplit == part and records their scores
+//   MODE 1  the parked pairs x nsplit: a copy of the parked state runs the loop for block `part` of the chains and records their scores (a memo answers requests it has solved for an earlier chain)
 //   MODE 2  the parked pairs: the loop replayed from the records in chain order (no DP), the final alignments, the record
 // ------------------------------------------------------------------------------------------------------------------------------
-struct pe_pslot_t { pe_ws_t ws; moni_dp_result_t res[AC_MAX_TASKS]; uint32_t cig[AK_CIG_CAP]; };
+struct pe_pslot_t { pe_ws_t ws; moni_dp_result_t res[AC_MAX_TASKS]; uint32_t cig[AK_CIG_CAP]; moni_dp_result_t memo[64]; };      // memo: results of the requests the scoring pass has solved for this item
 struct pe_oargs_t {
     pe_pslot_t* park; uint32_t* parked; uint32_t cap;      // the first cap listed pairs may park
     pe_orec_t* orec;                                        // cap x AC_MAX_CHAINS
@@ -327,9 +327,13 @@ struct pe_oargs_t {
     uint8_t* k1_dirs; uint32_t k1_dirs_cap;                 // and direction bytes for the gap fills between anchors (small problems: a larger one sends the pair to the host pipeline)
 };
 
+// A pair's chains lie on haplotypes that mostly agree around it: the requests of one chain (the anchored mate's score-only fills, the local alignment of the other
+// mate in the window, the extension over the narrowed window) are the requests of the next chain with the same query segment against a target window that spells
+// the same string.  Per item of the scoring pass a memo of up to 64 solved requests: lane e holds entry e's key (query segment, lengths, flags) and target offset, the results are in the wave's slot;
+// a request whose key matches and whose window equals the entry's (ak_same_target: compared by the wave) takes the entry's result.
 // the wave solves the DP requests lane 0's state machine has queued in ws (results to res / cig); false: one of them is beyond the kernel
 __device__ __forceinline__ bool pe_wave_solve(const pe_args_t& A, dp_lds_t& L, moni_dp_task_t* s_tasks, unsigned long long* s_cnt, uint8_t* dirs, uint64_t dirs_cap, pe_ws_t& ws,
-                                              moni_dp_result_t* res, uint32_t* cig) {
+                                              moni_dp_result_t* res, uint32_t* cig, moni_dp_result_t* memo, uint64_t& mk, uint64_t& mt, uint32_t& memo_n) {
     const int lane = threadIdx.x;
     const uint32_t* __restrict__ tsrc = reinterpret_cast<const uint32_t*>(ws.W.tasks);
     constexpr uint32_t TW = AC_MAX_TASKS * (uint32_t)(sizeof(moni_dp_task_t) / 4);
@@ -341,10 +345,27 @@ __device__ __forceinline__ bool pe_wave_solve(const pe_args_t& A, dp_lds_t& L, m
     uint32_t cig_used = 0;
     for (uint32_t t = 0; t < nt; ++t) {
         const moni_dp_task_t task = s_tasks[t];
+        const bool memoable = memo && (task.flag & (DP_EZ_SCORE_ONLY | DP_EZ_LOCAL)) && (task.reserved & DP_T_TEXT) && (task.reserved & DP_Q_READS) && task.qlen > 0 && task.tlen > 0 && task.tlen < 65536;
+        const uint64_t key = ((task.q_off - ws.off[0]) & 0x3FFFull) | ((uint64_t)(uint32_t)task.qlen & 0xFFFull) << 14 | ((uint64_t)(uint32_t)task.tlen & 0xFFFFull) << 26 |
+                             ((uint64_t)((task.flag & 0x43) | ((task.flag >> 8) & 1) << 2)) << 42 | ((uint64_t)task.reserved & 0xFFull) << 49;
+        int hit = -1;
+        if (memoable) {
+            for (unsigned long long cand = __ballot((uint32_t)lane < memo_n && mk == key); cand && hit < 0; cand &= cand - 1) {
+                const int e = __ffsll((long long)cand) - 1;
+                const uint64_t toff_e = ((uint64_t)(uint32_t)__shfl((int)(mt >> 32), e) << 32) | (uint64_t)(uint32_t)__shfl((int)(mt & 0xFFFFFFFFull), e);
+                if (toff_e == task.t_off || ak_same_target(A.D, (int)task.reserved, toff_e, task.t_off, task.tlen)) hit = e;
+            }
+        }
+        if (hit >= 0) {
+            if (lane == 0) res[t] = memo[hit];
+            __syncthreads();
+            continue;
+        }
         if (task.flag & DP_EZ_LOCAL) {
             if (task.qlen > DP_LDS_Q) { too_big = true; break; }
             pe_sw_local_wave(A.D, L, task, &res[t]);
             __syncthreads();
+            if (memoable && memo_n < 64) { if (lane == 0) { memo[memo_n] = res[t]; __threadfence(); } if ((uint32_t)lane == memo_n) { mk = key; mt = task.t_off; } ++memo_n; __syncthreads(); }
             continue;
         }
         const bool with_cigar = !(task.flag & DP_EZ_SCORE_ONLY);
@@ -356,6 +377,7 @@ __device__ __forceinline__ bool pe_wave_solve(const pe_args_t& A, dp_lds_t& L, m
         (void)extz_wave_lds_lite(A.D, task, L, dirs, cig + cig_at, &res[t], cig_at);
         if (lane == 0) { s_cnt[0]++; s_cnt[1] += (unsigned long long)(task.qlen > 0 ? task.qlen : 0) * (unsigned long long)(task.tlen > 0 ? task.tlen : 0); }
         __syncthreads();
+        if (memoable && memo_n < 64) { if (lane == 0) { memo[memo_n] = res[t]; __threadfence(); } if ((uint32_t)lane == memo_n) { mk = key; mt = task.t_off; } ++memo_n; __syncthreads(); }
     }
     return !too_big;
 }
@@ -367,6 +389,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     __shared__ unsigned long long s_cnt[2];
     __shared__ uint32_t s_go;
     const int lane = threadIdx.x;
+    uint64_t mk = ~0ull, mt = 0; uint32_t memo_n = 0;
     if (lane < 2) s_cnt[lane] = 0;
     __syncthreads();
     pe_slot_t* const own = MODE == 1 ? nullptr : A.slots + (size_t)blockIdx.x;
@@ -384,6 +407,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         const uint32_t li = MODE == 1 ? (uint32_t)(nxt / O.nsplit) : (uint32_t)nxt, part = MODE == 1 ? (uint32_t)(nxt % O.nsplit) : 0u;
         const uint64_t pair = A.pair_list[li];
         if (MODE != 3 && !O.parked[li]) continue;
+        memo_n = 0;
         const bool in_park = MODE == 2 || (MODE == 3 && li < O.cap);
         pe_ws_t* const W = in_park ? &O.park[li].ws : MODE == 1 ? &own1->ws : &own->ws;
         moni_dp_result_t* const res = in_park ? O.park[li].res : MODE == 1 ? own1->res : own->res;
@@ -422,7 +446,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         __syncthreads();
         while (s_go) {
             __threadfence();
-            const bool ok = pe_wave_solve(A, L, s_tasks, s_cnt, dirs, dirs_cap, *W, res, cig);
+            const bool ok = pe_wave_solve(A, L, s_tasks, s_cnt, dirs, dirs_cap, *W, res, cig, MODE == 1 ? own1->memo : nullptr, mk, mt, memo_n);
             __threadfence();
             __syncthreads();
             if (lane == 0) {

@@ -124,9 +124,22 @@ __device__ __attribute__((noinline)) void pe_sw_pass_wave(const dp_launch_t& D, 
             }
         }
         __syncthreads();
-        for (int l = 0; l < 64; ++l) {
-            const int r = __shfl(rmax, l), a = __shfl(rarg, l);
-            if (i0 + l < tlen && !stop && r > gmax) { gmax = r; te = i0 + l; qe = a; if (gmax >= endsc) stop = true; }
+        // klib's rule over the tile's rows in order - a row counts when its maximum exceeds every earlier row's, the first such row that reaches endsc ends the pass -
+        // by a prefix maximum over the lanes instead of 64 round trips: P(l) = the running maximum after row l; the rows that count are those where P rises
+        {
+            int P = row_ok ? rmax : INT32_MIN;
+            for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(P, o); if (lane >= o) P = P > x ? P : x; }
+            P = P > gmax ? P : gmax;
+            int Pprev = __shfl_up(P, 1);
+            if (lane == 0) Pprev = gmax;
+            const unsigned long long hits = __ballot(P > Pprev && P >= endsc);
+            const int last = hits ? __ffsll((long long)hits) - 1 : 63;
+            const int M = __shfl(P, last);
+            if (M > gmax) {
+                const int first = __ffsll((long long)__ballot(lane <= last && P == M)) - 1;
+                gmax = M; te = i0 + first; qe = __shfl(rarg, first);
+            }
+            if (hits) stop = true;
         }
     }
     if (qe < 0 && qlen > 0) qe = 0;

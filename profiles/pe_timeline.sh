@@ -19,7 +19,7 @@ starts = [i for i, e in enumerate(ev) if e[2].startswith("pack_kernel")]
 lo = starts[-1]
 t0 = ev[lo][0]
 for s, e, n, q in ev[lo:]:
-    if (e - s) < 150000 and not n.startswith(("pe_", "dp_lane", "ms_lf", "mem_k", "occ_k", "gather")): continue
+    if (e - s) < 150000 and not n.startswith(("pe_", "dp_lane", "ms_lf", "mem_k", "occ_k", "gather")) and not (int("${TL_FROM:-0}") * 1e6 <= s - t0 <= int("${TL_TO:-0}") * 1e6): continue
     print("%8.2f -> %8.2f ms  (%7.2f)  q%-3s %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, q, n))
 print("step span %.2f ms" % ((max(e for s, e, n, q in ev[lo:]) - t0) / 1e6))
 PY

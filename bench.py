@@ -590,6 +590,8 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx) -> 
         sam_len, st = ctx.pe_align_run(nm, no, ql, model, host_threads=threads, want_text=False)      # the text is in the context's pinned host buffer; no copy into a Python object
     sync_all()
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dist, coll_dev)
+    lf_ms = ctx.kernel_ms(0)                      # ms_lf_kernel of the last step (one launch over the 2 N mates), HIP events on its own stream
+    S_lf, J_lf = (int(x) for x in ctx.counters()[:2])
     sizes = mdist.gather_counts([st["aligned"], hi - lo], dist, coll_dev)
     if rank == 0:
         steps = max(1, args.steps)
@@ -604,6 +606,10 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx) -> 
                "model": {"count": int(model.count), "mean": model.mean, "std_dev": model.std_dev, "complete": bool(model.complete)},
                "aligned_pairs_all_ranks": sum(x[0] for x in sizes), "stages_s_per_step": {"seed": st["t_seed"], "kernel_and_copies": st["t_dp"], "host_finish": st["t_host"]},
                "dp_problems": st["dp_tasks"], "dp_cells": st["dp_cells"], "pairs_through_host_pipeline": st["handed_back"],
+               # the path's HBM-bound kernel is the single-end path's: the LF / threshold-jump stage of seeding over the 2 N mates (same model as the default line)
+               "roofline": {"bound": "hbm", "kernel": "ms_lf_kernel", "achieved": 73 * S_lf / (lf_ms / 1e3) / 1e9 if lf_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": 73 * S_lf / (lf_ms / 1e3) / 1e9 / HBM_PEAK_GBS if lf_ms > 0 else 0.0, "traffic": None, "model": "layout: 73 bytes per LF step", "avg_launch_ms": lf_ms,
+                            "survey_8d": {"bytes_per_launch": 128 * S_lf + 64 * J_lf, "frac": (128 * S_lf + 64 * J_lf) / (lf_ms / 1e3) / 1e9 / HBM_PEAK_GBS if lf_ms > 0 else 0.0}},
                "pairs_to_pe_align_kernel": st["kernel_fallback"], "handed_over_because": {k: v for k, v in st.get("handover_why", {}).items() if v},
                "host": {"cpus_usable": host_cpus(), "host_threads_per_gpu": threads}}
         if from_host is not None:

@@ -71,7 +71,7 @@ class AlignStatsC(C.Structure):
 
 class PeParamsC(C.Structure):
     _fields_ = [("filter_dir", C.c_uint32), ("find_orphan", C.c_uint32), ("dir_thr", C.c_double), ("ins_learning_n", C.c_uint64),
-                ("ins_learning_score_gap_threshold", C.c_uint64)]
+                ("ins_learning_score_gap_threshold", C.c_uint64), ("secondary_chains", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class PeModelC(C.Structure):

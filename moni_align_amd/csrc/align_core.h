@@ -171,7 +171,8 @@ AC_HD void ac_reset(ac_ws_t& W) {
     W.i = 0; W.n_diff = W.n_best = W.n_left = W.n_alt = 0; W.max_score = 0; W.score2 = 0; W.final_chain = 0;
     W.n_mems = W.n_anch = W.n_chains = W.pool_used = 0;
 }
-AC_HD_BIG bool ac_chain(ac_ws_t& W, const ac_params_t& P);
+struct ac_sec_t { int32_t f, p, t, msc; };          // the second track of find_chains_secondary (-Z, paired-end): f_sec / p_sec / t_sec / msc_sec of an anchor
+AC_HD_BIG bool ac_chain(ac_ws_t& W, const ac_params_t& P, ac_sec_t* sec = nullptr);
 AC_HD_BIG bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, uint64_t a, uint64_t b, const uint64_t* occs) {
     ac_reset(W);
     unsigned long long pc0 = AC_CLOCK();
@@ -187,8 +188,10 @@ AC_HD_BIG bool ac_init(ac_ws_t& W, const ac_params_t& P, const moni_mem_t* gm, u
     W.prof[0] += AC_CLOCK() - pc0;
     return ac_chain(W, P);
 }
-// find_chains (chain.hpp:221-438) over W.mems[0 .. n_mems): anchors, chaining DP, chain starts, backtrack, chains by score
-AC_HD_BIG bool ac_chain(ac_ws_t& W, const ac_params_t& P) {
+// find_chains (chain.hpp:221-438) over W.mems[0 .. n_mems): anchors, chaining DP, chain starts, backtrack, chains by score.
+// sec != nullptr: find_chains_secondary (chain.hpp:442-727, -Z): per anchor also the best predecessor that does not lie on the primary chain of the current best
+// one; the secondary chains are added behind the primary ones before the sort by score, and the chain starts of both tracks are sorted by score alone.
+AC_HD_BIG bool ac_chain(ac_ws_t& W, const ac_params_t& P, ac_sec_t* sec) {
     unsigned long long pc0 = AC_CLOCK();
     size_t tot_mem_length = 0, na = 0;
     for (uint32_t i = 0; i < W.n_mems; ++i) { na += W.mems[i].nocc; tot_mem_length += (size_t)W.mems[i].len * W.mems[i].nocc; }
@@ -208,13 +211,14 @@ AC_HD_BIG bool ac_chain(ac_ws_t& W, const ac_params_t& P) {
         nd.x = W.anch[i].x; nd.rpos = (uint16_t)m.rpos; nd.len = (uint16_t)m.len; nd.mate = (uint8_t)m.mate; nd.pad0 = 0; nd.pad1 = 0;
         nd.f = 0; nd.p = 0; nd.t = 0; nd.msc = 0;               // std::vector<ll> t(n, 0)
         W.node[i] = nd;
+        if (sec) { sec[i].f = 0; sec[i].p = 0; sec[i].t = 0; sec[i].msc = 0; }
     }
     long long lb = 0;
     for (size_t i = 0; i < na; ++i) {
         const ac_node_t ni = W.node[i];
         const long long x_i = (long long)ni.x, y_i = ni.rpos, w_i = ni.len;
         const uint32_t mate_i = ni.mate;
-        long long max_f = w_i, max_j = -1;
+        long long max_f = w_i, max_j = -1, max_sec_f = w_i, max_sec_j = -1;
         size_t n_pred = 0;
         if (i - (size_t)lb > (size_t)P.max_iter) lb = (long long)i - P.max_iter;
         for (long long j = (long long)i - 1; j >= lb; --j) {
@@ -238,11 +242,21 @@ AC_HD_BIG bool ac_chain(ac_ws_t& W, const ac_params_t& P) {
             }
             const long long score = nj.f + (alpha - beta);
             if (score > max_f) { max_f = score; max_j = j; if (n_pred > 0) --n_pred; }
+            else if (sec && (long long)sec[j].f + (alpha - beta) > max_sec_f) {          // chain.hpp:586-612
+                if (max_j >= 0) {
+                    const uint64_t pos_j = nj.x - nj.len + 1;                            // the occurrence the anchor stands for
+                    bool uniq = true;
+                    for (long long tmp = max_j; tmp >= 0; tmp = W.node[tmp].p) if (W.node[tmp].x - W.node[tmp].len + 1 == pos_j) { uniq = false; break; }
+                    if (uniq) { max_sec_f = (long long)sec[j].f + (alpha - beta); max_sec_j = j; }
+                }
+            }
             else if ((size_t)(long long)nj.t == i && (++n_pred > (size_t)P.max_pred)) break;
             if (nj.p > 0) W.node[nj.p].t = (int32_t)i;
+            if (sec && sec[j].p > 0) sec[sec[j].p].t = (int32_t)i;
         }
         W.node[i].f = (int32_t)max_f; W.node[i].p = (int32_t)max_j;
         W.node[i].msc = (max_j >= 0 && W.node[max_j].msc > max_f) ? W.node[max_j].msc : (int32_t)max_f;
+        if (sec) { sec[i].f = (int32_t)max_sec_f; sec[i].p = (int32_t)max_sec_j; sec[i].msc = (max_sec_j >= 0 && sec[max_sec_j].msc > max_sec_f) ? sec[max_sec_j].msc : (int32_t)max_sec_f; }
     }
     { const unsigned long long x = AC_CLOCK(); W.prof[2] += x - pc0; pc0 = x; }
     for (size_t i = 0; i < na; ++i) W.node[i].t = 0;
@@ -257,7 +271,8 @@ AC_HD_BIG bool ac_chain(ac_ws_t& W, const ac_params_t& P) {
         }
     }
     if (ns == 0) return false;
-    lsort::sort(W.starts, (long)ns, [](const ac_start_t& x, const ac_start_t& y) { return x.f > y.f || (x.f == y.f && x.j > y.j); }, W.sort_stack);   // std::greater<pair>
+    if (sec) lsort::sort(W.starts, (long)ns, [](const ac_start_t& x, const ac_start_t& y) { return x.f > y.f; }, W.sort_stack);      // chain_start_cmp (chain.hpp:663-668): the score alone
+    else lsort::sort(W.starts, (long)ns, [](const ac_start_t& x, const ac_start_t& y) { return x.f > y.f || (x.f == y.f && x.j > y.j); }, W.sort_stack);   // std::greater<pair>
     for (size_t i = 0; i < na; ++i) W.node[i].t = 0;
     for (uint32_t i = 0; i < ns; ++i) {
         long long j = (long long)W.starts[i].j;
@@ -275,6 +290,38 @@ AC_HD_BIG bool ac_chain(ac_ws_t& W, const ac_params_t& P) {
         if (j < 0) keep = (long long)c.cnt >= P.min_chain_length;
         else if (W.starts[i].f - W.node[j].f >= P.min_chain_score) keep = (long long)c.cnt >= P.min_chain_length;
         if (keep) W.chains[W.n_chains++] = c;            // (a dropped chain leaves its anchors in the pool; harmless)
+    }
+    if (sec) {          // the secondary track: chain ends, starts (their own sort), backtrack over p_sec / f_sec; the chains go behind the primary ones
+        for (size_t i = 0; i < na; ++i) sec[i].t = 0;
+        for (size_t i = 0; i < na; ++i) if (sec[i].p >= 0) sec[sec[i].p].t = 1;
+        uint32_t ns2 = 0;
+        for (size_t i = 0; i < na; ++i) {
+            if (sec[i].t == 0 && sec[i].msc > P.min_chain_score) {
+                size_t j = i;
+                while (sec[j].f < sec[j].msc) j = (size_t)sec[j].p;
+                if (ns2 >= AC_MAX_CHAINS) { W.overflow = 1; return false; }
+                W.starts[ns2].f = sec[j].f; W.starts[ns2].j = j; ++ns2;
+            }
+        }
+        lsort::sort(W.starts, (long)ns2, [](const ac_start_t& x, const ac_start_t& y) { return x.f > y.f; }, W.sort_stack);
+        for (size_t i = 0; i < na; ++i) sec[i].t = 0;
+        for (uint32_t i = 0; i < ns2; ++i) {
+            long long j = (long long)W.starts[i].j;
+            ac_chain_t c;
+            c.mate = W.node[j].mate;
+            c.score = W.starts[i].f;
+            c.off = W.pool_used; c.cnt = 0; c.paired = 0;
+            do {
+                c.paired |= (c.mate != (uint32_t)W.node[j].mate) ? 1u : 0u;
+                if (W.pool_used >= AC_MAX_POOL) { W.overflow = 1; return false; }
+                W.pool[W.pool_used++] = (uint32_t)j; c.cnt++;
+                sec[j].t = 1; j = sec[j].p;
+            } while (j >= 0 && sec[j].t == 0);
+            bool keep = false;
+            if (j < 0) keep = (long long)c.cnt >= P.min_chain_length;
+            else if (W.starts[i].f - sec[j].f >= P.min_chain_score) keep = (long long)c.cnt >= P.min_chain_length;
+            if (keep) { if (W.n_chains >= AC_MAX_CHAINS) { W.overflow = 1; return false; } W.chains[W.n_chains++] = c; }
+        }
     }
     lsort::sort(W.chains, (long)W.n_chains, [](const ac_chain_t& x, const ac_chain_t& y) { return x.score > y.score; }, W.sort_stack);
     for (uint32_t i = 0; i < W.n_chains; ++i) W.score_cache[i] = INT32_MIN;

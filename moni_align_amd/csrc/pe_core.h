@@ -23,7 +23,8 @@ struct pe_params_t {
     uint32_t find_orphan, w;             // w: the separator run between sequences (seqidx::get_w); orphan recovery for the pairs that chain but fail jointly (aligner_ksw2.hpp:900-906)
     double ins_mean, ins_std_dev;        // the model as doubles: the search window of paired_chain_orphan_score (aligner_ksw2.hpp:2398-2420)
     const double* pen_tab;               // the pairing term's penalty for dist < pen_tab_n, computed on the host with the host's libm (null: computed in place)
-    uint32_t pen_tab_n, pad_pen;
+    uint32_t pen_tab_n;
+    uint32_t secondary_chains;           // -Z: find_chains_secondary (aligner_ksw2.hpp:1190-1191)
 };
 
 #ifndef DP_EZ_LOCAL
@@ -44,6 +45,7 @@ struct pe_orec_t { uint32_t tag, kind; pe_pscore_t sc; };      // kind 1: the ch
 struct pe_ws_t {
     uint32_t o_mode, o_part, o_nsplit, o_tag, o_parked, o_pad;
     pe_orec_t* orec;                     // the pair's records, one per chain
+    ac_sec_t sec[AC_MAX_ANCH];           // -Z: the second track of the chaining
     ac_ws_t W;                           // mems, anchors, chains, DP requests, sort stack (W.off / W.m / W.fill / W.best / W.cigar unused)
     uint64_t off[2]; uint32_t m[2];      // the two mates in the resident batch (reads 2p and 2p + 1)
     int32_t min_score_m[2], min_score;
@@ -168,7 +170,7 @@ AC_HD_BIG bool pe_init(pe_ws_t& S, const pe_params_t& PP, const moni_mem_t* gm, 
         W.n_mems = k;
     }
     if (W.n_mems == 0) return false;                       // find_chains over no anchors: 0/0 average, no chain
-    return ac_chain(W, P);
+    return ac_chain(W, P, PP.secondary_chains ? S.sec : nullptr);
 }
 
 // aligner_ksw2.hpp:1471-1534

@@ -476,6 +476,7 @@ static size_t read_pairs_par(AnyReader& r1, AnyReader& r2, size_t n_pairs, Batch
 }
 static int run_paired(Args& a, const std::string& sam_filename) {
     a.PE.find_orphan = a.find_orphan ? 1 : 0;            // -u switches orphan recovery off (align_full_ksw2.cpp:248-250)
+    a.PE.secondary_chains = a.secondary ? 1 : 0;         // -Z: find_chains_secondary (every pair then takes pe_align_kernel)
     info("Output file: " + sam_filename);
     AnyReader r1(a.mate1), r2(a.mate2);
     if (a.dry_run) {
@@ -675,7 +676,7 @@ int main(int argc, char** argv) {
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
     Args a;
     parse(argc, argv, a);
-    if (a.secondary) die("option -Z is not implemented in moni-hip-align yet");
+    // -Z (secondary chains) acts in the paired path only, as in the reference (aligner_ksw2.hpp:1190-1191): run_paired passes it on; single-end input ignores it
     if (a.csv && (!a.mate1.empty() || !a.mate2.empty())) die("option -c is implemented for single-end input (-p) only");
     // -n: <prefix>.thrbv.full.ms (ms_pointers<>: no LCP samples; the occurrence walks measure the LCP on the text, seed_finder.hpp:346-370).
     // -q: the reference would take the text from <prefix>.slp (SelfShapedSlp) instead of <prefix>.plain.slp; both grammars spell the same

@@ -167,6 +167,144 @@ inline bool find_chains(const std::vector<mem_t>& mems, std::vector<std::pair<si
     return true;
 }
 
+// chain.hpp:442-727 (-Z, paired-end only: aligner_ksw2.hpp:1190-1191): the same chaining with a second track per anchor - the best predecessor whose
+// anchor is not on the primary chain of the current best predecessor - whose chains are added behind the primary ones before the sort by score.
+// NB the chain starts of BOTH tracks are sorted by score alone here (chain.hpp:663-668), not by (score, index) as in find_chains.
+inline bool find_chains_secondary(const std::vector<mem_t>& mems, std::vector<std::pair<size_t, size_t>>& anchors,
+                                  std::vector<chain_t>& chains, const chain_config_t config = chain_config_t()) {
+    auto cmp = [&](const std::pair<size_t, size_t>& i, const std::pair<size_t, size_t>& j) -> bool {
+        return (mems[i.first].occs[i.second] + mems[i.first].len - 1) < (mems[j.first].occs[j.second] + mems[j.first].len - 1);
+    };
+    size_t tot_mem_length = 0;
+    for (size_t i = 0; i < mems.size(); ++i) {
+        for (size_t j = 0; j < mems[i].occs.size(); ++j) anchors.push_back(std::make_pair(i, j));
+        tot_mem_length += mems[i].len * mems[i].occs.size();
+    }
+    float avg_mem_length = (float)tot_mem_length / anchors.size();
+    std::sort(anchors.begin(), anchors.end(), cmp);
+    const ll G = config.G;
+    const ll max_dist_x = config.max_dist_x, max_dist_y = config.max_dist_y, max_iter = config.max_iter;
+    const ll max_pred = config.max_pred, min_chain_score = config.min_chain_score, min_chain_length = config.min_chain_length;
+    const size_t n = anchors.size();
+    std::vector<ll> f(n, 0), f_sec(n, 0), p(n, 0), p_sec(n, 0), msc(n, 0), msc_sec(n, 0), t(n, 0), t_sec(n, 0);
+    ll lb = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const auto a_i = anchors[i];
+        const mem_t& mem_i = mems[a_i.first];
+        const ll x_i = mem_i.occs[a_i.second] + mem_i.len - 1;
+        const ll y_i = mem_i.rpos;
+        const ll w_i = mem_i.len;
+        const size_t mate_i = mem_i.mate;
+        ll max_f = w_i, max_sec_f = w_i;
+        ll max_j = -1, max_sec_j = -1;
+        size_t n_pred = 0;
+        if (i - lb > (size_t)max_iter) lb = i - max_iter;
+        for (ll j = i - 1; j >= lb; --j) {
+            const auto a_j = anchors[j];
+            const mem_t& mem_j = mems[a_j.first];
+            const ll x_j = mem_j.occs[a_j.second] + mem_j.len - 1;
+            const ll y_j = mem_j.rpos;
+            const size_t mate_j = mem_j.mate;
+            if ((mate_i != mate_j) and ((mate_i ^ mate_j) != 3)) continue;
+            if (x_i > x_j + max_dist_x) { lb = j; continue; }
+            const ll x_d = x_i - x_j;
+            const ll y_d = y_i - y_j;
+            const int32_t l = (y_d > x_d ? (y_d - x_d) : (x_d - y_d));
+            const uint32_t ilog_l = (l > 0 ? ilog2_32(l) : 0);
+            if ((mate_i == mate_j and (y_j >= y_i or y_d > max_dist_y)) or std::max(y_d, x_d) > G) continue;
+            const ll alpha = std::min(std::min(y_d, x_d), w_i);
+            ll beta = 0;
+            if (mate_i != mate_j) {
+                if (x_d == 0) ++beta;
+                else {
+                    const int c_lin = (int)(l * .01 * avg_mem_length);
+                    beta = c_lin < (ll)ilog_l ? c_lin : ilog_l;
+                }
+            } else {
+                beta = (l > 0 ? ((ll)(.01 * l * avg_mem_length) + ilog_l) >> 1 : 0);
+            }
+            ll score = f[j] + (alpha - beta);
+            ll score_sec = f_sec[j] + (alpha - beta);
+            if (score > max_f) {
+                max_f = score;
+                max_j = j;
+                if (n_pred > 0) --n_pred;
+            } else if (score_sec > max_sec_f) {
+                if (max_j >= 0) {          // j must not lie on the primary chain that starts at max_j (chain.hpp:590-612)
+                    ll tmp = max_j;
+                    bool uniq_chain = true;
+                    const size_t mem_j_pos = mems[anchors[j].first].occs[anchors[j].second];
+                    while (tmp >= 0) {
+                        const size_t mem_tmp_pos = mems[anchors[tmp].first].occs[anchors[tmp].second];
+                        if (mem_j_pos == mem_tmp_pos) { uniq_chain = false; break; }
+                        tmp = p[tmp];
+                    }
+                    if (uniq_chain) { max_sec_f = score_sec; max_sec_j = j; }
+                }
+            } else {
+                if ((size_t)t[j] == i and (++n_pred > (size_t)max_pred)) break;
+            }
+            if (p[j] > 0) t[p[j]] = i;
+            if (p_sec[j] > 0) t_sec[p_sec[j]] = i;
+        }
+        f[i] = max_f; p[i] = max_j;
+        if (max_j >= 0 and msc[max_j] > max_f) msc[i] = msc[max_j]; else msc[i] = max_f;
+        f_sec[i] = max_sec_f; p_sec[i] = max_sec_j;
+        if (max_sec_j >= 0 and msc_sec[max_sec_j] > max_sec_f) msc_sec[i] = msc_sec[max_sec_j]; else msc_sec[i] = max_sec_f;
+    }
+    std::fill(t.begin(), t.end(), 0);
+    std::fill(t_sec.begin(), t_sec.end(), 0);
+    for (size_t i = 0; i < n; ++i) if (p[i] >= 0) t[p[i]] = 1;
+    for (size_t i = 0; i < n; ++i) if (p_sec[i] >= 0) t_sec[p_sec[i]] = 1;
+    size_t n_chains = 0, n_chains_sec = 0;
+    for (size_t i = 0; i < n; ++i) if (t[i] == 0 and msc[i] > min_chain_score) n_chains++;
+    for (size_t i = 0; i < n; ++i) if (t_sec[i] == 0 and msc_sec[i] > min_chain_score) n_chains_sec++;
+    if (n_chains == 0) return false;
+    auto starts_of = [&](const std::vector<ll>& tt, const std::vector<ll>& ff, const std::vector<ll>& pp, const std::vector<ll>& mm, size_t cnt) {
+        std::vector<std::pair<ll, size_t>> cs(cnt);
+        size_t k = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (tt[i] == 0 and mm[i] > min_chain_score) {
+                size_t j = i;
+                while (ff[j] < mm[j]) j = pp[j];
+                cs[k++] = std::make_pair(ff[j], j);
+            }
+        }
+        cs.resize(k);
+        return cs;
+    };
+    auto chain_starts = starts_of(t, f, p, msc, n_chains);
+    auto chain_starts_sec = starts_of(t_sec, f_sec, p_sec, msc_sec, n_chains_sec);
+    auto chain_start_cmp = [](const std::pair<ll, size_t>& lhs, const std::pair<ll, size_t>& rhs) { return lhs.first > rhs.first; };
+    std::sort(chain_starts.begin(), chain_starts.end(), chain_start_cmp);
+    std::sort(chain_starts_sec.begin(), chain_starts_sec.end(), chain_start_cmp);
+    auto backtrack = [&](const std::vector<std::pair<ll, size_t>>& cs, std::vector<ll>& tt, const std::vector<ll>& ff, const std::vector<ll>& pp) {
+        std::fill(tt.begin(), tt.end(), 0);
+        for (size_t i = 0; i < cs.size(); ++i) {
+            ll j = cs[i].second;
+            chain_t chain;
+            chain.mate = mems[anchors[j].first].mate;
+            chain.score = cs[i].first;
+            do {
+                chain.paired = chain.paired or (chain.mate != mems[anchors[j].first].mate);
+                chain.anchors.push_back(j);
+                tt[j] = 1;
+                j = pp[j];
+            } while (j >= 0 && tt[j] == 0);
+            if (j < 0) {
+                if (chain.anchors.size() >= (size_t)min_chain_length) chains.push_back(std::move(chain));
+            } else if (cs[i].first - ff[j] >= min_chain_score) {
+                if (chain.anchors.size() >= (size_t)min_chain_length) chains.push_back(std::move(chain));
+            }
+        }
+    };
+    backtrack(chain_starts, t, f, p);
+    backtrack(chain_starts_sec, t_sec, f_sec, p_sec);
+    auto chain_t_cmp = [](const chain_t& i, const chain_t& j) -> bool { return i.score > j.score; };
+    std::sort(chains.begin(), chains.end(), chain_t_cmp);
+    return true;
+}
+
 // ---- mapq.hpp:146-184 -------------------------------------------------------------------------------------
 inline size_t compute_mapq_se_bwa(const int32_t score, const int32_t score2, const int32_t rlen, const int32_t qlen,
                                   const int32_t min_seed_length, const int32_t match_score, const int32_t mismatch_score,

@@ -53,6 +53,7 @@ struct pe_config_t {               // aligner_ksw2.hpp:94-128 defaults
     double dir_thr = 50.0;
     size_t ins_learning_n = 1000, ins_learning_score_gap_threshold = 0;
     bool find_orphan = false;          // aligner_ksw2.hpp:128 (true in the reference; -u clears it).  The product is checked in both modes
+    bool secondary_chains = false;     // -Z (aligner_ksw2.hpp:126, 1190-1191): find_chains_secondary instead of find_chains
 };
 
 struct aligner_pe : aligner {
@@ -342,7 +343,7 @@ struct aligner_pe : aligner {
             return true;
         }
         al.frac_rep_m1 = 0.0; al.frac_rep_m2 = 0.0;                  // compute_frac_rep (aligner_ksw2.hpp:1973-1981) returns 0.0
-        al.chained = find_chains(al.mems, al.anchors, al.chains, cfg.chain);
+        al.chained = pe.secondary_chains ? find_chains_secondary(al.mems, al.anchors, al.chains, cfg.chain) : find_chains(al.mems, al.anchors, al.chains, cfg.chain);      // aligner_ksw2.hpp:1190-1194
         if (not al.chained) return false;
         get_best_scores(al, cfg.check_k);
         auto& best = al.best_scores;

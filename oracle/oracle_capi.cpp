@@ -230,8 +230,9 @@ char* orc_align_pe(void* h, const uint8_t* seqs1, const uint64_t* off1, const ui
                    const uint8_t* quals2, uint64_t b_size, int find_orphan, uint64_t* out_len, double* out) {
     const FlatIndex& ix = *(FlatIndex*)h;
     align_config_t cfg;
-    if (find_orphan & 2) { cfg.report_mems = true; find_orphan &= 5; }          // bit 1: -m, the MEM records of the pairs instead of their alignments
+    if (find_orphan & 2) { cfg.report_mems = true; find_orphan &= 13; }          // bit 1: -m, the MEM records of the pairs instead of their alignments
     pe_config_t pcfg;
+    if (find_orphan & 8) { pcfg.secondary_chains = true; find_orphan &= 7; }   // bit 3: -Z
     if (find_orphan & 4) { pcfg.filter_dir = false; find_orphan &= 3; }         // bit 2: --no-filter-dir
     pcfg.find_orphan = (find_orphan & 1) != 0;
     aligner_pe A(ix, cfg, pcfg);

@@ -336,7 +336,7 @@ char* sim_align_pe_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint
     if (be.seed(sp, gm, go, rmo)) return nullptr;
     const std::vector<uint32_t>& aux = S->aux;
     pe_params_t PP;
-    PP.pen_tab = nullptr; PP.pen_tab_n = 0; PP.pad_pen = 0;
+    PP.pen_tab = nullptr; PP.pen_tab_n = 0; PP.secondary_chains = 0;
     ac_params_t& AP = PP.P;
     AP.min_len = P.min_len; AP.ext_len = P.ext_len; AP.check_k = P.check_k; AP.region_dist = P.region_dist; AP.filter_freq = P.filter_freq;
     AP.left_mem_check = P.left_mem_check; AP.freq_thr = P.freq_thr; AP.smatch = P.smatch; AP.gapo = P.gapo; AP.gapo2 = P.gapo2; AP.gape = P.gape;
@@ -346,7 +346,7 @@ char* sim_align_pe_batch(void* s, const uint8_t* seq, const uint64_t* offs, uint
     AP.lift_seqs = S->hix.lift_seqs.data(); AP.lift_runs = S->hix.lift_runs.data(); AP.pdir = S->pdir.data();
     PP.smismatch = P.smismatch; PP.max_penalty = std::max(P.smatch + P.smismatch, P.gapo + P.gape); PP.filter_dir = 1; PP.finalize = finalize ? 1 : 0;
     PP.dir_thr = 50.0; PP.mean = (float)mean; PP.std_dev = (float)std_dev;
-    PP.find_orphan = find_orphan ? 1 : 0; PP.w = (uint32_t)S->hix.w; PP.ins_mean = mean; PP.ins_std_dev = std_dev;
+    PP.find_orphan = (find_orphan & 1) ? 1 : 0; PP.secondary_chains = (find_orphan & 2) ? 1 : 0; PP.w = (uint32_t)S->hix.w; PP.ins_mean = mean; PP.ins_std_dev = std_dev;      // bit 1: -Z
     moni_dp_params_t dp;
     memset(&dp, 0, sizeof dp);
     dp.m = 5;
@@ -444,7 +444,7 @@ char* sim_align_pe_big_batch(void* s, const uint8_t* seq, const uint64_t* offs, 
     AP.lift_seqs = S->hix.lift_seqs.data(); AP.lift_runs = S->hix.lift_runs.data(); AP.pdir = nullptr;          // as moni_pe_align_batch hands it over
     PP.smismatch = P.smismatch; PP.max_penalty = std::max(P.smatch + P.smismatch, P.gapo + P.gape); PP.filter_dir = 1; PP.finalize = 1;
     PP.dir_thr = 50.0; PP.mean = (float)mean; PP.std_dev = (float)std_dev;
-    PP.find_orphan = find_orphan ? 1 : 0; PP.w = (uint32_t)S->hix.w; PP.ins_mean = mean; PP.ins_std_dev = std_dev;
+    PP.find_orphan = (find_orphan & 1) ? 1 : 0; PP.secondary_chains = (find_orphan & 2) ? 1 : 0; PP.w = (uint32_t)S->hix.w; PP.ins_mean = mean; PP.ins_std_dev = std_dev;      // bit 1: -Z
     moni_dp_params_t dp;
     memset(&dp, 0, sizeof dp);
     dp.m = 5;

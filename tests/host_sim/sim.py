@@ -126,7 +126,7 @@ class Sim:
         finally:
             lib().sim_free(p)
 
-    def align_pe_batch(self, seq, offsets, names, name_off, quals=None, finalize=True, mean=0.0, std_dev=0.0, find_orphan=False):
+    def align_pe_batch(self, seq, offsets, names, name_off, quals=None, finalize=True, mean=0.0, std_dev=0.0, find_orphan=False, secondary_chains=False):
         """Paired-end: reads 2p / 2p+1 are the mates of pair p; pe_core.h replayed on the host + pe_host.hpp.  finalize=False is the
         learn pass: returns (learn[n_pairs, 4] = aligned, best tot, second tot, dist; stats)."""
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
@@ -140,7 +140,7 @@ class Sim:
         st = np.zeros(5, dtype=np.uint64)
         learn = np.zeros((n_pairs, 4), dtype=np.int64)
         p = lib().sim_align_pe_batch(self.h, seq.ctypes.data, offsets.ctypes.data, n_pairs, names.ctypes.data, name_off.ctypes.data,
-                                     quals.ctypes.data if quals is not None else None, int(finalize), float(mean), float(std_dev), int(find_orphan),
+                                     quals.ctypes.data if quals is not None else None, int(finalize), float(mean), float(std_dev), int(find_orphan) | (2 if secondary_chains else 0),
                                      learn.ctypes.data, C.byref(ln), st.ctypes.data)
         if not p:
             raise RuntimeError("sim_align_pe_batch failed")
@@ -149,7 +149,7 @@ class Sim:
         finally:
             lib().sim_free(p)
 
-    def align_pe_big_batch(self, seq, offsets, names, name_off, quals=None, mean=0.0, std_dev=0.0, find_orphan=False):
+    def align_pe_big_batch(self, seq, offsets, names, name_off, quals=None, mean=0.0, std_dev=0.0, find_orphan=False, secondary_chains=False):
         """Every pair through the host pipeline for pairs (pe_big.cpp) with the CPU stand-ins for its DP batches."""
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -160,7 +160,7 @@ class Sim:
         ln = C.c_uint64()
         st = np.zeros(5, dtype=np.uint64)
         p = lib().sim_align_pe_big_batch(self.h, seq.ctypes.data, offsets.ctypes.data, (len(offsets) - 1) // 2, names.ctypes.data, name_off.ctypes.data,
-                                         quals.ctypes.data if quals is not None else None, float(mean), float(std_dev), int(find_orphan), C.byref(ln), st.ctypes.data)
+                                         quals.ctypes.data if quals is not None else None, float(mean), float(std_dev), int(find_orphan) | (2 if secondary_chains else 0), C.byref(ln), st.ctypes.data)
         if not p:
             raise RuntimeError("sim_align_pe_big_batch failed")
         try:

@@ -41,7 +41,7 @@ def test_dry_run_parsing(exe, small_case, tmp_path):
 def test_unsupported_modes_exit_1(exe, tmp_path):
     fq = str(tmp_path / "x.fq")
     open(fq, "w").write("@a\nACGT\n+\nIIII\n")
-    for extra in (["-1", fq, "-2", fq, "-c"], ["-1", fq, "-2", fq, "-Z"]):
+    for extra in (["-1", fq, "-2", fq, "-c"],):
         r = subprocess.run([exe, "x"] + extra, capture_output=True)
         assert r.returncode == 1 and (b"not implemented" in r.stderr or b"is implemented for single-end" in r.stderr)
     assert subprocess.run([exe], capture_output=True).returncode == 1
@@ -200,6 +200,11 @@ def test_cli_paired_end(exe, medium_case, tmp_path):
     if got3 != want3:
         from tests.test_host_sim_pe import first_diff
         raise AssertionError("-m records differ at record %d:\n got: %s\nwant: %s" % first_diff(got3, want3))
+    # -Z: secondary chains
+    out5 = str(tmp_path / "pe_z.sam")
+    subprocess.check_call([exe, prefix, "-1", f1, "-2", f2p, "-Z", "-o", out5, "-S", "1000", "-F", "0.5", "-t", "4", "-b", "512", "--gpu-batch", "2048"])
+    want5, _ = oracle_pe(o, m1, m2, b_size=512, find_orphan=True, secondary_chains=True)
+    assert want5 != want2 and open(out5, "rb").read()[len(hdr):] == want5
     out4 = str(tmp_path / "pe_plain.sam")
     subprocess.check_call([exe, prefix, "-1", f1, "-2", f2p, "-o", out4, "-S", "1000", "-F", "0.5", "-t", "4", "-b", "512", "--gpu-batch", "300"])
     assert open(out4, "rb").read()[len(hdr):] == want2

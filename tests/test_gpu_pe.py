@@ -286,3 +286,39 @@ def test_pe_orphan_loop_over_several_waves(case, monkeypatch):
     finally:
         ctx.close()
         idx.close()
+
+
+def test_pe_secondary_chains(case):
+    """-Z (moni_pe_params_t::secondary_chains): find_chains_secondary in learn_fragment_model and in the alignment, st_align's batch order; every pair takes
+    pe_align_kernel (the staged kernels chain without the second track).  Against the oracle; and the option must change the output"""
+    pg, fi, o = case
+    m1, m2, _ = make_pairs(pg, 1300)
+    h1, h2 = hard_pairs(pg)
+    m1, m2 = list(m1) + list(h1), list(m2) + list(h2)
+    want, st = oracle_pe(o, m1, m2, b_size=512, find_orphan=True, secondary_chains=True)
+    plain, _ = oracle_pe(o, m1, m2, b_size=512, find_orphan=True)
+    assert sum(x != y for x, y in zip(want.split(b"\n"), plain.split(b"\n"))) > 100
+    seq, offs, names, noff, q = interleave(m1, m2)
+    n = len(m1)
+    idx = capi.Index(fi=fi)
+    ctx = capi.Ctx(idx)
+    try:
+        model = capi.PeModelC()
+        at, learnt = 0, []
+        while at < n and not model.complete:
+            hi = min(n, at + 512)
+            ctx.pe_learn(seq[int(offs[2 * at]):int(offs[2 * hi])], offs[2 * at:2 * hi + 1] - offs[2 * at], model, secondary_chains=1)
+            learnt.append((at, hi)); at = hi
+        assert model.count == st["ins_count"] and model.mean == st["ins_mean"] and model.std_dev == st["ins_std_dev"]
+        out = []
+        for lo, hi in learnt + [(x, min(n, x + 512)) for x in range(at, n, 512)]:
+            sl = slice(2 * lo, 2 * hi + 1)
+            sam, _ = ctx.pe_align(seq[int(offs[2 * lo]):int(offs[2 * hi])], offs[sl] - offs[2 * lo], names[int(noff[2 * lo]):int(noff[2 * hi])], noff[sl] - noff[2 * lo],
+                                  q[int(offs[2 * lo]):int(offs[2 * hi])], model, host_threads=4, find_orphan=1, secondary_chains=1)
+            out.append(sam)
+        got = b"".join(out)
+    finally:
+        ctx.close()
+        idx.close()
+    if got != want:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))

@@ -25,7 +25,7 @@ def interleave(m1, m2, slash=True, names=None):
     return seq, offs, np.frombuffer(b"".join(nm), np.uint8), noff, np.full(len(seq), ord("I"), np.uint8)
 
 
-def oracle_pe(o, m1, m2, slash=True, b_size=512, find_orphan=False, report_mems=False):
+def oracle_pe(o, m1, m2, slash=True, b_size=512, find_orphan=False, report_mems=False, secondary_chains=False):
     n = len(m1)
     o1 = np.zeros(n + 1, np.uint64); o1[1:] = np.cumsum([len(x) for x in m1])
     o2 = np.zeros(n + 1, np.uint64); o2[1:] = np.cumsum([len(x) for x in m2])
@@ -35,7 +35,7 @@ def oracle_pe(o, m1, m2, slash=True, b_size=512, find_orphan=False, report_mems=
     no2 = np.zeros(n + 1, np.uint64); no2[1:] = np.cumsum([len(x) for x in nm2])
     q1 = np.full(int(o1[-1]), ord("I"), np.uint8); q2 = np.full(int(o2[-1]), ord("I"), np.uint8)
     return orc.align_pe(o, np.concatenate(m1), o1, np.concatenate(m2), o2, np.frombuffer(b"".join(nm1), np.uint8), no1,
-                        np.frombuffer(b"".join(nm2), np.uint8), no2, q1, q2, b_size=b_size, find_orphan=find_orphan, report_mems=report_mems)
+                        np.frombuffer(b"".join(nm2), np.uint8), no2, q1, q2, b_size=b_size, find_orphan=find_orphan, report_mems=report_mems, secondary_chains=secondary_chains)
 
 
 def first_diff(a: bytes, b: bytes):
@@ -215,6 +215,23 @@ def test_pe_host_pipeline_replay(case):
     assert st["orphan_recovered"] > 10
     seq, offs, names, noff, q = interleave(m1, m2)
     got, stats = S.align_pe_big_batch(seq, offs, names, noff, q, mean=st["ins_mean"], std_dev=st["ins_std_dev"], find_orphan=True)
+    if got != want:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
+    assert int(stats[1]) == st["aligned"]
+
+
+def test_pe_replay_secondary_chains(case):
+    """-Z (find_chains_secondary, chain.hpp:442-727): the second track of the chaining in pe_core.h's lane-serial form against the oracle's restatement,
+    with orphan recovery on; the option changes most records (more chains: sub_n, MAPQ, alternatives)"""
+    pg, fi, o = case
+    m1, m2, _ = make_pairs(pg, 500)
+    h1, h2 = hard_pairs(pg)
+    m1, m2 = list(m1) + list(h1), list(m2) + list(h2)
+    want, st = oracle_pe(o, m1, m2, b_size=4096, find_orphan=True, secondary_chains=True)
+    plain, _ = oracle_pe(o, m1, m2, b_size=4096, find_orphan=True)
+    assert sum(x != y for x, y in zip(want.split(b"\n"), plain.split(b"\n"))) > 100
+    seq, offs, names, noff, q = interleave(m1, m2)
+    got, stats = hs.Sim(fi).align_pe_batch(seq, offs, names, noff, q, finalize=True, mean=st["ins_mean"], std_dev=st["ins_std_dev"], find_orphan=True, secondary_chains=True)
     if got != want:
         raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
     assert int(stats[1]) == st["aligned"]

@@ -208,6 +208,19 @@ MONI_HD void ms_step_general(const moni_consts_t& K, const lds_tables_t& L, cons
     S.abs = true;
 }
 
+// -DMONI_MS_ATTR=1 / 2 (profiles/ms_attr.sh; never in the product build): the jump counter's bits 28.. count what a step reads beyond its own fast row -
+// 1: the next-run walks (the LF image lies past the destination run: one more fast row each), 2: the entries into the general path (32-byte row, c-run
+// record, ...).  J itself stays in bits 0..27.
+#if defined(MONI_MS_ATTR) && MONI_MS_ATTR == 1
+#define MS_ATTR_WALK(nj) ((nj) += (1ull << 28))
+#define MS_ATTR_GEN(nj)
+#elif defined(MONI_MS_ATTR) && MONI_MS_ATTR == 2
+#define MS_ATTR_WALK(nj)
+#define MS_ATTR_GEN(nj) ((nj) += (1ull << 28))
+#else
+#define MS_ATTR_WALK(nj)
+#define MS_ATTR_GEN(nj)
+#endif
 // One LF step of one task for symbol code c (moni.hpp:579-621).
 MONI_HD void ms_step(const moni_consts_t& K, const lds_tables_t& L, const moni_row_t* __restrict__ rows,
                      const moni_frow_t* __restrict__ frows, const uint32_t* __restrict__ cr, const moni_rec_t* __restrict__ recs,
@@ -216,7 +229,7 @@ MONI_HD void ms_step(const moni_consts_t& K, const lds_tables_t& L, const moni_r
         moni_row_t A;
         settle_run(rows, K.r, S.pos, S.run, A);
         S.off = (uint32_t)(S.pos - row_start(A));            // < 2^32 unless the run is longer, in which case the row is not "ok" anyway
-        if (S.pos - row_start(A) >= MONI_ROW_LEN_SAT) { ms_step_general(K, L, rows, cr, recs, c, S, n_jumps); return; }
+        if (S.pos - row_start(A) >= MONI_ROW_LEN_SAT) { MS_ATTR_GEN(n_jumps); ms_step_general(K, L, rows, cr, recs, c, S, n_jumps); return; }
         S.abs = false;
     }
     const uint32_t hc = L.hot_slot[c];
@@ -229,11 +242,12 @@ MONI_HD void ms_step(const moni_consts_t& K, const lds_tables_t& L, const moni_r
             const moni_row_t A = ld_row(rows, S.run);
             if (S.off == MONI_OFF_END) S.pos = ld_start(rows, S.run + 1) - 1;
             else S.pos = row_start(A) + S.off;
+            MS_ATTR_GEN(n_jumps);
             ms_step_general(K, L, rows, cr, recs, c, S, n_jumps);
             return;
         }
         if (S.off == MONI_OFF_END) S.off = len - 1;
-        if (S.off >= len) { S.off -= len; ++S.run; continue; }          // the LF image ran past the destination run: next run
+        if (S.off >= len) { S.off -= len; ++S.run; MS_ATTR_WALK(n_jumps); continue; }          // the LF image ran past the destination run: next run
         const uint32_t hh = (uint32_t)(w0 >> 56) & 3u;
         if (hc == hh) {                                      // bwt[pos] == c
             S.sample--;

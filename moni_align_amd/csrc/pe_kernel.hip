@@ -70,8 +70,8 @@ __device__ __attribute__((noinline)) void pe_sw_local(const dp_launch_t& D, pe_s
     }
     *out = r;
 }
-// The same pass by the whole wave (the kernel's default): 64 target rows at a time, lane l on row i0 + l, the cells of an anti-diagonal in one
-// step (lane l on column s - l); a lane takes H / E of the row above from lane l - 1 by one shuffle per step (lane 0: from the previous tile's
+// The same pass by the whole wave (the kernel's default): 128 target rows at a time, lane l on rows i0 + 2 l and i0 + 2 l + 1, the cells of an anti-diagonal in one
+// step (lane l on column s - l); a lane takes H / E of the row above its first row from lane l - 1 by one shuffle per step (lane 0: from the previous tile's
 // bottom row in LDS), keeps F and the diagonal to itself, and tracks its row's maximum and the leftmost column that reaches it; after a tile
 // the rows are visited in order for klib's rule (the first row that exceeds every earlier one; stop at endsc).  ~(qlen + 63) * tlen / 64 steps
 // instead of qlen * tlen cells by one lane.  qlen <= DP_LDS_Q; the dataflow was checked lane by lane against the oracle before it was written here.
@@ -91,53 +91,72 @@ __device__ __attribute__((noinline)) void pe_sw_pass_wave(const dp_launch_t& D, 
     const int gape = D.e, gapoe = D.qo + D.e;
     int gmax = 0, te = -1, qe = -1;
     bool stop = false;
-    for (int i0 = 0; i0 < tlen && !stop; i0 += 64) {
-        const int i = i0 + lane;
-        const bool row_ok = i < tlen;
-        uint32_t tc = 4;
-        if (row_ok) {
-            const int ti = (reverse && i <= t_last) ? t_last - i : i;
-            const uint64_t ta = task.t_off + (uint64_t)ti;
-            tc = dp_nt4(ta < D.n_text ? D.text[ta] : 0u);
-        }
-        int pubH = 0, pubE = 0, upH_prev = 0, f = 0, rmax = 0, rarg = -1;
+    // Two target rows per lane (a = i0 + 2 l, b = a + 1; 128 rows per tile): lane l is on column j = s - l of both in step s - row b's cell comes right after row a's,
+    // whose H / E it takes from registers - and hands row b's H / E to lane l + 1 by one shuffle per step: half the tiles, the same qlen + 63 steps per tile.
+    for (int i0 = 0; i0 < tlen && !stop; i0 += 128) {
+        const int ia = i0 + 2 * lane, ib = ia + 1;
+        const bool ok_a = ia < tlen, ok_b = ib < tlen;
+        uint32_t tca = 4, tcb = 4;
+        if (ok_a) { const int ti = (reverse && ia <= t_last) ? t_last - ia : ia; const uint64_t ta = task.t_off + (uint64_t)ti; tca = dp_nt4(ta < D.n_text ? D.text[ta] : 0u); }
+        if (ok_b) { const int ti = (reverse && ib <= t_last) ? t_last - ib : ib; const uint64_t ta = task.t_off + (uint64_t)ti; tcb = dp_nt4(ta < D.n_text ? D.text[ta] : 0u); }
+        int pubH = 0, pubE = 0, upH_prev = 0, ha_prev = 0, fa = 0, fb = 0, rmax_a = 0, rarg_a = -1, rmax_b = 0, rarg_b = -1;
         const int n_steps = qlen + 63;
         for (int s = 0; s < n_steps; ++s) {
             const int inH = __shfl_up(pubH, 1), inE = __shfl_up(pubE, 1);
             const int j = s - lane;
             const bool col_ok = j >= 0 && j < qlen;
-            int upH, upE, diag;
-            if (lane == 0) { upH = col_ok ? Hb[j] : 0; upE = col_ok ? Eb[j] : 0; diag = (j >= 1 && j < qlen) ? Hb[j - 1] : 0; }
-            else { upH = inH; upE = inE; diag = j >= 1 ? upH_prev : 0; upH_prev = upH; }
-            if (row_ok && col_ok) {
-                if (j == 0) f = 0;
+            int upE, diag;
+            if (lane == 0) { upE = col_ok ? Eb[j] : 0; diag = (j >= 1 && j < qlen) ? Hb[j - 1] : 0; }
+            else { upE = inE; diag = j >= 1 ? upH_prev : 0; upH_prev = inH; }
+            if (ok_a && col_ok) {
+                if (j == 0) { fa = 0; fb = 0; }
                 const uint32_t q = qc[j];
-                const int sc = (tc >= 4 || q >= 4) ? 0 : (tc == q ? D.sc_mch : D.sc_mis);
-                int h = diag + sc;
-                h = h > upE ? h : upE; h = h > f ? h : f;
+                // row a
+                const int sca = (tca >= 4 || q >= 4) ? 0 : (tca == q ? D.sc_mch : D.sc_mis);
+                int h = diag + sca;
+                h = h > upE ? h : upE; h = h > fa ? h : fa;
                 int hh = h - gapoe; hh = hh > 0 ? hh : 0;
-                int e2 = upE - gape; e2 = e2 > 0 ? e2 : 0; e2 = e2 > hh ? e2 : hh;
-                f -= gape; f = f > 0 ? f : 0; f = f > hh ? f : hh;
-                pubH = h; pubE = e2;
-                if (h > rmax) { rmax = h; rarg = j; }
-                if (lane == 63) { Hb[j] = h; Eb[j] = e2; }
+                int ea = upE - gape; ea = ea > 0 ? ea : 0; ea = ea > hh ? ea : hh;
+                fa -= gape; fa = fa > 0 ? fa : 0; fa = fa > hh ? fa : hh;
+                if (h > rmax_a) { rmax_a = h; rarg_a = j; }
+                const int ha = h;
+                pubH = ha; pubE = ea;
+                if (ok_b) {          // row b: the row above is row a at this column (ha, ea), its diagonal row a's cell of the step before
+                    const int scb = (tcb >= 4 || q >= 4) ? 0 : (tcb == q ? D.sc_mch : D.sc_mis);
+                    int g = (j >= 1 ? ha_prev : 0) + scb;
+                    g = g > ea ? g : ea; g = g > fb ? g : fb;
+                    int gg = g - gapoe; gg = gg > 0 ? gg : 0;
+                    int eb = ea - gape; eb = eb > 0 ? eb : 0; eb = eb > gg ? eb : gg;
+                    fb -= gape; fb = fb > 0 ? fb : 0; fb = fb > gg ? fb : gg;
+                    if (g > rmax_b) { rmax_b = g; rarg_b = j; }
+                    pubH = g; pubE = eb;
+                }
+                ha_prev = ha;
+                if (lane == 63) { Hb[j] = pubH; Eb[j] = pubE; }
             }
         }
         __syncthreads();
-        // klib's rule over the tile's rows in order - a row counts when its maximum exceeds every earlier row's, the first such row that reaches endsc ends the pass -
-        // by a prefix maximum over the lanes instead of 64 round trips: P(l) = the running maximum after row l; the rows that count are those where P rises
+        // klib's rule over the tile's rows in order (a of lane 0, b of lane 0, a of lane 1, ...): a row counts when its maximum exceeds every earlier row's, the first such
+        // row that reaches endsc ends the pass.  P = the running maximum after a row, by a prefix maximum over the lanes
         {
-            int P = row_ok ? rmax : INT32_MIN;
-            for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(P, o); if (lane >= o) P = P > x ? P : x; }
-            P = P > gmax ? P : gmax;
-            int Pprev = __shfl_up(P, 1);
-            if (lane == 0) Pprev = gmax;
-            const unsigned long long hits = __ballot(P > Pprev && P >= endsc);
-            const int last = hits ? __ffsll((long long)hits) - 1 : 63;
-            const int M = __shfl(P, last);
+            const int ra = ok_a ? rmax_a : INT32_MIN, rb = ok_b ? rmax_b : INT32_MIN;
+            int Q = ra > rb ? ra : rb;
+            for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(Q, o); if (lane >= o) Q = Q > x ? Q : x; }
+            int base = __shfl_up(Q, 1);
+            if (lane == 0) base = INT32_MIN;
+            base = base > gmax ? base : gmax;                       // the running maximum before this lane's rows
+            const int Pa = base > ra ? base : ra, Pb = Pa > rb ? Pa : rb;
+            const bool hit_a = Pa > base && Pa >= endsc, hit_b = Pb > Pa && Pb >= endsc;
+            const unsigned long long hits = __ballot(hit_a || hit_b);
+            int M;
+            if (hits) { const int Lh = __ffsll((long long)hits) - 1; const int ha_l = __shfl((int)hit_a, Lh); const int pa_l = __shfl(Pa, Lh), pb_l = __shfl(Pb, Lh); M = ha_l ? pa_l : pb_l; }
+            else M = __shfl(Pb, 63);
             if (M > gmax) {
-                const int first = __ffsll((long long)__ballot(lane <= last && P == M)) - 1;
-                gmax = M; te = i0 + first; qe = __shfl(rarg, first);
+                const int F = __ffsll((long long)__ballot(Pa == M || Pb == M)) - 1;          // the first row whose running maximum is M: where it was reached
+                const int is_a = __shfl((int)(Pa == M), F);
+                gmax = M; te = i0 + 2 * F + (is_a ? 0 : 1);
+                const int qa = __shfl(rarg_a, F), qb = __shfl(rarg_b, F);
+                qe = is_a ? qa : qb;
             }
             if (hits) stop = true;
         }

@@ -220,6 +220,14 @@ def test_pe_stream_variant_and_small_chunks(case, monkeypatch):
         for _ in range(2):
             b, sb = ctx.pe_align(seq, offs, names, noff, q, model, host_threads=3, find_orphan=1, stream=True)
             assert a == b and sa["aligned"] == sb["aligned"]
+        # moni_pe_align_run: the mates made resident by moni_reads_upload (what bench.py --paired times)
+        monkeypatch.delenv("MONI_PE_CHUNK")
+        ctx.upload(seq, offs)
+        r, sr = ctx.pe_align_run(names, noff, q, model, host_threads=4, find_orphan=1)
+        assert r == a and sr["aligned"] == sa["aligned"]
+        r2, _ = ctx.pe_align_run(names, noff, None, model, host_threads=4, find_orphan=1)          # without qualities
+        assert r2.count(b"\n") == a.count(b"\n") and r2 != a and b"\t*\tAS:i:" in r2
+        monkeypatch.setenv("MONI_PE_CHUNK", "64")
         half = 2 * 700
         c_, _ = ctx.pe_align(seq[:int(offs[half])], offs[:half + 1], names[:int(noff[half])], noff[:half + 1], q[:int(offs[half])], model, host_threads=4, find_orphan=1, stream=True)
         assert c_ == b"".join(a.split(b"\n")[i] + b"\n" for i in range(half))

@@ -184,7 +184,7 @@ struct af_wave_tt {
 };
 static_assert(AF_MAX_TASKS_READ <= 255, "ntasks is a byte");
 typedef af_wave_tt<96, 48, 24, 8, 32, 32> af_wave_small_t;                                                   // most reads: 8 waves per SIMD
-typedef af_wave_tt<160, 80, 32, 16, 64, 48> af_wave_mid_t;            // LEVEL 0 for reads of more than 200 bases (250 bp x 21 sequences: ~120 anchors per read, 27 % of the reads fit the small instance, 85 % this one): 5 waves per SIMD
+typedef af_wave_tt<192, 96, 32, 16, 64, 48> af_wave_mid_t;            // LEVEL 0 for reads of more than 200 bases (250 bp x 21 sequences: ~120 anchors per read, p99 210: 27 % of the reads fit the small instance, 98.8 % this one): 4 waves per SIMD (a 160-anchor one at 5 waves per SIMD: 7.70 against 7.88 M reads/s)
 typedef af_wave_tt<AF_MAX_ANCH, AF_MAX_CHAINS, AF_MAX_MEMS, AF_MAX_CAND, AF_PLAN_AN, AF_MAX_TASKS_READ> af_wave_t;   // reads that overflow it
 typedef af_wave_tt<2048, 1024, 256, AF_MAX_CAND, AF_PLAN_AN, AF_MAX_TASKS_READ> af_wave_huge_t;             // repeat-rich reads (hundreds of occurrences per seed): one wave per CU
 

@@ -1408,11 +1408,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 G.l0_mm = l0_mid ? (uint32_t)af_wave_mid_t::MM : (uint32_t)af_wave_small_t::MM; G.l0_ma = l0_mid ? (uint32_t)af_wave_mid_t::MA : (uint32_t)af_wave_small_t::MA;
                 hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
                 if (l0_mid) {
-                    static const int midocc = getenv("MONI_AF_MIDOCC") ? atoi(getenv("MONI_AF_MIDOCC")) : 5;          // measured 4 and 5 (7.58 / 7.66 M reads/s at 250 bp x 20 haplotypes; 6.92 M with the small instance as LEVEL 0)
-                    const dim3 g1((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 4 * midocc));
-                    if (midocc == 5) hipLaunchKernelGGL((chain_plan_kernel<af_wave_mid_t, 0, 5>), g1, dim3(64), 0, sx, G);
-                    else if (midocc == 3) hipLaunchKernelGGL((chain_plan_kernel<af_wave_mid_t, 0, 3>), g1, dim3(64), 0, sx, G);
-                    else hipLaunchKernelGGL((chain_plan_kernel<af_wave_mid_t, 0, 4>), g1, dim3(64), 0, sx, G);
+                    const dim3 g1((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 4 * 4));
+                    hipLaunchKernelGGL((chain_plan_kernel<af_wave_mid_t, 0, 4>), g1, dim3(64), 0, sx, G);
                 } else {
                     static const int k1occ = getenv("MONI_AF_K1OCC") ? atoi(getenv("MONI_AF_K1OCC")) : 8;      // 8 waves/SIMD: 32 reads in flight per CU (4.9 KB of LDS each); measured 5, 6, 8
                     const dim3 g1((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 4 * k1occ));

@@ -213,12 +213,24 @@ def run_rank(args) -> int:
             torch.cuda.empty_cache()
             log("flat index built on GPU in %.1fs: n=%d r=%d n/r=%.2f" % (time.time() - t0, fi.n, fi.r, fi.n / fi.r))
             if world > 1 or os.environ.get("MONI_BENCH_SAVE_INDEX"):
-                fi.save(path + ".tmp")
-                os.replace(path + ".tmp", path)
+                try:
+                    fi.save(path + ".tmp")
+                    os.replace(path + ".tmp", path)
+                except OSError as e:          # (no room for the 10 GB cache file: the other ranks then build the index on their own GPUs)
+                    log("could not write the index cache %s: %s" % (path, e))
+                    try:
+                        os.remove(path + ".tmp")
+                    except OSError:
+                        pass
     if world > 1:
         dist.barrier()
         if rank != 0:
-            fi = index_build.FlatIndex.load(path)
+            try:
+                fi = index_build.FlatIndex.load(path)
+            except (OSError, ValueError) as e:
+                log("rank %d: no usable index cache (%s): building on cuda:%d" % (rank, e, local_rank))
+                fi = index_build.build_from_pangenome(pg, device="cuda:%d" % local_rank, log=log, lifted=not args.fasta_index)
+                torch.cuda.empty_cache()
     t0 = time.time()
     idx = capi.Index(fi=fi, device=local_rank)
     log("rank %d: device image %.2f GB in %.1fs" % (rank, idx.device_bytes / 1e9, time.time() - t0))

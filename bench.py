@@ -622,7 +622,7 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx) -> 
                "roofline": {"bound": "hbm", "kernel": "ms_lf_kernel", "achieved": 73 * S_lf / (lf_ms / 1e3) / 1e9 if lf_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": 73 * S_lf / (lf_ms / 1e3) / 1e9 / HBM_PEAK_GBS if lf_ms > 0 else 0.0, "traffic": None, "model": "layout: 73 bytes per LF step", "avg_launch_ms": lf_ms,
                             "survey_8d": {"bytes_per_launch": 128 * S_lf + 64 * J_lf, "frac": (128 * S_lf + 64 * J_lf) / (lf_ms / 1e3) / 1e9 / HBM_PEAK_GBS if lf_ms > 0 else 0.0}},
-               "pairs_to_pe_align_kernel": st["kernel_fallback"], "handed_over_because": {k: v for k, v in st.get("handover_why", {}).items() if v},
+               "pairs_handed_over": st["kernel_fallback"],          # by the staged kernels to pe_orphan_kernel (orphan recovery: counted as loop_depends_on_score; capacities) "handed_over_because": {k: v for k, v in st.get("handover_why", {}).items() if v},
                "host": {"cpus_usable": host_cpus(), "host_threads_per_gpu": threads}}
         if from_host is not None:
             out["from_host"] = from_host

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         }
         __syncthreads();
         const pe_rec_t& R = L.rec;
-        bool to_host = R.status == 2 || R.status > 2 || m[0] > AF_MAX_READ || m[1] > AF_MAX_READ;
+        bool to_host = R.status >= 2 || m[0] > AF_MAX_READ || m[1] > AF_MAX_READ;          // status 2: beyond the kernels' capacities (the host pipeline's pair)
         const bool finalized = R.status == 1;
         const uint32_t strand = R.strand;
         const bool rev[2] = {finalized && strand != 0, finalized && strand == 0};

@@ -12,6 +12,6 @@ for even in 0 1; do
   python3 - <<PY
 import json
 d = json.loads(open("gpurun_out/r03r/bench_paired_even$even.json").read().strip().splitlines()[-1])
-print("paired even=$even", round(d["value"] / 1e6, 3), "M pairs/s", round(d["ms_per_step"], 1), "ms", d["stages_s_per_step"], d.get("from_host"), d.get("pairs_to_pe_align_kernel"), d.get("handed_over_because"))
+print("paired even=$even", round(d["value"] / 1e6, 3), "M pairs/s", round(d["ms_per_step"], 1), "ms", d["stages_s_per_step"], d.get("from_host"), d.get("pairs_handed_over"), d.get("handed_over_because"))
 PY
 done

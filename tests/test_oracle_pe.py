@@ -35,7 +35,7 @@ def case():
     return pg, fi, orc.OracleIndex(fi=fi)
 
 
-def run(o, m1, m2, b_size=512, slash=True):
+def run(o, m1, m2, b_size=512, slash=True, **kw):
     n = len(m1)
     L = len(m1[0])
     offs = np.arange(0, (n + 1) * L, L, dtype=np.uint64)
@@ -45,7 +45,7 @@ def run(o, m1, m2, b_size=512, slash=True):
     no2 = np.zeros(n + 1, np.uint64); no2[1:] = np.cumsum([len(x) for x in nm2])
     q = np.full(n * L, ord("I"), np.uint8)
     sam, st = orc.align_pe(o, np.concatenate(m1), offs, np.concatenate(m2), offs, np.frombuffer(b"".join(nm1), np.uint8), no1,
-                           np.frombuffer(b"".join(nm2), np.uint8), no2, q, q, b_size=b_size)
+                           np.frombuffer(b"".join(nm2), np.uint8), no2, q, q, b_size=b_size, **kw)
     recs = [l.split(b"\t") for l in sam.split(b"\n") if l]
     return recs, st
 
@@ -185,3 +185,29 @@ def test_orphan_recovery_places_the_seedless_mate(case):
             assert abs(abs(int(a[8])) - truth[i]) <= 60
             assert b"M" in b[5] and int(dict(x.split(b":", 2)[::2] for x in b[11:] if x.startswith(b"NM"))[b"NM"]) >= 4
     assert rec >= len(broken) // 3
+
+
+def test_secondary_chains_keep_the_pair_invariants_and_the_placements(case):
+    """-Z (find_chains_secondary, chain.hpp:442-727): more chains reach the selection loop, so second-best scores, sub_n, MAPQ and the alternative hits
+    change - but a pair's placement does not get worse: the same pairs are proper, at the same positions, with the SAM pair invariants, and no MAPQ rises"""
+    pg, fi, o = case
+    m1, m2, truth = make_pairs(pg, 800, seed=4)
+    plain, st0 = run(o, m1, m2)
+    sec, st1 = run(o, m1, m2, secondary_chains=True)
+    assert len(sec) == len(plain) == 1600
+    changed = sum(1 for x, y in zip(plain, sec) if x != y)
+    assert changed > 50
+    proper = 0
+    for i in range(800):
+        a, b = sec[2 * i], sec[2 * i + 1]
+        pa, pb = plain[2 * i], plain[2 * i + 1]
+        fa, fb = int(a[1]), int(b[1])
+        if int(pa[1]) & 2:
+            assert fa & 2 and fb & 2
+            assert (a[2], a[3], a[5]) == (pa[2], pa[3], pa[5]) and (b[2], b[3], b[5]) == (pb[2], pb[3], pb[5])          # RNAME, POS, CIGAR
+            assert int(a[4]) <= int(pa[4]) and int(b[4]) <= int(pb[4])                                                    # MAPQ: more competitors, never fewer
+        if fa & 2:
+            proper += 1
+            assert (fa & 64) and (fb & 128) and bool(fa & 16) != bool(fb & 16) and a[6] == b"=" and b[6] == b"="
+            assert int(a[7]) == int(b[3]) and int(b[7]) == int(a[3]) and int(a[8]) == -int(b[8])
+    assert proper > 740 and st1["aligned"] >= st0["aligned"] - 2

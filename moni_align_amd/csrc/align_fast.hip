@@ -161,25 +161,28 @@ struct af_left_t { uint64_t ref; int64_t score; };
 template <int MA_, int MC_, int MM_, int NC_, int NA_, int NT_, int PE_ = 0>
 struct af_wave_tt {
     static constexpr int MA = MA_, MC = MC_, MM = MM_, NC = NC_, NA = NA_, NT = NT_;
-    uint64_t left_ref2[PE_ ? MC_ : 1];   // paired-end: check_paired_left_MEM's coordinate of mate 2 (left_ref: of mate 1)
+    static constexpr int NSTACK = MA_ <= 128 ? 16 : MA_ <= 512 ? 20 : 24;      // pending partitions of the introsort emulation: at most 2 * floor(log2 n) + 1
     af_mem_t mem[MM_];
     uint64_t anch[MA_];                  // x (reference end, 40 bits) | mem << 40
     af_chain_t chains[MC_];
     uint16_t pool[MA_ + MC_];
-    uint64_t left_ref[MC_];              // check_left_MEM's lifted coordinate of every chain (lanes in parallel: each lift is a chain of dependent loads)
-    uint16_t left_idx[MC_];              // the chains check_left_MEM has recorded
-    int64_t diff[8];
     uint32_t n_chains_sh, status_sh, n_tasks;
     union {
-        struct {                         // chaining
-            lsort::frame stack[24];
+        struct {                         // chaining (dead once af_chain has returned)
+            lsort::frame stack[NSTACK];
             int32_t f[MA_], msc[MA_];
             int16_t p[MA_], t[MA_];
             af_start_t starts[MC_];
             uint16_t run_start[MA_ + 1];
             uint16_t s_off[MC_], s_cnt[MC_];       // per sorted start: where its chain's anchors are in the pool, how many (0: chain dropped)
         };
-        af_plan_lds_t<NC_, NA_, NT_> plan;      // the plan and its tasks
+        struct {                         // the selection loop and the plan
+            af_plan_lds_t<NC_, NA_, NT_> plan;      // the plan and its tasks
+            uint64_t left_ref[MC_];              // check_left_MEM's lifted coordinate of every chain (lanes in parallel: each lift is a chain of dependent loads)
+            uint64_t left_ref2[PE_ ? MC_ : 1];   // paired-end: check_paired_left_MEM's coordinate of mate 2 (left_ref: of mate 1)
+            uint16_t left_idx[MC_];              // the chains check_left_MEM has recorded
+            int64_t diff[8];
+        };
     };
 };
 static_assert(AF_MAX_TASKS_READ <= 255, "ntasks is a byte");
@@ -196,6 +199,28 @@ enum { AF_WHY_LONG = 0, AF_WHY_ANCHORS, AF_WHY_CHAINS, AF_WHY_CANDS, AF_WHY_CHAI
 #define MONI_POS_MASK_ ((1ull << 40) - 1)
 
 __device__ __forceinline__ uint32_t af_bin_of(int qlen, int tlen) { return (qlen <= AF_TS && tlen <= AF_TS) ? AF_BIN_SMALL : (uint32_t)((qlen - 1) >> 4); }
+
+// The lanes that work on one read: the whole wavefront (GW = 64) or a GROUP of GW consecutive lanes (GW = 16: four reads per wavefront, each with
+// its own LDS state).  chain_plan_kernel issues mostly one-lane instructions - the selection loop, the backtracking, a lane per run of anchors - and
+// with one read per wavefront 63 of 64 lanes idle while the SIMD's issue slots are the bound (8 waves per SIMD x 0.11 VALU-active = 0.89 of the issue
+// cycles); with four reads per wavefront those sections run four wide.  Control flow is uniform within a group and may diverge between the groups of
+// a wavefront: a ballot is cut down to the group's own lanes (lanes of another group that are not at the same instruction read as 0 and are not
+// looked at), shuffles stay inside the group, and __syncthreads() - one wavefront per workgroup - only orders the wave's own LDS traffic.
+template <int GW>
+struct af_grp_t {
+    static constexpr int W = GW;
+    static_assert(GW == 64 || GW == 32 || GW == 16, "group width");
+    int lane, base;          // lane within the group; the group's first lane in the wavefront
+    __device__ __forceinline__ af_grp_t() : lane((int)(threadIdx.x & (GW - 1))), base((int)(threadIdx.x & 63u & ~(unsigned)(GW - 1))) {}
+    __device__ __forceinline__ unsigned long long ballot(bool p) const {
+        const unsigned long long b = __ballot(p);
+        if (GW == 64) return b;
+        return (b >> base) & ((1ull << (GW & 63)) - 1ull);
+    }
+    __device__ __forceinline__ unsigned long long lt_mask() const { return (1ull << lane) - 1ull; }
+    template <class T> __device__ __forceinline__ T shfl(T v, int src) const { return __shfl(v, base + src); }
+    __device__ __forceinline__ int id() const { return base / GW; }
+};
 
 // std::sort of n <= 16 elements is one insertion sort, i.e. a stable sort: every lane places one element by its stable rank
 template <class T, class Less>
@@ -215,12 +240,14 @@ __device__ __forceinline__ void af_small_sort(T* a, uint32_t n, Less less, int l
 //   * std::__final_insertion_sort (guarded for the first 16, unguarded after) is a stable sort: every lane places its elements by
 //     stable rank;
 //   * the depth-limit fallback (heap sort of a range) stays serial: it needs 2 * log2(n) unlucky partitions in a row.
-// NC: elements per lane (n <= 64 * NC).  ipos / jpos: scratch of n entries each.
+// NC: elements per lane (n <= GW * NC, GW the lanes of the read's group).  ipos / jpos: scratch of n entries each.
 // key(x): the integer the elements are ordered by (ascending).
-template <int NC, class T, class Key>
-__device__ __forceinline__ void af_wave_sort(T* a, uint32_t n, lsort::frame* st, uint16_t* ipos, uint16_t* jpos, int lane, Key key) {
+template <int NC, class GT, class T, class Key>
+__device__ __forceinline__ void af_wave_sort(const GT& g, T* a, uint32_t n, lsort::frame* st, uint16_t* ipos, uint16_t* jpos, Key key) {
+    constexpr uint32_t GW = GT::W;
+    const int lane = g.lane;
     auto less = [&](const T& x, const T& y) { return key(x) < key(y); };
-    const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const unsigned long long lt_mask = g.lt_mask();
     if (n > 16) {
         int lg = 0;
         for (uint32_t v = n; v > 1; v >>= 1) ++lg;
@@ -245,23 +272,23 @@ __device__ __forceinline__ void af_wave_sort(T* a, uint32_t n, lsort::frame* st,
                 uint32_t nA = 0, nB = 0;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {          // ranks from the left among the elements not below the pivot
-                    const uint32_t i = lo + (uint32_t)lane + 64u * c;
+                    const uint32_t i = lo + (uint32_t)lane + GW * c;
                     fa[c] = fb[c] = false;
                     if (i < hi) { v[c] = a[i]; const auto k = key(v[c]); fa[c] = !(k < pk); fb[c] = !(pk < k); }
-                    const unsigned long long ba = __ballot(fa[c]);
+                    const unsigned long long ba = g.ballot(fa[c]);
                     ra[c] = nA + (uint32_t)__popcll(ba & lt_mask);
                     nA += (uint32_t)__popcll(ba);
                 }
 #pragma unroll
                 for (int c = NC - 1; c >= 0; --c) {     // ranks from the right among the elements not above it
-                    const unsigned long long bb = __ballot(fb[c]);
-                    const unsigned long long gt_mask = lane == 63 ? 0ull : (~0ull << (lane + 1));
+                    const unsigned long long bb = g.ballot(fb[c]);
+                    const unsigned long long gt_mask = ~((2ull << lane) - 1ull);
                     rb[c] = nB + (uint32_t)__popcll(bb & gt_mask);
                     nB += (uint32_t)__popcll(bb);
                 }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const uint32_t i = lo + (uint32_t)lane + 64u * c;
+                    const uint32_t i = lo + (uint32_t)lane + GW * c;
                     if (fa[c]) ipos[ra[c]] = (uint16_t)i;
                     if (fb[c]) jpos[rb[c]] = (uint16_t)i;
                 }
@@ -269,9 +296,9 @@ __device__ __forceinline__ void af_wave_sort(T* a, uint32_t n, lsort::frame* st,
                 uint32_t K = 0;                           // swaps: the pairs whose left element lies left of the right one (a prefix of the ranks)
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const uint32_t i = lo + (uint32_t)lane + 64u * c;
+                    const uint32_t i = lo + (uint32_t)lane + GW * c;
                     const bool sw = fa[c] && ra[c] < nB && i < (uint32_t)jpos[ra[c]];
-                    K += (uint32_t)__popcll(__ballot(sw));
+                    K += (uint32_t)__popcll(g.ballot(sw));
                 }
                 const uint32_t iK = K < nA ? (uint32_t)ipos[K] : 0xFFFFFFFFu, jK1 = K > 0 ? (uint32_t)jpos[K - 1] : 0xFFFFFFFFu;
                 const long cut = (long)(iK < jK1 ? iK : jK1);
@@ -293,7 +320,7 @@ __device__ __forceinline__ void af_wave_sort(T* a, uint32_t n, lsort::frame* st,
     T v[NC]; uint32_t rk[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const uint32_t i = (uint32_t)lane + 64u * c;
+        const uint32_t i = (uint32_t)lane + GW * c;
         rk[c] = 0;
         if (i < n) {
             v[c] = a[i];
@@ -303,7 +330,7 @@ __device__ __forceinline__ void af_wave_sort(T* a, uint32_t n, lsort::frame* st,
     }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < NC; ++c) if ((uint32_t)lane + 64u * c < n) a[rk[c]] = v[c];
+    for (int c = 0; c < NC; ++c) if ((uint32_t)lane + GW * c < n) a[rk[c]] = v[c];
     __syncthreads();
 }
 
@@ -312,10 +339,11 @@ __device__ __forceinline__ void af_wave_sort(T* a, uint32_t n, lsort::frame* st,
 // is a maximal stretch of the sorted anchors whose consecutive reference ends are at most max_dist_x apart, pairs from different
 // runs never pass the distance test of chain.hpp:300 (or are skipped for their mates before it), so runs share nothing but the
 // lower bound `lb`, which only ever excludes anchors that are too far anyway.  Returns the plan status (uniform).
-template <class WT>
-__device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t na, float avg_mem_length) {
+template <class WT, class GT = af_grp_t<64>>
+__device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t na, float avg_mem_length, const GT g = GT()) {
     const ac_params_t& P = G.A.P;
-    const int lane = threadIdx.x;
+    constexpr uint32_t GW = GT::W;
+    const int lane = g.lane;
     // ---- std::sort of the anchors by reference end (chain.hpp:246) ----
     AF_STAMP(s0);
 #if defined(AF_PROFILE) || defined(AF_CUTS)
@@ -325,17 +353,17 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
         if (na <= 16) af_small_sort(L.anch, na, [](const uint64_t& a, const uint64_t& b) { return AF_X(a) < AF_X(b); }, lane);
         else { if (lane == 0) lsort::sort(L.anch, (long)na, [](const uint64_t& a, const uint64_t& b) { return AF_X(a) < AF_X(b); }, L.stack); __syncthreads(); }
     } else {
-        af_wave_sort<(WT::MA + 63) / 64>(L.anch, na, L.stack, L.run_start, reinterpret_cast<uint16_t*>(L.p), lane, [](const uint64_t& x) { return AF_X(x); });
-        for (uint32_t i = lane; i < na; i += 64) L.p[i] = 0;        // (scratch of the sort)
+        af_wave_sort<(WT::MA + GT::W - 1) / GT::W>(g, L.anch, na, L.stack, L.run_start, reinterpret_cast<uint16_t*>(L.p), [](const uint64_t& x) { return AF_X(x); });
+        for (uint32_t i = lane; i < na; i += GW) L.p[i] = 0;        // (scratch of the sort)
         __syncthreads();
     }
     AF_STAMP(s1); AF_PROF(G, 5, s0, s1);
     // ---- runs ----
     uint32_t n_runs = 0;
-    for (uint32_t i0 = 0; i0 < na; i0 += 64) {
+    for (uint32_t i0 = 0; i0 < na; i0 += GW) {
         const uint32_t i = i0 + lane;
         const bool brk = i < na && (i == 0 || (long long)AF_X(L.anch[i]) > (long long)AF_X(L.anch[i - 1]) + P.max_dist_x);
-        const unsigned long long bal = __ballot(brk);
+        const unsigned long long bal = g.ballot(brk);
         if (brk) L.run_start[n_runs + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
         n_runs += (uint32_t)__popcll(bal);
     }
@@ -345,7 +373,7 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
     if (G.dbg & 128) return AF_ST_UNALIGNED;          // timing experiment: stop after the sort
 #endif
     // ---- chaining DP (chain.hpp:278-362), one lane per run ----
-    for (uint32_t k = lane; k < n_runs; k += 64) {
+    for (uint32_t k = lane; k < n_runs; k += GW) {
         const uint32_t fb = L.run_start[k], fe = L.run_start[k + 1];
         long long lb = fb;
         for (uint32_t i = fb; i < fe; ++i) {
@@ -391,17 +419,17 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
     if (G.dbg & 256) return AF_ST_UNALIGNED;          // ... after the chaining DP
 #endif
     // ---- chain ends and starts (chain.hpp:115-164) ----
-    for (uint32_t i = lane; i < na; i += 64) L.t[i] = 0;
+    for (uint32_t i = lane; i < na; i += GW) L.t[i] = 0;
     __syncthreads();
-    for (uint32_t i = lane; i < na; i += 64) if (L.p[i] >= 0) L.t[L.p[i]] = 1;
+    for (uint32_t i = lane; i < na; i += GW) if (L.p[i] >= 0) L.t[L.p[i]] = 1;
     __syncthreads();
     uint32_t ns = 0;
-    for (uint32_t i0 = 0; i0 < na; i0 += 64) {
+    for (uint32_t i0 = 0; i0 < na; i0 += GW) {
         const uint32_t i = i0 + lane;
         const bool is_end = i < na && L.t[i] == 0 && L.msc[i] > P.min_chain_score;
         af_start_t st; st.f = 0; st.j = 0;
         if (is_end) { uint32_t j = i; while (L.f[j] < L.msc[j]) j = (uint32_t)L.p[j]; st.f = L.f[j]; st.j = (int32_t)j; }
-        const unsigned long long bal = __ballot(is_end);
+        const unsigned long long bal = g.ballot(is_end);
         const uint32_t at = ns + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         if (is_end && at < (uint32_t)WT::MC) L.starts[at] = st;
         ns += (uint32_t)__popcll(bal);
@@ -412,25 +440,25 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
     // std::sort(chain_starts, greater<pair>) (chain.hpp:376): elements that compare equal are identical pairs (two chain ends can
     // lead back to the same start), so any sort gives the reference's array: by rank, equal elements in index order
     {
-        af_start_t v[(WT::MC + 63) / 64]; uint32_t rk[(WT::MC + 63) / 64];
+        af_start_t v[(WT::MC + GT::W - 1) / GT::W]; uint32_t rk[(WT::MC + GT::W - 1) / GT::W];
 #pragma unroll
-        for (int q = 0; q < (WT::MC + 63) / 64; ++q) {
-            const uint32_t s = (uint32_t)lane + 64u * q;
+        for (int q = 0; q < (WT::MC + GT::W - 1) / GT::W; ++q) {
+            const uint32_t s = (uint32_t)lane + GW * q;
             rk[q] = 0;
             if (s < ns) { v[q] = L.starts[s]; for (uint32_t k = 0; k < ns; ++k) { const af_start_t w = L.starts[k]; rk[q] += (w.f > v[q].f || (w.f == v[q].f && (w.j > v[q].j || (w.j == v[q].j && k < s)))) ? 1u : 0u; } }
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < (WT::MC + 63) / 64; ++q) if ((uint32_t)lane + 64u * q < ns) L.starts[rk[q]] = v[q];
+        for (int q = 0; q < (WT::MC + GT::W - 1) / GT::W; ++q) if ((uint32_t)lane + GW * q < ns) L.starts[rk[q]] = v[q];
         __syncthreads();
     }
 #if defined(AF_PROFILE) || defined(AF_CUTS)
     if (G.dbg & 512) return AF_ST_UNALIGNED;          // ... after the chain starts
 #endif
     // ---- backtracking (chain.hpp:166-200), one lane per run, every lane over the sorted starts of its run in order ----
-    for (uint32_t i = lane; i < na; i += 64) L.t[i] = 0;
+    for (uint32_t i = lane; i < na; i += GW) L.t[i] = 0;
     __syncthreads();
-    for (uint32_t k = lane; k < n_runs; k += 64) {
+    for (uint32_t k = lane; k < n_runs; k += GW) {
         const uint32_t fb = L.run_start[k], fe = L.run_start[k + 1];
         uint32_t used = fb;                                   // a run's chains use at most one pool entry per anchor and one more per start
         for (uint32_t s = 0; s < ns; ++s) used += (uint32_t)L.starts[s].j < fb ? 1u : 0u;
@@ -454,10 +482,10 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
     if (G.dbg & 1024) return AF_ST_UNALIGNED;         // ... after the backtracking
 #endif
     uint32_t n_chains = 0;
-    for (uint32_t s0 = 0; s0 < ns; s0 += 64) {
+    for (uint32_t s0 = 0; s0 < ns; s0 += GW) {
         const uint32_t sx = s0 + lane;
         const bool keep = sx < ns && L.s_cnt[sx] > 0;
-        const unsigned long long bal = __ballot(keep);
+        const unsigned long long bal = g.ballot(keep);
         if (keep) {
             af_chain_t c;
             c.score = L.starts[sx].f; c.mate = L.mem[L.anch[L.starts[sx].j] >> 40].mate | ((uint32_t)(L.s_cnt[sx] >> 15) << 8); c.off = L.s_off[sx]; c.cnt = L.s_cnt[sx] & 0x7FFFu;
@@ -471,7 +499,7 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
         if (n_chains <= 16) af_small_sort(L.chains, n_chains, [](const af_chain_t& x, const af_chain_t& y) { return x.score > y.score; }, lane);
         else { if (lane == 0) lsort::sort(L.chains, (long)n_chains, [](const af_chain_t& x, const af_chain_t& y) { return x.score > y.score; }, L.stack); __syncthreads(); }
     } else          // by the whole wave (run_start and p are free again: scratch)
-        af_wave_sort<(WT::MC + 63) / 64>(L.chains, n_chains, L.stack, L.run_start, reinterpret_cast<uint16_t*>(L.p), lane, [](const af_chain_t& x) { return -(int64_t)x.score; });
+        af_wave_sort<(WT::MC + GT::W - 1) / GT::W>(g, L.chains, n_chains, L.stack, L.run_start, reinterpret_cast<uint16_t*>(L.p), [](const af_chain_t& x) { return -(int64_t)x.score; });
     if (lane == 0) L.n_chains_sh = n_chains;
     __syncthreads();
     AF_STAMP(s3); AF_PROF(G, 7, s2, s3);
@@ -610,10 +638,11 @@ __device__ __forceinline__ uint32_t af_build_cand(const af_args_t& G, WT& L, af_
 // it scores - by lane 0 (a few comparisons per chain, no memory traffic), then one LANE per chain to score builds that chain's anchors and problems
 // (af_build_cand: the one-base gaps read the read and the text - dependent HBM loads that one lane used to take one after the other for every chain).
 // All lanes call it; the returned status is uniform: AF_ST_CAND, a fallback, or 0xFF (does not fit this instance: the next larger one takes the read).
-template <class WT>
-__device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, WT& L, uint64_t off, uint32_t m) {
+template <class WT, class GT>
+__device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, WT& L, uint64_t off, uint32_t m, const GT g) {
     const ac_params_t& P = G.A.P;
-    const int lane = threadIdx.x;
+    const int lane = g.lane;
+    static_assert(WT::NC <= GT::W, "one lane per chain to score");
     const uint32_t n_chains = L.n_chains_sh;
     auto& PL = L.plan;
     // a capacity of THIS instance (chains to score, their anchors, their problems): the next larger instance takes the read; the largest hands it to align_kernel
@@ -656,11 +685,11 @@ __device__ __forceinline__ uint32_t af_plan_cands(const af_args_t& G, WT& L, uin
     // ---- the problems of every chain to score: lane c takes chain c; count, prefix sum, write ----
     uint32_t nt = 0;
     if ((uint32_t)lane < n_cand) { af_cand_anchors(L, PL.cand[lane], 3u, 0u); nt = af_build_cand<false>(G, L, PL.cand[lane], off, m, 0u); }
-    const bool bad = __ballot(nt == 0xFFFFFFFFu) != 0ull;
+    const bool bad = g.ballot(nt == 0xFFFFFFFFu) != 0ull;
     if (bad) { if (lane == 0) L.status_sh = AF_FALLBACK(G, AF_WHY_TASK_SIZE); __syncthreads(); return L.status_sh; }
     uint32_t incl = nt;
     for (int o = 1; o < AF_MAX_CAND; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += x; }
-    const uint32_t total = (uint32_t)__shfl((int)incl, (int)(n_cand ? n_cand - 1 : 0));
+    const uint32_t total = (uint32_t)g.shfl((int)incl, (int)(n_cand ? n_cand - 1 : 0));
     if (n_cand && total > (uint32_t)WT::NT) {
         if (has_larger) return 0xFFu;
         if (lane == 0) L.status_sh = AF_FALLBACK(G, AF_WHY_CAPACITY);
@@ -728,25 +757,32 @@ __global__ void __launch_bounds__(256) classify_kernel(const af_args_t G) {
 }
 
 // WT: the LDS instance (capacities).  LEVEL 0 / 1 / 2: the reads of list0 / big_list / huge_list (classify_kernel); a read whose chains or plan overflow
-// the instance it was given goes to the next list, from the largest instance to align_kernel.
-template <class WT, int LEVEL, int OCC = (LEVEL == 0 ? 6 : LEVEL == 1 ? 3 : 1)>
+// the instance it was given goes to the next list, from the largest instance to align_kernel.  GW: the lanes of one read (af_grp_t): 64 / GW reads per
+// wavefront side by side, each in its own copy of WT.
+template <class WT, int LEVEL, int OCC = (LEVEL == 0 ? 6 : LEVEL == 1 ? 3 : 1), int GW = 64>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) chain_plan_kernel(const af_args_t G) {
-    __shared__ WT L;                          // one wavefront per workgroup: __syncthreads() orders the wave's own LDS traffic
-    const int lane = threadIdx.x;
+    constexpr uint32_t NG = 64 / GW;          // reads per wavefront
+    __shared__ WT Ls[NG];                     // one wavefront per workgroup: __syncthreads() orders the wave's own LDS traffic
+    typedef af_grp_t<GW> GT;
+    const GT g;
+    WT& L = Ls[NG > 1 ? g.id() : 0];
+    const int lane = g.lane;
     const ak_args_t& A = G.A;
     constexpr bool BIG = LEVEL > 0;
     const uint32_t n_work = G.ctr[LEVEL == 0 ? AFC_L0 : LEVEL == 1 ? AFC_BIG : AFC_HUGE];
-    constexpr uint32_t GRAB = BIG ? 1u : 8u;          // reads taken per visit to the shared cursor
+    constexpr uint32_t GRAB = BIG ? 1u : NG > 1 ? 2u : 8u;          // reads a group takes per visit of the wavefront to the shared cursor
     const uint32_t* const work_list = LEVEL == 0 ? G.list0 : LEVEL == 1 ? G.big_list : G.huge_list;
-    uint32_t w_next = 0, w_end = 0;
+    uint32_t w_base = 0, w_k = GRAB;          // wave-uniform
     while (true) {
-        if (w_next >= w_end) {
-            if (lane == 0) w_next = atomicAdd(&G.ctr[LEVEL == 0 ? AFC_READ_CUR : LEVEL == 1 ? AFC_BIG_CUR : AFC_HUGE_CUR], GRAB);
-            w_next = (uint32_t)__shfl((int)w_next, 0);
-            w_end = w_next + GRAB;
+        if (w_k >= GRAB) {
+            if (threadIdx.x == 0) w_base = atomicAdd(&G.ctr[LEVEL == 0 ? AFC_READ_CUR : LEVEL == 1 ? AFC_BIG_CUR : AFC_HUGE_CUR], GRAB * NG);
+            w_base = (uint32_t)__shfl((int)w_base, 0);
+            w_k = 0;
         }
-        const uint32_t w_in = w_next++;
-        if (w_in >= n_work) break;
+        if (w_base + w_k * NG >= n_work) break;          // (wave-uniform: the groups leave together)
+        const uint32_t w_in = w_base + w_k * NG + (NG > 1 ? (uint32_t)g.id() : 0u);
+        ++w_k;
+        if (w_in >= n_work) continue;                    // the list's last reads: fewer than the wavefront has groups
         const uint32_t r_in = work_list[w_in];
         AF_STAMP(c0);
         const uint64_t r = A.read_lo + r_in;
@@ -762,41 +798,50 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         if (!fallback && b > a) {
             // ---- seed_freq_filter (aligner_ksw2.hpp:1905-1933): lanes over the read's seeds ----
             unsigned long long total = 0;
-            for (uint64_t k = a + lane; k < b; k += 64) total += A.mems[k].occ_cnt;
-            for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+            for (uint64_t k = a + lane; k < b; k += GW) total += A.mems[k].occ_cnt;
+            for (int o = GW / 2; o > 0; o >>= 1) total += __shfl_xor(total, o);
             unsigned long long tot_len = 0, n_anch = 0;
-            for (uint64_t k0 = a; k0 < b; k0 += 64) {
+            for (uint64_t k0 = a; k0 < b; k0 += GW) {
                 const uint64_t k = k0 + lane;
                 bool keep = false;
-                moni_mem_t g;
+                moni_mem_t gm;
                 if (k < b) {
-                    g = A.mems[k];
+                    gm = A.mems[k];
                     keep = true;
-                    if (A.P.filter_freq) { const double fr = static_cast<double>(g.occ_cnt) / (double)(size_t)total; if (fr > A.P.freq_thr) keep = false; }
+                    if (A.P.filter_freq) { const double fr = static_cast<double>(gm.occ_cnt) / (double)(size_t)total; if (fr > A.P.freq_thr) keep = false; }
                 }
-                const unsigned long long bal = __ballot(keep);
-                const uint32_t at = n_mems + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                const unsigned long long bal = g.ballot(keep);
+                const uint32_t at = n_mems + (uint32_t)__popcll(bal & g.lt_mask());
                 if (keep && at < (uint32_t)WT::MM) {
-                    af_mem_t x; x.occ_off = g.occ_off; x.nocc = g.occ_cnt; x.len = (uint16_t)g.len; x.idx = (uint16_t)g.idx; x.rpos = (uint16_t)g.rpos; x.mate = (uint8_t)g.mate; x.pad = 0;
+                    af_mem_t x; x.occ_off = gm.occ_off; x.nocc = gm.occ_cnt; x.len = (uint16_t)gm.len; x.idx = (uint16_t)gm.idx; x.rpos = (uint16_t)gm.rpos; x.mate = (uint8_t)gm.mate; x.pad = 0;
                     L.mem[at] = x;
                 }
-                if (keep) { tot_len += (unsigned long long)g.len * g.occ_cnt; n_anch += g.occ_cnt; }
+                if (keep) { tot_len += (unsigned long long)gm.len * gm.occ_cnt; n_anch += gm.occ_cnt; }
                 n_mems += (uint32_t)__popcll(bal);
             }
-            for (int o = 32; o > 0; o >>= 1) { tot_len += __shfl_xor(tot_len, o); n_anch += __shfl_xor(n_anch, o); }
+            for (int o = GW / 2; o > 0; o >>= 1) { tot_len += __shfl_xor(tot_len, o); n_anch += __shfl_xor(n_anch, o); }
             if (n_mems > (uint32_t)WT::MM || n_anch > (unsigned long long)WT::MA) too_big = true;
             na = (uint32_t)n_anch;
             if (!too_big && na > 0) {
                 avg = (float)(size_t)tot_len / (size_t)n_anch;
                 __syncthreads();
                 // ---- populate_anchors (chain.hpp:83-95): mem by mem, occurrence by occurrence ----
-                uint32_t base = 0;
-                for (uint32_t i = 0; i < n_mems; ++i) {
-                    const af_mem_t mi = L.mem[i];
-                    for (uint32_t j = lane; j < mi.nocc; j += 64) L.anch[base + j] = (A.occs[mi.occ_off + j] + mi.len - 1) | ((uint64_t)i << 40);
-                    base += mi.nocc;
+                if (NG > 1) {          // few lanes: every lane finds the seed of its anchors (a seed has about as many occurrences as the index has sequences)
+                    for (uint32_t x = lane; x < na; x += GW) {
+                        uint32_t i = 0, base = 0;
+                        while (base + L.mem[i].nocc <= x) { base += L.mem[i].nocc; ++i; }
+                        const af_mem_t mi = L.mem[i];
+                        L.anch[x] = (A.occs[mi.occ_off + (x - base)] + mi.len - 1) | ((uint64_t)i << 40);
+                    }
+                } else {
+                    uint32_t base = 0;
+                    for (uint32_t i = 0; i < n_mems; ++i) {
+                        const af_mem_t mi = L.mem[i];
+                        for (uint32_t j = lane; j < mi.nocc; j += GW) L.anch[base + j] = (A.occs[mi.occ_off + j] + mi.len - 1) | ((uint64_t)i << 40);
+                        base += mi.nocc;
+                    }
                 }
-                for (uint32_t i = lane; i < na; i += 64) { L.f[i] = 0; L.msc[i] = 0; L.p[i] = 0; L.t[i] = 0; }
+                for (uint32_t i = lane; i < na; i += GW) { L.f[i] = 0; L.msc[i] = 0; L.p[i] = 0; L.t[i] = 0; }
             }
         }
         __syncthreads();
@@ -805,8 +850,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         if (G.dbg & 4) na = 0;                                   // timing experiments (results are wrong): stop after the anchors ...
 #endif
         if (!fallback && !too_big && na > 0) {
-            status = af_chain(G, L, na, avg);
-            status = (uint32_t)__shfl((int)status, 0);
+            status = af_chain(G, L, na, avg, g);
+            status = (uint32_t)g.shfl((int)status, 0);
             __syncthreads();
             AF_STAMP(c2); AF_PROF(G, 1, c1, c2);
 #if defined(AF_PROFILE) || defined(AF_CUTS)
@@ -815,7 +860,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
             if (status == 0xFFu) too_big = true;
             else if (status == AF_ST_CAND) {
                 // check_left_MEM's coordinate of every chain: index(lift(leftmost anchor)).second + 1 (aligner_ksw2.hpp:565-576)
-                for (uint32_t ci = lane; ci < L.n_chains_sh; ci += 64) {
+                for (uint32_t ci = lane; ci < L.n_chains_sh; ci += GW) {
                     const af_chain_t ch = L.chains[ci];
                     const uint64_t aw = L.anch[L.pool[ch.off + ch.cnt - 1]];
                     const af_mem_t ml = L.mem[aw >> 40];
@@ -826,7 +871,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 #if defined(AF_PROFILE) || defined(AF_CUTS)
                 if (G.dbg & 16) status = AF_ST_UNALIGNED; else      // ... after the lifts
 #endif
-                status = af_plan_cands(G, L, off, m);
+                status = af_plan_cands(G, L, off, m, g);
                 __syncthreads();
                 AF_STAMP(c4); AF_PROF(G, 3, c3, c4);
                 if (status == 0xFFu) too_big = true;              // the plan does not fit this instance
@@ -844,7 +889,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         const uint32_t nt = status == AF_ST_CAND ? L.n_tasks : 0u;
         const uint32_t t0 = r_in * AF_MAX_TASKS_READ;                 // the read's own slots (bin_tasks_kernel queues them)
         if (status == AF_ST_CAND) {
-            if ((uint32_t)lane < nt) G.tasks[t0 + lane] = PL.tasks[lane];
+            for (uint32_t k = lane; k < nt; k += GW) G.tasks[t0 + k] = PL.tasks[k];
             if ((uint32_t)lane < PL.n_cand) PL.cand[lane].task0 += t0;
         }
         if (lane == 0) G.ntasks[r_in] = (uint8_t)nt;
@@ -859,11 +904,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
             const uint32_t words = (uint32_t)((offsetof(af_plan_t, cand) + (status == AF_ST_CAND ? PL.n_cand : 0u) * sizeof(af_cand_t)) / 4);
             const uint32_t* src = reinterpret_cast<const uint32_t*>(&PL);
             uint32_t* dst = reinterpret_cast<uint32_t*>(G.plans + r_in);
-            for (uint32_t w = lane; w < words; w += 64) dst[w] = src[w];
+            for (uint32_t w = lane; w < words; w += GW) dst[w] = src[w];
             const uint32_t awords = status == AF_ST_CAND ? PL.n_an * (uint32_t)(sizeof(af_anchor_t) / 4) : 0u;
             const uint32_t* asrc = reinterpret_cast<const uint32_t*>(PL.an);
             uint32_t* adst = reinterpret_cast<uint32_t*>(G.plans[r_in].an);
-            for (uint32_t w = lane; w < awords; w += 64) adst[w] = asrc[w];
+            for (uint32_t w = lane; w < awords; w += GW) adst[w] = asrc[w];
         }
         __syncthreads();
         AF_STAMP(c5); AF_PROF(G, 4, c0, c5);

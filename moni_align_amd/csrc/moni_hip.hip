@@ -48,6 +48,7 @@ struct moni_index {
     moni_phi_t *d_phi = nullptr, *d_phi_inv = nullptr;
     uint32_t *d_phi_dir = nullptr, *d_phi_inv_dir = nullptr;
     uint8_t* d_text = nullptr;
+    uint64_t* d_text2 = nullptr; uint32_t* d_exc = nullptr; uint32_t exc_sh = 10, exc_words = 0;      // 2-bit text and its exception bitmap (seed_core.h: mem_fast_t)
     uint64_t* d_seq_starts = nullptr;
     uint32_t* d_name_id = nullptr;
     uint8_t* d_snames = nullptr; uint32_t* d_sname_off = nullptr;      // sequence names, ragged (SAM text in align_kernel)
@@ -339,6 +340,16 @@ int moni_index_create(const moni_flat_index_t* f, int device, moni_index_t** out
         moni_index_destroy(I);
         return rc;
     }
+    {   // the 2-bit text of mem_kernel's comparison loop, from the byte text on the device
+        const uint64_t n_text = f->n - 1, n_words = n_text / 32 + 2;
+        I->exc_sh = text2_exc_shift(n_text, MONI_EXC_BITS);
+        I->exc_words = (uint32_t)((((n_text >> I->exc_sh) + 1) + 31) / 32);
+        if (hipMalloc((void**)&I->d_text2, n_words * 8) != hipSuccess || hipMalloc((void**)&I->d_exc, (size_t)I->exc_words * 4 + 4) != hipSuccess) { moni_index_destroy(I); return MONI_ENOMEM; }
+        I->bytes += n_words * 8 + (uint64_t)I->exc_words * 4;
+        if (hipMemset(I->d_exc, 0, (size_t)I->exc_words * 4 + 4) != hipSuccess) { moni_index_destroy(I); return MONI_ENODEV; }
+        hipLaunchKernelGGL(text2_build_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, 0, I->d_text, n_text, n_words, I->d_text2, I->d_exc, I->exc_sh);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { moni_index_destroy(I); return MONI_ENODEV; }
+    }
     *out = I;
     return MONI_OK;
 }
@@ -418,7 +429,7 @@ int moni_index_load(const char* path, int device, moni_index_t** out) {
 void moni_index_destroy(moni_index_t* I) {
     if (!I) return;
     (void)hipSetDevice(I->device);
-    void* ps[] = {I->d_tables, I->d_rows, I->d_frows, I->d_cr, I->d_recs, I->d_phi, I->d_phi_inv, I->d_phi_dir, I->d_phi_inv_dir, I->d_text, I->d_seq_starts, I->d_name_id, I->d_snames, I->d_sname_off, I->d_lift_seqs, I->d_lift_runs, I->d_pdir};
+    void* ps[] = {I->d_tables, I->d_rows, I->d_frows, I->d_cr, I->d_recs, I->d_phi, I->d_phi_inv, I->d_phi_dir, I->d_phi_inv_dir, I->d_text, I->d_text2, I->d_exc, I->d_seq_starts, I->d_name_id, I->d_snames, I->d_sname_off, I->d_lift_seqs, I->d_lift_runs, I->d_pdir};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete I;
 }
@@ -508,7 +519,7 @@ static int reads_upload(moni_ctx* c, const moni_read_batch_t* b, bool keep_host_
             uint64_t lb = 0;
             for (uint64_t i = 32 * k; i < nr && i < 32 * k + 32; ++i) lb = std::max<uint64_t>(lb, b->offsets[i + 1] - b->offsets[i]);
             blk[k].x = qw; blk[k].y = pw;
-            qw += 64 * lb; pw += 64 * ((lb + 7) / 8);
+            qw += 64 * lb; pw += 64 * ws_pat_words(lb);
         }
         blk[n_blk].x = qw; blk[n_blk].y = pw;
     }
@@ -650,11 +661,17 @@ static int seed_all(moni_ctx* c, const moni_seed_params_t* prm) {
     const uint64_t* pat = c->pat.p; const uint64_t* ptr = c->ptr.p;
     const unsigned grid_t = (unsigned)((n_tasks + MS_BLOCK - 1) / MS_BLOCK);
     const uint32_t split_on = prm->report_mems ? 0u : 1u;
+    // the 2-bit comparison holds a lane's pattern in LDS: 5 words (160 bases) or 8 (256); reads beyond that compare bytes (MONI_MEM_BYTES=1: all do)
+    static const bool mem_bytes = getenv("MONI_MEM_BYTES") != nullptr;
+    const uint64_t* text2 = mem_bytes ? nullptr : I->d_text2;
+#define MEM_LAUNCH(EMIT, RMO, MEMS, AUX) do { \
+        if (c->max_len <= 160) hipLaunchKernelGGL((mem_kernel<EMIT, 5>), dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_text, text2, I->d_exc, I->exc_sh, I->exc_words, pat, offs, c->blk.p, \
+                                                  n_tasks, ptr, prm->min_len, split_on, cnt_m, cnt_s, RMO, MEMS, AUX, slots, c->d_counters); \
+        else hipLaunchKernelGGL((mem_kernel<EMIT, 8>), dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_text, text2, I->d_exc, I->exc_sh, I->exc_words, pat, offs, c->blk.p, \
+                                n_tasks, ptr, prm->min_len, split_on, cnt_m, cnt_s, RMO, MEMS, AUX, slots, c->d_counters); } while (0)
     rec(c, EV_MC0);
     if (n_tasks)
-        hipLaunchKernelGGL(mem_kernel<false>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, pat, offs, c->blk.p,
-                           n_tasks, ptr, prm->min_len, split_on, cnt_m, cnt_s, (const uint64_t*)nullptr,
-                           (moni_mem_t*)nullptr, (uint32_t*)nullptr, slots, c->d_counters);
+        MEM_LAUNCH(false, (const uint64_t*)nullptr, (moni_mem_t*)nullptr, (uint32_t*)nullptr);
     rec(c, EV_MC1);
     hipLaunchKernelGGL(read_totals_kernel, dim3((unsigned)((nr + 1 + 255) / 256)), dim3(256), 0, c->stream, cnt_m, cnt_s, nr, tot);
     if ((rc = exclusive_scan_u64(c, tot, rmo, nr + 1))) return rc;
@@ -672,8 +689,7 @@ static int seed_all(moni_ctx* c, const moni_seed_params_t* prm) {
     uint64_t* occ_cnt = c->occ_cnt.p; uint64_t* occ_off = c->occ_off.p;
     rec(c, EV_ME0);
     if (n_tasks)
-        hipLaunchKernelGGL(mem_kernel<true>, dim3(grid_t), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, I->d_text, pat, offs, c->blk.p,
-                           n_tasks, ptr, prm->min_len, split_on, cnt_m, cnt_s, (const uint64_t*)rmo, mems, aux, slots, c->d_counters);
+        MEM_LAUNCH(true, (const uint64_t*)rmo, mems, aux);
     rec(c, EV_ME1);
     occ_args_t A;
     A.phi.recs = I->d_phi; A.phi.dir = I->d_phi_dir; A.phi_inv.recs = I->d_phi_inv; A.phi_inv.dir = I->d_phi_inv_dir;
@@ -1411,9 +1427,13 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                     const dim3 g1((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 4 * 4));
                     hipLaunchKernelGGL((chain_plan_kernel<af_wave_mid_t, 0, 4>), g1, dim3(64), 0, sx, G);
                 } else {
-                    static const int k1occ = getenv("MONI_AF_K1OCC") ? atoi(getenv("MONI_AF_K1OCC")) : 8;      // 8 waves/SIMD: 32 reads in flight per CU (4.9 KB of LDS each); measured 5, 6, 8
-                    const dim3 g1((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 4 * k1occ));
-                    if (k1occ == 4) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, 0, 4>), g1, dim3(64), 0, sx, G);
+                    // four reads per wavefront (16 lanes each, 4 x 4.6 KB of LDS): 8 wavefronts = 32 reads in flight per CU, as with one read per wavefront at
+                    // 8 waves/SIMD, but the one-lane sections issue a quarter of the instructions.  MONI_AF_GW=64: one read per wavefront (MONI_AF_K1OCC waves/SIMD)
+                    static const int l0_gw = getenv("MONI_AF_GW") ? atoi(getenv("MONI_AF_GW")) : 64;
+                    static const int k1occ = getenv("MONI_AF_K1OCC") ? atoi(getenv("MONI_AF_K1OCC")) : (l0_gw == 16 ? 2 : 8);      // one read per wavefront: measured 5, 6, 8 waves/SIMD
+                    const dim3 g1((unsigned)std::min<uint64_t>(l0_gw == 16 ? (nr + 3) / 4 : nr, (uint64_t)n_cu * 4 * k1occ));
+                    if (l0_gw == 16) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, 0, 2, 16>), g1, dim3(64), 0, sx, G);
+                    else if (k1occ == 4) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, 0, 4>), g1, dim3(64), 0, sx, G);
                     else if (k1occ == 5) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, 0, 5>), g1, dim3(64), 0, sx, G);
                     else if (k1occ == 8) hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, 0, 8>), g1, dim3(64), 0, sx, G);
                     else hipLaunchKernelGGL((chain_plan_kernel<af_wave_small_t, 0, 6>), g1, dim3(64), 0, sx, G);
@@ -1496,6 +1516,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                     for (int x = 0; x < AF_WHY_N; ++x) why_sum[x] += fc[AFC_WHY + x];
                     if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "  staged kernels, sub-batch %llu: %u DP tasks, %llu cells, %u traced, %u large + %u small + %u global chunks, %u reads to align_kernel%s\n",
                                                            (unsigned long long)k, fc[AFC_NT], cells, fc[AFC_TRACED], fc[AFC_NCHUNKS], fc[AFC_NCHUNKS + 1], fc[AFC_NCHUNKS + 2], fbn[16 * k], fc[AFC_DIRS_OVF] ? " (direction bytes overflowed)" : "");
+                    if (getenv("MONI_AK_PROFILE")) { fprintf(stderr, "    DP problems per bin (large tile by query length / 16, small tile, global by query length / 16):"); for (int x = 0; x < AF_NBIN; ++x) fprintf(stderr, " %u", fc[AFC_BINS + x]); fprintf(stderr, "\n"); }
                     if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "    handed over because: long read %u, anchors/seeds %u, chains %u, chains to score %u, chain length %u, DP size %u, overlapping anchors %u, wildcard %u, "
                                                            "loop depends on a score %u, extension short of the query end %u, capacity %u, CIGAR %u\n",
                                                            fc[AFC_WHY + 0], fc[AFC_WHY + 1], fc[AFC_WHY + 2], fc[AFC_WHY + 3], fc[AFC_WHY + 4], fc[AFC_WHY + 5], fc[AFC_WHY + 6], fc[AFC_WHY + 7], fc[AFC_WHY + 8], fc[AFC_WHY + 9], fc[AFC_WHY + 10], fc[AFC_WHY + 11]);

@@ -34,6 +34,7 @@ struct alignas(32) moni_u64x4 { uint64_t x, y, z, w; };
 struct lds_tables_t {
     uint8_t code[256];
     uint8_t compl_tab[256];
+    uint8_t c2[256];                       // byte -> 2-bit code of mem_task's comparison (base2), 4 for a byte that is not A / C / G / T
     uint32_t abs_run[256];
     uint64_t abs_pos[256];
     uint32_t rec_base[MONI_MAX_SIGMA];     // copies of the per-code constants, so that a divergent code index is an LDS read
@@ -128,6 +129,37 @@ MONI_HD uint64_t bswap64_(uint64_t v) {
 MONI_HD uint64_t ws_ptr_base(const moni_u64x2* __restrict__ blk, uint64_t task) { return blk[task >> 6].x + (task & 63u); }
 MONI_HD uint64_t ws_pat_base(const moni_u64x2* __restrict__ blk, uint64_t task) { return blk[task >> 6].y + (task & 63u); }
 
+// ------------------------------------------------------------------------------------------------
+// 2-bit forms for mem_task's comparison loop (seed_finder.hpp:134-150 compares one byte at a time through the SLP): the text as 32 bases per
+// 64-bit word (text2: 200 MB for 800 M bases - the random accesses of the loop then hit a table that the 256 MB Infinity Cache can hold), and
+// every task's strand-resolved pattern likewise, in READ order (base qi of the pattern in word qi >> 5, bits 2 (qi & 31) ..).  Only A / C / G / T
+// have a code; a byte outside them reads as code 0 and is marked: text bytes in a bitmap with one bit per block of 2^exc_sh positions
+// (separators, N runs: a comparison that touches a marked block is redone byte by byte), pattern bytes in a mask word beside the code word
+// (the 2-bit comparison stops in front of them).  Results are those of the byte comparison in every case.
+// ------------------------------------------------------------------------------------------------
+MONI_HD uint32_t base2(uint32_t b) { return (b >> 1) & 3u; }              // 'A' 0, 'C' 1, 'T' 2, 'G' 3
+MONI_HD bool base_acgt(uint32_t b) { return b == 'A' || b == 'C' || b == 'G' || b == 'T'; }
+MONI_HD uint32_t ctz64_(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
+// word w of the 2-bit text: bases 32 w .. 32 w + 31 (beyond n_text: 0); any_bad: one of them is not A / C / G / T
+MONI_HD uint64_t text2_word(const uint8_t* __restrict__ text, uint64_t n_text, uint64_t w, bool& any_bad) {
+    uint64_t word = 0;
+    any_bad = false;
+    for (uint32_t k = 0; k < 32; ++k) {
+        const uint64_t p = 32 * w + k;
+        if (p >= n_text) break;
+        const uint32_t b = text[p];
+        if (base_acgt(b)) word |= (uint64_t)base2(b) << (2 * k); else any_bad = true;
+    }
+    return word;
+}
+// the smallest block size 2^sh (sh >= 10) whose bitmap has at most `max_bits` bits for a text of n_text bases (+ 1: position n_text itself is asked for)
+MONI_HD uint32_t text2_exc_shift(uint64_t n_text, uint64_t max_bits) { uint32_t sh = 10; while (((n_text >> sh) + 1) > max_bits) ++sh; return sh; }
+#define MONI_EXC_BITS 65536u              // 8 KB of LDS in mem_kernel
+
+// the pattern workspace of a block of 64 tasks whose longest read has lb bases: [bytes, 8 per word][codes, 32 per word][masks, 32 per word], each [word][task & 63]
+MONI_HD uint64_t ws_pat_words(uint64_t lb) { return (lb + 7) / 8 + 2 * ((lb + 31) / 32); }
+MONI_HD uint64_t ws_block_len(const moni_u64x2* __restrict__ blk, uint64_t task) { return (blk[(task >> 6) + 1].x - blk[task >> 6].x) >> 6; }      // (a block's pointer words: 64 per step)
+
 MONI_HD void pack_task(const lds_tables_t& L, const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, const moni_u64x2* __restrict__ blk,
                        uint64_t task, uint64_t* __restrict__ pat) {
     const uint64_t read = task >> 1;
@@ -151,6 +183,33 @@ MONI_HD void pack_task(const lds_tables_t& L, const uint8_t* __restrict__ seq, c
             }
         }
         pat[pb + (uint64_t)w * 64u] = word;
+    }
+    // the same pattern in read order, 2 bits per base: pattern[qi] = seq[off + qi] (forward strand) or the complement of seq[off + m - 1 - qi]
+    const uint64_t lb = ws_block_len(blk, task);
+    const uint64_t cb = pb + 64u * ((lb + 7) / 8), mb = cb + 64u * ((lb + 31) / 32);
+    const uint32_t n2 = (m + 31u) >> 5;
+    for (uint32_t w = 0; w < n2; ++w) {
+        uint64_t codes = 0, mask = 0;
+        for (uint32_t g = 0; g < 4; ++g) {
+            const uint32_t q0 = 32 * w + 8 * g;
+            if (q0 >= m) break;
+            const uint32_t nv = m - q0 < 8 ? m - q0 : 8;
+            uint64_t v = 0;                                        // pattern[q0 + j] in byte j
+            if (!strand) {
+                if (nv == 8) v = load8_unaligned(seq, off + q0);
+                else for (uint32_t j = 0; j < nv; ++j) v |= (uint64_t)seq[off + q0 + j] << (8 * j);
+            } else {
+                uint64_t u = 0;                                    // seq[off + m - 1 - q0 - j] in byte j
+                if (nv == 8) u = bswap64_(load8_unaligned(seq, off + m - 8 - q0));
+                else for (uint32_t j = 0; j < nv; ++j) u |= (uint64_t)seq[off + (m - 1 - q0 - j)] << (8 * j);
+                for (uint32_t j = 0; j < nv; ++j) v |= (uint64_t)L.compl_tab[(uint32_t)(u >> (8 * j)) & 0xFFu] << (8 * j);
+            }
+            uint32_t c16 = 0, b16 = 0;
+            for (uint32_t j = 0; j < nv; ++j) { const uint32_t t = L.c2[(uint32_t)(v >> (8 * j)) & 0xFFu]; c16 |= (t & 3u) << (2 * j); b16 |= (t >> 2) << (2 * j); }
+            codes |= (uint64_t)c16 << (16 * g); mask |= (uint64_t)b16 << (16 * g);
+        }
+        pat[cb + (uint64_t)w * 64u] = codes;
+        pat[mb + (uint64_t)w * 64u] = mask;
     }
 }
 
@@ -330,8 +389,17 @@ MONI_HD void ms_task(const moni_consts_t& K, const lds_tables_t& L, const moni_r
 // aux[g]: 0xFFFFFFFF plain MEM, 0xFFFFFFFE left half, 0xFFFFFFFD right half, else offset of the MEM's halves
 // from the read's first slot.
 // ------------------------------------------------------------------------------------------------
+// what the 2-bit comparison reads (text2 == nullptr: every comparison byte by byte)
+struct mem_fast_t {
+    const uint64_t* text2;            // 32 bases per word (text2_word)
+    const uint32_t* exc;              // bit b: text block [b << exc_sh, (b + 1) << exc_sh) holds a byte that is not A / C / G / T (the kernel's copy is in LDS)
+    uint32_t exc_sh;
+    uint64_t* pw;                     // this lane's pattern code words, word w at pw[w * pw_stride] (LDS); filled here from the pattern workspace
+    uint32_t pw_stride, pw_words;     // tasks of up to 32 * pw_words bases take the 2-bit comparison
+};
+
 template <bool EMIT>
-MONI_HD void mem_task(const moni_consts_t& K, const lds_tables_t& L, const uint8_t* __restrict__ text,
+MONI_HD void mem_task(const moni_consts_t& K, const mem_fast_t& F, const uint8_t* __restrict__ text,
                       const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, const moni_u64x2* __restrict__ blk, uint64_t task,
                       const uint64_t* __restrict__ ptr, uint32_t min_len, uint32_t split_on, uint32_t* __restrict__ cnt_m,
                       uint32_t* __restrict__ cnt_s, const uint64_t* __restrict__ read_mem_off, moni_mem_t* __restrict__ mems,
@@ -392,20 +460,75 @@ MONI_HD void mem_task(const moni_consts_t& K, const lds_tables_t& L, const uint8
     pat_cache_t pc; pc.w = 0xFFFFFFFFu; pc.word = 0;
     text_cache_t tc; tc.w = ~0ull; tc.word = 0;
     const uint64_t pb = ws_pat_base(blk, task), qb = ws_ptr_base(blk, task);
-    for (uint32_t i = 0; i < m; ++i) {
-        const uint64_t pos = ptr[qb + (uint64_t)(m - 1 - i) * 64u];
-        while (pos != prev_pos_plus_one && (i + l) < m && (pos + l) < n) {
-            const uint32_t qi = (uint32_t)(i + l);
-            const uint8_t qc = pat_byte(pat, pb, m, qi, pc);
-            ++n_cmp;
-            if (qc != text_byte(text, pos + l, tc)) break;
-            if (qc == 'N') n_Ns++; else n_Ns = 0;
-            ++l;
+    // the pattern's code words into the lane's LDS column; has_inv: the pattern holds a byte that is not A / C / G / T (its mask words are then read
+    // where they lie in the workspace)
+    const bool fast = F.text2 != nullptr && m <= 32u * F.pw_words;
+    uint64_t mb = 0;
+    bool has_inv = false;
+    if (fast) {
+        const uint64_t lb = ws_block_len(blk, task);
+        const uint64_t cb = pb + 64u * ((lb + 7) / 8);
+        mb = cb + 64u * ((lb + 31) / 32);
+        for (uint32_t w = 0; w < ((m + 31u) >> 5); ++w) { F.pw[w * F.pw_stride] = pat[cb + (uint64_t)w * 64u]; has_inv = has_inv || pat[mb + (uint64_t)w * 64u] != 0; }
+    }
+    // The reference's loop nest (seed_finder.hpp:134-160: for every read offset i, extend l while the bytes agree) as ONE loop whose iteration either
+    // extends by one window or closes offset i: lanes of a wavefront that are in a long extension do not hold up the lanes that are between
+    // extensions (with the nest, every offset costs the wavefront its longest extension).
+    uint32_t i = 0;
+    bool ext = false;
+    uint64_t pos = 0;
+    while (i < m) {
+        if (!ext) {
+            pos = ptr[qb + (uint64_t)(m - 1 - i) * 64u];
+            ext = pos != prev_pos_plus_one;
+        }
+        if (ext) {
+            bool more = false;
+            if ((i + l) < m && (pos + l) < n) {
+                bool bytes = !fast;
+                if (fast) {
+                    // one window: the bases both 2-bit words hold from here on (at most 32)
+                    const uint32_t qi = (uint32_t)(i + l);
+                    const uint64_t a = pos + l;
+                    const uint32_t to = (uint32_t)a & 31u, po = qi & 31u;
+                    uint64_t x = (F.text2[a >> 5] >> (2 * to)) ^ (F.pw[(qi >> 5) * F.pw_stride] >> (2 * po));
+                    if (has_inv) x |= pat[mb + (uint64_t)(qi >> 5) * 64u] >> (2 * po);
+                    uint32_t lim = 32u - (to > po ? to : po);
+                    if (m - qi < lim) lim = m - qi;
+                    if (n - a < (uint64_t)lim) lim = (uint32_t)(n - a);
+                    uint32_t k = x ? (ctz64_(x) >> 1) : 32u;
+                    if (k > lim) k = lim;
+                    // codes say [a, a + k) agrees and a + k does not (or the window ends there).  A text byte outside A / C / G / T reads as code 0: inside
+                    // [a, a + k) it may have "agreed" with an A, and at a + k it may be what a pattern byte outside A / C / G / T equals - either way the
+                    // block is marked, and the bytes decide
+                    const uint64_t b0 = a >> F.exc_sh, b1 = (a + k) >> F.exc_sh;
+                    bytes = (((F.exc[b0 >> 5] >> (b0 & 31u)) | (F.exc[b1 >> 5] >> (b1 & 31u))) & 1u) != 0;
+                    if (!bytes) {
+                        n_cmp += k + (k < lim ? 1u : 0u);
+                        l += k;
+                        if (k) n_Ns = 0;                      // (the bytes that agreed are A / C / G / T)
+                        more = k == lim;                      // no mismatch seen yet: next window (or the end of the pattern / the text: the test above)
+                    }
+                }
+                if (bytes) {
+                    while ((i + l) < m && (pos + l) < n) {
+                        const uint32_t qi = (uint32_t)(i + l);
+                        const uint8_t qc = pat_byte(pat, pb, m, qi, pc);
+                        ++n_cmp;
+                        if (qc != text_byte(text, pos + l, tc)) break;
+                        if (qc == 'N') n_Ns++; else n_Ns = 0;
+                        ++l;
+                    }
+                }
+            }
+            if (more) continue;
+            ext = false;
         }
         if (l >= pl && n_Ns < l && l >= min_len) found(pos, l, i);
         pl = l;
         l = (l == 0 ? 0 : (l - 1));
         prev_pos_plus_one = pos + 1;
+        ++i;
     }
     if (!EMIT) { cnt_m[task] = km; cnt_s[task] = ks; }
 }

@@ -25,6 +25,7 @@ __device__ __forceinline__ void load_tables(lds_tables_t& L, const moni_tables_t
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
         L.code[i] = T->code[i];
         L.compl_tab[i] = T->compl_tab[i];
+        L.c2[i] = base_acgt((uint32_t)i) ? (uint8_t)base2((uint32_t)i) : (uint8_t)4;
         L.abs_run[i] = T->abs_run[i];
         L.abs_pos[i] = T->abs_pos[i];
     }
@@ -61,21 +62,36 @@ ms_lf_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const m
     wave_add(n_jumps, &counters[1]);
 }
 
-template <bool EMIT>
+// W: 64-bit pattern code words per lane in LDS (reads of up to 32 W bases take the 2-bit comparison; longer ones in the same launch compare bytes)
+template <bool EMIT, int W>
 __global__ void __launch_bounds__(MS_BLOCK)
-mem_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const uint8_t* __restrict__ text,
+mem_kernel(const moni_consts_t K, const uint8_t* __restrict__ text, const uint64_t* __restrict__ text2, const uint32_t* __restrict__ exc, uint32_t exc_sh, uint32_t exc_words,
            const uint64_t* __restrict__ pat, const uint64_t* __restrict__ offs, const moni_u64x2* __restrict__ blk, uint64_t n_tasks,
            const uint64_t* __restrict__ ptr, uint32_t min_len, uint32_t split_on,
            uint32_t* __restrict__ cnt_m, uint32_t* __restrict__ cnt_s,
            const uint64_t* __restrict__ read_mem_off, moni_mem_t* __restrict__ mems, uint32_t* __restrict__ aux,
            moni_u64x2* __restrict__ slots, unsigned long long* __restrict__ counters) {
-    __shared__ lds_tables_t L;
-    load_tables(L, T, K);
+    __shared__ uint64_t PW[W][MS_BLOCK];                 // [word][lane]: a lane's words lie in its own banks whatever word it reads
+    __shared__ uint32_t EX[MONI_EXC_BITS / 32];
+    for (uint32_t i = threadIdx.x; i < exc_words && i < MONI_EXC_BITS / 32; i += MS_BLOCK) EX[i] = exc[i];
+    __syncthreads();
+    mem_fast_t F;
+    F.text2 = text2; F.exc = EX; F.exc_sh = exc_sh; F.pw = &PW[0][threadIdx.x]; F.pw_stride = MS_BLOCK; F.pw_words = W;
     const uint64_t task = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
     unsigned long long n_cmp = 0;
     if (task < n_tasks)
-        mem_task<EMIT>(K, L, text, pat, offs, blk, task, ptr, min_len, split_on, cnt_m, cnt_s, read_mem_off, mems, aux, slots, n_cmp);
+        mem_task<EMIT>(K, F, text, pat, offs, blk, task, ptr, min_len, split_on, cnt_m, cnt_s, read_mem_off, mems, aux, slots, n_cmp);
     if (!EMIT) wave_add(n_cmp, &counters[3]);
+}
+
+// the 2-bit text and the bitmap of its blocks that hold a byte outside A / C / G / T (seed_core.h: text2_word), one thread per word; once per index
+__global__ void __launch_bounds__(256) text2_build_kernel(const uint8_t* __restrict__ text, uint64_t n_text, uint64_t n_words, uint64_t* __restrict__ text2,
+                                                          uint32_t* __restrict__ exc, uint32_t exc_sh) {
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= n_words) return;
+    bool bad;
+    text2[w] = text2_word(text, n_text, w, bad);
+    if (bad) { const uint64_t b = (32 * w) >> exc_sh; atomicOr(&exc[b >> 5], 1u << (b & 31u)); }
 }
 
 // per-read final MEM count (orig + 2 * split)

@@ -49,6 +49,7 @@ void* sim_create(const moni_flat_index_t* f) {
     for (uint64_t i = 0; i < f->n_seq; ++i) S->name_id[i] = (uint32_t)i;
     memcpy(S->L.code, S->img.T.code, 256);
     memcpy(S->L.compl_tab, S->img.T.compl_tab, 256);
+    for (int i = 0; i < 256; ++i) S->L.c2[i] = base_acgt((uint32_t)i) ? (uint8_t)base2((uint32_t)i) : (uint8_t)4;
     memcpy(S->L.abs_run, S->img.T.abs_run, sizeof(S->L.abs_run));
     memcpy(S->L.abs_pos, S->img.T.abs_pos, sizeof(S->L.abs_pos));
     for (int i = 0; i < MONI_MAX_SIGMA; ++i) { S->L.rec_base[i] = S->img.K.rec_base[i]; S->L.rec_cnt[i] = S->img.K.rec_cnt[i]; S->L.hot_slot[i] = S->img.K.hot_slot[i]; }
@@ -79,7 +80,7 @@ int sim_seed_run(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_r
             uint64_t lb = 0;
             for (uint64_t i = 32 * k; i < n_reads && i < 32 * k + 32; ++i) lb = std::max<uint64_t>(lb, offs[i + 1] - offs[i]);
             S->blk[k].x = qw; S->blk[k].y = pw;
-            qw += 64 * lb; pw += 64 * ((lb + 7) / 8);
+            qw += 64 * lb; pw += 64 * ws_pat_words(lb);
         }
         S->blk[n_blk].x = qw; S->blk[n_blk].y = pw;
     }
@@ -97,8 +98,16 @@ int sim_seed_run(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_r
     std::vector<uint32_t> cnt_m(n_tasks + 1), cnt_s(n_tasks + 1);
     std::vector<moni_u64x2> slots(n_tasks * MONI_MEM_SLOTS + 1);
     const uint32_t split_on = prm->report_mems ? 0 : 1;
+    // the 2-bit text and its exception bitmap as the index builds them on the device; MONI_MEM_BYTES: every comparison byte by byte
+    const uint64_t n_text = K.n_text;
+    std::vector<uint64_t> text2(n_text / 32 + 2, 0), pw(64, 0);
+    mem_fast_t F;
+    F.exc_sh = text2_exc_shift(n_text, MONI_EXC_BITS);
+    std::vector<uint32_t> exc((((n_text >> F.exc_sh) + 1) + 31) / 32 + 1, 0);
+    for (uint64_t w = 0; w < text2.size(); ++w) { bool bad; text2[w] = text2_word(S->text.data(), n_text, w, bad); if (bad) { const uint64_t b = (32 * w) >> F.exc_sh; exc[b >> 5] |= 1u << (b & 31u); } }
+    F.text2 = getenv("MONI_MEM_BYTES") ? nullptr : text2.data(); F.exc = exc.data(); F.pw = pw.data(); F.pw_stride = 1; F.pw_words = getenv("MONI_SIM_PW") ? (uint32_t)atoi(getenv("MONI_SIM_PW")) : 8u;
     for (uint64_t t = 0; t < n_tasks; ++t)
-        mem_task<false>(K, S->L, S->text.data(), pat.data(), offs, blk, t, S->ptr.data(), prm->min_len, split_on, cnt_m.data(), cnt_s.data(),
+        mem_task<false>(K, F, S->text.data(), pat.data(), offs, blk, t, S->ptr.data(), prm->min_len, split_on, cnt_m.data(), cnt_s.data(),
                         nullptr, nullptr, nullptr, slots.data(), cnt[3]);
     S->read_mem_off.assign(n_reads + 1, 0);
     for (uint64_t r = 0; r < n_reads; ++r)
@@ -108,7 +117,7 @@ int sim_seed_run(void* s, const uint8_t* seq, const uint64_t* offs, uint64_t n_r
     std::vector<uint32_t> aux(n_mems + 1);
     unsigned long long dummy = 0;
     for (uint64_t t = 0; t < n_tasks; ++t)
-        mem_task<true>(K, S->L, S->text.data(), pat.data(), offs, blk, t, S->ptr.data(), prm->min_len, split_on, cnt_m.data(), cnt_s.data(),
+        mem_task<true>(K, F, S->text.data(), pat.data(), offs, blk, t, S->ptr.data(), prm->min_len, split_on, cnt_m.data(), cnt_s.data(),
                        S->read_mem_off.data(), S->mems.data(), aux.data(), slots.data(), dummy);
     std::vector<uint64_t> tmp(n_mems * tmp_cap + 1), lowers(n_mems + 1);
     std::vector<uint32_t> pool((size_t)pool_rows * K.n_seq + 1);

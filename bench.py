@@ -29,7 +29,6 @@ HBM traffic from rocprofv3 PMC passes cannot be collected from inside this proce
 import argparse
 import json
 import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")          # before anything initialises HIP (see moni_hip.hip: moni_hip_default_queues)
 import socket
 import subprocess
 import sys
@@ -37,10 +36,13 @@ import threading
 import time
 
 # HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); the align stage runs its launches on
-# two streams next to a copy stream and two hand-over streams, and with RCCL's own streams in the process (N > 1) some would share
-# a queue and serialise.  Read by the HIP runtime when it starts, so it is set before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+# two streams next to a copy stream and two hand-over streams (the paired path on ~11), and with RCCL's own streams in the process
+# (N > 1) some would share a queue and serialise (profiles/r03o: 4 queues 258 ms, 8: 214, 16: 194 per 1 M pairs).  Read by the HIP
+# runtime when it starts, so it is set before torch is imported; the library sets the same default (moni_hip_default_queues).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# The image's environment exports this (dmabuf IPC: the host driver supports no other, and RCCL between processes fails with
+# hipIpcGetMemHandle: invalid argument without it); kept for a launcher that starts the ranks from a clean environment.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 
@@ -86,6 +88,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
+    ap.add_argument("--no-scaling-base", action="store_true", help="N = 1: skip the extra leg that runs configs[3]'s read set (--scaling-base-reads reads, resident chunks of --reads) on the one GPU")
+    ap.add_argument("--scaling-base-reads", type=int, default=CONFIGS3_READS)
     ap.add_argument("--paired", action="store_true", help="the paired-end path instead (moni_pe_learn_batch / moni_pe_align_batch over --pairs FR pairs of 2 x --read-len, orphan recovery on): pairs/s")
     ap.add_argument("--pairs", type=int, default=1000000, help="--paired: read pairs (per GPU; sharded by contiguous ranges like the reads when --total-reads is given)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: launch, rendezvous (gloo), sharding and the SAM gather with placeholder records")
@@ -196,60 +200,97 @@ def run_rank(args) -> int:
     gather_on = (world > 1) if args.gather_sam is None else (args.gather_sam and world > 1)
 
     # ---- inputs (seeded, synthetic: SURVEY.md §8(d)) -------------------------------------------------
+    # Wall time of every phase in front of the timed region goes to stderr (rank 0) and into the line (`setup_s`): at N ranks the order is
+    # pangenome (every rank, side by side) -> rank 0 builds the flat index on its GPU and writes the cache file while the others generate their reads
+    # and drop the pangenome -> barrier -> every rank maps the file (one copy in the page cache for all) and builds its device image, side by side.
+    t_start = time.time()
+    phases = []
+
+    def phase(name, t_from):
+        phases.append((name, time.time() - t_from))
+        log("rank %d: %s %.1fs (at %.1fs)" % (rank, name, phases[-1][1], time.time() - t_start))
+
     t0 = time.time()
     pg = synth.make_pangenome(args.base_len, args.haps, seed=19, var_seed=12, repeat_frac=args.repeats)
-    log("rank %d: pangenome %d sequences, %.1f Mchar in %.1fs" % (rank, len(pg.seqs), sum(len(s) for s in pg.seqs) / 1e6, time.time() - t0))
+    n_seqs, n_chars = len(pg.seqs), sum(len(x) for x in pg.seqs)
+    phase("pangenome (%d sequences, %.1f Mchar)" % (n_seqs, n_chars / 1e6), t0)
     os.makedirs(args.cache, exist_ok=True)
     key = "idx_%d_%d_%s_%g.mfi" % (args.base_len, args.haps, "fasta" if args.fasta_index else "lifted", args.repeats)
     path = os.path.join(args.cache, key)
+    L = args.read_len
+
+    def my_reads():          # this rank's reads (host arrays); the pangenome is not needed after them
+        if args.paired:
+            return None
+        if sharded:            # strong scaling: one read set, this rank's contiguous range of it, in resident chunks
+            lo_, hi_ = mdist.shard_range(total, rank, world)
+            rd = synth.make_reads_range(pg, lo_, hi_, L, seed=1500, threads=max(1, host_cpus() // max(1, world)))
+            nm_, no_ = synth.make_names_range(lo_, hi_)
+            return lo_, hi_, rd, nm_, no_
+        rd = synth.make_reads(pg, args.reads, L, seed=150 + rank)
+        nm_, no_ = synth.make_names(args.reads)
+        return 0, args.reads, rd, nm_, no_
+
     fi = None
+    mine = None
     if rank == 0:
         if os.path.exists(path):
-            log("loading cached flat index", path)
-            fi = index_build.FlatIndex.load(path)
+            t0 = time.time()
+            fi = index_build.FlatIndex.load(path, mmap=True)
+            phase("cached flat index mapped (%s)" % path, t0)
         else:
             t0 = time.time()
             fi = index_build.build_from_pangenome(pg, device="cuda:%d" % local_rank, log=log, lifted=not args.fasta_index)
             torch.cuda.empty_cache()
-            log("flat index built on GPU in %.1fs: n=%d r=%d n/r=%.2f" % (time.time() - t0, fi.n, fi.r, fi.n / fi.r))
+            phase("flat index built on the GPU (n=%d r=%d n/r=%.2f)" % (fi.n, fi.r, fi.n / fi.r), t0)
             if world > 1 or os.environ.get("MONI_BENCH_SAVE_INDEX"):
+                t0 = time.time()
                 try:
                     fi.save(path + ".tmp")
                     os.replace(path + ".tmp", path)
+                    phase("index cache written", t0)
                 except OSError as e:          # (no room for the 10 GB cache file: the other ranks then build the index on their own GPUs)
                     log("could not write the index cache %s: %s" % (path, e))
                     try:
                         os.remove(path + ".tmp")
                     except OSError:
                         pass
+    elif not args.paired:
+        t0 = time.time()
+        mine = my_reads()          # while rank 0 builds the index
+        pg = None                  # (0.8 GB; not needed again unless the cache file turns out to be unusable)
+        phase("reads generated, pangenome dropped", t0)
     if world > 1:
+        t0 = time.time()
         dist.barrier()
-        if rank != 0:
-            try:
-                fi = index_build.FlatIndex.load(path)
-            except (OSError, ValueError) as e:
-                log("rank %d: no usable index cache (%s): building on cuda:%d" % (rank, e, local_rank))
-                fi = index_build.build_from_pangenome(pg, device="cuda:%d" % local_rank, log=log, lifted=not args.fasta_index)
-                torch.cuda.empty_cache()
+        phase("barrier behind rank 0's index", t0)
     t0 = time.time()
-    idx = capi.Index(fi=fi, device=local_rank)
-    log("rank %d: device image %.2f GB in %.1fs" % (rank, idx.device_bytes / 1e9, time.time() - t0))
+    if rank == 0:
+        idx = capi.Index(fi=fi, device=local_rank)
+    else:
+        try:
+            idx = capi.Index(path=path, device=local_rank)          # the file mapped by the library: no private host copy
+        except Exception as e:
+            log("rank %d: no usable index cache (%s): building on cuda:%d" % (rank, e, local_rank))
+            if pg is None:
+                pg = synth.make_pangenome(args.base_len, args.haps, seed=19, var_seed=12, repeat_frac=args.repeats)
+            fi = index_build.build_from_pangenome(pg, device="cuda:%d" % local_rank, log=log, lifted=not args.fasta_index)
+            torch.cuda.empty_cache()
+            idx = capi.Index(fi=fi, device=local_rank)
+    fi_n, fi_r = idx.n, idx.r
+    phase("device image (%.2f GB)" % (idx.device_bytes / 1e9), t0)
     ctx = capi.Ctx(idx)
-    L = args.read_len
     if args.paired:
         pass
-    elif sharded:            # strong scaling: one read set, this rank's contiguous range of it, in resident chunks
-        lo, hi = mdist.shard_range(total, rank, world)
-        reads = synth.make_reads_range(pg, lo, hi, L, seed=1500)
-        names, noff = synth.make_names_range(lo, hi)
-        scaling = "strong"
     else:
-        lo, hi = 0, args.reads
-        reads = synth.make_reads(pg, args.reads, L, seed=150 + rank)
-        names, noff = synth.make_names(args.reads)
-        scaling = "weak"
+        if mine is None:
+            t0 = time.time()
+            mine = my_reads()
+            phase("reads generated", t0)
+        lo, hi, reads, names, noff = mine
+        scaling = "strong" if sharded else "weak"
     if args.paired:
-        return run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx)
+        return run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx, phases, t_start)
     n_mine = reads.shape[0]
     cb = chunk_bounds(n_mine, args.reads)
     n_chunks = len(cb) - 1
@@ -263,8 +304,11 @@ def run_rank(args) -> int:
             ctx.swap(k)                                   # parked in HBM; swapped in for its turn
         chunk.append((names[int(noff[a]):int(noff[b])], (noff[a:b + 1] - noff[a]).astype(np.uint64), quals[a * L:b * L], b - a))
     offs = np.arange(0, (n_mine + 1) * L, L, dtype=np.uint64)
+    pg_keep = pg if (rank == 0 and world == 1 and not sharded and not args.no_scaling_base) else None      # (the scaling-base leg generates its read set from it)
     del pg
-    log("rank %d: reads [%d, %d) resident in %d chunk(s)" % (rank, lo, hi, n_chunks))
+    phases.append(("reads [%d, %d) resident in %d chunk(s)" % (lo, hi, n_chunks), 0.0))
+    log("rank %d: reads [%d, %d) resident in %d chunk(s); setup took %.1fs" % (rank, lo, hi, n_chunks, time.time() - t_start))
+    setup_s = time.time() - t_start
 
     def sync_all():
         if dist is not None:
@@ -299,7 +343,7 @@ def run_rank(args) -> int:
     kern = np.zeros(7)
     stage = {"seed": 0.0, "align_kernels_span": 0.0, "align_stage": 0.0, "host_stage_busy": 0.0}
     grp = {"chain_plan": 0.0, "dp_lane": 0.0, "select_traceback": 0.0, "finish": 0.0}
-    tot = {"aligned": 0, "dp_tasks": 0, "dp_cells": 0, "kernel_fallback": 0, "handed_back": 0, "dp_ref_bytes": 0}
+    tot = {"aligned": 0, "dp_tasks": 0, "dp_cells": 0, "kernel_fallback": 0, "handed_back": 0, "dp_ref_bytes": 0, "dp_cells_cut": 0, "dp_slots": 0}
     cnt = np.zeros(4, dtype=np.uint64)
     n_calls = [0]
 
@@ -413,6 +457,48 @@ def run_rank(args) -> int:
                                       "note": "two contexts on the GPU, one caller thread each (the arrangement of moni-hip-align's workers): uploads and seeding of one overlap the align kernels of the other"},
                      "note": "moni_align_stream: reads, names, qualities in pageable host memory -> SAM text in the context's pinned buffer; upload inside the timed call (align_full_ksw2.cpp:333,399-402 wraps file -> file; FASTQ parsing and file writes are the front end's, profiles/frontend.py)"}
 
+    # ---- N = 1: configs[3]'s read set on the one GPU (the base of the 1 -> N curve in the shape the N > 1 runs have) ------------------------
+    scaling_base = None
+    if pg_keep is not None:
+        tb0 = time.time()
+        sb_total = max(args.reads, args.scaling_base_reads)
+        sb_reads = synth.make_reads_range(pg_keep, 0, sb_total, L, seed=1500, threads=host_cpus())
+        sb_names, sb_noff = synth.make_names_range(0, sb_total)
+        t_gen = time.time() - tb0
+        del pg_keep
+        ctx_s = capi.Ctx(idx)
+        sb_cb = chunk_bounds(sb_total, args.reads)
+        sb_q = np.full(args.reads * L + L, ord("I"), dtype=np.uint8)
+        for k in range(len(sb_cb) - 1):
+            a, b = sb_cb[k], sb_cb[k + 1]
+            ctx_s.upload(sb_reads[a:b].reshape(-1), np.arange(0, (b - a + 1) * L, L, dtype=np.uint64))
+            ctx_s.swap(k)
+
+        def sb_pass():
+            al = 0
+            for k in range(len(sb_cb) - 1):
+                a, b = sb_cb[k], sb_cb[k + 1]
+                ctx_s.swap(k)
+                _, st_k = ctx_s.align_run(sb_names[int(sb_noff[a]):int(sb_noff[b])], (sb_noff[a:b + 1] - sb_noff[a]).astype(np.uint64), sb_q[:(b - a) * L], host_threads=threads, want_text=False)
+                ctx_s.swap(k)
+                al += st_k["aligned"]
+            return al
+        sb_pass()
+        torch.cuda.synchronize()
+        sb_steps = 2
+        t1 = time.perf_counter()
+        for _ in range(sb_steps):
+            sb_al = sb_pass()
+        torch.cuda.synchronize()
+        sb_s = (time.perf_counter() - t1) / sb_steps
+        ctx_s.close()
+        del sb_reads
+        scaling_base = {"workload": "BASELINE.json configs[3]'s read set on this one GPU: %d reads in %d resident chunks of <= %d (what `--total-reads %d` runs at N = 1; the N > 1 default shards the same set)"
+                                    % (sb_total, len(sb_cb) - 1, args.reads, sb_total),
+                        "value": sb_al / sb_s, "unit": "aligned reads/s", "reads_per_s": sb_total / sb_s, "ms_per_step": sb_s * 1e3, "steps": sb_steps, "warmup": 1, "scaling": "strong",
+                        "reads_generated_s": t_gen, "leg_s": time.time() - tb0}
+        log("scaling base: %d reads in %d chunks, %.1f ms per pass" % (sb_total, len(sb_cb) - 1, sb_s * 1e3))
+
     if rank == 0:
         S, J, P, C = (int(x) for x in cnt)          # per step, this rank
         R = int(tot["dp_ref_bytes"])
@@ -424,17 +510,24 @@ def run_rank(args) -> int:
         achieved = ms_bytes / ms_s / 1e9 if ms_s > 0 else 0.0
         layout_bytes = 73 * S1      # what the move-structure layout itself needs per LF step: one 64-byte fast row, one 8-byte pointer store, 1/8 of a packed pattern word
         path_bytes = 128 * S + 64 * J + 128 * P + C + R
-        value = n_all * steps / elapsed
+        aligned_all = sum(x[0] for x in sizes)          # per step, all ranks
+        value = aligned_all * steps / elapsed            # the metric counts ALIGNED reads; every read of the set goes through the path (reads_per_s)
+        # the align stage's own bound: VALU issue.  A DP cell of two problems side by side costs ~13 packed 16-bit instructions of one wavefront (dp_lane_kernel), a wavefront
+        # instruction occupies its SIMD for 4 cycles: peak = SIMDs x clock / 4 x 128 cells / 13.  The instruction count comes from the last committed counter pass (counters
+        # cannot be read inside this run) and is labelled as static.
+        simds, clk = 1024, 2.4e9
+        dp_peak_tcups = simds * clk / 4 * 128 / 13 / 1e12
+        dp_s = grp["dp_lane"]
         out = {
             "metric": "aligned reads/s (whole node), %d bp SE, mouse-chr19-scale x%d-haplotype index" % (L, args.haps),
-            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "reads/s", "reads_per_s": n_all * steps / elapsed, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u64/int32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: mouse-chr19-scale index (%d bp base%s + %d haplotypes, %s, n=%d, r=%d), "
                                    "%s x %d bp reads resident in HBM -> MEM seeding + staged align kernels (chaining, lane-per-problem ksw2 DP, traceback, "
                                    "lift-over, SAM lines, lines gathered in read order) -> SAM text in pinned host memory, one transfer per sub-batch (%d host threads per GPU stand by for reads handed back)"
                                    % (3 if sharded else 2, args.base_len, " with %g interspersed repeats" % args.repeats if args.repeats else "", args.haps,
-                                      "FASTA-built: null lifts" if args.fasta_index else "ref+VCF -H12 style: haplotypes lift onto the reference contig", fi.n, fi.r,
+                                      "FASTA-built: null lifts" if args.fasta_index else "ref+VCF -H12 style: haplotypes lift onto the reference contig", fi_n, fi_r,
                                       ("one set of %d sharded over %d rank(s) by contiguous ranges, %d resident chunk(s) of <= %d per rank" % (total, world, n_chunks, args.reads)) if sharded else ("%d per GPU" % args.reads), L, threads),
                        "reads_per_gpu": n_mine, "total_reads": n_all, "chunks_per_rank": n_chunks, "read_len": L, "parallelism": "reads sharded x%d, index replicated" % world,
                        "launched_by": "bench.py" if os.environ.get("MONI_BENCH_SELF_LAUNCHED") else ("torch.distributed.run / external launcher" if world > 1 else "single process")},
@@ -460,11 +553,22 @@ def run_rank(args) -> int:
                       "note": "HIP-event times of the staged align kernels by group, summed over the sub-batches (two launch streams overlap, so the sum exceeds the span)",
                       "dp_problems": tot["dp_tasks"], "dp_cells": tot["dp_cells"],
                       "dp_gcups_in_kernel": tot["dp_cells"] / grp["dp_lane"] / 1e9 if grp["dp_lane"] > 0 else None,
+                      "roofline": {"bound": "valu", "kernel": "dp_lane_kernel (all instances)", "unit": "TCUPS",
+                                   "cells": tot["dp_cells"], "cells_after_cut": tot["dp_cells_cut"], "cell_slots_run": tot["dp_slots"],
+                                   "padding": {"useful_over_slots": tot["dp_cells_cut"] / tot["dp_slots"] if tot["dp_slots"] else None,
+                                               "note": "cells: qlen x tlen of every ksw_extz2_sse call as the reference poses it; cells_after_cut: after the target rows of an extension that cannot hold its result are dropped "
+                                                       "(af_build_cand); cell_slots_run: 128 problems x the chunk's longest query x the target rows of its passes - what the kernels actually stepped through"},
+                                   "achieved": tot["dp_cells"] / dp_s / 1e12 if dp_s > 0 else None, "peak": dp_peak_tcups,
+                                   "frac": tot["dp_cells"] / dp_s / 1e12 / dp_peak_tcups if dp_s > 0 else None,
+                                   "peak_model": "%d SIMDs x %.1f GHz / 4 cycles per wavefront instruction x 128 cells per instruction (64 lanes x two 16-bit halves) / 13 instructions per cell" % (simds, clk / 1e9),
+                                   "achieved_note": "reference cells over the summed HIP-event time of the DP kernels (launches of two streams overlap: a lower bound of the in-kernel rate)",
+                                   "valu_static_from": "profiles/r04*/pmc_sq*.txt (rocprofv3 --pmc SQ_INSTS_VALU of this workload; see DESIGN.md 5.2 for the per-cell instruction count)"},
                       "reads_taken_by_general_kernel": tot["kernel_fallback"], "reads_handed_to_host_pipeline": tot["handed_back"],
                       "handed_over_because": {k: v // steps for k, v in why.items()}},
             "stages_s_per_step": stage,
             "aligned_per_step": tot["aligned"], "sam_bytes_per_step": sam_len,
-            "aligned_all_ranks": sum(x[0] for x in sizes),
+            "aligned_all_ranks": aligned_all,
+            "setup_s": {"total": setup_s, "phases": [[n_, round(d_, 2)] for n_, d_ in phases], "note": "rank 0's wall time in front of the timed region"},
             "kernels_ms": {"ms_lf": kern_launch[0], "mem_count": kern_launch[1], "mem_emit": kern_launch[2], "occ_count": kern_launch[3], "occ_fill": kern_launch[4],
                            "seeding_whole": kern_launch[6], "note": "per launch (one launch per resident chunk)"},
             "seeding": {"workload": "BASELINE.json configs[1]: MEM seeding stage alone on rank 0's first resident chunk (%d reads)" % n_first,
@@ -476,10 +580,12 @@ def run_rank(args) -> int:
             out["value_with_gather"] = n_all / (step_s + gather["seconds"])
         if from_host:
             out["from_host"] = from_host
+        if scaling_base:
+            out["scaling_base"] = scaling_base
         out["host"] = {"cpus_usable": host_cpus(), "cpu_count": os.cpu_count(), "host_threads_per_gpu": threads}
         if world == 1 and not args.no_cpu:
             from oracle import orc as _orc          # the CPU baseline / at-scale checker: the only use of oracle/ in this file
-            oidx = _orc.OracleIndex(fi=fi)
+            oidx = _orc.OracleIndex(fi=fi)          # (rank 0 holds the flat index: built here or mapped from the cache file)
             cpu_threads = host_cpus()
             nm, no, ql, nb = chunk[0]
             rd, ob = reads[:nb], offs[:nb + 1]
@@ -528,7 +634,7 @@ def run_rank(args) -> int:
 
 
 # ---- the paired-end path -----------------------------------------------------------------------------------
-def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx) -> int:
+def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx, phases, t_start) -> int:
     """One "step" = moni_pe_align_batch over this rank's pairs (host memory -> two SAM records per pair in host memory; the paired entry points
     have no resident form), fragment model learnt once on rank 0's first batches of 512 pairs (the reference's single learner,
     align_reads_dispatcher.hpp:356-389) and broadcast."""
@@ -613,7 +719,7 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx) -> 
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64/int32", "data": "synthetic",
                "config": {"workload": "SURVEY.md 8(f)-2: paired-end path on the BASELINE.json configs[2] index (%d bp base + %d haplotypes, n=%d, r=%d): %d FR pairs of 2 x %d bp per GPU "
                                       "(insert 350 +- 30, 0.5 %% substitutions) resident in HBM -> seeding kernels over the 2 N mates + staged paired kernels (wave per pair plan, lane per DP problem, select, finish, both SAM lines written and "
-                                      "ordered on the GPU; pe_align_kernel for the pairs they hand over: orphan recovery) -> two SAM records per pair in pinned host memory" % (args.base_len, args.haps, fi.n, fi.r, args.pairs, L),
+                                      "ordered on the GPU; pe_align_kernel for the pairs they hand over: orphan recovery) -> two SAM records per pair in pinned host memory" % (args.base_len, args.haps, idx.n, idx.r, args.pairs, L),
                           "pairs_per_gpu": hi - lo, "read_len": L, "parallelism": "pairs sharded x%d, index replicated, fragment model learnt on rank 0 and broadcast" % world},
                "model": {"count": int(model.count), "mean": model.mean, "std_dev": model.std_dev, "complete": bool(model.complete)},
                "aligned_pairs_all_ranks": sum(x[0] for x in sizes), "stages_s_per_step": {"seed": st["t_seed"], "kernel_and_copies": st["t_dp"], "host_finish": st["t_host"]},
@@ -646,7 +752,7 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx) -> 
             rate1 = n0 / (time.perf_counter() - t1)
             nseq0 = int(offs[2 * n0] - offs[0])
             got, _ = ctx.pe_align(seq[:nseq0], offs[:2 * n0 + 1], nm[:int(no[2 * n0])], no[:2 * n0 + 1], None if ql is None else ql[:nseq0], model, host_threads=threads)
-            per = int(max(2000, min((hi - lo) // cpu_threads, rate1 * args.cpu_seconds)))
+            per = int(max(1, min((hi - lo) // cpu_threads, max(2000, rate1 * args.cpu_seconds))))          # never past this rank's pairs (few pairs on many cores: shorter slices)
             res = [None] * cpu_threads
             th = [threading.Thread(target=lambda k=k: res.__setitem__(k, cpu_pe(k * per, (k + 1) * per))) for k in range(cpu_threads)]
             t1 = time.perf_counter()

@@ -10,7 +10,14 @@
  * on failure and never calls exit(); the caller owns every input buffer; the library owns all
  * device memory; one moni_ctx_t per host thread / HIP stream (not thread-safe per ctx, thread-safe
  * across ctxs — mirrors include/aligner/align_reads_dispatcher.hpp:226-235: shared const index,
- * per-thread everything else).  There is no CPU fallback anywhere behind this ABI.
+ * per-thread everything else).
+ *
+ * What runs where: every kernel-side stage of the path runs on the GPU only - without a HIP device moni_index_create returns
+ * MONI_ENODEV, and nothing under oracle/ is linked or called.  The library does contain host code that is part of the product,
+ * not a fallback for a missing GPU: (1) the "host pipeline" (align_host.hpp, pe_host.hpp, pe_big.cpp) redoes, with DP batches on
+ * the GPU, the few reads or pairs whose seeds / anchors / chains / CIGAR exceed even the general kernel's capacities (0 reads per
+ * 1 M in the benchmark; the statistics report them as handed_back), and (2) moni_align_csv_batch (`-c`) sends EVERY read through
+ * that host pipeline by design, because the per-read MEM statistics are taken inside its chaining loop.
  */
 #ifndef MONI_HIP_H
 #define MONI_HIP_H
@@ -201,6 +208,9 @@ typedef struct {
                                                              score, 4 anchors of the chains to score, 5 a DP problem beyond the register tile, 6 (unused), 7 wildcard base or
                                                              direction-bit budget, 8 selection loop depends on a score, 9 extension short of the query end, 10 a queue or pool
                                                              full, 11 CIGAR / MD / line beyond the staging (host pipeline) */
+    uint64_t dp_cells_cut;                                /* staged DP kernels: cells of the problems after an extension's target rows that cannot hold its result are
+                                                             cut (dp_cells counts the problems as the reference poses them: qlen x tlen of every ksw_extz2_sse call) */
+    uint64_t dp_slots;                                    /* ... and the cell slots those kernels ran (128 problems x the chunk's longest query x the target rows of its passes) */
 } moni_align_stats_t;
 
 void moni_align_params_default(moni_align_params_t *p);

@@ -66,7 +66,7 @@ class AlignStatsC(C.Structure):
                 ("t_dp_kernel", C.c_double), ("handed_back", C.c_uint64), ("dp_reused", C.c_uint64), ("dp_cells_reused", C.c_uint64),
                 ("kernel_fallback", C.c_uint64), ("dp_ref_bytes", C.c_uint64),
                 ("t_k_chain", C.c_double), ("t_k_dp", C.c_double), ("t_k_select", C.c_double), ("t_k_finish", C.c_double),
-                ("handover_why", C.c_uint64 * 12)]
+                ("handover_why", C.c_uint64 * 12), ("dp_cells_cut", C.c_uint64), ("dp_slots", C.c_uint64)]
 
 
 class PeParamsC(C.Structure):

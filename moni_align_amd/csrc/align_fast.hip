@@ -44,9 +44,10 @@
 #define AF_TS 32                 // target rows (one block) and longest query of the small tile (gap fills)
 #define AF_GBLK 104               // register block of the global problems (overlapping anchors)
 #define AF_GPASS 3                // their target blocks: up to AF_GPASS * AF_GBLK target rows
-#define AF_NBIN 33               // 16 query-length bins of the large tile, the small tile, 16 query-length bins of global problems
+#define AF_NBIN 35               // 16 query-length bins of the large tile, 3 of the small tile, 16 of the global problems
 #define AF_BIN_SMALL 16u
-#define AF_BIN_GLOBAL 17u
+#define AF_NSMALL 3u
+#define AF_BIN_GLOBAL 19u
 #define AF_TB_CIG 24             // CIGAR operations kept per traced problem
 #define AF_FIN_CIG 96            // ... of a stitched alignment
 #define AF_FIN_LCIG 160          // ... after lifting
@@ -143,8 +144,11 @@ struct af_args_t {
 #define AF_PROF(G, slot, t0, t1) do {} while (0)
 #endif
 enum { AFC_TASKS = 0, AFC_FALLBACK = 1, AFC_TRACED = 2, AFC_READ_CUR = 3, AFC_DIRS_OVF = 4, AFC_CELLS = 6 /* 64 bit */, AFC_DIROFF = 8 /* 64 bit */,
-       AFC_NCHUNKS = 10 /* + group */, AFC_CURSOR = 13 /* + group */, AFC_BINS = 16 /* + bin */, AFC_BIG = 49, AFC_BIG_CUR = 50, AFC_WHY = 52 /* + reason */, AFC_RBYTES = 64 /* 64 bit: text bytes of the DP targets, the R of SURVEY.md 8(d) */,
-       AFC_QBYTES = 66 /* 64 bit: read bytes of the DP queries */, AFC_NT = 68 /* DP problems queued by bin_tasks_kernel */, AFC_HUGE = 70, AFC_HUGE_CUR = 71, AFC_L0 = 72 /* reads of the small instance's list */, AF_NCTR = 96 };
+       AFC_NCHUNKS = 10 /* + group */, AFC_CURSOR = 13 /* + group */, AFC_BINS = 16 /* + bin */, AFC_BIG = 56, AFC_BIG_CUR = 57, AFC_WHY = 58 /* + reason */, AFC_RBYTES = 70 /* 64 bit: text bytes of the DP targets, the R of SURVEY.md 8(d) */,
+       AFC_QBYTES = 72 /* 64 bit: read bytes of the DP queries */, AFC_NT = 74 /* DP problems queued by bin_tasks_kernel */, AFC_HUGE = 75, AFC_HUGE_CUR = 76, AFC_L0 = 77 /* reads of the small instance's list */,
+       AFC_SLOTS = 78 /* 64 bit: cell slots the DP kernels computed (query positions of the chunk's longest problem x target rows of its passes x 128 problems) */,
+       AFC_CUTCELLS = 80 /* 64 bit: cells of the problems after an extension's target rows are cut (af_build_cand); AFC_CELLS counts them as the reference poses them */, AF_NCTR = 96 };
+static_assert(AFC_BINS + AF_NBIN <= AFC_BIG && AFC_WHY + 12 <= AFC_RBYTES, "counter layout");
 enum { AF_GRP_LARGE = 0, AF_GRP_SMALL = 1, AF_GRP_GLOBAL = 2 };
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -198,7 +202,26 @@ enum { AF_WHY_LONG = 0, AF_WHY_ANCHORS, AF_WHY_CHAINS, AF_WHY_CANDS, AF_WHY_CHAI
 #define AF_X(a) ((a) & MONI_POS_MASK_)
 #define MONI_POS_MASK_ ((1ull << 40) - 1)
 
-__device__ __forceinline__ uint32_t af_bin_of(int qlen, int tlen) { return (qlen <= AF_TS && tlen <= AF_TS) ? AF_BIN_SMALL : (uint32_t)((qlen - 1) >> 4); }
+// Bins of the DP problems.  A chunk of 128 problems runs as many query positions as its longest problem has, so bins are narrow where problems are
+// many: the large tile's upper bounds are 8, 13 (an extension of up to 13 bases needs 50 target rows: one pass of the 52-row block, af_build_cand),
+// 16, 24, 32, then every 16 up to 160, then every 32 up to AF_QCAP; the small tile's 8, 16, 32.
+__device__ __forceinline__ uint32_t af_large_bin(int q) {
+    if (q <= 16) return q <= 8 ? 0u : q <= 13 ? 1u : 2u;
+    if (q <= 32) return 3u + (uint32_t)((q - 17) >> 3);
+    if (q <= 160) return 5u + (uint32_t)((q - 33) >> 4);
+    return 13u + (uint32_t)((q - 161) >> 5);
+}
+__device__ __forceinline__ uint32_t af_large_qhi(uint32_t b) { return b < 3 ? (b == 0 ? 8u : b == 1 ? 13u : 16u) : b < 5 ? 24u + 8u * (b - 3) : b < 13 ? 48u + 16u * (b - 5) : 192u + 32u * (b - 13); }
+static_assert(AF_QCAP == 256, "af_large_bin covers query lengths up to 256");
+__device__ __forceinline__ uint32_t af_bin_of(int qlen, int tlen) {
+    return (qlen <= AF_TS && tlen <= AF_TS) ? AF_BIN_SMALL + (qlen <= 8 ? 0u : qlen <= 16 ? 1u : 2u) : af_large_bin(qlen);
+}
+__device__ __forceinline__ uint32_t af_grp_of_bin(uint32_t bin) { return bin < AF_BIN_SMALL ? AF_GRP_LARGE : bin < AF_BIN_GLOBAL ? AF_GRP_SMALL : AF_GRP_GLOBAL; }
+__device__ __forceinline__ uint32_t af_grp_b0(uint32_t grp) { return grp == AF_GRP_LARGE ? 0u : grp == AF_GRP_SMALL ? AF_BIN_SMALL : AF_BIN_GLOBAL; }
+__device__ __forceinline__ uint32_t af_grp_b1(uint32_t grp) { return grp == AF_GRP_LARGE ? AF_BIN_SMALL : grp == AF_GRP_SMALL ? AF_BIN_GLOBAL : (uint32_t)AF_NBIN; }
+__device__ __forceinline__ uint32_t af_bin_qhi(uint32_t bin) {
+    return bin < AF_BIN_SMALL ? af_large_qhi(bin) : bin < AF_BIN_GLOBAL ? (8u << (bin - AF_BIN_SMALL)) : (bin - AF_BIN_GLOBAL + 1u) * 16u;
+}
 
 // The lanes that work on one read: the whole wavefront (GW = 64) or a GROUP of GW consecutive lanes (GW = 16: four reads per wavefront, each with
 // its own LDS state).  chain_plan_kernel issues mostly one-lane instructions - the selection loop, the backtracking, a lane per run of anchors - and
@@ -548,6 +571,17 @@ __device__ __forceinline__ uint32_t af_build_cand(const af_args_t& G, WT& L, af_
     bool bad = false;
     auto add = [&](uint64_t q_off, uint64_t qlen, int qmode, uint64_t t_off, uint64_t tlen, int tmode, int flag) {
         if (qlen == 0 || tlen == 0 || qlen > AF_QCAP || tlen > AF_TB) { bad = true; return; }
+        if ((flag & DP_EZ_EXTZ_ONLY) && G.A.D.e > 0) {
+            // An extension is asked for mqe = max_i H(i, qlen - 1), the first row that holds it and the traceback from there: rows that
+            // cannot hold it need not be computed.  A path to (i, qlen - 1) with d = i + 1 - qlen > 0 takes at most qlen diagonal steps and deletes at
+            // least d target bases: H <= qlen sc_mch - (qo + d e); the diagonal itself gives mqe >= H(qlen - 1, qlen - 1) >= qlen min(sc_mis, sc_N).  Rows
+            // with d e > qlen (sc_mch - min(sc_mis, sc_N)) - qo lie strictly below that, and no cell of the kept rows depends on them: the target is cut
+            // there (an extension of 10 bases against the reference's 100 target rows keeps 38).  The uncut length rides in the flag word for the counters.
+            const int32_t worst = G.A.D.sc_mis < G.A.D.sc_N ? G.A.D.sc_mis : G.A.D.sc_N;
+            const int64_t num = (int64_t)qlen * (G.A.D.sc_mch - worst) - G.A.D.qo;
+            const uint64_t keep = qlen + (num > 0 ? (uint64_t)(num / G.A.D.e) : 0ull);
+            if (keep < tlen) { flag |= (int)(tlen << 16); tlen = keep; }
+        }
         if (WRITE) {
             moni_dp_task_t t;
             t.q_off = q_off; t.t_off = t_off; t.qlen = (int32_t)qlen; t.tlen = (int32_t)tlen; t.flag = flag; t.reserved = DP_Q_READS | DP_T_TEXT | qmode | tmode;
@@ -965,7 +999,7 @@ __global__ void __launch_bounds__(64) af_chunk_kernel(const af_args_t G, const u
     uint64_t doff;
     memcpy(&doff, &G.ctr[AFC_DIROFF], 8);
     for (uint32_t grp = first_group; grp <= last_group; ++grp) {
-        const uint32_t b0 = grp == AF_GRP_LARGE ? 0u : grp == AF_GRP_SMALL ? AF_BIN_SMALL : AF_BIN_GLOBAL, b1 = grp == AF_GRP_LARGE ? 16u : grp == AF_GRP_SMALL ? 17u : 33u;
+        const uint32_t b0 = af_grp_b0(grp), b1 = af_grp_b1(grp);
         const uint32_t nb = b1 - b0;                     // <= 16
         const uint32_t tb = grp == AF_GRP_SMALL ? AF_TS : grp == AF_GRP_GLOBAL ? AF_GBLK : AF_BLK, np = grp == AF_GRP_GLOBAL ? AF_GPASS : grp == AF_GRP_LARGE ? AF_LPASS : 1;
         uint32_t cnt = 0, nch = 0, qhi = 0, bin = 0; uint64_t bytes = 0;
@@ -973,7 +1007,7 @@ __global__ void __launch_bounds__(64) af_chunk_kernel(const af_args_t G, const u
             bin = b1 - 1 - (uint32_t)lane;
             cnt = G.ctr[AFC_BINS + bin] < G.bin_cap ? G.ctr[AFC_BINS + bin] : G.bin_cap;      // (a bin beyond its queue: bin_tasks_kernel sent the reads to align_kernel)
             nch = (cnt + 127) >> 7;
-            qhi = grp == AF_GRP_SMALL ? AF_TS : ((bin - b0) + 1) * 16;
+            qhi = af_bin_qhi(bin);
             bytes = (uint64_t)np * qhi * tb * 64;          // of one chunk: half a byte per cell
         }
         uint32_t cb = nch; uint64_t db = (uint64_t)nch * bytes;          // inclusive prefix sums over the lanes
@@ -1205,18 +1239,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
                 }
             }
         }
-        unsigned long long cells = 0, rq = 0;
+        unsigned long long cells = 0, rq = 0, cut = 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) if (has[h]) {
             if (wild[h]) { R[h].mqe = AF_NEG_INF; R[h].mqe_t = -1; R[h].score = AF_NEG_INF; R[h].flags = 1; }
-            else { cells += (unsigned long long)task[h].qlen * (unsigned long long)task[h].tlen; rq += ((unsigned long long)task[h].tlen << 32) | (unsigned long long)task[h].qlen; }
+            else {
+                const unsigned long long t_ref = (task[h].flag >> 16) ? (unsigned long long)(task[h].flag >> 16) : (unsigned long long)task[h].tlen;      // (an extension's target before the cut)
+                cells += (unsigned long long)task[h].qlen * t_ref; rq += (t_ref << 32) | (unsigned long long)task[h].qlen;
+                cut += (unsigned long long)task[h].qlen * (unsigned long long)task[h].tlen;
+            }
             G.res[tid[h]] = R[h];
         }
-        for (int o = 32; o > 0; o >>= 1) { cells += __shfl_xor(cells, o); rq += __shfl_xor(rq, o); }
+        for (int o = 32; o > 0; o >>= 1) { cells += __shfl_xor(cells, o); rq += __shfl_xor(rq, o); cut += __shfl_xor(cut, o); }
         if (lane == 0) {
             atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_CELLS]), cells);
             atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_RBYTES]), rq >> 32);
             atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_QBYTES]), rq & 0xFFFFFFFFull);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_CUTCELLS]), cut);
+            int np_run = 0;
+            for (int pass = 0; pass < NP && pass * TB < maxt; ++pass) ++np_run;
+            atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_SLOTS]), 128ull * (unsigned long long)maxq * (unsigned long long)(np_run * TB));
         }
         __syncthreads();
     }
@@ -1225,8 +1267,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
 // where the direction byte of cell (i, j) of a task is: its chunk, its lane there, the target block of i
 struct af_dirs_t { const uint8_t* base; uint32_t tb, half; uint64_t pass_stride; };      // half: which 16-bit half of the words holds the task
 __device__ __forceinline__ af_dirs_t af_dir_of(const af_args_t& G, uint32_t bin, uint32_t pos_in_bin) {
-    const uint32_t grp = bin < AF_BIN_SMALL ? AF_GRP_LARGE : bin == AF_BIN_SMALL ? AF_GRP_SMALL : AF_GRP_GLOBAL;
-    const uint32_t b1 = grp == AF_GRP_LARGE ? 16u : grp == AF_GRP_SMALL ? 17u : 33u;
+    const uint32_t grp = af_grp_of_bin(bin);
+    const uint32_t b1 = af_grp_b1(grp);
     uint32_t ci = 0;
     for (uint32_t g = 0; g < grp; ++g) ci += G.ctr[AFC_NCHUNKS + g];
     for (uint32_t b2 = bin + 1; b2 < b1; ++b2) ci += ((G.ctr[AFC_BINS + b2] < G.bin_cap ? G.ctr[AFC_BINS + b2] : G.bin_cap) + 127) >> 7;        // chunks are laid out from the group's last bin down

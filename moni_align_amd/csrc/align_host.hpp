@@ -847,7 +847,7 @@ static void parallel_for(Pool& pool, size_t n, Fn fn) {
     pool.run([&](int t) { const size_t lo = n * t / T, hi = n * (t + 1) / T; if (lo < hi) fn(t, lo, hi); });
 }
 
-struct AlignStats { uint64_t reads = 0, aligned = 0, dp_tasks = 0, dp_cells = 0, dp_rounds = 0, handed_back = 0, dp_reused = 0, dp_cells_reused = 0, kernel_fallback = 0, dp_ref_bytes = 0; double t_k_chain = 0, t_k_dp = 0, t_k_select = 0, t_k_finish = 0; double t_seed = 0, t_chain = 0, t_dp = 0, t_host = 0; };
+struct AlignStats { uint64_t reads = 0, aligned = 0, dp_tasks = 0, dp_cells = 0, dp_rounds = 0, handed_back = 0, dp_reused = 0, dp_cells_reused = 0, kernel_fallback = 0, dp_ref_bytes = 0, dp_cells_cut = 0, dp_slots = 0; double t_k_chain = 0, t_k_dp = 0, t_k_select = 0, t_k_finish = 0; double t_seed = 0, t_chain = 0, t_dp = 0, t_host = 0; };
 
 static inline double now_s() {
     using namespace std::chrono;

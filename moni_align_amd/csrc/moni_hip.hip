@@ -3,7 +3,12 @@
 // There is no CPU implementation of any kernel in this library: without a HIP device every entry
 // point fails with MONI_ENODEV.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cstring>
+#include <atomic>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -356,64 +361,80 @@ int moni_index_create(const moni_flat_index_t* f, int device, moni_index_t** out
 
 int moni_index_load(const char* path, int device, moni_index_t** out) {
     if (!path || !out) return MONI_EINVAL;
-    FILE* fp = fopen(path, "rb");
-    if (!fp) return MONI_EIO;
-    char magic[8];
+    // The file is mapped read-only and the arrays are used where they lie (every section starts on an 8-byte boundary): no private copy of the ~10 GB,
+    // and processes that load the same file - one rank per GPU - share its pages.
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return MONI_EIO;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size < 56) { ::close(fd); return MONI_EIO; }
+    const uint64_t fsize = (uint64_t)sb.st_size;
+    void* map = mmap(nullptr, fsize, PROT_READ, MAP_SHARED, fd, 0);
+    ::close(fd);
+    if (map == MAP_FAILED) return MONI_EIO;
+    struct Unmap { void* p; uint64_t n; ~Unmap() { munmap(p, n); } } unmap{map, fsize};
+    const uint8_t* base = static_cast<const uint8_t*>(map);
+    if (memcmp(base, "MONIFLT2", 8) != 0) return MONI_EIO;
     uint64_t hdr[6];
-    if (fread(magic, 1, 8, fp) != 8 || memcmp(magic, "MONIFLT2", 8) != 0 || fread(hdr, 8, 6, fp) != 6) { fclose(fp); return MONI_EIO; }
+    memcpy(hdr, base + 8, 48);
     const uint64_t n = hdr[0], r = hdr[1], w = hdr[2], nseq = hdr[3], nblob = hdr[4];
     const bool has_lifts = hdr[5] != 0;
-    // the header is not trusted: every count is checked against the file size before anything is allocated
-    uint64_t fsize = 0;
-    { const long at = ftell(fp); if (at < 0 || fseek(fp, 0, SEEK_END) != 0) { fclose(fp); return MONI_EIO; } fsize = (uint64_t)ftell(fp); if (fseek(fp, at, SEEK_SET) != 0) { fclose(fp); return MONI_EIO; } }
+    // the header is not trusted: every count is checked against the file size before anything is used
     auto pad8 = [](uint64_t b) { return (b + 7) & ~7ull; };
     if (n < 2 || r < 1 || r > n || nseq < 1 || nseq > n || n > fsize || nblob > fsize ||
-        56 + 256 * 8 + pad8(r) + (r + 1) * 8 + 4 * r * 8 + pad8(n - 1) + (nseq + 1) * 8 + pad8(nblob) > fsize) { fclose(fp); return MONI_EIO; }
+        56 + 256 * 8 + pad8(r) + (r + 1) * 8 + 4 * r * 8 + pad8(n - 1) + (nseq + 1) * 8 + pad8(nblob) > fsize) return MONI_EIO;
     try {
-        std::vector<uint64_t> F(256), starts(r + 1), ssa(r), esa(r), thr(r), slcp(r), seq_starts(nseq + 1);
-        std::vector<uint8_t> heads(r), text(n - 1);
-        auto get = [&](void* dst, size_t bytes) {
-            if (bytes && fread(dst, 1, bytes, fp) != bytes) return false;
-            size_t pad = (8 - bytes % 8) % 8;
-            char t8[8];
-            if (pad && fread(t8, 1, pad, fp) != pad) return false;
-            return true;
+        uint64_t at = 56;
+        bool ok = true;
+        auto take = [&](uint64_t bytes) -> const uint8_t* {
+            if (!ok || bytes > fsize || at + pad8(bytes) > fsize + 7 || at + bytes > fsize) { ok = false; return base; }
+            const uint8_t* p = base + at;
+            at += pad8(bytes);
+            return p;
         };
-        bool ok = get(F.data(), 256 * 8) && get(heads.data(), r) && get(starts.data(), (r + 1) * 8) && get(ssa.data(), r * 8) &&
-                  get(esa.data(), r * 8) && get(thr.data(), r * 8) && get(slcp.data(), r * 8) && get(text.data(), n - 1) &&
-                  get(seq_starts.data(), (nseq + 1) * 8);
-        std::vector<char> blob(nblob + 8), names_flat;
-        ok = ok && get(blob.data(), nblob);
+        const uint64_t* F = reinterpret_cast<const uint64_t*>(take(256 * 8));
+        const uint8_t* heads = take(r);
+        const uint64_t* starts = reinterpret_cast<const uint64_t*>(take((r + 1) * 8));
+        const uint64_t* ssa = reinterpret_cast<const uint64_t*>(take(r * 8));
+        const uint64_t* esa = reinterpret_cast<const uint64_t*>(take(r * 8));
+        const uint64_t* thr = reinterpret_cast<const uint64_t*>(take(r * 8));
+        const uint64_t* slcp = reinterpret_cast<const uint64_t*>(take(r * 8));
+        const uint8_t* text = take(n - 1);
+        const uint64_t* seq_starts = reinterpret_cast<const uint64_t*>(take((nseq + 1) * 8));
+        const char* blob = reinterpret_cast<const char*>(take(nblob));
+        if (!ok) return MONI_EIO;
         // lifts (liftidx.hpp:131-143): per sequence second, columns, #ins, #del, then the two lists of ones
         std::vector<uint64_t> l_second, l_len, l_ins_off(1, 0), l_del_off(1, 0), l_ins, l_del;
-        if (ok && has_lifts) {
+        if (has_lifts) {
             for (uint64_t i = 0; i < nseq && ok; ++i) {
                 uint64_t h4[4];
-                ok = get(h4, 32) && h4[2] <= fsize / 8 && h4[3] <= fsize / 8;
+                const uint8_t* hp = take(32);
                 if (!ok) break;
+                memcpy(h4, hp, 32);
+                if (h4[2] > fsize / 8 || h4[3] > fsize / 8) { ok = false; break; }
                 l_second.push_back(h4[0]); l_len.push_back(h4[1]);
-                const size_t a0 = l_ins.size(), d0 = l_del.size();
-                l_ins.resize(a0 + h4[2]); l_del.resize(d0 + h4[3]);
-                ok = get(l_ins.data() + a0, h4[2] * 8) && get(l_del.data() + d0, h4[3] * 8);
+                const uint64_t* a = reinterpret_cast<const uint64_t*>(take(h4[2] * 8));
+                const uint64_t* d = reinterpret_cast<const uint64_t*>(take(h4[3] * 8));
+                if (!ok) break;
+                l_ins.insert(l_ins.end(), a, a + h4[2]); l_del.insert(l_del.end(), d, d + h4[3]);
                 l_ins_off.push_back(l_ins.size()); l_del_off.push_back(l_del.size());
             }
         }
-        fclose(fp); fp = nullptr;
         if (!ok) return MONI_EIO;
+        std::vector<char> names_flat;
         for (uint64_t i = 0, p = 0; i < nseq; ++i) {
             uint64_t ln;
             if (p + 8 > nblob) return MONI_EIO;
-            memcpy(&ln, blob.data() + p, 8);
+            memcpy(&ln, blob + p, 8);
             if (ln > nblob || p + 8 + ln > nblob) return MONI_EIO;
-            names_flat.insert(names_flat.end(), blob.data() + p + 8, blob.data() + p + 8 + ln);
+            names_flat.insert(names_flat.end(), blob + p + 8, blob + p + 8 + ln);
             names_flat.push_back(0);
             p += 8 + ln;
         }
         moni_flat_index_t f;
         memset(&f, 0, sizeof f);
         f.n = n; f.r = r; f.w = w; f.n_seq = nseq;
-        f.F = F.data(); f.heads = heads.data(); f.starts = starts.data(); f.ssa = ssa.data(); f.esa = esa.data();
-        f.thr = thr.data(); f.slcp = slcp.data(); f.text = text.data(); f.seq_starts = seq_starts.data(); f.seq_names = names_flat.data();
+        f.F = F; f.heads = heads; f.starts = starts; f.ssa = ssa; f.esa = esa;
+        f.thr = thr; f.slcp = slcp; f.text = text; f.seq_starts = seq_starts; f.seq_names = names_flat.data();
         l_ins.push_back(0); l_del.push_back(0);      // never empty: the pointers stay valid
         if (has_lifts) {
             f.lift_second = l_second.data(); f.lift_len = l_len.data(); f.lift_ins_off = l_ins_off.data(); f.lift_ins = l_ins.data();
@@ -421,7 +442,6 @@ int moni_index_load(const char* path, int device, moni_index_t** out) {
         }
         return moni_index_create(&f, device, out);
     } catch (const std::bad_alloc&) {
-        if (fp) fclose(fp);
         return MONI_ENOMEM;
     }
 }
@@ -1510,7 +1530,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 }
                 if (use_fast) {         // the staged kernels' own counters
                     const uint32_t* fc = c->af_ctr_host.p + AF_NCTR * k;
-                    unsigned long long cells, rb; memcpy(&cells, fc + AFC_CELLS, 8); memcpy(&rb, fc + AFC_RBYTES, 8);
+                    unsigned long long cells, rb, cutc, slots; memcpy(&cells, fc + AFC_CELLS, 8); memcpy(&rb, fc + AFC_RBYTES, 8); memcpy(&cutc, fc + AFC_CUTCELLS, 8); memcpy(&slots, fc + AFC_SLOTS, 8);
+                    st.dp_cells_cut += cutc; st.dp_slots += slots;
                     any_dirs_ovf_batch = any_dirs_ovf_batch || fc[AFC_DIRS_OVF] != 0;
                     st.dp_tasks += fc[AFC_NT] + (fc[AFC_TASKS] >= (uint32_t)(sub_lo[k + 1] - sub_lo[k]) * AF_MAX_TASKS_READ ? fc[AFC_TASKS] - (uint32_t)(sub_lo[k + 1] - sub_lo[k]) * AF_MAX_TASKS_READ : 0u); st.dp_cells += cells; st.kernel_fallback += fbn[16 * k]; st.dp_ref_bytes += rb;
                     for (int x = 0; x < AF_WHY_N; ++x) why_sum[x] += fc[AFC_WHY + x];
@@ -1617,7 +1638,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         stats->t_seed = st.t_seed; stats->t_chain = st.t_chain; stats->t_dp = st.t_dp; stats->t_host = st.t_host;
         stats->t_dp_kernel = c->dp_kernel_ms_accum / 1e3;
         stats->handed_back = st.handed_back; stats->dp_reused = st.dp_reused; stats->dp_cells_reused = st.dp_cells_reused;
-        stats->kernel_fallback = st.kernel_fallback; stats->dp_ref_bytes = st.dp_ref_bytes;
+        stats->kernel_fallback = st.kernel_fallback; stats->dp_ref_bytes = st.dp_ref_bytes; stats->dp_cells_cut = st.dp_cells_cut; stats->dp_slots = st.dp_slots;
         stats->t_k_chain = st.t_k_chain; stats->t_k_dp = st.t_k_dp; stats->t_k_select = st.t_k_select; stats->t_k_finish = st.t_k_finish;
         for (int x = 0; x < 12; ++x) stats->handover_why[x] = why_out[x];
     }

@@ -476,10 +476,11 @@ MONI_HD void mem_task(const moni_consts_t& K, const mem_fast_t& F, const uint8_t
     // extensions (with the nest, every offset costs the wavefront its longest extension).
     uint32_t i = 0;
     bool ext = false;
-    uint64_t pos = 0;
+    uint64_t pos = 0, nxt = m ? ptr[qb + (uint64_t)(m - 1) * 64u] : 0;      // the pointer of offset i + 1 is asked for while offset i is worked on
     while (i < m) {
         if (!ext) {
-            pos = ptr[qb + (uint64_t)(m - 1 - i) * 64u];
+            pos = nxt;
+            if (i + 1 < m) nxt = ptr[qb + (uint64_t)(m - 2 - i) * 64u];
             ext = pos != prev_pos_plus_one;
         }
         if (ext) {

@@ -19,7 +19,8 @@
 // in-order window.  -m writes the report-MEMs records (aligner_ksw2.hpp:346-373);
 // --ms / --mems write the legacy `moni ms` / `moni mems` text outputs (src/matching_statistics.cpp:520-610, src/mems.cpp:520-600).
 // -n loads <prefix>.thrbv.full.ms (no LCP samples); -q is accepted (the text comes from the BWT, not from either grammar).
-// -c writes <sam>.csv (per-read MEM statistics, csv.hpp:55-67; single-end, through the host pipeline).  Not implemented here (exit 1 with a message): -Z.
+// -c writes <sam>.csv (per-read MEM statistics, csv.hpp:55-67; single-end, through the host pipeline; exit 1 with a message for pairs).  -Z (secondary chains,
+// chain.hpp:442-727) acts on paired input and is ignored for single-end input, as in the reference (aligner_ksw2.hpp:1190-1191 is the only call site).
 #include <fcntl.h>
 #include <getopt.h>
 #include <libgen.h>
@@ -182,6 +183,7 @@ struct Args {
     size_t gpu_batch = 1048576;
     int ctx_per_gpu = 3;               // streaming path: contexts (ranges in flight) per GPU
     bool dry_run = false;
+    bool dry_write = false;     // --dry-run-write: no GPU, but the single-end front end's batching runs - ranges, workers of all (absent) GPUs, blocks placed in input order - with placeholder records
     moni_pe_params_t PE;               // -d, -D (paired-end)
     bool find_orphan = true;           // -u switches orphan recovery off
 };
@@ -195,6 +197,7 @@ static void parse(int argc, char** argv, Args& a) {
         if (!strcmp(argv[i], "--gpus") && i + 1 < argc) { a.gpus = atoi(argv[++i]); continue; }
         if (!strcmp(argv[i], "--gpu-batch") && i + 1 < argc) { a.gpu_batch = strtoull(argv[++i], nullptr, 10); continue; }
         if (!strcmp(argv[i], "--dry-run")) { a.dry_run = true; continue; }
+        if (!strcmp(argv[i], "--dry-run-write")) { a.dry_run = true; a.dry_write = true; continue; }
         if (!strcmp(argv[i], "--ctx-per-gpu") && i + 1 < argc) { a.ctx_per_gpu = std::max(1, atoi(argv[++i])); continue; }
         if (!strcmp(argv[i], "--ms")) { a.legacy_ms = true; continue; }
         if (!strcmp(argv[i], "--mems")) { a.legacy_mems = true; continue; }
@@ -705,7 +708,7 @@ int main(int argc, char** argv) {
         printf("dry-run: reads=%zu bases=%zu min_len=%u ext_len=%u S=%u F=%.2f O=%d,%d E=%d,%d threads=%zu gpus=%d out=%s first=%.*s\n", n, bases, a.P.min_len,
                a.P.ext_len, a.P.n_seeds_thr, a.P.freq_thr, a.P.gapo, a.P.gapo2, a.P.gape, a.P.gape2, a.th, a.gpus, sam_filename.c_str(),
                n ? (int)b.name_off[1] : 0, n ? (const char*)b.names.data() : "");
-        return 0;
+        if (!a.dry_write || !mapped) return 0;
     }
     const std::string idx_path = a.filename + ".mfi";
     const bool fast = mapped && !legacy && !a.report_mems && !a.csv && getenv("MONI_CLI_QUEUE_PATH") == nullptr;
@@ -715,7 +718,7 @@ int main(int argc, char** argv) {
     const bool have_mfi = !a.no_lcp && access(idx_path.c_str(), R_OK) == 0;          // (the flat file always carries the LCP samples)
     const std::string ms_path = a.filename + (a.no_lcp ? ".thrbv.full.ms" : ".thrbv.full.lcp.ms"), ldx_path = a.filename + ".ldx", txt_path = a.filename + ".txt";
     const bool have_txt = access(txt_path.c_str(), R_OK) == 0;          // optional: without it the text is rebuilt from the BWT on the GPU
-    for (int g = 0; g < a.gpus; ++g) {
+    for (int g = 0; g < a.gpus && !a.dry_write; ++g) {
         if (have_mfi) { if (moni_index_load(idx_path.c_str(), g, &idx[g])) die("cannot load " + idx_path + " on GPU " + std::to_string(g) + " (moni-hip has no CPU path)"); }
         else if (moni_index_load_reference(ms_path.c_str(), ldx_path.c_str(), have_txt ? txt_path.c_str() : nullptr, g, &idx[g]))
             die("cannot load " + idx_path + " nor " + ms_path + " + " + ldx_path + " (reader of the reference's files: layout unverified against a real `moni build` output) on GPU " + std::to_string(g) + " (moni-hip has no CPU path)");
@@ -736,7 +739,7 @@ int main(int argc, char** argv) {
         const int fd = ::open(sam_filename.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) die("open() file " + sam_filename + " failed");
         uint64_t hdr_len = 0;
-        { char* h; uint64_t hl; if (moni_sam_header(idx[0], &h, &hl)) die("header"); pwrite_all(fd, h, hl, 0); hdr_len = hl; moni_free(h); }
+        if (!a.dry_write) { char* h; uint64_t hl; if (moni_sam_header(idx[0], &h, &hl)) die("header"); pwrite_all(fd, h, hl, 0); hdr_len = hl; moni_free(h); }
         std::mutex mu; std::condition_variable cv;
         std::vector<uint64_t> lens(n_chunks, ~0ull), starts(n_chunks, 0);
         size_t upto = 0; uint64_t off_upto = hdr_len;
@@ -755,7 +758,19 @@ int main(int argc, char** argv) {
                 double x1 = now(); t_parse[w] += x1 - x0;
                 char* sam = nullptr; uint64_t len = 0;
                 moni_align_stats_t st; memset(&st, 0, sizeof st);
-                if (B.n) {
+                std::string placeholder;
+                if (a.dry_write) {          // one unaligned record per read (what the library returns for a read without seeds), worker id in a tag
+                    for (size_t r = 0; r < B.n; ++r) {
+                        placeholder.append((const char*)B.names.p + B.name_off[r], (size_t)(B.name_off[r + 1] - B.name_off[r]));
+                        placeholder += "\t4\t*\t0\t255\t*\t*\t0\t0\t";
+                        placeholder.append((const char*)B.seq.p + B.off[r], (size_t)(B.off[r + 1] - B.off[r]));
+                        placeholder += "\t";
+                        if (fq) placeholder.append((const char*)B.qual.p + B.off[r], (size_t)(B.off[r + 1] - B.off[r])); else placeholder += "*";
+                        placeholder += "\tXW:i:" + std::to_string(w) + "\n";
+                    }
+                    sam = placeholder.data(); len = placeholder.size();
+                    std::this_thread::sleep_for(std::chrono::milliseconds(3));          // (a library call takes longer than that: the other workers get their ranges)
+                } else if (B.n) {
                     moni_read_batch_t rb{B.seq.p, B.off.data(), (uint64_t)B.n};
                     if (moni_align_stream(ctx[w], &rb, B.names.p, B.name_off.data(), fq ? B.qual.p : nullptr, &a.P, &sam, &len, &st)) die("moni_align_stream failed");
                 }
@@ -797,10 +812,11 @@ int main(int argc, char** argv) {
         for (size_t w = 0; w < ctx.size(); ++w) { sp += t_parse[w]; sl2 += t_lib[w]; sw += t_wait[w]; sr += t_write[w]; }
         info("Stage seconds summed over " + std::to_string(ctx.size()) + " workers (" + std::to_string(n_chunks) + " ranges, " + std::to_string(P) + " helper threads each): parse " + std::to_string(sp) +
              ", library calls " + std::to_string(sl2) + ", waiting for the block's place " + std::to_string(sw) + ", file writes " + std::to_string(sr));
-        for (size_t w = 0; w < ctx.size(); ++w) moni_ctx_destroy(ctx[w]);
-        for (int g = 0; g < a.gpus; ++g) moni_index_destroy(idx[g]);
+        for (size_t w = 0; w < ctx.size(); ++w) if (ctx[w]) moni_ctx_destroy(ctx[w]);
+        for (int g = 0; g < a.gpus; ++g) if (idx[g]) moni_index_destroy(idx[g]);
         return 0;
     }
+    if (a.dry_write) return 0;
     FILE* out = nullptr; FILE* out2 = nullptr;
     if (a.legacy_ms) { out = fopen((sam_filename + ".pointers").c_str(), "w"); out2 = fopen((sam_filename + ".lengths").c_str(), "w"); if (!out || !out2) die("open() file " + sam_filename + ".pointers/.lengths failed"); }
     else if (a.legacy_mems) { out = fopen((sam_filename + ".mems").c_str(), "w"); if (!out) die("open() file " + sam_filename + ".mems failed"); }

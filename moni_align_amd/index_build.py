@@ -110,16 +110,22 @@ class FlatIndex:
                     put(b, np.uint64)
 
     @staticmethod
-    def load(path: str) -> "FlatIndex":
-        with open(path, "rb") as f:
-            buf = f.read()
-        if buf[:8] != MAGIC:
+    def load(path: str, mmap: bool = False) -> "FlatIndex":
+        """mmap: the arrays are read-only views of the mapped file (no private copy of the ~10 GB; processes that load the same file share its pages)"""
+        if mmap:
+            buf = np.memmap(path, dtype=np.uint8, mode="r")
+        else:
+            with open(path, "rb") as f:
+                buf = f.read()
+        if bytes(buf[:8]) != MAGIC:
             raise ValueError("not a MONIFLT2 file: " + path)
         n, r, w, nseq, nblob, has_lifts = struct.unpack_from("<6Q", buf, 8)
         off = 8 + 48
         def get(count, dt):
             nonlocal off
-            a = np.frombuffer(buf, dtype=dt, count=count, offset=off).copy()
+            a = np.frombuffer(buf, dtype=dt, count=count, offset=off)
+            if not mmap:
+                a = a.copy()
             nb = count * np.dtype(dt).itemsize
             off += nb + ((-nb) % 8)
             return a
@@ -136,7 +142,7 @@ class FlatIndex:
         p = off
         for _ in range(nseq):
             (ln,) = struct.unpack_from("<Q", buf, p)
-            names.append(buf[p + 8:p + 8 + ln].decode())
+            names.append(bytes(buf[p + 8:p + 8 + ln]).decode())
             p += 8 + ln
         lifts = None
         if has_lifts:

@@ -244,21 +244,28 @@ def make_pair_names(n_pairs: int, prefix: str = "simulated"):
 READ_BLOCK = 250000
 
 
-def make_reads_range(pg: Pangenome, lo: int, hi: int, read_len: int = 150, seed: int = 1500, **kw) -> np.ndarray:
+def make_reads_range(pg: Pangenome, lo: int, hi: int, read_len: int = 150, seed: int = 1500, threads: int = 1, **kw) -> np.ndarray:
     """Reads [lo, hi) of an unbounded seeded read set made of blocks of READ_BLOCK reads (block b = make_reads(seed + b)): any
-    contiguous range can be generated on its own, so that a rank makes only its shard of a sharded read set."""
-    parts = []
-    for b in range(lo // READ_BLOCK, (max(hi, lo + 1) - 1) // READ_BLOCK + 1):
+    contiguous range can be generated on its own, so that a rank makes only its shard of a sharded read set.  threads > 1: the
+    blocks side by side (same reads: every block has its own generator)."""
+    def part(b):
         blk = make_reads(pg, READ_BLOCK, read_len, seed=seed + b, **kw)
-        parts.append(blk[max(lo, b * READ_BLOCK) - b * READ_BLOCK: min(hi, (b + 1) * READ_BLOCK) - b * READ_BLOCK])
+        return blk[max(lo, b * READ_BLOCK) - b * READ_BLOCK: min(hi, (b + 1) * READ_BLOCK) - b * READ_BLOCK]
+    blocks = range(lo // READ_BLOCK, (max(hi, lo + 1) - 1) // READ_BLOCK + 1)
+    if threads > 1 and len(blocks) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(min(threads, len(blocks))) as ex:
+            parts = list(ex.map(part, blocks))
+    else:
+        parts = [part(b) for b in blocks]
     return np.ascontiguousarray(np.concatenate(parts)) if parts else np.zeros((0, read_len), np.uint8)
 
 
 def make_names_range(lo: int, hi: int, prefix: str = "simulated"):
     """names of reads [lo, hi) of the set (`simulated.<i>`), ragged bytes + offsets"""
-    names = [("%s.%d" % (prefix, i)).encode() for i in range(lo, hi)]
+    names = [b"%s.%d" % (prefix.encode(), i) for i in range(lo, hi)]
     off = np.zeros(hi - lo + 1, dtype=np.uint64)
-    off[1:] = np.cumsum([len(x) for x in names])
+    off[1:] = np.cumsum(np.fromiter((len(x) for x in names), dtype=np.int64, count=hi - lo))
     return np.frombuffer(b"".join(names), dtype=np.uint8).copy(), off
 
 

@@ -16,8 +16,9 @@
 //   aligner_ksw2.hpp:1329-1431  get_best_scores;  :1471-1534 check_paired_left_MEM;  :2115-2290 paired_chain_score
 //   mapq.hpp:186-223            compute_mapq_pe_bwa;  common/sam.hpp:126-142 remove_slash_mate
 //   align_reads_dispatcher.hpp:356-389  st_align's paired loop: learn on the first batches, then align them, then the rest
-// PARITY UNPINNED: nothing in the reference tree fixes paired-end output; secondary_chains (-Z) is
-// not restated.  compute_frac_rep returns 0.0 in the reference (aligner_ksw2.hpp:1979-1981) and does here.
+// PARITY UNPINNED: nothing in the reference tree fixes paired-end output.  secondary_chains (-Z) IS restated
+// (find_chains_secondary, chain.hpp:442-727, in align.hpp); nothing upstream pins its output either, and it depends
+// on std::sort of the chain starts by score alone (ties in libstdc++'s order).  compute_frac_rep returns 0.0 in the reference (aligner_ksw2.hpp:1979-1981) and does here.
 #pragma once
 #include <mutex>
 
@@ -280,7 +281,7 @@ struct aligner_pe : aligner {
         al.second_best_score = (al.score2 >= al.min_score);
     }
 
-    // aligner_ksw2.hpp:1000-1326 (secondary_chains not restated); mems_out: the `out` of a call with report_mems (learn_fragment_model passes none)
+    // aligner_ksw2.hpp:1000-1326 (secondary_chains: find_chains_secondary below); mems_out: the `out` of a call with report_mems (learn_fragment_model passes none)
     bool align(paired_alignment_t& al, bool finalize = true, std::string* mems_out = nullptr) {
         const size_t l1 = al.mate1.seq.size(), l2 = al.mate2.seq.size();
         if (pe.filter_dir) {

@@ -38,6 +38,27 @@ def test_dry_run_parsing(exe, small_case, tmp_path):
     assert "S=5000 F=0.30" in out
 
 
+def test_dry_run_write_multi_gpu_batching(exe, small_case, tmp_path):
+    """--gpus 2 --dry-run-write: no GPU, but the single-end front end's multi-GPU batching runs - the mapped file cut into record-aligned ranges, the workers of
+    both (absent) GPUs taking ranges, every block written at its place in the file - with placeholder records: the output holds every read once, in input
+    order, and more than one worker of each GPU wrote into it (align_reads_dispatcher.hpp:201-294 is the shape this replaces)."""
+    reads = small_case.synth.make_reads(small_case.pg, 6000, 100, seed=5)
+    fq = str(tmp_path / "r.fastq")
+    small_case.synth.write_fastq(fq, reads)
+    out = str(tmp_path / "o.sam")
+    r = subprocess.run([exe, "idx/pref", "-p", fq, "-o", out, "--gpus", "2", "--gpu-batch", "250", "-t", "4", "--dry-run-write"], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert b"reads=6000 bases=600000" in r.stdout and b"gpus=2" in r.stdout
+    lines = open(out, "rb").read().split(b"\n")
+    assert lines[-1] == b"" and len(lines) == 6001
+    workers = set()
+    for i, ln in enumerate(lines[:-1]):
+        f = ln.split(b"\t")
+        assert f[0] == b"simulated.%d" % i and f[1] == b"4" and f[9] == reads[i].tobytes() and len(f[10]) == 100
+        workers.add(int(f[11][5:]))
+    assert len(workers) >= 3 and min(workers) < 3 <= max(workers)          # three contexts per GPU: workers 0-2 are GPU 0's, 3-5 GPU 1's
+
+
 def test_unsupported_modes_exit_1(exe, tmp_path):
     fq = str(tmp_path / "x.fq")
     open(fq, "w").write("@a\nACGT\n+\nIIII\n")

@@ -44,10 +44,12 @@
 #define AF_TS 32                 // target rows (one block) and longest query of the small tile (gap fills)
 #define AF_GBLK 104               // register block of the global problems (overlapping anchors)
 #define AF_GPASS 3                // their target blocks: up to AF_GPASS * AF_GBLK target rows
-#define AF_NBIN 35               // 16 query-length bins of the large tile, 3 of the small tile, 16 of the global problems
+#define AF_NBIN 51               // 16 query-length bins of the large tile, 3 of the small tile, 16 of the global problems, 16 of the banded global problems
 #define AF_BIN_SMALL 16u
 #define AF_NSMALL 3u
 #define AF_BIN_GLOBAL 19u
+#define AF_BIN_BAND 35u
+#define AF_BANDW 16              // diagonals a banded global problem keeps in registers (dp_band_kernel)
 #define AF_TB_CIG 24             // CIGAR operations kept per traced problem
 #define AF_FIN_CIG 96            // ... of a stitched alignment
 #define AF_FIN_LCIG 160          // ... after lifting
@@ -144,12 +146,16 @@ struct af_args_t {
 #define AF_PROF(G, slot, t0, t1) do {} while (0)
 #endif
 enum { AFC_TASKS = 0, AFC_FALLBACK = 1, AFC_TRACED = 2, AFC_READ_CUR = 3, AFC_DIRS_OVF = 4, AFC_CELLS = 6 /* 64 bit */, AFC_DIROFF = 8 /* 64 bit */,
-       AFC_NCHUNKS = 10 /* + group */, AFC_CURSOR = 13 /* + group */, AFC_BINS = 16 /* + bin */, AFC_BIG = 56, AFC_BIG_CUR = 57, AFC_WHY = 58 /* + reason */, AFC_RBYTES = 70 /* 64 bit: text bytes of the DP targets, the R of SURVEY.md 8(d) */,
-       AFC_QBYTES = 72 /* 64 bit: read bytes of the DP queries */, AFC_NT = 74 /* DP problems queued by bin_tasks_kernel */, AFC_HUGE = 75, AFC_HUGE_CUR = 76, AFC_L0 = 77 /* reads of the small instance's list */,
-       AFC_SLOTS = 78 /* 64 bit: cell slots the DP kernels computed (query positions of the chunk's longest problem x target rows of its passes x 128 problems) */,
-       AFC_CUTCELLS = 80 /* 64 bit: cells of the problems after an extension's target rows are cut (af_build_cand); AFC_CELLS counts them as the reference poses them */, AF_NCTR = 96 };
-static_assert(AFC_BINS + AF_NBIN <= AFC_BIG && AFC_WHY + 12 <= AFC_RBYTES, "counter layout");
-enum { AF_GRP_LARGE = 0, AF_GRP_SMALL = 1, AF_GRP_GLOBAL = 2 };
+       AFC_NCHUNKS = 10 /* + group (4) */, AFC_CURSOR = 14 /* + group (4) */, AFC_BIG = 18, AFC_BIG_CUR = 19, AFC_HUGE = 20, AFC_HUGE_CUR = 21, AFC_L0 = 22 /* reads of the small instance's list */,
+       AFC_NT = 23 /* DP problems queued by bin_tasks_kernel */, AFC_WHY = 24 /* + reason (12) */, AFC_RBYTES = 36 /* 64 bit: text bytes of the DP targets, the R of SURVEY.md 8(d) */,
+       AFC_QBYTES = 38 /* 64 bit: read bytes of the DP queries */,
+       AFC_SLOTS = 40 /* 64 bit: cell slots the DP kernels computed (query positions of the chunk's longest problem x target rows of its passes (or diagonals of its band) x 128 problems) */,
+       AFC_CUTCELLS = 42 /* 64 bit: cells of the problems after an extension's target rows are cut (af_build_cand) and a global problem is banded (af_global_band); AFC_CELLS counts them as the reference poses them */,
+       AFC_BANDH = 44 /* + min(W / 4, 13): global problems by the width of the band of diagonals their optimal paths can touch (af_global_band) */,
+       AFC_GT0 = 58 /* first global problem (behind the reads' task slots) */,
+       AFC_BINS = 64 /* + bin */, AF_NCTR = 128 };
+static_assert(AFC_BINS + AF_NBIN <= AF_NCTR && AFC_WHY + 12 <= AFC_RBYTES && AFC_BANDH + 14 <= AFC_GT0, "counter layout");
+enum { AF_GRP_LARGE = 0, AF_GRP_SMALL = 1, AF_GRP_GLOBAL = 2, AF_GRP_BAND = 3 };
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // chain_plan_kernel
@@ -216,12 +222,15 @@ static_assert(AF_QCAP == 256, "af_large_bin covers query lengths up to 256");
 __device__ __forceinline__ uint32_t af_bin_of(int qlen, int tlen) {
     return (qlen <= AF_TS && tlen <= AF_TS) ? AF_BIN_SMALL + (qlen <= 8 ? 0u : qlen <= 16 ? 1u : 2u) : af_large_bin(qlen);
 }
-__device__ __forceinline__ uint32_t af_grp_of_bin(uint32_t bin) { return bin < AF_BIN_SMALL ? AF_GRP_LARGE : bin < AF_BIN_GLOBAL ? AF_GRP_SMALL : AF_GRP_GLOBAL; }
-__device__ __forceinline__ uint32_t af_grp_b0(uint32_t grp) { return grp == AF_GRP_LARGE ? 0u : grp == AF_GRP_SMALL ? AF_BIN_SMALL : AF_BIN_GLOBAL; }
-__device__ __forceinline__ uint32_t af_grp_b1(uint32_t grp) { return grp == AF_GRP_LARGE ? AF_BIN_SMALL : grp == AF_GRP_SMALL ? AF_BIN_GLOBAL : (uint32_t)AF_NBIN; }
+__device__ __forceinline__ uint32_t af_grp_of_bin(uint32_t bin) { return bin < AF_BIN_SMALL ? AF_GRP_LARGE : bin < AF_BIN_GLOBAL ? AF_GRP_SMALL : bin < AF_BIN_BAND ? AF_GRP_GLOBAL : AF_GRP_BAND; }
+__device__ __forceinline__ uint32_t af_grp_b0(uint32_t grp) { return grp == AF_GRP_LARGE ? 0u : grp == AF_GRP_SMALL ? AF_BIN_SMALL : grp == AF_GRP_GLOBAL ? AF_BIN_GLOBAL : AF_BIN_BAND; }
+__device__ __forceinline__ uint32_t af_grp_b1(uint32_t grp) { return grp == AF_GRP_LARGE ? AF_BIN_SMALL : grp == AF_GRP_SMALL ? AF_BIN_GLOBAL : grp == AF_GRP_GLOBAL ? AF_BIN_BAND : (uint32_t)AF_NBIN; }
 __device__ __forceinline__ uint32_t af_bin_qhi(uint32_t bin) {
-    return bin < AF_BIN_SMALL ? af_large_qhi(bin) : bin < AF_BIN_GLOBAL ? (8u << (bin - AF_BIN_SMALL)) : (bin - AF_BIN_GLOBAL + 1u) * 16u;
+    return bin < AF_BIN_SMALL ? af_large_qhi(bin) : bin < AF_BIN_GLOBAL ? (8u << (bin - AF_BIN_SMALL)) : bin < AF_BIN_BAND ? (bin - AF_BIN_GLOBAL + 1u) * 16u : (bin - AF_BIN_BAND + 1u) * 16u;
 }
+// target rows (or diagonals) per block and blocks of a group's problems: what a chunk's direction bits are laid out by
+__device__ __forceinline__ uint32_t af_grp_tb(uint32_t grp) { return grp == AF_GRP_SMALL ? AF_TS : grp == AF_GRP_GLOBAL ? AF_GBLK : grp == AF_GRP_BAND ? AF_BANDW : AF_BLK; }
+__device__ __forceinline__ uint32_t af_grp_np(uint32_t grp) { return grp == AF_GRP_GLOBAL ? AF_GPASS : grp == AF_GRP_LARGE ? AF_LPASS : 1; }
 
 // The lanes that work on one read: the whole wavefront (GW = 64) or a GROUP of GW consecutive lanes (GW = 16: four reads per wavefront, each with
 // its own LDS state).  chain_plan_kernel issues mostly one-lane instructions - the selection loop, the backtracking, a lane per run of anchors - and
@@ -265,8 +274,11 @@ __device__ __forceinline__ void af_small_sort(T* a, uint32_t n, Less less, int l
 //   * the depth-limit fallback (heap sort of a range) stays serial: it needs 2 * log2(n) unlucky partitions in a row.
 // NC: elements per lane (n <= GW * NC, GW the lanes of the read's group).  ipos / jpos: scratch of n entries each.
 // key(x): the integer the elements are ordered by (ascending).
+// piece: scratch of n 32-bit entries - the leaf range (first | last << 16) of the introsort loop that holds an element.  Leaves lie in order (what a Hoare
+// partition leaves on its left is not above what it leaves on its right), a stable sort never moves an element in front of an equal one, so the final
+// insertion sort keeps every element inside its leaf: its stable rank there (<= 16 comparisons) is its place - not its rank in the whole array (n of them).
 template <int NC, class GT, class T, class Key>
-__device__ __forceinline__ void af_wave_sort(const GT& g, T* a, uint32_t n, lsort::frame* st, uint16_t* ipos, uint16_t* jpos, Key key) {
+__device__ __forceinline__ void af_wave_sort(const GT& g, T* a, uint32_t n, lsort::frame* st, uint16_t* ipos, uint16_t* jpos, uint32_t* piece, Key key) {
     constexpr uint32_t GW = GT::W;
     const int lane = g.lane;
     auto less = [&](const T& x, const T& y) { return key(x) < key(y); };
@@ -337,9 +349,14 @@ __device__ __forceinline__ void af_wave_sort(const GT& g, T* a, uint32_t n, lsor
                 last = cut;
                 __syncthreads();
             }
+            // [first, last) is a leaf: at most 16 elements, or a range the heap sort has put in order
+            for (uint32_t i = (uint32_t)first + (uint32_t)lane; i < (uint32_t)last; i += GW) piece[i] = (uint32_t)first | ((uint32_t)last << 16);
         }
+    } else {
+        for (uint32_t i = (uint32_t)lane; i < n; i += GW) piece[i] = n << 16;
     }
-    // ---- std::__final_insertion_sort == a stable sort of what the loop left ----
+    __syncthreads();
+    // ---- std::__final_insertion_sort == a stable sort of what the loop left: every element by its stable rank inside its leaf ----
     T v[NC]; uint32_t rk[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -348,7 +365,9 @@ __device__ __forceinline__ void af_wave_sort(const GT& g, T* a, uint32_t n, lsor
         if (i < n) {
             v[c] = a[i];
             const auto kx = key(v[c]);
-            for (uint32_t k = 0; k < n; ++k) { const auto kk = key(a[k]); rk[c] += (kk < kx || (kk == kx && k < i)) ? 1u : 0u; }
+            const uint32_t pc = piece[i], p0 = pc & 0xFFFFu, p1 = pc >> 16;
+            rk[c] = p0;
+            for (uint32_t k = p0; k < p1; ++k) { const auto kk = key(a[k]); rk[c] += (kk < kx || (kk == kx && k < i)) ? 1u : 0u; }
         }
     }
     __syncthreads();
@@ -376,7 +395,7 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
         if (na <= 16) af_small_sort(L.anch, na, [](const uint64_t& a, const uint64_t& b) { return AF_X(a) < AF_X(b); }, lane);
         else { if (lane == 0) lsort::sort(L.anch, (long)na, [](const uint64_t& a, const uint64_t& b) { return AF_X(a) < AF_X(b); }, L.stack); __syncthreads(); }
     } else {
-        af_wave_sort<(WT::MA + GT::W - 1) / GT::W>(g, L.anch, na, L.stack, L.run_start, reinterpret_cast<uint16_t*>(L.p), [](const uint64_t& x) { return AF_X(x); });
+        af_wave_sort<(WT::MA + GT::W - 1) / GT::W>(g, L.anch, na, L.stack, L.run_start, reinterpret_cast<uint16_t*>(L.p), reinterpret_cast<uint32_t*>(L.f), [](const uint64_t& x) { return AF_X(x); });
         for (uint32_t i = lane; i < na; i += GW) L.p[i] = 0;        // (scratch of the sort)
         __syncthreads();
     }
@@ -485,9 +504,14 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
         const uint32_t fb = L.run_start[k], fe = L.run_start[k + 1];
         uint32_t used = fb;                                   // a run's chains use at most one pool entry per anchor and one more per start
         for (uint32_t s = 0; s < ns; ++s) used += (uint32_t)L.starts[s].j < fb ? 1u : 0u;
-        for (uint32_t s = 0; s < ns; ++s) {
+        // every lane goes through the sorted starts looking for those of its run; the lanes look first and then walk their chains TOGETHER (a lane that walked
+        // as soon as it had found a start did so alone - the others were at other starts: 13 runs, 13 walks one after the other, 1330 of the kernel's 4980
+        // instructions per read; profiles/r04d)
+        uint32_t s = 0;
+        while (true) {
+            while (s < ns && ((uint32_t)L.starts[s].j < fb || (uint32_t)L.starts[s].j >= fe)) ++s;
+            if (s >= ns) break;
             const af_start_t st = L.starts[s];
-            if ((uint32_t)st.j < fb || (uint32_t)st.j >= fe) continue;
             long long j = st.j;
             uint32_t cnt = 0;
             const uint32_t off = used;
@@ -498,6 +522,7 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
             if (j < 0) keep = (long long)cnt >= P.min_chain_length;
             else if ((long long)st.f - L.f[j] >= P.min_chain_score) keep = (long long)cnt >= P.min_chain_length;
             L.s_off[s] = (uint16_t)off; L.s_cnt[s] = (uint16_t)(keep ? (cnt | (paired << 15)) : 0u);          // (cnt <= MA < 2^15)
+            ++s;
         }
     }
     __syncthreads();
@@ -522,7 +547,7 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
         if (n_chains <= 16) af_small_sort(L.chains, n_chains, [](const af_chain_t& x, const af_chain_t& y) { return x.score > y.score; }, lane);
         else { if (lane == 0) lsort::sort(L.chains, (long)n_chains, [](const af_chain_t& x, const af_chain_t& y) { return x.score > y.score; }, L.stack); __syncthreads(); }
     } else          // by the whole wave (run_start and p are free again: scratch)
-        af_wave_sort<(WT::MC + GT::W - 1) / GT::W>(g, L.chains, n_chains, L.stack, L.run_start, reinterpret_cast<uint16_t*>(L.p), [](const af_chain_t& x) { return -(int64_t)x.score; });
+        af_wave_sort<(WT::MC + GT::W - 1) / GT::W>(g, L.chains, n_chains, L.stack, L.run_start, reinterpret_cast<uint16_t*>(L.p), reinterpret_cast<uint32_t*>(L.f), [](const af_chain_t& x) { return -(int64_t)x.score; });
     if (lane == 0) L.n_chains_sh = n_chains;
     __syncthreads();
     AF_STAMP(s3); AF_PROF(G, 7, s2, s3);
@@ -790,9 +815,84 @@ __global__ void __launch_bounds__(256) classify_kernel(const af_args_t G) {
     }
 }
 
+// One read of chain_plan_kernel once its seeds and anchors are in LDS: chains (af_chain), check_left_MEM's lifts, the selection loop and the plan
+// (af_plan_cands), the hand-over lists, the plan and the tasks to HBM.  All lanes of the read's group call it.
+template <class WT, int LEVEL, class GT>
+__device__ __forceinline__ void af_plan_read(const af_args_t& G, WT& L, const GT g, uint32_t r_in, uint64_t off, uint32_t m, uint32_t na, float avg, bool fallback, bool too_big) {
+    constexpr uint32_t GW = GT::W;
+    const int lane = g.lane;
+    const ak_args_t& A = G.A;
+    const uint64_t r = A.read_lo + r_in;
+    uint32_t status = AF_ST_UNALIGNED;
+#if defined(AF_PROFILE) || defined(AF_CUTS)
+    if (G.dbg & 4) na = 0;                                   // timing experiments (results are wrong): stop after the anchors ...
+#endif
+    if (!fallback && !too_big && na > 0) {
+        status = af_chain(G, L, na, avg, g);
+        status = (uint32_t)g.shfl((int)status, 0);
+        __syncthreads();
+#if defined(AF_PROFILE) || defined(AF_CUTS)
+        if ((G.dbg & 8) && status == AF_ST_CAND) status = AF_ST_UNALIGNED;      // ... after the chains ...
+#endif
+        if (status == 0xFFu) too_big = true;
+        else if (status == AF_ST_CAND) {
+            // check_left_MEM's coordinate of every chain: index(lift(leftmost anchor)).second + 1 (aligner_ksw2.hpp:565-576)
+            for (uint32_t ci = lane; ci < L.n_chains_sh; ci += GW) {
+                const af_chain_t ch = L.chains[ci];
+                const uint64_t aw = L.anch[L.pool[ch.off + ch.cnt - 1]];
+                const af_mem_t ml = L.mem[aw >> 40];
+                L.left_ref[ci] = ac_seq_off(A.P, ac_lift(A.P, AF_X(aw) - ml.len + 1)) + 1;
+            }
+            __syncthreads();
+#if defined(AF_PROFILE) || defined(AF_CUTS)
+            if (G.dbg & 16) status = AF_ST_UNALIGNED; else      // ... after the lifts
+#endif
+            status = af_plan_cands(G, L, off, m, g);
+            __syncthreads();
+            if (status == 0xFFu) too_big = true;              // the plan does not fit this instance
+        }
+    }
+    __syncthreads();
+    if (too_big) {
+        if (LEVEL == 0) { if (lane == 0) G.big_list[atomicAdd(&G.ctr[AFC_BIG], 1u)] = r_in; return; }      // the next larger instance takes it
+        if (LEVEL == 1) { if (lane == 0) G.huge_list[atomicAdd(&G.ctr[AFC_HUGE], 1u)] = r_in; return; }
+        fallback = true;
+    }
+    if (fallback) { status = AF_ST_FALLBACK; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + (m >= AF_MAX_READ ? AF_WHY_LONG : AF_WHY_ANCHORS)], 1u); }
+    // ---- the read's tasks go to the batch's list and the bins of their tile / query length; the plan goes to HBM ----
+    auto& PL = L.plan;
+    const uint32_t nt = status == AF_ST_CAND ? L.n_tasks : 0u;
+    const uint32_t t0 = r_in * AF_MAX_TASKS_READ;                 // the read's own slots (bin_tasks_kernel queues them)
+    if (status == AF_ST_CAND) {
+        for (uint32_t k = lane; k < nt; k += GW) G.tasks[t0 + k] = PL.tasks[k];
+        if ((uint32_t)lane < PL.n_cand) PL.cand[lane].task0 += t0;
+    }
+    if (lane == 0) G.ntasks[r_in] = (uint8_t)nt;
+    if (lane == 0) {
+        if (status != AF_ST_CAND) { PL.n_cand = 0; PL.n_chains = 0; }
+        PL.status = (uint8_t)status; PL.final_cand = 0; PL.n_alt = 0; PL.pad = 0; PL.score2 = 0; PL.ref_pos = PL.ref_len = 0; PL.tb0 = 0; PL.pad2 = 0;
+        PL.min_score = A.min_score_of_len[m <= A.max_len ? m : A.max_len];
+        if (status == AF_ST_FALLBACK) G.fb_list[atomicAdd(G.fb_n, 1u)] = (uint32_t)r;
+    }
+    __syncthreads();
+    {   // plan: only the parts in use (header + chains to score; their anchors)
+        const uint32_t words = (uint32_t)((offsetof(af_plan_t, cand) + (status == AF_ST_CAND ? PL.n_cand : 0u) * sizeof(af_cand_t)) / 4);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&PL);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(G.plans + r_in);
+        for (uint32_t w = lane; w < words; w += GW) dst[w] = src[w];
+        const uint32_t awords = status == AF_ST_CAND ? PL.n_an * (uint32_t)(sizeof(af_anchor_t) / 4) : 0u;
+        const uint32_t* asrc = reinterpret_cast<const uint32_t*>(PL.an);
+        uint32_t* adst = reinterpret_cast<uint32_t*>(G.plans[r_in].an);
+        for (uint32_t w = lane; w < awords; w += GW) adst[w] = asrc[w];
+    }
+    __syncthreads();
+}
+
 // WT: the LDS instance (capacities).  LEVEL 0 / 1 / 2: the reads of list0 / big_list / huge_list (classify_kernel); a read whose chains or plan overflow
 // the instance it was given goes to the next list, from the largest instance to align_kernel.  GW: the lanes of one read (af_grp_t): 64 / GW reads per
 // wavefront side by side, each in its own copy of WT.
+// (Measured and not kept, profiles/r04f: classify_kernel gathering a read's seeds and anchors into a slot that the LEVEL-0 instance asks for one read ahead - the
+// kernel is bound by VALU issue, not by those loads: 9.36 against 9.2 ms per 1 M reads, and 1.5 ms more in classify_kernel.)
 template <class WT, int LEVEL, int OCC = (LEVEL == 0 ? 6 : LEVEL == 1 ? 3 : 1), int GW = 64>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) chain_plan_kernel(const af_args_t G) {
     constexpr uint32_t NG = 64 / GW;          // reads per wavefront
@@ -804,8 +904,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     const ak_args_t& A = G.A;
     constexpr bool BIG = LEVEL > 0;
     const uint32_t n_work = G.ctr[LEVEL == 0 ? AFC_L0 : LEVEL == 1 ? AFC_BIG : AFC_HUGE];
-    constexpr uint32_t GRAB = BIG ? 1u : NG > 1 ? 2u : 8u;          // reads a group takes per visit of the wavefront to the shared cursor
     const uint32_t* const work_list = LEVEL == 0 ? G.list0 : LEVEL == 1 ? G.big_list : G.huge_list;
+    constexpr uint32_t GRAB = BIG ? 1u : NG > 1 ? 2u : 8u;          // reads a group takes per visit of the wavefront to the shared cursor
     uint32_t w_base = 0, w_k = GRAB;          // wave-uniform
     while (true) {
         if (w_k >= GRAB) {
@@ -818,12 +918,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         ++w_k;
         if (w_in >= n_work) continue;                    // the list's last reads: fewer than the wavefront has groups
         const uint32_t r_in = work_list[w_in];
-        AF_STAMP(c0);
         const uint64_t r = A.read_lo + r_in;
         const uint64_t off = A.offs[r];
         const uint32_t m = (uint32_t)(A.offs[r + 1] - off);
         const uint64_t a = A.read_mem_off[r], b = A.read_mem_off[r + 1];
-        uint32_t status = AF_ST_UNALIGNED;
         if (lane == 0) L.n_tasks = 0;
         bool fallback = m >= AF_MAX_READ || (b - a) > 4 * AF_MAX_MEMS;      // not for any instance
         bool too_big = false;                                              // not for this instance
@@ -879,106 +977,48 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
             }
         }
         __syncthreads();
-        AF_STAMP(c1); AF_PROF(G, 0, c0, c1);
-#if defined(AF_PROFILE) || defined(AF_CUTS)
-        if (G.dbg & 4) na = 0;                                   // timing experiments (results are wrong): stop after the anchors ...
-#endif
-        if (!fallback && !too_big && na > 0) {
-            status = af_chain(G, L, na, avg, g);
-            status = (uint32_t)g.shfl((int)status, 0);
-            __syncthreads();
-            AF_STAMP(c2); AF_PROF(G, 1, c1, c2);
-#if defined(AF_PROFILE) || defined(AF_CUTS)
-            if ((G.dbg & 8) && status == AF_ST_CAND) status = AF_ST_UNALIGNED;      // ... after the chains ...
-#endif
-            if (status == 0xFFu) too_big = true;
-            else if (status == AF_ST_CAND) {
-                // check_left_MEM's coordinate of every chain: index(lift(leftmost anchor)).second + 1 (aligner_ksw2.hpp:565-576)
-                for (uint32_t ci = lane; ci < L.n_chains_sh; ci += GW) {
-                    const af_chain_t ch = L.chains[ci];
-                    const uint64_t aw = L.anch[L.pool[ch.off + ch.cnt - 1]];
-                    const af_mem_t ml = L.mem[aw >> 40];
-                    L.left_ref[ci] = ac_seq_off(A.P, ac_lift(A.P, AF_X(aw) - ml.len + 1)) + 1;
-                }
-                __syncthreads();
-                AF_STAMP(c3); AF_PROF(G, 2, c2, c3);
-#if defined(AF_PROFILE) || defined(AF_CUTS)
-                if (G.dbg & 16) status = AF_ST_UNALIGNED; else      // ... after the lifts
-#endif
-                status = af_plan_cands(G, L, off, m, g);
-                __syncthreads();
-                AF_STAMP(c4); AF_PROF(G, 3, c3, c4);
-                if (status == 0xFFu) too_big = true;              // the plan does not fit this instance
-            }
-        }
-        __syncthreads();
-        if (too_big) {
-            if (LEVEL == 0) { if (lane == 0) G.big_list[atomicAdd(&G.ctr[AFC_BIG], 1u)] = r_in; continue; }      // the next larger instance takes it
-            if (LEVEL == 1) { if (lane == 0) G.huge_list[atomicAdd(&G.ctr[AFC_HUGE], 1u)] = r_in; continue; }
-            fallback = true;
-        }
-        if (fallback) { status = AF_ST_FALLBACK; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + (m >= AF_MAX_READ ? AF_WHY_LONG : AF_WHY_ANCHORS)], 1u); }
-        // ---- the read's tasks go to the batch's list and the bins of their tile / query length; the plan goes to HBM ----
-        auto& PL = L.plan;
-        const uint32_t nt = status == AF_ST_CAND ? L.n_tasks : 0u;
-        const uint32_t t0 = r_in * AF_MAX_TASKS_READ;                 // the read's own slots (bin_tasks_kernel queues them)
-        if (status == AF_ST_CAND) {
-            for (uint32_t k = lane; k < nt; k += GW) G.tasks[t0 + k] = PL.tasks[k];
-            if ((uint32_t)lane < PL.n_cand) PL.cand[lane].task0 += t0;
-        }
-        if (lane == 0) G.ntasks[r_in] = (uint8_t)nt;
-        if (lane == 0) {
-            if (status != AF_ST_CAND) { PL.n_cand = 0; PL.n_chains = 0; }
-            PL.status = (uint8_t)status; PL.final_cand = 0; PL.n_alt = 0; PL.pad = 0; PL.score2 = 0; PL.ref_pos = PL.ref_len = 0; PL.tb0 = 0; PL.pad2 = 0;
-            PL.min_score = A.min_score_of_len[m <= A.max_len ? m : A.max_len];
-            if (status == AF_ST_FALLBACK) G.fb_list[atomicAdd(G.fb_n, 1u)] = (uint32_t)r;
-        }
-        __syncthreads();
-        {   // plan: only the parts in use (header + chains to score; their anchors)
-            const uint32_t words = (uint32_t)((offsetof(af_plan_t, cand) + (status == AF_ST_CAND ? PL.n_cand : 0u) * sizeof(af_cand_t)) / 4);
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(&PL);
-            uint32_t* dst = reinterpret_cast<uint32_t*>(G.plans + r_in);
-            for (uint32_t w = lane; w < words; w += GW) dst[w] = src[w];
-            const uint32_t awords = status == AF_ST_CAND ? PL.n_an * (uint32_t)(sizeof(af_anchor_t) / 4) : 0u;
-            const uint32_t* asrc = reinterpret_cast<const uint32_t*>(PL.an);
-            uint32_t* adst = reinterpret_cast<uint32_t*>(G.plans[r_in].an);
-            for (uint32_t w = lane; w < awords; w += GW) adst[w] = asrc[w];
-        }
-        __syncthreads();
-        AF_STAMP(c5); AF_PROF(G, 4, c0, c5);
+        af_plan_read<WT, LEVEL>(G, L, g, r_in, off, m, na, avg, fallback, too_big);
     }
 }
 
-// bin_tasks_kernel: the reads' DP problems go to the queues of their tile / query-length bins.  A block takes 4 reads (their 4 x 64 task
-// slots, one thread each), counts per bin in LDS and bumps every bin's global counter once: a few thousand atomics per address and
-// launch where one per task was the bound of chain_plan_kernel.
+// bin_tasks_kernel: the reads' DP problems go to the queues of their tile / query-length bins.  A block takes AF_BT_READS reads (rounds of 4 reads x 64
+// task slots, one thread per slot), counts per bin in LDS and bumps every bin's global counter once: a few thousand atomics per address and launch where
+// one per task was the bound of chain_plan_kernel (and one per bin and 4 reads, with 35 bins instead of 18, was 2.9 ms per 1 M reads: profiles/r04e).
+#define AF_BT_READS 32u
 __global__ void __launch_bounds__(256) bin_tasks_kernel(const af_args_t G) {
-    __shared__ uint32_t cnt[AF_NBIN], base[AF_NBIN], ovf[8];
-    static_assert(AF_MAX_TASKS_READ == 64, "bin_tasks_kernel: 4 reads x 64 slots per block");
+    __shared__ uint32_t cnt[AF_NBIN], base[AF_NBIN], ovf[AF_BT_READS];
+    static_assert(AF_MAX_TASKS_READ == 64, "bin_tasks_kernel: 4 reads x 64 slots per round");
+    constexpr uint32_t ROUNDS = AF_BT_READS / 4;
     const uint32_t tid = threadIdx.x;
     const uint64_t n_reads = G.A.n_reads;
     if (blockIdx.x == 0 && tid == 0) G.ctr[AFC_TASKS] = (uint32_t)n_reads * AF_MAX_TASKS_READ;      // the global problems (global_task_kernel) come after the slots
     if (tid < AF_NBIN) cnt[tid] = 0;
-    if (tid < 8) ovf[tid] = 0;
+    if (tid < AF_BT_READS) ovf[tid] = 0;
     __syncthreads();
-    const uint64_t r_in = (uint64_t)blockIdx.x * 4 + (tid >> 6);
     const uint32_t k = tid & 63u;
-    const bool valid = r_in < n_reads && k < (uint32_t)G.ntasks[r_in];
-    const uint32_t id = (uint32_t)r_in * AF_MAX_TASKS_READ + k;
-    uint32_t bin = 0, local = 0;
-    if (valid) { const moni_dp_task_t t = G.tasks[id]; bin = af_bin_of(t.qlen, t.tlen); local = atomicAdd(&cnt[bin], 1u); }
+    uint32_t bin[ROUNDS], local[ROUNDS];
+    bool valid[ROUNDS];
+#pragma unroll
+    for (uint32_t q = 0; q < ROUNDS; ++q) {
+        const uint64_t r_in = (uint64_t)blockIdx.x * AF_BT_READS + 4 * q + (tid >> 6);
+        valid[q] = r_in < n_reads && k < (uint32_t)G.ntasks[r_in];
+        bin[q] = 0; local[q] = 0;
+        if (valid[q]) { const moni_dp_task_t t = G.tasks[(uint32_t)r_in * AF_MAX_TASKS_READ + k]; bin[q] = af_bin_of(t.qlen, t.tlen); local[q] = atomicAdd(&cnt[bin[q]], 1u); }
+    }
     __syncthreads();
     if (tid < AF_NBIN && cnt[tid]) base[tid] = atomicAdd(&G.ctr[AFC_BINS + tid], cnt[tid]);
     if (tid == 0) { uint32_t n = 0; for (uint32_t b = 0; b < AF_NBIN; ++b) n += cnt[b]; if (n) atomicAdd(&G.ctr[AFC_NT], n); }
     __syncthreads();
-    if (valid) {
-        const uint32_t at = base[bin] + local;
-        if (at < G.bin_cap) { G.bin_q[(size_t)bin * G.bin_cap + at] = id; G.task_pos[id] = at | (bin << 26); }
-        else ovf[tid >> 6] = 1;                      // the queue is full: the read goes to align_kernel
+#pragma unroll
+    for (uint32_t q = 0; q < ROUNDS; ++q) if (valid[q]) {
+        const uint32_t id = (uint32_t)((uint64_t)blockIdx.x * AF_BT_READS + 4 * q + (tid >> 6)) * AF_MAX_TASKS_READ + k;
+        const uint32_t at = base[bin[q]] + local[q];
+        if (at < G.bin_cap) { G.bin_q[(size_t)bin[q] * G.bin_cap + at] = id; G.task_pos[id] = at | (bin[q] << 26); }
+        else ovf[4 * q + (tid >> 6)] = 1;                      // the queue is full: the read goes to align_kernel
     }
     __syncthreads();
-    if (tid < 4 && ovf[tid]) {
-        const uint64_t rr = (uint64_t)blockIdx.x * 4 + tid;
+    if (tid < AF_BT_READS && ovf[tid]) {
+        const uint64_t rr = (uint64_t)blockIdx.x * AF_BT_READS + tid;
         G.plans[rr].status = AF_ST_FALLBACK;
         G.fb_list[atomicAdd(G.fb_n, 1u)] = (uint32_t)(G.A.read_lo + rr);
         atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CAPACITY], 1u);
@@ -1001,7 +1041,7 @@ __global__ void __launch_bounds__(64) af_chunk_kernel(const af_args_t G, const u
     for (uint32_t grp = first_group; grp <= last_group; ++grp) {
         const uint32_t b0 = af_grp_b0(grp), b1 = af_grp_b1(grp);
         const uint32_t nb = b1 - b0;                     // <= 16
-        const uint32_t tb = grp == AF_GRP_SMALL ? AF_TS : grp == AF_GRP_GLOBAL ? AF_GBLK : AF_BLK, np = grp == AF_GRP_GLOBAL ? AF_GPASS : grp == AF_GRP_LARGE ? AF_LPASS : 1;
+        const uint32_t tb = af_grp_tb(grp), np = af_grp_np(grp);
         uint32_t cnt = 0, nch = 0, qhi = 0, bin = 0; uint64_t bytes = 0;
         if ((uint32_t)lane < nb) {
             bin = b1 - 1 - (uint32_t)lane;
@@ -1264,6 +1304,158 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// dp_band_kernel: a GLOBAL problem (ksw_extz2_sse without EXTZ_ONLY: score = H(tlen - 1, qlen - 1), traceback from that corner; call site
+// aligner_ksw2.hpp:3015) over the W diagonals global_band_kernel has shown to hold every cell of every best path.  Lane = two problems (16-bit halves, as
+// dp_lane_kernel).  Slot k of a lane's registers holds, at query column j, the cell of row i = j + dlo + k: its diagonal neighbour is the slot's own value of
+// the column before, its left neighbour slot k + 1 of the column before, its upper neighbour slot k - 1 of this column - so a column is one pass over the
+// slots in place, with nothing to shift.  What lies outside the band reads as "minus infinity"; the matrix's own border (row -1, column -1) needs no special
+// case: H(-1, -1) = 0 is set, and the recurrence then produces -(q + k e) along row -1 by itself (an insertion run), column -1 is written at the start.
+// Cells of best paths get exactly the values and direction bits of the full matrix (a neighbour that a best path could come from lies in the band; one that
+// lies outside loses strictly).  160 x 16 cell slots per problem where the full-matrix kernel steps through 160 x 208.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define AF_BTCAP (AF_QCAP + 2 * AF_BANDW)
+template <int W>
+__global__ void __launch_bounds__(64) dp_band_kernel(const af_args_t G) {
+    __shared__ uint8_t qs[AF_QCAP][64];          // query codes of the lane's two problems: low one in bits 0-1, high one in bits 4-5
+    __shared__ uint8_t ts[AF_BTCAP][64];         // target codes likewise
+    static_assert(W % 4 == 0 && W <= 16, "a lane's target window is one 32-bit word of 2-bit codes");
+    const int lane = threadIdx.x;
+    const dp_launch_t& D = G.A.D;
+    const uint32_t qo2 = af_pk2(D.qo), e2 = af_pk2(D.e), scM2 = af_pk2(D.sc_mch), scX2 = af_pk2(D.sc_mis), neg2 = af_pk2(AF_NEG16);
+    const int32_t qo = D.qo, e = D.e;
+    uint32_t chunk0 = 0;
+    for (uint32_t g = 0; g < AF_GRP_BAND; ++g) chunk0 += G.ctr[AFC_NCHUNKS + g];
+    const uint32_t n_chunks = G.ctr[AFC_NCHUNKS + AF_GRP_BAND];
+    while (true) {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(&G.ctr[AFC_CURSOR + AF_GRP_BAND], 1u);
+        c = (uint32_t)__shfl((int)c, 0);
+        if (c >= n_chunks) break;
+        const af_chunk_t ch = G.chunks[chunk0 + c];
+        const bool nodir = ch.dir_off == ~0ull;
+        bool has[2]; uint32_t tid[2] = {0, 0};
+        moni_dp_task_t task[2];
+        int dlo[2] = {0, 0};
+        int maxq = 0, maxt = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            has[h] = (uint32_t)lane + 64u * h < ch.n;
+            task[h].qlen = 0; task[h].tlen = 0; task[h].q_off = 0; task[h].t_off = 0; task[h].reserved = 0; task[h].flag = 0;
+            if (has[h]) { tid[h] = G.bin_q[(size_t)ch.bin * G.bin_cap + ch.start + lane + 64 * h]; task[h] = G.tasks[tid[h]]; dlo[h] = (int)(int16_t)((uint32_t)task[h].flag >> 16); }
+            maxq = task[h].qlen > maxq ? task[h].qlen : maxq; maxt = task[h].tlen > maxt ? task[h].tlen : maxt;
+        }
+        for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(maxq, o); maxq = w > maxq ? w : maxq; const int w2 = __shfl_xor(maxt, o); maxt = w2 > maxt ? w2 : maxt; }
+        if (maxq > AF_QCAP) maxq = AF_QCAP;
+        if (maxt > AF_BTCAP) maxt = AF_BTCAP;
+        bool wild[2] = {nodir, nodir};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {          // both sequences of both problems -> LDS, eight bases per load
+            if (task[h].qlen > AF_QCAP || task[h].tlen > AF_BTCAP) wild[h] = true;          // (cannot happen: the band is narrower than the two lengths differ)
+            const int qlen = task[h].qlen, tlen = task[h].tlen, mode = task[h].reserved;
+            af_bytes_t QS = af_bytes(D.reads, task[h].q_off, D.reads_limit, (mode & DP_Q_REV) != 0);
+            for (int g = 0; 8 * g < maxq; ++g) {
+                const uint64_t v = 8 * g < qlen ? af_group(QS, g) : 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    uint32_t cq = dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu);
+                    if ((mode & DP_Q_COMP) && cq < 4) cq = 3 - cq;
+                    const bool in = 8 * g + u < qlen;
+                    wild[h] |= in && cq > 3;
+                    if (8 * g + u < maxq) { if (h == 0) qs[8 * g + u][lane] = (uint8_t)(in ? (cq & 3u) : 0u); else qs[8 * g + u][lane] |= (uint8_t)((in ? (cq & 3u) : 0u) << 4); }
+                }
+            }
+            af_bytes_t TS = af_bytes(D.text, task[h].t_off, D.text_limit, (mode & DP_T_REV) != 0);
+            for (int g = 0; 8 * g < maxt; ++g) {
+                const uint64_t v = 8 * g < tlen ? af_group(TS, g) : 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t ct = dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu);
+                    const bool in = 8 * g + u < tlen;
+                    wild[h] |= in && ct > 3;
+                    if (8 * g + u < maxt) { if (h == 0) ts[8 * g + u][lane] = (uint8_t)(in ? (ct & 3u) : 0u); else ts[8 * g + u][lane] |= (uint8_t)((in ? (ct & 3u) : 0u) << 4); }
+                }
+            }
+        }
+        // target code of row i of problem h (rows outside the staged ones: any code - they hold no cell that counts)
+        auto tcode = [&](int i, int h) -> uint32_t { const int r = i < 0 ? 0 : i >= maxt ? maxt - 1 : i; return maxt > 0 ? ((uint32_t)ts[r][lane] >> (4 * h)) & 3u : 0u; };
+        // column -1: slot k holds row -1 + dlo + k
+        uint32_t Hb[W], Fb[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const int r0 = -1 + dlo[0] + k, r1 = -1 + dlo[1] + k;
+            const int v0 = r0 == -1 ? 0 : r0 >= 0 ? -(qo + (r0 + 1) * e) : AF_NEG16, v1 = r1 == -1 ? 0 : r1 >= 0 ? -(qo + (r1 + 1) * e) : AF_NEG16;
+            Hb[k] = ((uint32_t)v0 & 0xFFFFu) | ((uint32_t)v1 << 16);
+            Fb[k] = neg2;
+        }
+        uint32_t tw[2] = {0, 0};          // the target codes of the slots' rows at the current column, 2 bits per slot
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < W; ++k) tw[h] |= tcode(dlo[h] + k, h) << (2 * k);
+        uint32_t* __restrict__ dir = reinterpret_cast<uint32_t*>(G.dirs + (nodir ? 0ull : ch.dir_off)) + lane;
+        const int qe0 = task[0].qlen - 1, qe1 = task[1].qlen - 1;
+        const int ks0 = (task[0].tlen - 1) - qe0 - dlo[0], ks1 = (task[1].tlen - 1) - qe1 - dlo[1];          // the corner's slot at the last column
+        int score[2] = {AF_NEG_INF, AF_NEG_INF};
+        for (int j = 0; j < maxq; ++j) {
+            const uint32_t qb = qs[j][lane];
+            const uint32_t a0 = tw[0] ^ ((qb & 3u) * 0x55555555u), a1 = tw[1] ^ (((qb >> 4) & 3u) * 0x55555555u);
+            const uint32_t x0 = (a0 | (a0 >> 1)) & 0x55555555u, x1 = (a1 | (a1 >> 1)) & 0x55555555u;
+            uint32_t h_up = neg2, e_run = neg2, pack = 0;
+            uint32_t* __restrict__ drow = dir + (size_t)j * (W / 4) * 64;
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const uint32_t k0 = (uint32_t)__builtin_amdgcn_sbfe((int)x0, 2 * k, 1), k1 = (uint32_t)__builtin_amdgcn_sbfe((int)x1, 2 * k, 1);
+                const uint32_t mk = __builtin_amdgcn_perm(k1, k0, 0x05040100u);
+                const uint32_t sc = (mk & scX2) | (~mk & scM2);
+                const uint32_t h_old = Hb[k];
+                const uint32_t left_h = k + 1 < W ? Hb[k + 1] : neg2, left_f = k + 1 < W ? Fb[k + 1] : neg2;
+                const uint32_t E = af_pk_sub(af_pk_max(af_pk_sub(h_up, qo2), e_run), e2);
+                const uint32_t F = af_pk_sub(af_pk_max(af_pk_sub(left_h, qo2), left_f), e2);
+                const uint32_t zd = af_pk_add(h_old, sc);
+                const uint32_t z1 = af_pk_max(zd, E), z = af_pk_max(z1, F), zq = af_pk_sub(z, qo2);
+                uint32_t nb = af_pk_neg(af_pk_sub(E, zd));
+                nb |= af_pk_neg(af_pk_sub(F, z1)) << 1;
+                nb |= af_pk_neg(af_pk_sub(E, zq)) << 2;
+                nb |= af_pk_neg(af_pk_sub(F, zq)) << 3;
+                Hb[k] = z; Fb[k] = F; h_up = z; e_run = E;
+                pack = (pack << 4) | nb;
+                if ((k & 3) == 3) { drow[(k >> 2) * 64] = pack; pack = 0; }
+            }
+            if (j == qe0 || j == qe1) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    if (j == qe0 && k == ks0) score[0] = af_lo16(Hb[k]);
+                    if (j == qe1 && k == ks1) score[1] = af_hi16(Hb[k]);
+                }
+            }
+            // the rows move down by one with the next column
+            tw[0] = (tw[0] >> 2) | (tcode(j + 1 + dlo[0] + W - 1, 0) << (2 * (W - 1)));
+            tw[1] = (tw[1] >> 2) | (tcode(j + 1 + dlo[1] + W - 1, 1) << (2 * (W - 1)));
+        }
+        unsigned long long cells = 0, rq = 0, cut = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) if (has[h]) {
+            af_res_t R; R.mqe = AF_NEG_INF; R.mqe_t = -1; R.score = score[h]; R.flags = 0;
+            if (wild[h] || score[h] == AF_NEG_INF) { R.score = AF_NEG_INF; R.flags = 1; }
+            else {
+                cells += (unsigned long long)task[h].qlen * (unsigned long long)task[h].tlen; rq += ((unsigned long long)task[h].tlen << 32) | (unsigned long long)task[h].qlen;
+                cut += (unsigned long long)task[h].qlen * (unsigned long long)(task[h].tlen < W ? task[h].tlen : W);
+            }
+            G.res[tid[h]] = R;
+        }
+        for (int o = 32; o > 0; o >>= 1) { cells += __shfl_xor(cells, o); rq += __shfl_xor(rq, o); cut += __shfl_xor(cut, o); }
+        if (lane == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_CELLS]), cells);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_RBYTES]), rq >> 32);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_QBYTES]), rq & 0xFFFFFFFFull);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_CUTCELLS]), cut);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_SLOTS]), 128ull * (unsigned long long)maxq * (unsigned long long)W);
+        }
+        __syncthreads();
+    }
+}
+
 // where the direction byte of cell (i, j) of a task is: its chunk, its lane there, the target block of i
 struct af_dirs_t { const uint8_t* base; uint32_t tb, half; uint64_t pass_stride; };      // half: which 16-bit half of the words holds the task
 __device__ __forceinline__ af_dirs_t af_dir_of(const af_args_t& G, uint32_t bin, uint32_t pos_in_bin) {
@@ -1275,7 +1467,7 @@ __device__ __forceinline__ af_dirs_t af_dir_of(const af_args_t& G, uint32_t bin,
     ci += pos_in_bin >> 7;
     const af_chunk_t ch = G.chunks[ci];
     af_dirs_t X;
-    X.tb = grp == AF_GRP_SMALL ? AF_TS : grp == AF_GRP_GLOBAL ? AF_GBLK : AF_BLK;
+    X.tb = af_grp_tb(grp);
     X.pass_stride = (uint64_t)ch.qhi * X.tb * 64;
     X.base = G.dirs + ch.dir_off + (size_t)(pos_in_bin & 63) * 4;
     X.half = (pos_in_bin >> 6) & 1u;
@@ -1290,6 +1482,43 @@ __device__ __forceinline__ void af_window(const af_cand_t& C, const af_anchor_t*
     const uint64_t rcs_len = m - ((uint64_t)last.idx + last.len);
     const uint64_t rq = (uint64_t)(int64_t)(rcs_len > 0 ? rc_t + 1 : 0);
     ref_pos = lq > mem_pos ? 0 : mem_pos - lq; ref_len = lq + mem_len + rq;
+}
+
+// The diagonals d = i - j a best-scoring path of a GLOBAL problem (corner to corner, aligner_ksw2.hpp:3009-3015) can touch.  A lower bound of the
+// score from the alignment "diagonal 0, one gap of |tlen - qlen| where it pays most, diagonal tlen - qlen" (one pass over the two sequences);
+// an upper bound for any path that touches diagonal D outside [min(0, delta), max(0, delta)]: it holds at least 2 D - delta (above) or
+// delta - 2 D (below) gap bases in at least two gaps, and at most min(qlen, tlen) diagonal steps.  Diagonals whose upper bound lies strictly below
+// the lower bound hold no cell of any best path - nor of any path that ties with one.
+__device__ __forceinline__ void af_global_band(const dp_launch_t& D, const moni_dp_task_t& T, int& dmin, int& dmax) {
+    const int q = T.qlen, t = T.tlen, delta = t - q, ad = delta < 0 ? -delta : delta, n = q < t ? q : t;
+    const bool qrev = (T.reserved & DP_Q_REV) != 0, qcomp = (T.reserved & DP_Q_COMP) != 0, trev = (T.reserved & DP_T_REV) != 0;
+    const uint64_t qsh = delta < 0 ? (uint64_t)ad : 0ull, tsh = delta > 0 ? (uint64_t)ad : 0ull;
+    af_bytes_t Q0 = af_bytes(D.reads, T.q_off, D.reads_limit, qrev), Q1 = af_bytes(D.reads, qrev ? T.q_off - qsh : T.q_off + qsh, D.reads_limit, qrev);
+    af_bytes_t T0 = af_bytes(D.text, T.t_off, D.text_limit, trev), T1 = af_bytes(D.text, trev ? T.t_off - tsh : T.t_off + tsh, D.text_limit, trev);
+    int tot = 0, A = 0, maxA = 0;
+    for (int g = 0; 8 * g < n; ++g) {
+        const uint64_t vq0 = af_group(Q0, g), vt0 = af_group(T0, g);
+        const uint64_t vq1 = delta < 0 ? af_group(Q1, g) : vq0, vt1 = delta > 0 ? af_group(T1, g) : vt0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (8 * g + u >= n) break;
+            uint32_t a = dp_nt4((uint32_t)(vq0 >> (8 * u)) & 0xFFu), b = dp_nt4((uint32_t)(vq1 >> (8 * u)) & 0xFFu);
+            if (qcomp) { if (a < 4) a = 3 - a; if (b < 4) b = 3 - b; }
+            const uint32_t c = dp_nt4((uint32_t)(vt0 >> (8 * u)) & 0xFFu), d = dp_nt4((uint32_t)(vt1 >> (8 * u)) & 0xFFu);
+            const int s0 = (a > 3 || c > 3) ? D.sc_N : a == c ? D.sc_mch : D.sc_mis;          // diagonal 0
+            const int s1 = (b > 3 || d > 3) ? D.sc_N : b == d ? D.sc_mch : D.sc_mis;          // diagonal delta
+            tot += s1; A += s0 - s1; maxA = A > maxA ? A : maxA;
+        }
+    }
+    const int lb = tot + maxA - (delta ? D.qo + D.e * ad : 0);
+    const int G = D.e > 0 ? (D.sc_mch * n - 2 * D.qo - lb) : 0x3FFFFFFF;          // e x (gap bases a path can afford)
+    dmin = delta < 0 ? delta : 0; dmax = delta > 0 ? delta : 0;
+    if (G >= 0 && D.e > 0) {
+        const int gb = G / D.e;
+        const int up = (gb + delta) >> 1, dn = -((gb - delta) >> 1);
+        dmax = up > dmax ? up : dmax; dmin = dn < dmin ? dn : dmin;
+    }
+    if (D.e <= 0) { dmin = -q; dmax = t; }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -1340,30 +1569,67 @@ __global__ void __launch_bounds__(256) global_task_kernel(const af_args_t G) {
         base = (uint32_t)__shfl((int)base, __ffsll((long long)nm) - 1);
         const uint32_t tid = base + (uint32_t)__popcll(nm & lt_mask);
         if (need && tid >= G.task_cap) { why = AF_WHY_CAPACITY; need = false; }
-        const uint32_t bin = AF_BIN_GLOBAL + ((m - 1) >> 4);
-        uint32_t at = 0;
-        unsigned long long rest = __ballot(need);
-        while (rest) {                                     // one bump per distinct bin of the wave (reads of one length: one)
-            const int lead = __ffsll((long long)rest) - 1;
-            const uint32_t b = (uint32_t)__shfl((int)bin, lead);
-            const unsigned long long same = __ballot(need && bin == b);
-            uint32_t a0 = 0;
-            if (lane == lead) a0 = atomicAdd(&G.ctr[AFC_BINS + b], (uint32_t)__popcll(same));
-            a0 = (uint32_t)__shfl((int)a0, lead);
-            if (need && bin == b) at = a0 + (uint32_t)__popcll(same & lt_mask);
-            rest &= ~same;
-        }
-        if (need) {
+        if (need) {          // the problem's record; global_band_kernel (one lane per problem) bounds its diagonals and queues it
             moni_dp_task_t T;
             if (!Cp->strand) { T.q_off = off; T.reserved = DP_Q_READS | DP_T_TEXT; } else { T.q_off = off + m - 1; T.reserved = DP_Q_READS | DP_T_TEXT | DP_Q_REV | DP_Q_COMP; }
             T.t_off = ref_pos; T.qlen = (int32_t)m; T.tlen = (int32_t)ref_len; T.flag = DP_EZ_RIGHT;
             G.tasks[tid] = T;
-            G.bin_q[(size_t)bin * G.bin_cap + at] = tid;
-            G.task_pos[tid] = at | (bin << 26);
+            af_res_t R0; R0.mqe = AF_NEG_INF; R0.mqe_t = -1; R0.score = AF_NEG_INF; R0.flags = 1;          // (stays so if a queue turns out to be full: the read then takes align_kernel)
+            G.res[tid] = R0;
             Cp->gtask = tid;
         }
     }
     if (active && why != AF_WHY_N) { PLp->status = AF_ST_FALLBACK; G.fb_list[atomicAdd(G.fb_n, 1u)] = (uint32_t)r; atomicAdd(&G.ctr[AFC_WHY + why], 1u); }
+}
+
+// global_band_kernel: one lane per global problem (they lie behind the reads' task slots: [AFC_GT0, AFC_TASKS)).  The band of diagonals its optimal paths can
+// touch (af_global_band: a few for a read that differs from the window by substitutions - 77 % of the benchmark's global problems need at most 4 diagonals,
+// 99.8 % at most 16; profiles/r04e) decides the kernel: dp_band_kernel keeps AF_BANDW diagonals in registers and steps through qlen x AF_BANDW cells where
+// the full matrix has qlen x tlen; a problem with a wider band takes the full-matrix kernel as before.  The band's first diagonal rides in the task's flag word.
+__global__ void __launch_bounds__(256) global_band_kernel(const af_args_t G) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const uint32_t t0 = (uint32_t)G.A.n_reads * AF_MAX_TASKS_READ, t1 = G.ctr[AFC_TASKS] < G.task_cap ? G.ctr[AFC_TASKS] : G.task_cap;
+    const uint32_t tid = t0 + blockIdx.x * 256 + threadIdx.x;
+    bool need = tid < t1;
+    uint32_t bin = 0, hb = 0;
+    moni_dp_task_t T;
+    if (need) {
+        T = G.tasks[tid];
+        int dlo, dhi;
+        af_global_band(G.A.D, T, dlo, dhi);
+        const int W = dhi - dlo + 1;
+        hb = (uint32_t)(W / 4 < 13 ? W / 4 : 13);
+        const bool band = W <= AF_BANDW && !(G.dbg & 0x10000u);          // (MONI_AF_DBG=65536: every global problem through the full-matrix kernel)
+        if (band) {          // the band widened to AF_BANDW diagonals around what is needed (never beyond what the matrix has)
+            const int spare = AF_BANDW - W;
+            dlo -= spare / 2;
+            T.flag = (T.flag & 0xFFFF) | (int)(((uint32_t)dlo & 0xFFFFu) << 16);
+            G.tasks[tid].flag = T.flag;
+        }
+        bin = (band ? AF_BIN_BAND : AF_BIN_GLOBAL) + (uint32_t)((T.qlen - 1) >> 4);
+    }
+    uint32_t at = 0;
+    unsigned long long rest = __ballot(need);
+    while (rest) {                                     // one bump per distinct bin of the wave
+        const int lead = __ffsll((long long)rest) - 1;
+        const uint32_t b = (uint32_t)__shfl((int)bin, lead);
+        const unsigned long long same = __ballot(need && bin == b);
+        uint32_t a0 = 0;
+        if (lane == lead) a0 = atomicAdd(&G.ctr[AFC_BINS + b], (uint32_t)__popcll(same));
+        a0 = (uint32_t)__shfl((int)a0, lead);
+        if (need && bin == b) at = a0 + (uint32_t)__popcll(same & lt_mask);
+        rest &= ~same;
+    }
+    if (need && at < G.bin_cap) { G.bin_q[(size_t)bin * G.bin_cap + at] = tid; G.task_pos[tid] = at | (bin << 26); }
+    rest = __ballot(need);                             // the histogram of band widths, one bump per distinct class of the wave (one atomic per problem on the
+    while (rest) {                                     // counter of the narrowest class - three in four fall into it - took 2.4 ms per 1 M reads: profiles/r04g)
+        const int lead = __ffsll((long long)rest) - 1;
+        const uint32_t b = (uint32_t)__shfl((int)hb, lead);
+        const unsigned long long same = __ballot(need && hb == b);
+        if (lane == lead) atomicAdd(&G.ctr[AFC_BANDH + b], (uint32_t)__popcll(same));
+        rest &= ~same;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -1503,8 +1769,11 @@ __global__ void __launch_bounds__(256) traceback_kernel(const af_args_t G) {
         cur_op = op; cur_len = len;
     };
     int state = 0;
+    const bool banded = bin >= AF_BIN_BAND;                          // dp_band_kernel's layout: slot = i - j - first diagonal of the band (the task's flag word)
+    const int band_lo = (int)(int16_t)((uint32_t)T.flag >> 16);
     while (i >= 0 && j >= 0) {
-        const uint32_t ps = (uint32_t)i / tb, ii = (uint32_t)i - ps * tb;
+        uint32_t ps = (uint32_t)i / tb, ii = (uint32_t)i - ps * tb;
+        if (banded) { const int kk = i - j - band_lo; if (kk < 0 || kk >= (int)tb) { ovf = true; break; } ps = 0; ii = (uint32_t)kk; }      // (a best path never leaves the band)
         const uint32_t word = *reinterpret_cast<const uint32_t*>(X.base + ps * X.pass_stride + ((size_t)j * (tb / 4) + (size_t)(ii >> 2)) * 256);
         const uint32_t nb = (word >> (16 * X.half + 4 * (3 - (ii & 3)))) & 0xFu;      // sign bits of dp_lane_kernel: diagonal beats E, that beats F, E ends, F ends
         const uint32_t tmp = ((nb & 2u) ? ((nb & 1u) ? 0u : 1u) : 2u) | ((nb & 4u) ? 0u : 0x08u) | ((nb & 8u) ? 0u : 0x10u);      // ksw2's direction byte
@@ -2052,4 +2321,19 @@ __global__ void gather_summary_kernel(const uint64_t* __restrict__ len, const ui
         for (int s = 0; s < 16; ++s) al += dev_sum[8 + 8 * s];
         out3[2] = al;
     }
+}
+
+// The DP stage of the staged kernels, single-end and paired alike: the reads' (pairs') problems have been queued by bin_tasks_kernel; extension and gap problems
+// by tile, then the global problems: their records (global_task_kernel), their bands and queues (global_band_kernel), banded where a narrow band is proven,
+// the full matrix otherwise.  n_units: plans of the launch (reads or pairs).
+static inline void af_launch_dp(const af_args_t& G, hipStream_t sx, unsigned dp_grid, unsigned n_cu, uint64_t n_units) {
+    hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_SMALL);
+    hipLaunchKernelGGL((dp_lane_kernel<AF_BLK, AF_QCAP, AF_LPASS>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE);
+    hipLaunchKernelGGL((dp_lane_kernel<AF_TS, AF_TS, 1>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_SMALL);
+    hipLaunchKernelGGL(global_task_kernel, dim3((unsigned)((n_units + 255) / 256)), dim3(256), 0, sx, G);
+    const uint64_t gmax = G.task_cap > n_units * AF_MAX_TASKS_READ ? G.task_cap - n_units * AF_MAX_TASKS_READ : 0;          // global problems the slots hold
+    if (gmax) hipLaunchKernelGGL(global_band_kernel, dim3((unsigned)((gmax + 255) / 256)), dim3(256), 0, sx, G);
+    hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL, (uint32_t)AF_GRP_BAND);
+    hipLaunchKernelGGL((dp_band_kernel<AF_BANDW>), dim3(n_cu * 4), dim3(64), 0, sx, G);
+    hipLaunchKernelGGL((dp_lane_kernel<AF_GBLK, AF_QCAP, AF_GPASS>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL);
 }

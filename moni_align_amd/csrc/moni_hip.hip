@@ -1436,7 +1436,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
 #ifdef AF_CUTS
                 if (const char* v = getenv("MONI_AF_DBG")) G.dbg = (uint32_t)atoi(v);
 #endif
-                if (const char* v = getenv("MONI_AF_DBG")) G.dbg |= (uint32_t)atoi(v) & 64u;          // 64: the serial anchor sort (cross-check), any build
+                if (const char* v = getenv("MONI_AF_DBG")) G.dbg |= (uint32_t)atoi(v) & (64u | 65536u);          // any build: 64 the serial anchor sort (cross-check), 65536 every global problem through the full-matrix kernel
                 HIPCHK(hipMemsetAsync(S.ctr.p, 0, AF_NCTR * sizeof(uint32_t), sx));
                 // LEVEL 0's instance: the small one, or - reads of more than 200 bases, whose seeds have more occurrences than it holds - the middle one
                 static const int l0_force = getenv("MONI_AF_L0") ? atoi(getenv("MONI_AF_L0")) : -1;          // 0 small, 1 middle
@@ -1462,14 +1462,9 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 static const bool no_huge = getenv("MONI_AF_NOHUGE") != nullptr;          // (debugging aid: reads beyond the large instance then go straight to align_kernel)
                 if (!no_huge) hipLaunchKernelGGL((chain_plan_kernel<af_wave_huge_t, 2>), dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu)), dim3(64), 0, sx, G);      // ~90 KB of LDS per wave: one per CU
                 HIPCHK(hipGetLastError());
-                hipLaunchKernelGGL(bin_tasks_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, sx, G);
+                hipLaunchKernelGGL(bin_tasks_kernel, dim3((unsigned)((nr + AF_BT_READS - 1) / AF_BT_READS)), dim3(256), 0, sx, G);
                 HIPCHK(hipEventRecord(c->af_ev[3 * k], sx));
-                hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_SMALL);
-                hipLaunchKernelGGL((dp_lane_kernel<AF_BLK, AF_QCAP, AF_LPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE);
-                hipLaunchKernelGGL((dp_lane_kernel<AF_TS, AF_TS, 1>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_SMALL);
-                hipLaunchKernelGGL(global_task_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
-                hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL, (uint32_t)AF_GRP_GLOBAL);
-                hipLaunchKernelGGL((dp_lane_kernel<AF_GBLK, AF_QCAP, AF_GPASS>), dim3(af_dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL);
+                af_launch_dp(G, sx, af_dp_grid, (unsigned)n_cu, nr);
                 HIPCHK(hipEventRecord(c->af_ev[3 * k + 1], sx));
                 hipLaunchKernelGGL(select_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
                 hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)((af_tb_cap + 255) / 256)), dim3(256), 0, sx, G);
@@ -1537,7 +1532,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                     for (int x = 0; x < AF_WHY_N; ++x) why_sum[x] += fc[AFC_WHY + x];
                     if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "  staged kernels, sub-batch %llu: %u DP tasks, %llu cells, %u traced, %u large + %u small + %u global chunks, %u reads to align_kernel%s\n",
                                                            (unsigned long long)k, fc[AFC_NT], cells, fc[AFC_TRACED], fc[AFC_NCHUNKS], fc[AFC_NCHUNKS + 1], fc[AFC_NCHUNKS + 2], fbn[16 * k], fc[AFC_DIRS_OVF] ? " (direction bytes overflowed)" : "");
-                    if (getenv("MONI_AK_PROFILE")) { fprintf(stderr, "    DP problems per bin (large tile by query length / 16, small tile, global by query length / 16):"); for (int x = 0; x < AF_NBIN; ++x) fprintf(stderr, " %u", fc[AFC_BINS + x]); fprintf(stderr, "\n"); }
+                    if (getenv("MONI_AK_PROFILE")) { fprintf(stderr, "    DP problems per bin (16 of the large tile by query length <= 8 13 16 24 32 48 64 .. 160 192 224 256, 3 of the small tile <= 8 16 32, 16 global by query length / 16):"); for (int x = 0; x < AF_NBIN; ++x) fprintf(stderr, " %u", fc[AFC_BINS + x]); fprintf(stderr, "\n"); }
+                    if (getenv("MONI_AK_PROFILE")) { fprintf(stderr, "    global problems by band width / 4 (0-3, 4-7, ... , >= 52):"); for (int x = 0; x < 14; ++x) fprintf(stderr, " %u", fc[AFC_BANDH + x]); fprintf(stderr, "\n"); }
                     if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "    handed over because: long read %u, anchors/seeds %u, chains %u, chains to score %u, chain length %u, DP size %u, overlapping anchors %u, wildcard %u, "
                                                            "loop depends on a score %u, extension short of the query end %u, capacity %u, CIGAR %u\n",
                                                            fc[AFC_WHY + 0], fc[AFC_WHY + 1], fc[AFC_WHY + 2], fc[AFC_WHY + 3], fc[AFC_WHY + 4], fc[AFC_WHY + 5], fc[AFC_WHY + 6], fc[AFC_WHY + 7], fc[AFC_WHY + 8], fc[AFC_WHY + 9], fc[AFC_WHY + 10], fc[AFC_WHY + 11]);

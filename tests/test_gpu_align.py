@@ -46,6 +46,21 @@ def test_sam_identical_150bp(medium_case, env):
     assert st["aligned"] == wcnt["aligned"] > 19000
 
 
+def test_banded_global_problems_equal_the_full_matrix(medium_case, env, monkeypatch):
+    """Chains with overlapping anchors are scored by one global alignment of the whole read (aligner_ksw2.hpp:2984-3015).  dp_band_kernel computes the band
+    of diagonals global_band_kernel has bounded (lower bound from a two-piece diagonal alignment, upper bound from the gap bases a path off the band must
+    hold); a problem whose band is wider than 16 diagonals takes the full-matrix kernel.  Substitutions (narrow bands), indels (bands around tlen - qlen,
+    wide ones too) and both strands: the SAM text equals the oracle's, and nothing changes when every global problem is forced through the full matrix."""
+    reads = list(medium_case.synth.make_reads(medium_case.pg, 6000, 150, seed=161, sub_rate=0.02, indel_rate=0.004)) + \
+            list(medium_case.synth.make_reads(medium_case.pg, 3000, 250, seed=162, sub_rate=0.03, indel_rate=0.002)) + \
+            list(medium_case.synth.make_reads(medium_case.pg, 3000, 100, seed=163))
+    _, st = both(env, reads)
+    monkeypatch.setenv("MONI_AF_DBG", "65536")
+    _, st_full = both(env, reads)
+    assert st["aligned"] == st_full["aligned"] and st["dp_cells"] == st_full["dp_cells"]
+    assert st["dp_cells_cut"] < st_full["dp_cells_cut"]          # the banded problems step through fewer cells
+
+
 def test_sub_batches_and_handed_back_reads(medium_case, env, monkeypatch):
     """The batch goes through the GPU in sub-batches overlapped with the host stage; reads the kernel hands back go
     through the host pipeline and are spliced in at their positions.  Output must not depend on either."""

@@ -88,9 +88,11 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
+    ap.add_argument("--n-rate", type=float, default=0.0, help="robustness leg: this fraction of the reads gets one N at a random place (real Illumina data: 0.5-2 %% of the reads hold an N); the DP problems that touch it leave the packed 2-bit kernels")
     ap.add_argument("--no-scaling-base", action="store_true", help="N = 1: skip the extra leg that runs configs[3]'s read set (--scaling-base-reads reads, resident chunks of --reads) on the one GPU")
     ap.add_argument("--scaling-base-reads", type=int, default=CONFIGS3_READS)
     ap.add_argument("--paired", action="store_true", help="the paired-end path instead (moni_pe_learn_batch / moni_pe_align_batch over --pairs FR pairs of 2 x --read-len, orphan recovery on): pairs/s")
+    ap.add_argument("-Z", "--secondary-chains", dest="secondary_chains", action="store_true", help="--paired: find_chains_secondary (the reference's -Z) in the learning batches and the alignment")
     ap.add_argument("--pairs", type=int, default=1000000, help="--paired: read pairs (per GPU; sharded by contiguous ranges like the reads when --total-reads is given)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: launch, rendezvous (gloo), sharding and the SAM gather with placeholder records")
     ap.add_argument("--cache", default="/tmp/moni_bench_cache")
@@ -289,6 +291,11 @@ def run_rank(args) -> int:
             phase("reads generated", t0)
         lo, hi, reads, names, noff = mine
         scaling = "strong" if sharded else "weak"
+        if args.n_rate > 0:          # one N in a seeded choice of the reads (by global read number: the same reads whatever the sharding)
+            rn = np.random.Generator(np.random.MT19937(4242))
+            pick = rn.random(max(hi, 1))[lo:hi] < args.n_rate
+            at = rn.integers(0, L, size=max(hi, 1))[lo:hi]
+            reads[np.nonzero(pick)[0], at[pick]] = ord("N")
     if args.paired:
         return run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx, phases, t_start)
     n_mine = reads.shape[0]
@@ -566,6 +573,7 @@ def run_rank(args) -> int:
                       "reads_taken_by_general_kernel": tot["kernel_fallback"], "reads_handed_to_host_pipeline": tot["handed_back"],
                       "handed_over_because": {k: v // steps for k, v in why.items()}},
             "stages_s_per_step": stage,
+            "n_rate": args.n_rate,
             "aligned_per_step": tot["aligned"], "sam_bytes_per_step": sam_len,
             "aligned_all_ranks": aligned_all,
             "setup_s": {"total": setup_s, "phases": [[n_, round(d_, 2)] for n_, d_ in phases], "note": "rank 0's wall time in front of the timed region"},
@@ -646,12 +654,13 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx, pha
     names, noff = synth.make_pair_names(n_all)
     lo, hi = mdist.shard_range(n_all, rank, world)
     model = capi.PeModelC()
+    zsec = 1 if args.secondary_chains else 0
     vals = torch.zeros(8, dtype=torch.float64)
     if rank == 0:
         at = 0
         while not model.complete and at < n_all:
             e = min(n_all, at + 512)
-            ctx.pe_learn(mates[2 * at:2 * e].reshape(-1), np.arange(0, (2 * (e - at) + 1) * L, L, dtype=np.uint64), model)
+            ctx.pe_learn(mates[2 * at:2 * e].reshape(-1), np.arange(0, (2 * (e - at) + 1) * L, L, dtype=np.uint64), model, secondary_chains=zsec)
             at = e
         vals = torch.tensor([model.mean, model.std_dev, model.variance, model.sample_variance, model.m2, float(model.count), float(model.complete), 0.0], dtype=torch.float64)
     if dist is not None:          # learn once, broadcast (every rank aligns with the same model)
@@ -675,20 +684,20 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx, pha
     # reads handed over in host memory (moni_pe_align_stream: the upload inside the call): reported beside the headline, never as `value`
     from_host = None
     if not args.no_from_host:
-        ctx.pe_align(seq, offs, nm, no, ql, model, host_threads=threads, want_text=False, stream=True)
+        ctx.pe_align(seq, offs, nm, no, ql, model, host_threads=threads, want_text=False, stream=True, secondary_chains=zsec)
         t1 = time.perf_counter()
         for _ in range(max(1, args.steps)):
-            ctx.pe_align(seq, offs, nm, no, ql, model, host_threads=threads, want_text=False, stream=True)
+            ctx.pe_align(seq, offs, nm, no, ql, model, host_threads=threads, want_text=False, stream=True, secondary_chains=zsec)
         dt = (time.perf_counter() - t1) / max(1, args.steps)
         from_host = {"value": (hi - lo) / dt, "unit": "pairs/s (this rank)", "ms_per_batch": dt * 1e3, "note": "moni_pe_align_stream: mates, names, qualities in pageable host memory, upload inside the timed call"}
         if world == 1:          # a streaming caller keeps several contexts per GPU going (moni-hip-align -1/-2 runs three): one's upload, seeding and tail beside the other's paired kernels
             ctx_b = capi.Ctx(idx)
-            ctx_b.pe_align(seq, offs, nm, no, ql, model, host_threads=threads, want_text=False, stream=True)
+            ctx_b.pe_align(seq, offs, nm, no, ql, model, host_threads=threads, want_text=False, stream=True, secondary_chains=zsec)
             reps = max(2, min(6, args.steps))
 
             def pe_worker(cx):
                 for _ in range(reps):
-                    cx.pe_align(seq, offs, nm, no, ql, model, host_threads=max(1, threads // 2), want_text=False, stream=True)
+                    cx.pe_align(seq, offs, nm, no, ql, model, host_threads=max(1, threads // 2), want_text=False, stream=True, secondary_chains=zsec)
             th = [threading.Thread(target=pe_worker, args=(cx,)) for cx in (ctx, ctx_b)]
             t1 = time.perf_counter()
             for t in th:
@@ -701,11 +710,11 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx, pha
     # the headline: the mates resident in HBM when the timed region starts (moni_reads_upload), names and qualities host buffers as in moni_align_run
     ctx.upload(seq, offs)
     for _ in range(args.warmup):
-        ctx.pe_align_run(nm, no, ql, model, host_threads=threads, want_text=False)
+        ctx.pe_align_run(nm, no, ql, model, host_threads=threads, want_text=False, secondary_chains=zsec)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sam_len, st = ctx.pe_align_run(nm, no, ql, model, host_threads=threads, want_text=False)      # the text is in the context's pinned host buffer; no copy into a Python object
+        sam_len, st = ctx.pe_align_run(nm, no, ql, model, host_threads=threads, want_text=False, secondary_chains=zsec)      # the text is in the context's pinned host buffer; no copy into a Python object
     sync_all()
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dist, coll_dev)
     lf_ms = ctx.kernel_ms(0)                      # ms_lf_kernel of the last step (one launch over the 2 N mates), HIP events on its own stream
@@ -714,7 +723,7 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx, pha
     if rank == 0:
         steps = max(1, args.steps)
         step_s = elapsed / steps
-        out = {"metric": "aligned read pairs/s (whole node), 2 x %d bp PE, mouse-chr19-scale x%d-haplotype index, orphan recovery on" % (L, args.haps),
+        out = {"metric": "aligned read pairs/s (whole node), 2 x %d bp PE, mouse-chr19-scale x%d-haplotype index, orphan recovery on%s" % (L, args.haps, ", -Z (secondary chains)" if zsec else ""),
                "value": n_all / step_s, "unit": "pairs/s", "reads_per_s": 2 * n_all / step_s, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64/int32", "data": "synthetic",
                "config": {"workload": "SURVEY.md 8(f)-2: paired-end path on the BASELINE.json configs[2] index (%d bp base + %d haplotypes, n=%d, r=%d): %d FR pairs of 2 x %d bp per GPU "
@@ -745,13 +754,13 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx, pha
                 no2 = np.zeros(b - a + 1, np.uint64); no2[1:] = np.cumsum([int(noff[2 * p + 2] - noff[2 * p + 1]) for p in range(a, b)])
                 q = np.full((b - a) * L, ord("I"), np.uint8)
                 return _orc.align_pe(oidx, np.ascontiguousarray(m1).reshape(-1), o1, np.ascontiguousarray(m2).reshape(-1), o1, np.frombuffer(n1, np.uint8), no1,
-                                     np.frombuffer(n2, np.uint8), no2, q, q, b_size=512, find_orphan=True)
+                                     np.frombuffer(n2, np.uint8), no2, q, q, b_size=512, find_orphan=True, secondary_chains=bool(zsec))
             n0 = min(3000, hi - lo)
             t1 = time.perf_counter()
             want, ost = cpu_pe(0, n0)
             rate1 = n0 / (time.perf_counter() - t1)
             nseq0 = int(offs[2 * n0] - offs[0])
-            got, _ = ctx.pe_align(seq[:nseq0], offs[:2 * n0 + 1], nm[:int(no[2 * n0])], no[:2 * n0 + 1], None if ql is None else ql[:nseq0], model, host_threads=threads)
+            got, _ = ctx.pe_align(seq[:nseq0], offs[:2 * n0 + 1], nm[:int(no[2 * n0])], no[:2 * n0 + 1], None if ql is None else ql[:nseq0], model, host_threads=threads, secondary_chains=zsec)
             per = int(max(1, min((hi - lo) // cpu_threads, max(2000, rate1 * args.cpu_seconds))))          # never past this rank's pairs (few pairs on many cores: shorter slices)
             res = [None] * cpu_threads
             th = [threading.Thread(target=lambda k=k: res.__setitem__(k, cpu_pe(k * per, (k + 1) * per))) for k in range(cpu_threads)]

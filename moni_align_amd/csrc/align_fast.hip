@@ -44,12 +44,16 @@
 #define AF_TS 32                 // target rows (one block) and longest query of the small tile (gap fills)
 #define AF_GBLK 104               // register block of the global problems (overlapping anchors)
 #define AF_GPASS 3                // their target blocks: up to AF_GPASS * AF_GBLK target rows
-#define AF_NBIN 51               // 16 query-length bins of the large tile, 3 of the small tile, 16 of the global problems, 16 of the banded global problems
+#define AF_NBIN 67               // 16 query-length bins of the large tile, 3 of the small tile, 16 of the banded extensions / gap fills, 16 of the global problems, 16 of the banded global problems
 #define AF_BIN_SMALL 16u
 #define AF_NSMALL 3u
-#define AF_BIN_GLOBAL 19u
-#define AF_BIN_BAND 35u
+#define AF_BIN_BAND 19u          // extensions and gap fills with a proven band: computed BEFORE global_task_kernel (a global problem's window comes from its chain's extensions)
+#define AF_BIN_GLOBAL 35u
+#define AF_BIN_GBAND 51u
 #define AF_BANDW 16              // diagonals a banded global problem keeps in registers (dp_band_kernel)
+#define AF_BIN_PROV ((uint32_t)AF_NBIN)      // one more queue: the large tile's problems before band_tasks_kernel has looked at them
+#define AF_POS_BITS 25           // task_pos: a task's place in its bin's queue (a queue holds fewer than 2^25 entries), its bin (< 128) above
+static_assert(AF_NBIN + 1 <= (1 << (32 - AF_POS_BITS)), "task_pos");
 #define AF_TB_CIG 24             // CIGAR operations kept per traced problem
 #define AF_FIN_CIG 96            // ... of a stitched alignment
 #define AF_FIN_LCIG 160          // ... after lifting
@@ -57,7 +61,7 @@
 #define AF_NEG_INF (-0x40000000)
 
 enum { AF_GAP_NONE = 0, AF_GAP_INS, AF_GAP_DEL0, AF_GAP_TASK, AF_GAP_1X1 };
-enum { AF_ST_UNALIGNED = 0, AF_ST_CAND = 1, AF_ST_FALLBACK = 2, AF_ST_FINAL = 3 };
+enum { AF_ST_UNALIGNED = 0, AF_ST_CAND = 1, AF_ST_FALLBACK = 2, AF_ST_FINAL = 3, AF_ST_CHAINS = 4 /* chain_plan_kernel has left the read's chains for plan_kernel */ };
 
 struct af_anchor_t {             // one anchor of a chain to score, and the gap between it and the next one (16 bytes)
     uint64_t occ;
@@ -106,6 +110,9 @@ struct af_plan_lds_t {
     moni_dp_task_t tasks[NT];
     uint32_t n_an;               // anchors in use
 };
+struct af_ctab_t { int32_t score; uint16_t an0; uint8_t cnt, strand; uint64_t left_ref; };      // one chain of a read, in the order of chain.hpp:402's sort: its anchors are an[an0 .. an0 + cnt) of the read's plan
+static_assert(sizeof(af_ctab_t) == 16, "af_ctab_t");
+#define AF_CTAB 48               // chains per read in the table (the small LDS instance's capacity)
 struct af_res_t { int32_t mqe, mqe_t, score, flags; };      // flags: 1 = a wildcard base in an operand (not computed)
 struct af_chunk_t { uint32_t bin, start, n, qhi; uint64_t dir_off; };
 struct af_tb_t { uint32_t n_ops; uint32_t ops[AF_TB_CIG]; };      // raw backtrack order (end -> start); n_ops = ~0u: did not fit
@@ -122,12 +129,13 @@ struct af_args_t {
     uint8_t* ntasks;                         // per read: how many of its slots are in use
     af_res_t* res;
     uint32_t* bin_q; uint32_t bin_cap;       // AF_NBIN queues of task indices
-    uint32_t* task_pos;                      // where a task sits: position in its bin's queue | bin << 26
+    uint32_t* task_pos;                      // where a task sits: position in its bin's queue | bin << AF_POS_BITS
     af_chunk_t* chunks; uint32_t chunk_cap;  // 64-task chunks of the two tiles: large first
     uint8_t* dirs; uint64_t dirs_cap;
     uint32_t* tb_task; af_tb_t* tb; uint32_t tb_cap;      // problems to trace
     uint32_t* fb_list; uint32_t* fb_n;       // reads handed to align_kernel and their number: per sub-batch, not per buffer set (align_kernel reads them on its own stream
                                              // while the set's next sub-batch is already running)
+    af_ctab_t* ctab;                         // AF_CTAB per read of the launch: LEVEL 0's chains, for plan_kernel (nullptr: the LEVEL-0 instance plans by itself)
     uint32_t* list0; uint32_t* big_list; uint32_t* huge_list; // reads (indices in the launch) of the small / the large / the largest instance of chain_plan_kernel (classify_kernel)
     unsigned long long* txt_cur;             // AF_TXT_SHARDS cursors (one per 64 bytes) of the text pool's shard regions: a device-scope atomic on ONE address
     uint64_t txt_shard_words;                // sustains only ~50 M/s; region s + 1 of the pool (txt_shard_words each) belongs to shard s, region 0 to cursors[15]
@@ -146,16 +154,15 @@ struct af_args_t {
 #define AF_PROF(G, slot, t0, t1) do {} while (0)
 #endif
 enum { AFC_TASKS = 0, AFC_FALLBACK = 1, AFC_TRACED = 2, AFC_READ_CUR = 3, AFC_DIRS_OVF = 4, AFC_CELLS = 6 /* 64 bit */, AFC_DIROFF = 8 /* 64 bit */,
-       AFC_NCHUNKS = 10 /* + group (4) */, AFC_CURSOR = 14 /* + group (4) */, AFC_BIG = 18, AFC_BIG_CUR = 19, AFC_HUGE = 20, AFC_HUGE_CUR = 21, AFC_L0 = 22 /* reads of the small instance's list */,
-       AFC_NT = 23 /* DP problems queued by bin_tasks_kernel */, AFC_WHY = 24 /* + reason (12) */, AFC_RBYTES = 36 /* 64 bit: text bytes of the DP targets, the R of SURVEY.md 8(d) */,
-       AFC_QBYTES = 38 /* 64 bit: read bytes of the DP queries */,
-       AFC_SLOTS = 40 /* 64 bit: cell slots the DP kernels computed (query positions of the chunk's longest problem x target rows of its passes (or diagonals of its band) x 128 problems) */,
-       AFC_CUTCELLS = 42 /* 64 bit: cells of the problems after an extension's target rows are cut (af_build_cand) and a global problem is banded (af_global_band); AFC_CELLS counts them as the reference poses them */,
-       AFC_BANDH = 44 /* + min(W / 4, 13): global problems by the width of the band of diagonals their optimal paths can touch (af_global_band) */,
-       AFC_GT0 = 58 /* first global problem (behind the reads' task slots) */,
-       AFC_BINS = 64 /* + bin */, AF_NCTR = 128 };
-static_assert(AFC_BINS + AF_NBIN <= AF_NCTR && AFC_WHY + 12 <= AFC_RBYTES && AFC_BANDH + 14 <= AFC_GT0, "counter layout");
-enum { AF_GRP_LARGE = 0, AF_GRP_SMALL = 1, AF_GRP_GLOBAL = 2, AF_GRP_BAND = 3 };
+       AFC_NCHUNKS = 10 /* + group (5) */, AFC_CURSOR = 16 /* + group (5) */, AFC_BIG = 21, AFC_BIG_CUR = 22, AFC_HUGE = 23, AFC_HUGE_CUR = 24, AFC_L0 = 25 /* reads of the small instance's list */,
+       AFC_NT = 26 /* DP problems queued by bin_tasks_kernel */, AFC_WHY = 28 /* + reason (12) */, AFC_RBYTES = 40 /* 64 bit: text bytes of the DP targets, the R of SURVEY.md 8(d) */,
+       AFC_QBYTES = 42 /* 64 bit: read bytes of the DP queries */,
+       AFC_SLOTS = 44 /* 64 bit: cell slots the DP kernels computed (query positions of the chunk's longest problem x target rows of its passes (or diagonals of its band) x 128 problems) */,
+       AFC_CUTCELLS = 46 /* 64 bit: cells of the problems after an extension's target rows are cut (af_build_cand) and a problem is banded (af_ext_band, af_global_band); AFC_CELLS counts them as the reference poses them */,
+       AFC_BANDH = 48 /* + min(W / 4, 13): global problems by the width of the band of diagonals their optimal paths can touch (af_global_band) */,
+       AFC_BINS = 64 /* + bin */, AF_NCTR = 160 };
+static_assert(AFC_BINS + AF_NBIN + 1 <= AF_NCTR && AFC_WHY + 12 <= AFC_RBYTES && AFC_BANDH + 14 <= AFC_BINS && AFC_NCHUNKS + 5 <= AFC_CURSOR && AFC_CURSOR + 5 <= AFC_BIG, "counter layout");
+enum { AF_GRP_LARGE = 0, AF_GRP_SMALL = 1, AF_GRP_BAND = 2, AF_GRP_GLOBAL = 3, AF_GRP_GBAND = 4 };
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // chain_plan_kernel
@@ -168,14 +175,15 @@ struct af_left_t { uint64_t ref; int64_t score; };
 // LDS of one read.  MA / MC / MM: capacities for anchors, chains, seeds.  Two instances are launched: a small one that most reads
 // fit (more reads in flight per CU: the kernel is bound by the latency of its serial parts), and a large one for the reads that
 // overflow it.  Arrays that are dead by the time the plan is written share their space with it.
-template <int MA_, int MC_, int MM_, int NC_, int NA_, int NT_, int PE_ = 0>
+template <int MA_, int MC_, int MM_, int NC_, int NA_, int NT_, int PE_ = 0, int SEC_ = 0>
 struct af_wave_tt {
     static constexpr int MA = MA_, MC = MC_, MM = MM_, NC = NC_, NA = NA_, NT = NT_;
+    static constexpr bool SEC = SEC_ != 0;      // -Z: the second track of find_chains_secondary (chain.hpp:442-727): f2 / msc2 / p2 / t2 per anchor, twice the pool
     static constexpr int NSTACK = MA_ <= 128 ? 16 : MA_ <= 512 ? 20 : 24;      // pending partitions of the introsort emulation: at most 2 * floor(log2 n) + 1
     af_mem_t mem[MM_];
     uint64_t anch[MA_];                  // x (reference end, 40 bits) | mem << 40
     af_chain_t chains[MC_];
-    uint16_t pool[MA_ + MC_];
+    uint16_t pool[(MA_ + MC_) * (SEC_ ? 2 : 1)];
     uint32_t n_chains_sh, status_sh, n_tasks;
     union {
         struct {                         // chaining (dead once af_chain has returned)
@@ -185,6 +193,8 @@ struct af_wave_tt {
             af_start_t starts[MC_];
             uint16_t run_start[MA_ + 1];
             uint16_t s_off[MC_], s_cnt[MC_];       // per sorted start: where its chain's anchors are in the pool, how many (0: chain dropped)
+            int32_t f2[SEC_ ? MA_ : 1], msc2[SEC_ ? MA_ : 1];
+            int16_t p2[SEC_ ? MA_ : 1], t2[SEC_ ? MA_ : 1];
         };
         struct {                         // the selection loop and the plan
             af_plan_lds_t<NC_, NA_, NT_> plan;      // the plan and its tasks
@@ -222,15 +232,17 @@ static_assert(AF_QCAP == 256, "af_large_bin covers query lengths up to 256");
 __device__ __forceinline__ uint32_t af_bin_of(int qlen, int tlen) {
     return (qlen <= AF_TS && tlen <= AF_TS) ? AF_BIN_SMALL + (qlen <= 8 ? 0u : qlen <= 16 ? 1u : 2u) : af_large_bin(qlen);
 }
-__device__ __forceinline__ uint32_t af_grp_of_bin(uint32_t bin) { return bin < AF_BIN_SMALL ? AF_GRP_LARGE : bin < AF_BIN_GLOBAL ? AF_GRP_SMALL : bin < AF_BIN_BAND ? AF_GRP_GLOBAL : AF_GRP_BAND; }
-__device__ __forceinline__ uint32_t af_grp_b0(uint32_t grp) { return grp == AF_GRP_LARGE ? 0u : grp == AF_GRP_SMALL ? AF_BIN_SMALL : grp == AF_GRP_GLOBAL ? AF_BIN_GLOBAL : AF_BIN_BAND; }
-__device__ __forceinline__ uint32_t af_grp_b1(uint32_t grp) { return grp == AF_GRP_LARGE ? AF_BIN_SMALL : grp == AF_GRP_SMALL ? AF_BIN_GLOBAL : grp == AF_GRP_GLOBAL ? AF_BIN_BAND : (uint32_t)AF_NBIN; }
+__device__ __forceinline__ uint32_t af_grp_of_bin(uint32_t bin) { return bin < AF_BIN_SMALL ? AF_GRP_LARGE : bin < AF_BIN_BAND ? AF_GRP_SMALL : bin < AF_BIN_GLOBAL ? AF_GRP_BAND : bin < AF_BIN_GBAND ? AF_GRP_GLOBAL : AF_GRP_GBAND; }
+__device__ __forceinline__ uint32_t af_grp_b0(uint32_t grp) { return grp == AF_GRP_LARGE ? 0u : grp == AF_GRP_SMALL ? AF_BIN_SMALL : grp == AF_GRP_BAND ? AF_BIN_BAND : grp == AF_GRP_GLOBAL ? AF_BIN_GLOBAL : AF_BIN_GBAND; }
+__device__ __forceinline__ uint32_t af_grp_b1(uint32_t grp) { return grp == AF_GRP_LARGE ? AF_BIN_SMALL : grp == AF_GRP_SMALL ? AF_BIN_BAND : grp == AF_GRP_BAND ? AF_BIN_GLOBAL : grp == AF_GRP_GLOBAL ? AF_BIN_GBAND : (uint32_t)AF_NBIN; }
 __device__ __forceinline__ uint32_t af_bin_qhi(uint32_t bin) {
-    return bin < AF_BIN_SMALL ? af_large_qhi(bin) : bin < AF_BIN_GLOBAL ? (8u << (bin - AF_BIN_SMALL)) : bin < AF_BIN_BAND ? (bin - AF_BIN_GLOBAL + 1u) * 16u : (bin - AF_BIN_BAND + 1u) * 16u;
+    return bin < AF_BIN_SMALL ? af_large_qhi(bin) : bin < AF_BIN_BAND ? (8u << (bin - AF_BIN_SMALL)) : bin < AF_BIN_GLOBAL ? af_large_qhi(bin - AF_BIN_BAND)
+         : bin < AF_BIN_GBAND ? (bin - AF_BIN_GLOBAL + 1u) * 16u : af_large_qhi(bin - AF_BIN_GBAND);
 }
 // target rows (or diagonals) per block and blocks of a group's problems: what a chunk's direction bits are laid out by
-__device__ __forceinline__ uint32_t af_grp_tb(uint32_t grp) { return grp == AF_GRP_SMALL ? AF_TS : grp == AF_GRP_GLOBAL ? AF_GBLK : grp == AF_GRP_BAND ? AF_BANDW : AF_BLK; }
+__device__ __forceinline__ uint32_t af_grp_tb(uint32_t grp) { return grp == AF_GRP_SMALL ? AF_TS : grp == AF_GRP_GLOBAL ? AF_GBLK : (grp == AF_GRP_BAND || grp == AF_GRP_GBAND) ? AF_BANDW : AF_BLK; }
 __device__ __forceinline__ uint32_t af_grp_np(uint32_t grp) { return grp == AF_GRP_GLOBAL ? AF_GPASS : grp == AF_GRP_LARGE ? AF_LPASS : 1; }
+__device__ __forceinline__ bool af_bin_banded(uint32_t bin) { return (bin >= AF_BIN_BAND && bin < AF_BIN_GLOBAL) || bin >= AF_BIN_GBAND; }
 
 // The lanes that work on one read: the whole wavefront (GW = 64) or a GROUP of GW consecutive lanes (GW = 16: four reads per wavefront, each with
 // its own LDS state).  chain_plan_kernel issues mostly one-lane instructions - the selection loop, the backtracking, a lane per run of anchors - and
@@ -382,7 +394,7 @@ __device__ __forceinline__ void af_wave_sort(const GT& g, T* a, uint32_t n, lsor
 // runs never pass the distance test of chain.hpp:300 (or are skipped for their mates before it), so runs share nothing but the
 // lower bound `lb`, which only ever excludes anchors that are too far anyway.  Returns the plan status (uniform).
 template <class WT, class GT = af_grp_t<64>>
-__device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t na, float avg_mem_length, const GT g = GT()) {
+__device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t na, float avg_mem_length, const GT g = GT(), const bool sec_on = false) {
     const ac_params_t& P = G.A.P;
     constexpr uint32_t GW = GT::W;
     const int lane = g.lane;
@@ -423,7 +435,7 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
             const af_mem_t mi = L.mem[aw >> 40];
             const long long x_i = (long long)AF_X(aw), y_i = mi.rpos, w_i = mi.len;
             const uint32_t mate_i = mi.mate;
-            long long max_f = w_i, max_j = -1;
+            long long max_f = w_i, max_j = -1, max_sec_f = w_i, max_sec_j = -1;
             size_t n_pred = 0;
             if ((size_t)i - (size_t)lb > (size_t)P.max_iter) lb = (long long)i - P.max_iter;
             for (long long j = (long long)i - 1; j >= lb; --j) {
@@ -448,11 +460,21 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
                 }
                 const long long score = L.f[j] + (alpha - beta);
                 if (score > max_f) { max_f = score; max_j = j; if (n_pred > 0) --n_pred; }
+                else if (WT::SEC && sec_on && (long long)L.f2[j] + (alpha - beta) > max_sec_f) {          // chain.hpp:586-612: the best predecessor that is not on the primary chain of the best one
+                    if (max_j >= 0) {
+                        const uint64_t pos_j = (uint64_t)x_j - mj.len + 1;                                 // the occurrence the anchor stands for
+                        bool uniq = true;
+                        for (long long tmp = max_j; tmp >= 0; tmp = L.p[tmp]) { const uint64_t at = L.anch[tmp]; if (AF_X(at) - L.mem[at >> 40].len + 1 == pos_j) { uniq = false; break; } }
+                        if (uniq) { max_sec_f = (long long)L.f2[j] + (alpha - beta); max_sec_j = j; }
+                    }
+                }
                 else if ((size_t)(long long)L.t[j] == (size_t)i && (++n_pred > (size_t)P.max_pred)) break;
                 if (L.p[j] > 0) L.t[L.p[j]] = (int16_t)i;
+                if (WT::SEC && sec_on && L.p2[j] > 0) L.t2[L.p2[j]] = (int16_t)i;
             }
             L.f[i] = (int32_t)max_f; L.p[i] = (int16_t)max_j;
             L.msc[i] = (max_j >= 0 && L.msc[max_j] > max_f) ? L.msc[max_j] : (int32_t)max_f;
+            if (WT::SEC && sec_on) { L.f2[i] = (int32_t)max_sec_f; L.p2[i] = (int16_t)max_sec_j; L.msc2[i] = (max_sec_j >= 0 && L.msc2[max_sec_j] > max_sec_f) ? L.msc2[max_sec_j] : (int32_t)max_sec_f; }
         }
     }
     __syncthreads();
@@ -460,87 +482,99 @@ __device__ __forceinline__ uint32_t af_chain(const af_args_t& G, WT& L, uint32_t
 #if defined(AF_PROFILE) || defined(AF_CUTS)
     if (G.dbg & 256) return AF_ST_UNALIGNED;          // ... after the chaining DP
 #endif
-    // ---- chain ends and starts (chain.hpp:115-164) ----
-    for (uint32_t i = lane; i < na; i += GW) L.t[i] = 0;
-    __syncthreads();
-    for (uint32_t i = lane; i < na; i += GW) if (L.p[i] >= 0) L.t[L.p[i]] = 1;
-    __syncthreads();
-    uint32_t ns = 0;
-    for (uint32_t i0 = 0; i0 < na; i0 += GW) {
-        const uint32_t i = i0 + lane;
-        const bool is_end = i < na && L.t[i] == 0 && L.msc[i] > P.min_chain_score;
-        af_start_t st; st.f = 0; st.j = 0;
-        if (is_end) { uint32_t j = i; while (L.f[j] < L.msc[j]) j = (uint32_t)L.p[j]; st.f = L.f[j]; st.j = (int32_t)j; }
-        const unsigned long long bal = g.ballot(is_end);
-        const uint32_t at = ns + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (is_end && at < (uint32_t)WT::MC) L.starts[at] = st;
-        ns += (uint32_t)__popcll(bal);
-    }
-    if (ns > (uint32_t)WT::MC) return 0xFFu;          // does not fit this instance
-    if (ns == 0) return AF_ST_UNALIGNED;
-    __syncthreads();
-    // std::sort(chain_starts, greater<pair>) (chain.hpp:376): elements that compare equal are identical pairs (two chain ends can
-    // lead back to the same start), so any sort gives the reference's array: by rank, equal elements in index order
-    {
-        af_start_t v[(WT::MC + GT::W - 1) / GT::W]; uint32_t rk[(WT::MC + GT::W - 1) / GT::W];
-#pragma unroll
-        for (int q = 0; q < (WT::MC + GT::W - 1) / GT::W; ++q) {
-            const uint32_t s = (uint32_t)lane + GW * q;
-            rk[q] = 0;
-            if (s < ns) { v[q] = L.starts[s]; for (uint32_t k = 0; k < ns; ++k) { const af_start_t w = L.starts[k]; rk[q] += (w.f > v[q].f || (w.f == v[q].f && (w.j > v[q].j || (w.j == v[q].j && k < s)))) ? 1u : 0u; } }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < (WT::MC + GT::W - 1) / GT::W; ++q) if ((uint32_t)lane + GW * q < ns) L.starts[rk[q]] = v[q];
-        __syncthreads();
-    }
-#if defined(AF_PROFILE) || defined(AF_CUTS)
-    if (G.dbg & 512) return AF_ST_UNALIGNED;          // ... after the chain starts
-#endif
-    // ---- backtracking (chain.hpp:166-200), one lane per run, every lane over the sorted starts of its run in order ----
-    for (uint32_t i = lane; i < na; i += GW) L.t[i] = 0;
-    __syncthreads();
-    for (uint32_t k = lane; k < n_runs; k += GW) {
-        const uint32_t fb = L.run_start[k], fe = L.run_start[k + 1];
-        uint32_t used = fb;                                   // a run's chains use at most one pool entry per anchor and one more per start
-        for (uint32_t s = 0; s < ns; ++s) used += (uint32_t)L.starts[s].j < fb ? 1u : 0u;
-        // every lane goes through the sorted starts looking for those of its run; the lanes look first and then walk their chains TOGETHER (a lane that walked
-        // as soon as it had found a start did so alone - the others were at other starts: 13 runs, 13 walks one after the other, 1330 of the kernel's 4980
-        // instructions per read; profiles/r04d)
-        uint32_t s = 0;
-        while (true) {
-            while (s < ns && ((uint32_t)L.starts[s].j < fb || (uint32_t)L.starts[s].j >= fe)) ++s;
-            if (s >= ns) break;
-            const af_start_t st = L.starts[s];
-            long long j = st.j;
-            uint32_t cnt = 0;
-            const uint32_t off = used;
-            const uint32_t mate0 = L.mem[L.anch[j] >> 40].mate;
-            uint32_t paired = 0;                              // anchors of both mates (chain.hpp:186): only the paired-end path looks at it
-            do { paired |= L.mem[L.anch[j] >> 40].mate != mate0 ? 1u : 0u; L.pool[used++] = (uint16_t)j; cnt++; L.t[j] = 1; j = L.p[j]; } while (j >= 0 && L.t[j] == 0);
-            bool keep = false;
-            if (j < 0) keep = (long long)cnt >= P.min_chain_length;
-            else if ((long long)st.f - L.f[j] >= P.min_chain_score) keep = (long long)cnt >= P.min_chain_length;
-            L.s_off[s] = (uint16_t)off; L.s_cnt[s] = (uint16_t)(keep ? (cnt | (paired << 15)) : 0u);          // (cnt <= MA < 2^15)
-            ++s;
-        }
-    }
-    __syncthreads();
-#if defined(AF_PROFILE) || defined(AF_CUTS)
-    if (G.dbg & 1024) return AF_ST_UNALIGNED;         // ... after the backtracking
-#endif
+    // ---- chain ends, starts, backtracking, chains of ONE track (chain.hpp:115-200, 363-400; the second track: 640-700): its f / msc / p / t arrays, where its
+    // chains' anchors go in the pool, and how its starts are ordered - std::greater<pair> (ties are identical pairs: any sort gives the reference's array, by
+    // rank) or, with -Z, by score alone (chain_start_cmp, chain.hpp:663-668: ties in libstdc++'s order - the introsort emulation).  Returns false when the
+    // instance's capacities do not hold the track.
     uint32_t n_chains = 0;
-    for (uint32_t s0 = 0; s0 < ns; s0 += GW) {
-        const uint32_t sx = s0 + lane;
-        const bool keep = sx < ns && L.s_cnt[sx] > 0;
-        const unsigned long long bal = g.ballot(keep);
-        if (keep) {
-            af_chain_t c;
-            c.score = L.starts[sx].f; c.mate = L.mem[L.anch[L.starts[sx].j] >> 40].mate | ((uint32_t)(L.s_cnt[sx] >> 15) << 8); c.off = L.s_off[sx]; c.cnt = L.s_cnt[sx] & 0x7FFFu;
-            L.chains[n_chains + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = c;
+    auto track = [&](int32_t* F, int32_t* MSC, int16_t* PP, int16_t* TT, uint32_t pool0, bool by_score_alone, uint32_t& n_starts) -> bool {
+        for (uint32_t i = lane; i < na; i += GW) TT[i] = 0;
+        __syncthreads();
+        for (uint32_t i = lane; i < na; i += GW) if (PP[i] >= 0) TT[PP[i]] = 1;
+        __syncthreads();
+        uint32_t ns = 0;
+        for (uint32_t i0 = 0; i0 < na; i0 += GW) {
+            const uint32_t i = i0 + lane;
+            const bool is_end = i < na && TT[i] == 0 && MSC[i] > P.min_chain_score;
+            af_start_t st; st.f = 0; st.j = 0;
+            if (is_end) { uint32_t j = i; while (F[j] < MSC[j]) j = (uint32_t)PP[j]; st.f = F[j]; st.j = (int32_t)j; }
+            const unsigned long long bal = g.ballot(is_end);
+            const uint32_t at = ns + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (is_end && at < (uint32_t)WT::MC) L.starts[at] = st;
+            ns += (uint32_t)__popcll(bal);
         }
-        n_chains += (uint32_t)__popcll(bal);
-    }
+        n_starts = ns;
+        if (ns > (uint32_t)WT::MC) return false;          // does not fit this instance
+        __syncthreads();
+        if (ns == 0) return true;
+        if (by_score_alone) {          // (t, s_off and this track's part of the pool are free: scratch of the sort)
+            af_wave_sort<(WT::MC + GT::W - 1) / GT::W>(g, L.starts, ns, L.stack, reinterpret_cast<uint16_t*>(TT), L.s_off, reinterpret_cast<uint32_t*>(L.pool + pool0), [](const af_start_t& x) { return -(int64_t)x.f; });
+        } else {
+            af_start_t v[(WT::MC + GT::W - 1) / GT::W]; uint32_t rk[(WT::MC + GT::W - 1) / GT::W];
+#pragma unroll
+            for (int q = 0; q < (WT::MC + GT::W - 1) / GT::W; ++q) {
+                const uint32_t s = (uint32_t)lane + GW * q;
+                rk[q] = 0;
+                if (s < ns) { v[q] = L.starts[s]; for (uint32_t k = 0; k < ns; ++k) { const af_start_t w = L.starts[k]; rk[q] += (w.f > v[q].f || (w.f == v[q].f && (w.j > v[q].j || (w.j == v[q].j && k < s)))) ? 1u : 0u; } }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < (WT::MC + GT::W - 1) / GT::W; ++q) if ((uint32_t)lane + GW * q < ns) L.starts[rk[q]] = v[q];
+            __syncthreads();
+        }
+        // backtracking (chain.hpp:166-200), one lane per run, every lane over the sorted starts of its run in order
+        for (uint32_t i = lane; i < na; i += GW) TT[i] = 0;
+        __syncthreads();
+        for (uint32_t k = lane; k < n_runs; k += GW) {
+            const uint32_t fb = L.run_start[k], fe = L.run_start[k + 1];
+            uint32_t used = pool0 + fb;                           // a run's chains use at most one pool entry per anchor and one more per start
+            for (uint32_t s = 0; s < ns; ++s) used += (uint32_t)L.starts[s].j < fb ? 1u : 0u;
+            // every lane goes through the sorted starts looking for those of its run; the lanes look first and then walk their chains TOGETHER (a lane that walked
+            // as soon as it had found a start did so alone - the others were at other starts: 13 runs, 13 walks one after the other, 1330 of the kernel's 4980
+            // instructions per read; profiles/r04d)
+            uint32_t s = 0;
+            while (true) {
+                while (s < ns && ((uint32_t)L.starts[s].j < fb || (uint32_t)L.starts[s].j >= fe)) ++s;
+                if (s >= ns) break;
+                const af_start_t st = L.starts[s];
+                long long j = st.j;
+                uint32_t cnt = 0;
+                const uint32_t off = used;
+                const uint32_t mate0 = L.mem[L.anch[j] >> 40].mate;
+                uint32_t paired = 0;                              // anchors of both mates (chain.hpp:186): only the paired-end path looks at it
+                do { paired |= L.mem[L.anch[j] >> 40].mate != mate0 ? 1u : 0u; L.pool[used++] = (uint16_t)j; cnt++; TT[j] = 1; j = PP[j]; } while (j >= 0 && TT[j] == 0);
+                bool keep = false;
+                if (j < 0) keep = (long long)cnt >= P.min_chain_length;
+                else if ((long long)st.f - F[j] >= P.min_chain_score) keep = (long long)cnt >= P.min_chain_length;
+                L.s_off[s] = (uint16_t)off; L.s_cnt[s] = (uint16_t)(keep ? (cnt | (paired << 15)) : 0u);          // (cnt <= MA < 2^15)
+                ++s;
+            }
+        }
+        __syncthreads();
+        uint32_t kept = 0;
+        for (uint32_t s0 = 0; s0 < ns; s0 += GW) {
+            const uint32_t sx = s0 + lane;
+            const bool keep = sx < ns && L.s_cnt[sx] > 0;
+            const unsigned long long bal = g.ballot(keep);
+            const uint32_t at = n_chains + kept + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (keep && at < (uint32_t)WT::MC) {
+                af_chain_t c;
+                c.score = L.starts[sx].f; c.mate = L.mem[L.anch[L.starts[sx].j] >> 40].mate | ((uint32_t)(L.s_cnt[sx] >> 15) << 8); c.off = L.s_off[sx]; c.cnt = L.s_cnt[sx] & 0x7FFFu;
+                L.chains[at] = c;
+            }
+            kept += (uint32_t)__popcll(bal);
+        }
+        n_chains += kept;
+        __syncthreads();
+        return n_chains <= (uint32_t)WT::MC;
+    };
+    uint32_t ns1 = 0, ns2 = 0;
+    if (!track(L.f, L.msc, L.p, L.t, 0u, WT::SEC && sec_on, ns1)) return 0xFFu;
+    if (ns1 == 0) return AF_ST_UNALIGNED;          // (no chain start: not chained, whatever the second track holds - chain.hpp:640)
+#if defined(AF_PROFILE) || defined(AF_CUTS)
+    if (G.dbg & (512 | 1024)) return AF_ST_UNALIGNED;          // timing experiment: stop after the chains of the first track
+#endif
+    if (WT::SEC && sec_on) { if (!track(L.f2, L.msc2, L.p2, L.t2, (uint32_t)(WT::MA + WT::MC), true, ns2)) return 0xFFu; }
     __syncthreads();
     // std::sort of the chains by score (chain.hpp:402): ties
     if (G.dbg & 64) {
@@ -583,10 +617,11 @@ __device__ __forceinline__ uint32_t af_cand_anchors(WT& L, af_cand_t& C, uint32_
 
 // One chain to score (fill_chain, part 1: aligner_ksw2.hpp:2782-2979) by ONE lane: its anchors left to right into the plan's pool, the gaps between
 // them classified (closed forms need no DP: a pure insertion, the "deletion" the reference scores with l = 0, one base against one base), and its DP
-// problems [left extension][right extension][gap fills in anchor order].  WRITE = false: count the problems (and write the anchors); WRITE = true: write
-// the problems from task0 on.  Returns the number of problems, or 0xFFFFFFFF when one is beyond the DP tiles (the read leaves the staged path).
-template <bool WRITE, class WT>
+// problems [left extension][right extension][gap fills in anchor order].  MODE 0: count the problems and classify the gaps; MODE 1: write the problems from
+// task0 on; MODE 2: both at once.  Returns the number of problems, or 0xFFFFFFFF when one is beyond the DP tiles (the read leaves the staged path).
+template <int MODE, class WT>
 __device__ __forceinline__ uint32_t af_build_cand(const af_args_t& G, WT& L, af_cand_t& C, uint64_t off, uint32_t m, uint32_t task0) {
+    constexpr bool WRITE = MODE != 0, CLASSIFY = MODE != 1;          // MODE 0: count and classify; 1: write what MODE 0 classified; 2: both in one pass (plan_kernel)
     const ac_params_t& P = G.A.P;
     auto& PL = L.plan;
     struct { uint32_t cnt; } ch; ch.cnt = C.n_an;          // the anchors are in the plan's pool already (af_cand_anchors / the paired path's share of a chain)
@@ -614,7 +649,7 @@ __device__ __forceinline__ uint32_t af_build_cand(const af_args_t& G, WT& L, af_
         }
         ++nt;
     };
-    if (!WRITE) { C.has_lc = C.has_rc = C.n_gap_tasks = 0; C.overlap = 0; }
+    if (CLASSIFY) { C.has_lc = C.has_rc = C.n_gap_tasks = 0; C.overlap = 0; }
     const af_anchor_t first = AN[0], last = AN[ch.cnt - 1];
     const uint32_t strand = C.strand;
 #define qseg(a, len, reversed, q_off, qmode) af_qseg(off, m, strand, (a), (len), (reversed), (q_off), (qmode))
@@ -626,7 +661,7 @@ __device__ __forceinline__ uint32_t af_build_cand(const af_args_t& G, WT& L, af_
         uint64_t q_off; int qmode;
         qseg(0, lcs_len, true, q_off, qmode);
         add(q_off, lcs_len, qmode, lc_len ? lc_occ + lc_len - 1 : 0, lc_len, DP_T_REV, DP_EZ_EXTZ_ONLY | DP_EZ_RIGHT);
-        if (!WRITE) C.has_lc = 1;
+        if (CLASSIFY) C.has_lc = 1;
     }
     if (rcs_len > 0) {
         const uint64_t rc_occ = last.occ + last.len;
@@ -634,10 +669,10 @@ __device__ __forceinline__ uint32_t af_build_cand(const af_args_t& G, WT& L, af_
         uint64_t q_off; int qmode;
         qseg(rcs_occ, rcs_len, false, q_off, qmode);
         add(q_off, rcs_len, qmode, rc_occ, rc_len, 0, DP_EZ_EXTZ_ONLY | DP_EZ_RIGHT);
-        if (!WRITE) C.has_rc = 1;
+        if (CLASSIFY) C.has_rc = 1;
     }
     uint64_t last_ref = mem_pos + first.len, last_seq = (uint64_t)first.idx + first.len;
-    if (!WRITE) {
+    if (CLASSIFY) {
         for (uint32_t k = 1; k < ch.cnt; ++k) {                  // overlapping anchors: the global realignment of the whole read (aligner_ksw2.hpp:2888-2900, 2984-2996)
             const af_anchor_t ak = AN[k];
             if (last_ref > ak.occ || last_seq > ak.idx) C.overlap = 1;
@@ -650,7 +685,7 @@ __device__ __forceinline__ uint32_t af_build_cand(const af_args_t& G, WT& L, af_
         const af_anchor_t ak = AN[k], ap = AN[k - 1];
         af_anchor_t& GP = AN[k - 1];
         const uint64_t ref_occ = ak.occ, seq_occ = ak.idx;
-        if (WRITE) {                                             // the gaps were classified by the counting pass
+        if (MODE == 1) {                                         // the gaps were classified by the counting pass
             if (ap.gap_kind == AF_GAP_TASK) {
                 const uint64_t cc_occ = ap.occ + ap.len, cc_len = ref_occ - cc_occ;
                 const uint64_t ccs_pos = (uint64_t)ap.idx + ap.len, ccs_len = seq_occ - ccs_pos;
@@ -847,6 +882,44 @@ __device__ __forceinline__ void af_plan_read(const af_args_t& G, WT& L, const GT
 #if defined(AF_PROFILE) || defined(AF_CUTS)
             if (G.dbg & 16) status = AF_ST_UNALIGNED; else      // ... after the lifts
 #endif
+            if (LEVEL == 0 && (uint32_t)WT::MC <= AF_CTAB && (uint32_t)WT::MA <= AF_PLAN_AN && G.ctab != nullptr) {
+                // The selection loop and the plan of the DP problems are one-lane work (a third of this kernel's instructions at one read per wavefront): the chains
+                // go to HBM - a table entry per chain and ALL anchors, chain by chain and left to right, straight into the plan's anchor array - and plan_kernel
+                // does that work with one LANE per read (64 reads per wavefront).
+                const uint32_t n_chains = L.n_chains_sh;
+                af_ctab_t* const CT = G.ctab + (size_t)r_in * AF_CTAB;
+                af_anchor_t* const AN = G.plans[r_in].an;
+                uint32_t an0 = 0;                                  // exclusive prefix sum of the chains' anchor counts over the lanes
+                for (uint32_t c0 = 0; c0 < n_chains; c0 += GW) {
+                    const uint32_t ci = c0 + (uint32_t)lane;
+                    const uint32_t cnt = ci < n_chains ? L.chains[ci].cnt : 0u;
+                    uint32_t incl = cnt;
+                    for (int o = 1; o < (int)GW; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += x; }
+                    if (ci < n_chains) {
+                        const af_chain_t ch = L.chains[ci];
+                        const uint32_t at = an0 + incl - cnt;
+                        uint32_t strand = 0;
+                        for (uint32_t k = 0; k < ch.cnt; ++k) {          // stored right to left (chain.hpp:166-200); fill_chain wants left to right
+                            const uint64_t aw = L.anch[L.pool[ch.off + ch.cnt - 1 - k]];
+                            const af_mem_t mk = L.mem[aw >> 40];
+                            af_anchor_t X; X.occ = AF_X(aw) - mk.len + 1; X.len = mk.len; X.idx = mk.idx; X.gap_val = 0; X.gap_kind = AF_GAP_NONE; X.pad = 0;
+                            AN[at + k] = X;
+                            if (k == 0) strand = (mk.mate & 2) ? 1u : 0u;
+                        }
+                        af_ctab_t E; E.score = ch.score; E.an0 = (uint16_t)at; E.cnt = (uint8_t)ch.cnt; E.strand = (uint8_t)strand; E.left_ref = L.left_ref[ci];
+                        CT[ci] = E;
+                    }
+                    an0 += (uint32_t)g.shfl((int)incl, (int)GW - 1);
+                }
+                if (lane == 0) {          // the plan's header so far; plan_kernel completes it
+                    af_plan_t& PH = G.plans[r_in];
+                    PH.status = AF_ST_CHAINS; PH.n_cand = 0; PH.n_chains = (uint16_t)n_chains; PH.final_cand = 0; PH.n_alt = 0; PH.pad = 0; PH.score2 = 0; PH.ref_pos = PH.ref_len = 0; PH.tb0 = 0; PH.pad2 = 0;
+                    PH.min_score = A.min_score_of_len[m <= A.max_len ? m : A.max_len];
+                    G.ntasks[r_in] = 0;
+                }
+                __syncthreads();
+                return;
+            }
             status = af_plan_cands(G, L, off, m, g);
             __syncthreads();
             if (status == 0xFFu) too_big = true;              // the plan does not fit this instance
@@ -981,18 +1054,83 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     }
 }
 
+// plan_kernel: one LANE per read whose chains chain_plan_kernel's LEVEL-0 instance has left in HBM (status AF_ST_CHAINS): the chain-selection loop ahead of its
+// scores (aligner_ksw2.hpp:409-462: which chains get scored - af_plan_cands' loop, with the capacities of the largest instance), then for every chain to score
+// its gaps and DP problems (af_build_cand, one pass) straight into the read's task slots and plan.  The lists the loop keeps (distinct scores, the chains
+// check_left_MEM has recorded) live in the lane's own LDS columns.
+struct af_plan_view_t { af_anchor_t* an; moni_dp_task_t* tasks; };
+struct af_view_t { af_plan_view_t plan; };
+__global__ void __launch_bounds__(256) plan_kernel(const af_args_t G) {
+    __shared__ int32_t s_diff[8][256];
+    __shared__ uint8_t s_left[AF_CTAB][256];          // (the recorded chains' coordinates are read again from the table: 16-byte entries of the lane's own 768 bytes)
+    const int lane = threadIdx.x;
+    const ak_args_t& A = G.A;
+    const ac_params_t& P = A.P;
+    const uint64_t r_in = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r_in >= A.n_reads) return;
+    af_plan_t& PL = G.plans[r_in];
+    if (PL.status != AF_ST_CHAINS) return;
+    const uint64_t r = A.read_lo + r_in;
+    const uint64_t off = A.offs[r];
+    const uint32_t m = (uint32_t)(A.offs[r + 1] - off);
+    const uint32_t n_chains = PL.n_chains;
+    const af_ctab_t* const CT = G.ctab + (size_t)r_in * AF_CTAB;
+    const uint32_t t0 = (uint32_t)r_in * AF_MAX_TASKS_READ;
+    af_view_t V; V.plan.an = PL.an; V.plan.tasks = G.tasks + t0;
+    uint32_t status = AF_ST_CAND, why = AF_WHY_N;
+    uint32_t n_diff = 0, n_left = 0, n_cand = 0, n_tasks = 0;
+    const uint32_t check_k = P.check_k < 8u ? P.check_k : 8u;          // (the loop ends at check_k distinct scores; the lane's list holds 8)
+    if (P.check_k > 8u) { status = AF_ST_FALLBACK; why = AF_WHY_CAPACITY; }
+    for (uint32_t ci = 0; ci < n_chains && n_diff < check_k && status == AF_ST_CAND; ++ci) {
+        const af_ctab_t ch = CT[ci];
+        { bool f = false; for (uint32_t q = 0; q < n_diff; ++q) f = f || s_diff[q][lane] == ch.score; if (!f) s_diff[n_diff++][lane] = ch.score; }
+        if (P.left_mem_check) {                                  // check_left_MEM (aligner_ksw2.hpp:553-597)
+            bool seen = false;
+            for (uint32_t k = 0; k < n_left; ++k) {
+                const af_ctab_t o = CT[s_left[k][lane]];
+                const uint64_t d = o.left_ref > ch.left_ref ? o.left_ref - ch.left_ref : ch.left_ref - o.left_ref;
+                if (d < P.region_dist && o.score == ch.score) seen = true;
+            }
+            if (seen) continue;
+            s_left[n_left][lane] = (uint8_t)ci; ++n_left;
+        }
+        if (n_diff >= check_k) continue;                       // not scored; the loop condition ends the loop
+        if (n_cand >= AF_MAX_CAND) { status = AF_ST_FALLBACK; why = AF_WHY_CANDS; break; }
+        af_cand_t C;
+        C.chain_score = ch.score; C.chain_idx = (uint16_t)ci; C.n_an = ch.cnt; C.task0 = t0 + n_tasks; C.has_lc = C.has_rc = C.n_gap_tasks = 0; C.overlap = 0; C.score = 0; C.gtask = 0;
+        C.strand = ch.strand; C.an0 = ch.an0; C.pad = 0; C.pad2 = 0;
+        // its problems behind those of the chains before it; at most AF_MAX_TASKS_READ in all (a chain has at most 2 + n_an - 1)
+        if (n_tasks + 1u + ch.cnt > AF_MAX_TASKS_READ) { status = AF_ST_FALLBACK; why = AF_WHY_CAPACITY; break; }
+        const uint32_t nt = af_build_cand<2>(G, V, C, off, m, n_tasks);
+        if (nt == 0xFFFFFFFFu) { status = AF_ST_FALLBACK; why = AF_WHY_TASK_SIZE; break; }
+        n_tasks += nt;
+        PL.cand[n_cand++] = C;
+    }
+    if (status == AF_ST_FALLBACK) {
+        atomicAdd(&G.ctr[AFC_WHY + why], 1u);
+        G.fb_list[atomicAdd(G.fb_n, 1u)] = (uint32_t)r;
+        PL.status = AF_ST_FALLBACK; PL.n_cand = 0; PL.n_chains = 0;
+        G.ntasks[r_in] = 0;
+        return;
+    }
+    PL.status = AF_ST_CAND; PL.n_cand = (uint8_t)n_cand;
+    G.ntasks[r_in] = (uint8_t)n_tasks;
+}
+
 // bin_tasks_kernel: the reads' DP problems go to the queues of their tile / query-length bins.  A block takes AF_BT_READS reads (rounds of 4 reads x 64
 // task slots, one thread per slot), counts per bin in LDS and bumps every bin's global counter once: a few thousand atomics per address and launch where
 // one per task was the bound of chain_plan_kernel (and one per bin and 4 reads, with 35 bins instead of 18, was 2.9 ms per 1 M reads: profiles/r04e).
 #define AF_BT_READS 32u
+__device__ __forceinline__ void af_global_band(const dp_launch_t& D, const moni_dp_task_t& T, int& dmin, int& dmax);
+__device__ __forceinline__ void af_ext_band(const dp_launch_t& D, const moni_dp_task_t& T, int& dmin, int& dmax);
 __global__ void __launch_bounds__(256) bin_tasks_kernel(const af_args_t G) {
-    __shared__ uint32_t cnt[AF_NBIN], base[AF_NBIN], ovf[AF_BT_READS];
+    __shared__ uint32_t cnt[AF_NBIN + 1], base[AF_NBIN + 1], ovf[AF_BT_READS];
     static_assert(AF_MAX_TASKS_READ == 64, "bin_tasks_kernel: 4 reads x 64 slots per round");
     constexpr uint32_t ROUNDS = AF_BT_READS / 4;
     const uint32_t tid = threadIdx.x;
     const uint64_t n_reads = G.A.n_reads;
     if (blockIdx.x == 0 && tid == 0) G.ctr[AFC_TASKS] = (uint32_t)n_reads * AF_MAX_TASKS_READ;      // the global problems (global_task_kernel) come after the slots
-    if (tid < AF_NBIN) cnt[tid] = 0;
+    if (tid <= AF_NBIN) cnt[tid] = 0;
     if (tid < AF_BT_READS) ovf[tid] = 0;
     __syncthreads();
     const uint32_t k = tid & 63u;
@@ -1003,17 +1141,25 @@ __global__ void __launch_bounds__(256) bin_tasks_kernel(const af_args_t G) {
         const uint64_t r_in = (uint64_t)blockIdx.x * AF_BT_READS + 4 * q + (tid >> 6);
         valid[q] = r_in < n_reads && k < (uint32_t)G.ntasks[r_in];
         bin[q] = 0; local[q] = 0;
-        if (valid[q]) { const moni_dp_task_t t = G.tasks[(uint32_t)r_in * AF_MAX_TASKS_READ + k]; bin[q] = af_bin_of(t.qlen, t.tlen); local[q] = atomicAdd(&cnt[bin[q]], 1u); }
+        if (valid[q]) {
+            const uint32_t id = (uint32_t)r_in * AF_MAX_TASKS_READ + k;
+            const moni_dp_task_t t = G.tasks[id];
+            bin[q] = af_bin_of(t.qlen, t.tlen);
+            // a problem of the large tile - an extension, or a gap fill (a small global problem) - goes to a provisional list: band_tasks_kernel, one lane per entry,
+            // bounds its diagonals and queues it for dp_band_kernel or for the tile (MONI_AF_DBG=131072: the tile kernels take all)
+            if (bin[q] < AF_BIN_SMALL && !(G.dbg & 0x20000u)) bin[q] = AF_BIN_PROV;
+            local[q] = atomicAdd(&cnt[bin[q]], 1u);
+        }
     }
     __syncthreads();
-    if (tid < AF_NBIN && cnt[tid]) base[tid] = atomicAdd(&G.ctr[AFC_BINS + tid], cnt[tid]);
-    if (tid == 0) { uint32_t n = 0; for (uint32_t b = 0; b < AF_NBIN; ++b) n += cnt[b]; if (n) atomicAdd(&G.ctr[AFC_NT], n); }
+    if (tid <= AF_NBIN && cnt[tid]) base[tid] = atomicAdd(&G.ctr[AFC_BINS + tid], cnt[tid]);
+    if (tid == 0) { uint32_t n = 0; for (uint32_t b = 0; b <= AF_NBIN; ++b) n += cnt[b]; if (n) atomicAdd(&G.ctr[AFC_NT], n); }
     __syncthreads();
 #pragma unroll
     for (uint32_t q = 0; q < ROUNDS; ++q) if (valid[q]) {
         const uint32_t id = (uint32_t)((uint64_t)blockIdx.x * AF_BT_READS + 4 * q + (tid >> 6)) * AF_MAX_TASKS_READ + k;
         const uint32_t at = base[bin[q]] + local[q];
-        if (at < G.bin_cap) { G.bin_q[(size_t)bin[q] * G.bin_cap + at] = id; G.task_pos[id] = at | (bin[q] << 26); }
+        if (at < G.bin_cap) { G.bin_q[(size_t)bin[q] * G.bin_cap + at] = id; G.task_pos[id] = at | (bin[q] << AF_POS_BITS); }
         else ovf[4 * q + (tid >> 6)] = 1;                      // the queue is full: the read goes to align_kernel
     }
     __syncthreads();
@@ -1316,7 +1462,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
 // ------------------------------------------------------------------------------------------------------------------------------
 #define AF_BTCAP (AF_QCAP + 2 * AF_BANDW)
 template <int W>
-__global__ void __launch_bounds__(64) dp_band_kernel(const af_args_t G) {
+__global__ void __launch_bounds__(64) dp_band_kernel(const af_args_t G, const uint32_t grp) {
     __shared__ uint8_t qs[AF_QCAP][64];          // query codes of the lane's two problems: low one in bits 0-1, high one in bits 4-5
     __shared__ uint8_t ts[AF_BTCAP][64];         // target codes likewise
     static_assert(W % 4 == 0 && W <= 16, "a lane's target window is one 32-bit word of 2-bit codes");
@@ -1325,11 +1471,11 @@ __global__ void __launch_bounds__(64) dp_band_kernel(const af_args_t G) {
     const uint32_t qo2 = af_pk2(D.qo), e2 = af_pk2(D.e), scM2 = af_pk2(D.sc_mch), scX2 = af_pk2(D.sc_mis), neg2 = af_pk2(AF_NEG16);
     const int32_t qo = D.qo, e = D.e;
     uint32_t chunk0 = 0;
-    for (uint32_t g = 0; g < AF_GRP_BAND; ++g) chunk0 += G.ctr[AFC_NCHUNKS + g];
-    const uint32_t n_chunks = G.ctr[AFC_NCHUNKS + AF_GRP_BAND];
+    for (uint32_t g = 0; g < grp; ++g) chunk0 += G.ctr[AFC_NCHUNKS + g];
+    const uint32_t n_chunks = G.ctr[AFC_NCHUNKS + grp];
     while (true) {
         uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(&G.ctr[AFC_CURSOR + AF_GRP_BAND], 1u);
+        if (lane == 0) c = atomicAdd(&G.ctr[AFC_CURSOR + grp], 1u);
         c = (uint32_t)__shfl((int)c, 0);
         if (c >= n_chunks) break;
         const af_chunk_t ch = G.chunks[chunk0 + c];
@@ -1342,7 +1488,7 @@ __global__ void __launch_bounds__(64) dp_band_kernel(const af_args_t G) {
         for (int h = 0; h < 2; ++h) {
             has[h] = (uint32_t)lane + 64u * h < ch.n;
             task[h].qlen = 0; task[h].tlen = 0; task[h].q_off = 0; task[h].t_off = 0; task[h].reserved = 0; task[h].flag = 0;
-            if (has[h]) { tid[h] = G.bin_q[(size_t)ch.bin * G.bin_cap + ch.start + lane + 64 * h]; task[h] = G.tasks[tid[h]]; dlo[h] = (int)(int16_t)((uint32_t)task[h].flag >> 16); }
+            if (has[h]) { tid[h] = G.bin_q[(size_t)ch.bin * G.bin_cap + ch.start + lane + 64 * h]; task[h] = G.tasks[tid[h]]; dlo[h] = (int)(int16_t)((uint32_t)task[h].reserved >> 16); }
             maxq = task[h].qlen > maxq ? task[h].qlen : maxq; maxt = task[h].tlen > maxt ? task[h].tlen : maxt;
         }
         for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(maxq, o); maxq = w > maxq ? w : maxq; const int w2 = __shfl_xor(maxt, o); maxt = w2 > maxt ? w2 : maxt; }
@@ -1396,7 +1542,8 @@ __global__ void __launch_bounds__(64) dp_band_kernel(const af_args_t G) {
         uint32_t* __restrict__ dir = reinterpret_cast<uint32_t*>(G.dirs + (nodir ? 0ull : ch.dir_off)) + lane;
         const int qe0 = task[0].qlen - 1, qe1 = task[1].qlen - 1;
         const int ks0 = (task[0].tlen - 1) - qe0 - dlo[0], ks1 = (task[1].tlen - 1) - qe1 - dlo[1];          // the corner's slot at the last column
-        int score[2] = {AF_NEG_INF, AF_NEG_INF};
+        const bool ext0 = (task[0].flag & DP_EZ_EXTZ_ONLY) != 0, ext1 = (task[1].flag & DP_EZ_EXTZ_ONLY) != 0;      // an extension: the last column's maximum and its first row
+        int score[2] = {AF_NEG_INF, AF_NEG_INF}, mqe[2] = {AF_NEG_INF, AF_NEG_INF}, mqe_t[2] = {-1, -1};
         for (int j = 0; j < maxq; ++j) {
             const uint32_t qb = qs[j][lane];
             const uint32_t a0 = tw[0] ^ ((qb & 3u) * 0x55555555u), a1 = tw[1] ^ (((qb >> 4) & 3u) * 0x55555555u);
@@ -1425,8 +1572,16 @@ __global__ void __launch_bounds__(64) dp_band_kernel(const af_args_t G) {
             if (j == qe0 || j == qe1) {
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
-                    if (j == qe0 && k == ks0) score[0] = af_lo16(Hb[k]);
-                    if (j == qe1 && k == ks1) score[1] = af_hi16(Hb[k]);
+                    if (j == qe0) {
+                        const int hv = af_lo16(Hb[k]), i = qe0 + dlo[0] + k;
+                        if (k == ks0) score[0] = hv;
+                        if (ext0 && i >= 0 && i < task[0].tlen && hv > mqe[0]) { mqe[0] = hv; mqe_t[0] = i; }
+                    }
+                    if (j == qe1) {
+                        const int hv = af_hi16(Hb[k]), i = qe1 + dlo[1] + k;
+                        if (k == ks1) score[1] = hv;
+                        if (ext1 && i >= 0 && i < task[1].tlen && hv > mqe[1]) { mqe[1] = hv; mqe_t[1] = i; }
+                    }
                 }
             }
             // the rows move down by one with the next column
@@ -1436,10 +1591,12 @@ __global__ void __launch_bounds__(64) dp_band_kernel(const af_args_t G) {
         unsigned long long cells = 0, rq = 0, cut = 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) if (has[h]) {
-            af_res_t R; R.mqe = AF_NEG_INF; R.mqe_t = -1; R.score = score[h]; R.flags = 0;
-            if (wild[h] || score[h] == AF_NEG_INF) { R.score = AF_NEG_INF; R.flags = 1; }
+            const bool ext = (h ? ext1 : ext0);
+            af_res_t R; R.mqe = ext ? mqe[h] : AF_NEG_INF; R.mqe_t = ext ? mqe_t[h] : -1; R.score = ext ? AF_NEG_INF : score[h]; R.flags = 0;
+            if (wild[h] || (ext ? mqe_t[h] < 0 : score[h] == AF_NEG_INF)) { R.mqe = AF_NEG_INF; R.mqe_t = -1; R.score = AF_NEG_INF; R.flags = 1; }
             else {
-                cells += (unsigned long long)task[h].qlen * (unsigned long long)task[h].tlen; rq += ((unsigned long long)task[h].tlen << 32) | (unsigned long long)task[h].qlen;
+                const unsigned long long t_ref = (task[h].flag >> 16) ? (unsigned long long)(task[h].flag >> 16) : (unsigned long long)task[h].tlen;      // (an extension's target before the cut)
+                cells += (unsigned long long)task[h].qlen * t_ref; rq += (t_ref << 32) | (unsigned long long)task[h].qlen;
                 cut += (unsigned long long)task[h].qlen * (unsigned long long)(task[h].tlen < W ? task[h].tlen : W);
             }
             G.res[tid[h]] = R;
@@ -1521,6 +1678,33 @@ __device__ __forceinline__ void af_global_band(const dp_launch_t& D, const moni_
     if (D.e <= 0) { dmin = -q; dmax = t; }
 }
 
+// The same for an EXTENSION (EXTZ_ONLY: mqe = max_i H(i, qlen - 1), the first row that holds it, traceback from there): the path ends anywhere in the last
+// column, so only the lower bound's end is fixed - the diagonal itself, H(qlen - 1, qlen - 1) >= the sum of its match / mismatch scores.  A path that touches
+// diagonal D > 0 deletes at least D target bases (<= qlen sc_mch - qo - D e), one that touches D < 0 inserts at least |D| query bases and has that many fewer
+// diagonal steps (<= (qlen - |D|) sc_mch - qo - |D| e).  Rows that hold the maximum are reached by such paths: they lie in the band too.
+__device__ __forceinline__ void af_ext_band(const dp_launch_t& D, const moni_dp_task_t& T, int& dmin, int& dmax) {
+    const int q = T.qlen, t = T.tlen;
+    dmin = -q; dmax = t;
+    if (t < q || D.e <= 0) return;                         // (the target ends before the diagonal does: no bound from it)
+    const bool qrev = (T.reserved & DP_Q_REV) != 0, qcomp = (T.reserved & DP_Q_COMP) != 0, trev = (T.reserved & DP_T_REV) != 0;
+    af_bytes_t Q0 = af_bytes(D.reads, T.q_off, D.reads_limit, qrev), T0 = af_bytes(D.text, T.t_off, D.text_limit, trev);
+    int lb = 0;
+    for (int g = 0; 8 * g < q; ++g) {
+        const uint64_t vq = af_group(Q0, g), vt = af_group(T0, g);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (8 * g + u >= q) break;
+            uint32_t a = dp_nt4((uint32_t)(vq >> (8 * u)) & 0xFFu);
+            if (qcomp && a < 4) a = 3 - a;
+            const uint32_t c = dp_nt4((uint32_t)(vt >> (8 * u)) & 0xFFu);
+            lb += (a > 3 || c > 3) ? D.sc_N : a == c ? D.sc_mch : D.sc_mis;
+        }
+    }
+    const int G = D.sc_mch * q - D.qo - lb;
+    dmin = 0; dmax = 0;
+    if (G >= 0) { dmax = G / D.e; dmin = -(G / (D.e + D.sc_mch)); }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // global_task_kernel: chains with overlapping anchors are scored by one global alignment of the whole read against the window
 // their extensions give (aligner_ksw2.hpp:2984-2996, 3009-3015); one lane per read queues those problems
@@ -1585,7 +1769,7 @@ __global__ void __launch_bounds__(256) global_task_kernel(const af_args_t G) {
 // global_band_kernel: one lane per global problem (they lie behind the reads' task slots: [AFC_GT0, AFC_TASKS)).  The band of diagonals its optimal paths can
 // touch (af_global_band: a few for a read that differs from the window by substitutions - 77 % of the benchmark's global problems need at most 4 diagonals,
 // 99.8 % at most 16; profiles/r04e) decides the kernel: dp_band_kernel keeps AF_BANDW diagonals in registers and steps through qlen x AF_BANDW cells where
-// the full matrix has qlen x tlen; a problem with a wider band takes the full-matrix kernel as before.  The band's first diagonal rides in the task's flag word.
+// the full matrix has qlen x tlen; a problem with a wider band takes the full-matrix kernel as before.  The band's first diagonal rides in the upper half of the task's `reserved` word.
 __global__ void __launch_bounds__(256) global_band_kernel(const af_args_t G) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -1604,10 +1788,10 @@ __global__ void __launch_bounds__(256) global_band_kernel(const af_args_t G) {
         if (band) {          // the band widened to AF_BANDW diagonals around what is needed (never beyond what the matrix has)
             const int spare = AF_BANDW - W;
             dlo -= spare / 2;
-            T.flag = (T.flag & 0xFFFF) | (int)(((uint32_t)dlo & 0xFFFFu) << 16);
-            G.tasks[tid].flag = T.flag;
+            T.reserved = (T.reserved & 0xFFFF) | (int)(((uint32_t)dlo & 0xFFFFu) << 16);
+            G.tasks[tid].reserved = T.reserved;
         }
-        bin = (band ? AF_BIN_BAND : AF_BIN_GLOBAL) + (uint32_t)((T.qlen - 1) >> 4);
+        bin = band ? AF_BIN_GBAND + af_large_bin(T.qlen) : AF_BIN_GLOBAL + (uint32_t)((T.qlen - 1) >> 4);
     }
     uint32_t at = 0;
     unsigned long long rest = __ballot(need);
@@ -1621,7 +1805,7 @@ __global__ void __launch_bounds__(256) global_band_kernel(const af_args_t G) {
         if (need && bin == b) at = a0 + (uint32_t)__popcll(same & lt_mask);
         rest &= ~same;
     }
-    if (need && at < G.bin_cap) { G.bin_q[(size_t)bin * G.bin_cap + at] = tid; G.task_pos[tid] = at | (bin << 26); }
+    if (need && at < G.bin_cap) { G.bin_q[(size_t)bin * G.bin_cap + at] = tid; G.task_pos[tid] = at | (bin << AF_POS_BITS); }
     rest = __ballot(need);                             // the histogram of band widths, one bump per distinct class of the wave (one atomic per problem on the
     while (rest) {                                     // counter of the narrowest class - three in four fall into it - took 2.4 ms per 1 M reads: profiles/r04g)
         const int lead = __ffsll((long long)rest) - 1;
@@ -1629,6 +1813,48 @@ __global__ void __launch_bounds__(256) global_band_kernel(const af_args_t G) {
         const unsigned long long same = __ballot(need && hb == b);
         if (lane == lead) atomicAdd(&G.ctr[AFC_BANDH + b], (uint32_t)__popcll(same));
         rest &= ~same;
+    }
+}
+
+// band_tasks_kernel: one lane per problem of the provisional list (bin_tasks_kernel: extensions and gap fills of the large tile).  Its band of diagonals
+// (af_ext_band / af_global_band) - AF_BANDW or fewer: dp_band_kernel's queue of its query length, the band's first diagonal in the task record; else the
+// tile's.  (Bounding the band inside bin_tasks_kernel, whose lanes are task SLOTS - one in eight in use, a block's rounds one after the other - took
+// 7.3 ms per 1 M reads: profiles/r04h.)
+__global__ void __launch_bounds__(256) band_tasks_kernel(const af_args_t G) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const uint32_t n = G.ctr[AFC_BINS + AF_BIN_PROV] < G.bin_cap ? G.ctr[AFC_BINS + AF_BIN_PROV] : G.bin_cap;
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+    bool need = x < n;
+    uint32_t bin = 0, id = 0;
+    if (need) {
+        id = G.bin_q[(size_t)AF_BIN_PROV * G.bin_cap + x];
+        const moni_dp_task_t t = G.tasks[id];
+        int dlo, dhi;
+        if (t.flag & DP_EZ_EXTZ_ONLY) af_ext_band(G.A.D, t, dlo, dhi); else af_global_band(G.A.D, t, dlo, dhi);
+        const int W = dhi - dlo + 1;
+        bin = af_large_bin(t.qlen);
+        if (W <= AF_BANDW) {
+            dlo -= (AF_BANDW - W) / 2;
+            G.tasks[id].reserved = (t.reserved & 0xFFFF) | (int)(((uint32_t)dlo & 0xFFFFu) << 16);
+            bin += AF_BIN_BAND;
+        }
+    }
+    uint32_t at = 0;
+    unsigned long long rest = __ballot(need);
+    while (rest) {                                     // one bump per distinct bin of the wave
+        const int lead = __ffsll((long long)rest) - 1;
+        const uint32_t b = (uint32_t)__shfl((int)bin, lead);
+        const unsigned long long same = __ballot(need && bin == b);
+        uint32_t a0 = 0;
+        if (lane == lead) a0 = atomicAdd(&G.ctr[AFC_BINS + b], (uint32_t)__popcll(same));
+        a0 = (uint32_t)__shfl((int)a0, lead);
+        if (need && bin == b) at = a0 + (uint32_t)__popcll(same & lt_mask);
+        rest &= ~same;
+    }
+    if (need) {
+        if (at < G.bin_cap) { G.bin_q[(size_t)bin * G.bin_cap + at] = id; G.task_pos[id] = at | (bin << AF_POS_BITS); }
+        else { af_res_t R0; R0.mqe = AF_NEG_INF; R0.mqe_t = -1; R0.score = AF_NEG_INF; R0.flags = 1; G.res[id] = R0; }      // the queue is full: a result "not computed" sends the read to align_kernel (select_kernel)
     }
 }
 
@@ -1755,7 +1981,7 @@ __global__ void __launch_bounds__(256) traceback_kernel(const af_args_t G) {
     const uint32_t tid = G.tb_task[x];
     const moni_dp_task_t T = G.tasks[tid];
     const af_res_t R = G.res[tid];
-    const uint32_t bin = G.task_pos[tid] >> 26, pos = G.task_pos[tid] & ((1u << 26) - 1);
+    const uint32_t bin = G.task_pos[tid] >> AF_POS_BITS, pos = G.task_pos[tid] & ((1u << AF_POS_BITS) - 1);
     af_tb_t& O = G.tb[x];
     const af_dirs_t X = af_dir_of(G, bin, pos);
     const uint32_t tb = X.tb;
@@ -1769,8 +1995,8 @@ __global__ void __launch_bounds__(256) traceback_kernel(const af_args_t G) {
         cur_op = op; cur_len = len;
     };
     int state = 0;
-    const bool banded = bin >= AF_BIN_BAND;                          // dp_band_kernel's layout: slot = i - j - first diagonal of the band (the task's flag word)
-    const int band_lo = (int)(int16_t)((uint32_t)T.flag >> 16);
+    const bool banded = af_bin_banded(bin);                          // dp_band_kernel's layout: slot = i - j - first diagonal of the band (the task's flag word)
+    const int band_lo = (int)(int16_t)((uint32_t)T.reserved >> 16);
     while (i >= 0 && j >= 0) {
         uint32_t ps = (uint32_t)i / tb, ii = (uint32_t)i - ps * tb;
         if (banded) { const int kk = i - j - band_lo; if (kk < 0 || kk >= (int)tb) { ovf = true; break; } ps = 0; ii = (uint32_t)kk; }      // (a best path never leaves the band)
@@ -2327,13 +2553,15 @@ __global__ void gather_summary_kernel(const uint64_t* __restrict__ len, const ui
 // by tile, then the global problems: their records (global_task_kernel), their bands and queues (global_band_kernel), banded where a narrow band is proven,
 // the full matrix otherwise.  n_units: plans of the launch (reads or pairs).
 static inline void af_launch_dp(const af_args_t& G, hipStream_t sx, unsigned dp_grid, unsigned n_cu, uint64_t n_units) {
-    hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_SMALL);
+    if (!(G.dbg & 0x20000u)) hipLaunchKernelGGL(band_tasks_kernel, dim3((unsigned)((G.bin_cap + 255) / 256)), dim3(256), 0, sx, G);      // (the provisional list holds at most bin_cap problems)
+    hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_BAND);
     hipLaunchKernelGGL((dp_lane_kernel<AF_BLK, AF_QCAP, AF_LPASS>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE);
     hipLaunchKernelGGL((dp_lane_kernel<AF_TS, AF_TS, 1>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_SMALL);
-    hipLaunchKernelGGL(global_task_kernel, dim3((unsigned)((n_units + 255) / 256)), dim3(256), 0, sx, G);
+    hipLaunchKernelGGL((dp_band_kernel<AF_BANDW>), dim3(n_cu * 4), dim3(64), 0, sx, G, (uint32_t)AF_GRP_BAND);
+    hipLaunchKernelGGL(global_task_kernel, dim3((unsigned)((n_units + 255) / 256)), dim3(256), 0, sx, G);          // (a global problem's window comes from the extensions of its chain: all of them are through)
     const uint64_t gmax = G.task_cap > n_units * AF_MAX_TASKS_READ ? G.task_cap - n_units * AF_MAX_TASKS_READ : 0;          // global problems the slots hold
     if (gmax) hipLaunchKernelGGL(global_band_kernel, dim3((unsigned)((gmax + 255) / 256)), dim3(256), 0, sx, G);
-    hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL, (uint32_t)AF_GRP_BAND);
-    hipLaunchKernelGGL((dp_band_kernel<AF_BANDW>), dim3(n_cu * 4), dim3(64), 0, sx, G);
+    hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL, (uint32_t)AF_GRP_GBAND);
+    hipLaunchKernelGGL((dp_band_kernel<AF_BANDW>), dim3(n_cu * 4), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GBAND);
     hipLaunchKernelGGL((dp_lane_kernel<AF_GBLK, AF_QCAP, AF_GPASS>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL);
 }

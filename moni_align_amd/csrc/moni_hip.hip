@@ -144,8 +144,8 @@ struct moni_ctx {
     DBuf<uint8_t> dp_dir_big;
     struct AfSet {          // device buffers of the staged align kernels (align_fast.hip), one set per launch stream
         DBuf<af_plan_t> plans; DBuf<moni_dp_task_t> tasks; DBuf<af_res_t> res; DBuf<uint32_t> bin_q, task_pos, tb_task, big_list, ctr; DBuf<uint8_t> ntasks;
-        DBuf<af_chunk_t> chunks; DBuf<uint8_t> dirs, fin; DBuf<af_tb_t> tb; DBuf<uint64_t> bnd; DBuf<unsigned long long> prof, txt_cur;
-        void release() { ntasks.release(); bnd.release(); prof.release(); big_list.release(); txt_cur.release(); plans.release(); tasks.release(); res.release(); bin_q.release(); task_pos.release(); tb_task.release(); ctr.release();
+        DBuf<af_chunk_t> chunks; DBuf<uint8_t> dirs, fin; DBuf<af_ctab_t> ctab; DBuf<af_tb_t> tb; DBuf<uint64_t> bnd; DBuf<unsigned long long> prof, txt_cur;
+        void release() { ctab.release(); ntasks.release(); bnd.release(); prof.release(); big_list.release(); txt_cur.release(); plans.release(); tasks.release(); res.release(); bin_q.release(); task_pos.release(); tb_task.release(); ctr.release();
                          chunks.release(); dirs.release(); fin.release(); tb.release(); }
     } af[AK_NSET], af_pe[PE_NSET];
     HBuf<unsigned long long> pe_hcur;       // paired path, per chunk: the pool cursors / DP counters (8 words) and the number of pairs handed over, copied behind the chunk's kernels
@@ -1211,7 +1211,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             return rc;
         // task slots: AF_MAX_TASKS_READ per read (each read's problems at its own place) + the global problems; bin queues: as many entries as problems are expected
         const uint32_t af_slot_cap = (uint32_t)std::min<uint64_t>((uint64_t)AF_MAX_TASKS_READ * sub_reads + 4 * sub_reads + 4096, 0xFFFFFFF0ull);
-        const uint32_t af_task_cap = (uint32_t)std::min<uint64_t>(12 * sub_reads + 4096, (1ull << 26) - 1), af_tb_cap = (uint32_t)std::min<uint64_t>((4 + c->max_len / 50) * sub_reads + 1024, 0x7FFFFFFFull);      // traced problems: the final chain's extensions and gap fills (more anchors on longer reads)
+        const uint32_t af_task_cap = (uint32_t)std::min<uint64_t>(12 * sub_reads + 4096, (1ull << AF_POS_BITS) - 1), af_tb_cap = (uint32_t)std::min<uint64_t>((4 + c->max_len / 50) * sub_reads + 1024, 0x7FFFFFFFull);      // traced problems: the final chain's extensions and gap fills (more anchors on longer reads)
         const uint32_t af_chunk_cap = af_task_cap / 64 + 2 * AF_NBIN;
         // direction bits: half a byte per DP cell.  ~10 KB per 150 bp read on the bench; DP cells grow with the square of the read length (250 bp:
         // ~90 KB with the global realignments); a chunk that does not fit sends its reads to align_kernel, and a batch in which that happened
@@ -1235,8 +1235,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         if (inorder) { HIPCHK(hipMemsetAsync(c->ak_dev_sum.p, 0, (160 * n_sub + 8) * sizeof(unsigned long long), c->stream)); memset(c->h_sum.p, 0, (4 * n_sub + 4) * sizeof(unsigned long long)); }
         if (use_fast) for (int x = 0; x < (int)std::min<uint64_t>(n_sub, AK_NSET); ++x) {
             moni_ctx::AfSet& S = c->af[x];
-            if ((rc = S.plans.ensure(sub_reads + 1)) || (rc = S.tasks.ensure(af_slot_cap)) || (rc = S.res.ensure(af_slot_cap)) || (rc = S.ntasks.ensure(sub_reads + 8)) || (rc = S.bin_q.ensure((size_t)AF_NBIN * af_task_cap)) ||
-                (rc = S.task_pos.ensure(af_slot_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.big_list.ensure(3 * (sub_reads + 1))) ||
+            if ((rc = S.plans.ensure(sub_reads + 1)) || (rc = S.tasks.ensure(af_slot_cap)) || (rc = S.res.ensure(af_slot_cap)) || (rc = S.ntasks.ensure(sub_reads + 8)) || (rc = S.bin_q.ensure((size_t)(AF_NBIN + 1) * af_task_cap)) ||
+                (rc = S.task_pos.ensure(af_slot_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.big_list.ensure(3 * (sub_reads + 1))) || (rc = S.ctab.ensure((size_t)(sub_reads + 1) * AF_CTAB)) ||
                 (rc = S.ctr.ensure(AF_NCTR)) || (rc = S.txt_cur.ensure(AF_TXT_SHARDS * 8)) || (rc = S.bnd.ensure((size_t)af_dp_grid * AF_QCAP * 64)) || (rc = S.chunks.ensure(af_chunk_cap)) || (rc = S.dirs.ensure(af_dirs_cap)) || (rc = S.fin.ensure((size_t)af_fin_grid * 64 * sizeof(af_fin_t))))
                 return rc;
         }
@@ -1436,12 +1436,14 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
 #ifdef AF_CUTS
                 if (const char* v = getenv("MONI_AF_DBG")) G.dbg = (uint32_t)atoi(v);
 #endif
-                if (const char* v = getenv("MONI_AF_DBG")) G.dbg |= (uint32_t)atoi(v) & (64u | 65536u);          // any build: 64 the serial anchor sort (cross-check), 65536 every global problem through the full-matrix kernel
+                if (const char* v = getenv("MONI_AF_DBG")) G.dbg |= (uint32_t)atoi(v) & (64u | 65536u | 131072u);          // any build: 64 the serial anchor sort (cross-check), 65536 every global problem through the full-matrix kernel, 131072 every extension / gap fill through the tile kernels
                 HIPCHK(hipMemsetAsync(S.ctr.p, 0, AF_NCTR * sizeof(uint32_t), sx));
                 // LEVEL 0's instance: the small one, or - reads of more than 200 bases, whose seeds have more occurrences than it holds - the middle one
                 static const int l0_force = getenv("MONI_AF_L0") ? atoi(getenv("MONI_AF_L0")) : -1;          // 0 small, 1 middle
                 const bool l0_mid = l0_force >= 0 ? l0_force == 1 : c->max_len > 200;
                 G.l0_mm = l0_mid ? (uint32_t)af_wave_mid_t::MM : (uint32_t)af_wave_small_t::MM; G.l0_ma = l0_mid ? (uint32_t)af_wave_mid_t::MA : (uint32_t)af_wave_small_t::MA;
+                const bool no_k2 = getenv("MONI_AF_NOPLANK") != nullptr;          // (measurement: the LEVEL-0 instance runs the selection loop and builds the plan itself, as the others do)
+                G.ctab = (no_k2 || l0_mid) ? nullptr : S.ctab.p;
                 hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
                 if (l0_mid) {
                     const dim3 g1((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * 4 * 4));
@@ -1462,6 +1464,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 static const bool no_huge = getenv("MONI_AF_NOHUGE") != nullptr;          // (debugging aid: reads beyond the large instance then go straight to align_kernel)
                 if (!no_huge) hipLaunchKernelGGL((chain_plan_kernel<af_wave_huge_t, 2>), dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu)), dim3(64), 0, sx, G);      // ~90 KB of LDS per wave: one per CU
                 HIPCHK(hipGetLastError());
+                if (G.ctab) hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, sx, G);
                 hipLaunchKernelGGL(bin_tasks_kernel, dim3((unsigned)((nr + AF_BT_READS - 1) / AF_BT_READS)), dim3(256), 0, sx, G);
                 HIPCHK(hipEventRecord(c->af_ev[3 * k], sx));
                 af_launch_dp(G, sx, af_dp_grid, (unsigned)n_cu, nr);

@@ -53,6 +53,9 @@ typedef af_wave_tt<AF_MAX_ANCH, AF_MAX_CHAINS, AF_MAX_MEMS, 2 * PEF_MAX_Q, AF_PL
 // most pairs: 2 x 150 bp on a 13-sequence index seed ~8 MEMs and ~90 anchors per pair (p99.9: 13 and 157; profiles/r03l/pe_seed_hist.txt): 9 KB of LDS, 4 waves per SIMD.
 // A pair that overflows this instance is put on a list for the large one (LEVEL 1).
 typedef af_wave_tt<160, 80, 24, 2 * PEF_MAX_Q, 64, 48, 1> pef_wave_small_t;
+// -Z (find_chains_secondary): the same two instances with the second track's arrays
+typedef af_wave_tt<160, 80, 24, 2 * PEF_MAX_Q, 64, 48, 1, 1> pef_wave_small_z_t;
+typedef af_wave_tt<AF_MAX_ANCH, AF_MAX_CHAINS, AF_MAX_MEMS, 2 * PEF_MAX_Q, AF_PLAN_AN, AF_MAX_TASKS_READ, 1, 1> pef_wave_z_t;
 #define PEF_RAW_SMALL 32
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -174,7 +177,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         }
         __syncthreads();
         if (!fallback && na > 0) {
-            status = af_chain(G, L, na, avg);
+            status = af_chain(G, L, na, avg, af_grp_t<64>(), WT::SEC && X.PP.secondary_chains != 0);
             status = (uint32_t)__shfl((int)status, 0);
             __syncthreads();
             if (status == 0xFFu) { fallback = true; status = AF_ST_UNALIGNED; }

@@ -47,7 +47,8 @@ def test_sam_identical_150bp(medium_case, env):
 
 
 def test_banded_global_problems_equal_the_full_matrix(medium_case, env, monkeypatch):
-    """Chains with overlapping anchors are scored by one global alignment of the whole read (aligner_ksw2.hpp:2984-3015).  dp_band_kernel computes the band
+    """Chains with overlapping anchors are scored by one global alignment of the whole read (aligner_ksw2.hpp:2984-3015); extensions and gap fills are
+    banded the same way where a band of 16 diagonals is proven (bin_tasks_kernel: af_ext_band / af_global_band).  dp_band_kernel computes the band
     of diagonals global_band_kernel has bounded (lower bound from a two-piece diagonal alignment, upper bound from the gap bases a path off the band must
     hold); a problem whose band is wider than 16 diagonals takes the full-matrix kernel.  Substitutions (narrow bands), indels (bands around tlen - qlen,
     wide ones too) and both strands: the SAM text equals the oracle's, and nothing changes when every global problem is forced through the full matrix."""
@@ -55,10 +56,13 @@ def test_banded_global_problems_equal_the_full_matrix(medium_case, env, monkeypa
             list(medium_case.synth.make_reads(medium_case.pg, 3000, 250, seed=162, sub_rate=0.03, indel_rate=0.002)) + \
             list(medium_case.synth.make_reads(medium_case.pg, 3000, 100, seed=163))
     _, st = both(env, reads)
-    monkeypatch.setenv("MONI_AF_DBG", "65536")
+    monkeypatch.setenv("MONI_AF_DBG", "65536")                    # global problems through the full matrix
+    _, st_g = both(env, reads)
+    monkeypatch.setenv("MONI_AF_DBG", str(65536 + 131072))       # ... and the extensions / gap fills through the tile kernels: no band anywhere
     _, st_full = both(env, reads)
-    assert st["aligned"] == st_full["aligned"] and st["dp_cells"] == st_full["dp_cells"]
-    assert st["dp_cells_cut"] < st_full["dp_cells_cut"]          # the banded problems step through fewer cells
+    assert st["aligned"] == st_g["aligned"] == st_full["aligned"] and st["dp_cells"] == st_g["dp_cells"] == st_full["dp_cells"]
+    assert st["dp_cells_cut"] < st_g["dp_cells_cut"] < st_full["dp_cells_cut"]          # the banded problems step through fewer cells
+    assert st["handed_back"] == st_full["handed_back"] == 0 and st["kernel_fallback"] == st_full["kernel_fallback"]          # ... and no read leaves the staged kernels because of the band
 
 
 def test_sub_batches_and_handed_back_reads(medium_case, env, monkeypatch):

@@ -145,6 +145,21 @@ def test_configs2_paired_end_with_orphan_recovery():
     if got != want:
         raise AssertionError("paired SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
     assert aligned == st["aligned"] and aligned > 5800
+    # -Z (find_chains_secondary) on the same pairs and index: the staged kernels' second track against the oracle's
+    want_z, st_z = orc.align_pe(o, np.ascontiguousarray(mates[0::2]).reshape(-1), o1, np.ascontiguousarray(mates[1::2]).reshape(-1), o1, np.frombuffer(n1, np.uint8), no1,
+                                np.frombuffer(n2, np.uint8), no2, np.ascontiguousarray(qq[0::2]).reshape(-1), np.ascontiguousarray(qq[1::2]).reshape(-1), b_size=512, find_orphan=True,
+                                secondary_chains=True)
+    idx = capi.Index(fi=fi)
+    ctx = capi.Ctx(idx)
+    try:
+        got_z, model_z, aligned_z = gpu_align_all(ctx, mates.reshape(-1), offs, names, noff, q, 512, find_orphan=True, secondary_chains=1)
+    finally:
+        ctx.close()
+        idx.close()
+    assert model_z.count == st_z["ins_count"] and model_z.mean == st_z["ins_mean"] and model_z.std_dev == st_z["ins_std_dev"]
+    if got_z != want_z:
+        raise AssertionError("paired SAM with -Z differs at record %d:\n got: %s\nwant: %s" % first_diff(got_z, want_z))
+    assert aligned_z == st_z["aligned"]
 
 
 def test_configs4_shaped_chr21_scale_20_haplotypes_250bp():

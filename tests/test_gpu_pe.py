@@ -19,7 +19,7 @@ def case():
     return pg, fi, orc.OracleIndex(fi=fi)
 
 
-def gpu_align_all(ctx, seq, offs, names, noff, q, b_size, find_orphan=False):
+def gpu_align_all(ctx, seq, offs, names, noff, q, b_size, find_orphan=False, secondary_chains=0):
     """st_align's paired loop (align_reads_dispatcher.hpp:356-389) over the C ABI"""
     n = (len(offs) - 1) // 2
     model = capi.PeModelC()
@@ -33,13 +33,13 @@ def gpu_align_all(ctx, seq, offs, names, noff, q, b_size, find_orphan=False):
         s, o, _, _, _ = cut(at, hi)
         learnt.append((at, hi))
         at = hi
-        ctx.pe_learn(s, o, model)
+        ctx.pe_learn(s, o, model, secondary_chains=secondary_chains)
         if model.complete:
             break
     aligned = 0
     rest = [(lo, min(n, lo + b_size)) for lo in range(at, n, b_size)]
     for lo, hi in learnt + rest:
-        sam, st = ctx.pe_align(*cut(lo, hi), model, host_threads=4, find_orphan=int(find_orphan))
+        sam, st = ctx.pe_align(*cut(lo, hi), model, host_threads=4, find_orphan=int(find_orphan), secondary_chains=secondary_chains)
         out.append(sam); aligned += st["aligned"]
     return b"".join(out), model, aligned
 
@@ -297,8 +297,8 @@ def test_pe_orphan_loop_over_several_waves(case, monkeypatch):
 
 
 def test_pe_secondary_chains(case):
-    """-Z (moni_pe_params_t::secondary_chains): find_chains_secondary in learn_fragment_model and in the alignment, st_align's batch order; every pair takes
-    pe_align_kernel (the staged kernels chain without the second track).  Against the oracle; and the option must change the output"""
+    """-Z (moni_pe_params_t::secondary_chains): find_chains_secondary in learn_fragment_model and in the alignment, st_align's batch order, through the staged
+    kernels (af_chain's second track; the pairs they hand over take pe_core.h's).  Against the oracle; and the option must change the output"""
     pg, fi, o = case
     m1, m2, _ = make_pairs(pg, 1300)
     h1, h2 = hard_pairs(pg)

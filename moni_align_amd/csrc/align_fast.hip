@@ -135,6 +135,8 @@ struct af_args_t {
     uint32_t* tb_task; af_tb_t* tb; uint32_t tb_cap;      // problems to trace
     uint32_t* fb_list; uint32_t* fb_n;       // reads handed to align_kernel and their number: per sub-batch, not per buffer set (align_kernel reads them on its own stream
                                              // while the set's next sub-batch is already running)
+    const uint64_t* pat; const moni_u64x2* blk;      // the seeding stage's pattern workspace of the resident batch (seed_core.h: 2-bit code and mask words of every task, in read order)
+    const uint64_t* text2; const uint32_t* exc; uint32_t exc_sh;      // the 2-bit text and its exception bitmap (seed_core.h: mem_fast_t)
     af_ctab_t* ctab;                         // AF_CTAB per read of the launch: LEVEL 0's chains, for plan_kernel (nullptr: the LEVEL-0 instance plans by itself)
     uint32_t* list0; uint32_t* big_list; uint32_t* huge_list; // reads (indices in the launch) of the small / the large / the largest instance of chain_plan_kernel (classify_kernel)
     unsigned long long* txt_cur;             // AF_TXT_SHARDS cursors (one per 64 bytes) of the text pool's shard regions: a device-scope atomic on ONE address
@@ -1121,7 +1123,7 @@ __global__ void __launch_bounds__(256) plan_kernel(const af_args_t G) {
 // task slots, one thread per slot), counts per bin in LDS and bumps every bin's global counter once: a few thousand atomics per address and launch where
 // one per task was the bound of chain_plan_kernel (and one per bin and 4 reads, with 35 bins instead of 18, was 2.9 ms per 1 M reads: profiles/r04e).
 #define AF_BT_READS 32u
-__device__ __forceinline__ void af_global_band(const dp_launch_t& D, const moni_dp_task_t& T, int& dmin, int& dmax);
+__device__ __forceinline__ void af_global_band(const dp_launch_t& D, const moni_dp_task_t& T, int& dmin, int& dmax, bool* saw_wild = nullptr);
 __device__ __forceinline__ void af_ext_band(const dp_launch_t& D, const moni_dp_task_t& T, int& dmin, int& dmax);
 __global__ void __launch_bounds__(256) bin_tasks_kernel(const af_args_t G) {
     __shared__ uint32_t cnt[AF_NBIN + 1], base[AF_NBIN + 1], ovf[AF_BT_READS];
@@ -1272,10 +1274,11 @@ template <int TB, int QC, int NP>
 #define AF_DP_OCC 2          // 52 rows x two problems + the cell temporaries fit 256 registers without scratch; at 3 waves the block spills
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64 ? 1 : AF_DP_OCC, TB > 64 ? 1 : AF_DP_OCC))) dp_lane_kernel(const af_args_t G, const uint32_t grp) {
-    __shared__ uint8_t qs[QC][64];          // query codes of the lane's two problems: low one in bits 0-1, high one in bits 4-5
+    __shared__ uint8_t qs[QC][64];          // query codes of the lane's two problems: low one in bits 0-1 (bit 2: a wildcard), high one in bits 4-5 (bit 6)
+    __shared__ uint32_t tns[(TB + 15) / 16][64];      // the block's target rows that hold a wildcard: row i of the low problem in bit i & 15, of the high one in bit 16 + (i & 15), of word i >> 4
     const int lane = threadIdx.x;
     const dp_launch_t& D = G.A.D;
-    const uint32_t qo2 = af_pk2(D.qo), e2 = af_pk2(D.e), scM2 = af_pk2(D.sc_mch), scX2 = af_pk2(D.sc_mis);
+    const uint32_t qo2 = af_pk2(D.qo), e2 = af_pk2(D.e), scM2 = af_pk2(D.sc_mch), scX2 = af_pk2(D.sc_mis), scN2 = af_pk2(D.sc_N);
     const int32_t qo = D.qo, e = D.e;
     constexpr int NW = (TB + 15) / 16;
     uint64_t* __restrict__ bnd = NP > 1 ? G.bnd + (size_t)blockIdx.x * QC * 64 + lane : nullptr;
@@ -1300,8 +1303,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
             maxq = task[h].qlen > maxq ? task[h].qlen : maxq; maxt = task[h].tlen > maxt ? task[h].tlen : maxt;
         }
         for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(maxq, o); maxq = w > maxq ? w : maxq; const int w2 = __shfl_xor(maxt, o); maxt = w2 > maxt ? w2 : maxt; }
-        bool wild[2] = {nodir, nodir};
-        {   // query codes -> LDS, eight bases per load
+        bool wild[2] = {nodir, nodir};          // the problem is not computed (its direction bits have no room): the read takes align_kernel
+        bool any_n = false;                     // a wildcard base (N, any byte outside A / C / G / T) in an operand of the lane's problems
+        {   // query codes -> LDS, eight bases per load; bit 2 (bit 6: the high problem) marks a wildcard
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int qlen = task[h].qlen, mode = task[h].reserved;
@@ -1313,21 +1317,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
                         uint32_t cq = dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu);
                         if ((mode & DP_Q_COMP) && cq < 4) cq = 3 - cq;
                         const bool in = 8 * g + u < qlen;
-                        wild[h] |= in && cq > 3;
-                        if (8 * g + u < maxq) { if (h == 0) qs[8 * g + u][lane] = (uint8_t)(in ? (cq & 3u) : 0u); else qs[8 * g + u][lane] |= (uint8_t)((in ? (cq & 3u) : 0u) << 4); }
+                        const uint32_t code = in ? ((cq & 3u) | (cq > 3 ? 4u : 0u)) : 0u;
+                        any_n |= in && cq > 3;
+                        if (8 * g + u < maxq) { if (h == 0) qs[8 * g + u][lane] = (uint8_t)code; else qs[8 * g + u][lane] |= (uint8_t)(code << 4); }
                     }
-                }
-            }
-        }
-        if (NP > 1) {       // a wildcard anywhere in the target: known before the first block runs
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int tlen = task[h].tlen;
-                af_bytes_t TS = af_bytes(D.text, task[h].t_off, D.text_limit, (task[h].reserved & DP_T_REV) != 0);
-                for (int g = 0; 8 * g < maxt; ++g) {
-                    const uint64_t v = 8 * g < tlen ? af_group(TS, g) : 0ull;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) wild[h] |= 8 * g + u < tlen && dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu) > 3;
                 }
             }
         }
@@ -1336,7 +1329,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
         for (int h = 0; h < 2; ++h) { R[h].mqe = AF_NEG_INF; R[h].mqe_t = -1; R[h].score = AF_NEG_INF; R[h].flags = 0; }
         for (int pass = 0; pass < NP && pass * TB < maxt; ++pass) {
             const int i0 = pass * TB;
-            uint32_t tp[2][NW];      // target codes of the block -> registers (2 bits each)
+            uint32_t tp[2][NW], tn[NW];      // target codes of the block -> registers (2 bits each); tn: the rows that hold a wildcard (tns' layout)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tn[w] = 0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -1352,11 +1347,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
                         if (i < TB) {
                             const uint32_t ct = dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu);
                             const bool in = i0 + i < tlen;
-                            wild[h] |= in && ct > 3;
+                            any_n |= in && ct > 3;
                             tp[h][i >> 4] |= (in ? (ct & 3u) : 0u) << (2 * (i & 15));
+                            tn[i >> 4] |= (in && ct > 3 ? 1u : 0u) << (16 * h + (i & 15));
                         }
                     }
                 }
+            }
+            // A wildcard base scores sc_N against anything (ksw2: -e).  The chunks that hold one - wave-uniform - run the row loop that looks at the
+            // wildcard planes (four more instructions per cell); before, such a problem sent its read to align_kernel, and 1 % of the reads with an N halved the
+            // whole path's rate (profiles/r04j/bench_nrate.json)
+            const bool any_wild = __ballot(any_n) != 0ull;
+            if (any_wild) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) tns[w][lane] = tn[w];
             }
             uint32_t Hc[TB], Fc[TB];
 #pragma unroll
@@ -1388,29 +1392,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
                 }
                 uint32_t pack = 0;
                 uint32_t* __restrict__ drow = dir + (size_t)j * (TB / 4) * 64;
-#pragma unroll
-                for (int i = 0; i < TB; ++i) {
-                    const uint32_t k0 = (uint32_t)__builtin_amdgcn_sbfe((int)x0[i >> 4], 2 * (i & 15), 1), k1 = (uint32_t)__builtin_amdgcn_sbfe((int)x1[i >> 4], 2 * (i & 15), 1);
-                    const uint32_t mk = __builtin_amdgcn_perm(k1, k0, 0x05040100u);       // all ones in a half whose bases differ
-                    const uint32_t sc = (mk & scX2) | (~mk & scM2);
-                    const uint32_t h_old = Hc[i];
-                    const uint32_t E = af_pk_sub(af_pk_max(af_pk_sub(h_up, qo2), e_run), e2);
-                    const uint32_t F = af_pk_sub(af_pk_max(af_pk_sub(h_old, qo2), Fc[i]), e2);
-                    const uint32_t zd = af_pk_add(diag, sc);
-                    const uint32_t z1 = af_pk_max(zd, E), z = af_pk_max(z1, F), zq = af_pk_sub(z, qo2);
-                    // sign bits: E < zd (the diagonal wins), F < z1 (it stays), E < zq, F < zq (no continuation)
-                    uint32_t nb = af_pk_neg(af_pk_sub(E, zd));
-                    nb |= af_pk_neg(af_pk_sub(F, z1)) << 1;
-                    nb |= af_pk_neg(af_pk_sub(E, zq)) << 2;
-                    nb |= af_pk_neg(af_pk_sub(F, zq)) << 3;
-                    Hc[i] = z; Fc[i] = F; diag = h_old; h_up = z; e_run = E;
-                    pack = (pack << 4) | nb;
-#ifdef AF_PROFILE
-                    if ((i & 3) == 3) { if (!(G.dbg & 1)) drow[(i >> 2) * 64] = pack; pack = 0; }
-#else
-                    if ((i & 3) == 3) { drow[(i >> 2) * 64] = pack; pack = 0; }
-#endif
+#define AF_DP_ROWS(WILDC) \
+                _Pragma("unroll") \
+                for (int i = 0; i < TB; ++i) { \
+                    const uint32_t k0 = (uint32_t)__builtin_amdgcn_sbfe((int)x0[i >> 4], 2 * (i & 15), 1), k1 = (uint32_t)__builtin_amdgcn_sbfe((int)x1[i >> 4], 2 * (i & 15), 1); \
+                    const uint32_t mk = __builtin_amdgcn_perm(k1, k0, 0x05040100u);       /* all ones in a half whose bases differ */ \
+                    uint32_t sc = (mk & scX2) | (~mk & scM2); \
+                    if (WILDC) {      /* the row's wildcard bit of each problem to the sign of its half, spread over the half; or the column's */ \
+                        if ((i & 15) == 0) tnw = tns[i >> 4][lane]; \
+                        const uint32_t nm = af_pk(af_as_s2(af_pku(af_as_u2(tnw) << (af_u2)(uint16_t)(15 - (i & 15)))) >> (af_s2)15) | qn2; \
+                        sc = (nm & scN2) | (~nm & sc); \
+                    } \
+                    const uint32_t h_old = Hc[i]; \
+                    const uint32_t E = af_pk_sub(af_pk_max(af_pk_sub(h_up, qo2), e_run), e2); \
+                    const uint32_t F = af_pk_sub(af_pk_max(af_pk_sub(h_old, qo2), Fc[i]), e2); \
+                    const uint32_t zd = af_pk_add(diag, sc); \
+                    const uint32_t z1 = af_pk_max(zd, E), z = af_pk_max(z1, F), zq = af_pk_sub(z, qo2); \
+                    /* sign bits: E < zd (the diagonal wins), F < z1 (it stays), E < zq, F < zq (no continuation) */ \
+                    uint32_t nb = af_pk_neg(af_pk_sub(E, zd)); \
+                    nb |= af_pk_neg(af_pk_sub(F, z1)) << 1; \
+                    nb |= af_pk_neg(af_pk_sub(E, zq)) << 2; \
+                    nb |= af_pk_neg(af_pk_sub(F, zq)) << 3; \
+                    Hc[i] = z; Fc[i] = F; diag = h_old; h_up = z; e_run = E; \
+                    pack = (pack << 4) | nb; \
+                    if ((i & 3) == 3) { drow[(i >> 2) * 64] = pack; pack = 0; } \
                 }
+                if (any_wild) {
+                    // the column's wildcard flags spread over the halves
+                    const uint32_t qn2 = ((qb & 4u) ? 0xFFFFu : 0u) | ((qb & 0x40u) ? 0xFFFF0000u : 0u);
+                    uint32_t tnw = 0;
+                    AF_DP_ROWS(true)
+                } else {
+                    const uint32_t qn2 = 0; uint32_t tnw = 0; (void)qn2; (void)tnw;
+                    AF_DP_ROWS(false)
+                }
+#undef AF_DP_ROWS
                 if (NP > 1) bnd[(size_t)j * 64] = (uint64_t)h_up | ((uint64_t)e_run << 32);      // (H, E) of the block's last row
                 if (j == qe0 || j == qe1) {      // the last query column of one of the two problems: its mqe / score come from this column
 #pragma unroll
@@ -1646,13 +1662,14 @@ __device__ __forceinline__ void af_window(const af_cand_t& C, const af_anchor_t*
 // an upper bound for any path that touches diagonal D outside [min(0, delta), max(0, delta)]: it holds at least 2 D - delta (above) or
 // delta - 2 D (below) gap bases in at least two gaps, and at most min(qlen, tlen) diagonal steps.  Diagonals whose upper bound lies strictly below
 // the lower bound hold no cell of any best path - nor of any path that ties with one.
-__device__ __forceinline__ void af_global_band(const dp_launch_t& D, const moni_dp_task_t& T, int& dmin, int& dmax) {
+__device__ __forceinline__ void af_global_band(const dp_launch_t& D, const moni_dp_task_t& T, int& dmin, int& dmax, bool* saw_wild) {
     const int q = T.qlen, t = T.tlen, delta = t - q, ad = delta < 0 ? -delta : delta, n = q < t ? q : t;
     const bool qrev = (T.reserved & DP_Q_REV) != 0, qcomp = (T.reserved & DP_Q_COMP) != 0, trev = (T.reserved & DP_T_REV) != 0;
     const uint64_t qsh = delta < 0 ? (uint64_t)ad : 0ull, tsh = delta > 0 ? (uint64_t)ad : 0ull;
     af_bytes_t Q0 = af_bytes(D.reads, T.q_off, D.reads_limit, qrev), Q1 = af_bytes(D.reads, qrev ? T.q_off - qsh : T.q_off + qsh, D.reads_limit, qrev);
     af_bytes_t T0 = af_bytes(D.text, T.t_off, D.text_limit, trev), T1 = af_bytes(D.text, trev ? T.t_off - tsh : T.t_off + tsh, D.text_limit, trev);
     int tot = 0, A = 0, maxA = 0;
+    bool wildc = false;
     for (int g = 0; 8 * g < n; ++g) {
         const uint64_t vq0 = af_group(Q0, g), vt0 = af_group(T0, g);
         const uint64_t vq1 = delta < 0 ? af_group(Q1, g) : vq0, vt1 = delta > 0 ? af_group(T1, g) : vt0;
@@ -1664,9 +1681,11 @@ __device__ __forceinline__ void af_global_band(const dp_launch_t& D, const moni_
             const uint32_t c = dp_nt4((uint32_t)(vt0 >> (8 * u)) & 0xFFu), d = dp_nt4((uint32_t)(vt1 >> (8 * u)) & 0xFFu);
             const int s0 = (a > 3 || c > 3) ? D.sc_N : a == c ? D.sc_mch : D.sc_mis;          // diagonal 0
             const int s1 = (b > 3 || d > 3) ? D.sc_N : b == d ? D.sc_mch : D.sc_mis;          // diagonal delta
+            wildc = wildc || a > 3 || b > 3 || c > 3 || d > 3;
             tot += s1; A += s0 - s1; maxA = A > maxA ? A : maxA;
         }
     }
+    if (saw_wild) *saw_wild = wildc;          // (only the positions the two diagonals pair: a wildcard elsewhere in the longer sequence is found by the kernel that stages it)
     const int lb = tot + maxA - (delta ? D.qo + D.e * ad : 0);
     const int G = D.e > 0 ? (D.sc_mch * n - 2 * D.qo - lb) : 0x3FFFFFFF;          // e x (gap bases a path can afford)
     dmin = delta < 0 ? delta : 0; dmax = delta > 0 ? delta : 0;
@@ -1703,6 +1722,70 @@ __device__ __forceinline__ void af_ext_band(const dp_launch_t& D, const moni_dp_
     const int G = D.sc_mch * q - D.qo - lb;
     dmin = 0; dmax = 0;
     if (G >= 0) { dmax = G / D.e; dmin = -(G / (D.e + D.sc_mch)); }
+}
+
+// The mismatches on the main diagonal of a tile problem from the 2-bit forms the seeding stage keeps (32 bases per word: the diagonal of a 60-base extension is
+// two words of the pattern against two of the text, where the byte form walks 8 bases per load through up to four streams - band_tasks_kernel was bound by
+// those dependent loads: 2.5 ms per 1 M reads).  The query of a problem is a stretch [a, a + qlen) of the strand-resolved pattern of its read (the task's
+// byte offset and mode give read, strand and a); a left extension runs backwards through pattern and text alike, so its diagonal pairs are those of the two
+// stretches aligned at their ENDS.  n: positions compared (from the stretches' common start - or end, for a left extension).  False: a byte outside
+// A / C / G / T on either side, or a stretch that is not where the formulas put it (the caller then takes the byte form).
+__device__ __forceinline__ bool af_diag_mm2(const af_args_t& G, const moni_dp_task_t& T, uint64_t read, uint64_t off, uint32_t m, int n, uint32_t& mm) {
+    const dp_launch_t& D = G.A.D;
+    const int q = T.qlen;
+    if (!G.pat || !G.text2 || n <= 0 || n > q || n > T.tlen) return false;
+    const bool comp = (T.reserved & DP_Q_COMP) != 0, rev = (T.reserved & DP_Q_REV) != 0;
+    const bool reversed = comp ? !rev : rev;
+    const uint64_t d = T.q_off - off;
+    uint64_t a = !comp ? (rev ? d - (uint64_t)q + 1 : d) : (rev ? (uint64_t)m - 1 - d : (uint64_t)m - (uint64_t)q - d);
+    if (a + (uint64_t)q > m) return false;
+    if (reversed) a += (uint64_t)(q - n);                                       // the last n positions of the stretch
+    if (reversed && T.t_off + 1 < (uint64_t)n) return false;
+    const uint64_t t0 = reversed ? T.t_off - (uint64_t)n + 1 : T.t_off;          // first text position compared
+    if (t0 + (uint64_t)n > D.n_text) return false;
+    { const uint64_t b0 = t0 >> G.exc_sh, b1 = (t0 + (uint64_t)n - 1) >> G.exc_sh; if (((G.exc[b0 >> 5] >> (b0 & 31u)) | (G.exc[b1 >> 5] >> (b1 & 31u))) & 1u) return false; }
+    const uint64_t task = 2 * read + (comp ? 1u : 0u);
+    const uint64_t pb = ws_pat_base(G.blk, task), lb = ws_block_len(G.blk, task);
+    const uint64_t cb = pb + 64u * ((lb + 7) / 8), mb = cb + 64u * ((lb + 31) / 32);
+    uint64_t bad = 0;
+    mm = 0;
+    for (int k = 0; k < n; k += 32) {
+        const uint64_t pa = a + (uint64_t)k, ta = t0 + (uint64_t)k;
+        const uint32_t ps = 2u * (uint32_t)(pa & 31u), ts = 2u * (uint32_t)(ta & 31u);
+        const uint64_t p0 = G.pat[cb + (pa >> 5) * 64u], p1 = ps ? G.pat[cb + ((pa >> 5) + 1) * 64u] : 0ull;
+        const uint64_t w0 = G.text2[ta >> 5], w1 = ts ? G.text2[(ta >> 5) + 1] : 0ull;
+        bad |= G.pat[mb + (pa >> 5) * 64u] | (ps ? G.pat[mb + ((pa >> 5) + 1) * 64u] : 0ull);          // (whole words: a mark beside the stretch costs only the byte form)
+        const uint64_t pw = ps ? (p0 >> ps) | (p1 << (64u - ps)) : p0, tw = ts ? (w0 >> ts) | (w1 << (64u - ts)) : w0;
+        uint64_t x = pw ^ tw;
+        x = (x | (x >> 1)) & 0x5555555555555555ull;
+        const int left = n - k;
+        if (left < 32) x &= (1ull << (2 * left)) - 1ull;
+        mm += (uint32_t)__popcll(x);
+    }
+    return bad == 0;
+}
+// af_ext_band / af_global_band from that count.  An extension: the diagonal's score bounds mqe from below.  A gap fill or global problem whose two lengths
+// agree: the diagonal is itself a corner-to-corner path.  (Lengths that differ need the two-piece bound: the byte form.)
+__device__ __forceinline__ bool af_tile_band2(const af_args_t& G, const moni_dp_task_t& T, uint64_t read, uint64_t off, uint32_t m, int& dmin, int& dmax) {
+    const dp_launch_t& D = G.A.D;
+    const int q = T.qlen, t = T.tlen;
+    if (D.e <= 0) return false;
+    uint32_t mm = 0;
+    if (T.flag & DP_EZ_EXTZ_ONLY) {
+        dmin = -q; dmax = t;
+        if (t < q) return true;                                    // (no bound from the diagonal)
+        if (!af_diag_mm2(G, T, read, off, m, q, mm)) return false;
+        const int G_ = (D.sc_mch - D.sc_mis) * (int)mm - D.qo;          // qlen sc_mch - qo - (the diagonal's score)
+        dmin = 0; dmax = 0;
+        if (G_ >= 0) { dmax = G_ / D.e; dmin = -(G_ / (D.e + D.sc_mch)); }
+        return true;
+    }
+    if (q != t) return false;
+    if (!af_diag_mm2(G, T, read, off, m, q, mm)) return false;
+    const int G_ = (D.sc_mch - D.sc_mis) * (int)mm - 2 * D.qo;          // min(qlen, tlen) sc_mch - 2 qo - (the diagonal's score): af_global_band with delta = 0
+    dmin = 0; dmax = 0;
+    if (G_ >= 0) { const int gb = G_ / D.e; dmax = gb >> 1; dmin = -(gb >> 1); }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -1781,10 +1864,11 @@ __global__ void __launch_bounds__(256) global_band_kernel(const af_args_t G) {
     if (need) {
         T = G.tasks[tid];
         int dlo, dhi;
-        af_global_band(G.A.D, T, dlo, dhi);
+        bool saw_wild = false;
+        af_global_band(G.A.D, T, dlo, dhi, &saw_wild);
         const int W = dhi - dlo + 1;
         hb = (uint32_t)(W / 4 < 13 ? W / 4 : 13);
-        const bool band = W <= AF_BANDW && !(G.dbg & 0x10000u);          // (MONI_AF_DBG=65536: every global problem through the full-matrix kernel)
+        const bool band = W <= AF_BANDW && !saw_wild && !(G.dbg & 0x10000u);          // (a wildcard base: the full-matrix kernel scores it; the band kernel's 2-bit planes do not)          // (MONI_AF_DBG=65536: every global problem through the full-matrix kernel)
         if (band) {          // the band widened to AF_BANDW diagonals around what is needed (never beyond what the matrix has)
             const int spare = AF_BANDW - W;
             dlo -= spare / 2;
@@ -1821,17 +1905,28 @@ __global__ void __launch_bounds__(256) global_band_kernel(const af_args_t G) {
 // tile's.  (Bounding the band inside bin_tasks_kernel, whose lanes are task SLOTS - one in eight in use, a block's rounds one after the other - took
 // 7.3 ms per 1 M reads: profiles/r04h.)
 __global__ void __launch_bounds__(256) band_tasks_kernel(const af_args_t G) {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    __shared__ uint32_t cnt[AF_NBIN], base[AF_NBIN];
+    const uint32_t tid = threadIdx.x;
     const uint32_t n = G.ctr[AFC_BINS + AF_BIN_PROV] < G.bin_cap ? G.ctr[AFC_BINS + AF_BIN_PROV] : G.bin_cap;
+    if (blockIdx.x * 256u >= n) return;                    // (block-uniform)
+    if (tid < AF_NBIN) cnt[tid] = 0;
+    __syncthreads();
     const uint32_t x = blockIdx.x * 256 + threadIdx.x;
-    bool need = x < n;
-    uint32_t bin = 0, id = 0;
+    const bool need = x < n;
+    uint32_t bin = 0, id = 0, local = 0;
     if (need) {
         id = G.bin_q[(size_t)AF_BIN_PROV * G.bin_cap + x];
         const moni_dp_task_t t = G.tasks[id];
         int dlo, dhi;
-        if (t.flag & DP_EZ_EXTZ_ONLY) af_ext_band(G.A.D, t, dlo, dhi); else af_global_band(G.A.D, t, dlo, dhi);
+        {
+            // the read the problem belongs to: its plan (id / slots per read), paired-end: the mate whose bytes hold the query
+            uint64_t rd = G.A.read_lo + id / AF_MAX_TASKS_READ;
+            if (G.pe) { rd *= 2; if (t.q_off >= G.A.offs[rd + 1]) ++rd; }
+            const uint64_t off = G.A.offs[rd];
+            // (no bound from the 2-bit forms - a gap fill whose lengths differ, a byte outside A / C / G / T: the tile takes the problem.  One lane in the byte form's
+            // dependent loads would hold up its whole wavefront)
+            if (!af_tile_band2(G, t, rd, off, (uint32_t)(G.A.offs[rd + 1] - off), dlo, dhi)) { dlo = -t.qlen; dhi = t.tlen; }
+        }
         const int W = dhi - dlo + 1;
         bin = af_large_bin(t.qlen);
         if (W <= AF_BANDW) {
@@ -1839,20 +1934,15 @@ __global__ void __launch_bounds__(256) band_tasks_kernel(const af_args_t G) {
             G.tasks[id].reserved = (t.reserved & 0xFFFF) | (int)(((uint32_t)dlo & 0xFFFFu) << 16);
             bin += AF_BIN_BAND;
         }
+        local = atomicAdd(&cnt[bin], 1u);
     }
-    uint32_t at = 0;
-    unsigned long long rest = __ballot(need);
-    while (rest) {                                     // one bump per distinct bin of the wave
-        const int lead = __ffsll((long long)rest) - 1;
-        const uint32_t b = (uint32_t)__shfl((int)bin, lead);
-        const unsigned long long same = __ballot(need && bin == b);
-        uint32_t a0 = 0;
-        if (lane == lead) a0 = atomicAdd(&G.ctr[AFC_BINS + b], (uint32_t)__popcll(same));
-        a0 = (uint32_t)__shfl((int)a0, lead);
-        if (need && bin == b) at = a0 + (uint32_t)__popcll(same & lt_mask);
-        rest &= ~same;
-    }
+    __syncthreads();
+    // one bump of a queue's counter per block and queue, all of a block's bumps side by side (a wavefront that bumped the ~30 queues its problems fall into one
+    // after the other, each time waiting for the count to come back, made this kernel take 2.3 ms per 1 M reads: profiles/r04k)
+    if (tid < AF_NBIN && cnt[tid]) base[tid] = atomicAdd(&G.ctr[AFC_BINS + tid], cnt[tid]);
+    __syncthreads();
     if (need) {
+        const uint32_t at = base[bin] + local;
         if (at < G.bin_cap) { G.bin_q[(size_t)bin * G.bin_cap + at] = id; G.task_pos[id] = at | (bin << AF_POS_BITS); }
         else { af_res_t R0; R0.mqe = AF_NEG_INF; R0.mqe_t = -1; R0.score = AF_NEG_INF; R0.flags = 1; G.res[id] = R0; }      // the queue is full: a result "not computed" sends the read to align_kernel (select_kernel)
     }

@@ -1425,6 +1425,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 G.chunks = S.chunks.p; G.chunk_cap = af_chunk_cap; G.dirs = S.dirs.p; G.dirs_cap = af_dirs_cap; G.tb_task = S.tb_task.p; G.tb = S.tb.p; G.tb_cap = af_tb_cap;
                 G.fb_n = c->fb_all.p + 16 * k; G.fb_list = c->fb_all.p + 16 * n_sub + k * (sub_reads + 1); G.big_list = S.big_list.p; G.huge_list = S.big_list.p + (sub_reads + 1); G.list0 = S.big_list.p + 2 * (sub_reads + 1); G.fin_scratch = S.fin.p; G.fin_stride = sizeof(af_fin_t); G.ctr = S.ctr.p;
                 G.bnd = S.bnd.p;
+                G.pat = c->pat.p; G.blk = c->blk.p; G.text2 = I->d_text2; G.exc = I->d_exc; G.exc_sh = I->exc_sh;
                 G.txt_cur = S.txt_cur.p; G.txt_shard_words = txt_per / (AF_TXT_SHARDS + 1);
                 HIPCHK(hipMemsetAsync(S.txt_cur.p, 0, AF_TXT_SHARDS * 8 * sizeof(unsigned long long), sx));
 #ifdef AF_PROFILE

@@ -88,6 +88,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1, help="contexts of this rank that work through the timed steps side by side, each with the batch resident (one caller thread per context, as moni-hip-align's workers): "
+                                                            "the seeding kernels of one step overlap the align kernels of another; every step is still one whole pass over the batch")
     ap.add_argument("--n-rate", type=float, default=0.0, help="robustness leg: this fraction of the reads gets one N at a random place (real Illumina data: 0.5-2 %% of the reads hold an N); the DP problems that touch it leave the packed 2-bit kernels")
     ap.add_argument("--no-scaling-base", action="store_true", help="N = 1: skip the extra leg that runs configs[3]'s read set (--scaling-base-reads reads, resident chunks of --reads) on the one GPU")
     ap.add_argument("--scaling-base-reads", type=int, default=CONFIGS3_READS)
@@ -324,16 +326,25 @@ def run_rank(args) -> int:
 
     threads = max(1, host_cpus() // max(1, world))          # host stage threads of this rank
 
-    def one_pass(want_text=False, acc=None):
+    inflight = max(1, args.inflight) if n_chunks == 1 else 1
+    ctxs = [ctx]
+    for _ in range(inflight - 1):          # the same batch resident in every context
+        cx = capi.Ctx(idx)
+        cx.upload(reads[cb[0]:cb[1]].reshape(-1), np.arange(0, (cb[1] - cb[0] + 1) * L, L, dtype=np.uint64))
+        ctxs.append(cx)
+    threads_step = max(1, threads // inflight)
+
+    def one_pass(want_text=False, acc=None, cx=None):
         """the whole path over every resident chunk of this rank; returns (SAM bytes or total length, stats of the last chunk)"""
         outs, st_last, tot_len = [], None, 0
+        cx = cx or ctx
         for k in range(n_chunks):
             nm, no, ql, _ = chunk[k]
             if n_chunks > 1:
                 ctx.swap(k)
-            sam, st = ctx.align_run(nm, no, ql, host_threads=threads, want_text=want_text)
+            sam, st = cx.align_run(nm, no, ql, host_threads=threads if cx is ctx and inflight == 1 else threads_step, want_text=want_text)
             if acc is not None:
-                acc(st)
+                acc(st, cx)
             if n_chunks > 1:
                 ctx.swap(k)
             if want_text:
@@ -345,7 +356,8 @@ def run_rank(args) -> int:
 
     # ---- warmup + timed steps ------------------------------------------------------------------------------------------------
     for _ in range(args.warmup):
-        one_pass()
+        for cx in ctxs:
+            one_pass(cx=cx)
     sync_all()
     kern = np.zeros(7)
     stage = {"seed": 0.0, "align_kernels_span": 0.0, "align_stage": 0.0, "host_stage_busy": 0.0}
@@ -356,22 +368,44 @@ def run_rank(args) -> int:
 
     why = {}
 
-    def acc(st):
+    acc_lock = threading.Lock()
+
+    def acc(st, cx):
+      with acc_lock:
         for k2, v in st["handover_why"].items():
             why[k2] = why.get(k2, 0) + v
-        kern[:] += [ctx.kernel_ms(w) if w != 5 else 0.0 for w in range(7)]
+        kern[:] += [cx.kernel_ms(w) if w != 5 else 0.0 for w in range(7)]
         stage["seed"] += st["t_seed"]; stage["align_kernels_span"] += st["t_dp_kernel"]; stage["align_stage"] += st["t_dp"]
         stage["host_stage_busy"] += st["t_host"]
         grp["chain_plan"] += st["t_k_chain"]; grp["dp_lane"] += st["t_k_dp"]; grp["select_traceback"] += st["t_k_select"]; grp["finish"] += st["t_k_finish"]
         for k2 in tot:
             tot[k2] += st[k2]
-        cnt[:] += ctx.counters()
+        cnt[:] += cx.counters()
         n_calls[0] += 1
 
     sam_len = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sam_len, _ = one_pass(acc=acc)
+    if inflight == 1:
+        for _ in range(args.steps):
+            sam_len, _ = one_pass(acc=acc)
+    else:          # exactly args.steps passes in all: a context takes the next one as soon as it is through with its last
+        left = [args.steps]
+        lens = []
+
+        def stepper(cx):
+            while True:
+                with acc_lock:
+                    if left[0] <= 0:
+                        return
+                    left[0] -= 1
+                n, _ = one_pass(acc=acc, cx=cx)
+                lens.append(n)
+        th = [threading.Thread(target=stepper, args=(cx,)) for cx in ctxs]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        sam_len = lens[-1] if lens else 0
     sync_all()
     elapsed = time.perf_counter() - t0
     elapsed = mdist.max_over_ranks(elapsed, dist, coll_dev)
@@ -384,6 +418,8 @@ def run_rank(args) -> int:
         tot[k] //= steps
     cnt = cnt // np.uint64(steps)
     sizes = mdist.gather_counts([tot["aligned"], sam_len, n_mine], dist, coll_dev)     # per-rank record counts
+    for cx in ctxs[1:]:
+        cx.close()
 
     # ---- the final SAM gather of the north star: per-rank blocks to rank 0 over RCCL, timed on its own ----------------------
     gather = None
@@ -536,7 +572,7 @@ def run_rank(args) -> int:
                                    % (3 if sharded else 2, args.base_len, " with %g interspersed repeats" % args.repeats if args.repeats else "", args.haps,
                                       "FASTA-built: null lifts" if args.fasta_index else "ref+VCF -H12 style: haplotypes lift onto the reference contig", fi_n, fi_r,
                                       ("one set of %d sharded over %d rank(s) by contiguous ranges, %d resident chunk(s) of <= %d per rank" % (total, world, n_chunks, args.reads)) if sharded else ("%d per GPU" % args.reads), L, threads),
-                       "reads_per_gpu": n_mine, "total_reads": n_all, "chunks_per_rank": n_chunks, "read_len": L, "parallelism": "reads sharded x%d, index replicated" % world,
+                       "reads_per_gpu": n_mine, "total_reads": n_all, "chunks_per_rank": n_chunks, "contexts_in_flight": inflight, "read_len": L, "parallelism": "reads sharded x%d, index replicated" % world,
                        "launched_by": "bench.py" if os.environ.get("MONI_BENCH_SELF_LAUNCHED") else ("torch.distributed.run / external launcher" if world > 1 else "single process")},
             # headline: the bytes the layout itself has to move per launch (one 64-byte fast row + one 8-byte pointer store + 1/8 of a packed pattern
             # word per LF step = 73 S; the PMC passes count 1.33x that).  SURVEY.md 8(d)'s figure (128 S + 64 J: two requests per step, the reference's

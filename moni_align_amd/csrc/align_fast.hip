@@ -44,12 +44,15 @@
 #define AF_TS 32                 // target rows (one block) and longest query of the small tile (gap fills)
 #define AF_GBLK 104               // register block of the global problems (overlapping anchors)
 #define AF_GPASS 3                // their target blocks: up to AF_GPASS * AF_GBLK target rows
-#define AF_NBIN 67               // 16 query-length bins of the large tile, 3 of the small tile, 16 of the banded extensions / gap fills, 16 of the global problems, 16 of the banded global problems
+#define AF_NBIN 99               // 16 query-length bins of the large tile, 3 of the small tile, 16 of the banded extensions / gap fills, 16 of the global problems, 16 of the banded global
+                                 // problems, 16 of the extensions / gap fills that may hold a wildcard base, 16 of such global problems
 #define AF_BIN_SMALL 16u
 #define AF_NSMALL 3u
 #define AF_BIN_BAND 19u          // extensions and gap fills with a proven band: computed BEFORE global_task_kernel (a global problem's window comes from its chain's extensions)
 #define AF_BIN_GLOBAL 35u
 #define AF_BIN_GBAND 51u
+#define AF_BIN_WILD 67u          // a wildcard base (N, any byte outside A / C / G / T) in an operand: scored by the kernels' WILDC instances, never banded
+#define AF_BIN_GWILD 83u
 #define AF_BANDW 16              // diagonals a banded global problem keeps in registers (dp_band_kernel)
 #define AF_BIN_PROV ((uint32_t)AF_NBIN)      // one more queue: the large tile's problems before band_tasks_kernel has looked at them
 #define AF_POS_BITS 25           // task_pos: a task's place in its bin's queue (a queue holds fewer than 2^25 entries), its bin (< 128) above
@@ -137,6 +140,7 @@ struct af_args_t {
                                              // while the set's next sub-batch is already running)
     const uint64_t* pat; const moni_u64x2* blk;      // the seeding stage's pattern workspace of the resident batch (seed_core.h: 2-bit code and mask words of every task, in read order)
     const uint64_t* text2; const uint32_t* exc; uint32_t exc_sh;      // the 2-bit text and its exception bitmap (seed_core.h: mem_fast_t)
+    const uint8_t* pflag;                    // per seeding task (2 read + strand): the pattern holds a byte outside A / C / G / T
     af_ctab_t* ctab;                         // AF_CTAB per read of the launch: LEVEL 0's chains, for plan_kernel (nullptr: the LEVEL-0 instance plans by itself)
     uint32_t* list0; uint32_t* big_list; uint32_t* huge_list; // reads (indices in the launch) of the small / the large / the largest instance of chain_plan_kernel (classify_kernel)
     unsigned long long* txt_cur;             // AF_TXT_SHARDS cursors (one per 64 bytes) of the text pool's shard regions: a device-scope atomic on ONE address
@@ -146,6 +150,7 @@ struct af_args_t {
     uint32_t* ctr;                           // AF_NCTR counters, see the AFC_* indices
     unsigned long long* prof;                // AF_PROFILE builds: wave cycles per phase
     uint32_t l0_mm, l0_ma;                   // capacities (seeds, anchors) of the instance the launch uses for LEVEL 0 (classify_kernel)
+    uint32_t wave_max;                       // a group of the WILD / GLOBAL / GWILD queues with at most this many chunks is computed by dp_wave_kernel (af_chunk_kernel decides; MONI_AF_WAVE_MAX)
     uint32_t dbg;                            // AF_PROFILE builds: 1 = no direction stores, 2 = no DP rows (timing experiments; results are wrong)
 };
 #ifdef AF_PROFILE
@@ -156,15 +161,15 @@ struct af_args_t {
 #define AF_PROF(G, slot, t0, t1) do {} while (0)
 #endif
 enum { AFC_TASKS = 0, AFC_FALLBACK = 1, AFC_TRACED = 2, AFC_READ_CUR = 3, AFC_DIRS_OVF = 4, AFC_CELLS = 6 /* 64 bit */, AFC_DIROFF = 8 /* 64 bit */,
-       AFC_NCHUNKS = 10 /* + group (5) */, AFC_CURSOR = 16 /* + group (5) */, AFC_BIG = 21, AFC_BIG_CUR = 22, AFC_HUGE = 23, AFC_HUGE_CUR = 24, AFC_L0 = 25 /* reads of the small instance's list */,
-       AFC_NT = 26 /* DP problems queued by bin_tasks_kernel */, AFC_WHY = 28 /* + reason (12) */, AFC_RBYTES = 40 /* 64 bit: text bytes of the DP targets, the R of SURVEY.md 8(d) */,
-       AFC_QBYTES = 42 /* 64 bit: read bytes of the DP queries */,
-       AFC_SLOTS = 44 /* 64 bit: cell slots the DP kernels computed (query positions of the chunk's longest problem x target rows of its passes (or diagonals of its band) x 128 problems) */,
-       AFC_CUTCELLS = 46 /* 64 bit: cells of the problems after an extension's target rows are cut (af_build_cand) and a problem is banded (af_ext_band, af_global_band); AFC_CELLS counts them as the reference poses them */,
-       AFC_BANDH = 48 /* + min(W / 4, 13): global problems by the width of the band of diagonals their optimal paths can touch (af_global_band) */,
-       AFC_BINS = 64 /* + bin */, AF_NCTR = 160 };
-static_assert(AFC_BINS + AF_NBIN + 1 <= AF_NCTR && AFC_WHY + 12 <= AFC_RBYTES && AFC_BANDH + 14 <= AFC_BINS && AFC_NCHUNKS + 5 <= AFC_CURSOR && AFC_CURSOR + 5 <= AFC_BIG, "counter layout");
-enum { AF_GRP_LARGE = 0, AF_GRP_SMALL = 1, AF_GRP_BAND = 2, AF_GRP_GLOBAL = 3, AF_GRP_GBAND = 4 };
+       AFC_NCHUNKS = 10 /* + group (7) */, AFC_CURSOR = 18 /* + group (7) */, AFC_BIG = 26, AFC_BIG_CUR = 27, AFC_HUGE = 28, AFC_HUGE_CUR = 29, AFC_L0 = 30 /* reads of the small instance's list */,
+       AFC_NT = 31 /* DP problems queued by bin_tasks_kernel */, AFC_WHY = 32 /* + reason (12) */, AFC_RBYTES = 44 /* 64 bit: text bytes of the DP targets, the R of SURVEY.md 8(d) */,
+       AFC_QBYTES = 46 /* 64 bit: read bytes of the DP queries */,
+       AFC_SLOTS = 48 /* 64 bit: cell slots the DP kernels computed (query positions of the chunk's longest problem x target rows of its passes (or diagonals of its band) x 128 problems) */,
+       AFC_CUTCELLS = 50 /* 64 bit: cells of the problems after an extension's target rows are cut (af_build_cand) and a problem is banded (af_tile_band2, af_global_band); AFC_CELLS counts them as the reference poses them */,
+       AFC_BANDH = 52 /* + min(W / 4, 13): global problems by the width of the band of diagonals their optimal paths can touch (af_global_band) */,
+       AFC_BINS = 68 /* + bin */, AFC_WMODE = 172 /* + group (7): dp_wave_kernel computes the group, not dp_lane_kernel */, AF_NCTR = 192 };
+static_assert(AFC_BINS + AF_NBIN + 1 <= AFC_WMODE && AFC_WMODE + 7 <= AF_NCTR && AFC_WHY + 12 <= AFC_RBYTES && AFC_BANDH + 14 <= AFC_BINS && AFC_NCHUNKS + 7 <= AFC_CURSOR && AFC_CURSOR + 7 <= AFC_BIG, "counter layout");
+enum { AF_GRP_LARGE = 0, AF_GRP_SMALL = 1, AF_GRP_BAND = 2, AF_GRP_WILD = 3, AF_GRP_GLOBAL = 4, AF_GRP_GBAND = 5, AF_GRP_GWILD = 6 };
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // chain_plan_kernel
@@ -234,17 +239,38 @@ static_assert(AF_QCAP == 256, "af_large_bin covers query lengths up to 256");
 __device__ __forceinline__ uint32_t af_bin_of(int qlen, int tlen) {
     return (qlen <= AF_TS && tlen <= AF_TS) ? AF_BIN_SMALL + (qlen <= 8 ? 0u : qlen <= 16 ? 1u : 2u) : af_large_bin(qlen);
 }
-__device__ __forceinline__ uint32_t af_grp_of_bin(uint32_t bin) { return bin < AF_BIN_SMALL ? AF_GRP_LARGE : bin < AF_BIN_BAND ? AF_GRP_SMALL : bin < AF_BIN_GLOBAL ? AF_GRP_BAND : bin < AF_BIN_GBAND ? AF_GRP_GLOBAL : AF_GRP_GBAND; }
-__device__ __forceinline__ uint32_t af_grp_b0(uint32_t grp) { return grp == AF_GRP_LARGE ? 0u : grp == AF_GRP_SMALL ? AF_BIN_SMALL : grp == AF_GRP_BAND ? AF_BIN_BAND : grp == AF_GRP_GLOBAL ? AF_BIN_GLOBAL : AF_BIN_GBAND; }
-__device__ __forceinline__ uint32_t af_grp_b1(uint32_t grp) { return grp == AF_GRP_LARGE ? AF_BIN_SMALL : grp == AF_GRP_SMALL ? AF_BIN_BAND : grp == AF_GRP_BAND ? AF_BIN_GLOBAL : grp == AF_GRP_GLOBAL ? AF_BIN_GBAND : (uint32_t)AF_NBIN; }
+__device__ __forceinline__ uint32_t af_grp_of_bin(uint32_t bin) {
+    return bin < AF_BIN_SMALL ? AF_GRP_LARGE : bin < AF_BIN_BAND ? AF_GRP_SMALL : bin < AF_BIN_GLOBAL ? AF_GRP_BAND : bin < AF_BIN_GBAND ? AF_GRP_GLOBAL : bin < AF_BIN_WILD ? AF_GRP_GBAND
+         : bin < AF_BIN_GWILD ? AF_GRP_WILD : AF_GRP_GWILD;
+}
+__device__ __forceinline__ uint32_t af_grp_b0(uint32_t grp) {
+    return grp == AF_GRP_LARGE ? 0u : grp == AF_GRP_SMALL ? AF_BIN_SMALL : grp == AF_GRP_BAND ? AF_BIN_BAND : grp == AF_GRP_GLOBAL ? AF_BIN_GLOBAL : grp == AF_GRP_GBAND ? AF_BIN_GBAND
+         : grp == AF_GRP_WILD ? AF_BIN_WILD : AF_BIN_GWILD;
+}
+__device__ __forceinline__ uint32_t af_grp_b1(uint32_t grp) {
+    return grp == AF_GRP_LARGE ? AF_BIN_SMALL : grp == AF_GRP_SMALL ? AF_BIN_BAND : grp == AF_GRP_BAND ? AF_BIN_GLOBAL : grp == AF_GRP_GLOBAL ? AF_BIN_GBAND : grp == AF_GRP_GBAND ? AF_BIN_WILD
+         : grp == AF_GRP_WILD ? AF_BIN_GWILD : (uint32_t)AF_NBIN;
+}
 __device__ __forceinline__ uint32_t af_bin_qhi(uint32_t bin) {
     return bin < AF_BIN_SMALL ? af_large_qhi(bin) : bin < AF_BIN_BAND ? (8u << (bin - AF_BIN_SMALL)) : bin < AF_BIN_GLOBAL ? af_large_qhi(bin - AF_BIN_BAND)
-         : bin < AF_BIN_GBAND ? (bin - AF_BIN_GLOBAL + 1u) * 16u : af_large_qhi(bin - AF_BIN_GBAND);
+         : bin < AF_BIN_GBAND ? (bin - AF_BIN_GLOBAL + 1u) * 16u : bin < AF_BIN_WILD ? af_large_qhi(bin - AF_BIN_GBAND) : bin < AF_BIN_GWILD ? af_large_qhi(bin - AF_BIN_WILD)
+         : (bin - AF_BIN_GWILD + 1u) * 16u;
 }
 // target rows (or diagonals) per block and blocks of a group's problems: what a chunk's direction bits are laid out by
-__device__ __forceinline__ uint32_t af_grp_tb(uint32_t grp) { return grp == AF_GRP_SMALL ? AF_TS : grp == AF_GRP_GLOBAL ? AF_GBLK : (grp == AF_GRP_BAND || grp == AF_GRP_GBAND) ? AF_BANDW : AF_BLK; }
-__device__ __forceinline__ uint32_t af_grp_np(uint32_t grp) { return grp == AF_GRP_GLOBAL ? AF_GPASS : grp == AF_GRP_LARGE ? AF_LPASS : 1; }
-__device__ __forceinline__ bool af_bin_banded(uint32_t bin) { return (bin >= AF_BIN_BAND && bin < AF_BIN_GLOBAL) || bin >= AF_BIN_GBAND; }
+__device__ __forceinline__ uint32_t af_grp_tb(uint32_t grp) {
+    return grp == AF_GRP_SMALL ? AF_TS : (grp == AF_GRP_GLOBAL || grp == AF_GRP_GWILD) ? AF_GBLK : (grp == AF_GRP_BAND || grp == AF_GRP_GBAND) ? AF_BANDW : AF_BLK;
+}
+__device__ __forceinline__ uint32_t af_grp_np(uint32_t grp) { return (grp == AF_GRP_GLOBAL || grp == AF_GRP_GWILD) ? AF_GPASS : (grp == AF_GRP_LARGE || grp == AF_GRP_WILD) ? AF_LPASS : 1; }
+__device__ __forceinline__ bool af_bin_banded(uint32_t bin) { return (bin >= AF_BIN_BAND && bin < AF_BIN_GLOBAL) || (bin >= AF_BIN_GBAND && bin < AF_BIN_WILD); }
+// the text blocks a target lies in hold a byte outside A / C / G / T (the exception bitmap of the 2-bit text): the problem may hold a wildcard
+__device__ __forceinline__ bool af_target_exc(const af_args_t& G, const moni_dp_task_t& T) {
+    if (!G.exc || T.tlen <= 0) return true;
+    const uint64_t lo = (T.reserved & DP_T_REV) ? (T.t_off + 1 >= (uint64_t)T.tlen ? T.t_off + 1 - (uint64_t)T.tlen : 0ull) : T.t_off;
+    const uint64_t hi = (T.reserved & DP_T_REV) ? T.t_off : T.t_off + (uint64_t)T.tlen - 1;
+    bool x = false;
+    for (uint64_t b = lo >> G.exc_sh; b <= (hi >> G.exc_sh); ++b) x = x || ((G.exc[b >> 5] >> (b & 31u)) & 1u);
+    return x;
+}
 
 // The lanes that work on one read: the whole wavefront (GW = 64) or a GROUP of GW consecutive lanes (GW = 16: four reads per wavefront, each with
 // its own LDS state).  chain_plan_kernel issues mostly one-lane instructions - the selection loop, the backtracking, a lane per run of anchors - and
@@ -1123,6 +1149,7 @@ __global__ void __launch_bounds__(256) plan_kernel(const af_args_t G) {
 // task slots, one thread per slot), counts per bin in LDS and bumps every bin's global counter once: a few thousand atomics per address and launch where
 // one per task was the bound of chain_plan_kernel (and one per bin and 4 reads, with 35 bins instead of 18, was 2.9 ms per 1 M reads: profiles/r04e).
 #define AF_BT_READS 32u
+#define AF_T_WILDQ 0x4000          // in a global problem's `reserved`: its read holds a wildcard base (global_task_kernel -> global_band_kernel)
 __device__ __forceinline__ void af_global_band(const dp_launch_t& D, const moni_dp_task_t& T, int& dmin, int& dmax, bool* saw_wild = nullptr);
 __device__ __forceinline__ void af_ext_band(const dp_launch_t& D, const moni_dp_task_t& T, int& dmin, int& dmax);
 __global__ void __launch_bounds__(256) bin_tasks_kernel(const af_args_t G) {
@@ -1147,6 +1174,12 @@ __global__ void __launch_bounds__(256) bin_tasks_kernel(const af_args_t G) {
             const uint32_t id = (uint32_t)r_in * AF_MAX_TASKS_READ + k;
             const moni_dp_task_t t = G.tasks[id];
             bin[q] = af_bin_of(t.qlen, t.tlen);
+            // a wildcard base may lie in the problem (the read holds one, or the target touches a block of the text that does): the WILDC instance's queues
+            {
+                uint64_t rd = G.A.read_lo + r_in;
+                if (G.pe) { rd *= 2; if (t.q_off >= G.A.offs[rd + 1]) ++rd; }
+                if (!G.pflag || G.pflag[2 * rd + ((t.reserved & DP_Q_COMP) ? 1u : 0u)] || af_target_exc(G, t)) bin[q] = AF_BIN_WILD + af_large_bin(t.qlen);
+            }
             // a problem of the large tile - an extension, or a gap fill (a small global problem) - goes to a provisional list: band_tasks_kernel, one lane per entry,
             // bounds its diagonals and queues it for dp_band_kernel or for the tile (MONI_AF_DBG=131072: the tile kernels take all)
             if (bin[q] < AF_BIN_SMALL && !(G.dbg & 0x20000u)) bin[q] = AF_BIN_PROV;
@@ -1215,7 +1248,7 @@ __global__ void __launch_bounds__(64) af_chunk_kernel(const af_args_t G, const u
             if (at + s_bytes[l] > G.dirs_cap) { ch.dir_off = ~0ull; G.ctr[AFC_DIRS_OVF] = 1; } else ch.dir_off = at;
             G.chunks[nc + c] = ch;
         }
-        if (lane == 0) G.ctr[AFC_NCHUNKS + grp] = total;
+        if (lane == 0) { G.ctr[AFC_NCHUNKS + grp] = total; G.ctr[AFC_WMODE + grp] = (grp == AF_GRP_WILD || grp == AF_GRP_GLOBAL || grp == AF_GRP_GWILD) && total <= G.wave_max ? 1u : 0u; }
         nc += total; doff += total_bytes;
         __syncthreads();
     }
@@ -1269,22 +1302,27 @@ __device__ __forceinline__ uint32_t af_pk2(int v) { return ((uint32_t)v & 0xFFFF
 __device__ __forceinline__ int af_lo16(uint32_t x) { return (int)(int16_t)(x & 0xFFFFu); }
 __device__ __forceinline__ int af_hi16(uint32_t x) { return (int)(int16_t)(x >> 16); }
 
-template <int TB, int QC, int NP>
+// WILDC: the instance for the problems that may hold a wildcard base (queues AF_BIN_WILD / AF_BIN_GWILD: bin_tasks_kernel and global_band_kernel send a problem
+// there when its read has a byte outside A / C / G / T or its target touches such a block of the text).  It keeps two more planes (the rows and columns that
+// hold a wildcard) and four more instructions per cell, which do not fit the registers beside a 52-row block - it runs with scratch; the plain instance,
+// which takes everything else, is the code without them.
+template <int TB, int QC, int NP, bool WILDC = false>
 #ifndef AF_DP_OCC
 #define AF_DP_OCC 2          // 52 rows x two problems + the cell temporaries fit 256 registers without scratch; at 3 waves the block spills
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64 ? 1 : AF_DP_OCC, TB > 64 ? 1 : AF_DP_OCC))) dp_lane_kernel(const af_args_t G, const uint32_t grp) {
     __shared__ uint8_t qs[QC][64];          // query codes of the lane's two problems: low one in bits 0-1 (bit 2: a wildcard), high one in bits 4-5 (bit 6)
-    __shared__ uint32_t tns[(TB + 15) / 16][64];      // the block's target rows that hold a wildcard: row i of the low problem in bit i & 15, of the high one in bit 16 + (i & 15), of word i >> 4
+    __shared__ uint32_t tns[WILDC ? (TB + 15) / 16 : 1][64];      // (WILDC) the block's target rows that hold a wildcard: row i of the low problem in bit i & 15, of the high one in bit 16 + (i & 15), of word i >> 4
     const int lane = threadIdx.x;
     const dp_launch_t& D = G.A.D;
-    const uint32_t qo2 = af_pk2(D.qo), e2 = af_pk2(D.e), scM2 = af_pk2(D.sc_mch), scX2 = af_pk2(D.sc_mis), scN2 = af_pk2(D.sc_N);
+    const uint32_t qo2 = af_pk2(D.qo), e2 = af_pk2(D.e), scM2 = af_pk2(D.sc_mch), scX2 = af_pk2(D.sc_mis), scN2 = af_pk2(D.sc_N); (void)scN2;
     const int32_t qo = D.qo, e = D.e;
     constexpr int NW = (TB + 15) / 16;
     uint64_t* __restrict__ bnd = NP > 1 ? G.bnd + (size_t)blockIdx.x * QC * 64 + lane : nullptr;
     uint32_t chunk0 = 0;
     for (uint32_t g = 0; g < grp; ++g) chunk0 += G.ctr[AFC_NCHUNKS + g];
     const uint32_t n_chunks = G.ctr[AFC_NCHUNKS + grp];
+    if (G.ctr[AFC_WMODE + grp]) return;          // few problems: dp_wave_kernel's (a lane's pair of problems takes the same time whether 1 or 2000 chunks are in flight)
     while (true) {
         uint32_t c = 0;
         if (lane == 0) c = atomicAdd(&G.ctr[AFC_CURSOR + grp], 1u);
@@ -1303,8 +1341,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
             maxq = task[h].qlen > maxq ? task[h].qlen : maxq; maxt = task[h].tlen > maxt ? task[h].tlen : maxt;
         }
         for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(maxq, o); maxq = w > maxq ? w : maxq; const int w2 = __shfl_xor(maxt, o); maxt = w2 > maxt ? w2 : maxt; }
-        bool wild[2] = {nodir, nodir};          // the problem is not computed (its direction bits have no room): the read takes align_kernel
-        bool any_n = false;                     // a wildcard base (N, any byte outside A / C / G / T) in an operand of the lane's problems
+        bool wild[2] = {nodir, nodir};          // the problem is not computed (its direction bits have no room; a wildcard base met by the plain instance - the queues keep those apart, so: never): the read takes align_kernel
         {   // query codes -> LDS, eight bases per load; bit 2 (bit 6: the high problem) marks a wildcard
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -1318,7 +1355,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
                         if ((mode & DP_Q_COMP) && cq < 4) cq = 3 - cq;
                         const bool in = 8 * g + u < qlen;
                         const uint32_t code = in ? ((cq & 3u) | (cq > 3 ? 4u : 0u)) : 0u;
-                        any_n |= in && cq > 3;
+                        if (!WILDC) wild[h] |= in && cq > 3;
                         if (8 * g + u < maxq) { if (h == 0) qs[8 * g + u][lane] = (uint8_t)code; else qs[8 * g + u][lane] |= (uint8_t)(code << 4); }
                     }
                 }
@@ -1329,9 +1366,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
         for (int h = 0; h < 2; ++h) { R[h].mqe = AF_NEG_INF; R[h].mqe_t = -1; R[h].score = AF_NEG_INF; R[h].flags = 0; }
         for (int pass = 0; pass < NP && pass * TB < maxt; ++pass) {
             const int i0 = pass * TB;
-            uint32_t tp[2][NW], tn[NW];      // target codes of the block -> registers (2 bits each); tn: the rows that hold a wildcard (tns' layout)
+            uint32_t tp[2][NW], tn[WILDC ? NW : 1];      // target codes of the block -> registers (2 bits each); tn: the rows that hold a wildcard (tns' layout)
 #pragma unroll
-            for (int w = 0; w < NW; ++w) tn[w] = 0;
+            for (int w = 0; w < (WILDC ? NW : 1); ++w) tn[w] = 0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -1347,18 +1384,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
                         if (i < TB) {
                             const uint32_t ct = dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu);
                             const bool in = i0 + i < tlen;
-                            any_n |= in && ct > 3;
                             tp[h][i >> 4] |= (in ? (ct & 3u) : 0u) << (2 * (i & 15));
-                            tn[i >> 4] |= (in && ct > 3 ? 1u : 0u) << (16 * h + (i & 15));
+                            if (WILDC) tn[i >> 4] |= (in && ct > 3 ? 1u : 0u) << (16 * h + (i & 15));
+                            else wild[h] |= in && ct > 3;
                         }
                     }
                 }
             }
-            // A wildcard base scores sc_N against anything (ksw2: -e).  The chunks that hold one - wave-uniform - run the row loop that looks at the
-            // wildcard planes (four more instructions per cell); before, such a problem sent its read to align_kernel, and 1 % of the reads with an N halved the
-            // whole path's rate (profiles/r04j/bench_nrate.json)
-            const bool any_wild = __ballot(any_n) != 0ull;
-            if (any_wild) {
+            // A wildcard base scores sc_N against anything (ksw2: -e).  Before, such a problem sent its read to align_kernel, and 1 % of the reads
+            // with an N halved the whole path's rate (profiles/r04j/bench_nrate.json)
+            if (WILDC) {
 #pragma unroll
                 for (int w = 0; w < NW; ++w) tns[w][lane] = tn[w];
             }
@@ -1392,41 +1427,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
                 }
                 uint32_t pack = 0;
                 uint32_t* __restrict__ drow = dir + (size_t)j * (TB / 4) * 64;
-#define AF_DP_ROWS(WILDC) \
-                _Pragma("unroll") \
-                for (int i = 0; i < TB; ++i) { \
-                    const uint32_t k0 = (uint32_t)__builtin_amdgcn_sbfe((int)x0[i >> 4], 2 * (i & 15), 1), k1 = (uint32_t)__builtin_amdgcn_sbfe((int)x1[i >> 4], 2 * (i & 15), 1); \
-                    const uint32_t mk = __builtin_amdgcn_perm(k1, k0, 0x05040100u);       /* all ones in a half whose bases differ */ \
-                    uint32_t sc = (mk & scX2) | (~mk & scM2); \
-                    if (WILDC) {      /* the row's wildcard bit of each problem to the sign of its half, spread over the half; or the column's */ \
-                        if ((i & 15) == 0) tnw = tns[i >> 4][lane]; \
-                        const uint32_t nm = af_pk(af_as_s2(af_pku(af_as_u2(tnw) << (af_u2)(uint16_t)(15 - (i & 15)))) >> (af_s2)15) | qn2; \
-                        sc = (nm & scN2) | (~nm & sc); \
-                    } \
-                    const uint32_t h_old = Hc[i]; \
-                    const uint32_t E = af_pk_sub(af_pk_max(af_pk_sub(h_up, qo2), e_run), e2); \
-                    const uint32_t F = af_pk_sub(af_pk_max(af_pk_sub(h_old, qo2), Fc[i]), e2); \
-                    const uint32_t zd = af_pk_add(diag, sc); \
-                    const uint32_t z1 = af_pk_max(zd, E), z = af_pk_max(z1, F), zq = af_pk_sub(z, qo2); \
-                    /* sign bits: E < zd (the diagonal wins), F < z1 (it stays), E < zq, F < zq (no continuation) */ \
-                    uint32_t nb = af_pk_neg(af_pk_sub(E, zd)); \
-                    nb |= af_pk_neg(af_pk_sub(F, z1)) << 1; \
-                    nb |= af_pk_neg(af_pk_sub(E, zq)) << 2; \
-                    nb |= af_pk_neg(af_pk_sub(F, zq)) << 3; \
-                    Hc[i] = z; Fc[i] = F; diag = h_old; h_up = z; e_run = E; \
-                    pack = (pack << 4) | nb; \
-                    if ((i & 3) == 3) { drow[(i >> 2) * 64] = pack; pack = 0; } \
+                const uint32_t qn2 = WILDC ? (((qb & 4u) ? 0xFFFFu : 0u) | ((qb & 0x40u) ? 0xFFFF0000u : 0u)) : 0u;      // the column's wildcard flags spread over the halves
+                uint32_t tnw = 0;
+#pragma unroll
+                for (int i = 0; i < TB; ++i) {
+                    const uint32_t k0 = (uint32_t)__builtin_amdgcn_sbfe((int)x0[i >> 4], 2 * (i & 15), 1), k1 = (uint32_t)__builtin_amdgcn_sbfe((int)x1[i >> 4], 2 * (i & 15), 1);
+                    const uint32_t mk = __builtin_amdgcn_perm(k1, k0, 0x05040100u);       // all ones in a half whose bases differ
+                    uint32_t sc = (mk & scX2) | (~mk & scM2);
+                    if (WILDC) {      // the row's wildcard bit of each problem to the sign of its half, spread over the half; or the column's
+                        if ((i & 15) == 0) tnw = tns[i >> 4][lane];
+                        const uint32_t nm = af_pk(af_as_s2(af_pku(af_as_u2(tnw) << (af_u2)(uint16_t)(15 - (i & 15)))) >> (af_s2)15) | qn2;
+                        sc = (nm & scN2) | (~nm & sc);
+                    }
+                    const uint32_t h_old = Hc[i];
+                    const uint32_t E = af_pk_sub(af_pk_max(af_pk_sub(h_up, qo2), e_run), e2);
+                    const uint32_t F = af_pk_sub(af_pk_max(af_pk_sub(h_old, qo2), Fc[i]), e2);
+                    const uint32_t zd = af_pk_add(diag, sc);
+                    const uint32_t z1 = af_pk_max(zd, E), z = af_pk_max(z1, F), zq = af_pk_sub(z, qo2);
+                    // sign bits: E < zd (the diagonal wins), F < z1 (it stays), E < zq, F < zq (no continuation)
+                    uint32_t nb = af_pk_neg(af_pk_sub(E, zd));
+                    nb |= af_pk_neg(af_pk_sub(F, z1)) << 1;
+                    nb |= af_pk_neg(af_pk_sub(E, zq)) << 2;
+                    nb |= af_pk_neg(af_pk_sub(F, zq)) << 3;
+                    Hc[i] = z; Fc[i] = F; diag = h_old; h_up = z; e_run = E;
+                    pack = (pack << 4) | nb;
+                    if ((i & 3) == 3) { drow[(i >> 2) * 64] = pack; pack = 0; }
                 }
-                if (any_wild) {
-                    // the column's wildcard flags spread over the halves
-                    const uint32_t qn2 = ((qb & 4u) ? 0xFFFFu : 0u) | ((qb & 0x40u) ? 0xFFFF0000u : 0u);
-                    uint32_t tnw = 0;
-                    AF_DP_ROWS(true)
-                } else {
-                    const uint32_t qn2 = 0; uint32_t tnw = 0; (void)qn2; (void)tnw;
-                    AF_DP_ROWS(false)
-                }
-#undef AF_DP_ROWS
                 if (NP > 1) bnd[(size_t)j * 64] = (uint64_t)h_up | ((uint64_t)e_run << 32);      // (H, E) of the block's last row
                 if (j == qe0 || j == qe1) {      // the last query column of one of the two problems: its mqe / score come from this column
 #pragma unroll
@@ -1463,6 +1489,177 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TB > 64
             atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_SLOTS]), 128ull * (unsigned long long)maxq * (unsigned long long)(np_run * TB));
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// dp_wave_kernel: the same recurrence, direction bits and results as dp_lane_kernel, one WAVEFRONT per pair of problems.  Lane l owns R target rows
+// (R l .. R l + R - 1, counted through the passes) and walks the query one column behind lane l - 1: at step s it computes column s - l of its rows, with
+// H and E of the row above (lane l - 1's last row, the column it finished in the step before) handed down by a DPP wave shift.  q + t / R steps of R cells
+// where a lane of dp_lane_kernel makes q x t: a 160 x 312 global problem takes ~0.1 ms instead of ~1.9 ms.  That latency is all that counts for a queue
+// with a few dozen problems (the global problems whose band is wider than AF_BANDW: ~50 per 250 000 reads; the problems with a wildcard base when few
+// reads hold one) - dp_lane_kernel's launch took its 1.9 ms for a single chunk (profiles/r04m).  Per problem it issues ~4x the instructions, so
+// af_chunk_kernel gives it a group only while the group has at most G.wave_max chunks.  Always keeps the wildcard planes (R rows per lane: registers are no
+// concern here).  Chunk, pairing (problems w and 64 + w of a chunk in the two 16-bit halves) and direction layout are dp_lane_kernel's: traceback_kernel
+// does not know which kernel wrote them.
+// ------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t af_wave_shr1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false); }      // lane l gets lane l - 1's value (lane 0 keeps its own)
+template <int TB, int NP, int R>
+__global__ void __launch_bounds__(64) dp_wave_kernel(const af_args_t G, const uint32_t grp_a, const uint32_t grp_b) {
+    static_assert(TB % R == 0 && R % 4 == 0 && R <= 16 && (TB / R) * NP <= 64, "a wavefront's lanes hold all rows of the passes");
+    __shared__ uint8_t qs[AF_QCAP];          // query codes of the pair: low problem in bits 0-1 (bit 2: a wildcard), high one in bits 4-5 (bit 6)
+    const int lane = threadIdx.x;
+    const dp_launch_t& D = G.A.D;
+    const uint32_t qo2 = af_pk2(D.qo), e2 = af_pk2(D.e), scM2 = af_pk2(D.sc_mch), scX2 = af_pk2(D.sc_mis), scN2 = af_pk2(D.sc_N);
+    const int32_t qo = D.qo, e = D.e;
+    for (int gi = 0; gi < 2; ++gi) {
+        const uint32_t grp = gi ? grp_b : grp_a;
+        if (gi && grp_b == grp_a) break;
+        if (!G.ctr[AFC_WMODE + grp]) continue;
+        uint32_t chunk0 = 0;
+        for (uint32_t g = 0; g < grp; ++g) chunk0 += G.ctr[AFC_NCHUNKS + g];
+        const uint32_t n_items = G.ctr[AFC_NCHUNKS + grp] * 64u;
+        while (true) {
+            uint32_t it = 0;
+            if (lane == 0) it = atomicAdd(&G.ctr[AFC_CURSOR + grp], 1u);
+            it = (uint32_t)__shfl((int)it, 0);
+            if (it >= n_items) break;
+            const af_chunk_t ch = G.chunks[chunk0 + (it >> 6)];
+            const uint32_t w = it & 63u;
+            if (w >= ch.n) continue;
+            const bool nodir = ch.dir_off == ~0ull;
+            bool has[2]; uint32_t tid[2] = {0, 0};
+            moni_dp_task_t task[2];
+            int maxq = 0, maxt = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                has[h] = w + 64u * h < ch.n;
+                task[h].qlen = 0; task[h].tlen = 0; task[h].q_off = 0; task[h].t_off = 0; task[h].reserved = 0; task[h].flag = 0;
+                if (has[h]) { tid[h] = G.bin_q[(size_t)ch.bin * G.bin_cap + ch.start + w + 64 * h]; task[h] = G.tasks[tid[h]]; }
+                maxq = task[h].qlen > maxq ? task[h].qlen : maxq; maxt = task[h].tlen > maxt ? task[h].tlen : maxt;
+            }
+            af_res_t Rs[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { Rs[h].mqe = AF_NEG_INF; Rs[h].mqe_t = -1; Rs[h].score = AF_NEG_INF; Rs[h].flags = 0; }
+            const bool fits = maxq <= AF_QCAP && maxt <= TB * NP && (uint32_t)maxq <= ch.qhi;          // (always: the queue's bounds)
+            if (nodir || !fits) {
+                if (lane == 0) for (int h = 0; h < 2; ++h) if (has[h]) { Rs[h].flags = 1; G.res[tid[h]] = Rs[h]; }
+                continue;
+            }
+            // the pair's query codes -> LDS
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int qlen = task[h].qlen, mode = task[h].reserved;
+                for (int k = lane; k < maxq; k += 64) {
+                    uint32_t code = 0;
+                    if (k < qlen) {
+                        uint32_t cq = dp_nt4((uint32_t)D.reads[(mode & DP_Q_REV) ? task[h].q_off - (uint64_t)k : task[h].q_off + (uint64_t)k]);
+                        if ((mode & DP_Q_COMP) && cq < 4) cq = 3 - cq;
+                        code = (cq & 3u) | (cq > 3 ? 4u : 0u);
+                    }
+                    if (h == 0) qs[k] = (uint8_t)code; else qs[k] |= (uint8_t)(code << 4);
+                }
+            }
+            // the lane's R target rows: 2-bit codes, and the rows that hold a wildcard (low problem: bit u, high one: bit 16 + u)
+            uint32_t tp[2] = {0, 0}, tnw = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int tlen = task[h].tlen, mode = task[h].reserved;
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    const int g = R * lane + u;
+                    if (g < tlen) {
+                        const uint32_t ct = dp_nt4((uint32_t)D.text[(mode & DP_T_REV) ? task[h].t_off - (uint64_t)g : task[h].t_off + (uint64_t)g]);
+                        tp[h] |= (ct & 3u) << (2 * u);
+                        if (ct > 3) tnw |= 1u << (16 * h + u);
+                    }
+                }
+            }
+            __syncthreads();
+            uint32_t Hc[R], Fc[R];
+#pragma unroll
+            for (int u = 0; u < R; ++u) { Hc[u] = af_pk2(-(qo + (R * lane + u + 1) * e)); Fc[u] = af_pk2(AF_NEG16); }
+            uint32_t prev_hb = af_pk2(-(qo + R * lane * e));                           // H(R lane - 1, -1)
+            // the lane's rows in the direction layout: pass (R lane) / TB, row (R lane) % TB of it
+            const int my_pass = (R * lane) / TB, my_i = (R * lane) % TB;
+            uint32_t* __restrict__ dir = reinterpret_cast<uint32_t*>(G.dirs + ch.dir_off + (size_t)my_pass * ch.qhi * TB * 64) + (size_t)(my_i >> 2) * 64 + w;
+            const int nl = (maxt + R - 1) / R, n_steps = maxq + nl - 1;
+            const int qe0 = task[0].qlen - 1, qe1 = task[1].qlen - 1;
+            uint32_t out_h = 0, out_e = 0;
+            int bm[2] = {AF_NEG_INF, AF_NEG_INF}, bt[2] = {-1, -1}, bs[2] = {AF_NEG_INF, AF_NEG_INF};
+            for (int s = 0; s < n_steps; ++s) {
+                const uint32_t in_h = af_wave_shr1(out_h), in_e = af_wave_shr1(out_e);
+                const int j = s - lane;
+                if (j >= 0 && j < maxq && lane < nl) {
+                    const uint32_t qb = qs[j];
+                    const uint32_t a0 = tp[0] ^ ((qb & 3u) * 0x55555555u), a1 = tp[1] ^ (((qb >> 4) & 3u) * 0x55555555u);
+                    const uint32_t x0 = (a0 | (a0 >> 1)) & 0x55555555u, x1 = (a1 | (a1 >> 1)) & 0x55555555u;
+                    const uint32_t qn2 = ((qb & 4u) ? 0xFFFFu : 0u) | ((qb & 0x40u) ? 0xFFFF0000u : 0u);
+                    uint32_t diag, h_up, e_run;
+                    if (lane > 0) { h_up = in_h; e_run = in_e; diag = prev_hb; prev_hb = in_h; }
+                    else { diag = af_pk2(j == 0 ? 0 : -(qo + j * e)); h_up = af_pk2(-(qo + (j + 1) * e)); e_run = af_pk2(AF_NEG16); }
+                    uint32_t pack = 0;
+                    uint32_t* __restrict__ drow = dir + (size_t)j * (TB / 4) * 64;
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        const uint32_t k0 = (uint32_t)__builtin_amdgcn_sbfe((int)x0, 2 * u, 1), k1 = (uint32_t)__builtin_amdgcn_sbfe((int)x1, 2 * u, 1);
+                        const uint32_t mk = __builtin_amdgcn_perm(k1, k0, 0x05040100u);
+                        uint32_t sc = (mk & scX2) | (~mk & scM2);
+                        const uint32_t nm = af_pk(af_as_s2(af_pku(af_as_u2(tnw) << (af_u2)(uint16_t)(15 - u))) >> (af_s2)15) | qn2;
+                        sc = (nm & scN2) | (~nm & sc);
+                        const uint32_t h_old = Hc[u];
+                        const uint32_t E = af_pk_sub(af_pk_max(af_pk_sub(h_up, qo2), e_run), e2);
+                        const uint32_t F = af_pk_sub(af_pk_max(af_pk_sub(h_old, qo2), Fc[u]), e2);
+                        const uint32_t zd = af_pk_add(diag, sc);
+                        const uint32_t z1 = af_pk_max(zd, E), z = af_pk_max(z1, F), zq = af_pk_sub(z, qo2);
+                        uint32_t nb = af_pk_neg(af_pk_sub(E, zd));
+                        nb |= af_pk_neg(af_pk_sub(F, z1)) << 1;
+                        nb |= af_pk_neg(af_pk_sub(E, zq)) << 2;
+                        nb |= af_pk_neg(af_pk_sub(F, zq)) << 3;
+                        Hc[u] = z; Fc[u] = F; diag = h_old; h_up = z; e_run = E;
+                        pack = (pack << 4) | nb;
+                        if ((u & 3) == 3) { drow[(u >> 2) * 64] = pack; pack = 0; }
+                    }
+                    out_h = h_up; out_e = e_run;
+                    if (j == qe0 || j == qe1) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) if (j == (h ? qe1 : qe0) && has[h]) {
+                            const int tlen = task[h].tlen;
+#pragma unroll
+                            for (int u = 0; u < R; ++u) {
+                                const int g = R * lane + u, hv = h ? af_hi16(Hc[u]) : af_lo16(Hc[u]);
+                                if (g < tlen) { if (hv > bm[h]) { bm[h] = hv; bt[h] = g; } if (g == tlen - 1) bs[h] = hv; }
+                            }
+                        }
+                    }
+                }
+            }
+            // the lanes' shares of the last query column: the largest H, at the lowest row among equals; the corner
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                for (int o = 32; o > 0; o >>= 1) {
+                    const int om = __shfl_xor(bm[h], o), ot = __shfl_xor(bt[h], o), os = __shfl_xor(bs[h], o);
+                    if (om > bm[h] || (om == bm[h] && ot >= 0 && (bt[h] < 0 || ot < bt[h]))) { bm[h] = om; bt[h] = ot; }
+                    bs[h] = os > bs[h] ? os : bs[h];
+                }
+                Rs[h].mqe = bm[h]; Rs[h].mqe_t = bt[h]; Rs[h].score = bs[h];
+            }
+            if (lane == 0) {
+                unsigned long long cells = 0, rb = 0, qb_ = 0, cut = 0;
+                for (int h = 0; h < 2; ++h) if (has[h]) {
+                    const unsigned long long t_ref = (task[h].flag >> 16) ? (unsigned long long)(task[h].flag >> 16) : (unsigned long long)task[h].tlen;
+                    cells += (unsigned long long)task[h].qlen * t_ref; rb += t_ref; qb_ += (unsigned long long)task[h].qlen;
+                    cut += (unsigned long long)task[h].qlen * (unsigned long long)task[h].tlen;
+                    G.res[tid[h]] = Rs[h];
+                }
+                atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_CELLS]), cells);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_RBYTES]), rb);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_QBYTES]), qb_);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_CUTCELLS]), cut);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&G.ctr[AFC_SLOTS]), 2ull * (unsigned long long)maxq * (unsigned long long)(nl * R));
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -1840,6 +2037,7 @@ __global__ void __launch_bounds__(256) global_task_kernel(const af_args_t G) {
             moni_dp_task_t T;
             if (!Cp->strand) { T.q_off = off; T.reserved = DP_Q_READS | DP_T_TEXT; } else { T.q_off = off + m - 1; T.reserved = DP_Q_READS | DP_T_TEXT | DP_Q_REV | DP_Q_COMP; }
             T.t_off = ref_pos; T.qlen = (int32_t)m; T.tlen = (int32_t)ref_len; T.flag = DP_EZ_RIGHT;
+            if (!G.pflag || G.pflag[2 * (G.pe ? 2 * r + (Cp->pad & 1u) : r) + (Cp->strand ? 1u : 0u)]) T.reserved |= AF_T_WILDQ;
             G.tasks[tid] = T;
             af_res_t R0; R0.mqe = AF_NEG_INF; R0.mqe_t = -1; R0.score = AF_NEG_INF; R0.flags = 1;          // (stays so if a queue turns out to be full: the read then takes align_kernel)
             G.res[tid] = R0;
@@ -1868,14 +2066,15 @@ __global__ void __launch_bounds__(256) global_band_kernel(const af_args_t G) {
         af_global_band(G.A.D, T, dlo, dhi, &saw_wild);
         const int W = dhi - dlo + 1;
         hb = (uint32_t)(W / 4 < 13 ? W / 4 : 13);
-        const bool band = W <= AF_BANDW && !saw_wild && !(G.dbg & 0x10000u);          // (a wildcard base: the full-matrix kernel scores it; the band kernel's 2-bit planes do not)          // (MONI_AF_DBG=65536: every global problem through the full-matrix kernel)
+        const bool wq = saw_wild || (T.reserved & AF_T_WILDQ) || af_target_exc(G, T);          // a wildcard base may lie in the problem: the full-matrix kernel's WILDC instance scores it
+        const bool band = W <= AF_BANDW && !wq && !(G.dbg & 0x10000u);          // (MONI_AF_DBG=65536: every global problem through the full-matrix kernel)
         if (band) {          // the band widened to AF_BANDW diagonals around what is needed (never beyond what the matrix has)
             const int spare = AF_BANDW - W;
             dlo -= spare / 2;
             T.reserved = (T.reserved & 0xFFFF) | (int)(((uint32_t)dlo & 0xFFFFu) << 16);
             G.tasks[tid].reserved = T.reserved;
         }
-        bin = band ? AF_BIN_GBAND + af_large_bin(T.qlen) : AF_BIN_GLOBAL + (uint32_t)((T.qlen - 1) >> 4);
+        bin = band ? AF_BIN_GBAND + af_large_bin(T.qlen) : (wq ? AF_BIN_GWILD : AF_BIN_GLOBAL) + (uint32_t)((T.qlen - 1) >> 4);
     }
     uint32_t at = 0;
     unsigned long long rest = __ballot(need);
@@ -2642,16 +2841,22 @@ __global__ void gather_summary_kernel(const uint64_t* __restrict__ len, const ui
 // The DP stage of the staged kernels, single-end and paired alike: the reads' (pairs') problems have been queued by bin_tasks_kernel; extension and gap problems
 // by tile, then the global problems: their records (global_task_kernel), their bands and queues (global_band_kernel), banded where a narrow band is proven,
 // the full matrix otherwise.  n_units: plans of the launch (reads or pairs).
+// chunks up to which dp_wave_kernel takes a group (a pair costs it ~0.1 ms of one SIMD; dp_lane_kernel's launch ~2 ms whatever the count): MONI_AF_WAVE_MAX, 0 = never
+static inline uint32_t af_wave_max() { const char* v = getenv("MONI_AF_WAVE_MAX"); return v ? (uint32_t)strtoul(v, nullptr, 10) : 96u; }
 static inline void af_launch_dp(const af_args_t& G, hipStream_t sx, unsigned dp_grid, unsigned n_cu, uint64_t n_units) {
     if (!(G.dbg & 0x20000u)) hipLaunchKernelGGL(band_tasks_kernel, dim3((unsigned)((G.bin_cap + 255) / 256)), dim3(256), 0, sx, G);      // (the provisional list holds at most bin_cap problems)
-    hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_BAND);
+    hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_WILD);
     hipLaunchKernelGGL((dp_lane_kernel<AF_BLK, AF_QCAP, AF_LPASS>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE);
     hipLaunchKernelGGL((dp_lane_kernel<AF_TS, AF_TS, 1>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_SMALL);
     hipLaunchKernelGGL((dp_band_kernel<AF_BANDW>), dim3(n_cu * 4), dim3(64), 0, sx, G, (uint32_t)AF_GRP_BAND);
+    hipLaunchKernelGGL((dp_lane_kernel<AF_BLK, AF_QCAP, AF_LPASS, true>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_WILD);
+    hipLaunchKernelGGL((dp_wave_kernel<AF_BLK, AF_LPASS, 4>), dim3(n_cu * 8), dim3(64), 0, sx, G, (uint32_t)AF_GRP_WILD, (uint32_t)AF_GRP_WILD);
     hipLaunchKernelGGL(global_task_kernel, dim3((unsigned)((n_units + 255) / 256)), dim3(256), 0, sx, G);          // (a global problem's window comes from the extensions of its chain: all of them are through)
     const uint64_t gmax = G.task_cap > n_units * AF_MAX_TASKS_READ ? G.task_cap - n_units * AF_MAX_TASKS_READ : 0;          // global problems the slots hold
     if (gmax) hipLaunchKernelGGL(global_band_kernel, dim3((unsigned)((gmax + 255) / 256)), dim3(256), 0, sx, G);
-    hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL, (uint32_t)AF_GRP_GBAND);
+    hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL, (uint32_t)AF_GRP_GWILD);
     hipLaunchKernelGGL((dp_band_kernel<AF_BANDW>), dim3(n_cu * 4), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GBAND);
     hipLaunchKernelGGL((dp_lane_kernel<AF_GBLK, AF_QCAP, AF_GPASS>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL);
+    hipLaunchKernelGGL((dp_lane_kernel<AF_GBLK, AF_QCAP, AF_GPASS, true>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GWILD);
+    hipLaunchKernelGGL((dp_wave_kernel<AF_GBLK, AF_GPASS, 8>), dim3(n_cu * 8), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL, (uint32_t)AF_GRP_GWILD);
 }

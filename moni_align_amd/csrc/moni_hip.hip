@@ -98,7 +98,9 @@ struct HBuf {                  // pinned host buffer, grow-only
 
 #define PE_NSET 1          // sets of the staged paired kernels' large buffers (pe_api.inc): the chunks' staged kernels run one after the other on one stream, what outlives them is per chunk
 #define PE_NSTREAM 4       // hand-over launches of the paired path in flight, one stream and one slot array each
-#define AK_NSET 2          // launch streams of the align stage, each with its own buffer set: sub-batch k runs on set k % AK_NSET
+#ifndef AK_NSET
+#define AK_NSET 2
+#endif                     // launch streams of the align stage, each with its own buffer set: sub-batch k runs on set k % AK_NSET
 struct moni_ctx {
     moni_index* idx = nullptr;
     hipStream_t stream = nullptr;
@@ -114,7 +116,7 @@ struct moni_ctx {
     struct Stash { DBuf<uint8_t> seq; DBuf<uint64_t> offs; DBuf<moni_u64x2> blk; std::vector<moni_u64x2> h_blk; uint64_t n_reads = 0, total_len = 0, max_len = 0; std::vector<uint8_t> h_seq; std::vector<uint64_t> h_offs; };
     std::vector<Stash> stash;                // moni_reads_swap: further batches kept in HBM beside the resident one
     // workspaces
-    DBuf<uint64_t> ptr, pat;
+    DBuf<uint64_t> ptr, pat; DBuf<uint8_t> pflag;      // pflag: per seeding task, its pattern holds a byte outside A / C / G / T (pack_kernel)
     DBuf<uint32_t> cnt_m, cnt_s;
     DBuf<moni_u64x2> mem_slots;
     DBuf<uint64_t> tot, read_mem_off;
@@ -484,7 +486,7 @@ void moni_ctx_destroy(moni_ctx_t* c) {
     (void)hipSetDevice(c->idx->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& x : c->stash) { x.seq.release(); x.offs.release(); x.blk.release(); }
-    c->blk.release(); c->seq.release(); c->offs.release(); c->ptr.release(); c->pat.release(); c->cnt_m.release(); c->cnt_s.release(); c->mem_slots.release(); c->tot.release();
+    c->blk.release(); c->seq.release(); c->offs.release(); c->ptr.release(); c->pat.release(); c->pflag.release(); c->cnt_m.release(); c->cnt_s.release(); c->mem_slots.release(); c->tot.release();
     c->read_mem_off.release(); c->mems.release(); c->aux.release(); c->lowers.release(); c->tmp.release();
     c->occ_cnt.release(); c->occ_off.release(); c->occs.release(); c->pool.release(); c->scan_tmp.release();
     for (int x = 0; x < AK_NSET; ++x) c->af[x].release();
@@ -575,10 +577,10 @@ static int ms_launch(moni_ctx* c) {
     const uint64_t n_tasks = 2 * c->n_reads;
     int rc;
     if (c->h_blk.empty()) return MONI_EINVAL;
-    if ((rc = c->ptr.ensure(c->h_blk.back().x + 1)) || (rc = c->pat.ensure(c->h_blk.back().y + 1))) return rc;
+    if ((rc = c->ptr.ensure(c->h_blk.back().x + 1)) || (rc = c->pat.ensure(c->h_blk.back().y + 1)) || (rc = c->pflag.ensure(n_tasks + 8))) return rc;
     const unsigned grid = (unsigned)((n_tasks + MS_BLOCK - 1) / MS_BLOCK);
     if (n_tasks)
-        hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, c->seq.p, c->offs.p, c->blk.p, n_tasks, c->pat.p);
+        hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(MS_BLOCK), 0, c->stream, I->K, I->d_tables, c->seq.p, c->offs.p, c->blk.p, n_tasks, c->pat.p, c->pflag.p);
     rec(c, EV_MS0);
     if (n_tasks) {
 #define MS_LAUNCH(NCH, MINW) do { const uint64_t nl = (n_tasks + (NCH) - 1) / (NCH); \
@@ -1230,7 +1232,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         size_t gather_tmp_bytes = 0;
         if (inorder) {
             if (rocprim::exclusive_scan(nullptr, gather_tmp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, (size_t)sub_reads, rocprim::plus<uint64_t>(), c->stream) != hipSuccess) return MONI_ENODEV;
-            if ((rc = c->gather_tmp[0].ensure(gather_tmp_bytes + 16)) || (rc = c->gather_tmp[1].ensure(gather_tmp_bytes + 16)) || (rc = c->gather_tmp[AK_NSET - 1].ensure(gather_tmp_bytes + 16))) return rc;
+            for (int x = 0; x < AK_NSET; ++x) if ((rc = c->gather_tmp[x].ensure(gather_tmp_bytes + 16))) return rc;
         }
         if (inorder) { HIPCHK(hipMemsetAsync(c->ak_dev_sum.p, 0, (160 * n_sub + 8) * sizeof(unsigned long long), c->stream)); memset(c->h_sum.p, 0, (4 * n_sub + 4) * sizeof(unsigned long long)); }
         if (use_fast) for (int x = 0; x < (int)std::min<uint64_t>(n_sub, AK_NSET); ++x) {
@@ -1425,7 +1427,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 G.chunks = S.chunks.p; G.chunk_cap = af_chunk_cap; G.dirs = S.dirs.p; G.dirs_cap = af_dirs_cap; G.tb_task = S.tb_task.p; G.tb = S.tb.p; G.tb_cap = af_tb_cap;
                 G.fb_n = c->fb_all.p + 16 * k; G.fb_list = c->fb_all.p + 16 * n_sub + k * (sub_reads + 1); G.big_list = S.big_list.p; G.huge_list = S.big_list.p + (sub_reads + 1); G.list0 = S.big_list.p + 2 * (sub_reads + 1); G.fin_scratch = S.fin.p; G.fin_stride = sizeof(af_fin_t); G.ctr = S.ctr.p;
                 G.bnd = S.bnd.p;
-                G.pat = c->pat.p; G.blk = c->blk.p; G.text2 = I->d_text2; G.exc = I->d_exc; G.exc_sh = I->exc_sh;
+                G.pat = c->pat.p; G.blk = c->blk.p; G.text2 = I->d_text2; G.exc = I->d_exc; G.exc_sh = I->exc_sh; G.pflag = c->pflag.p; G.wave_max = af_wave_max();
                 G.txt_cur = S.txt_cur.p; G.txt_shard_words = txt_per / (AF_TXT_SHARDS + 1);
                 HIPCHK(hipMemsetAsync(S.txt_cur.p, 0, AF_TXT_SHARDS * 8 * sizeof(unsigned long long), sx));
 #ifdef AF_PROFILE

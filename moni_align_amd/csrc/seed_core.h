@@ -161,7 +161,7 @@ MONI_HD uint64_t ws_pat_words(uint64_t lb) { return (lb + 7) / 8 + 2 * ((lb + 31
 MONI_HD uint64_t ws_block_len(const moni_u64x2* __restrict__ blk, uint64_t task) { return (blk[(task >> 6) + 1].x - blk[task >> 6].x) >> 6; }      // (a block's pointer words: 64 per step)
 
 MONI_HD void pack_task(const lds_tables_t& L, const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, const moni_u64x2* __restrict__ blk,
-                       uint64_t task, uint64_t* __restrict__ pat) {
+                       uint64_t task, uint64_t* __restrict__ pat, uint8_t* __restrict__ pflag = nullptr) {      // pflag[task]: the pattern holds a byte outside A / C / G / T
     const uint64_t read = task >> 1;
     const uint32_t strand = (uint32_t)task & 1u;
     const uint64_t off = offs[read];
@@ -188,6 +188,7 @@ MONI_HD void pack_task(const lds_tables_t& L, const uint8_t* __restrict__ seq, c
     const uint64_t lb = ws_block_len(blk, task);
     const uint64_t cb = pb + 64u * ((lb + 7) / 8), mb = cb + 64u * ((lb + 31) / 32);
     const uint32_t n2 = (m + 31u) >> 5;
+    uint64_t any_mask = 0;
     for (uint32_t w = 0; w < n2; ++w) {
         uint64_t codes = 0, mask = 0;
         for (uint32_t g = 0; g < 4; ++g) {
@@ -210,7 +211,9 @@ MONI_HD void pack_task(const lds_tables_t& L, const uint8_t* __restrict__ seq, c
         }
         pat[cb + (uint64_t)w * 64u] = codes;
         pat[mb + (uint64_t)w * 64u] = mask;
+        any_mask |= mask;
     }
+    if (pflag) pflag[task] = any_mask ? 1 : 0;
 }
 
 // byte qi of the strand-oriented pattern (= the byte consumed at step m-1-qi), through a one-word register cache

@@ -39,11 +39,11 @@ __device__ __forceinline__ void wave_add(unsigned long long v, unsigned long lon
 
 extern "C" __global__ void __launch_bounds__(MS_BLOCK)
 pack_kernel(const moni_consts_t K, const moni_tables_t* __restrict__ T, const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, const moni_u64x2* __restrict__ blk,
-            uint64_t n_tasks, uint64_t* __restrict__ pat) {
+            uint64_t n_tasks, uint64_t* __restrict__ pat, uint8_t* __restrict__ pflag) {
     __shared__ lds_tables_t L;
     load_tables(L, T, K);
     const uint64_t task = (uint64_t)blockIdx.x * MS_BLOCK + threadIdx.x;
-    if (task < n_tasks) pack_task(L, seq, offs, blk, task, pat);
+    if (task < n_tasks) pack_task(L, seq, offs, blk, task, pat, pflag);
 }
 
 // NCH independent tasks per lane (see ms_task); MINW = minimum waves per SIMD the register allocator must leave room for.

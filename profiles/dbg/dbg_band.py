@@ -20,19 +20,25 @@ else:
     reads = reads[:N]
     offs = np.arange(0, (N + 1) * 150, 150, dtype=np.uint64)
     seq = reads.reshape(-1)
+nrate = float(os.environ.get("DBG_N_RATE", "0"))
+if nrate > 0:      # a wildcard base in that share of the reads
+    seq = seq.copy(); rng = np.random.default_rng(7)
+    for r in np.nonzero(rng.random(N) < nrate)[0]:
+        seq[int(offs[r]) + int(rng.integers(0, int(offs[r + 1] - offs[r])))] = ord("N")
 names, noff = orc.make_names(N)
 q = np.full(len(seq), ord("I"), dtype=np.uint8)
 want, _ = orc.align_batch(orc.OracleIndex(path), seq, offs, names, noff, q, threads=8)
 idx = capi.Index(fi=fi); ctx = capi.Ctx(idx)
 wl = want.split(b"\n")
-for flag, noplank in (("0", False), ("0", True), ("131072", False), ("65536", False), ("196608", False)):
-    os.environ["MONI_AF_DBG"] = flag
-    if noplank: os.environ["MONI_AF_NOPLANK"] = "1"
-    else: os.environ.pop("MONI_AF_NOPLANK", None)
+SW = ("MONI_AF_DBG", "MONI_AF_NOPLANK", "MONI_AF_WAVE_MAX")
+for cfg in ({}, {"MONI_AF_NOPLANK": "1"}, {"MONI_AF_DBG": "131072"}, {"MONI_AF_DBG": "65536"}, {"MONI_AF_DBG": "196608"}, {"MONI_AF_WAVE_MAX": "0"}, {"MONI_AF_WAVE_MAX": "1000000"},
+            {"MONI_AF_WAVE_MAX": "1000000", "MONI_AF_DBG": "196608"}):
+    for k in SW: os.environ.pop(k, None)
+    os.environ.update(cfg)
     got, st = ctx.align_batch(seq, offs, names, noff, q, host_threads=8)
     gl = got.split(b"\n")
     bad = [k for k, (a, b) in enumerate(zip(gl, wl)) if a != b]
-    print("MONI_AF_DBG=%s noplank=%s: %d differing records of %d, %d to align_kernel, %d to host; cells %d cut %d slots %d; why %s" % (flag, noplank, len(bad), N, st["kernel_fallback"], st["handed_back"], st["dp_cells"], st["dp_cells_cut"], st["dp_slots"], st["handover_why"]), bad[:20])
+    print("%s: %d differing records of %d, %d to align_kernel, %d to host; cells %d cut %d slots %d; why %s" % (cfg, len(bad), N, st["kernel_fallback"], st["handed_back"], st["dp_cells"], st["dp_cells_cut"], st["dp_slots"], st["handover_why"]), bad[:20])
     for k in bad[:3]:
         ga, wa = gl[k].split(b"\t"), wl[k].split(b"\t")
         print("  got :", b" ".join(ga[:9] + ga[11:]).decode()[:400]); print("  want:", b" ".join(wa[:9] + wa[11:]).decode()[:400])

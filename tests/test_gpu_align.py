@@ -65,6 +65,33 @@ def test_banded_global_problems_equal_the_full_matrix(medium_case, env, monkeypa
     assert st["handed_back"] == st_full["handed_back"] == 0 and st["kernel_fallback"] == st_full["kernel_fallback"]          # ... and no read leaves the staged kernels because of the band
 
 
+def test_wildcard_bases_stay_on_the_staged_kernels(medium_case, env, monkeypatch):
+    """A base outside A / C / G / T scores sc_N against anything (ksw2's matrix).  A problem whose read holds one, or whose target touches a
+    text block that does, goes to queues of its own (bin_tasks_kernel / global_band_kernel) and is scored by the WILDC instance of dp_lane_kernel or - a queue
+    with few chunks - by dp_wave_kernel, one wavefront per pair of problems.  Every read with an N, one read in five, none: the SAM text equals the oracle's
+    under either kernel, no read is handed to align_kernel because of the wildcard, and dp_wave_kernel alone (every global problem forced through the full
+    matrix, every extension through the tile) gives the same text as well."""
+    base = list(medium_case.synth.make_reads(medium_case.pg, 3000, 150, seed=171, sub_rate=0.02, indel_rate=0.004)) + \
+           list(medium_case.synth.make_reads(medium_case.pg, 1500, 250, seed=172, sub_rate=0.03, indel_rate=0.002)) + \
+           list(medium_case.synth.make_reads(medium_case.pg, 1500, 90, seed=173))
+    rng = np.random.default_rng(23)
+    for rate in (1.0, 0.2, 0.0):
+        reads = [r.copy() for r in base]
+        for r in reads:
+            if rng.random() < rate:
+                r[int(rng.integers(0, len(r)))] = ord("N")
+                if rng.random() < 0.3: r[int(rng.integers(0, len(r)))] = ord("R")
+        stats = []
+        for wave_max, dbg in (("96", "0"), ("0", "0"), ("1000000", "0"), ("1000000", str(65536 + 131072))):
+            monkeypatch.setenv("MONI_AF_WAVE_MAX", wave_max)
+            monkeypatch.setenv("MONI_AF_DBG", dbg)
+            _, st = both(env, reads)
+            stats.append(st)
+            assert st["handed_back"] == 0 and st["handover_why"].get("wildcard_or_dirs", 0) == 0
+        assert len({st["aligned"] for st in stats}) == 1 and len({st["dp_cells"] for st in stats}) == 1
+        assert len({st["kernel_fallback"] for st in stats[:3]}) == 1
+
+
 def test_sub_batches_and_handed_back_reads(medium_case, env, monkeypatch):
     """The batch goes through the GPU in sub-batches overlapped with the host stage; reads the kernel hands back go
     through the host pipeline and are spliced in at their positions.  Output must not depend on either."""

@@ -88,8 +88,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
-    ap.add_argument("--inflight", type=int, default=1, help="contexts of this rank that work through the timed steps side by side, each with the batch resident (one caller thread per context, as moni-hip-align's workers): "
+    ap.add_argument("--inflight", type=int, default=2, help="contexts of this rank that work through the timed steps side by side, each with the batch resident (one caller thread per context, as moni-hip-align's workers): "
                                                             "the seeding kernels of one step overlap the align kernels of another; every step is still one whole pass over the batch")
+    ap.add_argument("--no-single-context", action="store_true", help="skip the leg that runs a few steps with one context alone after the timed region (--inflight > 1)")
     ap.add_argument("--n-rate", type=float, default=0.0, help="robustness leg: this fraction of the reads gets one N at a random place (real Illumina data: 0.5-2 %% of the reads hold an N); the DP problems that touch it leave the packed 2-bit kernels")
     ap.add_argument("--no-scaling-base", action="store_true", help="N = 1: skip the extra leg that runs configs[3]'s read set (--scaling-base-reads reads, resident chunks of --reads) on the one GPU")
     ap.add_argument("--scaling-base-reads", type=int, default=CONFIGS3_READS)
@@ -333,6 +334,8 @@ def run_rank(args) -> int:
         cx.upload(reads[cb[0]:cb[1]].reshape(-1), np.arange(0, (cb[1] - cb[0] + 1) * L, L, dtype=np.uint64))
         ctxs.append(cx)
     threads_step = max(1, threads // inflight)
+    if inflight > 1:          # two steps side by side fill the GPU by themselves: larger sub-batches (fewer, longer launches) do better then (profiles/r04o)
+        os.environ.setdefault("MONI_ALIGN_SUB", "500000")
 
     def one_pass(want_text=False, acc=None, cx=None):
         """the whole path over every resident chunk of this rank; returns (SAM bytes or total length, stats of the last chunk)"""
@@ -420,6 +423,23 @@ def run_rank(args) -> int:
     sizes = mdist.gather_counts([tot["aligned"], sam_len, n_mine], dist, coll_dev)     # per-rank record counts
     for cx in ctxs[1:]:
         cx.close()
+    # one context alone (no second step beside it): the latency of a step, and the kernels' durations without a neighbour
+    single = None
+    if inflight > 1 and not args.no_single_context:
+        sub_was = os.environ.pop("MONI_ALIGN_SUB", None)
+        one_pass()
+        sync_all()
+        n1s = max(1, min(4, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(n1s):
+            _, st1 = ctx.align_run(chunk[0][0], chunk[0][1], chunk[0][2], host_threads=threads, want_text=False)
+        sync_all()
+        e1 = mdist.max_over_ranks(time.perf_counter() - t1, dist, coll_dev)
+        single = {"ms_per_step": e1 / n1s * 1e3, "steps": n1s, "reads_per_s_this_rank": chunk[0][3] * n1s / e1, "ms_lf_kernel_ms": ctx.kernel_ms(0),
+                  "stages_ms": {"seed": st1["t_seed"] * 1e3, "align_kernels_span": st1["t_dp_kernel"] * 1e3},
+                  "note": "the same resident batch, one context by itself (sub-batches of 250 000), after the timed region"}
+        if sub_was is not None:
+            os.environ["MONI_ALIGN_SUB"] = sub_was
 
     # ---- the final SAM gather of the north star: per-rank blocks to rank 0 over RCCL, timed on its own ----------------------
     gather = None
@@ -626,6 +646,12 @@ def run_rank(args) -> int:
             out["from_host"] = from_host
         if scaling_base:
             out["scaling_base"] = scaling_base
+        if single:
+            out["single_context"] = single
+            if single["ms_lf_kernel_ms"] > 0:          # the headline leg's launches share the GPU with another step's kernels: the kernel by itself
+                a_s = single["ms_lf_kernel_ms"] / 1e3
+                out["roofline"]["kernel_alone"] = {"avg_launch_ms": single["ms_lf_kernel_ms"], "achieved": layout_bytes / a_s / 1e9, "frac": layout_bytes / a_s / 1e9 / HBM_PEAK_GBS,
+                                                   "note": "last launch of the single-context leg (HIP events): no other step's kernels beside it"}
         out["host"] = {"cpus_usable": host_cpus(), "cpu_count": os.cpu_count(), "host_threads_per_gpu": threads}
         if world == 1 and not args.no_cpu:
             from oracle import orc as _orc          # the CPU baseline / at-scale checker: the only use of oracle/ in this file
@@ -744,15 +770,48 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx, pha
             ctx_b.close()
             from_host["two_contexts"] = {"value": (hi - lo) / two_s, "unit": "pairs/s", "ms_per_batch": two_s * 1e3, "note": "two contexts on the GPU, one caller thread each"}
     # the headline: the mates resident in HBM when the timed region starts (moni_reads_upload), names and qualities host buffers as in moni_align_run
-    ctx.upload(seq, offs)
-    for _ in range(args.warmup):
-        ctx.pe_align_run(nm, no, ql, model, host_threads=threads, want_text=False, secondary_chains=zsec)
+    inflight = max(1, args.inflight)
+    ctxs = [ctx] + [capi.Ctx(idx) for _ in range(inflight - 1)]          # --inflight: the same mates resident in every context, one caller thread each
+    th_step = max(1, threads // inflight)
+    for cx in ctxs:
+        cx.upload(seq, offs)
+        for _ in range(args.warmup):
+            cx.pe_align_run(nm, no, ql, model, host_threads=th_step, want_text=False, secondary_chains=zsec)
     sync_all()
+    left, last, lk = [args.steps], {}, threading.Lock()
+
+    def stepper(cx):          # exactly args.steps passes in all: a context takes the next one as soon as it is through with its last
+        while True:
+            with lk:
+                if left[0] <= 0:
+                    return
+                left[0] -= 1
+            r_ = cx.pe_align_run(nm, no, ql, model, host_threads=th_step, want_text=False, secondary_chains=zsec)      # the text is in the context's pinned host buffer; no copy into a Python object
+            with lk:
+                last["r"] = r_
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sam_len, st = ctx.pe_align_run(nm, no, ql, model, host_threads=threads, want_text=False, secondary_chains=zsec)      # the text is in the context's pinned host buffer; no copy into a Python object
+    if inflight == 1:
+        stepper(ctx)
+    else:
+        th = [threading.Thread(target=stepper, args=(cx,)) for cx in ctxs]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
     sync_all()
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dist, coll_dev)
+    sam_len, st = last["r"]
+    single = None
+    if inflight > 1 and not args.no_single_context:
+        n1s = max(1, min(3, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(n1s):
+            _, st = ctx.pe_align_run(nm, no, ql, model, host_threads=threads, want_text=False, secondary_chains=zsec)
+        sync_all()
+        e1 = mdist.max_over_ranks(time.perf_counter() - t1, dist, coll_dev)
+        single = {"ms_per_step": e1 / n1s * 1e3, "steps": n1s, "pairs_per_s_this_rank": (hi - lo) * n1s / e1, "note": "the same resident mates, one context by itself, after the timed region; the stage times and the roofline's launch time below are this leg's"}
+    for cx in ctxs[1:]:
+        cx.close()
     lf_ms = ctx.kernel_ms(0)                      # ms_lf_kernel of the last step (one launch over the 2 N mates), HIP events on its own stream
     S_lf, J_lf = (int(x) for x in ctx.counters()[:2])
     sizes = mdist.gather_counts([st["aligned"], hi - lo], dist, coll_dev)
@@ -765,10 +824,11 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx, pha
                "config": {"workload": "SURVEY.md 8(f)-2: paired-end path on the BASELINE.json configs[2] index (%d bp base + %d haplotypes, n=%d, r=%d): %d FR pairs of 2 x %d bp per GPU "
                                       "(insert 350 +- 30, 0.5 %% substitutions) resident in HBM -> seeding kernels over the 2 N mates + staged paired kernels (wave per pair plan, lane per DP problem, select, finish, both SAM lines written and "
                                       "ordered on the GPU; pe_align_kernel for the pairs they hand over: orphan recovery) -> two SAM records per pair in pinned host memory" % (args.base_len, args.haps, idx.n, idx.r, args.pairs, L),
-                          "pairs_per_gpu": hi - lo, "read_len": L, "parallelism": "pairs sharded x%d, index replicated, fragment model learnt on rank 0 and broadcast" % world},
+                          "pairs_per_gpu": hi - lo, "read_len": L, "contexts_in_flight": inflight, "parallelism": "pairs sharded x%d, index replicated, fragment model learnt on rank 0 and broadcast" % world},
                "model": {"count": int(model.count), "mean": model.mean, "std_dev": model.std_dev, "complete": bool(model.complete)},
                "aligned_pairs_all_ranks": sum(x[0] for x in sizes), "stages_s_per_step": {"seed": st["t_seed"], "kernel_and_copies": st["t_dp"], "host_finish": st["t_host"]},
                "dp_problems": st["dp_tasks"], "dp_cells": st["dp_cells"], "pairs_through_host_pipeline": st["handed_back"],
+               "pairs_taken_by_pe_align_kernel": st["kernel_fallback"], "handed_over_because": st["handover_why"],
                # the path's HBM-bound kernel is the single-end path's: the LF / threshold-jump stage of seeding over the 2 N mates (same model as the default line)
                "roofline": {"bound": "hbm", "kernel": "ms_lf_kernel", "achieved": 73 * S_lf / (lf_ms / 1e3) / 1e9 if lf_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": 73 * S_lf / (lf_ms / 1e3) / 1e9 / HBM_PEAK_GBS if lf_ms > 0 else 0.0, "traffic": None, "model": "layout: 73 bytes per LF step", "avg_launch_ms": lf_ms,
@@ -777,6 +837,8 @@ def run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx, pha
                "host": {"cpus_usable": host_cpus(), "host_threads_per_gpu": threads}}
         if from_host is not None:
             out["from_host"] = from_host
+        if single is not None:
+            out["single_context"] = single
         if world == 1 and not args.no_cpu:
             from oracle import orc as _orc          # the CPU baseline / at-scale checker
             oidx = _orc.OracleIndex(fi=fi)

@@ -186,6 +186,7 @@ template <int MA_, int MC_, int MM_, int NC_, int NA_, int NT_, int PE_ = 0, int
 struct af_wave_tt {
     static constexpr int MA = MA_, MC = MC_, MM = MM_, NC = NC_, NA = NA_, NT = NT_;
     static constexpr bool SEC = SEC_ != 0;      // -Z: the second track of find_chains_secondary (chain.hpp:442-727): f2 / msc2 / p2 / t2 per anchor, twice the pool
+    static_assert(MC_ <= MA_, "the sorts of the chain starts and of the chains use per-anchor arrays as scratch");
     static constexpr int NSTACK = MA_ <= 128 ? 16 : MA_ <= 512 ? 20 : 24;      // pending partitions of the introsort emulation: at most 2 * floor(log2 n) + 1
     af_mem_t mem[MM_];
     uint64_t anch[MA_];                  // x (reference end, 40 bits) | mem << 40
@@ -213,6 +214,7 @@ struct af_wave_tt {
     };
 };
 static_assert(AF_MAX_TASKS_READ <= 255, "ntasks is a byte");
+// (an instance needs MC <= MA: the sorts of the chain starts and of the chains take per-anchor arrays as their scratch)
 typedef af_wave_tt<96, 48, 24, 8, 32, 32> af_wave_small_t;                                                   // most reads: 8 waves per SIMD
 typedef af_wave_tt<192, 96, 32, 16, 64, 48> af_wave_mid_t;            // LEVEL 0 for reads of more than 200 bases (250 bp x 21 sequences: ~120 anchors per read, p99 210: 27 % of the reads fit the small instance, 98.8 % this one): 4 waves per SIMD (a 160-anchor one at 5 waves per SIMD: 7.70 against 7.88 M reads/s)
 typedef af_wave_tt<AF_MAX_ANCH, AF_MAX_CHAINS, AF_MAX_MEMS, AF_MAX_CAND, AF_PLAN_AN, AF_MAX_TASKS_READ> af_wave_t;   // reads that overflow it

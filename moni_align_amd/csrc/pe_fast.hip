@@ -56,6 +56,9 @@ typedef af_wave_tt<160, 80, 24, 2 * PEF_MAX_Q, 64, 48, 1> pef_wave_small_t;
 // -Z (find_chains_secondary): the same two instances with the second track's arrays
 typedef af_wave_tt<160, 80, 24, 2 * PEF_MAX_Q, 64, 48, 1, 1> pef_wave_small_z_t;
 typedef af_wave_tt<AF_MAX_ANCH, AF_MAX_CHAINS, AF_MAX_MEMS, 2 * PEF_MAX_Q, AF_PLAN_AN, AF_MAX_TASKS_READ, 1, 1> pef_wave_z_t;
+// -Z: the second track starts a chain at about every anchor of a repeat-rich pair - more chains than AF_MAX_CHAINS for one pair in eighty of the benchmark
+// (profiles/r04p: 12 731 of 1 M pairs went to pe_align_kernel for it, two thirds of the -Z run's time).  LEVEL 2: four times the chains (and twice the anchors).
+typedef af_wave_tt<2 * AF_MAX_ANCH, 4 * AF_MAX_CHAINS, AF_MAX_MEMS, 2 * PEF_MAX_Q, AF_PLAN_AN, AF_MAX_TASKS_READ, 1, 1> pef_wave_zz_t;          // (the sorts' scratch arrays are per anchor: chains <= anchors)
 #define PEF_RAW_SMALL 32
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -64,8 +67,8 @@ typedef af_wave_tt<AF_MAX_ANCH, AF_MAX_CHAINS, AF_MAX_MEMS, 2 * PEF_MAX_Q, AF_PL
 __global__ void iota_kernel(uint32_t* __restrict__ out, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = i; }
 
 // LEVEL 0: every pair of the launch, the small instance; a pair beyond its capacities goes to G.big_list.  LEVEL 1: that list, the large instance;
-// a pair beyond ITS capacities goes to pe_align_kernel.
-template <class WT, int OCC, int RAW, int LEVEL>
+// a pair beyond ITS capacities goes to pe_align_kernel - or (LAST = 0: -Z) one with more chains than it holds to G.huge_list for LEVEL 2.
+template <class WT, int OCC, int RAW, int LEVEL, int LAST = 1>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) pe_plan_kernel(const pef_args_t X) {
     __shared__ WT L;
     __shared__ af_mem_t raw[RAW];               // the seeds of both mates as the seeding kernels left them (mate field: their strand bit)
@@ -76,13 +79,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     const ak_args_t& A = G.A;
     const ac_params_t& P = A.P;
     const int lane = threadIdx.x;
-    const uint32_t n_work = LEVEL == 0 ? (uint32_t)A.n_reads : G.ctr[AFC_BIG];
+    const uint32_t n_work = LEVEL == 0 ? (uint32_t)A.n_reads : G.ctr[LEVEL == 1 ? AFC_BIG : AFC_HUGE];
     while (true) {
         uint32_t w_in = 0;
-        if (lane == 0) w_in = atomicAdd(&G.ctr[LEVEL == 0 ? AFC_READ_CUR : AFC_BIG_CUR], 1u);
+        if (lane == 0) w_in = atomicAdd(&G.ctr[LEVEL == 0 ? AFC_READ_CUR : LEVEL == 1 ? AFC_BIG_CUR : AFC_HUGE_CUR], 1u);
         w_in = (uint32_t)__shfl((int)w_in, 0);
         if (w_in >= n_work) break;
-        const uint32_t r_in = LEVEL == 0 ? w_in : G.big_list[w_in];
+        const uint32_t r_in = LEVEL == 0 ? w_in : LEVEL == 1 ? G.big_list[w_in] : G.huge_list[w_in];
         const uint64_t pair = A.read_lo + r_in, r1 = 2 * pair, r2 = r1 + 1;
         const uint64_t off1 = A.offs[r1], off2 = A.offs[r2];
         const uint32_t m1 = (uint32_t)(off2 - off1), m2 = (uint32_t)(A.offs[r2 + 1] - off2);
@@ -92,6 +95,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         const bool too_long = m1 >= AF_MAX_READ || m2 >= AF_MAX_READ;
         bool fallback = too_long || n1 + n2 > (uint32_t)RAW;
         bool retry = false;                                       // LEVEL 0: beyond this instance, not (yet) beyond the staged kernels
+        bool chains_ovf = false;                                  // more chains than the instance holds
         if (m1 == 0 || m2 == 0) fallback = false;                 // (an empty mate: the pair is not aligned, pe_align_kernel's rule)
         uint32_t n_mems = 0, na = 0;
         float avg = 0.f;
@@ -180,7 +184,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
             status = af_chain(G, L, na, avg, af_grp_t<64>(), WT::SEC && X.PP.secondary_chains != 0);
             status = (uint32_t)__shfl((int)status, 0);
             __syncthreads();
-            if (status == 0xFFu) { fallback = true; status = AF_ST_UNALIGNED; }
+            if (status == 0xFFu) { fallback = true; chains_ovf = true; status = AF_ST_UNALIGNED; }
             else if (status == AF_ST_CAND) {
                 // check_paired_left_MEM's coordinates of every chain: the leftmost anchor of each mate, lifted (aligner_ksw2.hpp:1471-1500); 0: none
                 for (uint32_t ci = lane; ci < L.n_chains_sh; ci += 64) {
@@ -272,12 +276,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         }
         __syncthreads();
         if (LEVEL == 0 && fallback && !too_long) retry = true;
-        if (retry) {                                              // the large instance takes the pair
-            if (lane == 0) G.big_list[atomicAdd(&G.ctr[AFC_BIG], 1u)] = r_in;
+        if (LEVEL == 1 && !LAST && chains_ovf) retry = true;
+        if (retry) {                                              // the next larger instance takes the pair
+            if (lane == 0) { if (LEVEL == 0) G.big_list[atomicAdd(&G.ctr[AFC_BIG], 1u)] = r_in; else G.huge_list[atomicAdd(&G.ctr[AFC_HUGE], 1u)] = r_in; }
             __syncthreads();
             continue;
         }
-        if (fallback) { status = AF_ST_FALLBACK; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + (too_long ? AF_WHY_LONG : AF_WHY_ANCHORS)], 1u); }
+        if (fallback) { status = AF_ST_FALLBACK; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + (too_long ? AF_WHY_LONG : chains_ovf ? AF_WHY_CHAINS : AF_WHY_ANCHORS)], 1u); }
         // ---- the pair's tasks go to its own slots; the plan goes to HBM ----
         auto& PL = L.plan;
         const uint32_t nt = status == AF_ST_CAND ? L.n_tasks : 0u;

@@ -679,6 +679,8 @@ int main(int argc, char** argv) {
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
     Args a;
     parse(argc, argv, a);
+    // several contexts per GPU keep it busy by themselves: the library's sub-batches can be larger then (fewer, longer launches; bench.py --inflight, profiles/r04o)
+    if (a.ctx_per_gpu >= 2) setenv("MONI_ALIGN_SUB", "500000", 0);
     // -Z (secondary chains) acts in the paired path only, as in the reference (aligner_ksw2.hpp:1190-1191): run_paired passes it on; single-end input ignores it
     if (a.csv && (!a.mate1.empty() || !a.mate2.empty())) die("option -c is implemented for single-end input (-p) only");
     // -n: <prefix>.thrbv.full.ms (ms_pointers<>: no LCP samples; the occurrence walks measure the LCP on the text, seed_finder.hpp:346-370).

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 cd /tmp
 [ -f /tmp/moni_bench_cache/idx_61420004_12_lifted_0.mfi ] || MONI_BENCH_SAVE_INDEX=1 python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-from-host --no-scaling-base > /dev/null 2>&1
 OUT=$ROOT/gpurun_out/prof_clean; rm -rf $OUT; mkdir -p $OUT
-MONI_ALIGN_SUB=1000000 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu --no-from-host --no-scaling-base ${CLEAN_ARGS} > $OUT/b.json 2> $OUT/b.log
+MONI_ALIGN_SUB=1000000 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu --no-from-host --no-scaling-base --inflight 1 ${CLEAN_ARGS} > $OUT/b.json 2> $OUT/b.log
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 python3 - <<PY
 import csv, collections, statistics

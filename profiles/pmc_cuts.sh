@@ -7,10 +7,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-MONI_BENCH_SAVE_INDEX=1 python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-from-host > $OUT/bench_build.json 2> $OUT/bench_build.log || exit 1
+MONI_BENCH_SAVE_INDEX=1 python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-from-host --no-scaling-base --inflight 1 > $OUT/bench_build.json 2> $OUT/bench_build.log || exit 1
 for v in "$@"; do
   MONI_AF_DBG=$v MONI_HIP_LIB=$ROOT/moni_align_amd/csrc/libmoni_hip_cuts.so timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
-      --kernel-include-regex "chain_plan|finish_wave" --output-format csv -d $OUT/pmc_$v -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-from-host > $OUT/b_$v.json 2> $OUT/b_$v.log || { echo "cut $v failed"; tail -3 $OUT/b_$v.log; continue; }
+      --kernel-include-regex "chain_plan|finish_wave" --output-format csv -d $OUT/pmc_$v -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-from-host --no-scaling-base --inflight 1 > $OUT/b_$v.json 2> $OUT/b_$v.log || { echo "cut $v failed"; tail -3 $OUT/b_$v.log; continue; }
   python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/pmc_$v/**/*counter_collection.csv", recursive=True)[0]

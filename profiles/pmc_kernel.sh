@@ -9,12 +9,12 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-MONI_BENCH_SAVE_INDEX=1 python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-from-host > $OUT/bench_build.json 2> $OUT/bench_build.log || exit 1
+MONI_BENCH_SAVE_INDEX=1 python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-from-host --no-scaling-base --inflight 1 > $OUT/bench_build.json 2> $OUT/bench_build.log || exit 1
 i=0
 for E in "$@"; do
   i=$((i+1))
   echo "== $E =="
-  ( export $E; rocprofv3 --pmc $CTRS --kernel-include-regex "$RE" --output-format csv -d $OUT/pmc_$i -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-from-host > $OUT/bench_pmc_$i.json 2> $OUT/bench_pmc_$i.log ) || exit 1
+  ( export $E; rocprofv3 --pmc $CTRS --kernel-include-regex "$RE" --output-format csv -d $OUT/pmc_$i -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-from-host --no-scaling-base --inflight 1 > $OUT/bench_pmc_$i.json 2> $OUT/bench_pmc_$i.log ) || exit 1
   python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/pmc_$i/**/*counter_collection.csv", recursive=True)[0]

@@ -281,6 +281,15 @@ int moni_pe_align_stream(moni_ctx_t *ctx, const moni_read_batch_t *batch, const 
  * are host buffers as in moni_align_run); *sam in the context's buffer as for moni_pe_align_stream. */
 int moni_pe_align_run(moni_ctx_t *ctx, const uint8_t *names, const uint64_t *name_off, const uint8_t *quals, const moni_align_params_t *prm,
                       const moni_pe_params_t *pe, const moni_pe_model_t *model, char **sam, uint64_t *sam_len, moni_align_stats_t *stats);
+/* aligner::align(kpbseq_t*, out, csv_out) with csv (-c for pairs; aligner_ksw2.hpp:888-918, 1030-1031, 1066-1075, 1115-1118, 1354-1358;
+ * include/common/csv.hpp:26-67): the SAM records of moni_pe_align_batch and one line of MEM statistics per PAIR under mate 1's name (the MEMs of a
+ * pair are kept together: alignment.record_csv writes csv_m1 alone, aligner_ksw2.hpp:787-791).  A diagnostics mode like moni_align_csv_batch: the
+ * counts of filtered MEMs and skipped chains exist only in the selection loop, so every pair takes the host's state machine (pe_big.cpp) over the GPU's
+ * seeds and DP batches.  *sam and *csv are malloc'ed (moni_free). */
+int moni_pe_align_csv_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,
+                            const uint8_t *quals, const moni_align_params_t *prm, const moni_pe_params_t *pe,
+                            const moni_pe_model_t *model, char **sam, uint64_t *sam_len, char **csv, uint64_t *csv_len,
+                            moni_align_stats_t *stats);
 /* aligner::align(paired_alignment_t&) with report_mems (-m for pairs; aligner_ksw2.hpp:1118-1180): one secondary record per occurrence of every MEM
  * the direction and frequency filters leave, under its mate's name.  *sam is malloc'ed. */
 int moni_pe_report_mems_batch(moni_ctx_t *ctx, const moni_read_batch_t *batch, const uint8_t *names, const uint64_t *name_off,

@@ -27,7 +27,7 @@ EXPORTS = [
     "moni_align_params_default", "moni_align_batch", "moni_align_csv_batch", "moni_align_run", "moni_align_stream", "moni_sam_header",
     "moni_ldx_info", "moni_ldx_rewrite", "moni_ldx_lift_batch", "moni_ldx_write",
     "moni_ms_file_info", "moni_ms_file_read", "moni_ms_file_write", "moni_index_load_reference", "moni_ms_lengths_batch", "moni_report_mems_batch",
-    "moni_pe_params_default", "moni_pe_learn_batch", "moni_pe_align_batch", "moni_pe_align_stream", "moni_pe_align_run", "moni_pe_report_mems_batch",
+    "moni_pe_params_default", "moni_pe_learn_batch", "moni_pe_align_batch", "moni_pe_align_stream", "moni_pe_align_run", "moni_pe_align_csv_batch", "moni_pe_report_mems_batch",
 ]
 
 
@@ -152,6 +152,7 @@ def lib():
         L.moni_pe_align_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC),
                                           C.POINTER(PeParamsC), C.POINTER(PeModelC), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
         L.moni_pe_align_stream.argtypes = L.moni_pe_align_batch.argtypes
+        L.moni_pe_align_csv_batch.argtypes = L.moni_pe_align_batch.argtypes[:-1] + [C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
         L.moni_pe_align_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC), C.POINTER(PeParamsC), C.POINTER(PeModelC),
                                         C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(AlignStatsC)]
         L.moni_pe_report_mems_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatchC), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AlignParamsC), C.POINTER(PeParamsC),
@@ -419,6 +420,23 @@ class Ctx:
             if not stream:
                 self._L.moni_free(out)
         return sam, _stats_dict(st)
+
+    def pe_align_csv(self, seq, offsets, names, name_off, quals, model: "PeModelC", host_threads: Optional[int] = None, **overrides):
+        """(SAM text, CSV lines, stats) of moni_pe_align_csv_batch (`-c` for pairs: one line per pair)"""
+        b, keep = self._batch(seq, offsets)
+        names = np.ascontiguousarray(names, dtype=np.uint8)
+        name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
+        if quals is not None:
+            quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        prm, pe = self._pe_params(host_threads, overrides)
+        sam, sl, csv, cl, st = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64(), AlignStatsC()
+        _chk(self._L.moni_pe_align_csv_batch(self._h, C.byref(b), names.ctypes.data, name_off.ctypes.data, quals.ctypes.data if quals is not None else None,
+                                             C.byref(prm), C.byref(pe), C.byref(model), C.byref(sam), C.byref(sl), C.byref(csv), C.byref(cl), C.byref(st)), "moni_pe_align_csv_batch")
+        try:
+            return C.string_at(sam, sl.value), C.string_at(csv, cl.value), _stats_dict(st)
+        finally:
+            self._L.moni_free(sam)
+            self._L.moni_free(csv)
 
     def pe_align_run(self, names: np.ndarray, name_off: np.ndarray, quals, model: "PeModelC", host_threads: Optional[int] = None, want_text: bool = True, **overrides):
         """moni_pe_align_run over the interleaved pairs made resident by upload(); the text is in the context's buffer (want_text=False: its length)"""

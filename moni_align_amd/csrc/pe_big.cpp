@@ -22,6 +22,7 @@
 #define AC_MAX_CIGAR 8192
 #define PE_MAX_BEST 1024
 
+#define PE_CSV_COUNT
 namespace pe_big {
 #include "align_core.h"
 #include "pe_core.h"
@@ -52,7 +53,7 @@ int pe_big_run(const void* pe_params, size_t pe_params_size, const moni_mem_t* m
                 too_long = too_long || W.m[k] >= 32768;                    // 16-bit read coordinates in the chaining nodes
             }
             W.min_score = (int32_t)((uint32_t)W.min_score_m[0] + (uint32_t)W.min_score_m[1]);
-            if (too_long || W.m[0] == 0 || W.m[1] == 0) { ac_reset(W.W); W.W.overflow = too_long ? 1u : 0u; W.final = pe_pscore_t(); W.score2 = W.score2_m[0] = W.score2_m[1] = 0; W.sub_n = 0; W.strand = 0; W.filled[0] = W.filled[1] = 0; W.n_alt[0] = W.n_alt[1] = 0; continue; }
+            if (too_long || W.m[0] == 0 || W.m[1] == 0) { W.csv_filter = W.csv_skipped = 0; ac_reset(W.W); W.W.overflow = too_long ? 1u : 0u; W.final = pe_pscore_t(); W.score2 = W.score2_m[0] = W.score2_m[1] = 0; W.sub_n = 0; W.strand = 0; W.filled[0] = W.filled[1] = 0; W.n_alt[0] = W.n_alt[1] = 0; continue; }
             if (pe_init(W, PP, mems, rmo, aux, occs, p)) pe_drive(W, PP, nullptr, nullptr);
         }
         while (true) {                                                      // DP rounds of the group
@@ -78,6 +79,7 @@ int pe_big_run(const void* pe_params, size_t pe_params_size, const moni_mem_t* m
             R.status = W.W.overflow ? 2u : (W.W.aligned ? 1u : 0u);
             R.strand = W.strand; R.tot = W.final.tot; R.score2 = W.score2; R.sub_n = W.sub_n; R.dist = W.final.dist;
             R.mate_score[0] = W.final.m1.score; R.mate_score[1] = W.final.m2.score;
+            R.csv_filter = W.csv_filter; R.csv_skipped = W.csv_skipped;
             for (int k = 0; k < 2; ++k) {
                 R.score2_m[k] = W.score2_m[k];
                 R.filled[k] = 0; R.orphan[k] = 0; R.cig[k].clear(); R.alt_pos[k].clear(); R.alt_score[k].clear();

@@ -20,6 +20,7 @@ struct PeBigPair {
     std::vector<uint32_t> cig[2];
     std::vector<uint64_t> alt_pos[2];
     std::vector<int32_t> alt_score[2];
+    uint64_t csv_filter = 0, csv_skipped = 0;      // `-c`: occurrences of the MEMs the direction / frequency filters dropped, chains check_paired_left_MEM skipped
 };
 // one batch of DP problems (operands: the resident reads and the index text): results + CIGAR pool
 typedef std::function<int(const std::vector<moni_dp_task_t>&, std::vector<moni_dp_result_t>&, std::vector<uint32_t>&)> PeBigDp;

@@ -42,7 +42,15 @@ struct pe_left_t { uint64_t r1, r2, score; };
 // pair's state stays in its slot); 1: it runs the loop for its block of consecutive chains (block o_part of o_nsplit) and RECORDS each chain's score instead of
 // absorbing it; 2: it runs the loop in chain order from the records - no DP - and goes on to the final alignments.  0: the whole thing in one go.
 struct pe_orec_t { uint32_t tag, kind; pe_pscore_t sc; };      // kind 1: the chain's score; 2: the chain's requests were beyond the kernel (-> the pair's status 2)
+// PE_CSV_COUNT (the host build of pe_big.cpp only): the two numbers of the `-c` line that the state machine alone knows - occurrences of the MEMs the
+// direction and frequency filters drop (aligner_ksw2.hpp:1066-1075, 1905-1933), chains check_paired_left_MEM skips (:1354-1358)
+#ifdef PE_CSV_COUNT
+#define PE_CSV(x) x
+#else
+#define PE_CSV(x)
+#endif
 struct pe_ws_t {
+    PE_CSV(uint64_t csv_filter; uint64_t csv_skipped;)
     uint32_t o_mode, o_part, o_nsplit, o_tag, o_parked, o_pad;
     pe_orec_t* orec;                     // the pair's records, one per chain
     ac_sec_t sec[AC_MAX_ANCH];           // -Z: the second track of the chaining
@@ -105,6 +113,7 @@ AC_HD_BIG bool pe_init(pe_ws_t& S, const pe_params_t& PP, const moni_mem_t* gm, 
     ac_ws_t& W = S.W;
     const ac_params_t& P = PP.P;
     ac_reset(W);
+    PE_CSV(S.csv_filter = 0; S.csv_skipped = 0;)
     S.o_mode = 0; S.o_part = 0; S.o_nsplit = 1; S.o_tag = 0; S.o_parked = 0; S.orec = nullptr;
     S.n_best = S.n_left = 0; S.n_alt[0] = S.n_alt[1] = 0; S.max_m[0] = S.max_m[1] = 0;
     S.score2 = S.score2_m[0] = S.score2_m[1] = 0; S.sub_n = 0; S.strand = 0; S.filled[0] = S.filled[1] = 0; S.n_cigar[0] = S.n_cigar[1] = 0;
@@ -154,6 +163,7 @@ AC_HD_BIG bool pe_init(pe_ws_t& S, const pe_params_t& PP, const moni_mem_t* gm, 
         uint32_t lo = 0, hi = W.n_mems;
         if (a1 > a2 && (a1 - a2) > PP.dir_thr) hi = n_dir1;
         if (a2 > a1 && (a2 - a1) > PP.dir_thr) lo = n_dir1;
+        PE_CSV(for (uint32_t i = 0; i < lo; ++i) S.csv_filter += W.mems[i].nocc; for (uint32_t i = hi; i < W.n_mems; ++i) S.csv_filter += W.mems[i].nocc;)
         if (lo > 0) for (uint32_t i = lo; i < hi; ++i) W.mems[i - lo] = W.mems[i];
         W.n_mems = hi - lo;
     }
@@ -163,7 +173,7 @@ AC_HD_BIG bool pe_init(pe_ws_t& S, const pe_params_t& PP, const moni_mem_t* gm, 
         uint32_t k = 0;
         for (uint32_t i = 0; i < W.n_mems; ++i) {
             const double fr = static_cast<double>(W.mems[i].nocc) / total;
-            if (fr > P.freq_thr) continue;
+            if (fr > P.freq_thr) { PE_CSV(S.csv_filter += W.mems[i].nocc;) continue; }
             if (k != i) W.mems[k] = W.mems[i];
             ++k;
         }
@@ -367,7 +377,7 @@ AC_HD_BIG bool pe_advance(pe_ws_t& S, const pe_params_t& PP) {
     while (W.stage == AC_LOOP && !W.overflow) {
         if (W.i < W.n_chains && W.n_diff < P.check_k) {
             { const uint64_t v = (uint64_t)W.chains[W.i].score; bool f = false; for (uint32_t q = 0; q < W.n_diff; ++q) f = f || W.diff[q] == v; if (!f) W.diff[W.n_diff++] = v; }
-            if (P.left_mem_check && pe_check_left(S, PP, W.i)) { ++W.i; continue; }
+            if (P.left_mem_check && pe_check_left(S, PP, W.i)) { ++W.i; PE_CSV(++S.csv_skipped;) continue; }
             if (W.overflow) return false;
             if (W.n_diff < P.check_k) {
                 if (!W.chains[W.i].paired) {              // paired_chain_score returns the empty score (aligner_ksw2.hpp:2145)

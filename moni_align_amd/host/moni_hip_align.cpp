@@ -19,7 +19,7 @@
 // in-order window.  -m writes the report-MEMs records (aligner_ksw2.hpp:346-373);
 // --ms / --mems write the legacy `moni ms` / `moni mems` text outputs (src/matching_statistics.cpp:520-610, src/mems.cpp:520-600).
 // -n loads <prefix>.thrbv.full.ms (no LCP samples); -q is accepted (the text comes from the BWT, not from either grammar).
-// -c writes <sam>.csv (per-read MEM statistics, csv.hpp:55-67; single-end, through the host pipeline; exit 1 with a message for pairs).  -Z (secondary chains,
+// -c writes <sam>.csv (per-read MEM statistics, csv.hpp:55-67; through the host pipeline - for pairs one line per pair, moni_pe_align_csv_batch).  -Z (secondary chains,
 // chain.hpp:442-727) acts on paired input and is ignored for single-end input, as in the reference (aligner_ksw2.hpp:1190-1191 is the only call site).
 #include <fcntl.h>
 #include <getopt.h>
@@ -506,6 +506,17 @@ static int run_paired(Args& a, const std::string& sam_filename) {
     FILE* out = fopen(sam_filename.c_str(), "w");
     if (!out) die("open() file " + sam_filename + " failed");
     { char* h; uint64_t hl; if (moni_sam_header(idx[0], &h, &hl)) die("header"); put(h, hl, out); moni_free(h); }
+    // -c: <sam>.csv, one line per pair (aligner_ksw2.hpp:911-914; header of aligner::to_csv, :3230-3234); the blocks of the batches are kept and written in input order at the end
+    FILE* out2 = nullptr;
+    std::map<size_t, std::string> csv_blocks;
+    std::mutex mu_csv;
+    std::string csv_first;
+    if (a.csv) {
+        out2 = fopen((sam_filename + ".csv").c_str(), "w");
+        if (!out2) die("open() file " + sam_filename + ".csv failed");
+        static const char hdr[] = "Read,Unique,Total,Max_Freq,Min_Freq,Highest_Occ,Lowest_Occ,Filtered,Chains_Skipped\n";
+        put(hdr, sizeof hdr - 1, out2);
+    }
     moni_pe_model_t model;
     memset(&model, 0, sizeof model);
     size_t processed = 0, aligned = 0;
@@ -516,6 +527,14 @@ static int run_paired(Args& a, const std::string& sam_filename) {
             const int rm = moni_pe_report_mems_batch(ctx[g], &rb, b.names.data(), b.name_off.data(), b.has_qual ? b.qual.data() : nullptr, &a.P, &a.PE, sam, len);
             if (rm) die("moni_pe_report_mems_batch failed (" + std::to_string(rm) + ")");
             *n_al = 0;
+            return;
+        }
+        if (a.csv) {
+            char* cs = nullptr; uint64_t cl = 0;
+            const int rc = moni_pe_align_csv_batch(ctx[g], &rb, b.names.data(), b.name_off.data(), b.has_qual ? b.qual.data() : nullptr, &a.P, &a.PE, &model, sam, len, &cs, &cl, &st);
+            if (rc) die("moni_pe_align_csv_batch failed (" + std::to_string(rc) + ")");
+            csv_first.assign(cs, cl); moni_free(cs);
+            *n_al = st.aligned;
             return;
         }
         const int rc = moni_pe_align_batch(ctx[g], &rb, b.names.data(), b.name_off.data(), b.has_qual ? b.qual.data() : nullptr, &a.P, &a.PE, &model, sam, len, &st);
@@ -547,6 +566,7 @@ static int run_paired(Args& a, const std::string& sam_filename) {
             char* sam = nullptr; uint64_t len = 0, n_al = 0;
             align_one(0, all, &sam, &len, &n_al);
             put(sam, len, out); moni_free(sam);
+            if (out2) put(csv_first.data(), csv_first.size(), out2);
             processed += all.n() / 2; aligned += n_al;
         }
     }
@@ -616,6 +636,14 @@ static int run_paired(Args& a, const std::string& sam_filename) {
             if (a.report_mems) {
                 const int rm = moni_pe_report_mems_batch(C, &rb, v_names, v_noff, v_qual, &a.P, &a.PE, &sam, &len);
                 if (rm) die("moni_pe_report_mems_batch failed (" + std::to_string(rm) + ")");
+            } else if (a.csv) {
+                moni_align_stats_t st;
+                char* cs = nullptr; uint64_t cl = 0;
+                const int rc = moni_pe_align_csv_batch(C, &rb, v_names, v_noff, v_qual, &a.P, &a.PE, &model, &sam, &len, &cs, &cl, &st);
+                if (rc) die("moni_pe_align_csv_batch failed (" + std::to_string(rc) + ")");
+                { std::lock_guard<std::mutex> lk(mu_csv); csv_blocks[it.id].assign(cs, cl); }
+                moni_free(cs);
+                n_al = st.aligned;
             } else {          // the text in the context's pinned buffer: written out before the context's next call
                 moni_align_stats_t st;
                 const int rc = moni_pe_align_stream(C, &rb, v_names, v_noff, v_qual, &a.P, &a.PE, &model, &sam, &len, &st);
@@ -644,7 +672,7 @@ static int run_paired(Args& a, const std::string& sam_filename) {
             t_lib[w] += x2 - x1; t_wait[w] += x3 - x2; t_write[w] += x4 - x3;
             if (verbose_batches) fprintf(stderr, "batch %zu (worker %d, %zu pairs): library %.0f ms, wait %.0f ms, write %.0f ms, done at %.3f s\n", it.id, w, v_n / 2, (x2 - x1) * 1e3, (x3 - x2) * 1e3, (x4 - x3) * 1e3,
                                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-            if (a.report_mems) moni_free(sam);
+            if (a.report_mems || a.csv) moni_free(sam);
             n_proc += v_n / 2; n_al_all += n_al;
             delete it.b; delete it.f;
         }
@@ -655,6 +683,7 @@ static int run_paired(Args& a, const std::string& sam_filename) {
         for (auto& t : th) t.join();
     }
     reader.join();
+    if (out2) { for (auto& kv : csv_blocks) put(kv.second.data(), kv.second.size(), out2); if (fclose(out2) != 0) die("short write to the csv file"); }
     processed += n_proc.load(); aligned += n_al_all.load();
     {
         double sl = 0, sw = 0, sr = 0;
@@ -682,7 +711,6 @@ int main(int argc, char** argv) {
     // several contexts per GPU keep it busy by themselves: the library's sub-batches can be larger then (fewer, longer launches; bench.py --inflight, profiles/r04o)
     if (a.ctx_per_gpu >= 2) setenv("MONI_ALIGN_SUB", "500000", 0);
     // -Z (secondary chains) acts in the paired path only, as in the reference (aligner_ksw2.hpp:1190-1191): run_paired passes it on; single-end input ignores it
-    if (a.csv && (!a.mate1.empty() || !a.mate2.empty())) die("option -c is implemented for single-end input (-p) only");
     // -n: <prefix>.thrbv.full.ms (ms_pointers<>: no LCP samples; the occurrence walks measure the LCP on the text, seed_finder.hpp:346-370).
     // -q: the reference would take the text from <prefix>.slp (SelfShapedSlp) instead of <prefix>.plain.slp; both grammars spell the same
     //     text and neither is read here - the text is rebuilt from the BWT - so the flag changes nothing (align_full_ksw2.cpp:414-426)

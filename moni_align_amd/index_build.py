@@ -28,6 +28,7 @@ import io
 import struct
 from typing import List, Optional
 
+import os
 import numpy as np
 import torch
 
@@ -176,15 +177,17 @@ def _rank32(rank: torch.Tensor) -> torch.Tensor:
     return (((rank + (1 << 31)) & 0xFFFFFFFF) - (1 << 31)).to(torch.int32)
 
 
-def suffix_array(codes: torch.Tensor, bits: int, keep_levels: bool = True, log=None, _force_wide: bool = False):
+def suffix_array(codes: torch.Tensor, bits: int, keep_levels: bool = True, log=None, _force_wide: bool = False, rank64: bool = False):
     """codes: uint8/int64 [n] with a unique smallest 0 at the end.  Returns (sa, key0, k0, levels)
     where levels = [(k, rank_k int32)] for every doubling level (rank_k equal <=> first k
-    symbols equal).  n < 2^32 (the levels keep 32 bits of a rank); the doubling key rank * (n + 1) + rank' fits a signed 64-bit word up to
+    symbols equal).  The levels keep 32 bits of a rank (n < 2^32) or - rank64, the only form for n >= 2^32: a GRCh38-scale pangenome - the whole
+    64-bit rank (8 bytes per position and level instead of 4); the doubling key rank * (n + 1) + rank' fits a signed 64-bit word up to
     n = 3.03e9 - beyond that (_force_wide: always, for tests) a level is two stable sorts instead of one."""
     dev = codes.device
     n = codes.numel()
-    if n >= (1 << 32):
-        raise ValueError("index_build: n = %d does not fit the 32-bit rank levels of the LCP computation" % n)
+    if n >= (1 << 32) and not rank64:
+        raise ValueError("index_build: n = %d does not fit the 32-bit rank levels of the LCP computation (build with rank64=True / MONI_BUILD_RANK64=1)" % n)
+    lvl = (lambda r: r.clone()) if rank64 else _rank32
     wide = _force_wide or (n + 1) * (n + 1) >= (1 << 63)
     k0 = 60 // bits
     c64 = torch.cat([codes.to(torch.int64), torch.zeros(k0, dtype=torch.int64, device=dev)])
@@ -197,7 +200,7 @@ def suffix_array(codes: torch.Tensor, bits: int, keep_levels: bool = True, log=N
     del skey
     rank = torch.empty(n, dtype=torch.int64, device=dev)
     rank[sa] = gstart
-    levels = [(k0, _rank32(rank))] if keep_levels else []
+    levels = [(k0, lvl(rank))] if keep_levels else []
     k = k0
     while not bool(flag.all()):
         if log:
@@ -230,7 +233,7 @@ def suffix_array(codes: torch.Tensor, bits: int, keep_levels: bool = True, log=N
         rank[sa] = gstart
         k *= 2
         if keep_levels:
-            levels.append((k, _rank32(rank)))
+            levels.append((k, lvl(rank)))
     return sa, key0, k0, levels
 
 
@@ -288,9 +291,10 @@ def build_flat_index(text: np.ndarray, seq_starts: np.ndarray, names: List[str],
     codes = torch.from_numpy(np.concatenate([b2c[text], np.zeros(1, np.uint8)])).to(dev)
     if log:
         log("suffix array: n=%d sigma=%d bits=%d on %s" % (n, sigma, bits, dev))
-    sa, key0, k0, levels = suffix_array(codes, bits, keep_levels=True, log=log)
+    rank64 = n >= (1 << 32) or os.environ.get("MONI_BUILD_RANK64", "") not in ("", "0")      # (the flag: the wide form on any text, e.g. to test it)
+    sa, key0, k0, levels = suffix_array(codes, bits, keep_levels=True, log=log, rank64=rank64)
     if log:
-        log("lcp from %d levels" % len(levels))
+        log("lcp from %d levels%s" % (len(levels), " (64-bit ranks)" if rank64 else ""))
     lcp = lcp_from_levels(sa, key0, k0, bits, levels)
     del levels, key0
     # BWT (codes), runs

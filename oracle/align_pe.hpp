@@ -98,6 +98,7 @@ struct aligner_pe : aligner {
         std::vector<std::pair<size_t, size_t>> anchors;
         std::vector<chain_t> chains;
         std::vector<paired_score_t> best_scores;
+        csv_t csv_m1;                                       // -c: the pair's MEM statistics (aligner_ksw2.hpp:672, 787-791: one line per pair, under mate 1's name)
     };
 
     static void remove_slash_mate(read_t& r) {             // common/sam.hpp:132-141
@@ -246,7 +247,7 @@ struct aligner_pe : aligner {
         while (i < al.chains.size() and different_scores.size() < k) {
             different_scores.insert(al.chains[i].score);
             if (cfg.left_mem_check) {
-                if (check_paired_left_MEM(m1_left, m2_left, al, i)) { ++i; continue; }
+                if (check_paired_left_MEM(m1_left, m2_left, al, i)) { ++i; al.csv_m1.num_chains_skipped++; continue; }      // aligner_ksw2.hpp:1354-1358
             }
             if (different_scores.size() < k) {
                 paired_score_t score = paired_chain_score(al, i);
@@ -292,6 +293,7 @@ struct aligner_pe : aligner {
             mem_finder.find_mems(al.mate1_rev.seq.data(), l1, al.mems, l2, MATE_1 | MATE_RC);
             al.n_mems_dir2 = al.mems.size() - al.n_mems_dir1; al.n_seeds_dir2 = 0;
             mem_finder.populate_seeds(al.mems, cfg.report_mems);
+            if (csv_out) calculate_MEM_stats(al.mems, al.csv_m1);          // aligner_ksw2.hpp:1030-1031
             // NB: populate_seeds appends the halves of long MEMs behind all four calls' MEMs; the direction statistics below run over
             // the first n_mems_dir1 entries and "the rest", halves included, exactly as the reference's index arithmetic does
             for (size_t i = 0; i < al.n_mems_dir1; ++i) {
@@ -308,18 +310,23 @@ struct aligner_pe : aligner {
                 al.armonic_avg_seed_length_dir2 += (double)l2 / (double)al.mems[i].len;
             }
             if (al.n_mems_dir2 > 0) { al.avg_seed_length_dir2 /= al.n_mems_dir2; al.avg_w_seed_length_dir2 /= al.n_seeds_dir2; al.armonic_avg_seed_length_dir2 = (double)al.n_mems_dir2 / al.armonic_avg_seed_length_dir2; }
-            if ((al.avg_seed_length_dir1 > al.avg_seed_length_dir2) and ((al.avg_seed_length_dir1 - al.avg_seed_length_dir2) > pe.dir_thr))
+            if ((al.avg_seed_length_dir1 > al.avg_seed_length_dir2) and ((al.avg_seed_length_dir1 - al.avg_seed_length_dir2) > pe.dir_thr)) {
+                for (size_t i = al.n_mems_dir1; i < al.mems.size(); ++i) al.csv_m1.num_mems_filter += al.mems[i].occs.size();      // aligner_ksw2.hpp:1066-1068
                 al.mems.erase(al.mems.begin() + al.n_mems_dir1, al.mems.end());
-            if ((al.avg_seed_length_dir2 > al.avg_seed_length_dir1) and ((al.avg_seed_length_dir2 - al.avg_seed_length_dir1) > pe.dir_thr))
+            }
+            if ((al.avg_seed_length_dir2 > al.avg_seed_length_dir1) and ((al.avg_seed_length_dir2 - al.avg_seed_length_dir1) > pe.dir_thr)) {
+                for (size_t i = 0; i < al.n_mems_dir1; ++i) al.csv_m1.num_mems_filter += al.mems[i].occs.size();                  // aligner_ksw2.hpp:1073-1075
                 al.mems.erase(al.mems.begin(), al.mems.begin() + al.n_mems_dir1);
-            if (cfg.filter_freq) { csv_t csv_m1; seed_freq_filter(al.mems, cfg.freq_thr, csv_m1); }
+            }
+            if (cfg.filter_freq) seed_freq_filter(al.mems, cfg.freq_thr, al.csv_m1);
         } else {
             mem_finder.find_mems(al.mate1.seq.data(), l1, al.mems, 0, MATE_1 | MATE_F);
             mem_finder.find_mems(al.mate1_rev.seq.data(), l1, al.mems, l2, MATE_1 | MATE_RC);
             mem_finder.find_mems(al.mate2.seq.data(), l2, al.mems, 0, MATE_2 | MATE_F);
             mem_finder.find_mems(al.mate2_rev.seq.data(), l2, al.mems, l1, MATE_2 | MATE_RC);
             mem_finder.populate_seeds(al.mems, cfg.report_mems);
-            if (cfg.filter_freq) { csv_t csv_m1; seed_freq_filter(al.mems, cfg.freq_thr, csv_m1); }
+            if (csv_out) calculate_MEM_stats(al.mems, al.csv_m1);          // aligner_ksw2.hpp:1115-1116
+            if (cfg.filter_freq) seed_freq_filter(al.mems, cfg.freq_thr, al.csv_m1);
         }
         if (cfg.report_mems && mems_out != nullptr) {               // aligner_ksw2.hpp:1118-1180: one secondary record per occurrence of every MEM left
             for (size_t i = 0; i < al.mems.size(); ++i) {
@@ -618,10 +625,12 @@ struct aligner_pe : aligner {
                 write_sam(out, al.sam_m1);
                 write_sam(out, al.sam_m2);
             }
+            if (csv_out) write_csv(*csv_out, al.mate1.name, al.csv_m1);      // alignment.record_csv (aligner_ksw2.hpp:911-914): mate 1's name as remove_slash_mate left it
             if (al.aligned) ++aligned;
         }
         return aligned;
     }
+    std::string* csv_out = nullptr;          // -c: where align_batch puts the pairs' lines (include/common/csv.hpp:55-67)
 
     // st_align's paired loop (align_reads_dispatcher.hpp:356-389): batches of b_size pairs; learn until the model is complete (or the input
     // ends), align the batches read so far, then the rest

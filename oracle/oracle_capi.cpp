@@ -225,11 +225,14 @@ char* orc_align_csv(void* h, const uint8_t* seqs, const uint64_t* offsets, uint6
 }
 // Paired-end path (align_pe.hpp; find_orphan == 0: the reference with -u), one thread, st_align's batch order: mate k of pair i is
 // read i of batch k.  out[0] = aligned pairs, out[1..4] = the learnt insert-size model (count, mean, std dev, complete).
+// (bit 4 of find_orphan: -c - the text returned is the pairs' CSV lines, include/common/csv.hpp:55-67, instead of the SAM records)
 char* orc_align_pe(void* h, const uint8_t* seqs1, const uint64_t* off1, const uint8_t* seqs2, const uint64_t* off2, uint64_t n_pairs,
                    const uint8_t* names1, const uint64_t* noff1, const uint8_t* names2, const uint64_t* noff2, const uint8_t* quals1,
                    const uint8_t* quals2, uint64_t b_size, int find_orphan, uint64_t* out_len, double* out) {
     const FlatIndex& ix = *(FlatIndex*)h;
     align_config_t cfg;
+    const bool want_csv = (find_orphan & 16) != 0;
+    find_orphan &= 15;
     if (find_orphan & 2) { cfg.report_mems = true; find_orphan &= 13; }          // bit 1: -m, the MEM records of the pairs instead of their alignments
     pe_config_t pcfg;
     if (find_orphan & 8) { pcfg.secondary_chains = true; find_orphan &= 7; }   // bit 3: -Z
@@ -245,8 +248,10 @@ char* orc_align_pe(void* h, const uint8_t* seqs1, const uint64_t* off1, const ui
         if (quals1) { m1[i].qual.assign((const char*)quals1 + off1[i], (const char*)quals1 + off1[i + 1]); m1[i].has_qual = true; }
         if (quals2) { m2[i].qual.assign((const char*)quals2 + off2[i], (const char*)quals2 + off2[i + 1]); m2[i].has_qual = true; }
     }
-    std::string all;
+    std::string all, csv;
+    if (want_csv) A.csv_out = &csv;
     const size_t aligned = A.align_all(m1, m2, b_size ? b_size : 512, all);
+    if (want_csv) all.swap(csv);
     if (out) { out[0] = (double)aligned; out[1] = (double)A.ins_count; out[2] = A.ins_mean; out[3] = A.ins_std_dev; out[4] = A.ins_learning_complete ? 1.0 : 0.0; out[5] = (double)A.orphan_pairs; out[6] = (double)A.orphan_recovered; }
     char* buf = (char*)malloc(all.size() + 1);
     memcpy(buf, all.data(), all.size());

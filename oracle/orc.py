@@ -210,9 +210,9 @@ def align_csv(oidx: "OracleIndex", seqs: np.ndarray, offsets: np.ndarray, names,
 
 
 def align_pe(oidx: "OracleIndex", seqs1, offs1, seqs2, offs2, names1, noff1, names2, noff2, quals1=None, quals2=None, b_size: int = 512,
-             find_orphan: bool = False, report_mems: bool = False, filter_dir: bool = True, secondary_chains: bool = False):
+             find_orphan: bool = False, report_mems: bool = False, filter_dir: bool = True, secondary_chains: bool = False, csv: bool = False):
     """SAM text (bytes) of the reference's paired-end path without orphan recovery (oracle/align_pe.hpp), one thread, st_align's
-    batch order, plus {"aligned", "ins_count", "ins_mean", "ins_std_dev", "ins_complete"}."""
+    batch order, plus {"aligned", "ins_count", "ins_mean", "ins_std_dev", "ins_complete"}.  csv: the pairs' `-c` lines instead of the SAM text."""
     c = lambda a, t: np.ascontiguousarray(a, dtype=t)
     seqs1, seqs2, names1, names2 = c(seqs1, np.uint8), c(seqs2, np.uint8), c(names1, np.uint8), c(names2, np.uint8)
     offs1, offs2, noff1, noff2 = c(offs1, np.uint64), c(offs2, np.uint64), c(noff1, np.uint64), c(noff2, np.uint64)
@@ -223,7 +223,7 @@ def align_pe(oidx: "OracleIndex", seqs1, offs1, seqs2, offs2, names1, noff1, nam
     st = np.zeros(7, dtype=np.float64)
     p = lib().orc_align_pe(oidx._h, seqs1.ctypes.data, offs1.ctypes.data, seqs2.ctypes.data, offs2.ctypes.data, n, names1.ctypes.data, noff1.ctypes.data,
                            names2.ctypes.data, noff2.ctypes.data, quals1.ctypes.data if quals1 is not None else None,
-                           quals2.ctypes.data if quals2 is not None else None, b_size, int(find_orphan) | (2 if report_mems else 0) | (0 if filter_dir else 4) | (8 if secondary_chains else 0), ctypes.byref(out_len), st.ctypes.data)
+                           quals2.ctypes.data if quals2 is not None else None, b_size, int(find_orphan) | (2 if report_mems else 0) | (0 if filter_dir else 4) | (8 if secondary_chains else 0) | (16 if csv else 0), ctypes.byref(out_len), st.ctypes.data)
     try:
         sam = ctypes.string_at(p, out_len.value)
     finally:

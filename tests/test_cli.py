@@ -62,9 +62,9 @@ def test_dry_run_write_multi_gpu_batching(exe, small_case, tmp_path):
 def test_unsupported_modes_exit_1(exe, tmp_path):
     fq = str(tmp_path / "x.fq")
     open(fq, "w").write("@a\nACGT\n+\nIIII\n")
-    for extra in (["-1", fq, "-2", fq, "-c"],):
+    for extra, msg in ((["-1", fq], b"needs both -1 and -2"), (["-1", fq, "-2", fq, "--ms"], b"take single-end input"), ([], b"no reads given")):
         r = subprocess.run([exe, "x"] + extra, capture_output=True)
-        assert r.returncode == 1 and (b"not implemented" in r.stderr or b"is implemented for single-end" in r.stderr)
+        assert r.returncode == 1 and msg in r.stderr
     assert subprocess.run([exe], capture_output=True).returncode == 1
 
 
@@ -226,6 +226,13 @@ def test_cli_paired_end(exe, medium_case, tmp_path):
     subprocess.check_call([exe, prefix, "-1", f1, "-2", f2p, "-Z", "-o", out5, "-S", "1000", "-F", "0.5", "-t", "4", "-b", "512", "--gpu-batch", "2048"])
     want5, _ = oracle_pe(o, m1, m2, b_size=512, find_orphan=True, secondary_chains=True)
     assert want5 != want2 and open(out5, "rb").read()[len(hdr):] == want5
+    # -c: one line of MEM statistics per pair in <sam>.csv, the SAM file unchanged (several batches, several workers: the lines in input order)
+    out6 = str(tmp_path / "pe_csv.sam")
+    subprocess.check_call([exe, prefix, "-1", f1, "-2", f2p, "-u", "-c", "-o", out6, "-S", "1000", "-F", "0.5", "-t", "4", "-b", "512", "--gpu-batch", "700"])
+    want6, _ = oracle_pe(o, m1, m2, b_size=512, csv=True)
+    assert open(out6, "rb").read()[len(hdr):] == want
+    got6 = open(out6 + ".csv", "rb").read()
+    assert got6 == b"Read,Unique,Total,Max_Freq,Min_Freq,Highest_Occ,Lowest_Occ,Filtered,Chains_Skipped\n" + want6 and got6.count(b"\n") == 1501
     out4 = str(tmp_path / "pe_plain.sam")
     subprocess.check_call([exe, prefix, "-1", f1, "-2", f2p, "-o", out4, "-S", "1000", "-F", "0.5", "-t", "4", "-b", "512", "--gpu-batch", "300"])
     assert open(out4, "rb").read()[len(hdr):] == want2

@@ -204,6 +204,38 @@ def test_pe_report_mems(case, filter_dir):
         raise AssertionError("MEM records differ at record %d:\n got: %s\nwant: %s" % first_diff(got, want))
 
 
+@pytest.mark.parametrize("filter_dir", [1, 0])
+def test_pe_csv_statistics(case, filter_dir):
+    """-c for pairs (moni_pe_align_csv_batch; aligner_ksw2.hpp:888-918, 1030-1031, 1066-1075, 1115-1118, 1354-1358; csv.hpp:55-67): one line per pair under
+    mate 1's name without its slash suffix - MEMs of both mates and their halves, their occurrences, the extreme frequencies and per-genome counts, the
+    occurrences the direction and frequency filters drop, the chains check_paired_left_MEM skips - and the unchanged SAM records: both equal the oracle's."""
+    pg, fi, o = case
+    a1, a2 = hard_pairs(pg, n=260, seed=43)
+    b1, b2, _ = make_pairs(pg, 340)
+    m1, m2 = list(a1) + list(b1), list(a2) + list(b2)
+    n = len(m1)
+    want_sam, st = oracle_pe(o, m1, m2, b_size=n, filter_dir=bool(filter_dir))
+    want_csv, _ = oracle_pe(o, m1, m2, b_size=n, filter_dir=bool(filter_dir), csv=True)
+    seq, offs, names, noff, q = interleave(m1, m2)
+    idx = capi.Index(fi=fi)
+    ctx = capi.Ctx(idx)
+    try:
+        model = capi.PeModelC()
+        ctx.pe_learn(seq, offs, model, filter_dir=filter_dir)
+        sam, csv, gst = ctx.pe_align_csv(seq, offs, names, noff, q, model, host_threads=4, filter_dir=filter_dir, find_orphan=0)
+    finally:
+        ctx.close()
+        idx.close()
+    assert model.count == st["ins_count"] and model.mean == st["ins_mean"]
+    if sam != want_sam:
+        raise AssertionError("SAM differs at record %d:\n got: %s\nwant: %s" % first_diff(sam, want_sam))
+    if csv != want_csv:
+        raise AssertionError("CSV differs at line %d:\n got: %s\nwant: %s" % first_diff(csv, want_csv))
+    cols = np.array([[float(x) for x in ln.split(b",")[1:]] for ln in csv.split(b"\n") if ln])
+    assert cols.shape == (n, 8) and cols[:, 0].max() > 2 and cols[:, 7].sum() > 0          # chains were skipped somewhere
+    assert csv.split(b"\n")[0].startswith(b"p0,")                                            # remove_slash_mate
+
+
 def test_pe_stream_variant_and_small_chunks(case, monkeypatch):
     """moni_pe_align_stream (text in the context's buffer, kept across calls) = moni_pe_align_batch; many chunks in flight (every chunk owns its
     records and pools, the hand-over kernels run on several streams)"""

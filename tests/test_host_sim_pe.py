@@ -25,7 +25,7 @@ def interleave(m1, m2, slash=True, names=None):
     return seq, offs, np.frombuffer(b"".join(nm), np.uint8), noff, np.full(len(seq), ord("I"), np.uint8)
 
 
-def oracle_pe(o, m1, m2, slash=True, b_size=512, find_orphan=False, report_mems=False, secondary_chains=False):
+def oracle_pe(o, m1, m2, slash=True, b_size=512, find_orphan=False, report_mems=False, secondary_chains=False, csv=False, filter_dir=True):
     n = len(m1)
     o1 = np.zeros(n + 1, np.uint64); o1[1:] = np.cumsum([len(x) for x in m1])
     o2 = np.zeros(n + 1, np.uint64); o2[1:] = np.cumsum([len(x) for x in m2])
@@ -35,7 +35,7 @@ def oracle_pe(o, m1, m2, slash=True, b_size=512, find_orphan=False, report_mems=
     no2 = np.zeros(n + 1, np.uint64); no2[1:] = np.cumsum([len(x) for x in nm2])
     q1 = np.full(int(o1[-1]), ord("I"), np.uint8); q2 = np.full(int(o2[-1]), ord("I"), np.uint8)
     return orc.align_pe(o, np.concatenate(m1), o1, np.concatenate(m2), o2, np.frombuffer(b"".join(nm1), np.uint8), no1,
-                        np.frombuffer(b"".join(nm2), np.uint8), no2, q1, q2, b_size=b_size, find_orphan=find_orphan, report_mems=report_mems, secondary_chains=secondary_chains)
+                        np.frombuffer(b"".join(nm2), np.uint8), no2, q1, q2, b_size=b_size, find_orphan=find_orphan, report_mems=report_mems, secondary_chains=secondary_chains, csv=csv, filter_dir=filter_dir)
 
 
 def first_diff(a: bytes, b: bytes):

@@ -86,6 +86,21 @@ def test_wide_doubling_and_32_bit_rank_levels_equal_the_default_path():
     assert torch.equal(sa0, sa1) and k0 == k1 and len(lv0) == len(lv1) and len(lv0) >= 4
     assert all(torch.equal(a[1], b[1]) for a, b in zip(lv0, lv1))
     assert torch.equal(ib.lcp_from_levels(sa0, key0, k0, 3, lv0), ib.lcp_from_levels(sa1, key1, k1, 3, lv1))
+    # n >= 2^32 (a GRCh38-scale pangenome): the levels keep the whole 64-bit rank - same arrays
+    sa2, key2, k2, lv2 = ib.suffix_array(c, 3, _force_wide=True, rank64=True)
+    assert torch.equal(sa0, sa2) and all(b[1].dtype == torch.int64 and torch.equal(a[1].to(torch.int64), b[1]) for a, b in zip(lv0, lv2))
+    assert torch.equal(ib.lcp_from_levels(sa0, key0, k0, 3, lv0), ib.lcp_from_levels(sa2, key2, k2, 3, lv2))
     r = torch.tensor([0, 5, (1 << 31) - 1, 1 << 31, (1 << 31) + 7, (1 << 32) - 1], dtype=torch.int64)
     w = ib._rank32(r)
     assert w.dtype == torch.int32 and len(set(w.tolist())) == len(r) and w[:3].tolist() == [0, 5, (1 << 31) - 1]
+
+
+def test_rank64_build_gives_the_same_index(small_case, tmp_path, monkeypatch):
+    """MONI_BUILD_RANK64=1 (what a text of 2^32 positions or more takes by itself): the saved index is byte for byte the default build's"""
+    from moni_align_amd import index_build as ib
+    pg = small_case.pg
+    a, b = str(tmp_path / "a.mfi"), str(tmp_path / "b.mfi")
+    ib.build_from_pangenome(pg, device="cpu").save(a)
+    monkeypatch.setenv("MONI_BUILD_RANK64", "1")
+    ib.build_from_pangenome(pg, device="cpu").save(b)
+    assert open(a, "rb").read() == open(b, "rb").read()

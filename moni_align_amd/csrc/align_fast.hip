@@ -2804,6 +2804,461 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
 
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// finish_prep_kernel + finish_render_kernel: finish_wave_kernel's work in two kernels.  What lane 0 of a wavefront did alone there - stitch the CIGAR
+// (aligner_ksw2.hpp:3049-3108), lift it (:3133-3160), MAPQ (mapq.hpp:146-184), and the MD / NM walks (sam.hpp:249-287), which were 64 columns wide but a
+// few items long - is ONE LANE's work per read here: 64 reads per wavefront, 1 / 64 of the wavefront instructions (finish_wave_kernel issued ~3500 per
+// read, 63 of 64 lanes idle in two thirds of them: profiles/r04t).  The lane leaves a "recipe" in HBM (AFP_WORDS words per read: header numbers, the
+// alternatives, the stitched and the lifted CIGAR, the MD items).  finish_render_kernel, one wavefront per read, stages the recipe, lays the line's segments
+// out BY ALL LANES (a segment's kind and length follow from its index; offsets by a wavefront scan - finish_wave_kernel's lane 0 listed them one by one) and
+// renders and stores the bytes as before.  Same bytes, same records, same hand-overs to the host pipeline.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define AFP_WORDS 512u
+#define AFP_ALT 16u              // 3 words per alternative: sequence, 1-based position, score
+#define AFP_CIG 64u
+#define AFP_LCIG 128u
+#define AFP_MD 256u
+enum { AFP_F_ALIGNED = 1u, AFP_F_MAPPED = 2u, AFP_F_STRAND = 4u, AFP_F_HOST = 8u };
+enum { AFP_H_FLAGS = 0, AFP_H_NCIG, AFP_H_NMD, AFP_H_NM, AFP_H_LIFTNM, AFP_H_MAPQ, AFP_H_SCORE, AFP_H_SCORE2, AFP_H_POS1, AFP_H_OAPOS, AFP_H_SIDS, AFP_H_LIFTED_LO, AFP_H_LIFTED_HI,
+       AFP_H_POS_LO, AFP_H_POS_HI, AFP_H_N };
+static_assert(AFP_H_N <= AFP_ALT && AFP_ALT + 3 * AF_MAX_CAND <= AFP_CIG && AFP_CIG + AFS_CIG <= AFP_LCIG && AFP_LCIG + AFS_LCIG <= AFP_MD && AFP_MD + AFS_MAXMD <= AFP_WORDS, "recipe layout");
+
+// a sequence of bytes read front to back by one lane, eight per load (af_bytes_t; element e = byte start + e, or start - e)
+struct afl_stream_t { af_bytes_t S; uint64_t w; int g; };
+__device__ __forceinline__ afl_stream_t afl_stream(const uint8_t* base, uint64_t start, uint64_t limit, bool rev) { afl_stream_t x; x.S = af_bytes(base, start, limit, rev); x.w = 0; x.g = -1; return x; }
+__device__ __forceinline__ uint32_t afl_at(afl_stream_t& x, uint32_t e) {
+    const int g = (int)(e >> 3);
+    if (g != x.g) { x.w = af_group(x.S, g); x.g = g; }
+    return (uint32_t)(x.w >> (8 * (e & 7u))) & 0xFFu;
+}
+// The 2-bit forms of the read (the seeding stage's pattern workspace: code and mask words of the read's strand-resolved pattern, 64 words apart) and of the text
+struct afl_two_t { const uint64_t* pat; uint64_t cb, mb, n2w; const uint64_t* text2; uint64_t n_tw; const uint32_t* exc; uint32_t exc_sh; };
+// 32 bases from base `first` of a 2-bit sequence whose words lie `stride` apart (n_w of them)
+__device__ __forceinline__ uint64_t afl_bits2(const uint64_t* __restrict__ w, uint64_t stride, uint64_t n_w, uint64_t first) {
+    const uint64_t i = first >> 5; const uint32_t sh = 2u * (uint32_t)(first & 31u);
+    const uint64_t lo = i < n_w ? w[i * stride] : 0ull;
+    if (!sh) return lo;
+    const uint64_t hi = i + 1 < n_w ? w[(i + 1) * stride] : 0ull;
+    return (lo >> sh) | (hi << (64u - sh));
+}
+// MD / NM of one CIGAR (write_MD_core), one lane: afs_md's items, one after the other.  A stretch of matches / mismatches is compared 32 columns at a time through the
+// 2-bit forms (one XOR; an item per set bit) - column by column only where a byte outside A / C / G / T may lie (the read's mask words, the text's exception
+// bitmap): with 64 reads per wavefront the column loop's ~100 instructions per column were this kernel's whole cost (profiles/r04v).
+__device__ __forceinline__ int afl_md(const dp_launch_t& D, const afl_two_t& W, uint64_t off, uint32_t m, uint32_t strand, const uint32_t* __restrict__ cg, uint32_t n_cig, uint64_t t0,
+                                      bool items, uint32_t& n_items, uint32_t* __restrict__ md) {
+    afl_stream_t TS = afl_stream(D.text, t0, D.text_limit, false), RS = afl_stream(D.reads, strand ? off + m - 1 : off, D.reads_limit, strand != 0);
+    int NM = 0; uint32_t l_MD = 0, ni = 0;
+    bool bad = false;
+    uint64_t t = t0; uint32_t q = 0;
+    for (uint32_t i = 0; i < n_cig; ++i) {
+        const uint32_t op = cg[i] & 0xf, len = cg[i] >> 4;
+        if (op == 0 || op == 7 || op == 8) {
+            for (uint32_t k0 = 0; k0 < len; k0 += 32) {
+                const uint32_t n = len - k0 < 32 ? len - k0 : 32;
+                const uint64_t ta = t + k0; const uint32_t qa = q + k0;
+                const uint64_t lowm = n < 32 ? (1ull << (2 * n)) - 1ull : ~0ull;
+                bool two = W.pat != nullptr && ta + n <= D.n_text && qa + n <= m;
+                uint64_t pw = 0, tw = 0;
+                if (two) {
+                    const uint64_t b0 = ta >> W.exc_sh, b1 = (ta + n - 1) >> W.exc_sh;
+                    if (((W.exc[b0 >> 5] >> (b0 & 31u)) | (W.exc[b1 >> 5] >> (b1 & 31u))) & 1u) two = false;
+                    else if (afl_bits2(W.pat + W.mb, 64, W.n2w, qa) & lowm) two = false;
+                    else { pw = afl_bits2(W.pat + W.cb, 64, W.n2w, qa); tw = afl_bits2(W.text2, 1, W.n_tw, ta); }
+                }
+                if (two) {
+                    uint64_t x = pw ^ tw;
+                    x = (x | (x >> 1)) & 0x5555555555555555ull & lowm;
+                    uint32_t prev = 0;
+                    while (x) {
+                        const uint32_t b = (uint32_t)__builtin_ctzll(x), k = b >> 1, c2 = (uint32_t)(tw >> b) & 3u;
+                        const uint32_t tc = c2 == 2 ? 3u : c2 == 3 ? 2u : c2;          // (b >> 1) & 3: A 0, C 1, T 2, G 3 -> seq_nt4_table's A 0, C 1, G 2, T 3
+                        const uint32_t run = l_MD + (k - prev);
+                        if (items) { if (ni < AFS_MAXMD) md[ni] = 1u | ((run & 0x3FFu) << 2) | (tc << 12); if (run > 0x3FFu) bad = true; }
+                        ++ni; ++NM; l_MD = 0; prev = k + 1;
+                        x &= x - 1;
+                    }
+                    l_MD += n - prev;
+                } else {
+                    for (uint32_t k = k0; k < k0 + n; ++k) {
+                        const uint64_t a = t + k;
+                        const uint32_t tc = a < D.n_text ? dp_nt4(afl_at(TS, (uint32_t)(a - t0))) : dp_nt4(0u);
+                        const uint32_t rb = q + k < m ? afl_at(RS, q + k) : 0u;
+                        const uint32_t rc = dp_nt4(strand ? (uint32_t)ak_compl((uint8_t)rb) : rb);          // the read in alignment orientation (kpbseq.h:120-137), as finish_wave_kernel stages it
+                        if (rc != tc) {
+                            if (items) { if (ni < AFS_MAXMD) md[ni] = 1u | ((l_MD & 0x3FFu) << 2) | (tc << 12); if (l_MD > 0x3FFu) bad = true; }
+                            ++ni; ++NM; l_MD = 0;
+                        } else ++l_MD;
+                    }
+                }
+            }
+            q += len; t += len;
+        } else if (op == 1) { q += len; NM += (int)len; }
+        else if (op == 2) {
+            if (items) {
+                if (ni < AFS_MAXMD) md[ni] = 2u | ((l_MD & 0x3FFu) << 2) | ((len & 0x1FFu) << 12) | ((uint32_t)(t - t0) << 21);
+                if (l_MD > 0x3FFu || len > 0x1FFu || (t - t0) > 0x7FFu) bad = true;
+            }
+            ++ni;
+            l_MD = 0; t += len; NM += (int)len;
+        } else if (op == 3) t += len;
+    }
+    if (items && l_MD > 0) { if (ni < AFS_MAXMD) md[ni] = (l_MD & 0x3FFu) << 2; if (l_MD > 0x3FFu) bad = true; ++ni; }
+    n_items = (bad || ni > AFS_MAXMD) ? AFS_MAXMD + 1 : ni;
+    return NM;
+}
+
+__global__ void __launch_bounds__(64) finish_prep_kernel(const af_args_t G, uint32_t* __restrict__ recipes) {
+    const ak_args_t& A = G.A;
+    const ak_fmt_t& F = A.fmt;
+    for (uint64_t r_in = (uint64_t)blockIdx.x * 64 + threadIdx.x; r_in < A.n_reads; r_in += (uint64_t)gridDim.x * 64) {
+        const af_plan_t& PL = G.plans[r_in];
+        const uint64_t* H = reinterpret_cast<const uint64_t*>(&PL);
+        const uint64_t h0 = H[0], h1 = H[1], h2 = H[2], h4 = H[4];
+        const uint32_t st = (uint32_t)(h0 & 0xFFu);
+        if (st == AF_ST_FALLBACK) continue;
+        uint32_t* __restrict__ S = recipes + (size_t)r_in * AFP_WORDS;
+        const bool aligned = st == AF_ST_FINAL;
+        if (!aligned) { S[AFP_H_FLAGS] = 0; continue; }
+        const uint32_t h_final = (uint32_t)(h1 & 0xFFu), n_alt = (uint32_t)((h1 >> 8) & 0xFFu), strand = (uint32_t)((h1 >> 16) & 0xFFu);
+        const int32_t score2 = (int32_t)(uint32_t)(h1 >> 32);
+        const uint32_t h_tb0 = (uint32_t)h4, h_an0 = (uint32_t)(h4 >> 32) & 0xFFFFu;
+        const uint64_t r = A.read_lo + r_in;
+        const uint64_t off = A.offs[r];
+        const uint32_t m = (uint32_t)(A.offs[r + 1] - off);
+        const uint64_t aln_pos = h2;
+        uint32_t hint0 = 0xFFFFFFFFu;
+        const uint32_t sid0 = ac_seq_of(A.P, aln_pos, &hint0);
+        const moni_lift_seq_t LS0 = A.P.lift_seqs[sid0];
+        const af_cand_t C = PL.cand[h_final];
+        uint32_t* const cig = S + AFP_CIG; uint32_t* const lcig = S + AFP_LCIG;
+        // ---- CIGAR stitching (aligner_ksw2.hpp:3049-3108); the last operation written is kept in a register (a match run merges into it) ----
+        uint32_t n = 0, last = 0; bool ovf = false;
+#define PUSH(op) do { if (n < AFS_CIG) { last = (op); cig[n++] = last; } else ovf = true; } while (0)
+#define PUSH_MERGE_FIRST(op, first) do { const uint32_t o_ = (op); if ((first) && (o_ & 0xf) == 0 && n > 0) { last += o_; cig[n - 1] = last; } else PUSH(o_); } while (0)
+        uint32_t tbx = h_tb0;
+        if (C.overlap) {
+            const af_tb_t& T = G.tb[tbx];
+            if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) PUSH(T.ops[T.n_ops - 1 - k]);
+        } else {
+            if (C.has_lc) { const af_tb_t& T = G.tb[tbx++]; if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) PUSH(T.ops[k]); }
+            const uint32_t rc_x = C.has_rc ? tbx++ : 0u;
+            const af_anchor_t* const AN = PL.an + h_an0;
+            for (uint32_t j = 0; j < C.n_an; ++j) {
+                const af_anchor_t g = AN[j];
+                const uint32_t mlen = g.len;
+                if (n > 0 && (last & 0xf) == 0) { last += mlen << 4; cig[n - 1] = last; } else PUSH(mlen << 4);
+                if (j + 1 < C.n_an) {
+                    if (g.gap_kind == AF_GAP_TASK) { const af_tb_t& T = G.tb[tbx++]; if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) PUSH_MERGE_FIRST(T.ops[T.n_ops - 1 - k], k == 0); }
+                    else if (g.gap_kind == AF_GAP_INS) PUSH_MERGE_FIRST(((uint32_t)(uint16_t)g.gap_val << 4) | 1u, true);
+                    else if (g.gap_kind == AF_GAP_DEL0) PUSH_MERGE_FIRST(2u, true);
+                    else if (g.gap_kind == AF_GAP_1X1) PUSH_MERGE_FIRST(1u << 4, true);
+                }
+            }
+            if (C.has_rc) { const af_tb_t& T = G.tb[rc_x]; if (T.n_ops == ~0u) ovf = true; else for (uint32_t k = 0; k < T.n_ops; ++k) PUSH_MERGE_FIRST(T.ops[T.n_ops - 1 - k], k == 0); }
+        }
+#undef PUSH
+#undef PUSH_MERGE_FIRST
+#if defined(AF_CUTS)
+        if (G.dbg & 0x100000u) { S[AFP_H_FLAGS] = n; continue; }          // timing experiments (results are wrong): stop after the stitching ...
+#endif
+        // ---- the alignment lifted to the reference contig (aligner_ksw2.hpp:3133-3160) ----
+        const moni_lift_run_t* __restrict__ runs = A.P.lift_runs + LS0.run_off;
+        const uint32_t rel = hint0 == 0xFFFFFFFFu ? hint0 : hint0 - LS0.run_off;
+        uint64_t lp = 0;
+        const int nl = ovf ? -1 : lift_cigar(runs, LS0.n_runs, aln_pos - LS0.start, cig, n, lcig, AFS_LCIG, rel, &lp);
+        if (nl < 0) ovf = true;
+        const uint64_t lifted = LS0.second + (ovf ? 0ull : lp);
+        const uint32_t n_cig = n, n_lcig = nl < 0 ? 0u : (uint32_t)nl;
+#if defined(AF_CUTS)
+        if (G.dbg & 0x200000u) { S[AFP_H_FLAGS] = n_lcig + (uint32_t)lifted; continue; }          // ... after the lift
+#endif
+        uint32_t flags = AFP_F_ALIGNED | (strand ? AFP_F_STRAND : 0u);
+        int nm = 0, lift_nm = 0, mapq = 0, oa_pos = 0, pos1 = 0;
+        uint32_t n_md = 0, lsid = 0;
+        if (ovf || m > AF_MAX_READ) flags |= AFP_F_HOST;      // more operations than the staging holds: the host pipeline redoes the read
+        else {
+            uint64_t ref_len = 0;
+            for (uint32_t k = 0; k < n_lcig; ++k) { const uint32_t o = lcig[k]; const int op = o & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += o >> 4; }
+            const bool mapped = ref_len > 0;
+            if (mapped) flags |= AFP_F_MAPPED;
+            lsid = ac_seq_of(A.P, lifted);
+            oa_pos = (int)(aln_pos - LS0.start + 1);
+            pos1 = (int)(lifted - A.P.lift_seqs[lsid].start + 1);
+            const int32_t score = C.score;
+            {   // compute_mapq_se_bwa (mapq.hpp:146-184), the operations in the host's order, none contracted
+                const int32_t rl = mapped ? (int32_t)ref_len : 0;
+                const int32_t l = rl > (int32_t)m ? rl : (int32_t)m;
+                const int32_t sub = score2 ? score2 : F.min_len * F.smatch;
+                if (sub < score) {
+                    const double identity = __dsub_rn(1., __ddiv_rn(__ddiv_rn((double)(l * F.smatch - score), (double)(F.smatch + F.smismatch)), (double)l));
+                    if (score != 0) {
+                        double tmp = (double)l < 50.0 ? 1. : ((uint32_t)l < F.mapq_tab_n ? F.mapq_tab[l] : F.mapq_tab[F.mapq_tab_n - 1]);
+                        tmp = __dmul_rn(tmp, __dmul_rn(identity, identity));
+                        const double v = __dadd_rn(__dmul_rn(__dmul_rn(__ddiv_rn(__dmul_rn(6.02, (double)(score - sub)), (double)F.smatch), tmp), tmp), .499);
+                        mapq = (int)v;
+                    }
+                    if (mapq > 60) mapq = 60;
+                    if (mapq < 0) mapq = 0;
+                    mapq = (int)__dadd_rn(__dmul_rn((double)mapq, 1.), .499);
+                }
+            }
+            bool same = n_lcig == n_cig && lifted == aln_pos;
+            for (uint32_t k = 0; same && k < n_cig; ++k) same = lcig[k] == cig[k];
+            uint32_t dummy = 0;
+            afl_two_t W;
+            W.pat = (G.pat && G.text2 && G.exc && !G.pe) ? G.pat : nullptr; W.text2 = G.text2; W.n_tw = (A.D.n_text + 31) >> 5; W.exc = G.exc; W.exc_sh = G.exc_sh; W.cb = W.mb = W.n2w = 0;
+            if (W.pat) {
+                const uint64_t task = 2 * r + strand, pb = ws_pat_base(G.blk, task), lb = ws_block_len(G.blk, task);
+                W.cb = pb + 64u * ((lb + 7) / 8); W.n2w = (lb + 31) / 32; W.mb = W.cb + 64u * W.n2w;
+            }
+#if defined(AF_CUTS)
+            if (G.dbg & 0x400000u) { S[AFP_H_FLAGS] = (uint32_t)mapq + lsid; continue; }          // ... in front of the MD walks
+#endif
+            if (mapped) nm = afl_md(A.D, W, off, m, strand, lcig, n_lcig, lifted, true, n_md, S + AFP_MD);
+            lift_nm = same ? nm : afl_md(A.D, W, off, m, strand, cig, n_cig, aln_pos, false, dummy, nullptr);
+            if (n_md > AFS_MAXMD) { flags |= AFP_F_HOST; n_md = 0; }
+            for (uint32_t k = 0; k < n_alt && k < AF_MAX_CAND; ++k) {       // the alternatives' sequences and 1-based positions
+                const uint64_t ap = PL.alt_pos[k];
+                const uint32_t s2 = ac_seq_of(A.P, ap);
+                S[AFP_ALT + 3 * k] = s2; S[AFP_ALT + 3 * k + 1] = (uint32_t)(ap - A.P.lift_seqs[s2].start + 1); S[AFP_ALT + 3 * k + 2] = (uint32_t)PL.alt_score[k];
+            }
+        }
+        S[AFP_H_FLAGS] = flags | (n_alt << 8); S[AFP_H_NCIG] = n_cig | (n_lcig << 16); S[AFP_H_NMD] = n_md; S[AFP_H_NM] = (uint32_t)nm; S[AFP_H_LIFTNM] = (uint32_t)lift_nm;
+        S[AFP_H_MAPQ] = (uint32_t)mapq; S[AFP_H_SCORE] = (uint32_t)C.score; S[AFP_H_SCORE2] = (uint32_t)score2; S[AFP_H_POS1] = (uint32_t)pos1; S[AFP_H_OAPOS] = (uint32_t)oa_pos;
+        S[AFP_H_SIDS] = sid0 | (lsid << 16); S[AFP_H_LIFTED_LO] = (uint32_t)lifted; S[AFP_H_LIFTED_HI] = (uint32_t)(lifted >> 32); S[AFP_H_POS_LO] = (uint32_t)aln_pos; S[AFP_H_POS_HI] = (uint32_t)(aln_pos >> 32);
+    }
+}
+
+#define AFR_MAXSEG 136u          // 35 fixed segments + 6 per alternative + the newline
+struct af_finr_t {
+    uint8_t line[AFS_LINE];
+    uint8_t seq[AF_MAX_READ];
+    uint32_t hdr[AFP_CIG];               // the recipe's header and alternatives
+    uint32_t cig[AFS_CIG], lcig[AFS_LCIG];
+    uint32_t md_item[AFS_MAXMD];
+    uint16_t md_off[AFS_MAXMD + 1], cig_off[AFS_CIG + 1], lcig_off[AFS_LCIG + 1];
+    uint8_t names[AFW_NAMES]; uint16_t name_off[AFW_NSEQ + 2];
+    uint16_t seg_off[AFR_MAXSEG + 1]; uint8_t seg_kind[AFR_MAXSEG]; uint32_t seg_val[AFR_MAXSEG];
+};
+// exclusive prefix sums of len[0 .. n) over the wavefront, 64 at a time: off[k] = sum of the lengths before k, off[n] = the total (returned).  len(k) is evaluated by lane k & 63.
+template <class LenF>
+__device__ __forceinline__ uint32_t afr_scan(uint32_t n, uint16_t* off, LenF len) {
+    const int lane = threadIdx.x;
+    uint32_t base = 0;
+    for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        const uint32_t mine = k < n ? len(k) : 0u;
+        uint32_t inc = mine;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += x; }
+        if (k < n) off[k] = (uint16_t)(base + inc - mine < 0xFFFFu ? base + inc - mine : 0xFFFFu);
+        base += (uint32_t)__shfl((int)inc, 63);
+    }
+    if (lane == 0) off[n] = (uint16_t)(base < 0xFFFFu ? base : 0xFFFFu);
+    return base;
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) finish_render_kernel(const af_args_t G, const uint32_t* __restrict__ recipes) {
+    __shared__ af_finr_t L;
+    const int lane = threadIdx.x;
+    const ak_args_t& A = G.A;
+    const ak_fmt_t& F = A.fmt;
+    const uint32_t n_seq = (uint32_t)A.P.n_seq;
+    const bool names_lds = n_seq <= AFW_NSEQ && F.sname_off[n_seq] <= AFW_NAMES;
+    if (names_lds) {
+        for (uint32_t k = lane; k <= n_seq; k += 64) L.name_off[k] = (uint16_t)F.sname_off[k];
+        for (uint32_t k = lane; k < F.sname_off[n_seq]; k += 64) L.names[k] = F.snames[k];
+    }
+#define NAME_LEN(sid) (names_lds ? (uint32_t)(L.name_off[(sid) + 1] - L.name_off[sid]) : F.sname_off[(sid) + 1] - F.sname_off[sid])
+    // a read's status and the recipe's first words come with one round trip, the next read's while this one is rendered
+    uint32_t st_n = AF_ST_FALLBACK, hw_n = 0;
+    if (blockIdx.x < A.n_reads) { st_n = G.plans[blockIdx.x].status; hw_n = recipes[(size_t)blockIdx.x * AFP_WORDS + lane]; }
+    for (uint64_t r_in = blockIdx.x; r_in < A.n_reads; r_in += gridDim.x) {
+        const uint32_t st = st_n, hw = hw_n;
+        if (r_in + gridDim.x < A.n_reads) { st_n = G.plans[r_in + gridDim.x].status; hw_n = recipes[(size_t)(r_in + gridDim.x) * AFP_WORDS + lane]; }
+        if (st == AF_ST_FALLBACK) continue;
+        const uint32_t* __restrict__ S = recipes + (size_t)r_in * AFP_WORDS;
+        __syncthreads();
+        L.hdr[lane] = hw;
+        __syncthreads();
+        const uint32_t flags = L.hdr[AFP_H_FLAGS];
+        const bool aligned = (flags & AFP_F_ALIGNED) != 0 && st == AF_ST_FINAL;
+        const bool mapped = (flags & AFP_F_MAPPED) != 0;
+        const uint32_t strand = aligned && (flags & AFP_F_STRAND) ? 1u : 0u;
+        const uint32_t n_alt = aligned ? (flags >> 8) & 0xFFu : 0u;
+        const uint32_t n_cig = aligned ? L.hdr[AFP_H_NCIG] & 0xFFFFu : 0u, n_lcig = aligned ? L.hdr[AFP_H_NCIG] >> 16 : 0u, n_md = aligned ? L.hdr[AFP_H_NMD] : 0u;
+        const uint64_t r = A.read_lo + r_in;
+        const uint64_t off = A.offs[r];
+        const uint32_t m = (uint32_t)(A.offs[r + 1] - off);
+        const uint64_t lifted = (uint64_t)L.hdr[AFP_H_LIFTED_LO] | ((uint64_t)L.hdr[AFP_H_LIFTED_HI] << 32);
+        const uint64_t aln_pos = aligned ? (uint64_t)L.hdr[AFP_H_POS_LO] | ((uint64_t)L.hdr[AFP_H_POS_HI] << 32) : 0ull;
+        const int32_t score = aligned ? (int32_t)L.hdr[AFP_H_SCORE] : 0, score2 = aligned ? (int32_t)L.hdr[AFP_H_SCORE2] : 0;
+        bool to_host = (aligned && (flags & AFP_F_HOST)) || m > AF_MAX_READ;
+        if (aligned && (flags & AFP_F_HOST) && lane == 0) atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CIGAR], 1u);
+        // ---- the CIGARs, the MD items and the read in alignment orientation ----
+        if (!to_host) {
+            for (uint32_t k = lane; k < n_cig; k += 64) L.cig[k] = S[AFP_CIG + k];
+            for (uint32_t k = lane; k < n_lcig; k += 64) L.lcig[k] = S[AFP_LCIG + k];
+            for (uint32_t k = lane; k < n_md; k += 64) L.md_item[k] = S[AFP_MD + k];
+            for (uint32_t k = lane; k < m; k += 64) L.seq[k] = strand ? ak_compl(A.D.reads[off + m - 1 - k]) : A.D.reads[off + k];
+        }
+        __syncthreads();
+        moni_aln_rec_t rec;
+        rec.status = aligned ? 1u : 0u; rec.strand = strand; rec.ref_pos = aln_pos; rec.score = score; rec.score2 = score2;
+        rec.n_cigar = 0; rec.n_alt = 0; rec.cigar_off = 0; rec.alt_off = 0; rec.nm = 0; rec.md_len = 0; rec.md_off = 0; rec.txt_len = 0; rec.lift_nm = 0; rec.txt_off = 0;
+        uint32_t p = 0;
+        const uint64_t n0 = F.rname_off[r], n1 = F.rname_off[r + 1];
+        if (!to_host) {
+            const int nm = (int)L.hdr[AFP_H_NM], lift_nm = (int)L.hdr[AFP_H_LIFTNM], mapq = (int)L.hdr[AFP_H_MAPQ], pos1 = (int)L.hdr[AFP_H_POS1], oa_pos = (int)L.hdr[AFP_H_OAPOS];
+            const uint32_t sid = L.hdr[AFP_H_SIDS] & 0xFFFFu, lsid = L.hdr[AFP_H_SIDS] >> 16;
+            // ---- where the texts of the CIGAR operations and of the MD items start ----
+            uint32_t w_lcig = 0, w_cig = 0, w_md = 0;
+            if (aligned) {
+                w_lcig = afr_scan(n_lcig, L.lcig_off, [&](uint32_t k) { return afs_ndig(L.lcig[k] >> 4) + 1u; });
+                w_cig = afr_scan(n_cig, L.cig_off, [&](uint32_t k) { return afs_ndig(L.cig[k] >> 4) + 1u; });
+                w_md = afr_scan(n_md, L.md_off, [&](uint32_t k) { const uint32_t it = L.md_item[k], ty = it & 3u; return afs_ndig((it >> 2) & 0x3FFu) + (ty == 1 ? 1u : ty == 2 ? 1u + ((it >> 12) & 0x1FFu) : 0u); });
+            }
+            // ---- the segments of the line (sam.hpp:144-188): segment i's kind, value and length from i alone, its offset by a scan ----
+            const uint32_t n_seg = aligned ? 36u + 6u * n_alt : 6u;
+            const uint32_t has_q = F.quals ? 1u : 0u;
+            auto seg = [&](uint32_t i, uint32_t& kind, uint32_t& val) -> uint32_t {
+                auto lit = [&](uint32_t at, uint32_t len) { kind = SK_LIT; val = at; return len; };
+                auto num = [&](int v) { if (v < 0) { const uint32_t u = 0u - (uint32_t)v; kind = SK_NEG; val = u; return afs_ndig(u) + 1u; } kind = SK_NUM; val = (uint32_t)v; return afs_ndig((uint32_t)v); };
+                if (!aligned) {
+                    switch (i) {
+                    case 0: kind = SK_RNAME; val = 0; return (uint32_t)(n1 - n0);
+                    case 1: return lit(LT_UNAL, 19);
+                    case 2: kind = SK_SEQ; val = 0; return m;
+                    case 3: return lit(LT_TAB, 1);
+                    case 4: if (has_q) { kind = SK_QUAL; val = 0; return m; } return lit(LT_STAR, 1);
+                    default: return lit(LT_NL, 1);
+                    }
+                }
+                if (i >= 35u && i < 35u + 6u * n_alt) {
+                    const uint32_t k = (i - 35u) / 6u, x = (i - 35u) % 6u;
+                    const uint32_t s2 = L.hdr[AFP_ALT + 3 * k];
+                    switch (x) {
+                    case 0: kind = SK_NAME; val = s2; return NAME_LEN(s2);
+                    case 1: return lit(LT_COMMA, 1);
+                    case 2: return num((int)L.hdr[AFP_ALT + 3 * k + 1]);
+                    case 3: return lit(LT_COMMA, 1);
+                    case 4: return num((int)L.hdr[AFP_ALT + 3 * k + 2]);
+                    default: return lit(LT_SEMI, 1);
+                    }
+                }
+                if (i >= 35u) return lit(LT_NL, 1);
+                switch (i) {
+                case 0: kind = SK_RNAME; val = 0; return (uint32_t)(n1 - n0);
+                case 1: return lit(LT_TAB, 1);
+                case 2: return num(strand ? 16 : 0);
+                case 3: return lit(LT_TAB, 1);
+                case 4: if (mapped) { kind = SK_NAME; val = lsid; return NAME_LEN(lsid); } return lit(LT_STAR, 1);
+                case 5: return lit(LT_TAB, 1);
+                case 6: return num(mapped ? pos1 : 0);
+                case 7: return lit(LT_TAB, 1);
+                case 8: return num(mapq);
+                case 9: return lit(LT_TAB, 1);
+                case 10: if (mapped) { kind = SK_CIG; val = 0u | (n_lcig << 1); return w_lcig; } return lit(LT_STAR, 1);
+                case 11: return lit(LT_MATE, 7);
+                case 12: kind = SK_SEQ; val = 0; return m;
+                case 13: return lit(LT_TAB, 1);
+                case 14: if (has_q) { kind = SK_QUAL; val = 0; return m; } return lit(LT_STAR, 1);
+                case 15: return lit(LT_AS, 6);
+                case 16: return num(score);
+                case 17: return lit(LT_NM, 6);
+                case 18: return num(mapped ? nm : 0);
+                case 19: return score2 != 0 ? lit(LT_ZS, 6) : lit(LT_ZS, 0);
+                case 20: if (score2 != 0) return num(score2); return lit(LT_ZS, 0);
+                case 21: return lit(LT_MD, 6);
+                case 22: kind = SK_MD; val = n_md; return w_md;
+                case 23: return lit(LT_OA, 6);
+                case 24: kind = SK_NAME; val = sid; return NAME_LEN(sid);
+                case 25: return lit(LT_COMMA, 1);
+                case 26: return num(oa_pos);
+                case 27: return lit(strand ? LT_MINUS : LT_PLUS, 3);
+                case 28: kind = SK_CIG; val = 1u | (n_cig << 1); return w_cig;
+                case 29: return lit(LT_COMMA, 1);
+                case 30: return num(mapq);
+                case 31: return lit(LT_COMMA, 1);
+                case 32: return num(lift_nm);
+                case 33: return lit(LT_SEMI, 1);
+                default: return lit(LT_AA, 6);          // 34
+                }
+            };
+            p = afr_scan(n_seg, L.seg_off, [&](uint32_t i) { uint32_t kind = 0, val = 0; const uint32_t len = seg(i, kind, val); L.seg_kind[i] = (uint8_t)kind; L.seg_val[i] = val; return len; });
+            __syncthreads();
+            if (p > AFS_LINE) { to_host = true; if (lane == 0) atomicAdd(&G.ctr[AFC_WHY + AF_WHY_CAPACITY], 1u); }
+            if (!to_host) {
+                // ---- SEQ and QUAL are plain copies; every lane renders its share of the other bytes of the line ----
+                const uint32_t s_at = L.seg_off[aligned ? 12 : 2], q_at = has_q ? (uint32_t)L.seg_off[aligned ? 14 : 4] : ~0u, holes = m + (q_at != ~0u ? m : 0u);
+                if (s_at + m <= AFS_LINE) for (uint32_t k = lane; k < m; k += 64) L.line[s_at + k] = L.seq[k];
+                if (q_at != ~0u && q_at + m <= AFS_LINE) for (uint32_t k = lane; k < m; k += 64) L.line[q_at + k] = F.quals[strand ? off + m - 1 - k : off + k];
+                for (uint32_t i = lane; i + holes < p; i += 64) {
+                    uint32_t b = i;
+                    if (b >= s_at) b += m;
+                    if (q_at != ~0u && b >= q_at) b += m;
+                    uint32_t lo = 0, hi = n_seg;                       // last segment that starts at or before b (an empty segment shares its offset with the next: never the last such)
+                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)L.seg_off[mid] <= b) lo = mid; else hi = mid; }
+                    const uint32_t d = b - L.seg_off[lo], kind = L.seg_kind[lo], val = L.seg_val[lo];
+                    uint8_t ch;
+                    if (kind == SK_LIT) ch = (uint8_t)afs_lit[val + d];
+                    else if (kind == SK_NUM || kind == SK_NEG) {
+                        const uint32_t len = (uint32_t)L.seg_off[lo + 1] - L.seg_off[lo];
+                        if (kind == SK_NEG && d == 0) ch = '-';
+                        else { uint32_t u = val; for (uint32_t t = d + 1; t < len; ++t) u /= 10u; ch = (uint8_t)('0' + u % 10u); }
+                    }
+                    else if (kind == SK_SEQ) ch = L.seq[d];
+                    else if (kind == SK_QUAL) ch = F.quals[strand ? off + m - 1 - d : off + d];
+                    else if (kind == SK_NAME) ch = names_lds ? L.names[L.name_off[val] + d] : F.snames[F.sname_off[val] + d];
+                    else if (kind == SK_RNAME) ch = F.rnames[n0 + d];
+                    else if (kind == SK_CIG) {          // operation k of a CIGAR: its length, then its letter
+                        const uint16_t* offs = (val & 1u) ? L.cig_off : L.lcig_off; const uint32_t* cg = (val & 1u) ? L.cig : L.lcig;
+                        uint32_t a = 0, z = val >> 1;
+                        while (z - a > 1) { const uint32_t mid = (a + z) >> 1; if ((uint32_t)offs[mid] <= d) a = mid; else z = mid; }
+                        const uint32_t e = d - offs[a], nd = (uint32_t)offs[a + 1] - offs[a] - 1u;
+                        if (e == nd) ch = (uint8_t)afs_lit[LT_OPS + (cg[a] & 0xfu)];
+                        else { uint32_t u = cg[a] >> 4; for (uint32_t t = e + 1; t < nd; ++t) u /= 10u; ch = (uint8_t)('0' + u % 10u); }
+                    } else {                            // SK_MD: item k of the MD string: the count of matches, then the base or ^ and the deleted bases
+                        uint32_t a = 0, z = val;
+                        while (z - a > 1) { const uint32_t mid = (a + z) >> 1; if ((uint32_t)L.md_off[mid] <= d) a = mid; else z = mid; }
+                        const uint32_t it = L.md_item[a], ty = it & 3u, run = (it >> 2) & 0x3FFu, e = d - L.md_off[a], nd = afs_ndig(run);
+                        if (e < nd) { uint32_t u = run; for (uint32_t t = e + 1; t < nd; ++t) u /= 10u; ch = (uint8_t)('0' + u % 10u); }
+                        else if (ty == 1) { const uint32_t bc = (it >> 12) & 7u; ch = (uint8_t)afs_lit[LT_BASES + (bc > 4 ? 4 : bc)]; }
+                        else if (e == nd) ch = '^';
+                        else { const uint64_t ta = lifted + (it >> 21) + (e - nd - 1u); ch = (uint8_t)afs_lit[LT_BASES + dp_nt4(ta < A.D.n_text ? A.D.text[ta] : 0u)]; }
+                    }
+                    L.line[b] = ch;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- out: the text pool (8-byte words, bump-allocated), coalesced; the record ----
+        if (to_host) rec.status = 2;           // does not fit the staging: the host pipeline redoes the read
+        else {
+            const unsigned long long words = (unsigned long long)((p + 7) >> 3);
+            const uint32_t shard = blockIdx.x % AF_TXT_SHARDS;
+            unsigned long long to = 0;
+            if (lane == 0) to = atomicAdd(&G.txt_cur[shard * 8], words);
+            to = ((unsigned long long)(uint32_t)__shfl((int)(to >> 32), 0) << 32) | (uint32_t)__shfl((int)(to & 0xFFFFFFFFull), 0);
+            if (to + words > G.txt_shard_words) rec.status = 2;
+            else {
+                to += (unsigned long long)(shard + 1) * G.txt_shard_words;
+                const uint64_t* src = reinterpret_cast<const uint64_t*>(L.line);
+                for (unsigned long long k = lane; k < words; k += 64) F.txt_pool[to + k] = src[k];
+                rec.txt_len = p; rec.txt_off = to;
+            }
+        }
+        if (lane == 0) {
+            A.recs[r_in] = rec;
+            if (A.dev_len) {
+                A.dev_len[r_in] = rec.txt_len; A.dev_off[r_in] = rec.txt_off;
+                if (rec.status == 2 || rec.txt_len == 0) atomicAdd(&A.dev_sum[0], 1ull);
+                else if (rec.status == 1) atomicAdd(&A.dev_sum[8 + 8 * (blockIdx.x % 16)], 1ull);      // sharded: one address takes only ~50 M atomics/s
+            }
+        }
+    }
+#undef NAME_LEN
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // gather_lines_kernel: the SAM lines of a sub-batch, which the kernels wrote to the text pool in completion order, copied into one
 // block in read order (pos = exclusive scan of the line lengths): the host receives the block with one transfer and does nothing else
 // ------------------------------------------------------------------------------------------------------------------------------

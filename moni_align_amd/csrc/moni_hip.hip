@@ -146,9 +146,9 @@ struct moni_ctx {
     DBuf<uint8_t> dp_dir_big;
     struct AfSet {          // device buffers of the staged align kernels (align_fast.hip), one set per launch stream
         DBuf<af_plan_t> plans; DBuf<moni_dp_task_t> tasks; DBuf<af_res_t> res; DBuf<uint32_t> bin_q, task_pos, tb_task, big_list, ctr; DBuf<uint8_t> ntasks;
-        DBuf<af_chunk_t> chunks; DBuf<uint8_t> dirs, fin; DBuf<af_ctab_t> ctab; DBuf<af_tb_t> tb; DBuf<uint64_t> bnd; DBuf<unsigned long long> prof, txt_cur;
+        DBuf<af_chunk_t> chunks; DBuf<uint8_t> dirs, fin; DBuf<uint32_t> recipes; DBuf<af_ctab_t> ctab; DBuf<af_tb_t> tb; DBuf<uint64_t> bnd; DBuf<unsigned long long> prof, txt_cur;
         void release() { ctab.release(); ntasks.release(); bnd.release(); prof.release(); big_list.release(); txt_cur.release(); plans.release(); tasks.release(); res.release(); bin_q.release(); task_pos.release(); tb_task.release(); ctr.release();
-                         chunks.release(); dirs.release(); fin.release(); tb.release(); }
+                         chunks.release(); dirs.release(); fin.release(); recipes.release(); tb.release(); }
     } af[AK_NSET], af_pe[PE_NSET];
     HBuf<unsigned long long> pe_hcur;       // paired path, per chunk: the pool cursors / DP counters (8 words) and the number of pairs handed over, copied behind the chunk's kernels
     HBuf<uint32_t> af_ctr_host;             // counters of the last batch's launches (64 words per sub-batch), pinned
@@ -1150,6 +1150,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         // SAM text in the kernel (default; MONI_ALIGN_HOST_FORMAT=1 leaves the formatting to the host stage): read names and
         // qualities go to the device while the seeding runs
         const bool gpu_text = getenv("MONI_ALIGN_HOST_FORMAT") == nullptr && NR > 0;
+        const bool fin_v1 = getenv("MONI_AF_FIN_V1") != nullptr;          // finish_wave_kernel (one wavefront per read for all of it) instead of finish_prep_kernel + finish_render_kernel
         std::thread uploader;
         int rc_up = MONI_OK;
         if (gpu_text) {
@@ -1239,7 +1240,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
             moni_ctx::AfSet& S = c->af[x];
             if ((rc = S.plans.ensure(sub_reads + 1)) || (rc = S.tasks.ensure(af_slot_cap)) || (rc = S.res.ensure(af_slot_cap)) || (rc = S.ntasks.ensure(sub_reads + 8)) || (rc = S.bin_q.ensure((size_t)(AF_NBIN + 1) * af_task_cap)) ||
                 (rc = S.task_pos.ensure(af_slot_cap)) || (rc = S.tb_task.ensure(af_tb_cap)) || (rc = S.tb.ensure(af_tb_cap)) || (rc = S.big_list.ensure(3 * (sub_reads + 1))) || (rc = S.ctab.ensure((size_t)(sub_reads + 1) * AF_CTAB)) ||
-                (rc = S.ctr.ensure(AF_NCTR)) || (rc = S.txt_cur.ensure(AF_TXT_SHARDS * 8)) || (rc = S.bnd.ensure((size_t)af_dp_grid * AF_QCAP * 64)) || (rc = S.chunks.ensure(af_chunk_cap)) || (rc = S.dirs.ensure(af_dirs_cap)) || (rc = S.fin.ensure((size_t)af_fin_grid * 64 * sizeof(af_fin_t))))
+                (rc = S.ctr.ensure(AF_NCTR)) || (rc = S.txt_cur.ensure(AF_TXT_SHARDS * 8)) || (rc = S.bnd.ensure((size_t)af_dp_grid * AF_QCAP * 64)) || (rc = S.chunks.ensure(af_chunk_cap)) || (rc = S.dirs.ensure(af_dirs_cap)) || (rc = S.fin.ensure((size_t)af_fin_grid * 64 * sizeof(af_fin_t))) || (gpu_text && !fin_v1 && (rc = S.recipes.ensure((size_t)(sub_reads + 1) * AFP_WORDS))))
                 return rc;
         }
         // the launches alternate between the context's stream and one more: HIP multiplexes streams onto a handful of hardware queues
@@ -1483,7 +1484,10 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 hipLaunchKernelGGL(align_kernel, dim3((unsigned)ak_waves), dim3(64), 0, sf, A);
                 // the record and the SAM line of every read that stayed on the staged path: one wave per read when the kernel spells the text
                 static const int fin_mult = getenv("MONI_AF_FINGRID") ? atoi(getenv("MONI_AF_FINGRID")) : 96;          // blocks per CU: 4x what is resident (24 by LDS), so that the strided share of a block is short and the tail even (measured 24 .. 768)
-                if (gpu_text) hipLaunchKernelGGL(finish_wave_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * fin_mult)), dim3(64), 0, sx, G);
+                if (gpu_text && !fin_v1) {          // a lane per read for the serial work (CIGAR, lift, MD / NM, MAPQ -> a recipe), then a wavefront per read for the line
+                    hipLaunchKernelGGL(finish_prep_kernel, dim3((unsigned)std::min<uint64_t>((nr + 63) / 64, (uint64_t)n_cu * 32)), dim3(64), 0, sx, G, S.recipes.p);
+                    hipLaunchKernelGGL(finish_render_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * fin_mult)), dim3(64), 0, sx, G, (const uint32_t*)S.recipes.p);
+                } else if (gpu_text) hipLaunchKernelGGL(finish_wave_kernel, dim3((unsigned)std::min<uint64_t>(nr, (uint64_t)n_cu * fin_mult)), dim3(64), 0, sx, G);
                 else hipLaunchKernelGGL(finish_kernel, dim3((unsigned)std::min<uint64_t>((nr + 63) / 64, af_fin_grid)), dim3(64), 0, sx, G);
                 HIPCHK(hipMemcpyAsync(c->af_ctr_host.p + AF_NCTR * k, S.ctr.p, AF_NCTR * sizeof(uint32_t), hipMemcpyDeviceToHost, sx));      // (before the set's next sub-batch clears them)
                 HIPCHK(hipEventRecord(c->ak_fin[k], sx));

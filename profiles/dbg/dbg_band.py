@@ -30,8 +30,8 @@ q = np.full(len(seq), ord("I"), dtype=np.uint8)
 want, _ = orc.align_batch(orc.OracleIndex(path), seq, offs, names, noff, q, threads=8)
 idx = capi.Index(fi=fi); ctx = capi.Ctx(idx)
 wl = want.split(b"\n")
-SW = ("MONI_AF_DBG", "MONI_AF_NOPLANK", "MONI_AF_WAVE_MAX")
-for cfg in ({}, {"MONI_AF_NOPLANK": "1"}, {"MONI_AF_DBG": "131072"}, {"MONI_AF_DBG": "65536"}, {"MONI_AF_DBG": "196608"}, {"MONI_AF_WAVE_MAX": "0"}, {"MONI_AF_WAVE_MAX": "1000000"},
+SW = ("MONI_AF_DBG", "MONI_AF_NOPLANK", "MONI_AF_WAVE_MAX", "MONI_AF_FIN_V1")
+for cfg in ({}, {"MONI_AF_FIN_V1": "1"}, {"MONI_AF_NOPLANK": "1"}, {"MONI_AF_DBG": "131072"}, {"MONI_AF_DBG": "65536"}, {"MONI_AF_DBG": "196608"}, {"MONI_AF_WAVE_MAX": "0"}, {"MONI_AF_WAVE_MAX": "1000000"},
             {"MONI_AF_WAVE_MAX": "1000000", "MONI_AF_DBG": "196608"}):
     for k in SW: os.environ.pop(k, None)
     os.environ.update(cfg)

@@ -305,13 +305,22 @@ def run_rank(args) -> int:
     cb = chunk_bounds(n_mine, args.reads)
     n_chunks = len(cb) - 1
     quals = np.full(n_mine * L, ord("I"), dtype=np.uint8)
+    # contexts of this rank (--inflight): with ONE resident chunk every context holds the same batch and they share the timed steps; with several chunks
+    # (a sharded read set) chunk k belongs to context k % inflight, parked there (moni_reads_swap) and swapped in for its turn - a step is still every chunk once
+    inflight = max(1, args.inflight)
+    ctxs = [ctx] + [capi.Ctx(idx) for _ in range(inflight - 1)]
+    shared_batch = n_chunks == 1
+    owner = [0 if shared_batch else k % inflight for k in range(n_chunks)]
+    slot = [0 if shared_batch else k // inflight for k in range(n_chunks)]
+    n_own = [sum(1 for o in owner if o == i) for i in range(inflight)]
     chunk = []          # per chunk: (names, name offsets, quals) views + the read count
     for k in range(n_chunks):
         a, b = cb[k], cb[k + 1]
         offs_k = np.arange(0, (b - a + 1) * L, L, dtype=np.uint64)
-        ctx.upload(reads[a:b].reshape(-1), offs_k)
-        if n_chunks > 1:
-            ctx.swap(k)                                   # parked in HBM; swapped in for its turn
+        for cx in (ctxs if shared_batch else [ctxs[owner[k]]]):
+            cx.upload(reads[a:b].reshape(-1), offs_k)
+        if n_own[owner[k]] > 1:
+            ctxs[owner[k]].swap(slot[k])                  # parked in HBM; swapped in for its turn
         chunk.append((names[int(noff[a]):int(noff[b])], (noff[a:b + 1] - noff[a]).astype(np.uint64), quals[a * L:b * L], b - a))
     offs = np.arange(0, (n_mine + 1) * L, L, dtype=np.uint64)
     pg_keep = pg if (rank == 0 and world == 1 and not sharded and not args.no_scaling_base) else None      # (the scaling-base leg generates its read set from it)
@@ -327,29 +336,26 @@ def run_rank(args) -> int:
 
     threads = max(1, host_cpus() // max(1, world))          # host stage threads of this rank
 
-    inflight = max(1, args.inflight) if n_chunks == 1 else 1
-    ctxs = [ctx]
-    for _ in range(inflight - 1):          # the same batch resident in every context
-        cx = capi.Ctx(idx)
-        cx.upload(reads[cb[0]:cb[1]].reshape(-1), np.arange(0, (cb[1] - cb[0] + 1) * L, L, dtype=np.uint64))
-        ctxs.append(cx)
     threads_step = max(1, threads // inflight)
     if inflight > 1:          # two steps side by side fill the GPU by themselves: larger sub-batches (fewer, longer launches) do better then (profiles/r04o)
         os.environ.setdefault("MONI_ALIGN_SUB", "500000")
 
-    def one_pass(want_text=False, acc=None, cx=None):
-        """the whole path over every resident chunk of this rank; returns (SAM bytes or total length, stats of the last chunk)"""
+    def one_pass(want_text=False, acc=None, ci=None):
+        """the whole path over the resident chunks (ci: those of context ci; None: all of this rank's, in order); returns (SAM bytes or total length, stats of the last chunk)"""
         outs, st_last, tot_len = [], None, 0
-        cx = cx or ctx
         for k in range(n_chunks):
+            if ci is not None and not shared_batch and owner[k] != ci:
+                continue
+            cx = ctxs[ci if (shared_batch and ci is not None) else owner[k]]
             nm, no, ql, _ = chunk[k]
-            if n_chunks > 1:
-                ctx.swap(k)
-            sam, st = cx.align_run(nm, no, ql, host_threads=threads if cx is ctx and inflight == 1 else threads_step, want_text=want_text)
+            parked = n_own[owner[k]] > 1
+            if parked:
+                cx.swap(slot[k])
+            sam, st = cx.align_run(nm, no, ql, host_threads=threads if inflight == 1 else threads_step, want_text=want_text)
             if acc is not None:
                 acc(st, cx)
-            if n_chunks > 1:
-                ctx.swap(k)
+            if parked:
+                cx.swap(slot[k])
             if want_text:
                 outs.append(sam)
             else:
@@ -359,8 +365,8 @@ def run_rank(args) -> int:
 
     # ---- warmup + timed steps ------------------------------------------------------------------------------------------------
     for _ in range(args.warmup):
-        for cx in ctxs:
-            one_pass(cx=cx)
+        for ci in range(inflight):
+            one_pass(ci=ci)
     sync_all()
     kern = np.zeros(7)
     stage = {"seed": 0.0, "align_kernels_span": 0.0, "align_stage": 0.0, "host_stage_busy": 0.0}
@@ -391,24 +397,36 @@ def run_rank(args) -> int:
     if inflight == 1:
         for _ in range(args.steps):
             sam_len, _ = one_pass(acc=acc)
-    else:          # exactly args.steps passes in all: a context takes the next one as soon as it is through with its last
+    elif shared_batch:          # exactly args.steps passes in all: a context takes the next one as soon as it is through with its last
         left = [args.steps]
         lens = []
 
-        def stepper(cx):
+        def stepper(ci):
             while True:
                 with acc_lock:
                     if left[0] <= 0:
                         return
                     left[0] -= 1
-                n, _ = one_pass(acc=acc, cx=cx)
+                n, _ = one_pass(acc=acc, ci=ci)
                 lens.append(n)
-        th = [threading.Thread(target=stepper, args=(cx,)) for cx in ctxs]
+        th = [threading.Thread(target=stepper, args=(ci,)) for ci in range(inflight)]
         for t in th:
             t.start()
         for t in th:
             t.join()
         sam_len = lens[-1] if lens else 0
+    else:                       # every context goes args.steps times through its own chunks; the contexts side by side
+        lens = [0] * inflight
+
+        def stepper(ci):
+            for _ in range(args.steps):
+                lens[ci], _ = one_pass(acc=acc, ci=ci)
+        th = [threading.Thread(target=stepper, args=(ci,)) for ci in range(inflight)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        sam_len = sum(lens)
     sync_all()
     elapsed = time.perf_counter() - t0
     elapsed = mdist.max_over_ranks(elapsed, dist, coll_dev)
@@ -421,13 +439,12 @@ def run_rank(args) -> int:
         tot[k] //= steps
     cnt = cnt // np.uint64(steps)
     sizes = mdist.gather_counts([tot["aligned"], sam_len, n_mine], dist, coll_dev)     # per-rank record counts
-    for cx in ctxs[1:]:
-        cx.close()
+    mem_free, mem_total = torch.cuda.mem_get_info()          # with every context's working memory allocated (grow-only buffers, kept across batches)
     # one context alone (no second step beside it): the latency of a step, and the kernels' durations without a neighbour
     single = None
-    if inflight > 1 and not args.no_single_context:
+    if inflight > 1 and shared_batch and not args.no_single_context:
         sub_was = os.environ.pop("MONI_ALIGN_SUB", None)
-        one_pass()
+        one_pass(ci=0)
         sync_all()
         n1s = max(1, min(4, args.steps))
         t1 = time.perf_counter()
@@ -474,9 +491,11 @@ def run_rank(args) -> int:
                 del pg2
                 gather["identical_to_unsharded"] = bool(bytes(got.cpu().numpy().tobytes()) == b"".join(whole))
         del got, blk
+    for cx in ctxs[1:]:
+        cx.close()
 
     # ---- seeding stage alone (BASELINE.json configs[1]) on the first resident chunk ------------------------------------------
-    if n_chunks > 1:
+    if n_own[0] > 1:
         ctx.swap(0)
     ts = time.perf_counter()
     n_seed_rep = 3
@@ -529,23 +548,39 @@ def run_rank(args) -> int:
         sb_names, sb_noff = synth.make_names_range(0, sb_total)
         t_gen = time.time() - tb0
         del pg_keep
-        ctx_s = capi.Ctx(idx)
+        sb_ctx = [capi.Ctx(idx) for _ in range(inflight)]          # chunk k on context k % inflight, as the sharded runs hold theirs
         sb_cb = chunk_bounds(sb_total, args.reads)
+        sb_n = len(sb_cb) - 1
         sb_q = np.full(args.reads * L + L, ord("I"), dtype=np.uint8)
-        for k in range(len(sb_cb) - 1):
+        sb_own = [sum(1 for k in range(sb_n) if k % inflight == i) for i in range(inflight)]
+        for k in range(sb_n):
             a, b = sb_cb[k], sb_cb[k + 1]
-            ctx_s.upload(sb_reads[a:b].reshape(-1), np.arange(0, (b - a + 1) * L, L, dtype=np.uint64))
-            ctx_s.swap(k)
+            cx = sb_ctx[k % inflight]
+            cx.upload(sb_reads[a:b].reshape(-1), np.arange(0, (b - a + 1) * L, L, dtype=np.uint64))
+            if sb_own[k % inflight] > 1:
+                cx.swap(k // inflight)
+        sb_al_of = [0] * inflight
+
+        def sb_ctx_pass(i):
+            al = 0
+            for k in range(i, sb_n, inflight):
+                a, b = sb_cb[k], sb_cb[k + 1]
+                cx = sb_ctx[i]
+                if sb_own[i] > 1:
+                    cx.swap(k // inflight)
+                _, st_k = cx.align_run(sb_names[int(sb_noff[a]):int(sb_noff[b])], (sb_noff[a:b + 1] - sb_noff[a]).astype(np.uint64), sb_q[:(b - a) * L], host_threads=threads if inflight == 1 else threads_step, want_text=False)
+                if sb_own[i] > 1:
+                    cx.swap(k // inflight)
+                al += st_k["aligned"]
+            sb_al_of[i] = al
 
         def sb_pass():
-            al = 0
-            for k in range(len(sb_cb) - 1):
-                a, b = sb_cb[k], sb_cb[k + 1]
-                ctx_s.swap(k)
-                _, st_k = ctx_s.align_run(sb_names[int(sb_noff[a]):int(sb_noff[b])], (sb_noff[a:b + 1] - sb_noff[a]).astype(np.uint64), sb_q[:(b - a) * L], host_threads=threads, want_text=False)
-                ctx_s.swap(k)
-                al += st_k["aligned"]
-            return al
+            th = [threading.Thread(target=sb_ctx_pass, args=(i,)) for i in range(inflight)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            return sum(sb_al_of)
         sb_pass()
         torch.cuda.synchronize()
         sb_steps = 2
@@ -554,13 +589,15 @@ def run_rank(args) -> int:
             sb_al = sb_pass()
         torch.cuda.synchronize()
         sb_s = (time.perf_counter() - t1) / sb_steps
-        ctx_s.close()
+        for cx in sb_ctx:
+            cx.close()
         del sb_reads
         scaling_base = {"workload": "BASELINE.json configs[3]'s read set on this one GPU: %d reads in %d resident chunks of <= %d (what `--total-reads %d` runs at N = 1; the N > 1 default shards the same set)"
-                                    % (sb_total, len(sb_cb) - 1, args.reads, sb_total),
+                                    % (sb_total, sb_n, args.reads, sb_total),
+                        "contexts_in_flight": inflight,
                         "value": sb_al / sb_s, "unit": "aligned reads/s", "reads_per_s": sb_total / sb_s, "ms_per_step": sb_s * 1e3, "steps": sb_steps, "warmup": 1, "scaling": "strong",
                         "reads_generated_s": t_gen, "leg_s": time.time() - tb0}
-        log("scaling base: %d reads in %d chunks, %.1f ms per pass" % (sb_total, len(sb_cb) - 1, sb_s * 1e3))
+        log("scaling base: %d reads in %d chunks, %.1f ms per pass" % (sb_total, sb_n, sb_s * 1e3))
 
     if rank == 0:
         S, J, P, C = (int(x) for x in cnt)          # per step, this rank
@@ -655,6 +692,8 @@ def run_rank(args) -> int:
                 out["roofline"]["kernel_alone"] = {"avg_launch_ms": single["ms_lf_kernel_ms"], "achieved": layout_bytes / a_s / 1e9, "frac": layout_bytes / a_s / 1e9 / HBM_PEAK_GBS,
                                                    "note": "last launch of the single-context leg (HIP events): no other step's kernels beside it"}
         out["host"] = {"cpus_usable": host_cpus(), "cpu_count": os.cpu_count(), "host_threads_per_gpu": threads}
+        out["device_memory_GB"] = {"used_after_timed_region": (mem_total - mem_free) / 1e9, "total": mem_total / 1e9,
+                                   "note": "rank 0's GPU: index image + the working memory of its %d context(s)" % inflight}
         if world == 1 and not args.no_cpu:
             from oracle import orc as _orc          # the CPU baseline / at-scale checker: the only use of oracle/ in this file
             oidx = _orc.OracleIndex(fi=fi)          # (rank 0 holds the flat index: built here or mapped from the cache file)

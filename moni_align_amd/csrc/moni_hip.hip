@@ -1219,8 +1219,8 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
         // direction bits: half a byte per DP cell.  ~10 KB per 150 bp read on the bench; DP cells grow with the square of the read length (250 bp:
         // ~90 KB with the global realignments); a chunk that does not fit sends its reads to align_kernel, and a batch in which that happened
         // doubles the budget of the next ones
-        uint64_t dirs_per_read = 32768;
-        { const double f = (double)c->max_len / 150.0; if (f > 1.0) dirs_per_read = (uint64_t)(32768.0 * f * f); }
+        uint64_t dirs_per_read = 16384;          // (measured: 2.9 KB per 150 bp read with the banded problems, 11 KB with every problem on the full tiles, 21 KB for 250 bp reads on 20 haplotypes: profiles/r05a)
+        { const double f = (double)c->max_len / 150.0; if (f > 1.0) dirs_per_read = (uint64_t)(16384.0 * f * f); }
         dirs_per_read = std::min<uint64_t>(dirs_per_read * c->dirs_scale, 1ull << 20);
         const uint64_t af_dirs_cap = dirs_per_read * sub_reads + (16ull << 20);
         const unsigned af_dp_grid = (unsigned)n_cu * 12;
@@ -1540,6 +1540,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                     any_dirs_ovf_batch = any_dirs_ovf_batch || fc[AFC_DIRS_OVF] != 0;
                     st.dp_tasks += fc[AFC_NT] + (fc[AFC_TASKS] >= (uint32_t)(sub_lo[k + 1] - sub_lo[k]) * AF_MAX_TASKS_READ ? fc[AFC_TASKS] - (uint32_t)(sub_lo[k + 1] - sub_lo[k]) * AF_MAX_TASKS_READ : 0u); st.dp_cells += cells; st.kernel_fallback += fbn[16 * k]; st.dp_ref_bytes += rb;
                     for (int x = 0; x < AF_WHY_N; ++x) why_sum[x] += fc[AFC_WHY + x];
+                    if (getenv("MONI_AK_PROFILE")) { unsigned long long du; memcpy(&du, fc + AFC_DIROFF, 8); fprintf(stderr, "  direction bits of sub-batch %llu: %.1f MB used of %.1f MB\n", (unsigned long long)k, du / 1e6, af_dirs_cap / 1e6); }
                     if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "  staged kernels, sub-batch %llu: %u DP tasks, %llu cells, %u traced, %u large + %u small + %u global chunks, %u reads to align_kernel%s\n",
                                                            (unsigned long long)k, fc[AFC_NT], cells, fc[AFC_TRACED], fc[AFC_NCHUNKS], fc[AFC_NCHUNKS + 1], fc[AFC_NCHUNKS + 2], fbn[16 * k], fc[AFC_DIRS_OVF] ? " (direction bytes overflowed)" : "");
                     if (getenv("MONI_AK_PROFILE")) { fprintf(stderr, "    DP problems per bin (16 of the large tile by query length <= 8 13 16 24 32 48 64 .. 160 192 224 256, 3 of the small tile <= 8 16 32, 16 global by query length / 16):"); for (int x = 0; x < AF_NBIN; ++x) fprintf(stderr, " %u", fc[AFC_BINS + x]); fprintf(stderr, "\n"); }
@@ -1553,7 +1554,7 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                 for (int x = 0; x < 7; ++x) cyc[x] += (double)q[24 + x];
             }
         }
-        if (any_dirs_ovf_batch && c->dirs_scale < 16) c->dirs_scale *= 2;
+        if (any_dirs_ovf_batch && c->dirs_scale < 32) c->dirs_scale *= 2;
         static_assert(AF_WHY_N == 12, "moni_align_stats_t::handover_why");
         for (int x = 0; x < AF_WHY_N; ++x) why_out[x] = why_sum[x];
 #ifdef AF_PROFILE

@@ -54,7 +54,7 @@ typedef af_wave_tt<AF_MAX_ANCH, AF_MAX_CHAINS, AF_MAX_MEMS, 2 * PEF_MAX_Q, AF_PL
 // A pair that overflows this instance is put on a list for the large one (LEVEL 1).
 typedef af_wave_tt<160, 80, 24, 2 * PEF_MAX_Q, 64, 48, 1> pef_wave_small_t;
 // -Z (find_chains_secondary): the same two instances with the second track's arrays
-typedef af_wave_tt<160, 80, 24, 2 * PEF_MAX_Q, 64, 48, 1, 1> pef_wave_small_z_t;
+typedef af_wave_tt<160, 160, 24, 2 * PEF_MAX_Q, 64, 48, 1, 1> pef_wave_small_z_t;          // (as many chains as anchors: the second track starts one at about every anchor, and with 80 nearly half of the benchmark's pairs ran here and again on the large instance - profiles/r05e)
 typedef af_wave_tt<AF_MAX_ANCH, AF_MAX_CHAINS, AF_MAX_MEMS, 2 * PEF_MAX_Q, AF_PLAN_AN, AF_MAX_TASKS_READ, 1, 1> pef_wave_z_t;
 // -Z: the second track starts a chain at about every anchor of a repeat-rich pair - more chains than AF_MAX_CHAINS for one pair in eighty of the benchmark
 // (profiles/r04p: 12 731 of 1 M pairs went to pe_align_kernel for it, two thirds of the -Z run's time).  LEVEL 2: four times the chains (and twice the anchors).

@@ -655,7 +655,7 @@ def run_rank(args) -> int:
                       "note": "HIP-event times of the staged align kernels by group, summed over the sub-batches (two launch streams overlap, so the sum exceeds the span)",
                       "dp_problems": tot["dp_tasks"], "dp_cells": tot["dp_cells"],
                       "dp_gcups_in_kernel": tot["dp_cells"] / grp["dp_lane"] / 1e9 if grp["dp_lane"] > 0 else None,
-                      "roofline": {"bound": "valu", "kernel": "dp_lane_kernel (all instances)", "unit": "TCUPS",
+                      "roofline": {"bound": "valu", "kernel": "dp_lane_kernel / dp_band_kernel / dp_wave_kernel (all instances)", "unit": "TCUPS",
                                    "cells": tot["dp_cells"], "cells_after_cut": tot["dp_cells_cut"], "cell_slots_run": tot["dp_slots"],
                                    "padding": {"useful_over_slots": tot["dp_cells_cut"] / tot["dp_slots"] if tot["dp_slots"] else None,
                                                "note": "cells: qlen x tlen of every ksw_extz2_sse call as the reference poses it; cells_after_cut: after the target rows of an extension that cannot hold its result are dropped "

@@ -1945,15 +1945,18 @@ __device__ __forceinline__ bool af_diag_mm2(const af_args_t& G, const moni_dp_ta
     { const uint64_t b0 = t0 >> G.exc_sh, b1 = (t0 + (uint64_t)n - 1) >> G.exc_sh; if (((G.exc[b0 >> 5] >> (b0 & 31u)) | (G.exc[b1 >> 5] >> (b1 & 31u))) & 1u) return false; }
     const uint64_t task = 2 * read + (comp ? 1u : 0u);
     const uint64_t pb = ws_pat_base(G.blk, task), lb = ws_block_len(G.blk, task);
-    const uint64_t cb = pb + 64u * ((lb + 7) / 8), mb = cb + 64u * ((lb + 31) / 32);
+    const uint64_t n2w = (lb + 31) / 32, cb = pb + 64u * ((lb + 7) / 8), mb = cb + 64u * n2w;
     uint64_t bad = 0;
     mm = 0;
     for (int k = 0; k < n; k += 32) {
         const uint64_t pa = a + (uint64_t)k, ta = t0 + (uint64_t)k;
         const uint32_t ps = 2u * (uint32_t)(pa & 31u), ts = 2u * (uint32_t)(ta & 31u);
-        const uint64_t p0 = G.pat[cb + (pa >> 5) * 64u], p1 = ps ? G.pat[cb + ((pa >> 5) + 1) * 64u] : 0ull;
+        // (the word behind a stretch's last one may lie behind the read's words - the next region of the workspace: such a load made every stretch that ends
+        // in the read's last word - a right extension, mostly - look marked, and a third of the extensions went to the full tile without a bound: profiles/r05f)
+        const bool more = ps && (pa >> 5) + 1 < n2w;
+        const uint64_t p0 = G.pat[cb + (pa >> 5) * 64u], p1 = more ? G.pat[cb + ((pa >> 5) + 1) * 64u] : 0ull;
         const uint64_t w0 = G.text2[ta >> 5], w1 = ts ? G.text2[(ta >> 5) + 1] : 0ull;
-        bad |= G.pat[mb + (pa >> 5) * 64u] | (ps ? G.pat[mb + ((pa >> 5) + 1) * 64u] : 0ull);          // (whole words: a mark beside the stretch costs only the byte form)
+        bad |= G.pat[mb + (pa >> 5) * 64u] | (more ? G.pat[mb + ((pa >> 5) + 1) * 64u] : 0ull);          // (whole words: a mark beside the stretch costs only the byte form)
         const uint64_t pw = ps ? (p0 >> ps) | (p1 << (64u - ps)) : p0, tw = ts ? (w0 >> ts) | (w1 << (64u - ts)) : w0;
         uint64_t x = pw ^ tw;
         x = (x | (x >> 1)) & 0x5555555555555555ull;
@@ -1963,8 +1966,83 @@ __device__ __forceinline__ bool af_diag_mm2(const af_args_t& G, const moni_dp_ta
     }
     return bad == 0;
 }
+// af_global_band's bound for a gap fill whose lengths differ, from the 2-bit forms: the alignment "diagonal 0, one gap of |tlen - qlen| where it pays most, diagonal
+// tlen - qlen" scores tot + maxA - (qo + e |delta|), tot = the score of diagonal delta over its n = min(qlen, tlen) pairs, maxA = the largest prefix sum of
+// (diagonal 0's score - diagonal delta's) over the pairs in the problem's order.  In read / text coordinates the two diagonals are the stretches aligned at their
+// STARTS and at their ENDS (which is which, and the order of the pairs, turn around for a problem that runs backwards); per 32 pairs one XOR each, and the prefix
+// maximum walks the set bits of the two mismatch words - a handful.  (Since round 4's first banding these problems - 129 000 per 250 000 reads, 40 % of the tile
+// kernel's - had gone to the full tile: the byte form of this bound was what made band_tasks_kernel slow.)  False: a stretch that is not where the formulas put it.
+__device__ __forceinline__ bool af_two_piece2(const af_args_t& G, const moni_dp_task_t& T, uint64_t read, uint64_t off, uint32_t m, int& dmin, int& dmax) {
+    const dp_launch_t& D = G.A.D;
+    const int q = T.qlen, t = T.tlen, delta = t - q, ad = delta < 0 ? -delta : delta, n = q < t ? q : t;
+    if (!G.pat || !G.text2 || n <= 0 || n > 128 || D.e <= 0) return false;
+    const bool comp = (T.reserved & DP_Q_COMP) != 0, rev = (T.reserved & DP_Q_REV) != 0, trev = (T.reserved & DP_T_REV) != 0;
+    const bool reversed = comp ? !rev : rev;
+    if (reversed != trev) return false;                                         // (query and target of a problem run the same way)
+    const uint64_t d = T.q_off - off;
+    const uint64_t a = !comp ? (rev ? d - (uint64_t)q + 1 : d) : (rev ? (uint64_t)m - 1 - d : (uint64_t)m - (uint64_t)q - d);      // the query is pattern[a, a + q) of the read's strand-resolved pattern
+    if (a + (uint64_t)q > m) return false;
+    if (reversed && T.t_off + 1 < (uint64_t)t) return false;
+    const uint64_t tlo = reversed ? T.t_off - (uint64_t)t + 1 : T.t_off;          // the target is text[tlo, tlo + t)
+    if (tlo + (uint64_t)t > D.n_text) return false;
+    { const uint64_t b0 = tlo >> G.exc_sh, b1 = (tlo + (uint64_t)t - 1) >> G.exc_sh; if (((G.exc[b0 >> 5] >> (b0 & 31u)) | (G.exc[b1 >> 5] >> (b1 & 31u))) & 1u) return false; }
+    const uint64_t task = 2 * read + (comp ? 1u : 0u);
+    if (G.pflag && G.pflag[task]) return false;                                 // (a byte outside A / C / G / T somewhere in the read: the tile)
+    const uint64_t pb = ws_pat_base(G.blk, task), lb = ws_block_len(G.blk, task);
+    const uint64_t cb = pb + 64u * ((lb + 7) / 8), n2w = (lb + 31) / 32, n_tw = (D.n_text + 31) >> 5;
+    auto pbits = [&](uint64_t first) -> uint64_t {
+        const uint64_t i = first >> 5; const uint32_t sh = 2u * (uint32_t)(first & 31u);
+        const uint64_t lo = i < n2w ? G.pat[cb + i * 64u] : 0ull;
+        if (!sh) return lo;
+        return (lo >> sh) | ((i + 1 < n2w ? G.pat[cb + (i + 1) * 64u] : 0ull) << (64u - sh));
+    };
+    auto tbits = [&](uint64_t first) -> uint64_t {
+        const uint64_t i = first >> 5; const uint32_t sh = 2u * (uint32_t)(first & 31u);
+        const uint64_t lo = i < n_tw ? G.text2[i] : 0ull;
+        if (!sh) return lo;
+        return (lo >> sh) | ((i + 1 < n_tw ? G.text2[i + 1] : 0ull) << (64u - sh));
+    };
+    // mismatch words of the two alignments, 32 pairs per word (bit 2 u of word c: pair 32 c + u), in read / text coordinates
+    uint64_t xs[4] = {0, 0, 0, 0}, xe[4] = {0, 0, 0, 0};
+    const uint64_t pe0 = a + (uint64_t)(q - n), te0 = tlo + (uint64_t)(t - n);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (32 * c < n) {
+        const int left = n - 32 * c;
+        const uint64_t lowm = left < 32 ? (1ull << (2 * left)) - 1ull : ~0ull;
+        uint64_t x = pbits(a + 32u * c) ^ tbits(tlo + 32u * c);
+        xs[c] = (x | (x >> 1)) & 0x5555555555555555ull & lowm;
+        x = pbits(pe0 + 32u * c) ^ tbits(te0 + 32u * c);
+        xe[c] = (x | (x >> 1)) & 0x5555555555555555ull & lowm;
+    }
+    // diagonal 0 pairs the problem's k-th elements: the starts for a problem that runs forwards, the ends for one that runs backwards; diagonal delta the other
+    int pc1 = 0, run = 0, best = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pc1 += (int)__popcll(reversed ? xs[c] : xe[c]);
+    if (!reversed) {
+        for (int c = 0; c < 4 && 32 * c < n; ++c) {
+            uint64_t m0 = xs[c], m1 = xe[c], any = m0 | m1;
+            while (any) { const uint64_t bit = any & (0ull - any); run += ((m1 & bit) ? 1 : 0) - ((m0 & bit) ? 1 : 0); best = run > best ? run : best; any ^= bit; }
+        }
+    } else {
+        for (int c = 3; c >= 0; --c) if (32 * c < n) {
+            uint64_t m0 = xe[c], m1 = xs[c], any = m0 | m1;
+            while (any) { const uint64_t bit = 1ull << (63 - __builtin_clzll(any)); run += ((m1 & bit) ? 1 : 0) - ((m0 & bit) ? 1 : 0); best = run > best ? run : best; any ^= bit; }
+        }
+    }
+    const int dm = D.sc_mch - D.sc_mis;
+    const int tot = D.sc_mch * n - dm * pc1, maxA = dm * best;
+    const int lbnd = tot + maxA - (D.qo + D.e * ad);
+    const int Gq = D.sc_mch * n - 2 * D.qo - lbnd;
+    dmin = delta < 0 ? delta : 0; dmax = delta > 0 ? delta : 0;
+    if (Gq >= 0) {
+        const int gb = Gq / D.e;
+        const int up = (gb + delta) >> 1, dn = -((gb - delta) >> 1);
+        dmax = up > dmax ? up : dmax; dmin = dn < dmin ? dn : dmin;
+    }
+    return true;
+}
 // af_ext_band / af_global_band from that count.  An extension: the diagonal's score bounds mqe from below.  A gap fill or global problem whose two lengths
-// agree: the diagonal is itself a corner-to-corner path.  (Lengths that differ need the two-piece bound: the byte form.)
+// agree: the diagonal is itself a corner-to-corner path; lengths that differ: af_two_piece2.
 __device__ __forceinline__ bool af_tile_band2(const af_args_t& G, const moni_dp_task_t& T, uint64_t read, uint64_t off, uint32_t m, int& dmin, int& dmax) {
     const dp_launch_t& D = G.A.D;
     const int q = T.qlen, t = T.tlen;
@@ -1979,7 +2057,7 @@ __device__ __forceinline__ bool af_tile_band2(const af_args_t& G, const moni_dp_
         if (G_ >= 0) { dmax = G_ / D.e; dmin = -(G_ / (D.e + D.sc_mch)); }
         return true;
     }
-    if (q != t) return false;
+    if (q != t) return af_two_piece2(G, T, read, off, m, dmin, dmax);
     if (!af_diag_mm2(G, T, read, off, m, q, mm)) return false;
     const int G_ = (D.sc_mch - D.sc_mis) * (int)mm - 2 * D.qo;          // min(qlen, tlen) sc_mch - 2 qo - (the diagonal's score): af_global_band with delta = 0
     dmin = 0; dmax = 0;
@@ -2126,10 +2204,22 @@ __global__ void __launch_bounds__(256) band_tasks_kernel(const af_args_t G) {
             const uint64_t off = G.A.offs[rd];
             // (no bound from the 2-bit forms - a gap fill whose lengths differ, a byte outside A / C / G / T: the tile takes the problem.  One lane in the byte form's
             // dependent loads would hold up its whole wavefront)
-            if (!af_tile_band2(G, t, rd, off, (uint32_t)(G.A.offs[rd + 1] - off), dlo, dhi)) { dlo = -t.qlen; dhi = t.tlen; }
+            const bool found = af_tile_band2(G, t, rd, off, (uint32_t)(G.A.offs[rd + 1] - off), dlo, dhi);
+            if (!found) { dlo = -t.qlen; dhi = t.tlen; }
+#if defined(AF_CUTS)
+            {   // (experiments: the tile problems by kind and by what the bound says)
+                const bool ext = (t.flag & DP_EZ_EXTZ_ONLY) != 0;
+                const uint32_t kind = ext ? 0u : t.qlen == t.tlen ? 1u : 2u;
+                const uint32_t what = !found ? 3u : (ext && t.tlen < t.qlen) ? 2u : (dhi - dlo + 1 <= AF_BANDW) ? 0u : 1u;
+                atomicAdd(&G.ctr[180 + 4 * kind + what], 1u);
+            }
+#endif
         }
         const int W = dhi - dlo + 1;
         bin = af_large_bin(t.qlen);
+#if defined(AF_CUTS)
+
+#endif
         if (W <= AF_BANDW) {
             dlo -= (AF_BANDW - W) / 2;
             G.tasks[id].reserved = (t.reserved & 0xFFFF) | (int)(((uint32_t)dlo & 0xFFFFu) << 16);

@@ -1544,6 +1544,9 @@ static int align_core(moni_ctx* c, const moni_read_batch_t* b, bool resident, bo
                     if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "  staged kernels, sub-batch %llu: %u DP tasks, %llu cells, %u traced, %u large + %u small + %u global chunks, %u reads to align_kernel%s\n",
                                                            (unsigned long long)k, fc[AFC_NT], cells, fc[AFC_TRACED], fc[AFC_NCHUNKS], fc[AFC_NCHUNKS + 1], fc[AFC_NCHUNKS + 2], fbn[16 * k], fc[AFC_DIRS_OVF] ? " (direction bytes overflowed)" : "");
                     if (getenv("MONI_AK_PROFILE")) { fprintf(stderr, "    DP problems per bin (16 of the large tile by query length <= 8 13 16 24 32 48 64 .. 160 192 224 256, 3 of the small tile <= 8 16 32, 16 global by query length / 16):"); for (int x = 0; x < AF_NBIN; ++x) fprintf(stderr, " %u", fc[AFC_BINS + x]); fprintf(stderr, "\n"); }
+#if defined(AF_CUTS)
+                    if (getenv("MONI_AK_PROFILE")) { fprintf(stderr, "    tile problems (extension | gap fill q = t | gap fill q != t) x (band <= 16 | wider | extension with t < q | no bound):"); for (int x = 0; x < 12; ++x) fprintf(stderr, "%s %u", x % 4 == 0 ? " |" : "", fc[180 + x]); fprintf(stderr, "\n"); }
+#endif
                     if (getenv("MONI_AK_PROFILE")) { fprintf(stderr, "    global problems by band width / 4 (0-3, 4-7, ... , >= 52):"); for (int x = 0; x < 14; ++x) fprintf(stderr, " %u", fc[AFC_BANDH + x]); fprintf(stderr, "\n"); }
                     if (getenv("MONI_AK_PROFILE")) fprintf(stderr, "    handed over because: long read %u, anchors/seeds %u, chains %u, chains to score %u, chain length %u, DP size %u, overlapping anchors %u, wildcard %u, "
                                                            "loop depends on a score %u, extension short of the query end %u, capacity %u, CIGAR %u\n",

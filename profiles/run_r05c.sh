@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 4, final build: the whole GPU suite, smoke, the driver's bench command, the robustness leg, the other configurations, the paired lines
+# round 4, final build (bash profiles/run_r05c.sh [tag]): the whole GPU suite, smoke, the driver's bench command, the robustness leg, the other configurations, the paired lines
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r05c; mkdir -p $OUT
+OUT=$ROOT/gpurun_out/${1:-r05c}; mkdir -p $OUT
 export TMPDIR=/tmp
 cd $ROOT
 echo "== GPU tests =="

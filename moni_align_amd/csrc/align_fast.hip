@@ -2050,7 +2050,19 @@ __device__ __forceinline__ bool af_tile_band2(const af_args_t& G, const moni_dp_
     uint32_t mm = 0;
     if (T.flag & DP_EZ_EXTZ_ONLY) {
         dmin = -q; dmax = t;
-        if (t < q) return true;                                    // (no bound from the diagonal)
+        if (t < q) {
+            // More query than target (the reference cuts an extension's target at ext_len rows whatever the read's part is): every end cell (i, q - 1) lies on a diagonal
+            // <= t - q = -ad.  Lower bound of mqe: the diagonal over the t target rows, then the ad remaining query bases as one insertion.  A path whose lowest
+            // diagonal is -(ad + y) inserts at least ad + y bases, so it has at most t - y diagonal steps: t mch - y (mch + e) - (qo + ad e) at best; one that rises to
+            // diagonal d > 0 deletes d bases and inserts d + ad: (t - d) mch - 2 qo - (2 d + ad) e at best.  Diagonals whose best lies below the bound hold no cell of a
+            // best path.  (22 000 extensions per 250 000 reads, the tile kernel's longest: with the bound nearly all of them fit dp_band_kernel's 16 diagonals.  A
+            // 32-diagonal instance of that kernel for the rest was built and measured: its launch cost more than the 2 700 problems it took saved - profiles/r05i.)
+            if (!af_diag_mm2(G, T, read, off, m, t, mm)) return false;
+            const int ad = q - t, dm = (D.sc_mch - D.sc_mis) * (int)mm;
+            dmin = -ad - dm / (D.e + D.sc_mch);
+            dmax = dm - D.qo > 0 ? (dm - D.qo) / (D.sc_mch + 2 * D.e) : 0;
+            return true;
+        }
         if (!af_diag_mm2(G, T, read, off, m, q, mm)) return false;
         const int G_ = (D.sc_mch - D.sc_mis) * (int)mm - D.qo;          // qlen sc_mch - qo - (the diagonal's score)
         dmin = 0; dmax = 0;

@@ -612,7 +612,7 @@ def run_rank(args) -> int:
         path_bytes = 128 * S + 64 * J + 128 * P + C + R
         aligned_all = sum(x[0] for x in sizes)          # per step, all ranks
         value = aligned_all * steps / elapsed            # the metric counts ALIGNED reads; every read of the set goes through the path (reads_per_s)
-        # the align stage's own bound: VALU issue.  A DP cell PAIR (two problems side by side in the 16-bit halves) costs 31 instructions of one wavefront, counted (profiles/r05h/summary.txt:
+        # the align stage's own bound: VALU issue.  A DP cell PAIR (two problems side by side in the 16-bit halves) costs 31 instructions of one wavefront, counted (profiles/r05k/summary.txt:
         # SQ_INSTS_VALU of the dp_lane kernels over the cell slots they stepped through; 28 of them in the row loop), i.e. 15.5 per cell; a wavefront
         # instruction occupies its SIMD for 4 cycles: peak = SIMDs x clock / 4 x 128 cells / 31.  The instruction count comes from the last committed counter pass (counters
         # cannot be read inside this run) and is labelled as static.
@@ -641,7 +641,7 @@ def run_rank(args) -> int:
                          "bytes_per_launch": layout_bytes, "avg_launch_ms": kern_launch[0], "per_read_bytes": layout_bytes / max(1, n_first),
                          "survey_8d": {"bytes_per_launch": ms_bytes, "formula": "128 S + 64 J (SURVEY.md 8(d): two 64-byte requests per LF step, one per threshold jump)",
                                        "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "per_read_bytes": ms_bytes / max(1, n_first)},
-                         "traffic_static_from": "profiles/r05h/pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of this "
+                         "traffic_static_from": "profiles/r05k/pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of this "
                                                 "workload: 26.64 GB fetched + 2.40 GB written = 29.04 GB per launch of 1 M reads = 1.33 x the layout's 21.9 GB, 0.62 x the survey's 47.18 GB; "
                                                 "counters cannot be read inside this run, so `traffic` stays null)",
                          "note": "the path's HBM-bound kernel (LF / threshold-jump stage of seeding), one launch per resident chunk inside the timed region, HIP events on its own stream "
@@ -664,7 +664,7 @@ def run_rank(args) -> int:
                                    "frac": tot["dp_cells"] / dp_s / 1e12 / dp_peak_tcups if dp_s > 0 else None,
                                    "peak_model": "%d SIMDs x %.1f GHz / 4 cycles per wavefront instruction x 128 cells per instruction (64 lanes x two 16-bit halves) / 31 instructions per cell pair" % (simds, clk / 1e9),
                                    "achieved_note": "reference cells over the summed HIP-event time of the DP kernels (launches of two streams overlap: a lower bound of the in-kernel rate)",
-                                   "valu_static_from": "profiles/r05h/summary.txt (rocprofv3 --pmc SQ_INSTS_VALU of this workload with every problem on dp_lane_kernel: 4.22e9 wavefront instructions for 1.74e10 cell slots = 31.1 per cell pair)"},
+                                   "valu_static_from": "profiles/r05k/summary.txt (rocprofv3 --pmc SQ_INSTS_VALU of this workload with every problem on dp_lane_kernel: 4.22e9 wavefront instructions for 1.74e10 cell slots = 31.1 per cell pair)"},
                       "reads_taken_by_general_kernel": tot["kernel_fallback"], "reads_handed_to_host_pipeline": tot["handed_back"],
                       "handed_over_because": {k: v // steps for k, v in why.items()}},
             "stages_s_per_step": stage,

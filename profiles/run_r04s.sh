@@ -6,7 +6,7 @@
 #   4. --pmc SQ issue counters (own pass)                                                   -> pmc_sq.csv
 # Summaries are printed and written to gpurun_out/prof_<tag>/summary.txt; copy that directory's small files into profiles/<tag>/.
 set -o pipefail
-TAG=${1:-r05h}
+TAG=${1:-r05k}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-KERNELS="ms_lf|mem_kernel|occ_kernel|pack_kernel|classify|bin_tasks|band_tasks|chain_plan|plan_kernel|dp_lane|dp_band|dp_wave|select_kernel|traceback|finish_wave|finish_kernel|global_task|global_band|af_chunk|gather_lines|align_kernel"
+KERNELS="ms_lf|mem_kernel|occ_kernel|pack_kernel|classify|bin_tasks|band_tasks|chain_plan|plan_kernel|dp_lane|dp_band|dp_wave|select_kernel|traceback|finish_wave|finish_kernel|finish_prep|finish_render|global_task|global_band|af_chunk|gather_lines|align_kernel"
 LEAN="--no-cpu --no-from-host --no-scaling-base --no-single-context"
 echo "[1/4] building + caching the index"
 MONI_BENCH_SAVE_INDEX=1 python3 $ROOT/bench.py --steps 1 --warmup 0 $LEAN --inflight 1 > $OUT/bench_build.json 2> $OUT/bench_build.log || exit 1

@@ -92,6 +92,33 @@ def test_wildcard_bases_stay_on_the_staged_kernels(medium_case, env, monkeypatch
         assert len({st["kernel_fallback"] for st in stats[:3]}) == 1
 
 
+def test_extensions_with_more_query_than_target(medium_case, env, monkeypatch):
+    """The reference cuts an extension's target at ext_len = 100 rows whatever the read's part is (aligner_ksw2.hpp:2796-2812): a read whose only seeds lie in its last (or
+    first) 30-45 bases asks for an extension of 105-120 query bases against 100 target rows.  Such a problem gets its band from the diagonal over the target rows followed
+    by one insertion (af_tile_band2) - few substitutions: dp_band_kernel's 16 diagonals; many, or an indel: the tile.  Both strands, so the long extension lies on either
+    side; the SAM text equals the oracle's, with the bands and with every problem forced through the full tiles."""
+    rng = np.random.default_rng(29)
+    exact = list(medium_case.synth.make_reads(medium_case.pg, 3000, 150, seed=181, sub_rate=0.0, indel_rate=0.0))
+    reads = []
+    for r in exact:
+        r = r.copy()
+        keep = int(rng.integers(30, 46))                      # bases left exact at one end
+        lo, hi = (0, 150 - keep) if rng.random() < 0.5 else (keep, 150)
+        rate = (0.01, 0.04, 0.10)[int(rng.integers(0, 3))]
+        for i in range(lo, hi):
+            if rng.random() < rate:
+                r[i] = ord("ACGT"[(("ACGT".index(chr(r[i])) if chr(r[i]) in "ACGT" else 0) + int(rng.integers(1, 4))) % 4])
+        if rng.random() < 0.2 and hi - lo > 40:               # a short deletion inside the mutated part
+            at = int(rng.integers(lo + 10, hi - 10)); d = int(rng.integers(1, 4))
+            r = np.concatenate([r[:at], r[at + d:]])
+        reads.append(r)
+    _, st = both(env, reads)
+    monkeypatch.setenv("MONI_AF_DBG", str(65536 + 131072))
+    _, st_full = both(env, reads)
+    assert st["aligned"] == st_full["aligned"] > 2000 and st["dp_cells"] == st_full["dp_cells"] and st["dp_cells_cut"] < st_full["dp_cells_cut"]
+    assert st["handed_back"] == st_full["handed_back"] == 0
+
+
 def test_sub_batches_and_handed_back_reads(medium_case, env, monkeypatch):
     """The batch goes through the GPU in sub-batches overlapped with the host stage; reads the kernel hands back go
     through the host pipeline and are spliced in at their positions.  Output must not depend on either."""

@@ -173,9 +173,12 @@ def dry_run(args) -> int:
     return 0
 
 
-def chunk_bounds(n: int, chunk_max: int):
-    """even split of n reads into the fewest chunks of at most chunk_max reads: k+1 boundaries"""
+def chunk_bounds(n: int, chunk_max: int, multiple_of: int = 1):
+    """even split of n reads into the fewest chunks of at most chunk_max reads - when more than one is needed, a multiple of `multiple_of` of them (the contexts
+    of a rank take turns at the chunks: an equal share each): k+1 boundaries"""
     k = max(1, -(-n // max(1, chunk_max)))
+    if k > 1 and multiple_of > 1:
+        k = -(-k // multiple_of) * multiple_of
     return [n * i // k for i in range(k + 1)]
 
 
@@ -302,7 +305,7 @@ def run_rank(args) -> int:
     if args.paired:
         return run_paired(args, rank, world, dist, coll_dev, backend, pg, fi, idx, ctx, phases, t_start)
     n_mine = reads.shape[0]
-    cb = chunk_bounds(n_mine, args.reads)
+    cb = chunk_bounds(n_mine, args.reads, max(1, args.inflight))
     n_chunks = len(cb) - 1
     quals = np.full(n_mine * L, ord("I"), dtype=np.uint8)
     # contexts of this rank (--inflight): with ONE resident chunk every context holds the same batch and they share the timed steps; with several chunks
@@ -549,7 +552,7 @@ def run_rank(args) -> int:
         t_gen = time.time() - tb0
         del pg_keep
         sb_ctx = [capi.Ctx(idx) for _ in range(inflight)]          # chunk k on context k % inflight, as the sharded runs hold theirs
-        sb_cb = chunk_bounds(sb_total, args.reads)
+        sb_cb = chunk_bounds(sb_total, args.reads, inflight)
         sb_n = len(sb_cb) - 1
         sb_q = np.full(args.reads * L + L, ord("I"), dtype=np.uint8)
         sb_own = [sum(1 for k in range(sb_n) if k % inflight == i) for i in range(inflight)]

@@ -44,3 +44,15 @@ def test_chunk_bounds():
     assert bench.chunk_bounds(0, 1000000) == [0, 0]
     b = bench.chunk_bounds(5000000, 1000000)
     assert len(b) == 6 and all(b[i + 1] - b[i] == 1000000 for i in range(5))
+
+
+def test_chunk_count_is_a_multiple_of_the_contexts():
+    """a rank's share of a sharded read set is cut into equal chunks of at most --reads reads, a multiple of --inflight of them when more than one is needed"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    for n, cap, k, want in ((1000000, 1000000, 2, 1), (1250000, 1000000, 2, 2), (2500000, 1000000, 2, 4), (2500000, 1000000, 1, 3), (5000000, 1000000, 2, 6), (10000000, 1000000, 3, 12), (0, 1000000, 2, 1)):
+        cb = b.chunk_bounds(n, cap, k)
+        sizes = [cb[i + 1] - cb[i] for i in range(len(cb) - 1)]
+        assert len(sizes) == want and sum(sizes) == n and (not sizes or max(sizes) <= cap) and max(sizes) - min(sizes) <= 1

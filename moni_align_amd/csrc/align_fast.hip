@@ -1678,8 +1678,9 @@ __global__ void __launch_bounds__(64) dp_wave_kernel(const af_args_t G, const ui
 #define AF_BTCAP (AF_QCAP + 2 * AF_BANDW)
 template <int W>
 __global__ void __launch_bounds__(64) dp_band_kernel(const af_args_t G, const uint32_t grp) {
-    __shared__ uint8_t qs[AF_QCAP][64];          // query codes of the lane's two problems: low one in bits 0-1, high one in bits 4-5
-    __shared__ uint8_t ts[AF_BTCAP][64];         // target codes likewise
+    __shared__ uint8_t qs[AF_QCAP / 2][64];      // query codes of the lane's two problems, two positions per byte: position x in nibble x & 1 of byte x >> 1, the low problem's
+    __shared__ uint8_t ts[AF_BTCAP / 2][64];     // code in the nibble's bits 0-1, the high one's in bits 2-3; target codes likewise (17 KB: two blocks per SIMD - a byte per position was 35 KB, one)
+    static_assert(AF_QCAP % 2 == 0 && AF_BTCAP % 2 == 0, "two positions per byte");
     static_assert(W % 4 == 0 && W <= 16, "a lane's target window is one 32-bit word of 2-bit codes");
     const int lane = threadIdx.x;
     const dp_launch_t& D = G.A.D;
@@ -1723,7 +1724,10 @@ __global__ void __launch_bounds__(64) dp_band_kernel(const af_args_t G, const ui
                     if ((mode & DP_Q_COMP) && cq < 4) cq = 3 - cq;
                     const bool in = 8 * g + u < qlen;
                     wild[h] |= in && cq > 3;
-                    if (8 * g + u < maxq) { if (h == 0) qs[8 * g + u][lane] = (uint8_t)(in ? (cq & 3u) : 0u); else qs[8 * g + u][lane] |= (uint8_t)((in ? (cq & 3u) : 0u) << 4); }
+                    if (8 * g + u < maxq) {
+                        const uint32_t c = in ? (cq & 3u) : 0u;
+                        if (h == 0 && (u & 1) == 0) qs[4 * g + (u >> 1)][lane] = (uint8_t)c; else qs[4 * g + (u >> 1)][lane] |= (uint8_t)(c << (2 * h + 4 * (u & 1)));
+                    }
                 }
             }
             af_bytes_t TS = af_bytes(D.text, task[h].t_off, D.text_limit, (mode & DP_T_REV) != 0);
@@ -1734,12 +1738,15 @@ __global__ void __launch_bounds__(64) dp_band_kernel(const af_args_t G, const ui
                     const uint32_t ct = dp_nt4((uint32_t)(v >> (8 * u)) & 0xFFu);
                     const bool in = 8 * g + u < tlen;
                     wild[h] |= in && ct > 3;
-                    if (8 * g + u < maxt) { if (h == 0) ts[8 * g + u][lane] = (uint8_t)(in ? (ct & 3u) : 0u); else ts[8 * g + u][lane] |= (uint8_t)((in ? (ct & 3u) : 0u) << 4); }
+                    if (8 * g + u < maxt) {
+                        const uint32_t c = in ? (ct & 3u) : 0u;
+                        if (h == 0 && (u & 1) == 0) ts[4 * g + (u >> 1)][lane] = (uint8_t)c; else ts[4 * g + (u >> 1)][lane] |= (uint8_t)(c << (2 * h + 4 * (u & 1)));
+                    }
                 }
             }
         }
         // target code of row i of problem h (rows outside the staged ones: any code - they hold no cell that counts)
-        auto tcode = [&](int i, int h) -> uint32_t { const int r = i < 0 ? 0 : i >= maxt ? maxt - 1 : i; return maxt > 0 ? ((uint32_t)ts[r][lane] >> (4 * h)) & 3u : 0u; };
+        auto tcode = [&](int i, int h) -> uint32_t { const int r = i < 0 ? 0 : i >= maxt ? maxt - 1 : i; return maxt > 0 ? ((uint32_t)ts[r >> 1][lane] >> (4 * (r & 1) + 2 * h)) & 3u : 0u; };
         // column -1: slot k holds row -1 + dlo + k
         uint32_t Hb[W], Fb[W];
 #pragma unroll
@@ -1760,8 +1767,8 @@ __global__ void __launch_bounds__(64) dp_band_kernel(const af_args_t G, const ui
         const bool ext0 = (task[0].flag & DP_EZ_EXTZ_ONLY) != 0, ext1 = (task[1].flag & DP_EZ_EXTZ_ONLY) != 0;      // an extension: the last column's maximum and its first row
         int score[2] = {AF_NEG_INF, AF_NEG_INF}, mqe[2] = {AF_NEG_INF, AF_NEG_INF}, mqe_t[2] = {-1, -1};
         for (int j = 0; j < maxq; ++j) {
-            const uint32_t qb = qs[j][lane];
-            const uint32_t a0 = tw[0] ^ ((qb & 3u) * 0x55555555u), a1 = tw[1] ^ (((qb >> 4) & 3u) * 0x55555555u);
+            const uint32_t qb = ((uint32_t)qs[j >> 1][lane] >> (4 * (j & 1))) & 0xFu;
+            const uint32_t a0 = tw[0] ^ ((qb & 3u) * 0x55555555u), a1 = tw[1] ^ (((qb >> 2) & 3u) * 0x55555555u);
             const uint32_t x0 = (a0 | (a0 >> 1)) & 0x55555555u, x1 = (a1 | (a1 >> 1)) & 0x55555555u;
             uint32_t h_up = neg2, e_run = neg2, pack = 0;
             uint32_t* __restrict__ drow = dir + (size_t)j * (W / 4) * 64;
@@ -3407,14 +3414,14 @@ static inline void af_launch_dp(const af_args_t& G, hipStream_t sx, unsigned dp_
     hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE, (uint32_t)AF_GRP_WILD);
     hipLaunchKernelGGL((dp_lane_kernel<AF_BLK, AF_QCAP, AF_LPASS>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_LARGE);
     hipLaunchKernelGGL((dp_lane_kernel<AF_TS, AF_TS, 1>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_SMALL);
-    hipLaunchKernelGGL((dp_band_kernel<AF_BANDW>), dim3(n_cu * 4), dim3(64), 0, sx, G, (uint32_t)AF_GRP_BAND);
+    hipLaunchKernelGGL((dp_band_kernel<AF_BANDW>), dim3(n_cu * 8), dim3(64), 0, sx, G, (uint32_t)AF_GRP_BAND);
     hipLaunchKernelGGL((dp_lane_kernel<AF_BLK, AF_QCAP, AF_LPASS, true>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_WILD);
     hipLaunchKernelGGL((dp_wave_kernel<AF_BLK, AF_LPASS, 4>), dim3(n_cu * 8), dim3(64), 0, sx, G, (uint32_t)AF_GRP_WILD, (uint32_t)AF_GRP_WILD);
     hipLaunchKernelGGL(global_task_kernel, dim3((unsigned)((n_units + 255) / 256)), dim3(256), 0, sx, G);          // (a global problem's window comes from the extensions of its chain: all of them are through)
     const uint64_t gmax = G.task_cap > n_units * AF_MAX_TASKS_READ ? G.task_cap - n_units * AF_MAX_TASKS_READ : 0;          // global problems the slots hold
     if (gmax) hipLaunchKernelGGL(global_band_kernel, dim3((unsigned)((gmax + 255) / 256)), dim3(256), 0, sx, G);
     hipLaunchKernelGGL(af_chunk_kernel, dim3(1), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL, (uint32_t)AF_GRP_GWILD);
-    hipLaunchKernelGGL((dp_band_kernel<AF_BANDW>), dim3(n_cu * 4), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GBAND);
+    hipLaunchKernelGGL((dp_band_kernel<AF_BANDW>), dim3(n_cu * 8), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GBAND);
     hipLaunchKernelGGL((dp_lane_kernel<AF_GBLK, AF_QCAP, AF_GPASS>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL);
     hipLaunchKernelGGL((dp_lane_kernel<AF_GBLK, AF_QCAP, AF_GPASS, true>), dim3(dp_grid), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GWILD);
     hipLaunchKernelGGL((dp_wave_kernel<AF_GBLK, AF_GPASS, 8>), dim3(n_cu * 8), dim3(64), 0, sx, G, (uint32_t)AF_GRP_GLOBAL, (uint32_t)AF_GRP_GWILD);

@@ -251,7 +251,7 @@ typedef struct {
     uint64_t ins_learning_n;                              /* 1000 */
     uint64_t ins_learning_score_gap_threshold;            /* 0 */
     uint32_t secondary_chains, reserved;                  /* 0: -Z, find_chains_secondary instead of find_chains (include/aligner/chain.hpp:442-727, aligner_ksw2.hpp:1190-1191);
-                                                           * every pair then takes pe_align_kernel (the staged kernels chain without the second track) */
+                                                           * the staged paired kernels keep the second track of the chaining in LDS (pe_plan_kernel's SEC instances) */
 } moni_pe_params_t;
 /* The insert-size model (aligner_ksw2.hpp:3252-3262): zero-initialise, feed batches to moni_pe_learn_batch until complete != 0 (or
  * the input ends), then align - the order of st_align's paired loop (align_reads_dispatcher.hpp:356-389). */

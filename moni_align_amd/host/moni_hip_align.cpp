@@ -479,7 +479,7 @@ static size_t read_pairs_par(AnyReader& r1, AnyReader& r2, size_t n_pairs, Batch
 }
 static int run_paired(Args& a, const std::string& sam_filename) {
     a.PE.find_orphan = a.find_orphan ? 1 : 0;            // -u switches orphan recovery off (align_full_ksw2.cpp:248-250)
-    a.PE.secondary_chains = a.secondary ? 1 : 0;         // -Z: find_chains_secondary (every pair then takes pe_align_kernel)
+    a.PE.secondary_chains = a.secondary ? 1 : 0;         // -Z: find_chains_secondary (the second track of the chaining, on the staged paired kernels)
     info("Output file: " + sam_filename);
     AnyReader r1(a.mate1), r2(a.mate2);
     if (a.dry_run) {
